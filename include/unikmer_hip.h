@@ -1,0 +1,171 @@
+/*
+ * unikmer_hip.h — C ABI of libunikmer_hip.so, the MI355X (gfx950) implementation of the
+ * k-mer encode / ntHash / sort / set-operation hot path of shenwei356/unikmer v0.21.0.
+ *
+ * The reference has no FFI; the seam is the Go package API of its third-party modules plus
+ * a few in-tree loops.  Each entry point below names the reference
+ * interface it replaces (paths relative to /root/reference/unikmer/cmd/).  INTEGRATION.md
+ * shows the cgo binding a maintainer would add on the Go side.
+ *
+ * Conventions
+ *  - Every call returns int: 0 = UKM_OK, negative = error class; the message is available
+ *    through ukm_last_error() (thread-local).  Nothing here ever calls exit()/abort()
+ *    (the reference's checkError -> os.Exit(-1), util-cli.go:39-44, stays on the Go side).
+ *  - Array arguments may be HOST or DEVICE pointers, independently per argument
+ *    (hipPointerGetAttributes decides).  Device pointers are used in place; host arrays are
+ *    staged through the context's device workspace.  Scalar outputs (n_out) are host
+ *    pointers.  All buffers are caller-owned; nothing is retained after the call returns
+ *    (cgo pointer-passing rules), except the taxonomy which is copied into the context.
+ *  - Outputs are caller-allocated with capacity `out_cap` (elements); upper bounds:
+ *    union <= sum(n), inter <= n[0], diff <= n[0], common <= sum(n), unique <= n (2n for
+ *    UKM_REPEATED_CHUNK), encode/nthash <= number of windows.  Too small -> UKM_ERR_CAPACITY.
+ *  - A ukm_ctx owns one HIP stream and one growable device workspace; it is NOT thread-safe.
+ *    Use one ctx per calling OS thread (the reference calls these seams from several
+ *    goroutines: sort.go:257, diff.go:280).  There is no global mutable state.
+ *  - Records are (code uint64, taxid uint32) in structure-of-arrays form (kmers.go:24-27 is
+ *    the AoS Go struct).  `taxids == NULL` means "no taxid information".
+ *  - Sorted inputs are required where the reference requires the sorted flag
+ *    (inter.go:139-141, diff.go:115-117); the library verifies sortedness on the fly where
+ *    that is free and returns UKM_ERR_UNSORTED.
+ */
+#ifndef UNIKMER_HIP_H
+#define UNIKMER_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define UKM_OK 0
+#define UKM_ERR_INVALID (-1)      /* bad argument */
+#define UKM_ERR_HIP (-2)          /* HIP runtime failure (message has the hipError string) */
+#define UKM_ERR_NOMEM (-3)        /* device or host allocation failed */
+#define UKM_ERR_ILLEGAL_BASE (-4) /* kmers.ErrIllegalBase: a window contains a non-IUPAC byte */
+#define UKM_ERR_UNSORTED (-5)     /* an input that must be sorted is not */
+#define UKM_ERR_NO_TAXONOMY (-6)  /* taxids present but ukm_taxonomy_load was not called */
+#define UKM_ERR_CAPACITY (-7)     /* out_cap too small; *n_out holds the required size */
+#define UKM_ERR_K (-8)            /* k out of range (1..32 codes, 1..64 hashes; count.go:81-87) */
+
+/* scan / merge modes: sort.go:484-572 (-u / -d / plain), util-sort.go:35-190 (chunk protocol) */
+#define UKM_PLAIN 0
+#define UKM_UNIQUE 1
+#define UKM_REPEATED 2
+#define UKM_REPEATED_CHUNK 3
+
+/* 2-way set operations */
+#define UKM_OP_UNION 0
+#define UKM_OP_INTER 1
+#define UKM_OP_DIFF 2
+
+/* flags */
+#define UKM_F_MIX_TAXID 2u   /* inter --mix-taxid, inter.go:229-236 */
+#define UKM_F_CMP_TAXID 4u   /* diff -t/--compare-taxid, diff.go:361-362,406-407 */
+#define UKM_F_ASSUME_SET 8u  /* caller guarantees strictly increasing inputs (skips nothing;
+                                duplicates are still detected and handled) */
+
+typedef struct ukm_ctx ukm_ctx;
+
+/* ---- library / context -------------------------------------------------------------- */
+const char *ukm_last_error(void);
+int ukm_version(void);                       /* 1000*major + minor */
+int ukm_device_count(int *n);
+int ukm_ctx_create(int device, ukm_ctx **out);
+int ukm_ctx_destroy(ukm_ctx *ctx);
+/* borrow a caller's hipStream_t (e.g. the framework's current stream); NULL = own stream */
+int ukm_ctx_set_stream(ukm_ctx *ctx, void *hip_stream);
+int ukm_ctx_sync(ukm_ctx *ctx);
+/* pre-size the device workspace so that later calls do not allocate */
+int ukm_ctx_reserve(ukm_ctx *ctx, uint64_t bytes);
+/* device-memory helpers for hosts without their own allocator (the cgo shim) */
+int ukm_dev_alloc(ukm_ctx *ctx, uint64_t bytes, void **dptr);
+int ukm_dev_free(ukm_ctx *ctx, void *dptr);
+int ukm_copy(ukm_ctx *ctx, void *dst, const void *src, uint64_t bytes); /* any direction */
+/* duration in ms of the device work of the most recent compute call on this ctx
+ * (hipEvent pair recorded on the ctx stream around the kernels) */
+int ukm_last_kernel_ms(ukm_ctx *ctx, float *ms);
+
+/* ---- taxonomy: replaces taxdump.NewTaxonomyFromNCBI / LoadMergedNodesFromNCBI / LCA
+ *      (util.go:119-171; 14 taxondb.LCA call sites).
+ *      child/parent = the first two columns of nodes.dmp; merged_* = merged.dmp (may be NULL).
+ *      Contract (taxdump parity is unpinned): LCA(0,x)=LCA(x,0)=0; LCA(x,x)=x;
+ *      merged ids are remapped; ids absent from nodes.dmp -> 0. */
+int ukm_taxonomy_load(ukm_ctx *ctx, const uint32_t *child, const uint32_t *parent, uint64_t n,
+                      const uint32_t *merged_old, const uint32_t *merged_new, uint64_t m);
+int ukm_taxonomy_max_taxid(ukm_ctx *ctx, uint32_t *max_taxid); /* taxdump.MaxTaxid, util.go:169 */
+int ukm_lca(ukm_ctx *ctx, const uint32_t *a, const uint32_t *b, uint64_t n, uint32_t *out);
+
+/* ---- encode: replaces sketches.NewKmerIterator(seq,k,canonical,circular).NextKmer()
+ *      (count.go:321,363) = kmers v0.1.0 2-bit encode + canonical.
+ *      bases = concatenated records, rec_off[n_rec+1] = record boundaries.  Records shorter
+ *      than k are skipped (sketches.ErrShortSeq, count.go:323-328).  Output = every window of
+ *      every record in order. */
+int ukm_encode_kmers(ukm_ctx *ctx, const uint8_t *bases, const uint64_t *rec_off,
+                     uint64_t n_rec, int k, int canonical, int circular, uint64_t *out,
+                     uint64_t out_cap, uint64_t *n_out);
+
+/* ---- ntHash: replaces sketches.NewHashIterator(...).NextHash() (count.go:319,361) and
+ *      nthash.NewHasher(&seq,k).Next(canonical) (dump.go:253-260) = ntHash v1; fused with the
+ *      Scaled-MinHash filter `code > maxHash -> skip` (count.go:98,373-375) when max_hash != 0.
+ *      Output keeps window order. */
+int ukm_nthash(ukm_ctx *ctx, const uint8_t *bases, const uint64_t *rec_off, uint64_t n_rec,
+               int k, int canonical, int circular, uint64_t max_hash, uint64_t *out,
+               uint64_t out_cap, uint64_t *n_out);
+/* count.go:98  maxHash = uint64(float64(^uint64(0)) / float64(scale)) */
+uint64_t ukm_max_hash(uint64_t scale);
+
+/* ---- sorts: replace sortutil.Uint64s (count.go:581, union.go:274,295, sort.go:463 ...) and
+ *      sorts.Quicksort(CodeTaxidSlice) (sort.go:268,331,457).  In place, ascending by code;
+ *      pairs are sorted by code only, stably.  key_bits = number of significant low bits
+ *      (2k for k-mer codes, 0 or 64 for hashes): higher radix passes are skipped. */
+int ukm_sort_u64(ukm_ctx *ctx, uint64_t *keys, uint64_t n, int key_bits);
+int ukm_sort_pairs(ukm_ctx *ctx, uint64_t *keys, uint32_t *taxids, uint64_t n, int key_bits);
+
+/* ---- scans over a sorted stream: replace sort.go:484-572 and dumpCodes2File /
+ *      dumpCodesTaxids2File (util-sort.go:35-190).  taxids may be NULL. */
+int ukm_unique(ukm_ctx *ctx, const uint64_t *keys, const uint32_t *taxids, uint64_t n,
+               int mode, uint64_t *out_keys, uint32_t *out_taxids, uint64_t out_cap,
+               uint64_t *n_out);
+
+/* ---- k-way merge: replaces mergeChunksFile (util-sort.go:227-606).  Streams must be
+ *      sorted.  mode/final_round as the reference's unique/repeated/finalRound arguments. */
+int ukm_merge_k(ukm_ctx *ctx, const uint64_t *const *keys, const uint32_t *const *taxids,
+                const uint64_t *lens, int nstreams, int mode, int final_round,
+                uint64_t *out_keys, uint32_t *out_taxids, uint64_t out_cap, uint64_t *n_out);
+
+/* ---- 2-way set operation on two SORTED streams — the device hot path that the n-way
+ *      entries below are folded from, and what bench.py measures. */
+int ukm_setop2(ukm_ctx *ctx, int op, const uint64_t *a_keys, const uint32_t *a_taxids,
+               uint64_t na, const uint64_t *b_keys, const uint32_t *b_taxids, uint64_t nb,
+               uint32_t flags, uint64_t *out_keys, uint32_t *out_taxids, uint64_t out_cap,
+               uint64_t *n_out);
+
+/* ---- n-way set operations; output is the sorted (code, taxid) stream.
+ *      union  : union.go:186-305  (inputs need not be sorted)
+ *      inter  : inter.go:188-286  (all inputs sorted)
+ *      diff   : diff.go:341-454   (first input sorted; sorted_flags[i]==0 marks unsorted ones,
+ *                                  NULL = all sorted)
+ *      common : common.go:220-344 (threshold = number of files, common.go:93-105) */
+int ukm_union(ukm_ctx *ctx, const uint64_t *const *keys, const uint32_t *const *taxids,
+              const uint64_t *lens, int nstreams, uint32_t flags, uint64_t *out_keys,
+              uint32_t *out_taxids, uint64_t out_cap, uint64_t *n_out);
+int ukm_inter(ukm_ctx *ctx, const uint64_t *const *keys, const uint32_t *const *taxids,
+              const uint64_t *lens, int nstreams, uint32_t flags, uint64_t *out_keys,
+              uint32_t *out_taxids, uint64_t out_cap, uint64_t *n_out);
+int ukm_diff(ukm_ctx *ctx, const uint64_t *const *keys, const uint32_t *const *taxids,
+             const uint64_t *lens, int nstreams, const uint8_t *sorted_flags, uint32_t flags,
+             uint64_t *out_keys, uint32_t *out_taxids, uint64_t out_cap, uint64_t *n_out);
+int ukm_common(ukm_ctx *ctx, const uint64_t *const *keys, const uint32_t *const *taxids,
+               const uint64_t *lens, int nstreams, uint32_t threshold, uint32_t flags,
+               uint64_t *out_keys, uint32_t *out_taxids, uint64_t out_cap, uint64_t *n_out);
+uint32_t ukm_common_threshold(uint32_t nfiles, double proportion, uint32_t number);
+
+/* ---- multi-GPU helper: split points of a sorted stream for prefix sharding (SURVEY.md
+ *      §8(e)): cuts[g] = lower_bound(keys, splitters[g]) for g in [0, n_split). */
+int ukm_partition_points(ukm_ctx *ctx, const uint64_t *keys, uint64_t n,
+                         const uint64_t *splitters, int n_split, uint64_t *cuts);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -354,6 +354,9 @@ ukmo_tax *ukmo_tax_create(const uint32_t *child, const uint32_t *parent, uint64_
     t->parent = (uint32_t *)calloc(t->size, sizeof(uint32_t));
     t->merged = (uint32_t *)calloc(t->size, sizeof(uint32_t));
     for (uint64_t i = 0; i < n; i++) t->parent[child[i]] = parent[i];
+    /* a parent id that never appears as a child acts as a root of its own */
+    for (uint64_t i = 0; i < n; i++)
+        if (t->parent[parent[i]] == 0) t->parent[parent[i]] = parent[i];
     for (uint64_t i = 0; i < m; i++) t->merged[merged_old[i]] = merged_new[i];
     return t;
 }

@@ -1,0 +1,56 @@
+"""CPU-side checks of the C-ABI library: it loads, exports every symbol include/unikmer_hip.h
+declares, and fails loudly (no fallback) when there is no GPU.  No compute calls."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from unikmer_amd import build, lib as L
+    build.build()
+    return L
+
+
+def test_header_symbols_exported(lib):
+    hdr = open(os.path.join(ROOT, "include", "unikmer_hip.h")).read()
+    declared = set(re.findall(r"\b(ukm_[a-z0-9_]+)\s*\(", hdr)) - {"ukm_ctx"}
+    assert declared == set(lib.SYMBOLS), declared ^ set(lib.SYMBOLS)
+    L = lib.load()
+    for name in declared:
+        assert hasattr(L, name), name
+
+
+def test_pure_host_entry_points(lib):
+    L = lib.load()
+    assert L.ukm_version() >= 1
+    assert L.ukm_max_hash(1000) == 18446744073709552          # count.go:98
+    assert L.ukm_max_hash(15) == 1229782938247303424
+    assert L.ukm_common_threshold(10, 0.75, 0) == 7            # common.go:93-105 (truncation)
+    assert L.ukm_common_threshold(10, 1.0, 3) == 3
+
+
+def test_no_gpu_fails_loudly(lib):
+    L = lib.load()
+    n = C.c_int(-1)
+    assert L.ukm_device_count(C.byref(n)) == 0
+    if n.value > 0:
+        pytest.skip("a GPU is visible")
+    h = C.c_void_p()
+    rc = L.ukm_ctx_create(0, C.byref(h))
+    assert rc == lib.ERR_HIP and not h.value
+    assert b"no HIP device" in L.ukm_last_error()
+    with pytest.raises(RuntimeError):
+        lib.Context()
+
+
+def test_null_arguments_return_error_codes(lib):
+    L = lib.load()
+    n = C.c_uint64()
+    assert L.ukm_setop2(None, 0, None, None, 0, None, None, 0, 0, None, None, 0, C.byref(n)) == lib.ERR_INVALID
+    assert L.ukm_sort_u64(None, None, 0, 64) == lib.ERR_INVALID
+    assert L.ukm_ctx_destroy(None) == 0

@@ -1,0 +1,406 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle, bit-exact.
+Run on the MI355X box with `pytest -m gpu`."""
+import numpy as np
+import pytest
+
+from conftest import AMUC, IAI39, MG1655, splitmix64, synth_tree
+
+pytestmark = pytest.mark.gpu
+
+SEED = 0x756E696B6D6572  # "unikmer" 
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from unikmer_amd import lib
+    c = lib.Context(0)
+    yield c
+    c.close()
+
+
+@pytest.fixture(scope="module")
+def O():
+    from oracle import oracle
+    return oracle
+
+
+@pytest.fixture(scope="module")
+def L():
+    from unikmer_amd import lib
+    return lib
+
+
+def synth_sets(n_universe, gap_bits, seed=SEED, probs=(1, 1, 2)):
+    """universe = prefix sum of random gaps; membership by hash bits
+    (0 -> A only, 1 -> B only, 2/3 -> both)."""
+    j = np.arange(n_universe, dtype=np.uint64)
+    gaps = np.uint64(1) + (splitmix64(np.uint64(seed) ^ j) & np.uint64((1 << gap_bits) - 1))
+    U = np.cumsum(gaps, dtype=np.uint64)
+    m = splitmix64(np.uint64(seed + 1) ^ j) & np.uint64(3)
+    A = U[(m == 0) | (m >= 2)]
+    B = U[(m == 1) | (m >= 2)]
+    return A, B
+
+
+def taxids_for(codes, T, seed=SEED + 2):
+    return (np.uint64(1) + splitmix64(np.uint64(seed) ^ codes) % np.uint64(T)).astype(np.uint32)
+
+
+@pytest.fixture(scope="module")
+def tree(ctx, O):
+    child, parent = synth_tree(depth=5, arity=8)
+    ctx.taxonomy_load(child, parent)
+    return O.Taxonomy(child, parent), len(child)
+
+
+# ---------------------------------------------------------------------------------- set ops
+@pytest.mark.parametrize("n", [0, 1, 5, 4095, 4096, 4097, 100_000, 1_333_000])
+def test_setop2_matches_oracle(ctx, O, L, n):
+    A, B = synth_sets(n, 22) if n else (np.empty(0, np.uint64), np.empty(0, np.uint64))
+    u = ctx.setop2(L.OP_UNION, A, B)
+    i = ctx.setop2(L.OP_INTER, A, B)
+    d = ctx.setop2(L.OP_DIFF, A, B)
+    assert np.array_equal(u, O.union([A, B]))
+    assert np.array_equal(i, O.inter([A, B]) if len(A) else np.empty(0, np.uint64))
+    assert np.array_equal(d, O.diff([A, B]))
+    # size-independent identities
+    assert len(u) == len(A) + len(B) - len(i)
+    assert len(d) == len(A) - len(i)
+
+
+def test_setop2_edge_cases(ctx, O, L):
+    e = np.empty(0, np.uint64)
+    a = np.array([0, 1, 2, 2**62 - 1, 2**64 - 1], dtype=np.uint64)
+    b = np.array([0, 2, 3, 2**64 - 1], dtype=np.uint64)
+    for x, y in [(a, b), (b, a), (a, a), (a, e), (e, a), (a[:1], a[:1]), (a[:1], b[1:2])]:
+        assert np.array_equal(ctx.setop2(L.OP_UNION, x, y), np.union1d(x, y))
+        assert np.array_equal(ctx.setop2(L.OP_INTER, x, y), np.intersect1d(x, y))
+        assert np.array_equal(ctx.setop2(L.OP_DIFF, x, y), np.setdiff1d(x, y))
+    # disjoint / interleaved / all-equal large
+    x = np.arange(0, 200000, 2, dtype=np.uint64)
+    y = np.arange(1, 200001, 2, dtype=np.uint64)
+    assert np.array_equal(ctx.setop2(L.OP_UNION, x, y), np.arange(200000, dtype=np.uint64))
+    assert len(ctx.setop2(L.OP_INTER, x, y)) == 0
+    assert np.array_equal(ctx.setop2(L.OP_DIFF, x, y), x)
+    assert np.array_equal(ctx.setop2(L.OP_INTER, x, x), x)
+    assert len(ctx.setop2(L.OP_DIFF, x, x)) == 0
+    # all of A below all of B
+    assert np.array_equal(ctx.setop2(L.OP_UNION, x, x + np.uint64(10**6)), np.concatenate([x, x + np.uint64(10**6)]))
+
+
+def test_setop2_unsorted_is_an_error(ctx, L):
+    a = np.array([5, 3, 9], dtype=np.uint64)
+    b = np.array([1, 2, 3], dtype=np.uint64)
+    with pytest.raises(L.UnsortedError):
+        ctx.setop2(L.OP_INTER, a, b)
+
+
+def test_setop2_capacity_error(ctx, L):
+    A, B = synth_sets(10000, 20)
+    out = np.empty(10, dtype=np.uint64)
+    with pytest.raises(L.CapacityError):
+        ctx.setop2(L.OP_UNION, A, B, out=out)
+
+
+def test_setop2_multiset_semantics(ctx, O, L):
+    # duplicates inside an input: the reference's 2-pointer advances both cursors on equality
+    rng = np.random.default_rng(7)
+    a = np.sort(rng.integers(0, 3000, 20000).astype(np.uint64))
+    b = np.sort(rng.integers(0, 3000, 15000).astype(np.uint64))
+    assert np.array_equal(ctx.setop2(L.OP_INTER, a, b), O.inter([a, b]))
+    assert np.array_equal(ctx.setop2(L.OP_DIFF, a, b), O.diff([a, b]))
+    assert np.array_equal(ctx.setop2(L.OP_UNION, a, b), O.union([a, b]))
+    # long runs (exercise the lower_bound branch of rank-in-run)
+    a = np.sort(np.concatenate([np.full(500, 7), np.full(100, 9), np.arange(100)]).astype(np.uint64))
+    b = np.sort(np.concatenate([np.full(200, 7), np.full(300, 9), np.arange(50, 150)]).astype(np.uint64))
+    assert np.array_equal(ctx.setop2(L.OP_INTER, a, b), O.inter([a, b]))
+    assert np.array_equal(ctx.setop2(L.OP_DIFF, a, b), O.diff([a, b]))
+
+
+@pytest.mark.parametrize("n", [10, 5000, 300_000])
+def test_setop2_taxids_lca(ctx, O, L, tree, n):
+    tax, T = tree
+    A, B = synth_sets(n, 22)
+    ta, tb = taxids_for(A, T), taxids_for(B, T, SEED + 5)
+    uk, ut = ctx.setop2(L.OP_UNION, A, B, ta, tb)
+    ok, ot = O.union([A, B], [ta, tb], tax)
+    assert np.array_equal(uk, ok) and np.array_equal(ut, ot)
+    ik, it = ctx.setop2(L.OP_INTER, A, B, ta, tb)
+    ok, ot = O.inter([A, B], [ta, tb], tax)
+    assert np.array_equal(ik, ok) and np.array_equal(it, ot)
+    dk, dt = ctx.setop2(L.OP_DIFF, A, B, ta, tb, flags=L.F_CMP_TAXID)
+    ok, ot = O.diff([A, B], [ta, tb], tax, compare_taxid=True)
+    assert np.array_equal(dk, ok) and np.array_equal(dt, ot)
+    dk, dt = ctx.setop2(L.OP_DIFF, A, B, ta, tb)
+    ok, ot = O.diff([A, B], [ta, tb], tax)
+    assert np.array_equal(dk, ok) and np.array_equal(dt, ot)
+    # mix-taxid: zeros on either side
+    ta0 = ta.copy(); ta0[::3] = 0
+    tb0 = tb.copy(); tb0[::5] = 0
+    ik, it = ctx.setop2(L.OP_INTER, A, B, ta0, tb0, flags=L.F_MIX_TAXID)
+    ok, ot = O.inter([A, B], [ta0, tb0], tax, mix_taxid=True)
+    assert np.array_equal(ik, ok) and np.array_equal(it, ot)
+
+
+def test_lca_matches_oracle(ctx, O, tree):
+    tax, T = tree
+    rng = np.random.default_rng(3)
+    a = rng.integers(0, T + 50, 20000).astype(np.uint32)   # includes 0 and unknown ids
+    b = rng.integers(0, T + 50, 20000).astype(np.uint32)
+    got = ctx.lca(a, b)
+    exp = np.array([tax.lca(x, y) for x, y in zip(a, b)], dtype=np.uint32)
+    assert np.array_equal(got, exp)
+
+
+def test_lca_merged_and_forest(ctx, O):
+    from unikmer_amd import lib
+    c = lib.Context(0)
+    child = np.array([1, 2, 3, 4, 5, 10, 11], dtype=np.uint32)
+    parent = np.array([1, 1, 1, 2, 2, 10, 10], dtype=np.uint32)
+    mo, mn = np.array([7, 8], dtype=np.uint32), np.array([4, 99], dtype=np.uint32)
+    c.taxonomy_load(child, parent, mo, mn)
+    tax = O.Taxonomy(child, parent, mo, mn)
+    ids = np.array([0, 1, 2, 3, 4, 5, 6, 7, 8, 10, 11, 99, 1000], dtype=np.uint32)
+    a, b = np.meshgrid(ids, ids)
+    a, b = a.ravel().copy(), b.ravel().copy()
+    exp = np.array([tax.lca(x, y) for x, y in zip(a, b)], dtype=np.uint32)
+    assert np.array_equal(c.lca(a, b), exp)
+    assert c.max_taxid() == 11
+    c.close()
+
+
+# ---------------------------------------------------------------------------------- n-way
+def _files(nfiles, n_universe, p, seed=11):
+    j = np.arange(n_universe, dtype=np.uint64)
+    gaps = np.uint64(1) + (splitmix64(np.uint64(SEED) ^ j) & np.uint64((1 << 20) - 1))
+    U = np.cumsum(gaps, dtype=np.uint64)
+    out = []
+    for f in range(nfiles):
+        h = splitmix64(np.uint64(seed + 1000 * f) ^ j)
+        out.append(U[(h >> np.uint64(11)).astype(np.float64) / float(1 << 53) < p])
+    return out
+
+
+@pytest.mark.parametrize("nfiles", [1, 2, 3, 7, 16])
+def test_nway_ops_match_oracle(ctx, O, L, tree, nfiles):
+    tax, T = tree
+    files = _files(nfiles, 60000, 0.7)
+    taxs = [taxids_for(f, T, SEED + 13 * i) for i, f in enumerate(files)]
+    assert np.array_equal(ctx.union(files), O.union(files))
+    assert np.array_equal(ctx.inter(files), O.inter(files))
+    assert np.array_equal(ctx.diff(files), O.diff(files))
+    for thr in {1, max(1, nfiles // 2), nfiles}:
+        assert np.array_equal(ctx.common(files, thr), O.common(files, thr))
+    for fn, ofn in [(ctx.union, O.union), (ctx.inter, O.inter), (ctx.diff, O.diff)]:
+        gk, gt = fn(files, taxs)
+        ok, ot = ofn(files, taxs, tax)
+        assert np.array_equal(gk, ok) and np.array_equal(gt, ot)
+    gk, gt = ctx.common(files, max(1, nfiles - 1), taxs)
+    ok, ot = O.common(files, max(1, nfiles - 1), taxs, tax)
+    assert np.array_equal(gk, ok) and np.array_equal(gt, ot)
+    gk, gt = ctx.diff(files, taxs, compare_taxid=True)
+    ok, ot = O.diff(files, taxs, tax, compare_taxid=True)
+    assert np.array_equal(gk, ok) and np.array_equal(gt, ot)
+
+
+def test_nway_edge_cases(ctx, O, L):
+    files = _files(4, 5000, 0.5)
+    e = np.empty(0, np.uint64)
+    # union tolerates unsorted inputs with duplicates (hash-map semantics, union.go:186-208)
+    rng = np.random.default_rng(5)
+    shuffled = [rng.permutation(np.concatenate([f, f[:100]])) for f in files]
+    assert np.array_equal(ctx.union(shuffled), O.union(shuffled))
+    # inter: an empty LATER file stops the fold and keeps the running result (inter.go:211-217)
+    assert np.array_equal(ctx.inter([files[0], files[1], e, files[2]]), O.inter([files[0], files[1], e, files[2]]))
+    assert np.array_equal(ctx.inter([files[0], files[1], e, files[2]]), np.intersect1d(files[0], files[1]))
+    assert len(ctx.inter([e, files[0]])) == 0
+    # diff: unsorted later files, empty files
+    sf = [1, 0, 1, 0]
+    mixed = [files[0], rng.permutation(files[1]), files[2], rng.permutation(files[3])]
+    assert np.array_equal(ctx.diff(mixed, sorted_flags=sf), O.diff(mixed, sorted_flags=sf))
+    assert np.array_equal(ctx.diff([files[0], e, files[1]]), O.diff([files[0], e, files[1]]))
+    with pytest.raises(L.UnsortedError):
+        ctx.diff([rng.permutation(files[0]), files[1]])
+    # common threshold helper
+    assert ctx.common_threshold(4, 0.6) == O.common_threshold(4, 0.6)
+
+
+# ---------------------------------------------------------------------------------- sort / unique / merge
+@pytest.mark.parametrize("n,bits", [(0, 64), (1, 64), (2, 64), (4096, 64), (4097, 62), (100_003, 42), (1_000_000, 62), (300_000, 64)])
+def test_sort_u64(ctx, O, n, bits):
+    rng = np.random.default_rng(n + bits)
+    keys = rng.integers(0, 2**63, n, dtype=np.uint64) * np.uint64(2) + rng.integers(0, 2, n, dtype=np.uint64)
+    if bits < 64:
+        keys &= np.uint64((1 << bits) - 1)
+    exp = np.sort(keys)
+    got = ctx.sort_u64(keys.copy(), bits)
+    assert np.array_equal(got, exp)
+    assert np.array_equal(O.sort_u64(keys), exp)
+
+
+def test_sort_skewed_and_sorted_inputs(ctx):
+    n = 500_000
+    for keys in (np.arange(n, dtype=np.uint64), np.arange(n, dtype=np.uint64)[::-1].copy(),
+                 np.full(n, 12345, dtype=np.uint64), (np.arange(n, dtype=np.uint64) % np.uint64(3)) << np.uint64(40)):
+        assert np.array_equal(ctx.sort_u64(keys.copy()), np.sort(keys))
+
+
+def test_sort_pairs_is_stable(ctx, O):
+    rng = np.random.default_rng(1)
+    n = 400_000
+    keys = rng.integers(0, 5000, n).astype(np.uint64) << np.uint64(20)
+    vals = np.arange(n, dtype=np.uint32)
+    gk, gv = ctx.sort_pairs(keys.copy(), vals.copy(), 62)
+    order = np.argsort(keys, kind="stable")
+    assert np.array_equal(gk, keys[order]) and np.array_equal(gv, vals[order])
+    ok, ov = O.sort_pairs(keys, vals)
+    assert np.array_equal(gk, ok) and np.array_equal(gv, ov)
+
+
+@pytest.mark.parametrize("n", [0, 1, 2, 2047, 2048, 2049, 250_000])
+def test_unique_modes(ctx, O, L, tree, n):
+    tax, T = tree
+    rng = np.random.default_rng(n)
+    keys = np.sort(rng.integers(0, max(1, n // 3) + 1, n).astype(np.uint64))
+    tx = taxids_for(np.arange(n, dtype=np.uint64), T)
+    for mode in (L.PLAIN, L.UNIQUE, L.REPEATED, L.REPEATED_CHUNK):
+        assert np.array_equal(ctx.unique(keys, mode=mode), O.unique(keys, mode=mode))
+        gk, gt = ctx.unique(keys, tx, mode=mode)
+        ok, ot = O.unique(keys, tx, mode=mode, tax=tax)
+        assert np.array_equal(gk, ok) and np.array_equal(gt, ot)
+
+
+def test_unique_unsorted_is_an_error(ctx, L):
+    with pytest.raises(L.UnsortedError):
+        ctx.unique(np.array([3, 1, 2], dtype=np.uint64))
+
+
+@pytest.mark.parametrize("nstreams", [1, 2, 5])
+def test_merge_k(ctx, O, L, tree, nstreams):
+    tax, T = tree
+    rng = np.random.default_rng(nstreams)
+    streams = [np.sort(rng.integers(0, 20000, 30000).astype(np.uint64)) for _ in range(nstreams)]
+    taxs = [taxids_for(s + np.uint64(i), T) for i, s in enumerate(streams)]
+    for mode in (L.PLAIN, L.UNIQUE, L.REPEATED):
+        for final in (True, False):
+            assert np.array_equal(ctx.merge_k(streams, mode=mode, final_round=final),
+                                  O.merge_k(streams, mode=mode, final_round=final))
+            gk, gt = ctx.merge_k(streams, taxs, mode=mode, final_round=final)
+            ok, ot = O.merge_k(streams, taxs, mode=mode, final_round=final, tax=tax)
+            assert np.array_equal(gk, ok) and np.array_equal(gt, ot)
+    # C-9: union -s == sort -u == merge -u of sorted chunks
+    assert np.array_equal(ctx.merge_k(streams, mode=L.UNIQUE), ctx.union(streams))
+
+
+# ---------------------------------------------------------------------------------- encode / hash
+def _synth_fasta(n_bases, seed=SEED):
+    i = np.arange(n_bases, dtype=np.uint64)
+    w = splitmix64(np.uint64(seed) ^ (i >> np.uint64(5)))
+    code = (w >> (np.uint64(2) * (i & np.uint64(31)))) & np.uint64(3)
+    return np.frombuffer(b"ACGT", dtype=np.uint8)[code.astype(np.int64)]
+
+
+@pytest.mark.parametrize("k", [1, 4, 21, 31, 32])
+@pytest.mark.parametrize("canonical", [True, False])
+def test_encode_kmers(ctx, O, k, canonical):
+    bases = _synth_fasta(300_000)
+    # ragged records incl. empty ones and ones shorter than k
+    cuts = np.array([0, 0, 3, 40, 41, 4096, 4096 + 31, 100_000, 100_010, 299_999, 300_000], dtype=np.uint64)
+    got = ctx.encode_kmers(bases, cuts, k, canonical=canonical)
+    exp = O.count_windows(bases, cuts, k, hashed=False, canonical=canonical)
+    assert np.array_equal(got, exp)
+
+
+@pytest.mark.parametrize("k", [1, 23, 51, 64])
+def test_nthash(ctx, O, k):
+    bases = _synth_fasta(200_000, SEED + 9)
+    cuts = np.array([0, 150, 300, 301, 5000, 5000, 77_777, 200_000], dtype=np.uint64)
+    for canonical in (True, False):
+        got = ctx.nthash(bases, cuts, k, canonical=canonical)
+        exp = O.count_windows(bases, cuts, k, hashed=True, canonical=canonical)
+        assert np.array_equal(got, exp)
+    mh = O.max_hash(50)
+    got = ctx.nthash(bases, cuts, k, max_hash=mh)
+    exp = O.count_windows(bases, cuts, k, hashed=True, max_hash=mh)
+    assert np.array_equal(got, exp)
+
+
+def test_circular_and_reads(ctx, O):
+    bases = _synth_fasta(50_000, SEED + 1)
+    one = np.array([0, 50_000], dtype=np.uint64)
+    for k in (5, 31):
+        assert np.array_equal(ctx.encode_kmers(bases, one, k, circular=True),
+                              O.count_windows(bases, one, k, circular=True))
+        assert np.array_equal(ctx.nthash(bases, one, k, circular=True),
+                              O.count_windows(bases, one, k, hashed=True, circular=True))
+    reads = np.arange(0, 50_001, 150, dtype=np.uint64)   # 150 bp reads
+    assert np.array_equal(ctx.encode_kmers(bases, reads, 31), O.count_windows(bases, reads, 31))
+    assert np.array_equal(ctx.nthash(bases, reads, 51), O.count_windows(bases, reads, 51, hashed=True))
+    small = np.arange(0, 1001, 7, dtype=np.uint64)       # many records per tile, some < k
+    assert np.array_equal(ctx.encode_kmers(bases[:1001], small, 5, circular=True),
+                          O.count_windows(bases[:1001], small, 5, circular=True))
+
+
+def test_illegal_and_degenerate_bases(ctx, O, L):
+    seq = np.frombuffer(b"ACGTNNACGTRYKMacgtuACGTACGTACGT", dtype=np.uint8)
+    off = np.array([0, len(seq)], dtype=np.uint64)
+    assert np.array_equal(ctx.encode_kmers(seq, off, 5), O.count_windows(seq, off, 5))
+    assert np.array_equal(ctx.nthash(seq, off, 5), O.count_windows(seq, off, 5, hashed=True))
+    bad = np.frombuffer(b"ACGTACGT*ACGTACGT", dtype=np.uint8)
+    with pytest.raises(L.IllegalBaseError):
+        ctx.encode_kmers(bad, np.array([0, len(bad)], dtype=np.uint64), 4)
+
+
+# ---------------------------------------------------------------------------------- KATs through the GPU
+def test_kat_count_sort_unique_genomes(ctx, L, genomes):
+    """README.md:200-204,270-278 through the HIP path: count -k 23 -K -s, then union/inter/diff."""
+    sets = {}
+    for name, expected in ((MG1655, 4546632), (IAI39, 4902266), (AMUC, 2630905)):
+        bases, off = genomes(name)
+        codes = ctx.encode_kmers(bases, off, 23, canonical=True)
+        ctx.sort_u64(codes, 46)
+        sets[name] = ctx.unique(codes, mode=L.UNIQUE)
+        assert len(sets[name]) == expected
+    assert [int(c) for c in sets[MG1655][:3]] == [87360378, 94155581, 98566170]
+    a, b = sets[IAI39], sets[MG1655]
+    assert len(ctx.union([a, b])) == 6872728
+    assert len(ctx.inter([a, b])) == 2576170
+    assert len(ctx.diff([a, b])) == 2326096
+    assert len(ctx.merge_k([a, b], mode=L.REPEATED)) == 2576170
+    assert len(ctx.common([a, b], 2)) == 2576170
+
+
+def test_kat_scaled_minhash(ctx, L, genomes):
+    """analysis/distance/README.md:9: count -k 31 -K -s -H -D 15 on MG1655 -> 586,734."""
+    bases, off = genomes(MG1655)
+    h = ctx.nthash(bases, off, 31, canonical=True, max_hash=ctx.max_hash(15))
+    ctx.sort_u64(h)
+    assert len(ctx.unique(h)) == 586734
+
+
+# ---------------------------------------------------------------------------------- device-resident tensors
+def test_device_tensors_roundtrip(ctx, O, L):
+    import torch
+    A, B = synth_sets(400_000, 22)
+    dA = torch.from_numpy(A.view(np.int64)).cuda()
+    dB = torch.from_numpy(B.view(np.int64)).cuda()
+    out = torch.empty(len(A) + len(B), dtype=torch.int64, device="cuda")
+    torch.cuda.synchronize()
+    u = ctx.setop2(L.OP_UNION, dA, dB, out=out)
+    assert u.is_cuda and np.array_equal(u.cpu().numpy().view(np.uint64), O.union([A, B]))
+    i = ctx.setop2(L.OP_INTER, dA, dB)
+    assert np.array_equal(i.cpu().numpy().view(np.uint64), O.inter([A, B]))
+    # sort on device, in place
+    rng = np.random.default_rng(0)
+    k = rng.integers(0, 2**62, 1_000_000, dtype=np.uint64)
+    dk = torch.from_numpy(k.view(np.int64)).cuda()
+    torch.cuda.synchronize()
+    ctx.sort_u64(dk, 62)
+    assert np.array_equal(dk.cpu().numpy().view(np.uint64), np.sort(k))
+    assert ctx.last_kernel_ms() > 0
+
+
+def test_partition_points(ctx):
+    A, _ = synth_sets(100_000, 22)
+    sp = np.array([0, A[10], A[10] + np.uint64(1), A[-1], 2**63], dtype=np.uint64)
+    assert np.array_equal(ctx.partition_points(A, sp), np.searchsorted(A, sp, side="left").astype(np.uint64))

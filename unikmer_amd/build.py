@@ -1,0 +1,61 @@
+"""Builds libunikmer_hip.so (gfx950) in-tree with hipcc.  `python -m unikmer_amd.build`."""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+SO = os.path.join(HERE, "libunikmer_hip.so")
+SOURCES = ["ukm_ctx.hip", "ukm_setops.hip", "ukm_scan.hip", "ukm_sort.hip", "ukm_encode.hip",
+           "ukm_tax.hip", "ukm_nway.hip"]
+HEADERS = ["ukm_internal.h", "ukm_device.h", os.path.join("..", "..", "include", "unikmer_hip.h")]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+
+
+def _hipcc():
+    for cand in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if cand and (os.path.isabs(cand) and os.path.exists(cand) or not os.path.isabs(cand)):
+            return cand
+    return "hipcc"
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=False):
+    hdrs = [os.path.join(CSRC, h) for h in HEADERS]
+    objs = []
+    procs = []
+    for src in SOURCES:
+        s = os.path.join(CSRC, src)
+        o = os.path.join(CSRC, src.replace(".hip", ".o"))
+        objs.append(o)
+        if force or _stale(o, [s] + hdrs):
+            cmd = [_hipcc()] + FLAGS + ["-c", s, "-o", o]
+            if verbose:
+                print(" ".join(cmd))
+            procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+    failed = False
+    for src, p in procs:
+        out, _ = p.communicate()
+        if p.returncode != 0:
+            failed = True
+            sys.stderr.write("hipcc failed for %s:\n%s\n" % (src, out.decode(errors="replace")))
+        elif verbose and out:
+            sys.stderr.write(out.decode(errors="replace"))
+    if failed:
+        raise RuntimeError("building libunikmer_hip.so failed")
+    if force or procs or _stale(SO, objs):
+        cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", SO] + objs
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    return SO
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,351 @@
+// ukm_ctx.hip — context, workspace arena, pointer staging and error plumbing of
+// libunikmer_hip.so.  Boundary conventions: include/unikmer_hip.h.
+#include <stdarg.h>
+#include <stdlib.h>
+
+#include <algorithm>
+
+#include "ukm_internal.h"
+
+static thread_local char g_err[512] = "";
+
+void ukm_set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char *ukm_last_error(void) { return g_err; }
+extern "C" int ukm_version(void) { return 1000 * 0 + 1; }
+
+extern "C" int ukm_device_count(int *n) {
+    if (!n) UKM_FAIL(UKM_ERR_INVALID, "ukm_device_count: n is NULL");
+    int c = 0;
+    hipError_t e = hipGetDeviceCount(&c);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        c = 0;
+    }
+    *n = c;
+    return UKM_OK;
+}
+
+extern "C" int ukm_ctx_create(int device, ukm_ctx **out) {
+    if (!out) UKM_FAIL(UKM_ERR_INVALID, "ukm_ctx_create: out is NULL");
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n == 0) {
+        (void)hipGetLastError();
+        UKM_FAIL(UKM_ERR_HIP, "ukm_ctx_create: no HIP device available (%s)",
+                 e == hipSuccess ? "count=0" : hipGetErrorString(e));
+    }
+    if (device < 0 || device >= n)
+        UKM_FAIL(UKM_ERR_INVALID, "ukm_ctx_create: device %d out of range [0,%d)", device, n);
+    UKM_HIP(hipSetDevice(device));
+    ukm_ctx *c = new ukm_ctx();
+    c->device = device;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->num_cu = prop.multiProcessorCount;
+    hipError_t e1 = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    hipError_t e2 = hipEventCreate(&c->ev_start);
+    hipError_t e3 = hipEventCreate(&c->ev_stop);
+    hipError_t e4 = hipHostMalloc((void **)&c->h_scratch, 64 * sizeof(u64), hipHostMallocDefault);
+    if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess || e4 != hipSuccess) {
+        delete c;
+        UKM_FAIL(UKM_ERR_HIP, "ukm_ctx_create: stream/event/pinned allocation failed");
+    }
+    c->own_stream = true;
+    *out = c;
+    return UKM_OK;
+}
+
+static void ws_free_all(ukm_ctx *c) {
+    for (auto &b : c->blocks) (void)hipFree(b.base);
+    c->blocks.clear();
+}
+
+extern "C" int ukm_ctx_destroy(ukm_ctx *c) {
+    if (!c) return UKM_OK;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    ws_free_all(c);
+    if (c->tax_parent) (void)hipFree(c->tax_parent);
+    if (c->tax_depth) (void)hipFree(c->tax_depth);
+    if (c->tax_merged) (void)hipFree(c->tax_merged);
+    if (c->h_scratch) (void)hipHostFree(c->h_scratch);
+    if (c->ev_start) (void)hipEventDestroy(c->ev_start);
+    if (c->ev_stop) (void)hipEventDestroy(c->ev_stop);
+    if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+    return UKM_OK;
+}
+
+extern "C" int ukm_ctx_set_stream(ukm_ctx *c, void *hip_stream) {
+    if (!c) UKM_FAIL(UKM_ERR_INVALID, "ukm_ctx_set_stream: ctx is NULL");
+    UKM_HIP(hipSetDevice(c->device));
+    UKM_HIP(hipStreamSynchronize(c->stream));
+    if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
+    if (hip_stream) {
+        c->stream = (hipStream_t)hip_stream;
+        c->own_stream = false;
+    } else {
+        UKM_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+        c->own_stream = true;
+    }
+    return UKM_OK;
+}
+
+extern "C" int ukm_ctx_sync(ukm_ctx *c) {
+    if (!c) UKM_FAIL(UKM_ERR_INVALID, "ukm_ctx_sync: ctx is NULL");
+    UKM_HIP(hipSetDevice(c->device));
+    UKM_HIP(hipStreamSynchronize(c->stream));
+    return UKM_OK;
+}
+
+// ---- arena ---------------------------------------------------------------------------------
+static const size_t WS_ALIGN = 256;
+static const size_t WS_MIN_BLOCK = (size_t)64 << 20;
+
+static int ws_new_block(ukm_ctx *c, size_t need) {
+    size_t total = 0;
+    for (auto &b : c->blocks) total += b.cap;
+    size_t cap = std::max(need, std::max(WS_MIN_BLOCK, total));  // at least double
+    void *p = nullptr;
+    hipError_t e = hipMalloc(&p, cap);
+    if (e != hipSuccess && cap > need) {
+        (void)hipGetLastError();
+        cap = need;
+        e = hipMalloc(&p, cap);
+    }
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        UKM_FAIL(UKM_ERR_NOMEM, "device workspace allocation of %zu bytes failed: %s", cap,
+                 hipGetErrorString(e));
+    }
+    c->blocks.push_back(WsBlock{(char *)p, cap, 0});
+    return UKM_OK;
+}
+
+int ws_alloc(ukm_ctx *c, size_t bytes, void **out) {
+    bytes = (bytes + WS_ALIGN - 1) / WS_ALIGN * WS_ALIGN;
+    if (bytes == 0) bytes = WS_ALIGN;
+    if (c->blocks.empty() || c->blocks.back().cap - c->blocks.back().used < bytes)
+        UKM_TRY(ws_new_block(c, bytes));
+    WsBlock &b = c->blocks.back();
+    *out = b.base + b.used;
+    b.used += bytes;
+    size_t used = 0;
+    for (auto &x : c->blocks) used += x.used;
+    c->ws_high = std::max(c->ws_high, used);
+    return UKM_OK;
+}
+
+WsMark ws_mark(ukm_ctx *c) {
+    WsMark m;
+    m.nblocks = c->blocks.size();
+    m.used_last = c->blocks.empty() ? 0 : c->blocks.back().used;
+    return m;
+}
+
+void ws_release(ukm_ctx *c, WsMark m) {
+    // blocks created after the mark stay allocated (they are reused) but become empty
+    for (size_t i = m.nblocks; i < c->blocks.size(); i++) c->blocks[i].used = 0;
+    if (m.nblocks > 0) c->blocks[m.nblocks - 1].used = m.used_last;
+    // keep allocation order valid: the "current" block is always blocks.back(); after a
+    // release the tail blocks are empty, so move the largest empty tail block to the position
+    // right after the mark to be used next.
+    if (c->blocks.size() > m.nblocks + 1) {
+        auto it = std::max_element(c->blocks.begin() + m.nblocks, c->blocks.end(),
+                                   [](const WsBlock &a, const WsBlock &b) { return a.cap < b.cap; });
+        std::iter_swap(it, c->blocks.end() - 1);
+    }
+}
+
+static int ws_reset_top(ukm_ctx *c) {
+    // consolidate into one block sized to the high-water mark so the next call does not grow
+    if (c->blocks.size() > 1) {
+        size_t want = c->ws_high + (c->ws_high >> 3) + WS_ALIGN * 64;
+        ws_free_all(c);
+        void *p = nullptr;
+        if (hipMalloc(&p, want) == hipSuccess)
+            c->blocks.push_back(WsBlock{(char *)p, want, 0});
+        else
+            (void)hipGetLastError();
+    }
+    for (auto &b : c->blocks) b.used = 0;
+    c->ws_high = 0;
+    return UKM_OK;
+}
+
+extern "C" int ukm_ctx_reserve(ukm_ctx *c, uint64_t bytes) {
+    if (!c) UKM_FAIL(UKM_ERR_INVALID, "ukm_ctx_reserve: ctx is NULL");
+    UKM_HIP(hipSetDevice(c->device));
+    UKM_HIP(hipStreamSynchronize(c->stream));
+    size_t total = 0;
+    for (auto &b : c->blocks) total = std::max(total, b.cap);
+    if (total >= bytes) return UKM_OK;
+    ws_free_all(c);
+    void *p = nullptr;
+    hipError_t e = hipMalloc(&p, bytes);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        UKM_FAIL(UKM_ERR_NOMEM, "ukm_ctx_reserve: %llu bytes: %s", (unsigned long long)bytes,
+                 hipGetErrorString(e));
+    }
+    c->blocks.push_back(WsBlock{(char *)p, (size_t)bytes, 0});
+    return UKM_OK;
+}
+
+// ---- pointer classification + staging --------------------------------------------------------
+bool ukm_is_device_ptr(const void *p) {
+    if (!p) return false;
+    hipPointerAttribute_t attr;
+    hipError_t e = hipPointerGetAttributes(&attr, p);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();  // unregistered host memory
+        return false;
+    }
+    return attr.type == hipMemoryTypeDevice || attr.type == hipMemoryTypeManaged;
+}
+
+int ukm_in(ukm_ctx *c, const void *p, size_t bytes, const void **dev) {
+    if (ukm_is_device_ptr(p)) {
+        *dev = p;
+        return UKM_OK;
+    }
+    void *d = nullptr;
+    UKM_TRY(ws_alloc(c, bytes, &d));
+    if (bytes) UKM_HIP(hipMemcpyAsync(d, p, bytes, hipMemcpyHostToDevice, c->stream));
+    *dev = d;
+    return UKM_OK;
+}
+
+int ukm_out(ukm_ctx *c, void *p, size_t bytes, void **dev) {
+    if (ukm_is_device_ptr(p)) {
+        *dev = p;
+        return UKM_OK;
+    }
+    void *d = nullptr;
+    UKM_TRY(ws_alloc(c, bytes, &d));
+    c->copybacks.push_back(ukm_ctx::CopyBack{p, d, bytes});
+    *dev = d;
+    return UKM_OK;
+}
+
+void ukm_out_resize(ukm_ctx *c, void *host, size_t bytes) {
+    for (auto &cb : c->copybacks)
+        if (cb.host == host) cb.bytes = std::min(cb.bytes, bytes);
+}
+
+int ukm_inout(ukm_ctx *c, void *p, size_t bytes, void **dev) {
+    if (ukm_is_device_ptr(p)) {
+        *dev = p;
+        return UKM_OK;
+    }
+    void *d = nullptr;
+    UKM_TRY(ws_alloc(c, bytes, &d));
+    if (bytes) UKM_HIP(hipMemcpyAsync(d, p, bytes, hipMemcpyHostToDevice, c->stream));
+    c->copybacks.push_back(ukm_ctx::CopyBack{p, d, bytes});
+    *dev = d;
+    return UKM_OK;
+}
+
+int ukm_begin(ukm_ctx *c, CallScope *s) {
+    if (!c) UKM_FAIL(UKM_ERR_INVALID, "ctx is NULL");
+    s->c = c;
+    s->top = (c->depth == 0);
+    c->depth++;
+    if (s->top) {
+        hipError_t e = hipSetDevice(c->device);
+        if (e != hipSuccess) {
+            c->depth--;
+            UKM_FAIL(UKM_ERR_HIP, "hipSetDevice(%d): %s", c->device, hipGetErrorString(e));
+        }
+        c->copybacks.clear();
+        (void)hipEventRecord(c->ev_start, c->stream);
+        c->ev_valid = false;
+    }
+    s->mark = ws_mark(c);
+    return UKM_OK;
+}
+
+int ukm_finish(CallScope *s, int rc) {
+    ukm_ctx *c = s->c;
+    c->depth--;
+    if (!s->top) {
+        ws_release(c, s->mark);
+        return rc;
+    }
+    (void)hipEventRecord(c->ev_stop, c->stream);
+    c->ev_valid = true;
+    if (rc == UKM_OK) {
+        for (auto &cb : c->copybacks) {
+            if (cb.bytes == 0) continue;
+            hipError_t e = hipMemcpyAsync(cb.host, cb.dev, cb.bytes, hipMemcpyDeviceToHost, c->stream);
+            if (e != hipSuccess) {
+                ukm_set_error("copy-back failed: %s", hipGetErrorString(e));
+                rc = UKM_ERR_HIP;
+                break;
+            }
+        }
+    }
+    hipError_t e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess && rc == UKM_OK) {
+        ukm_set_error("stream synchronize failed: %s", hipGetErrorString(e));
+        rc = UKM_ERR_HIP;
+    }
+    c->copybacks.clear();
+    ws_reset_top(c);
+    return rc;
+}
+
+int ukm_read_u64(ukm_ctx *c, const u64 *dev, u64 *host, int n) {
+    if (n > 64) UKM_FAIL(UKM_ERR_INVALID, "ukm_read_u64: n too large");
+    UKM_HIP(hipMemcpyAsync(c->h_scratch, dev, n * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
+    UKM_HIP(hipStreamSynchronize(c->stream));
+    for (int i = 0; i < n; i++) host[i] = c->h_scratch[i];
+    return UKM_OK;
+}
+
+extern "C" int ukm_last_kernel_ms(ukm_ctx *c, float *ms) {
+    if (!c || !ms) UKM_FAIL(UKM_ERR_INVALID, "ukm_last_kernel_ms: NULL argument");
+    if (!c->ev_valid) UKM_FAIL(UKM_ERR_INVALID, "ukm_last_kernel_ms: no completed call");
+    UKM_HIP(hipEventSynchronize(c->ev_stop));
+    UKM_HIP(hipEventElapsedTime(ms, c->ev_start, c->ev_stop));
+    return UKM_OK;
+}
+
+// ---- device memory helpers --------------------------------------------------------------------
+extern "C" int ukm_dev_alloc(ukm_ctx *c, uint64_t bytes, void **dptr) {
+    if (!c || !dptr) UKM_FAIL(UKM_ERR_INVALID, "ukm_dev_alloc: NULL argument");
+    UKM_HIP(hipSetDevice(c->device));
+    void *p = nullptr;
+    hipError_t e = hipMalloc(&p, bytes ? bytes : 1);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        UKM_FAIL(UKM_ERR_NOMEM, "ukm_dev_alloc(%llu): %s", (unsigned long long)bytes,
+                 hipGetErrorString(e));
+    }
+    *dptr = p;
+    return UKM_OK;
+}
+
+extern "C" int ukm_dev_free(ukm_ctx *c, void *dptr) {
+    if (!c) UKM_FAIL(UKM_ERR_INVALID, "ukm_dev_free: ctx is NULL");
+    if (!dptr) return UKM_OK;
+    UKM_HIP(hipSetDevice(c->device));
+    UKM_HIP(hipStreamSynchronize(c->stream));
+    UKM_HIP(hipFree(dptr));
+    return UKM_OK;
+}
+
+extern "C" int ukm_copy(ukm_ctx *c, void *dst, const void *src, uint64_t bytes) {
+    if (!c || (!dst && bytes) || (!src && bytes)) UKM_FAIL(UKM_ERR_INVALID, "ukm_copy: NULL argument");
+    if (bytes == 0) return UKM_OK;
+    UKM_HIP(hipSetDevice(c->device));
+    UKM_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDefault, c->stream));
+    UKM_HIP(hipStreamSynchronize(c->stream));
+    return UKM_OK;
+}

@@ -1,0 +1,174 @@
+// ukm_internal.h — shared host-side plumbing of libunikmer_hip.so (context, workspace arena,
+// host/device pointer staging, error reporting).  gfx950 only; no portability layer.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/unikmer_hip.h"
+
+typedef uint64_t u64;
+typedef uint32_t u32;
+typedef uint8_t u8;
+
+// ---- error reporting (thread-local message, never exit) -------------------------------------
+void ukm_set_error(const char *fmt, ...);
+
+#define UKM_FAIL(code, ...)        \
+    do {                           \
+        ukm_set_error(__VA_ARGS__); \
+        return (code);             \
+    } while (0)
+
+#define UKM_HIP(expr)                                                                    \
+    do {                                                                                 \
+        hipError_t _e = (expr);                                                          \
+        if (_e != hipSuccess) {                                                          \
+            ukm_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, \
+                          __LINE__);                                                     \
+            return _e == hipErrorOutOfMemory ? UKM_ERR_NOMEM : UKM_ERR_HIP;              \
+        }                                                                                \
+    } while (0)
+
+#define UKM_TRY(expr)            \
+    do {                         \
+        int _rc = (expr);        \
+        if (_rc != UKM_OK) return _rc; \
+    } while (0)
+
+// ---- device taxonomy ------------------------------------------------------------------------
+struct TaxDev {
+    const u32 *parent;  // dense [size]; 0 = absent; root: parent[r] == r
+    const u8 *depth;    // dense [size]; root depth 0
+    const u32 *merged;  // dense [size] or nullptr; 0 = not merged
+    u32 size;
+};
+
+// ---- workspace arena: chunked bump allocator on the ctx's device ------------------------------
+struct WsBlock {
+    char *base;
+    size_t cap;
+    size_t used;
+};
+
+struct ukm_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+    bool ev_valid = false;
+    int depth = 0;  // nesting depth of API calls (n-way ops call 2-way ops)
+
+    std::vector<WsBlock> blocks;
+    size_t ws_high = 0;  // high-water mark of one top-level call, for consolidation
+
+    // pending host copy-backs of the current top-level call
+    struct CopyBack {
+        void *host;
+        const void *dev;
+        size_t bytes;
+    };
+    std::vector<CopyBack> copybacks;
+
+    // taxonomy (device arrays owned by the ctx)
+    u32 *tax_parent = nullptr;
+    u8 *tax_depth = nullptr;
+    u32 *tax_merged = nullptr;
+    u32 tax_size = 0;
+    u32 tax_max = 0;
+
+    // pinned host scratch for small D2H results
+    u64 *h_scratch = nullptr;  // 64 x u64
+
+    int num_cu = 256;
+};
+
+// Arena API.  Pointers stay valid until the enclosing top-level call returns.
+int ws_alloc(ukm_ctx *c, size_t bytes, void **out);
+template <typename T>
+static inline int ws_alloc_t(ukm_ctx *c, size_t n, T **out) {
+    void *p = nullptr;
+    int rc = ws_alloc(c, n * sizeof(T), &p);
+    *out = (T *)p;
+    return rc;
+}
+struct WsMark {
+    size_t nblocks;
+    size_t used_last;
+};
+WsMark ws_mark(ukm_ctx *c);
+void ws_release(ukm_ctx *c, WsMark m);  // frees allocations made after the mark (LIFO)
+
+// true if p is a device pointer usable by kernels on this ctx's device
+bool ukm_is_device_ptr(const void *p);
+
+// Input staging: returns p itself for device pointers, else an arena copy (H2D on the stream).
+int ukm_in(ukm_ctx *c, const void *p, size_t bytes, const void **dev);
+template <typename T>
+static inline int ukm_in_t(ukm_ctx *c, const T *p, size_t n, const T **dev) {
+    const void *d = nullptr;
+    if (p == nullptr || n == 0) {
+        *dev = p;
+        if (p == nullptr) return UKM_OK;
+    }
+    int rc = ukm_in(c, p, n * sizeof(T), &d);
+    *dev = (const T *)d;
+    return rc;
+}
+// Output staging: device pointers pass through; host pointers get an arena buffer whose
+// first `bytes` are copied back by ukm_finish() (use ukm_out_resize to shrink the copy).
+int ukm_out(ukm_ctx *c, void *p, size_t bytes, void **dev);
+template <typename T>
+static inline int ukm_out_t(ukm_ctx *c, T *p, size_t n, T **dev) {
+    void *d = nullptr;
+    if (p == nullptr) {
+        *dev = nullptr;
+        return UKM_OK;
+    }
+    int rc = ukm_out(c, p, n * sizeof(T), &d);
+    *dev = (T *)d;
+    return rc;
+}
+void ukm_out_resize(ukm_ctx *c, void *host, size_t bytes);
+// In-place staging (sort): host array copied in, and copied back at finish.
+int ukm_inout(ukm_ctx *c, void *p, size_t bytes, void **dev);
+
+// Call bracket.  ukm_begin at the top of every compute entry; ukm_finish before returning:
+// performs copy-backs, stream sync, arena reset (top level only).  Nested calls are cheap.
+struct CallScope {
+    ukm_ctx *c;
+    bool top;
+    WsMark mark;
+};
+int ukm_begin(ukm_ctx *c, CallScope *s);
+int ukm_finish(CallScope *s, int rc);
+
+// read one u64 (or several) from device memory to host, synchronising the stream
+int ukm_read_u64(ukm_ctx *c, const u64 *dev, u64 *host, int n = 1);
+
+static inline TaxDev ukm_taxdev(const ukm_ctx *c) {
+    TaxDev t;
+    t.parent = c->tax_parent;
+    t.depth = c->tax_depth;
+    t.merged = c->tax_merged;
+    t.size = c->tax_size;
+    return t;
+}
+
+// ---- internal device-pointer entry points (all pointers are device pointers) ------------------
+int ukm_dev_setop2(ukm_ctx *c, int op, const u64 *a, const u32 *ta, u64 na, const u64 *b,
+                   const u32 *tb, u64 nb, u32 flags, u64 *out, u32 *tout, u64 out_cap,
+                   u64 *n_out);
+int ukm_dev_sort(ukm_ctx *c, u64 *keys, u32 *vals, u64 n, int key_bits);
+int ukm_dev_unique(ukm_ctx *c, const u64 *keys, const u32 *taxids, u64 n, int mode, u64 *out,
+                   u32 *tout, u64 out_cap, u64 *n_out);
+// mode 4 = UNIQUE_LAST (last record of each run), 5 = COMMON (run length >= threshold)
+int ukm_dev_unique_ex(ukm_ctx *c, const u64 *keys, const u32 *taxids, u64 n, int mode, u32 threshold,
+                      u64 *out, u32 *tout, u64 out_cap, u64 *n_out);
+int ukm_dev_check_sorted(ukm_ctx *c, const u64 *keys, u64 n, bool *sorted, bool *strict);
+int ukm_dev_exclusive_scan_u64(ukm_ctx *c, const u64 *in, u64 *out, u64 n, u64 *total_dev);

@@ -1,0 +1,380 @@
+// ukm_nway.hip — n-way set operations and the k-way merge, folded from the 2-way device path
+// (ukm_setops.hip), the radix sort (ukm_sort.hip) and the sorted-stream scans (ukm_scan.hip).
+// Replaces the per-file loops of
+//   union  : union.go:126-305   -> pairwise merge TREE of unions (LCA is associative and
+//                                  commutative on a tree, so the tree equals the reference's
+//                                  arrival-order left fold on the sorted output stream)
+//   inter  : inter.go:175-286   -> the same running intersection, one 2-way kernel per file,
+//                                  with the reference's early exits
+//   diff   : diff.go:280-523    -> sequential subtraction (= one worker, `-j 1`)
+//   common : common.go:205-344  -> concatenate, stable radix sort, run-length threshold scan
+//   merge  : util-sort.go:227-606 (mergeChunksFile) -> concatenate sorted chunks, stable radix
+//                                  sort, unique/repeated scan (a heap has no place on a GPU)
+// All of it is host-side orchestration; every byte of data stays on the device.
+#include <algorithm>
+#include <vector>
+
+#include "ukm_device.h"
+
+namespace {
+
+struct Stream {
+    const u64 *k;
+    const u32 *t;
+    u64 n;
+};
+
+// stage the caller's streams (host or device pointers) as device streams
+int stage_streams(ukm_ctx *c, const uint64_t *const *keys, const uint32_t *const *taxids,
+                  const uint64_t *lens, int nstreams, bool want_tax, std::vector<Stream> &out) {
+    out.resize((size_t)nstreams);
+    for (int i = 0; i < nstreams; i++) {
+        Stream s;
+        s.n = lens[i];
+        s.k = nullptr;
+        s.t = nullptr;
+        if (s.n && !keys[i]) UKM_FAIL(UKM_ERR_INVALID, "stream %d: keys is NULL", i);
+        UKM_TRY(ukm_in_t(c, keys[i], s.n, &s.k));
+        if (want_tax && taxids && taxids[i]) UKM_TRY(ukm_in_t(c, taxids[i], s.n, &s.t));
+        out[(size_t)i] = s;
+    }
+    return UKM_OK;
+}
+
+bool any_taxids(const uint32_t *const *taxids, int nstreams) {
+    if (!taxids) return false;
+    for (int i = 0; i < nstreams; i++)
+        if (taxids[i]) return true;
+    return false;
+}
+
+int check_common_args(ukm_ctx *ctx, const uint64_t *const *keys, const uint64_t *lens, int nstreams,
+                      uint64_t *out_keys, uint64_t out_cap, uint64_t *n_out, const char *name) {
+    if (!ctx || !n_out || nstreams < 0 || (nstreams && (!keys || !lens)) || (!out_keys && out_cap))
+        UKM_FAIL(UKM_ERR_INVALID, "%s: bad argument", name);
+    return UKM_OK;
+}
+
+// make a sorted, duplicate-free (LCA-folded) copy of a stream if it is not already one
+int normalise_set(ukm_ctx *c, Stream &s, bool tax) {
+    bool sorted = true, strict = true;
+    UKM_TRY(ukm_dev_check_sorted(c, s.k, s.n, &sorted, &strict));
+    if (strict) return UKM_OK;
+    u64 *k = nullptr;
+    u32 *t = nullptr;
+    UKM_TRY(ws_alloc_t(c, s.n, &k));
+    if (tax) UKM_TRY(ws_alloc_t(c, s.n, &t));
+    if (!sorted) {
+        UKM_HIP(hipMemcpyAsync(k, s.k, s.n * sizeof(u64), hipMemcpyDeviceToDevice, c->stream));
+        if (tax) {
+            if (s.t) UKM_HIP(hipMemcpyAsync(t, s.t, s.n * sizeof(u32), hipMemcpyDeviceToDevice, c->stream));
+            else UKM_HIP(hipMemsetAsync(t, 0, s.n * sizeof(u32), c->stream));
+        }
+        UKM_TRY(ukm_dev_sort(c, k, tax ? t : nullptr, s.n, 64));
+        u64 *k2 = nullptr;
+        u32 *t2 = nullptr;
+        UKM_TRY(ws_alloc_t(c, s.n, &k2));
+        if (tax) UKM_TRY(ws_alloc_t(c, s.n, &t2));
+        u64 nu = 0;
+        UKM_TRY(ukm_dev_unique(c, k, tax ? t : nullptr, s.n, UKM_UNIQUE, k2, t2, s.n, &nu));
+        s.k = k2; s.t = tax ? t2 : nullptr; s.n = nu;
+    } else {
+        u64 nu = 0;
+        UKM_TRY(ukm_dev_unique(c, s.k, tax ? s.t : nullptr, s.n, UKM_UNIQUE, k, t, s.n, &nu));
+        s.k = k; s.t = tax ? t : nullptr; s.n = nu;
+    }
+    return UKM_OK;
+}
+
+int copy_result(ukm_ctx *c, const Stream &s, bool tax, u64 *out, u32 *tout, u64 out_cap, u64 *n_out) {
+    *n_out = s.n;
+    if (s.n > out_cap)
+        UKM_FAIL(UKM_ERR_CAPACITY, "output needs %llu records, capacity is %llu", (unsigned long long)s.n,
+                 (unsigned long long)out_cap);
+    if (s.n && out != s.k) UKM_HIP(hipMemcpyAsync(out, s.k, s.n * sizeof(u64), hipMemcpyDeviceToDevice, c->stream));
+    if (tax && tout && s.n) {
+        if (s.t) {
+            if (tout != s.t) UKM_HIP(hipMemcpyAsync(tout, s.t, s.n * sizeof(u32), hipMemcpyDeviceToDevice, c->stream));
+        } else {
+            UKM_HIP(hipMemsetAsync(tout, 0, s.n * sizeof(u32), c->stream));
+        }
+    }
+    return UKM_OK;
+}
+
+// concatenate streams into one device buffer (missing taxids -> 0)
+int concat_streams(ukm_ctx *c, const std::vector<Stream> &ss, bool tax, u64 **k, u32 **t, u64 *total) {
+    u64 n = 0;
+    for (auto &s : ss) n += s.n;
+    *total = n;
+    UKM_TRY(ws_alloc_t(c, n + 1, k));
+    if (tax) UKM_TRY(ws_alloc_t(c, n + 1, t));
+    u64 off = 0;
+    for (auto &s : ss) {
+        if (!s.n) continue;
+        UKM_HIP(hipMemcpyAsync(*k + off, s.k, s.n * sizeof(u64), hipMemcpyDeviceToDevice, c->stream));
+        if (tax) {
+            if (s.t) UKM_HIP(hipMemcpyAsync(*t + off, s.t, s.n * sizeof(u32), hipMemcpyDeviceToDevice, c->stream));
+            else UKM_HIP(hipMemsetAsync(*t + off, 0, s.n * sizeof(u32), c->stream));
+        }
+        off += s.n;
+    }
+    return UKM_OK;
+}
+
+struct OutBufs {
+    u64 *k = nullptr;
+    u32 *t = nullptr;
+};
+
+template <typename F>
+int run_entry(ukm_ctx *ctx, uint64_t *out_keys, uint32_t *out_taxids, uint64_t out_cap, uint64_t *n_out,
+              bool tax, F body) {
+    CallScope s;
+    UKM_TRY(ukm_begin(ctx, &s));
+    int rc = [&]() -> int {
+        OutBufs o;
+        UKM_TRY(ukm_out_t(ctx, out_keys, out_cap, &o.k));
+        if (tax && !out_taxids) UKM_FAIL(UKM_ERR_INVALID, "records carry taxids but out_taxids is NULL");
+        if (tax) UKM_TRY(ukm_out_t(ctx, out_taxids, out_cap, &o.t));
+        *n_out = 0;
+        int r = body(o);
+        u64 n = (r == UKM_OK) ? *n_out : 0;
+        ukm_out_resize(ctx, out_keys, n * sizeof(u64));
+        if (out_taxids) ukm_out_resize(ctx, out_taxids, n * sizeof(u32));
+        return r;
+    }();
+    return ukm_finish(&s, rc);
+}
+
+}  // namespace
+
+extern "C" int ukm_union(ukm_ctx *ctx, const uint64_t *const *keys, const uint32_t *const *taxids,
+                         const uint64_t *lens, int nstreams, uint32_t flags, uint64_t *out_keys,
+                         uint32_t *out_taxids, uint64_t out_cap, uint64_t *n_out) {
+    UKM_TRY(check_common_args(ctx, keys, lens, nstreams, out_keys, out_cap, n_out, "ukm_union"));
+    const bool tax = any_taxids(taxids, nstreams);
+    return run_entry(ctx, out_keys, out_taxids, out_cap, n_out, tax, [&](OutBufs &o) -> int {
+        std::vector<Stream> cur;
+        UKM_TRY(stage_streams(ctx, keys, taxids, lens, nstreams, tax, cur));
+        // drop empty streams; make each one a sorted set
+        std::vector<Stream> ss;
+        for (auto &s : cur)
+            if (s.n) {
+                UKM_TRY(normalise_set(ctx, s, tax));
+                ss.push_back(s);
+            }
+        if (ss.empty()) return UKM_OK;
+        if (ss.size() == 1) return copy_result(ctx, ss[0], tax, o.k, o.t, out_cap, n_out);
+        u64 total = 0;
+        for (auto &s : ss) total += s.n;
+        // ping-pong level buffers, each able to hold the worst case of a whole level
+        u64 *bk[2] = {nullptr, nullptr};
+        u32 *bt[2] = {nullptr, nullptr};
+        if (ss.size() > 2) {
+            for (int i = 0; i < 2; i++) {
+                UKM_TRY(ws_alloc_t(ctx, total + 1, &bk[i]));
+                if (tax) UKM_TRY(ws_alloc_t(ctx, total + 1, &bt[i]));
+            }
+        }
+        int level = 0;
+        while (ss.size() > 1) {
+            std::vector<Stream> next;
+            const bool last = ss.size() == 2;
+            u64 off = 0;
+            for (size_t i = 0; i + 1 < ss.size(); i += 2) {
+                const Stream &a = ss[i], &b = ss[i + 1];
+                u64 *ok = last ? o.k : bk[level & 1] + off;
+                u32 *ot = tax ? (last ? o.t : bt[level & 1] + off) : nullptr;
+                const u64 cap = last ? out_cap : a.n + b.n;
+                u64 n = 0;
+                int r = ukm_dev_setop2(ctx, UKM_OP_UNION, a.k, a.t, a.n, b.k, b.t, b.n, flags, ok, ot, cap, &n);
+                if (last) *n_out = n;
+                UKM_TRY(r);
+                next.push_back(Stream{ok, ot, n});
+                off += a.n + b.n;
+            }
+            if (ss.size() & 1) {
+                // carry the odd stream INTO this level's buffer, so that the next level (which
+                // writes the other buffer) never overwrites something it still has to read
+                const Stream &z = ss.back();
+                u64 *zk = bk[level & 1] + off;
+                u32 *zt = tax ? bt[level & 1] + off : nullptr;
+                UKM_HIP(hipMemcpyAsync(zk, z.k, z.n * sizeof(u64), hipMemcpyDeviceToDevice, ctx->stream));
+                if (tax) {
+                    if (z.t) UKM_HIP(hipMemcpyAsync(zt, z.t, z.n * sizeof(u32), hipMemcpyDeviceToDevice, ctx->stream));
+                    else UKM_HIP(hipMemsetAsync(zt, 0, z.n * sizeof(u32), ctx->stream));
+                }
+                next.push_back(Stream{zk, zt, z.n});
+            }
+            ss.swap(next);
+            level++;
+        }
+        return UKM_OK;
+    });
+}
+
+extern "C" int ukm_inter(ukm_ctx *ctx, const uint64_t *const *keys, const uint32_t *const *taxids,
+                         const uint64_t *lens, int nstreams, uint32_t flags, uint64_t *out_keys,
+                         uint32_t *out_taxids, uint64_t out_cap, uint64_t *n_out) {
+    UKM_TRY(check_common_args(ctx, keys, lens, nstreams, out_keys, out_cap, n_out, "ukm_inter"));
+    const bool tax = any_taxids(taxids, nstreams);
+    return run_entry(ctx, out_keys, out_taxids, out_cap, n_out, tax, [&](OutBufs &o) -> int {
+        if (nstreams == 0) return UKM_OK;
+        std::vector<Stream> ss;
+        UKM_TRY(stage_streams(ctx, keys, taxids, lens, nstreams, tax, ss));
+        Stream acc = ss[0];  // inter.go:189-200: the running result starts as file 1
+        u64 *bk[2] = {nullptr, nullptr};
+        u32 *bt[2] = {nullptr, nullptr};
+        if (nstreams > 1 && acc.n) {
+            for (int i = 0; i < 2; i++) {
+                UKM_TRY(ws_alloc_t(ctx, acc.n + 1, &bk[i]));
+                if (tax) UKM_TRY(ws_alloc_t(ctx, acc.n + 1, &bt[i]));
+            }
+        }
+        int flip = 0;
+        for (int i = 1; i < nstreams && acc.n > 0; i++) {
+            const Stream &q = ss[(size_t)i];
+            if (q.n == 0) break;  // inter.go:211-217 (flagBreak: the running result is kept)
+            u64 n = 0;
+            UKM_TRY(ukm_dev_setop2(ctx, UKM_OP_INTER, acc.k, acc.t, acc.n, q.k, q.t, q.n, flags, bk[flip],
+                                   tax ? bt[flip] : nullptr, acc.n, &n));
+            acc = Stream{bk[flip], tax ? bt[flip] : nullptr, n};
+            flip ^= 1;
+        }
+        return copy_result(ctx, acc, tax, o.k, o.t, out_cap, n_out);
+    });
+}
+
+extern "C" int ukm_diff(ukm_ctx *ctx, const uint64_t *const *keys, const uint32_t *const *taxids,
+                        const uint64_t *lens, int nstreams, const uint8_t *sorted_flags, uint32_t flags,
+                        uint64_t *out_keys, uint32_t *out_taxids, uint64_t out_cap, uint64_t *n_out) {
+    UKM_TRY(check_common_args(ctx, keys, lens, nstreams, out_keys, out_cap, n_out, "ukm_diff"));
+    const bool tax = any_taxids(taxids, nstreams);
+    if ((flags & UKM_F_CMP_TAXID) && !tax) UKM_FAIL(UKM_ERR_INVALID, "ukm_diff: -t needs taxids");
+    return run_entry(ctx, out_keys, out_taxids, out_cap, n_out, tax, [&](OutBufs &o) -> int {
+        if (nstreams == 0) return UKM_OK;
+        std::vector<Stream> ss;
+        UKM_TRY(stage_streams(ctx, keys, taxids, lens, nstreams, tax, ss));
+        Stream acc = ss[0];
+        bool a_sorted = true, a_strict = true;
+        UKM_TRY(ukm_dev_check_sorted(ctx, acc.k, acc.n, &a_sorted, &a_strict));
+        if (!a_sorted) UKM_FAIL(UKM_ERR_UNSORTED, "ukm_diff: the first stream must be sorted (diff.go:115-117)");
+        u64 *bk[3] = {nullptr, nullptr, nullptr};
+        u32 *bt[3] = {nullptr, nullptr, nullptr};
+        if (acc.n) {
+            for (int i = 0; i < 3; i++) {
+                UKM_TRY(ws_alloc_t(ctx, acc.n + 1, &bk[i]));
+                if (tax) UKM_TRY(ws_alloc_t(ctx, acc.n + 1, &bt[i]));
+            }
+        }
+        int flip = 0;
+        for (int i = 1; i < nstreams && acc.n > 0; i++) {
+            Stream q = ss[(size_t)i];
+            if (q.n == 0) continue;
+            WsMark mark = ws_mark(ctx);
+            if (sorted_flags && !sorted_flags[i]) {  // unsorted file (diff.go:341-378): sort a copy
+                u64 *k = nullptr;
+                u32 *t = nullptr;
+                UKM_TRY(ws_alloc_t(ctx, q.n, &k));
+                UKM_HIP(hipMemcpyAsync(k, q.k, q.n * sizeof(u64), hipMemcpyDeviceToDevice, ctx->stream));
+                if (tax) {
+                    UKM_TRY(ws_alloc_t(ctx, q.n, &t));
+                    if (q.t) UKM_HIP(hipMemcpyAsync(t, q.t, q.n * sizeof(u32), hipMemcpyDeviceToDevice, ctx->stream));
+                    else UKM_HIP(hipMemsetAsync(t, 0, q.n * sizeof(u32), ctx->stream));
+                }
+                UKM_TRY(ukm_dev_sort(ctx, k, t, q.n, 64));
+                q.k = k;
+                q.t = t;
+            }
+            u64 n = 0;
+            UKM_TRY(ukm_dev_setop2(ctx, UKM_OP_DIFF, acc.k, acc.t, acc.n, q.k, q.t, q.n, flags, bk[flip],
+                                   tax ? bt[flip] : nullptr, acc.n, &n));
+            acc = Stream{bk[flip], tax ? bt[flip] : nullptr, n};
+            flip ^= 1;
+            ws_release(ctx, mark);
+        }
+        if (!a_strict && acc.n) {
+            // the survivor map collapses duplicate codes, last record wins (diff.go:449-453)
+            u64 n = 0;
+            UKM_TRY(ukm_dev_unique_ex(ctx, acc.k, acc.t, acc.n, 4, 0, bk[2], tax ? bt[2] : nullptr, acc.n, &n));
+            acc = Stream{bk[2], tax ? bt[2] : nullptr, n};
+        }
+        return copy_result(ctx, acc, tax, o.k, o.t, out_cap, n_out);
+    });
+}
+
+// common.go:93-105
+extern "C" uint32_t ukm_common_threshold(uint32_t nfiles, double proportion, uint32_t number) {
+    if (number == 0) return (uint32_t)(uint16_t)((double)nfiles * proportion);
+    return (uint32_t)(uint16_t)number;
+}
+
+extern "C" int ukm_common(ukm_ctx *ctx, const uint64_t *const *keys, const uint32_t *const *taxids,
+                          const uint64_t *lens, int nstreams, uint32_t threshold, uint32_t flags,
+                          uint64_t *out_keys, uint32_t *out_taxids, uint64_t out_cap, uint64_t *n_out) {
+    (void)flags;
+    UKM_TRY(check_common_args(ctx, keys, lens, nstreams, out_keys, out_cap, n_out, "ukm_common"));
+    if (nstreams > 65535) UKM_FAIL(UKM_ERR_INVALID, "ukm_common: at most 65535 streams (common.go:75-77)");
+    const bool tax = any_taxids(taxids, nstreams);
+    return run_entry(ctx, out_keys, out_taxids, out_cap, n_out, tax, [&](OutBufs &o) -> int {
+        if (nstreams == 0) return UKM_OK;
+        std::vector<Stream> ss;
+        UKM_TRY(stage_streams(ctx, keys, taxids, lens, nstreams, tax, ss));
+        // first file: every code counts once (common.go:232,244) -> collapse duplicates, last wins
+        if (ss[0].n) {
+            bool sorted = true, strict = true;
+            UKM_TRY(ukm_dev_check_sorted(ctx, ss[0].k, ss[0].n, &sorted, &strict));
+            if (!strict) {
+                u64 *k = nullptr, *k2 = nullptr;
+                u32 *t = nullptr, *t2 = nullptr;
+                UKM_TRY(ws_alloc_t(ctx, ss[0].n, &k));
+                UKM_TRY(ws_alloc_t(ctx, ss[0].n, &k2));
+                UKM_HIP(hipMemcpyAsync(k, ss[0].k, ss[0].n * sizeof(u64), hipMemcpyDeviceToDevice, ctx->stream));
+                if (tax) {
+                    UKM_TRY(ws_alloc_t(ctx, ss[0].n, &t));
+                    UKM_TRY(ws_alloc_t(ctx, ss[0].n, &t2));
+                    if (ss[0].t) UKM_HIP(hipMemcpyAsync(t, ss[0].t, ss[0].n * sizeof(u32), hipMemcpyDeviceToDevice, ctx->stream));
+                    else UKM_HIP(hipMemsetAsync(t, 0, ss[0].n * sizeof(u32), ctx->stream));
+                }
+                if (!sorted) UKM_TRY(ukm_dev_sort(ctx, k, t, ss[0].n, 64));
+                u64 nu = 0;
+                UKM_TRY(ukm_dev_unique_ex(ctx, k, t, ss[0].n, 4, 0, k2, t2, ss[0].n, &nu));
+                ss[0] = Stream{k2, t2, nu};
+            }
+        }
+        u64 *k = nullptr;
+        u32 *t = nullptr;
+        u64 total = 0;
+        UKM_TRY(concat_streams(ctx, ss, tax, &k, &t, &total));
+        if (total == 0) return UKM_OK;
+        UKM_TRY(ukm_dev_sort(ctx, k, t, total, 64));
+        int r = ukm_dev_unique_ex(ctx, k, t, total, 5, threshold ? threshold : 0, o.k, o.t, out_cap, n_out);
+        return r;
+    });
+}
+
+extern "C" int ukm_merge_k(ukm_ctx *ctx, const uint64_t *const *keys, const uint32_t *const *taxids,
+                           const uint64_t *lens, int nstreams, int mode, int final_round,
+                           uint64_t *out_keys, uint32_t *out_taxids, uint64_t out_cap, uint64_t *n_out) {
+    UKM_TRY(check_common_args(ctx, keys, lens, nstreams, out_keys, out_cap, n_out, "ukm_merge_k"));
+    if (mode != UKM_PLAIN && mode != UKM_UNIQUE && mode != UKM_REPEATED)
+        UKM_FAIL(UKM_ERR_INVALID, "ukm_merge_k: mode must be UKM_PLAIN, UKM_UNIQUE or UKM_REPEATED");
+    const bool tax = any_taxids(taxids, nstreams);
+    return run_entry(ctx, out_keys, out_taxids, out_cap, n_out, tax, [&](OutBufs &o) -> int {
+        std::vector<Stream> ss;
+        UKM_TRY(stage_streams(ctx, keys, taxids, lens, nstreams, tax, ss));
+        u64 *k = nullptr;
+        u32 *t = nullptr;
+        u64 total = 0;
+        UKM_TRY(concat_streams(ctx, ss, tax, &k, &t, &total));
+        if (total == 0) return UKM_OK;
+        int live = 0;
+        for (auto &s : ss) live += s.n ? 1 : 0;
+        if (live > 1) UKM_TRY(ukm_dev_sort(ctx, k, t, total, 64));
+        // util-sort.go:377-388,519-530: in a non-final round the one/two-copy protocol is kept
+        int m = mode;
+        if (mode == UKM_REPEATED && !final_round) m = UKM_REPEATED_CHUNK;
+        return ukm_dev_unique(ctx, k, t, total, m, o.k, o.t, out_cap, n_out);
+    });
+}

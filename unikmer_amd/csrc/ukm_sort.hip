@@ -1,0 +1,303 @@
+// ukm_sort.hip — LSD radix sort of uint64 codes (optionally carrying uint32 taxids), the
+// MI355X replacement for sortutil.Uint64s / sorts.Quicksort(CodeTaxidSlice)
+// (twotwotwo/sorts; call sites count.go:581, union.go:274,295, sort.go:268,331,457,463 ...).
+//
+// Design (HBM-bound, integer):
+//   * one histogram kernel reads the keys once and builds the 256-bin digit histograms of ALL
+//     passes (LDS atomics, with a wave-uniform fast path so sorted/skewed input does not
+//     serialise on one bin); the host turns them into per-pass digit bases and drops passes
+//     whose digit is constant (k=31 -> 62 significant bits; top bits of k=21 codes are zero);
+//   * per executed pass ONE "onesweep" kernel: each 256-thread workgroup takes a ticketed tile
+//     of 4096 keys, ranks them stably with wave64 ballot match-any (8 ballots per key) into
+//     per-wave LDS digit counters, resolves the tile's global digit offsets by a per-digit
+//     decoupled look-back over the previous tiles' counts (thread d owns digit d), reorders
+//     the tile through LDS so that global stores are contiguous per digit, and scatters.
+//   Algorithmic bytes: 8n (histogram) + P * (8n read + 8n write) [+ P * 8n for taxids].
+#include <algorithm>
+
+#include "ukm_device.h"
+
+namespace {
+
+constexpr int NT = 256;
+constexpr int NW = NT / 64;
+constexpr int VT = 16;
+constexpr int TILE = NT * VT;
+constexpr int RADIX = 256;
+constexpr int MAX_PASSES = 8;
+
+// ---- histogram of all digits -------------------------------------------------------------------
+__global__ __launch_bounds__(NT) void radix_hist_kernel(const u64 *k, u64 n, int passes, u64 *ghist) {
+    __shared__ u32 s_h[MAX_PASSES * RADIX];
+    const int tid = (int)threadIdx.x;
+    for (int i = tid; i < MAX_PASSES * RADIX; i += NT) s_h[i] = 0;
+    __syncthreads();
+    const u64 per_block = ((n + gridDim.x - 1) / gridDim.x + 63) / 64 * 64;
+    const u64 beg = (u64)blockIdx.x * per_block;
+    const u64 end = (beg + per_block < n) ? beg + per_block : n;
+    for (u64 i = beg + tid; i < ((end + NT - 1) / NT) * NT && beg < end; i += NT) {
+        const bool valid = i < end;
+        const u64 key = valid ? k[i] : 0;
+        for (int p = 0; p < passes; p++) {
+            const u32 d = (u32)(key >> (8 * p)) & 255u;
+            const u32 d0 = __builtin_amdgcn_readfirstlane(d);
+            const u64 vm = __ballot(valid);
+            if (vm == ~0ull && __all(d == d0)) {
+                if (lane_id() == 0) atomicAdd(&s_h[p * RADIX + d0], 64u);
+            } else if (valid) {
+                atomicAdd(&s_h[p * RADIX + d], 1u);
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < passes * RADIX; i += NT) {
+        u32 v = s_h[i];
+        if (v) atomicAdd((unsigned long long *)&ghist[i], (unsigned long long)v);
+    }
+}
+
+// ---- onesweep pass -------------------------------------------------------------------------------
+template <typename SW> struct SWTraits;
+template <> struct SWTraits<u32> {
+    static constexpr u32 AGG = 1u << 30, INCL = 2u << 30, VAL = (1u << 30) - 1;
+    static constexpr int SHIFT = 30;
+};
+template <> struct SWTraits<u64> {
+    static constexpr u64 AGG = 1ull << 62, INCL = 2ull << 62, VAL = (1ull << 62) - 1;
+    static constexpr int SHIFT = 62;
+};
+
+template <typename SW>
+struct PassArgs {
+    const u64 *kin;
+    u64 *kout;
+    const u32 *vin;
+    u32 *vout;
+    u64 n;
+    int shift;
+    SW *status;  // [ntiles][256]
+    u32 *ticket;
+    const u64 *gbase;  // [256] exclusive digit bases of this pass
+    u64 ntiles;
+};
+
+template <typename SW, bool PAIRS>
+__global__ __launch_bounds__(NT) void onesweep_kernel(PassArgs<SW> p) {
+    using T = SWTraits<SW>;
+    __shared__ u64 s_keys[TILE];
+    __shared__ u32 s_vals[PAIRS ? TILE : 1];
+    __shared__ u32 s_whist[NW][RADIX];
+    __shared__ u32 s_dexcl[RADIX];
+    __shared__ u64 s_gbase[RADIX];
+    __shared__ u32 s_scan[NW + 1];
+    __shared__ u32 s_tile;
+    const int tid = (int)threadIdx.x, lane = lane_id(), wave = tid >> 6;
+    if (tid == 0) s_tile = atomicAdd(p.ticket, 1u);
+    for (int i = tid; i < NW * RADIX; i += NT) (&s_whist[0][0])[i] = 0;
+    __syncthreads();
+    const u64 tile = s_tile;
+    const u64 tbase = tile * (u64)TILE;
+    const u32 valid_count = (u32)((p.n - tbase < (u64)TILE) ? (p.n - tbase) : (u64)TILE);
+
+    // wave w owns keys [w*64*VT, (w+1)*64*VT) of the tile, striped across its lanes
+    u64 key[VT];
+    u32 val[VT];
+    u32 rank[VT];
+    const u32 wbase_idx = (u32)wave * 64 * VT + (u32)lane;
+#pragma unroll
+    for (int j = 0; j < VT; j++) {
+        const u32 li = wbase_idx + j * 64;
+        const bool v = li < valid_count;
+        key[j] = v ? p.kin[tbase + li] : ~0ull;
+        if (PAIRS) val[j] = v ? p.vin[tbase + li] : 0;
+    }
+    const u64 lt_mask = (1ull << lane) - 1;
+#pragma unroll
+    for (int j = 0; j < VT; j++) {
+        const u32 li = wbase_idx + j * 64;
+        // padding items take digit 255; they sit at the end of the tile order, so they rank
+        // after every real key of that digit and are dropped at write-out
+        const u32 d = (li < valid_count) ? ((u32)(key[j] >> p.shift) & 255u) : 255u;
+        u64 peers = ~0ull;
+#pragma unroll
+        for (int b = 0; b < 8; b++) {
+            const bool bit = (d >> b) & 1u;
+            const u64 m = __ballot(bit);
+            peers &= bit ? m : ~m;
+        }
+        const u32 pre = s_whist[wave][d];
+        const u32 r = (u32)__popcll(peers & lt_mask);
+        rank[j] = pre + r;
+        if (r == (u32)__popcll(peers) - 1) s_whist[wave][d] = pre + r + 1;  // highest peer lane
+    }
+    __syncthreads();
+
+    // thread d: exclusive scan over the waves, tile count of digit d
+    const int d = tid;
+    u32 cnt = 0;
+#pragma unroll
+    for (int w = 0; w < NW; w++) {
+        u32 c = s_whist[w][d];
+        s_whist[w][d] = cnt;
+        cnt += c;
+    }
+    u32 real_cnt = cnt;
+    if (d == 255) real_cnt -= (u32)TILE - valid_count;
+    // publish the tile's count of digit d, then look back
+    SW *st = p.status + tile * RADIX + d;
+    if (tile == 0) __hip_atomic_store(st, (SW)(T::INCL | (SW)real_cnt), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else __hip_atomic_store(st, (SW)(T::AGG | (SW)real_cnt), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+
+    u32 tile_total;
+    const u32 dex = block_excl_scan_u32<NT>(cnt, s_scan, &tile_total);  // contains barriers
+    s_dexcl[d] = dex;
+    __syncthreads();
+
+    // local reorder: tile becomes digit-sorted (stable) in LDS
+#pragma unroll
+    for (int j = 0; j < VT; j++) {
+        const u32 li = wbase_idx + j * 64;
+        const u32 dd = (li < valid_count) ? ((u32)(key[j] >> p.shift) & 255u) : 255u;
+        const u32 pos = s_dexcl[dd] + s_whist[wave][dd] + rank[j];
+        s_keys[pos] = key[j];
+        if (PAIRS) s_vals[pos] = val[j];
+    }
+
+    // per-digit decoupled look-back (thread d walks back over tiles)
+    u64 excl = 0;
+    if (tile > 0) {
+        long long t = (long long)tile - 1;
+        for (;;) {
+            SW w = __hip_atomic_load(p.status + (u64)t * RADIX + d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const u32 state = (u32)(w >> T::SHIFT);
+            if (state == 0) {
+                __builtin_amdgcn_s_sleep(1);
+                continue;
+            }
+            excl += (u64)(w & T::VAL);
+            if (state == 2) break;
+            t--;  // aggregate only: keep walking (tile 0 always publishes an inclusive value)
+        }
+        __hip_atomic_store(st, (SW)(T::INCL | (SW)(excl + real_cnt)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    s_gbase[d] = p.gbase[d] + excl - (u64)dex;
+    __syncthreads();
+
+    for (u32 i = (u32)tid; i < valid_count; i += NT) {
+        const u64 kk = s_keys[i];
+        const u32 dd = (u32)(kk >> p.shift) & 255u;
+        const u64 pos = s_gbase[dd] + i;
+        p.kout[pos] = kk;
+        if (PAIRS) p.vout[pos] = s_vals[i];
+    }
+}
+
+template <typename SW>
+int run_passes(ukm_ctx *c, u64 *keys, u32 *vals, u64 *tk, u32 *tv, u64 n, int npass,
+               const int *shifts, const u64 *gbase_dev, bool *result_in_tmp) {
+    const u64 ntiles = (n + TILE - 1) / TILE;
+    SW *status = nullptr;
+    u64 *ticket = nullptr;
+    UKM_TRY(ws_alloc_t(c, ntiles * RADIX, &status));
+    UKM_TRY(ws_alloc_t(c, 1, &ticket));
+    u64 *src_k = keys, *dst_k = tk;
+    u32 *src_v = vals, *dst_v = tv;
+    for (int i = 0; i < npass; i++) {
+        UKM_HIP(hipMemsetAsync(status, 0, ntiles * RADIX * sizeof(SW), c->stream));
+        UKM_HIP(hipMemsetAsync(ticket, 0, sizeof(u64), c->stream));
+        PassArgs<SW> p;
+        p.kin = src_k; p.kout = dst_k; p.vin = src_v; p.vout = dst_v;
+        p.n = n; p.shift = shifts[i];
+        p.status = status; p.ticket = (u32 *)ticket;
+        p.gbase = gbase_dev + (size_t)i * RADIX;
+        p.ntiles = ntiles;
+        if (vals) hipLaunchKernelGGL((onesweep_kernel<SW, true>), dim3((unsigned)ntiles), dim3(NT), 0, c->stream, p);
+        else hipLaunchKernelGGL((onesweep_kernel<SW, false>), dim3((unsigned)ntiles), dim3(NT), 0, c->stream, p);
+        UKM_HIP(hipGetLastError());
+        std::swap(src_k, dst_k);
+        std::swap(src_v, dst_v);
+    }
+    *result_in_tmp = (src_k != keys);
+    return UKM_OK;
+}
+
+}  // namespace
+
+// keys (and vals, may be NULL) are device pointers; sorted in place (stable for pairs)
+int ukm_dev_sort(ukm_ctx *c, u64 *keys, u32 *vals, u64 n, int key_bits) {
+    if (n < 2) return UKM_OK;
+    if (key_bits <= 0 || key_bits > 64) key_bits = 64;
+    if (n >= (1ull << 32))
+        UKM_FAIL(UKM_ERR_INVALID, "ukm_sort: n = %llu exceeds 2^32-1 records per call; sort chunks and "
+                 "combine them with ukm_merge_k (the reference's `sort -m` protocol)", (unsigned long long)n);
+    const int passes = (key_bits + 7) / 8;
+
+    u64 *ghist = nullptr;
+    UKM_TRY(ws_alloc_t(c, MAX_PASSES * RADIX, &ghist));
+    UKM_HIP(hipMemsetAsync(ghist, 0, MAX_PASSES * RADIX * sizeof(u64), c->stream));
+    unsigned hblocks = (unsigned)std::min<u64>((n + TILE - 1) / TILE, (u64)c->num_cu * 8);
+    hipLaunchKernelGGL(radix_hist_kernel, dim3(hblocks), dim3(NT), 0, c->stream, keys, n, passes, ghist);
+    UKM_HIP(hipGetLastError());
+    std::vector<u64> h((size_t)passes * RADIX);
+    UKM_HIP(hipMemcpyAsync(h.data(), ghist, h.size() * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
+    UKM_HIP(hipStreamSynchronize(c->stream));
+
+    int shifts[MAX_PASSES];
+    std::vector<u64> gb;
+    int npass = 0;
+    for (int p = 0; p < passes; p++) {
+        const u64 *hp = &h[(size_t)p * RADIX];
+        bool constant = false;
+        for (int d = 0; d < RADIX; d++)
+            if (hp[d] == n) constant = true;
+        if (constant) continue;  // every key has the same digit: the pass is the identity
+        shifts[npass++] = 8 * p;
+        u64 sum = 0;
+        for (int d = 0; d < RADIX; d++) {
+            gb.push_back(sum);
+            sum += hp[d];
+        }
+    }
+    if (npass == 0) return UKM_OK;
+
+    u64 *gbase_dev = nullptr, *tk = nullptr;
+    u32 *tv = nullptr;
+    UKM_TRY(ws_alloc_t(c, gb.size(), &gbase_dev));
+    UKM_HIP(hipMemcpyAsync(gbase_dev, gb.data(), gb.size() * sizeof(u64), hipMemcpyHostToDevice, c->stream));
+    UKM_HIP(hipStreamSynchronize(c->stream));  // gb is a local
+    UKM_TRY(ws_alloc_t(c, n, &tk));
+    if (vals) UKM_TRY(ws_alloc_t(c, n, &tv));
+    bool in_tmp = false;
+    if (n < (1ull << 30)) UKM_TRY(run_passes<u32>(c, keys, vals, tk, tv, n, npass, shifts, gbase_dev, &in_tmp));
+    else UKM_TRY(run_passes<u64>(c, keys, vals, tk, tv, n, npass, shifts, gbase_dev, &in_tmp));
+    if (in_tmp) {
+        UKM_HIP(hipMemcpyAsync(keys, tk, n * sizeof(u64), hipMemcpyDeviceToDevice, c->stream));
+        if (vals) UKM_HIP(hipMemcpyAsync(vals, tv, n * sizeof(u32), hipMemcpyDeviceToDevice, c->stream));
+    }
+    return UKM_OK;
+}
+
+extern "C" int ukm_sort_u64(ukm_ctx *ctx, uint64_t *keys, uint64_t n, int key_bits) {
+    if (!ctx || (!keys && n)) UKM_FAIL(UKM_ERR_INVALID, "ukm_sort_u64: NULL argument");
+    CallScope s;
+    UKM_TRY(ukm_begin(ctx, &s));
+    int rc = [&]() -> int {
+        void *d = nullptr;
+        UKM_TRY(ukm_inout(ctx, keys, n * sizeof(u64), &d));
+        return ukm_dev_sort(ctx, (u64 *)d, nullptr, n, key_bits);
+    }();
+    return ukm_finish(&s, rc);
+}
+
+extern "C" int ukm_sort_pairs(ukm_ctx *ctx, uint64_t *keys, uint32_t *taxids, uint64_t n, int key_bits) {
+    if (!ctx || (!keys && n) || (!taxids && n)) UKM_FAIL(UKM_ERR_INVALID, "ukm_sort_pairs: NULL argument");
+    CallScope s;
+    UKM_TRY(ukm_begin(ctx, &s));
+    int rc = [&]() -> int {
+        void *dk = nullptr, *dv = nullptr;
+        UKM_TRY(ukm_inout(ctx, keys, n * sizeof(u64), &dk));
+        UKM_TRY(ukm_inout(ctx, taxids, n * sizeof(u32), &dv));
+        return ukm_dev_sort(ctx, (u64 *)dk, (u32 *)dv, n, key_bits);
+    }();
+    return ukm_finish(&s, rc);
+}

@@ -1,0 +1,367 @@
+"""ctypes binding of libunikmer_hip.so (C ABI: include/unikmer_hip.h).
+
+There is NO CPU fallback: if the HIP library is missing, cannot be loaded, or no GPU is
+present, calls raise.  Arrays may be numpy arrays (host) or torch tensors (host or device);
+device tensors are passed by data_ptr and never copied.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(_HERE, "libunikmer_hip.so")
+
+OK = 0
+ERR_INVALID, ERR_HIP, ERR_NOMEM, ERR_ILLEGAL_BASE = -1, -2, -3, -4
+ERR_UNSORTED, ERR_NO_TAXONOMY, ERR_CAPACITY, ERR_K = -5, -6, -7, -8
+PLAIN, UNIQUE, REPEATED, REPEATED_CHUNK = 0, 1, 2, 3
+OP_UNION, OP_INTER, OP_DIFF = 0, 1, 2
+F_MIX_TAXID, F_CMP_TAXID, F_ASSUME_SET = 2, 4, 8
+
+# every symbol include/unikmer_hip.h declares (checked by tests/test_abi.py)
+SYMBOLS = [
+    "ukm_last_error", "ukm_version", "ukm_device_count", "ukm_ctx_create", "ukm_ctx_destroy",
+    "ukm_ctx_set_stream", "ukm_ctx_sync", "ukm_ctx_reserve", "ukm_dev_alloc", "ukm_dev_free",
+    "ukm_copy", "ukm_last_kernel_ms", "ukm_taxonomy_load", "ukm_taxonomy_max_taxid", "ukm_lca",
+    "ukm_encode_kmers", "ukm_nthash", "ukm_max_hash", "ukm_sort_u64", "ukm_sort_pairs",
+    "ukm_unique", "ukm_merge_k", "ukm_setop2", "ukm_union", "ukm_inter", "ukm_diff",
+    "ukm_common", "ukm_common_threshold", "ukm_partition_points",
+]
+
+
+class UkmError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("libunikmer_hip error %d: %s" % (code, msg))
+        self.code = code
+
+
+class IllegalBaseError(UkmError):
+    pass
+
+
+class UnsortedError(UkmError):
+    pass
+
+
+class CapacityError(UkmError):
+    pass
+
+
+_lib = None
+
+
+def load():
+    """dlopen the HIP library; raises if it has not been built (python -m unikmer_amd.build)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(SO_PATH):
+        raise ImportError("libunikmer_hip.so is not built (%s); run `python -m unikmer_amd.build`. "
+                          "There is no CPU fallback." % SO_PATH)
+    L = C.CDLL(SO_PATH)
+    vp, u64, u32, i32 = C.c_void_p, C.c_uint64, C.c_uint32, C.c_int
+    pu64 = C.POINTER(C.c_uint64)
+    pvp = C.POINTER(C.c_void_p)
+    L.ukm_last_error.restype = C.c_char_p
+    L.ukm_version.restype = i32
+    L.ukm_device_count.argtypes = [C.POINTER(i32)]
+    L.ukm_ctx_create.argtypes = [i32, pvp]
+    L.ukm_ctx_destroy.argtypes = [vp]
+    L.ukm_ctx_set_stream.argtypes = [vp, vp]
+    L.ukm_ctx_sync.argtypes = [vp]
+    L.ukm_ctx_reserve.argtypes = [vp, u64]
+    L.ukm_dev_alloc.argtypes = [vp, u64, pvp]
+    L.ukm_dev_free.argtypes = [vp, vp]
+    L.ukm_copy.argtypes = [vp, vp, vp, u64]
+    L.ukm_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
+    L.ukm_taxonomy_load.argtypes = [vp, vp, vp, u64, vp, vp, u64]
+    L.ukm_taxonomy_max_taxid.argtypes = [vp, C.POINTER(u32)]
+    L.ukm_lca.argtypes = [vp, vp, vp, u64, vp]
+    L.ukm_encode_kmers.argtypes = [vp, vp, vp, u64, i32, i32, i32, vp, u64, pu64]
+    L.ukm_nthash.argtypes = [vp, vp, vp, u64, i32, i32, i32, u64, vp, u64, pu64]
+    L.ukm_max_hash.argtypes = [u64]
+    L.ukm_max_hash.restype = u64
+    L.ukm_sort_u64.argtypes = [vp, vp, u64, i32]
+    L.ukm_sort_pairs.argtypes = [vp, vp, vp, u64, i32]
+    L.ukm_unique.argtypes = [vp, vp, vp, u64, i32, vp, vp, u64, pu64]
+    L.ukm_merge_k.argtypes = [vp, pvp, pvp, pu64, i32, i32, i32, vp, vp, u64, pu64]
+    L.ukm_setop2.argtypes = [vp, i32, vp, vp, u64, vp, vp, u64, u32, vp, vp, u64, pu64]
+    for f in (L.ukm_union, L.ukm_inter):
+        f.argtypes = [vp, pvp, pvp, pu64, i32, u32, vp, vp, u64, pu64]
+    L.ukm_diff.argtypes = [vp, pvp, pvp, pu64, i32, vp, u32, vp, vp, u64, pu64]
+    L.ukm_common.argtypes = [vp, pvp, pvp, pu64, i32, u32, u32, vp, vp, u64, pu64]
+    L.ukm_common_threshold.argtypes = [u32, C.c_double, u32]
+    L.ukm_common_threshold.restype = u32
+    L.ukm_partition_points.argtypes = [vp, vp, u64, vp, i32, vp]
+    _lib = L
+    return L
+
+
+def _check(rc):
+    if rc == OK:
+        return
+    msg = load().ukm_last_error().decode(errors="replace")
+    cls = {ERR_ILLEGAL_BASE: IllegalBaseError, ERR_UNSORTED: UnsortedError,
+           ERR_CAPACITY: CapacityError}.get(rc, UkmError)
+    raise cls(rc, msg)
+
+
+def _is_torch(x):
+    return type(x).__module__.startswith("torch")
+
+
+_NP2TORCH = {np.dtype(np.uint64): "int64", np.dtype(np.uint32): "int32", np.dtype(np.uint8): "uint8"}
+
+
+def _ptr(x, dtype):
+    """(pointer, length, keepalive) of a numpy array / torch tensor viewed as `dtype` items."""
+    if x is None:
+        return None, 0, None
+    if _is_torch(x):
+        assert x.is_contiguous(), "tensors passed to libunikmer_hip must be contiguous"
+        assert x.element_size() == np.dtype(dtype).itemsize, "tensor item size mismatch"
+        return x.data_ptr() if x.numel() else None, x.numel(), x
+    a = np.ascontiguousarray(x, dtype=dtype)
+    return (a.ctypes.data if a.size else None), a.size, a
+
+
+def _empty_like_kind(ref, n, dtype):
+    """allocate an output of n items where `ref` lives (device tensor -> device tensor)."""
+    if _is_torch(ref):
+        import torch
+        return torch.empty(max(n, 1), dtype=getattr(torch, _NP2TORCH[np.dtype(dtype)]), device=ref.device)
+    return np.empty(max(n, 1), dtype=dtype)
+
+
+class Context:
+    """One ukm_ctx: a HIP stream + device workspace.  Not thread-safe (one per thread)."""
+
+    def __init__(self, device=0, stream=None):
+        L = load()
+        n = C.c_int(0)
+        L.ukm_device_count(C.byref(n))
+        if n.value == 0:
+            raise RuntimeError("libunikmer_hip: no HIP device visible; this path has no CPU fallback")
+        h = C.c_void_p()
+        _check(L.ukm_ctx_create(device, C.byref(h)))
+        self.h = h
+        self.L = L
+        if stream is not None:
+            _check(L.ukm_ctx_set_stream(self.h, C.c_void_p(stream)))
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.ukm_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- plumbing ----
+    def set_stream(self, stream):
+        _check(self.L.ukm_ctx_set_stream(self.h, C.c_void_p(stream)))
+
+    def sync(self):
+        _check(self.L.ukm_ctx_sync(self.h))
+
+    def reserve(self, nbytes):
+        _check(self.L.ukm_ctx_reserve(self.h, nbytes))
+
+    def last_kernel_ms(self):
+        ms = C.c_float()
+        _check(self.L.ukm_last_kernel_ms(self.h, C.byref(ms)))
+        return ms.value
+
+    # ---- taxonomy ----
+    def taxonomy_load(self, child, parent, merged_old=None, merged_new=None):
+        pc, n, k1 = _ptr(child, np.uint32)
+        pp, n2, k2 = _ptr(parent, np.uint32)
+        assert n == n2
+        po, m, k3 = _ptr(merged_old, np.uint32)
+        pn, m2, k4 = _ptr(merged_new, np.uint32)
+        assert m == m2
+        _check(self.L.ukm_taxonomy_load(self.h, pc, pp, n, po, pn, m))
+
+    def max_taxid(self):
+        v = C.c_uint32()
+        _check(self.L.ukm_taxonomy_max_taxid(self.h, C.byref(v)))
+        return v.value
+
+    def lca(self, a, b):
+        pa, n, k1 = _ptr(a, np.uint32)
+        pb, n2, k2 = _ptr(b, np.uint32)
+        assert n == n2
+        out = _empty_like_kind(a, n, np.uint32)
+        po, _, _ = _ptr(out, np.uint32)
+        _check(self.L.ukm_lca(self.h, pa, pb, n, po))
+        return out[:n]
+
+    # ---- encode / hash ----
+    def _windows(self, fn, bases, rec_off, k, canonical, circular, max_hash, out):
+        pb, nb, k1 = _ptr(bases, np.uint8)
+        poff, noff, k2 = _ptr(rec_off, np.uint64)
+        n_rec = noff - 1
+        if out is None:
+            if _is_torch(rec_off):
+                lens = (rec_off[1:] - rec_off[:-1])
+                cap = int(lens.sum().item()) if circular else int(lens.clamp(min=k - 1).sub(k - 1).sum().item())
+            else:
+                lens = np.diff(np.asarray(rec_off).astype(np.int64))
+                cap = int(lens.sum()) if circular else int(np.maximum(lens - (k - 1), 0).sum())
+            out = _empty_like_kind(bases, cap, np.uint64)
+        po, cap, _ = _ptr(out, np.uint64)
+        n = C.c_uint64()
+        if fn == "enc":
+            rc = self.L.ukm_encode_kmers(self.h, pb, poff, n_rec, k, int(canonical), int(circular), po, cap,
+                                         C.byref(n))
+        else:
+            rc = self.L.ukm_nthash(self.h, pb, poff, n_rec, k, int(canonical), int(circular), max_hash, po, cap,
+                                   C.byref(n))
+        _check(rc)
+        return out[: n.value]
+
+    def encode_kmers(self, bases, rec_off, k, canonical=True, circular=False, out=None):
+        return self._windows("enc", bases, rec_off, k, canonical, circular, 0, out)
+
+    def nthash(self, bases, rec_off, k, canonical=True, circular=False, max_hash=0, out=None):
+        return self._windows("nt", bases, rec_off, k, canonical, circular, max_hash, out)
+
+    def max_hash(self, scale):
+        return self.L.ukm_max_hash(scale)
+
+    # ---- sort / scans ----
+    def sort_u64(self, keys, key_bits=64):
+        """In place; returns keys."""
+        if not _is_torch(keys):
+            assert isinstance(keys, np.ndarray) and keys.dtype == np.uint64 and keys.flags.c_contiguous
+        p, n, _ = _ptr(keys, np.uint64)
+        _check(self.L.ukm_sort_u64(self.h, p, n, key_bits))
+        return keys
+
+    def sort_pairs(self, keys, taxids, key_bits=64):
+        if not _is_torch(keys):
+            assert isinstance(keys, np.ndarray) and keys.dtype == np.uint64 and keys.flags.c_contiguous
+            assert isinstance(taxids, np.ndarray) and taxids.dtype == np.uint32 and taxids.flags.c_contiguous
+        pk, n, _ = _ptr(keys, np.uint64)
+        pt, n2, _ = _ptr(taxids, np.uint32)
+        assert n == n2
+        _check(self.L.ukm_sort_pairs(self.h, pk, pt, n, key_bits))
+        return keys, taxids
+
+    def unique(self, keys, taxids=None, mode=UNIQUE, out=None, out_taxids=None):
+        pk, n, k1 = _ptr(keys, np.uint64)
+        pt, _, k2 = _ptr(taxids, np.uint32)
+        cap = 2 * n if mode == REPEATED_CHUNK else n
+        if out is None:
+            out = _empty_like_kind(keys, cap, np.uint64)
+        if taxids is not None and out_taxids is None:
+            out_taxids = _empty_like_kind(keys, cap, np.uint32)
+        po, cap, _ = _ptr(out, np.uint64)
+        pot, _, _ = _ptr(out_taxids, np.uint32)
+        m = C.c_uint64()
+        _check(self.L.ukm_unique(self.h, pk, pt, n, mode, po, pot, cap, C.byref(m)))
+        return (out[: m.value], out_taxids[: m.value]) if taxids is not None else out[: m.value]
+
+    # ---- set operations ----
+    def setop2(self, op, a, b, a_taxids=None, b_taxids=None, flags=0, out=None, out_taxids=None):
+        pa, na, k1 = _ptr(a, np.uint64)
+        pb, nb, k2 = _ptr(b, np.uint64)
+        pta, _, k3 = _ptr(a_taxids, np.uint32)
+        ptb, _, k4 = _ptr(b_taxids, np.uint32)
+        tax = a_taxids is not None or b_taxids is not None
+        bound = na + nb if op == OP_UNION else na
+        if out is None:
+            out = _empty_like_kind(a, bound, np.uint64)
+        if tax and out_taxids is None:
+            out_taxids = _empty_like_kind(a, bound, np.uint32)
+        po, cap, _ = _ptr(out, np.uint64)
+        pot, _, _ = _ptr(out_taxids, np.uint32)
+        n = C.c_uint64()
+        _check(self.L.ukm_setop2(self.h, op, pa, pta, na, pb, ptb, nb, flags, po, pot, cap, C.byref(n)))
+        return (out[: n.value], out_taxids[: n.value]) if tax else out[: n.value]
+
+    def _nway_args(self, keys_list, taxids_list):
+        n = len(keys_list)
+        keep = []
+        kp = (C.c_void_p * max(n, 1))()
+        tp = (C.c_void_p * max(n, 1))()
+        lens = (C.c_uint64 * max(n, 1))()
+        tax = taxids_list is not None and any(t is not None for t in taxids_list)
+        for i, k in enumerate(keys_list):
+            p, ln, ka = _ptr(k, np.uint64)
+            kp[i] = p
+            lens[i] = ln
+            keep.append(ka)
+            if tax and taxids_list[i] is not None:
+                pt, lt, kt = _ptr(taxids_list[i], np.uint32)
+                assert lt == ln
+                tp[i] = pt
+                keep.append(kt)
+        total = sum(int(lens[i]) for i in range(n))
+        return kp, (tp if tax else None), lens, n, tax, total, keep
+
+    def _nway(self, which, keys_list, taxids_list, bound, extra, flags, out, out_taxids):
+        kp, tp, lens, n, tax, total, keep = self._nway_args(keys_list, taxids_list)
+        ref = keys_list[0] if n else np.empty(0, np.uint64)
+        cap = bound(total, int(lens[0]) if n else 0)
+        if out is None:
+            out = _empty_like_kind(ref, cap, np.uint64)
+        if tax and out_taxids is None:
+            out_taxids = _empty_like_kind(ref, cap, np.uint32)
+        po, cap, _ = _ptr(out, np.uint64)
+        pot, _, _ = _ptr(out_taxids, np.uint32)
+        m = C.c_uint64()
+        kpp = C.cast(kp, C.POINTER(C.c_void_p))
+        tpp = C.cast(tp, C.POINTER(C.c_void_p)) if tp is not None else None
+        L = self.L
+        if which == "union":
+            rc = L.ukm_union(self.h, kpp, tpp, lens, n, flags, po, pot, cap, C.byref(m))
+        elif which == "inter":
+            rc = L.ukm_inter(self.h, kpp, tpp, lens, n, flags, po, pot, cap, C.byref(m))
+        elif which == "diff":
+            sf = extra
+            psf = None
+            if sf is not None:
+                sf = np.ascontiguousarray(sf, dtype=np.uint8)
+                psf = sf.ctypes.data
+            rc = L.ukm_diff(self.h, kpp, tpp, lens, n, psf, flags, po, pot, cap, C.byref(m))
+        elif which == "common":
+            rc = L.ukm_common(self.h, kpp, tpp, lens, n, extra, flags, po, pot, cap, C.byref(m))
+        else:
+            mode, final_round = extra
+            rc = L.ukm_merge_k(self.h, kpp, tpp, lens, n, mode, int(final_round), po, pot, cap, C.byref(m))
+        _check(rc)
+        return (out[: m.value], out_taxids[: m.value]) if tax else out[: m.value]
+
+    def union(self, keys_list, taxids_list=None, out=None, out_taxids=None):
+        return self._nway("union", keys_list, taxids_list, lambda t, f: t, None, 0, out, out_taxids)
+
+    def inter(self, keys_list, taxids_list=None, mix_taxid=False, out=None, out_taxids=None):
+        return self._nway("inter", keys_list, taxids_list, lambda t, f: f, None,
+                          F_MIX_TAXID if mix_taxid else 0, out, out_taxids)
+
+    def diff(self, keys_list, taxids_list=None, compare_taxid=False, sorted_flags=None, out=None,
+             out_taxids=None):
+        return self._nway("diff", keys_list, taxids_list, lambda t, f: f, sorted_flags,
+                          F_CMP_TAXID if compare_taxid else 0, out, out_taxids)
+
+    def common(self, keys_list, threshold, taxids_list=None, out=None, out_taxids=None):
+        return self._nway("common", keys_list, taxids_list, lambda t, f: t, int(threshold), 0, out, out_taxids)
+
+    def merge_k(self, keys_list, taxids_list=None, mode=PLAIN, final_round=True, out=None, out_taxids=None):
+        return self._nway("merge", keys_list, taxids_list, lambda t, f: 2 * t, (mode, final_round), 0, out,
+                          out_taxids)
+
+    def common_threshold(self, nfiles, proportion=1.0, number=0):
+        return self.L.ukm_common_threshold(nfiles, proportion, number)
+
+    def partition_points(self, keys, splitters):
+        pk, n, k1 = _ptr(keys, np.uint64)
+        sp = np.ascontiguousarray(splitters, dtype=np.uint64)
+        cuts = np.empty(len(sp), dtype=np.uint64)
+        _check(self.L.ukm_partition_points(self.h, pk, n, sp.ctypes.data, len(sp), cuts.ctypes.data))
+        return cuts
