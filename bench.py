@@ -1,0 +1,286 @@
+#!/usr/bin/env python
+"""bench.py — k-mers/sec for `union` + `inter` of two sorted k=31 k-mer sets on MI355X.
+
+Contract: `python bench.py --gpus N --steps K --warmup W` prints ONE JSON line (rank 0).
+A step = one pass of the hot path over one batch = ukm_setop2(UNION) + ukm_setop2(INTER) on
+the two device-resident sets, through the C ABI of libunikmer_hip.so.  Inputs (and output
+buffers) are resident in HBM when the timed region starts; per step every rank processes
+2 x (|A|+|B|) input k-mers.
+
+Workload (BASELINE.json metric): synthetic sets of --n (default 1e9) uint64
+k=31 codes each, generated on the device: universe U[i] = prefix sum of gaps
+1 + (splitmix64(seed ^ j) mod G), membership m = splitmix64(seed2 ^ i) & 3 (0 -> A only,
+1 -> B only, 2/3 -> both), |U| = 4n/3, so |A ∩ B| ≈ 2n/3 and |A ∪ B| = 4n/3.
+
+N > 1 (weak scaling): the code space is sharded by high-bits prefix; rank r holds the r-th
+prefix range of both sets (|A_r| ≈ |B_r| ≈ n), i.e. the state after the prefix redistribution,
+and runs the 1-GPU path on it with no data-path collective.  The redistribution itself
+(RCCL all-to-all-v over xGMI, unikmer_amd/dist.py) is timed separately and reported under
+"exchange" — it is bounded by xGMI, not HBM.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+SEED = 0x756E696B6D6572  # "unikmer"
+M64 = (1 << 64) - 1
+
+
+def _i64(x):
+    """python int (uint64 value) -> the int64 with the same bit pattern"""
+    x &= M64
+    return x - (1 << 64) if x >= (1 << 63) else x
+
+
+def splitmix64_torch(x):
+    """splitmix64 finaliser on int64 tensors holding uint64 bit patterns (logical shifts)."""
+    import torch
+    z = x + _i64(0x9E3779B97F4A7C15)
+    z = (z ^ ((z >> 30) & ((1 << 34) - 1))) * _i64(0xBF58476D1CE4E5B9)
+    z = (z ^ ((z >> 27) & ((1 << 37) - 1))) * _i64(0x94D049BB133111EB)
+    return z ^ ((z >> 31) & ((1 << 33) - 1))
+
+
+def splitmix64_np(x):
+    x = np.asarray(x, dtype=np.uint64)
+    with np.errstate(over="ignore"):
+        z = x + np.uint64(0x9E3779B97F4A7C15)
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        return z ^ (z >> np.uint64(31))
+
+
+def gen_sets_device(n_universe, gap_bits, base, seed, device, chunk=1 << 27):
+    """Returns (A, B) int64 device tensors (uint64 bit patterns), sorted, strictly increasing."""
+    import torch
+    A_parts, B_parts = [], []
+    run = base
+    for lo in range(0, n_universe, chunk):
+        hi = min(lo + chunk, n_universe)
+        j = torch.arange(lo, hi, dtype=torch.int64, device=device)
+        gaps = 1 + (splitmix64_torch(j ^ _i64(seed)) & ((1 << gap_bits) - 1))
+        U = torch.cumsum(gaps, 0) + run
+        run = int(U[-1].item())
+        m = splitmix64_torch(j ^ _i64(seed + 1)) & 3
+        A_parts.append(U[(m == 0) | (m >= 2)])
+        B_parts.append(U[(m == 1) | (m >= 2)])
+        del j, gaps, U, m
+    A = torch.cat(A_parts)
+    B = torch.cat(B_parts)
+    del A_parts, B_parts
+    torch.cuda.empty_cache()
+    return A, B
+
+
+def gen_sets_numpy(n_universe, gap_bits, base, seed):
+    j = np.arange(n_universe, dtype=np.uint64)
+    gaps = np.uint64(1) + (splitmix64_np(j ^ np.uint64(seed)) & np.uint64((1 << gap_bits) - 1))
+    U = np.cumsum(gaps, dtype=np.uint64) + np.uint64(base)
+    m = splitmix64_np(j ^ np.uint64(seed + 1)) & np.uint64(3)
+    return U[(m == 0) | (m >= 2)], U[(m == 1) | (m >= 2)]
+
+
+def cpu_baseline(sample_universe, gap_bits):
+    """The reference's algorithms (hash-map union + sort of keys, union.go:186-305; 2-pointer
+    inter, inter.go:205-278) as restated in oracle/, single thread, on a bounded sample of the
+    same generator.  Reported, never the target."""
+    from oracle import oracle as O
+    A, B = gen_sets_numpy(sample_universe, gap_bits, 0, SEED)
+    tu, u = O.time_union2(A, B)
+    ti, i = O.time_inter2(A, B)
+    kmers = 2 * (len(A) + len(B))
+    return {
+        "value": kmers / (tu + ti),
+        "unit": "k-mers/s",
+        "cores": 1,
+        "kind": "port",
+        "sample": "union+inter of 2 x %d synthetic k=31 codes (same generator; C restatement of the "
+                  "reference's hash-map union and 2-pointer inter, 1 thread; Go toolchain absent)" % len(A),
+        "union_s": tu, "inter_s": ti, "union_out": int(len(u)), "inter_out": int(len(i)),
+        "host_cores_available": os.cpu_count(),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--n", type=float, default=1e9, help="k-mers per set per GPU")
+    ap.add_argument("--cpu-sample", type=float, default=2e7, help="k-mers per set for the CPU baseline (0 = skip)")
+    ap.add_argument("--no-exchange", action="store_true", help="skip the separate all-to-all timing at N>1")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from unikmer_amd import lib
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(0)
+    assert args.gpus == world, "--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world)
+    dev = torch.device("cuda", local_rank if world > 1 else 0)
+
+    n = int(args.n)
+    n_universe = (4 * n + 2) // 3
+    log2w = max(0, (world - 1).bit_length())
+    gap_bits = 32 - log2w                      # keeps world * sum(gaps) below 2^62 (k=31)
+    base = rank * ((1 << 62) // world)         # prefix shard r of the k=31 code space
+    while n_universe * (1 << (gap_bits - 1)) > (1 << 62) // max(world, 1) and gap_bits > 2:
+        gap_bits -= 1
+    A, B = gen_sets_device(n_universe, gap_bits, base, SEED + 7919 * rank, dev)
+    na, nb = A.numel(), B.numel()
+
+    # verify the device generator against numpy on a 1e6 sub-sample (rank's own seed/base)
+    An, Bn = gen_sets_numpy(1_000_000, gap_bits, base, SEED + 7919 * rank)
+    ma, mb = min(na, len(An)), min(nb, len(Bn))
+    assert np.array_equal(A[:ma].cpu().numpy().view(np.uint64), An[:ma]), "device generator != numpy generator"
+    assert np.array_equal(B[:mb].cpu().numpy().view(np.uint64), Bn[:mb]), "device generator != numpy generator"
+
+    out_u = torch.empty(na + nb, dtype=torch.int64, device=dev)
+    out_i = torch.empty(min(na, nb), dtype=torch.int64, device=dev)
+    stream = torch.cuda.current_stream(dev)
+    ctx = lib.Context(dev.index, stream=stream.cuda_stream)
+
+    def step():
+        u = ctx.setop2(lib.OP_UNION, A, B, out=out_u)
+        ku = ctx.last_kernel_ms()
+        i = ctx.setop2(lib.OP_INTER, A, B, out=out_i)
+        ki = ctx.last_kernel_ms()
+        return u.numel(), i.numel(), ku, ki
+
+    for _ in range(args.warmup):
+        nu, ni, _, _ = step()
+    if args.warmup == 0:
+        nu, ni, _, _ = step()
+    # size-independent parity properties at full size (tests/ hold the bit-exact comparisons)
+    assert nu + ni == na + nb, "inclusion-exclusion violated"
+    u_t, i_t = out_u[:nu], out_i[:ni]
+    assert bool((u_t[1:] > u_t[:-1]).all()) and bool((i_t[1:] > i_t[:-1]).all()), "output not strictly sorted"
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    barrier()
+    t0 = time.perf_counter()
+    ku_sum = ki_sum = 0.0
+    for _ in range(args.steps):
+        nu, ni, ku, ki = step()
+        ku_sum += ku
+        ki_sum += ki
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+        cnt = torch.tensor([na + nb, nu, ni], dtype=torch.int64, device=dev)
+        dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
+        tot_in, tot_u, tot_i = (int(x) for x in cnt.cpu())
+    else:
+        tot_in, tot_u, tot_i = na + nb, nu, ni
+
+    ms_per_step = dt * 1e3 / args.steps
+    value = 2.0 * tot_in * args.steps / dt  # each op consumes |A|+|B| input k-mers
+
+    # ---- separate timing of the prefix redistribution (N > 1) ----
+    exchange = None
+    if world > 1 and not args.no_exchange:
+        from unikmer_amd import dist as ud
+        # file-sharded starting state: every rank holds a 1/world sample of the GLOBAL A
+        # (stride-sampled so it spans the whole code space); ship slices to their owners.
+        spl = ud.prefix_splitters(62, world)[:-1]
+        # build a full-range stream of size ~n on this rank by gathering strided pieces
+        # every rank contributes its stride-`world` residue class `r` to rank r
+        send = [A[r::world].contiguous() for r in range(world)]
+        send_cat = torch.cat(send)
+        scounts = [s.numel() for s in send]
+        full, _, rc = ud.exchange_sorted(send_cat, scounts)
+        # `full` = world sorted pieces, one per prefix range, concatenated in range order -> sorted
+        cuts = ctx.partition_points(full, spl)
+        counts = ud.cuts_to_counts(cuts, full.numel())
+        barrier()
+        te = time.perf_counter()
+        reps = 3
+        for _ in range(reps):
+            got, _, _ = ud.exchange_sorted(full, counts)
+        barrier()
+        te = (time.perf_counter() - te) / reps
+        tt = torch.tensor([te], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        moved = full.numel() - counts[rank]
+        exchange = {"ms": float(tt.item()) * 1e3, "records_per_rank": int(full.numel()),
+                    "bytes_sent_per_rank": int(moved) * 8,
+                    "GBps_per_rank": int(moved) * 8 / float(tt.item()) / 1e9,
+                    "note": "one all-to-all-v (RCCL) redistributing one file-sharded set of ~n codes per rank "
+                            "to prefix owners; not part of `value`"}
+        del full, got, send_cat, send
+
+    if rank == 0:
+        # roofline of the dominant kernel (union tile kernel): algorithmic bytes per launch
+        # = 8(|A|+|B|) read + 8|A∪B| written, rank 0's launch
+        ku = ku_sum / args.steps * 1e-3
+        ki = ki_sum / args.steps * 1e-3
+        bytes_u = 8.0 * (na + nb) + 8.0 * nu
+        bytes_i = 8.0 * (na + nb) + 8.0 * ni
+        peak = 8000.0
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            try:
+                tj = json.load(open(tpath))
+                if int(tj.get("n", 0)) == n:
+                    traffic = tj.get("union_traffic_bytes_per_launch")
+            except Exception:
+                traffic = None
+        roofline = {"bound": "hbm", "kernel": "setop_tile_kernel<UNION>", "achieved": bytes_u / ku / 1e9,
+                    "peak": peak, "unit": "GB/s", "frac": bytes_u / ku / 1e9 / peak, "traffic": traffic,
+                    "algorithmic_bytes": bytes_u, "kernel_ms": ku * 1e3}
+        roofline_inter = {"bound": "hbm", "kernel": "setop_tile_kernel<INTER>", "achieved": bytes_i / ki / 1e9,
+                          "peak": peak, "unit": "GB/s", "frac": bytes_i / ki / 1e9 / peak,
+                          "algorithmic_bytes": bytes_i, "kernel_ms": ki * 1e3}
+        cpu = None
+        if world == 1 and args.cpu_sample > 0:
+            cpu = cpu_baseline((4 * int(args.cpu_sample) + 2) // 3, 32)
+        res = {
+            "metric": "k-mers/sec for union+inter of 1e9-k-mer k=31 sets",
+            "value": value, "unit": "k-mers/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u64", "data": "synthetic",
+            "config": {"workload": "union+inter of two sorted k=31 sets of %d uint64 codes per GPU "
+                                   "(|A|=%d |B|=%d |A∪B|=%d |A∩B|=%d on rank 0)" % (n, na, nb, nu, ni),
+                       "k": 31, "per_gpu_set_size": n, "parallelism": "prefix-sharded x%d" % world,
+                       "ops_per_step": ["ukm_setop2(UNION)", "ukm_setop2(INTER)"]},
+            "roofline": roofline, "roofline_inter": roofline_inter, "cpu_baseline": cpu,
+            "union_kmers_per_s_kernel": (na + nb) / ku, "inter_kmers_per_s_kernel": (na + nb) / ki,
+        }
+        if exchange:
+            res["exchange"] = exchange
+        if cpu:
+            res["speedup_vs_cpu_port"] = value / cpu["value"]
+        print(json.dumps(res))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

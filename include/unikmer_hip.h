@@ -81,9 +81,11 @@ int ukm_ctx_reserve(ukm_ctx *ctx, uint64_t bytes);
 int ukm_dev_alloc(ukm_ctx *ctx, uint64_t bytes, void **dptr);
 int ukm_dev_free(ukm_ctx *ctx, void *dptr);
 int ukm_copy(ukm_ctx *ctx, void *dst, const void *src, uint64_t bytes); /* any direction */
-/* duration in ms of the device work of the most recent compute call on this ctx
- * (hipEvent pair recorded on the ctx stream around the kernels) */
+/* ms between hipEvents recorded on the ctx stream (a) around the DOMINANT kernel of the most
+ * recent compute call (the tiled set-op kernel for ukm_setop2; falls back to (b) when a call
+ * records none) and (b) around all device work of the call */
 int ukm_last_kernel_ms(ukm_ctx *ctx, float *ms);
+int ukm_last_call_ms(ukm_ctx *ctx, float *ms);
 
 /* ---- taxonomy: replaces taxdump.NewTaxonomyFromNCBI / LoadMergedNodesFromNCBI / LCA
  *      (util.go:119-171; 14 taxondb.LCA call sites).

@@ -51,6 +51,8 @@ extern "C" int ukm_ctx_create(int device, ukm_ctx **out) {
     hipError_t e1 = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     hipError_t e2 = hipEventCreate(&c->ev_start);
     hipError_t e3 = hipEventCreate(&c->ev_stop);
+    if (e3 == hipSuccess) e3 = hipEventCreate(&c->ev_k0);
+    if (e3 == hipSuccess) e3 = hipEventCreate(&c->ev_k1);
     hipError_t e4 = hipHostMalloc((void **)&c->h_scratch, 64 * sizeof(u64), hipHostMallocDefault);
     if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess || e4 != hipSuccess) {
         delete c;
@@ -77,6 +79,8 @@ extern "C" int ukm_ctx_destroy(ukm_ctx *c) {
     if (c->h_scratch) (void)hipHostFree(c->h_scratch);
     if (c->ev_start) (void)hipEventDestroy(c->ev_start);
     if (c->ev_stop) (void)hipEventDestroy(c->ev_stop);
+    if (c->ev_k0) (void)hipEventDestroy(c->ev_k0);
+    if (c->ev_k1) (void)hipEventDestroy(c->ev_k1);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return UKM_OK;
@@ -266,6 +270,7 @@ int ukm_begin(ukm_ctx *c, CallScope *s) {
         c->copybacks.clear();
         (void)hipEventRecord(c->ev_start, c->stream);
         c->ev_valid = false;
+        c->evk_valid = false;
     }
     s->mark = ws_mark(c);
     return UKM_OK;
@@ -309,11 +314,19 @@ int ukm_read_u64(ukm_ctx *c, const u64 *dev, u64 *host, int n) {
     return UKM_OK;
 }
 
-extern "C" int ukm_last_kernel_ms(ukm_ctx *c, float *ms) {
-    if (!c || !ms) UKM_FAIL(UKM_ERR_INVALID, "ukm_last_kernel_ms: NULL argument");
-    if (!c->ev_valid) UKM_FAIL(UKM_ERR_INVALID, "ukm_last_kernel_ms: no completed call");
+extern "C" int ukm_last_call_ms(ukm_ctx *c, float *ms) {
+    if (!c || !ms) UKM_FAIL(UKM_ERR_INVALID, "ukm_last_call_ms: NULL argument");
+    if (!c->ev_valid) UKM_FAIL(UKM_ERR_INVALID, "ukm_last_call_ms: no completed call");
     UKM_HIP(hipEventSynchronize(c->ev_stop));
     UKM_HIP(hipEventElapsedTime(ms, c->ev_start, c->ev_stop));
+    return UKM_OK;
+}
+
+extern "C" int ukm_last_kernel_ms(ukm_ctx *c, float *ms) {
+    if (!c || !ms) UKM_FAIL(UKM_ERR_INVALID, "ukm_last_kernel_ms: NULL argument");
+    if (!c->evk_valid) return ukm_last_call_ms(c, ms);
+    UKM_HIP(hipEventSynchronize(c->ev_k1));
+    UKM_HIP(hipEventElapsedTime(ms, c->ev_k0, c->ev_k1));
     return UKM_OK;
 }
 

@@ -60,8 +60,10 @@ struct ukm_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
-    hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+    hipEvent_t ev_start = nullptr, ev_stop = nullptr;  // whole call
     bool ev_valid = false;
+    hipEvent_t ev_k0 = nullptr, ev_k1 = nullptr;  // dominant kernel of the call
+    bool evk_valid = false;
     int depth = 0;  // nesting depth of API calls (n-way ops call 2-way ops)
 
     std::vector<WsBlock> blocks;

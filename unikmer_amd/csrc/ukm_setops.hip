@@ -342,6 +342,7 @@ int run_setop_pass(ukm_ctx *c, int op, const u64 *a, const u32 *ta, const u32 *r
     else
         hipLaunchKernelGGL(setop_partition_kernel<false>, dim3(pblocks), dim3(256), 0, c->stream, p, (int)tile_items);
 
+    (void)hipEventRecord(c->ev_k0, c->stream);
     if (rank) {
         if (tax) launch_op<true, true, VT_TAX>(op, p, c->stream);
         else launch_op<false, true, VT_TAX>(op, p, c->stream);
@@ -349,6 +350,8 @@ int run_setop_pass(ukm_ctx *c, int op, const u64 *a, const u32 *ta, const u32 *r
         if (tax) launch_op<true, false, VT_TAX>(op, p, c->stream);
         else launch_op<false, false, VT_PLAIN>(op, p, c->stream);
     }
+    (void)hipEventRecord(c->ev_k1, c->stream);
+    c->evk_valid = true;
     UKM_HIP(hipGetLastError());
     UKM_TRY(ukm_read_u64(c, p.result, result_host, 2));
     return UKM_OK;

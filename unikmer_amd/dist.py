@@ -1,0 +1,101 @@
+"""Multi-GPU prefix sharding: one process per GPU, torch.distributed over
+RCCL ("nccl" backend on ROCm; "gloo" in the CPU tests).
+
+Codes are independent under every set operation, so the VALUE SPACE is partitioned by high
+bits: rank g owns [splitter[g], splitter[g+1]).  A sorted stream's share for each rank is a
+contiguous slice (cut points come from ukm_partition_points on the GPU), so redistribution is
+one all-to-all-v of contiguous slices.  After it every rank runs the single-GPU path on its
+range; the global result is the concatenation of the ranks' results in rank order.
+
+Nothing here computes on the CPU: cut points are an argument (the GPU library produces them),
+the exchange is pure torch.distributed plumbing.
+"""
+import torch
+import torch.distributed as dist
+
+
+def prefix_splitters(key_bits, world):
+    """world+1 boundaries of the code space [0, 2^key_bits): rank g owns
+    [s[g], s[g+1]).  key_bits = 2k for k-mer codes, 64 for hashes."""
+    top = 1 << key_bits
+    return [min((g * top) // world, (1 << 64) - 1) for g in range(world)] + [top if key_bits < 64 else (1 << 64) - 1]
+
+
+def cuts_to_counts(cuts, n):
+    """cut indices (lower bounds of splitters[0..world-1] in the sorted stream) -> slice sizes."""
+    c = [int(x) for x in cuts] + [int(n)]
+    return [c[i + 1] - c[i] for i in range(len(cuts))]
+
+
+def exchange_sorted(keys, counts, taxids=None, group=None):
+    """All-to-all-v of the contiguous slices of ONE sorted stream.
+
+    keys:   1-D int64 tensor (uint64 bit patterns), sorted, on this rank's device
+    counts: list[world] — number of records of `keys` that belong to each rank, in rank order
+    returns (recv_keys, recv_taxids, recv_counts): the received slices concatenated in source
+    rank order; each slice is sorted, and slices from different ranks cover the SAME value
+    range (this rank's), so they are inputs to one n-way merge/union on this rank.
+    """
+    world = dist.get_world_size(group)
+    assert len(counts) == world and sum(counts) == keys.numel()
+    send = torch.tensor(counts, dtype=torch.int64, device=keys.device)
+    recv = torch.empty(world, dtype=torch.int64, device=keys.device)
+    dist.all_to_all_single(recv, send, group=group)
+    recv_counts = [int(x) for x in recv.cpu()]
+    out = torch.empty(sum(recv_counts), dtype=keys.dtype, device=keys.device)
+    dist.all_to_all_single(out, keys, output_split_sizes=recv_counts, input_split_sizes=list(counts),
+                           group=group)
+    out_t = None
+    if taxids is not None:
+        out_t = torch.empty(sum(recv_counts), dtype=taxids.dtype, device=taxids.device)
+        dist.all_to_all_single(out_t, taxids, output_split_sizes=recv_counts,
+                               input_split_sizes=list(counts), group=group)
+    return out, out_t, recv_counts
+
+
+def split_by_counts(t, counts):
+    """views of the received buffer, one per source rank"""
+    out, off = [], 0
+    for c in counts:
+        out.append(t[off:off + c])
+        off += c
+    return out
+
+
+def sharded_setop(ctx, op, files_keys, key_bits, files_taxids=None, group=None, **kw):
+    """`union` / `inter` / `diff` / `common` over files that are FILE-sharded across ranks
+    (every rank holds whole sorted files spanning the full code range).
+
+    1. cut every local file at the prefix splitters (GPU lower_bound),
+    2. one all-to-all-v per file ships slice g to rank g,
+    3. each rank rebuilds its range of every file (slices are disjoint across source files,
+       so the received pieces of one logical file position are concatenated by rank order),
+    4. the single-GPU n-way op runs on the rank's range.
+    Returns this rank's part of the result; concatenating the parts in rank order gives the
+    globally sorted output, bit-identical to the 1-GPU result.
+
+    files_keys: list of 1-D int64 device tensors; every rank must pass the SAME number of
+    files (file i of every rank are the per-rank chunks of logical input i).
+    """
+    world = dist.get_world_size(group)
+    spl = prefix_splitters(key_bits, world)[:-1]
+    local = []
+    local_t = [] if files_taxids is not None else None
+    for i, k in enumerate(files_keys):
+        cuts = ctx.partition_points(k, spl)
+        counts = cuts_to_counts(cuts, k.numel())
+        t = files_taxids[i] if files_taxids is not None else None
+        rk, rt, rc = exchange_sorted(k, counts, t, group)
+        # pieces from different source ranks overlap in value -> merge them into one sorted set
+        pieces = split_by_counts(rk, rc)
+        tpieces = split_by_counts(rt, rc) if rt is not None else None
+        merged = ctx.union(pieces, tpieces)
+        if tpieces is not None:
+            local.append(merged[0])
+            local_t.append(merged[1])
+        else:
+            local.append(merged)
+    fn = {"union": ctx.union, "inter": ctx.inter, "diff": ctx.diff, "common": ctx.common}[op]
+    if op == "common":
+        return fn(local, kw["threshold"], local_t)
+    return fn(local, local_t)

@@ -23,7 +23,7 @@ F_MIX_TAXID, F_CMP_TAXID, F_ASSUME_SET = 2, 4, 8
 SYMBOLS = [
     "ukm_last_error", "ukm_version", "ukm_device_count", "ukm_ctx_create", "ukm_ctx_destroy",
     "ukm_ctx_set_stream", "ukm_ctx_sync", "ukm_ctx_reserve", "ukm_dev_alloc", "ukm_dev_free",
-    "ukm_copy", "ukm_last_kernel_ms", "ukm_taxonomy_load", "ukm_taxonomy_max_taxid", "ukm_lca",
+    "ukm_copy", "ukm_last_kernel_ms", "ukm_last_call_ms", "ukm_taxonomy_load", "ukm_taxonomy_max_taxid", "ukm_lca",
     "ukm_encode_kmers", "ukm_nthash", "ukm_max_hash", "ukm_sort_u64", "ukm_sort_pairs",
     "ukm_unique", "ukm_merge_k", "ukm_setop2", "ukm_union", "ukm_inter", "ukm_diff",
     "ukm_common", "ukm_common_threshold", "ukm_partition_points",
@@ -51,6 +51,26 @@ class CapacityError(UkmError):
 _lib = None
 
 
+def _preload_hip_runtime():
+    """One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64.so (SONAME
+    libamdhip64.so.7).  If ours were loaded from /opt/rocm first, a later `import torch` would
+    bring up a second runtime that sees no GPU.  Loading torch's copy first (without importing
+    torch) makes the dynamic loader bind libunikmer_hip.so to it by SONAME."""
+    import importlib.util
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        try:
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def load():
     """dlopen the HIP library; raises if it has not been built (python -m unikmer_amd.build)."""
     global _lib
@@ -59,6 +79,7 @@ def load():
     if not os.path.exists(SO_PATH):
         raise ImportError("libunikmer_hip.so is not built (%s); run `python -m unikmer_amd.build`. "
                           "There is no CPU fallback." % SO_PATH)
+    _preload_hip_runtime()
     L = C.CDLL(SO_PATH)
     vp, u64, u32, i32 = C.c_void_p, C.c_uint64, C.c_uint32, C.c_int
     pu64 = C.POINTER(C.c_uint64)
@@ -75,6 +96,7 @@ def load():
     L.ukm_dev_free.argtypes = [vp, vp]
     L.ukm_copy.argtypes = [vp, vp, vp, u64]
     L.ukm_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
+    L.ukm_last_call_ms.argtypes = [vp, C.POINTER(C.c_float)]
     L.ukm_taxonomy_load.argtypes = [vp, vp, vp, u64, vp, vp, u64]
     L.ukm_taxonomy_max_taxid.argtypes = [vp, C.POINTER(u32)]
     L.ukm_lca.argtypes = [vp, vp, vp, u64, vp]
@@ -174,6 +196,11 @@ class Context:
     def last_kernel_ms(self):
         ms = C.c_float()
         _check(self.L.ukm_last_kernel_ms(self.h, C.byref(ms)))
+        return ms.value
+
+    def last_call_ms(self):
+        ms = C.c_float()
+        _check(self.L.ukm_last_call_ms(self.h, C.byref(ms)))
         return ms.value
 
     # ---- taxonomy ----
