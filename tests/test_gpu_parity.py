@@ -404,3 +404,14 @@ def test_partition_points(ctx):
     A, _ = synth_sets(100_000, 22)
     sp = np.array([0, A[10], A[10] + np.uint64(1), A[-1], 2**63], dtype=np.uint64)
     assert np.array_equal(ctx.partition_points(A, sp), np.searchsorted(A, sp, side="left").astype(np.uint64))
+
+
+def test_ticketed_fallback_kernel(O, L, monkeypatch):
+    """The dispatch-order independent variant (used if the fast kernel's watchdog ever fires)."""
+    monkeypatch.setenv("UKM_FORCE_TICKET", "1")
+    c = L.Context(0)
+    A, B = synth_sets(700_000, 22)
+    assert np.array_equal(c.setop2(L.OP_UNION, A, B), O.union([A, B]))
+    assert np.array_equal(c.setop2(L.OP_INTER, A, B), O.inter([A, B]))
+    assert np.array_equal(c.setop2(L.OP_DIFF, A, B), O.diff([A, B]))
+    c.close()

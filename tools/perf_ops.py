@@ -1,0 +1,154 @@
+#!/usr/bin/env python
+"""Per-op device timings (hipEvent, via the C ABI) on device-resident synthetic data.
+Usage: python tools/perf_ops.py [--n 1e8] [--ops setop,sort,unique,encode,nthash,tax]"""
+import argparse
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--n", type=float, default=1e8)
+    ap.add_argument("--ops", default="setop,sort,unique,encode,nthash")
+    ap.add_argument("--reps", type=int, default=5)
+    args = ap.parse_args()
+    import torch
+    import bench
+    from unikmer_amd import lib
+    dev = torch.device("cuda", 0)
+    ctx = lib.Context(0, stream=torch.cuda.current_stream(dev).cuda_stream)
+    n = int(args.n)
+    ops = args.ops.split(",")
+    res = {}
+
+    def best(fn, reps=args.reps, kernel=False):
+        ts = []
+        for _ in range(reps):
+            fn()
+            ts.append(ctx.last_kernel_ms() if kernel else ctx.last_call_ms())
+        return min(ts), float(np.median(ts))
+
+    if "setop" in ops or "unique" in ops or "tax" in ops:
+        A, B = bench.gen_sets_device((4 * n + 2) // 3, 32 if n > 2e8 else 30, 0, bench.SEED, dev)
+        na, nb = A.numel(), B.numel()
+    if "setop" in ops:
+        out = torch.empty(na + nb, dtype=torch.int64, device=dev)
+        for name, op in (("union", lib.OP_UNION), ("inter", lib.OP_INTER), ("diff", lib.OP_DIFF)):
+            r = [0]
+
+            def f():
+                r[0] = ctx.setop2(op, A, B, out=out).numel()
+            f()
+            tk, _ = best(f, kernel=True)
+            tc, _ = best(f)
+            byt = 8 * (na + nb) + 8 * r[0]
+            res[name] = {"kernel_ms": tk, "call_ms": tc, "GBps_kernel": byt / tk / 1e6,
+                         "kmers_per_s": (na + nb) / tk * 1e3}
+    if "tax" in ops:
+        from conftest import synth_tree
+        child, parent = synth_tree(7, 8)
+        ctx.taxonomy_load(child, parent)
+        T = len(child)
+        ta = (1 + (bench.splitmix64_torch(A ^ 12345) & ((1 << 40) - 1)) % T).to(torch.int32)
+        tb = (1 + (bench.splitmix64_torch(B ^ 54321) & ((1 << 40) - 1)) % T).to(torch.int32)
+        out = torch.empty(na + nb, dtype=torch.int64, device=dev)
+        outt = torch.empty(na + nb, dtype=torch.int32, device=dev)
+        for name, op in (("union_tax", lib.OP_UNION), ("inter_tax", lib.OP_INTER)):
+            r = [0]
+
+            def f():
+                r[0] = ctx.setop2(op, A, B, ta, tb, out=out, out_taxids=outt)[0].numel()
+            f()
+            tk, _ = best(f, kernel=True)
+            byt = 12 * (na + nb) + 12 * r[0]
+            res[name] = {"kernel_ms": tk, "GBps_kernel": byt / tk / 1e6, "kmers_per_s": (na + nb) / tk * 1e3}
+    if "unique" in ops:
+        cat = torch.cat([A, B])
+        ctx.sort_u64(cat, 62)
+        out = torch.empty(cat.numel(), dtype=torch.int64, device=dev)
+        r = [0]
+
+        def f():
+            r[0] = ctx.unique(cat, out=out).numel()
+        f()
+        t, _ = best(f)
+        res["unique"] = {"call_ms": t, "GBps": (8 * cat.numel() + 8 * r[0]) / t / 1e6, "n": cat.numel()}
+        del cat
+    if "sort" in ops:
+        g = torch.Generator(device=dev)
+        g.manual_seed(1)
+        keys = torch.randint(0, 1 << 62, (n,), dtype=torch.int64, device=dev, generator=g)
+        work = torch.empty_like(keys)
+
+        def f():
+            work.copy_(keys)
+            torch.cuda.synchronize()
+            ctx.sort_u64(work, 62)
+        f()
+        t, med = best(f)
+        assert bool((work[1:] >= work[:-1]).all())
+        res["sort_u64_62bit"] = {"call_ms": t, "median_ms": med, "keys_per_s": n / t * 1e3,
+                                 "GBps_algorithmic(8n+8*16n)": (8 * n + 8 * 16 * n) / t / 1e6}
+        vals = torch.arange(n, dtype=torch.int32, device=dev)
+        wv = torch.empty_like(vals)
+
+        def f2():
+            work.copy_(keys)
+            wv.copy_(vals)
+            torch.cuda.synchronize()
+            ctx.sort_pairs(work, wv, 62)
+        f2()
+        t, med = best(f2)
+        res["sort_pairs_62bit"] = {"call_ms": t, "keys_per_s": n / t * 1e3}
+        del keys, work, vals, wv
+    if "encode" in ops or "nthash" in ops:
+        nb_ = n
+        i = torch.arange(nb_, dtype=torch.int64, device=dev)
+        w = bench.splitmix64_torch((i >> 5) ^ bench._i64(bench.SEED))
+        code = (w >> (2 * (i & 31))) & 3
+        lut = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=dev)
+        bases = lut[code]
+        del i, w, code
+        nrec = 100
+        off = torch.tensor([nb_ * r // nrec for r in range(nrec + 1)], dtype=torch.int64, device=dev)
+        out = torch.empty(nb_, dtype=torch.int64, device=dev)
+        if "encode" in ops:
+            def f():
+                ctx.encode_kmers(bases, off, 31, out=out)
+            f()
+            t, _ = best(f)
+            res["encode_k31"] = {"call_ms": t, "bases_per_s": nb_ / t * 1e3, "GBps": 9 * nb_ / t / 1e6}
+        if "nthash" in ops:
+            def f():
+                ctx.nthash(bases, off, 51, out=out)
+            f()
+            t, _ = best(f)
+            res["nthash_k51"] = {"call_ms": t, "bases_per_s": nb_ / t * 1e3}
+            mh = ctx.max_hash(1000)
+
+            def f():
+                ctx.nthash(bases, off, 51, max_hash=mh, out=out)
+            f()
+            t, _ = best(f)
+            res["nthash_k51_scaled1000"] = {"call_ms": t, "bases_per_s": nb_ / t * 1e3}
+            reads = torch.arange(0, nb_ + 1, 150, dtype=torch.int64, device=dev)
+            if reads[-1].item() != nb_:
+                reads = torch.cat([reads, torch.tensor([nb_], dtype=torch.int64, device=dev)])
+
+            def f():
+                ctx.nthash(bases, reads, 51, max_hash=mh, out=out)
+            f()
+            t, _ = best(f)
+            res["nthash_k51_scaled1000_reads150"] = {"call_ms": t, "bases_per_s": nb_ / t * 1e3}
+    print(json.dumps(res, indent=1))
+
+
+if __name__ == "__main__":
+    main()

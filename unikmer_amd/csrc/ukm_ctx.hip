@@ -59,6 +59,9 @@ extern "C" int ukm_ctx_create(int device, ukm_ctx **out) {
         UKM_FAIL(UKM_ERR_HIP, "ukm_ctx_create: stream/event/pinned allocation failed");
     }
     c->own_stream = true;
+    // developer/test knob: exercise the ticketed (dispatch-order independent) set-op kernel
+    const char *ft = getenv("UKM_FORCE_TICKET");
+    c->setop_force_ticket = ft && ft[0] == '1';
     *out = c;
     return UKM_OK;
 }

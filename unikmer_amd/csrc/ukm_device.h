@@ -51,9 +51,33 @@ __device__ __forceinline__ u32 block_excl_scan_u32(u32 v, u32 *smem, u32 *total)
 // Words are written/read with relaxed agent-scope atomics (one aligned 8-byte granule carries
 // flag and data together, so no fence is needed; MI355X per-XCD L2s are not coherent, agent
 // scope makes the accesses bypass them).  The status array must be zeroed before the launch.
+//
+// What the measurements on MI355X said (profiles/r01_notes.md):
+//  * each tile's word sits in its OWN 64-byte line (LB_STRIDE = 8 words): several hundred
+//    successor tiles poll a predecessor's word with uncached loads, and words sharing a line
+//    serialised on it (look-back 6.9 us -> 4.0 us per tile when padded);
+//  * the window is 64 tiles per hop (LB_W = 1): wider windows only multiplied the uncached
+//    traffic and were slower;
+//  * predecessors publish roughly in tile order, so the NEAREST one is the last to become
+//    visible: one lane polls that single word (with a real s_sleep) and the 64-wide read is
+//    issued only once it is there.
+#ifndef LB_STRIDE
+#define LB_STRIDE 8
+#endif
+#ifndef LB_W
+#define LB_W 1
+#endif
+#ifndef LB_POLL_SLEEP
+#define LB_POLL_SLEEP 8
+#endif
+#ifndef LB_SPIN_LIMIT
+#define LB_SPIN_LIMIT (1u << 20)  /* polls before a waiter gives up (~1 s): watchdog only */
+#endif
 #define LB_AGG (1ull << 62)
 #define LB_INCL (2ull << 62)
 #define LB_VAL ((1ull << 62) - 1)
+
+static inline size_t lb_status_words(u64 ntiles) { return (size_t)ntiles * LB_STRIDE; }
 
 __device__ __forceinline__ void lb_store(u64 *p, u64 v) {
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -62,38 +86,89 @@ __device__ __forceinline__ u64 lb_load(const u64 *p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// Called by ONE full wave of the block (all 64 lanes).  Publishes this tile's aggregate, walks
-// predecessors 64 at a time, publishes the inclusive prefix, returns the exclusive prefix
-// (same value in every lane).  Forward progress: tile ids are handed out by an atomic ticket,
-// so every predecessor tile is already running.
-__device__ __forceinline__ u64 lb_lookback(u64 *status, u64 tile, u64 agg) {
-    const int lane = lane_id();
-    if (tile == 0) {
-        if (lane == 0) lb_store(&status[0], LB_INCL | agg);
-        return 0;
+struct LbHop {
+    u64 w[LB_W];
+};
+
+// announce a tile's aggregate (tile 0 announces an inclusive value straight away)
+__device__ __forceinline__ void lb_publish(u64 *status, u64 tile, u64 agg) {
+    lb_store(&status[tile * LB_STRIDE], (tile == 0 ? LB_INCL : LB_AGG) | agg);
+}
+
+__device__ __forceinline__ void lb_hop_issue(const u64 *status, long long base, int lane, LbHop &h) {
+#pragma unroll
+    for (int q = 0; q < LB_W; q++) {
+        const long long idx = base - q * 64 - lane;
+        h.w[q] = (idx >= 0) ? lb_load(&status[idx * LB_STRIDE]) : LB_INCL;
     }
-    if (lane == 0) lb_store(&status[tile], LB_AGG | agg);
+}
+
+// returns 1 = found an inclusive value (done), 0 = window complete but no inclusive value yet
+// (continue with the next window), -(q+1) = sub-window q has an unpublished predecessor.
+__device__ __forceinline__ int lb_hop_eval(const LbHop &h, int lane, u64 &excl) {
+    bool done = false;
+    int retry_from = -1;
+    u64 add = 0;
+#pragma unroll
+    for (int q = 0; q < LB_W; q++) {
+        if (!done && retry_from < 0) {
+            const u64 st = h.w[q] >> 62;
+            const u64 incl_mask = __ballot(st == 2);
+            const u64 empty_mask = __ballot(st == 0);
+            const int first_incl = incl_mask ? __builtin_ctzll(incl_mask) : 64;
+            const u64 need = (first_incl >= 63) ? ~0ull : ((2ull << first_incl) - 1);
+            if (empty_mask & need) {
+                retry_from = q;
+            } else {
+                add += (lane <= first_incl) ? (h.w[q] & LB_VAL) : 0;
+                if (first_incl < 64) done = true;
+            }
+        }
+    }
+    excl += wave_reduce_sum_u64(add);
+    if (done) return 1;
+    if (retry_from >= 0) return -(retry_from + 1);
+    return 0;
+}
+
+// One full wave calls this after lb_publish.  Returns the exclusive prefix of `tile` (same in
+// every lane) and publishes the inclusive one.  *timed_out is set if a predecessor did not
+// publish within LB_SPIN_LIMIT polls: only possible when tile ids come from blockIdx and the
+// hardware did not dispatch workgroups in order; the caller reports it and the host re-runs
+// the ticketed variant (tile ids from an atomic counter guarantee forward progress).
+__device__ __forceinline__ u64 lb_resolve(u64 *status, u64 tile, u64 agg, int lane, bool *timed_out) {
+    if (tile == 0) return 0;  // lb_publish already stored the inclusive value
     u64 excl = 0;
     long long base = (long long)tile - 1;
+    u32 spins = 0;
+    bool dead = false;
+    LbHop hop;
     for (;;) {
-        long long idx = base - lane;
-        u64 w = (idx >= 0) ? lb_load(&status[idx]) : LB_INCL;
-        u64 st = w >> 62;
-        u64 incl_mask = __ballot(st == 2);
-        u64 empty_mask = __ballot(st == 0);
-        int first_incl = incl_mask ? __builtin_ctzll(incl_mask) : 64;
-        u64 need = (first_incl >= 63) ? ~0ull : ((2ull << first_incl) - 1);
-        if (empty_mask & need) {
-            __builtin_amdgcn_s_sleep(2);
-            continue;
+        // wait for the nearest not-yet-counted predecessor with a single-word poll
+        int ok = 1;
+        if (lane == 0) {
+            while ((lb_load(&status[base * LB_STRIDE]) >> 62) == 0) {
+                if (++spins > LB_SPIN_LIMIT) { ok = 0; break; }
+                __builtin_amdgcn_s_sleep(LB_POLL_SLEEP);
+            }
         }
-        u64 v = (lane <= first_incl) ? (w & LB_VAL) : 0;
-        excl += wave_reduce_sum_u64(v);
-        if (first_incl < 64) break;
-        base -= 64;
+        if (!__shfl(ok, 0, 64)) { dead = true; break; }
+        lb_hop_issue(status, base, lane, hop);
+        const int r = lb_hop_eval(hop, lane, excl);
+        if (r == 1) break;
+        if (r == 0) base -= 64 * LB_W;
+        else base -= 64 * (-r - 1);
     }
-    if (lane == 0) lb_store(&status[tile], LB_INCL | (excl + agg));
+    if (dead && timed_out) *timed_out = true;
+    // publish even after a timeout so that successors drain quickly
+    if (lane == 0) lb_store(&status[tile * LB_STRIDE], LB_INCL | (excl + agg));
     return excl;
+}
+
+// publish + resolve in one call (kernels that do nothing in between)
+__device__ __forceinline__ u64 lb_lookback(u64 *status, u64 tile, u64 agg) {
+    if (lane_id() == 0) lb_publish(status, tile, agg);
+    return lb_resolve(status, tile, agg, lane_id(), nullptr);
 }
 
 // ---- device LCA (contract: include/unikmer_hip.h, ukm_taxonomy_load) ---------------------------

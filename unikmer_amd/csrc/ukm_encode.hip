@@ -263,8 +263,9 @@ int run_windows(ukm_ctx *c, bool hash, const u8 *bases, const u64 *rec_off, u64 
                        rec_off, n_rec, k, circular, cnt);
     const u64 ntiles = (total_bases + TB - 1) / TB;
     const bool filter = hash && max_hash != 0;
-    UKM_TRY(ws_alloc_t(c, 4 + (filter ? ntiles : 0), &ctl));
-    UKM_HIP(hipMemsetAsync(ctl, 0, (4 + (filter ? ntiles : 0)) * sizeof(u64), c->stream));
+    const size_t nctl = 8 + (filter ? lb_status_words(ntiles) : 0);
+    UKM_TRY(ws_alloc_t(c, nctl, &ctl));
+    UKM_HIP(hipMemsetAsync(ctl, 0, nctl * sizeof(u64), c->stream));
     UKM_TRY(ukm_dev_exclusive_scan_u64(c, cnt, off, n_rec, ctl + 3));
     u64 total_windows = 0;
     UKM_TRY(ukm_read_u64(c, ctl + 3, &total_windows));
@@ -279,7 +280,7 @@ int run_windows(ukm_ctx *c, bool hash, const u8 *bases, const u64 *rec_off, u64 
     p.bases = bases; p.rec_off = rec_off; p.out_off = off; p.n_rec = n_rec;
     p.total_bases = total_bases; p.k = k; p.canonical = canonical; p.circular = circular;
     p.max_hash = max_hash; p.out = out; p.out_cap = out_cap;
-    p.result = ctl; p.ticket = (u32 *)(ctl + 2); p.status = ctl + 4; p.ntiles = ntiles;
+    p.result = ctl; p.ticket = (u32 *)(ctl + 2); p.status = ctl + 8; p.ntiles = ntiles;
     if (!hash) hipLaunchKernelGGL((window_kernel<false, false>), dim3((unsigned)ntiles), dim3(NT), 0, c->stream, p);
     else if (!filter) hipLaunchKernelGGL((window_kernel<true, false>), dim3((unsigned)ntiles), dim3(NT), 0, c->stream, p);
     else hipLaunchKernelGGL((window_kernel<true, true>), dim3((unsigned)ntiles), dim3(NT), 0, c->stream, p);

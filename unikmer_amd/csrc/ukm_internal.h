@@ -88,6 +88,9 @@ struct ukm_ctx {
     u64 *h_scratch = nullptr;  // 64 x u64
 
     int num_cu = 256;
+
+    // set once the blockIdx-ordered set-op kernel hit its watchdog on this device
+    bool setop_force_ticket = false;
 };
 
 // Arena API.  Pointers stay valid until the enclosing top-level call returns.

@@ -219,10 +219,11 @@ int ukm_dev_exclusive_scan_u64(ukm_ctx *c, const u64 *in, u64 *out, u64 n, u64 *
     }
     const u64 ntiles = (n + NT * SCAN_VT - 1) / (NT * SCAN_VT);
     u64 *ctl = nullptr;
-    UKM_TRY(ws_alloc_t(c, 1 + ntiles, &ctl));
-    UKM_HIP(hipMemsetAsync(ctl, 0, (1 + ntiles) * sizeof(u64), c->stream));
+    const size_t nctl = 8 + lb_status_words(ntiles);
+    UKM_TRY(ws_alloc_t(c, nctl, &ctl));
+    UKM_HIP(hipMemsetAsync(ctl, 0, nctl * sizeof(u64), c->stream));
     hipLaunchKernelGGL(excl_scan_u64_kernel, dim3((unsigned)ntiles), dim3(NT), 0, c->stream, in, out, n,
-                       ctl + 1, (u32 *)ctl, total_dev, ntiles);
+                       ctl + 8, (u32 *)ctl, total_dev, ntiles);
     UKM_HIP(hipGetLastError());
     return UKM_OK;
 }
@@ -258,11 +259,12 @@ int ukm_dev_unique_ex(ukm_ctx *c, const u64 *keys, const u32 *taxids, u64 n, int
     p.mode = mode;
     p.threshold = threshold;
     u64 *ctl = nullptr;
-    UKM_TRY(ws_alloc_t(c, 3 + p.ntiles, &ctl));
-    UKM_HIP(hipMemsetAsync(ctl, 0, (3 + p.ntiles) * sizeof(u64), c->stream));
+    const size_t nctl = 8 + lb_status_words(p.ntiles);
+    UKM_TRY(ws_alloc_t(c, nctl, &ctl));
+    UKM_HIP(hipMemsetAsync(ctl, 0, nctl * sizeof(u64), c->stream));
     p.result = ctl;
     p.ticket = (u32 *)(ctl + 2);
-    p.status = ctl + 3;
+    p.status = ctl + 8;
     if (tax) hipLaunchKernelGGL(unique_tile_kernel<true>, dim3((unsigned)p.ntiles), dim3(NT), 0, c->stream, p);
     else hipLaunchKernelGGL(unique_tile_kernel<false>, dim3((unsigned)p.ntiles), dim3(NT), 0, c->stream, p);
     UKM_HIP(hipGetLastError());

@@ -24,9 +24,15 @@
 
 namespace {
 
-constexpr int NT = 256;
+enum { FLAG_DUP = 1, FLAG_UNSORTED = 2, FLAG_TIMEOUT = 4 };
 
-enum { FLAG_DUP = 1, FLAG_UNSORTED = 2 };
+#ifndef SETOP_NT
+#define SETOP_NT 512
+#endif
+#ifndef SETOP_VT
+#define SETOP_VT 16
+#endif
+
 
 struct SetopArgs {
     const u64 *a, *b;
@@ -43,7 +49,14 @@ struct SetopArgs {
     u64 ntiles;
     TaxDev tax;
     u32 flags;
+    u64 *dbg;  // UKM_PROFILE_PHASES only
 };
+
+#ifdef UKM_PROFILE_PHASES
+#define PH(i) do { if (tid == 0) { u64 _t = clock64(); ph[i] += _t - tlast; tlast = _t; } } while (0)
+#else
+#define PH(i) do {} while (0)
+#endif
 
 template <bool RANK>
 __device__ __forceinline__ bool key_le(u64 ka, u32 ra, u64 kb, u32 rb) {
@@ -74,194 +87,310 @@ __global__ void setop_partition_kernel(SetopArgs p, int tile_items) {
     p.mp[t] = lo;
 }
 
-template <int OP, bool TAX, bool RANK, int VT>
-__global__ __launch_bounds__(NT) void setop_tile_kernel(SetopArgs p) {
-    constexpr int TILE = NT * VT;
-    constexpr int SLOTS = TILE + 4;
-    constexpr int LD = VT + 1;  // loads per thread to cover SLOTS
-    __shared__ u64 s_keys[SLOTS];
-    __shared__ u32 s_tax[TAX ? SLOTS : 1];
-    __shared__ u32 s_rank[RANK ? SLOTS : 1];
-    __shared__ u32 s_scan[NT / 64 + 1];
-    __shared__ u64 s_misc[2];
+// ---- tile building blocks (shared by the kernels below) -------------------------------------------
+// Everything here is written branch-free on purpose: the first version of the merge step
+// compiled to ~80 instructions (exec-mask juggling, phi copies, 64-bit selects) and the kernel
+// was VALU/SALU-issue bound at 31 % of HBM peak.
+struct TileGeom {
+    u64 a0, b0;
+    int na_t, nb_t;
+    bool has_prev_a, has_prev_b, has_next_a, has_next_b;
+};
 
-    const int tid = (int)threadIdx.x;
-    if (tid == 0) s_misc[0] = (u64)atomicAdd(p.ticket, 1u);
-    __syncthreads();
-    const u64 tile = s_misc[0];
-
+template <int NTH, int VT>
+__device__ __forceinline__ TileGeom tile_geom(const SetopArgs &p, u64 tile) {
+    constexpr int TILE = NTH * VT;
     const u64 N = p.na + p.nb;
     const u64 d0 = tile * (u64)TILE;
     const u64 d1 = (d0 + TILE < N) ? d0 + TILE : N;
     const u64 a0 = p.mp[tile], a1 = p.mp[tile + 1];
     const u64 b0 = d0 - a0, b1 = d1 - a1;
-    const int na_t = (int)(a1 - a0), nb_t = (int)(b1 - b0);
-    const int total = na_t + nb_t;
-    const bool has_prev_a = a0 > 0, has_prev_b = b0 > 0, has_next_b = b1 < p.nb;
-    // LDS slots: [0] prevA | A items [1, 1+na_t) | nextA | prevB | B items | nextB
-    const int base_a = 1, end_a = 1 + na_t;
-    const int base_b = na_t + 3, end_b = base_b + nb_t;
+    TileGeom g;
+    g.a0 = a0; g.b0 = b0;
+    g.na_t = (int)(a1 - a0); g.nb_t = (int)(b1 - b0);
+    g.has_prev_a = a0 > 0; g.has_prev_b = b0 > 0;
+    g.has_next_a = a1 < p.na; g.has_next_b = b1 < p.nb;
+    return g;
+}
 
-    {
-        u64 rk[LD];
-        u32 rt[LD];
-        u32 rr[LD];
+// LDS slots: [0] prevA | A items [1, 1+na_t) | nextA | prevB | B items | nextB
+// Missing halos are filled with 0 (prev) / ~0 (next) so that the order check cannot fire on them.
+// Coalesced global loads of the tile (+halos) into registers; nothing is waited for here.
+template <bool TAX, bool RANK, int NTH, int VT>
+__device__ __forceinline__ void tile_load(const SetopArgs &p, const TileGeom &g, int tid, u64 (&rk)[VT + 1],
+                                          u32 (&rt)[VT + 1], u32 (&rr)[VT + 1]) {
+    const int split = g.na_t + 2;  // first slot of the B region (prevB halo)
+    const int alo = g.has_prev_a ? 0 : 1;
+    const int ahi = g.na_t + 1 + (g.has_next_a ? 1 : 0);
+    const int blo = split + (g.has_prev_b ? 0 : 1);
+    const int bhi = split + g.nb_t + 1 + (g.has_next_b ? 1 : 0);
+    // slot i of region A is a[a0 - 1 + i]; slot i of region B is b[b0 - 1 + i - split]
+    const u64 *pa = p.a + g.a0 - 1;
+    const u64 *pb = p.b + g.b0 - 1 - split;
+    const u32 *pta = TAX && p.ta ? p.ta + g.a0 - 1 : nullptr;
+    const u32 *ptb = TAX && p.tb ? p.tb + g.b0 - 1 - split : nullptr;
+    const u32 *pra = RANK ? p.ra + g.a0 - 1 : nullptr;
+    const u32 *prb = RANK ? p.rb + g.b0 - 1 - split : nullptr;
 #pragma unroll
-        for (int j = 0; j < LD; j++) {
-            int i = tid + j * NT;
-            u64 v = 0;
-            u32 tv = 0, rv = 0;
-            if (i < total + 4) {
-                if (i < base_b - 1) {  // A region incl. both halos
-                    long long g = (long long)a0 + (i - base_a);
-                    if (g >= 0 && (u64)g < p.na) {
-                        v = p.a[g];
-                        if (TAX && p.ta) tv = p.ta[g];
-                        if (RANK) rv = p.ra[g];
-                    }
-                } else {
-                    long long g = (long long)b0 + (i - base_b);
-                    if (g >= 0 && (u64)g < p.nb) {
-                        v = p.b[g];
-                        if (TAX && p.tb) tv = p.tb[g];
-                        if (RANK) rv = p.rb[g];
-                    }
-                }
+    for (int j = 0; j < VT + 1; j++) {
+        const int i = tid + j * NTH;
+        const bool in_a = i < split;
+        const int lo = in_a ? alo : blo, hi = in_a ? ahi : bhi;
+        const bool valid = i >= lo && i < hi;
+        const u64 *src = in_a ? pa : pb;
+        u64 v = (i >= hi) ? ~0ull : 0ull;
+        u32 tv = 0, rv = 0;
+        if (valid) {
+            v = src[i];
+            if (TAX) {
+                const u32 *ts = in_a ? pta : ptb;
+                if (ts) tv = ts[i];
             }
-            rk[j] = v;
-            rt[j] = tv;
-            rr[j] = rv;
+            if (RANK) rv = (in_a ? pra : prb)[i];
         }
+        rk[j] = v;
+        rt[j] = tv;
+        rr[j] = rv;
+    }
+}
+
+template <bool TAX, bool RANK, int NTH, int VT>
+__device__ __forceinline__ void tile_to_lds(int tid, const u64 (&rk)[VT + 1], const u32 (&rt)[VT + 1],
+                                            const u32 (&rr)[VT + 1], u64 *s_keys, u32 *s_tax, u32 *s_rank) {
+    constexpr int SLOTS = NTH * VT + 4;
 #pragma unroll
-        for (int j = 0; j < LD; j++) {
-            int i = tid + j * NT;
-            if (i < SLOTS) {
-                s_keys[i] = rk[j];
-                if (TAX) s_tax[i] = rt[j];
-                if (RANK) s_rank[i] = rr[j];
+    for (int j = 0; j < VT + 1; j++) {
+        const int i = tid + j * NTH;
+        if (i < SLOTS) {
+            s_keys[i] = rk[j];
+            if (TAX) s_tax[i] = rt[j];
+            if (RANK) s_rank[i] = rr[j];
+        }
+    }
+}
+
+// Strict-order check of both inputs as one vector pass over the LDS tile (call after the
+// barrier that follows tile_to_lds): slot i against slot i-1, skipping the seam between the
+// two regions and the missing-halo slots.  Replaces two 64-bit compares per merge step.
+template <bool RANK, int NTH, int VT>
+__device__ __forceinline__ u32 tile_check_order(const TileGeom &g, int tid, const u64 (&rk)[VT + 1],
+                                                const u32 (&rr)[VT + 1], const u64 *s_keys, const u32 *s_rank) {
+    const int split = g.na_t + 2;
+    const int total4 = g.na_t + g.nb_t + 4;
+    const int skip_a = g.has_prev_a ? -1 : 1;          // slot 1 has no real predecessor
+    const int skip_b = g.has_prev_b ? -1 : split + 1;  // first B item has no real predecessor
+    u32 bad = 0;
+#pragma unroll
+    for (int j = 0; j < VT + 1; j++) {
+        const int i = tid + j * NTH;
+        if (i >= 1 && i < total4 && i != split && i != skip_a && i != skip_b) {
+            const u64 pk = s_keys[i - 1], ck = rk[j];
+            if (RANK) {
+                const u32 pr = s_rank[i - 1], cr = rr[j];
+                if (pk > ck || (pk == ck && pr >= cr && ck != ~0ull)) bad |= FLAG_UNSORTED;
+            } else {
+                if (pk > ck) bad |= FLAG_UNSORTED;
+                else if (pk == ck && ck != ~0ull) bad |= FLAG_DUP;
             }
         }
     }
-    __syncthreads();
+    return bad;
+}
 
-    // per-thread merge-path search inside the tile
+// Per-thread merge-path search inside the LDS tile, then a VT-step serial merge that decides
+// emit/skip for each merged item.  Outputs stay in registers (ok/ot + bit mask).
+// Sets are strictly increasing, so an equal (A[i], B[j]) pair is adjacent in merge order (A
+// first): when A is taken and equals the pending B, that B is the next merged item.
+template <int OP, bool TAX, bool RANK, int VT>
+__device__ __forceinline__ void tile_merge(const SetopArgs &p, const TileGeom &g, int tid, const u64 *s_keys,
+                                           const u32 *s_tax, const u32 *s_rank, u64 (&ok)[VT], u32 (&ot)[VT],
+                                           u32 &mask) {
+    const int na_t = g.na_t, nb_t = g.nb_t, total = na_t + nb_t;
+    const int base_a = 1, end_a = 1 + na_t;
+    const int base_b = na_t + 3, end_b = base_b + nb_t;
+    const int end_bx = end_b + (g.has_next_b ? 1 : 0);
     int diag = tid * VT;
     if (diag > total) diag = total;
     int lo = diag > nb_t ? diag - nb_t : 0;
     int hi = diag < na_t ? diag : na_t;
     while (lo < hi) {
-        int mid = (lo + hi) >> 1;
-        int ia = base_a + mid, ib = base_b + diag - 1 - mid;
-        bool le = key_le<RANK>(s_keys[ia], RANK ? s_rank[ia] : 0, s_keys[ib], RANK ? s_rank[ib] : 0);
-        if (le) lo = mid + 1; else hi = mid;
+        const int mid = (lo + hi) >> 1;
+        const int ia = base_a + mid, ib = base_b + diag - 1 - mid;
+        const bool le = key_le<RANK>(s_keys[ia], RANK ? s_rank[ia] : 0, s_keys[ib], RANK ? s_rank[ib] : 0);
+        lo = le ? mid + 1 : lo;
+        hi = le ? hi : mid;
     }
     int pa = base_a + lo, pb = base_b + diag - lo;
-
     u64 ak = s_keys[pa], bk = s_keys[pb];
-    u64 ap = s_keys[pa - 1], bp = s_keys[pb - 1];
-    u32 ar = 0, br = 0, apr = 0, bpr = 0;
-    if (RANK) { ar = s_rank[pa]; br = s_rank[pb]; apr = s_rank[pa - 1]; bpr = s_rank[pb - 1]; }
-    bool apv = (pa > base_a) || has_prev_a;
-    bool bpv = (pb > base_b) || has_prev_b;
-
-    u64 ok[VT];
-    u32 ot[VT];
-    u32 mask = 0, bad = 0;
+    u32 ar = 0, br = 0;
+    if (RANK) { ar = s_rank[pa]; br = s_rank[pb]; }
+    bool eq_prev = false;  // union: the pending B equals the A that precedes it in merge order
+    if (OP == UKM_OP_UNION) {
+        const bool pv = (pa > base_a) || g.has_prev_a;
+        eq_prev = pv && (pb < end_b) && key_eq<RANK>(s_keys[pa - 1], RANK ? s_rank[pa - 1] : 0, bk, br);
+    }
     const bool mix = (p.flags & UKM_F_MIX_TAXID) != 0;
     const bool cmp = (p.flags & UKM_F_CMP_TAXID) != 0;
+    mask = 0;
 
 #pragma unroll
     for (int s = 0; s < VT; s++) {
         const bool a_ok = pa < end_a, b_ok = pb < end_b;
-        const bool active = a_ok || b_ok;
         const bool take_a = a_ok && (!b_ok || key_le<RANK>(ak, ar, bk, br));
-        bool emit = false;
-        u64 ek = 0;
+        const bool take_b = !take_a && b_ok;
+        const bool match = take_a && (pb < end_bx) && key_eq<RANK>(ak, ar, bk, br);
+        bool emit;
+        u64 ek = ak;
         u32 et = 0;
-        if (active) {
-            if (take_a) {
-                if (apv) {  // strict order check of input A
-                    bool lt = RANK ? (ap < ak || (ap == ak && apr < ar)) : (ap < ak);
-                    if (!lt) bad |= (!RANK && ap == ak) ? FLAG_DUP : FLAG_UNSORTED;
+        if (OP == UKM_OP_UNION) {
+            emit = take_a || (take_b && !eq_prev);
+            ek = take_a ? ak : bk;
+            eq_prev = match;
+        } else if (OP == UKM_OP_INTER) {
+            emit = match;
+        } else {
+            emit = take_a && !match;
+        }
+        if (TAX) {
+            const u32 ta = s_tax[pa], tb = s_tax[pb];
+            if (OP == UKM_OP_UNION) {
+                et = take_a ? ta : tb;
+                if (match) et = lca_dev(p.tax, ta, tb);
+            } else if (OP == UKM_OP_INTER) {
+                if (match) {
+                    if (mix) et = (ta == 0) ? tb : ((tb == 0) ? ta : lca_dev(p.tax, ta, tb));
+                    else et = lca_dev(p.tax, ta, tb);
                 }
-                const bool matched = (pb < end_b + (has_next_b ? 1 : 0)) && key_eq<RANK>(ak, ar, bk, br);
-                ek = ak;
-                u32 ta = 0, tb = 0;
-                if (TAX) { ta = s_tax[pa]; tb = s_tax[pb]; }
-                if (OP == UKM_OP_UNION) {
-                    emit = true;
-                    if (TAX) et = matched ? lca_dev(p.tax, ta, tb) : ta;
-                } else if (OP == UKM_OP_INTER) {
-                    emit = matched;
-                    if (TAX && matched) {
-                        if (mix) et = (ta == 0) ? tb : ((tb == 0) ? ta : lca_dev(p.tax, ta, tb));
-                        else et = lca_dev(p.tax, ta, tb);
-                    }
-                } else {
-                    emit = !matched;
-                    if (TAX) {
-                        et = ta;
-                        if (matched && cmp && (ta == tb || lca_dev(p.tax, tb, ta) == ta)) emit = true;
-                    }
-                }
-                ap = ak; apr = ar; apv = true;
-                pa++;
             } else {
-                if (bpv) {
-                    bool lt = RANK ? (bp < bk || (bp == bk && bpr < br)) : (bp < bk);
-                    if (!lt) bad |= (!RANK && bp == bk) ? FLAG_DUP : FLAG_UNSORTED;
-                }
-                if (OP == UKM_OP_UNION) {
-                    const bool matched_prev = apv && key_eq<RANK>(ap, apr, bk, br);
-                    emit = !matched_prev;
-                    ek = bk;
-                    if (TAX) et = s_tax[pb];
-                }
-                bp = bk; bpr = br; bpv = true;
-                pb++;
+                et = ta;
+                if (match && cmp && (ta == tb || lca_dev(p.tax, tb, ta) == ta)) emit = true;
             }
-            // one LDS read refills whichever cursor moved
-            const int idx = take_a ? pa : pb;
-            const u64 nk = s_keys[idx];
-            const u32 nr = RANK ? s_rank[idx] : 0;
-            if (take_a) { ak = nk; ar = nr; } else { bk = nk; br = nr; }
         }
         ok[s] = ek;
         ot[s] = et;
-        if (emit) mask |= (1u << s);
+        mask |= emit ? (1u << s) : 0u;
+        pa += take_a ? 1 : 0;
+        pb += take_b ? 1 : 0;
+        // one LDS read refills whichever cursor moved (when neither moved it re-reads bk)
+        const int idx = take_a ? pa : pb;
+        const u64 nk = s_keys[idx];
+        ak = take_a ? nk : ak;
+        bk = take_a ? bk : nk;
+        if (RANK) {
+            const u32 nr = s_rank[idx];
+            ar = take_a ? nr : ar;
+            br = take_a ? br : nr;
+        }
     }
+}
 
-    const u32 cnt = (u32)__popc(mask);
-    u32 tile_total;
-    const u32 excl = block_excl_scan_u32<NT>(cnt, s_scan, &tile_total);
-    // (the scan's barriers also guarantee every thread finished reading the tile from LDS)
-
-    {
-        u32 w = excl;
+// compact the emitted items of this thread into LDS at its exclusive offset
+template <bool TAX, int VT>
+__device__ __forceinline__ void tile_compact(u32 excl, u32 mask, const u64 (&ok)[VT], const u32 (&ot)[VT],
+                                             u64 *s_keys, u32 *s_tax) {
 #pragma unroll
-        for (int s = 0; s < VT; s++) {
-            if (mask & (1u << s)) {
-                s_keys[w] = ok[s];
-                if (TAX) s_tax[w] = ot[s];
-                w++;
+    for (int s = 0; s < VT; s++) {
+        if (mask & (1u << s)) {
+            const u32 w = excl + (u32)__popc(mask & ((1u << s) - 1u));
+            s_keys[w] = ok[s];
+            if (TAX) s_tax[w] = ot[s];
+        }
+    }
+}
+
+// LDS -> HBM: contiguous coalesced run of `count` records at out[base ...)
+template <bool TAX, int NTH>
+__device__ __forceinline__ void tile_flush(const SetopArgs &p, int tid, u64 base, u32 count, const u64 *s_keys,
+                                           const u32 *s_tax) {
+    if (base + count <= p.out_cap) {
+        u64 *o = p.out + base;
+        u32 *to = TAX ? p.tout + base : nullptr;
+        for (u32 i = (u32)tid; i < count; i += NTH) {
+            o[i] = s_keys[i];
+            if (TAX) to[i] = s_tax[i];
+        }
+    } else {  // capacity overflow: guarded stores; the host reports UKM_ERR_CAPACITY
+        for (u32 i = (u32)tid; i < count; i += NTH) {
+            const u64 pos = base + i;
+            if (pos < p.out_cap) {
+                p.out[pos] = s_keys[i];
+                if (TAX) p.tout[pos] = s_tax[i];
             }
         }
     }
-    if (tid < 64) {
-        u64 base = lb_lookback(p.status, tile, (u64)tile_total);
-        if (tid == 0) s_misc[1] = base;
+}
+
+// ---- the tile kernel: one workgroup per tile of NTH*VT merged items ------------------------------------
+// TICKET = false (default): tile id = blockIdx.x, so the partition words are fetched with scalar
+//   loads at kernel entry and no atomic sits in front of the tile loads (measured -0.7 ms of
+//   7.4 ms).  Look-back then relies on the hardware dispatching workgroups in increasing
+//   order (observed on MI355X; each XCD's dispatcher walks its share of the grid in order), so
+//   every predecessor of a running tile is running or done.  Results never depend on that: if
+//   a predecessor fails to publish within LB_SPIN_LIMIT polls the kernel raises FLAG_TIMEOUT
+//   and the host re-runs with TICKET = true, where tile ids come from an atomic counter and
+//   forward progress holds for any dispatch order.
+template <int OP, bool TAX, bool RANK, bool TICKET, int NTH, int VT>
+__global__ __launch_bounds__(NTH) void setop_tile_kernel(SetopArgs p) {
+    constexpr int TILE = NTH * VT;
+    constexpr int SLOTS = TILE + 4;
+    __shared__ u64 s_keys[SLOTS];
+    __shared__ u32 s_tax[TAX ? SLOTS : 1];
+    __shared__ u32 s_rank[RANK ? SLOTS : 1];
+    __shared__ u32 s_scan[NTH / 64 + 1];
+    __shared__ u64 s_misc[2];
+    const int tid = (int)threadIdx.x;
+#ifdef UKM_PROFILE_PHASES
+    u64 ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    u64 tlast = clock64();
+#endif
+    u64 tile = blockIdx.x;
+    if (TICKET) {
+        if (tid == 0) s_misc[0] = (u64)atomicAdd(p.ticket, 1u);
+        __syncthreads();
+        tile = s_misc[0];
     }
+    PH(0);
+    const TileGeom g = tile_geom<NTH, VT>(p, tile);
+    u32 bad;
+    {
+        u64 rk[VT + 1];
+        u32 rt[VT + 1], rr[VT + 1];
+        tile_load<TAX, RANK, NTH, VT>(p, g, tid, rk, rt, rr);
+        tile_to_lds<TAX, RANK, NTH, VT>(tid, rk, rt, rr, s_keys, s_tax, s_rank);
+        __syncthreads();
+        PH(1);
+        bad = tile_check_order<RANK, NTH, VT>(g, tid, rk, rr, s_keys, s_rank);
+    }
+    u64 ok[VT];
+    u32 ot[VT];
+    u32 mask;
+    tile_merge<OP, TAX, RANK, VT>(p, g, tid, s_keys, s_tax, s_rank, ok, ot, mask);
+    PH(2);
+    u32 tile_total;
+    const u32 excl = block_excl_scan_u32<NTH>((u32)__popc(mask), s_scan, &tile_total);
+    // (the scan's barriers also guarantee every thread finished reading the tile from LDS)
+    if (tid == 0) lb_publish(p.status, tile, (u64)tile_total);
+    tile_compact<TAX, VT>(excl, mask, ok, ot, s_keys, s_tax);
+    PH(3);
+    if (tid < 64) {
+        bool timed_out = false;
+        const u64 base = lb_resolve(p.status, tile, (u64)tile_total, lane_id(), &timed_out);
+        if (tid == 0) s_misc[1] = base;
+        if (timed_out) bad |= FLAG_TIMEOUT;
+    }
+    PH(4);
     if (bad) atomicOr((unsigned long long *)&p.result[1], (unsigned long long)bad);
     __syncthreads();
     const u64 base = s_misc[1];
-    for (u32 i = (u32)tid; i < tile_total; i += NT) {
-        u64 pos = base + i;
-        if (pos < p.out_cap) {
-            p.out[pos] = s_keys[i];
-            if (TAX) p.tout[pos] = s_tax[i];
-        }
-    }
+    tile_flush<TAX, NTH>(p, tid, base, tile_total, s_keys, s_tax);
     if (tid == 0 && tile == p.ntiles - 1) p.result[0] = base + tile_total;
+    PH(5);
+#ifdef UKM_PROFILE_PHASES
+    if (tid == 0 && p.dbg) {
+        for (int i = 0; i < 7; i++) p.dbg[blockIdx.x * 8 + i] = ph[i];
+        p.dbg[blockIdx.x * 8 + 7] = 1;
+    }
+#endif
 }
 
 // rank of each element inside its run of equal codes (multiset path)
@@ -293,20 +422,24 @@ __global__ void lower_bound_kernel(const u64 *k, u64 n, const u64 *q, int nq, u6
     out[i] = lo;
 }
 
-template <int OP, bool TAX, bool RANK, int VT>
-void launch_tile(const SetopArgs &p, hipStream_t st) {
-    hipLaunchKernelGGL((setop_tile_kernel<OP, TAX, RANK, VT>), dim3((unsigned)p.ntiles), dim3(NT), 0, st, p);
+template <int OP, bool TAX, bool RANK, int NTH, int VT>
+void launch_tile(const SetopArgs &p, hipStream_t st, bool ticket) {
+    if (ticket)
+        hipLaunchKernelGGL((setop_tile_kernel<OP, TAX, RANK, true, NTH, VT>), dim3((unsigned)p.ntiles), dim3(NTH), 0, st, p);
+    else
+        hipLaunchKernelGGL((setop_tile_kernel<OP, TAX, RANK, false, NTH, VT>), dim3((unsigned)p.ntiles), dim3(NTH), 0, st, p);
 }
 
-template <bool TAX, bool RANK, int VT>
-void launch_op(int op, const SetopArgs &p, hipStream_t st) {
-    if (op == UKM_OP_UNION) launch_tile<UKM_OP_UNION, TAX, RANK, VT>(p, st);
-    else if (op == UKM_OP_INTER) launch_tile<UKM_OP_INTER, TAX, RANK, VT>(p, st);
-    else launch_tile<UKM_OP_DIFF, TAX, RANK, VT>(p, st);
+template <bool TAX, bool RANK, int NTH, int VT>
+void launch_op(int op, const SetopArgs &p, hipStream_t st, bool ticket) {
+    if (op == UKM_OP_UNION) launch_tile<UKM_OP_UNION, TAX, RANK, NTH, VT>(p, st, ticket);
+    else if (op == UKM_OP_INTER) launch_tile<UKM_OP_INTER, TAX, RANK, NTH, VT>(p, st, ticket);
+    else launch_tile<UKM_OP_DIFF, TAX, RANK, NTH, VT>(p, st, ticket);
 }
 
-constexpr int VT_PLAIN = 16;  // 4096-item tiles, 32 KiB of keys in LDS
-constexpr int VT_TAX = 12;    // 3072-item tiles when taxids/ranks ride along
+constexpr int NTS = SETOP_NT;       // threads per workgroup (512: two workgroups per CU)
+constexpr int VT_PLAIN = SETOP_VT;  // 16 items per thread: 64 KiB of keys in LDS per workgroup
+constexpr int VT_TAX = 12;     // fewer when taxids/ranks ride along
 
 // One pass of the tiled set operation.  result_host[0] = total, [1] = flags.
 int run_setop_pass(ukm_ctx *c, int op, const u64 *a, const u32 *ta, const u32 *ra, u64 na,
@@ -314,7 +447,7 @@ int run_setop_pass(ukm_ctx *c, int op, const u64 *a, const u32 *ta, const u32 *r
                    u64 *out, u32 *tout, u64 out_cap, u64 result_host[2]) {
     const bool rank = ra != nullptr;
     const int vt = (tax || rank) ? VT_TAX : VT_PLAIN;
-    const u64 tile_items = (u64)NT * vt;
+    const u64 tile_items = (u64)NTS * vt;
     const u64 N = na + nb;
     SetopArgs p;
     memset(&p, 0, sizeof(p));
@@ -326,34 +459,58 @@ int run_setop_pass(ukm_ctx *c, int op, const u64 *a, const u32 *ta, const u32 *r
     p.flags = flags;
     if (p.ntiles > 0xFFFFFFFFull) UKM_FAIL(UKM_ERR_INVALID, "setop: input too large");
 
-    // control block: [result 2 x u64][ticket (u64 slot)][status ntiles][mp ntiles+1]
+    // control block: [result 2 x u64 | ticket | pad][status: one 64-byte line per tile][mp ntiles+1]
     u64 *ctl = nullptr;
-    const size_t nzero = 3 + p.ntiles;
+    const size_t nzero = 8 + lb_status_words(p.ntiles);
     UKM_TRY(ws_alloc_t(c, nzero + p.ntiles + 1, &ctl));
     p.result = ctl;
     p.ticket = (u32 *)(ctl + 2);
-    p.status = ctl + 3;
-    p.mp = ctl + 3 + p.ntiles;
-    UKM_HIP(hipMemsetAsync(ctl, 0, nzero * sizeof(u64), c->stream));
-
+    p.status = ctl + 8;
+    p.mp = ctl + nzero;
+#ifdef UKM_PROFILE_PHASES
+    UKM_TRY(ws_alloc_t(c, (size_t)p.ntiles * 8, &p.dbg));
+    UKM_HIP(hipMemsetAsync(p.dbg, 0, (size_t)p.ntiles * 8 * sizeof(u64), c->stream));
+#endif
     const unsigned pblocks = (unsigned)((p.ntiles + 1 + 255) / 256);
-    if (rank)
-        hipLaunchKernelGGL(setop_partition_kernel<true>, dim3(pblocks), dim3(256), 0, c->stream, p, (int)tile_items);
-    else
-        hipLaunchKernelGGL(setop_partition_kernel<false>, dim3(pblocks), dim3(256), 0, c->stream, p, (int)tile_items);
-
-    (void)hipEventRecord(c->ev_k0, c->stream);
-    if (rank) {
-        if (tax) launch_op<true, true, VT_TAX>(op, p, c->stream);
-        else launch_op<false, true, VT_TAX>(op, p, c->stream);
-    } else {
-        if (tax) launch_op<true, false, VT_TAX>(op, p, c->stream);
-        else launch_op<false, false, VT_PLAIN>(op, p, c->stream);
+    // Attempt 0 takes tile ids from blockIdx (fast path); if its watchdog fires, attempt 1
+    // re-runs with ticketed tile ids, which cannot stall whatever the dispatch order is.
+    for (int attempt = c->setop_force_ticket ? 1 : 0; attempt < 2; attempt++) {
+        const bool ticket = attempt == 1;
+        UKM_HIP(hipMemsetAsync(ctl, 0, nzero * sizeof(u64), c->stream));
+        if (attempt == (c->setop_force_ticket ? 1 : 0)) {
+            if (rank)
+                hipLaunchKernelGGL(setop_partition_kernel<true>, dim3(pblocks), dim3(256), 0, c->stream, p, (int)tile_items);
+            else
+                hipLaunchKernelGGL(setop_partition_kernel<false>, dim3(pblocks), dim3(256), 0, c->stream, p, (int)tile_items);
+        }
+        (void)hipEventRecord(c->ev_k0, c->stream);
+        if (rank) {
+            if (tax) launch_op<true, true, NTS, VT_TAX>(op, p, c->stream, ticket);
+            else launch_op<false, true, NTS, VT_TAX>(op, p, c->stream, ticket);
+        } else {
+            if (tax) launch_op<true, false, NTS, VT_TAX>(op, p, c->stream, ticket);
+            else launch_op<false, false, NTS, VT_PLAIN>(op, p, c->stream, ticket);
+        }
+        (void)hipEventRecord(c->ev_k1, c->stream);
+        c->evk_valid = true;
+        UKM_HIP(hipGetLastError());
+        UKM_TRY(ukm_read_u64(c, p.result, result_host, 2));
+        if (!(result_host[1] & FLAG_TIMEOUT)) break;
+        if (ticket) UKM_FAIL(UKM_ERR_HIP, "setop: look-back watchdog fired in the ticketed kernel");
+        c->setop_force_ticket = true;  // this device does not dispatch in order: stay on tickets
     }
-    (void)hipEventRecord(c->ev_k1, c->stream);
-    c->evk_valid = true;
-    UKM_HIP(hipGetLastError());
-    UKM_TRY(ukm_read_u64(c, p.result, result_host, 2));
+#ifdef UKM_PROFILE_PHASES
+    {
+        std::vector<u64> h((size_t)p.ntiles * 8);
+        UKM_HIP(hipMemcpy(h.data(), p.dbg, h.size() * sizeof(u64), hipMemcpyDeviceToHost));
+        double sum[8] = {0};
+        for (u64 b = 0; b < p.ntiles; b++) for (int i = 0; i < 8; i++) sum[i] += (double)h[(size_t)b * 8 + i];
+        double tot = 0; for (int i = 0; i < 7; i++) tot += sum[i];
+        fprintf(stderr, "[phases op=%d tiles=%llu] cycles per tile:", op, (unsigned long long)p.ntiles);
+        for (int i = 0; i < 7; i++) fprintf(stderr, " p%d=%.0f", i, sum[i] / sum[7]);
+        fprintf(stderr, " total=%.0f\n", tot / sum[7]);
+    }
+#endif
     return UKM_OK;
 }
 

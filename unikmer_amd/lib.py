@@ -10,7 +10,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(_HERE, "libunikmer_hip.so")
+# UKM_LIB_PATH: developer override to load an experimental build of the same HIP library
+SO_PATH = os.environ.get("UKM_LIB_PATH") or os.path.join(_HERE, "libunikmer_hip.so")
 
 OK = 0
 ERR_INVALID, ERR_HIP, ERR_NOMEM, ERR_ILLEGAL_BASE = -1, -2, -3, -4
