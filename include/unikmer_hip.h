@@ -72,7 +72,9 @@ int ukm_version(void);                       /* 1000*major + minor */
 int ukm_device_count(int *n);
 int ukm_ctx_create(int device, ukm_ctx **out);
 int ukm_ctx_destroy(ukm_ctx *ctx);
-/* borrow a caller's hipStream_t (e.g. the framework's current stream); NULL = own stream */
+/* borrow a caller's hipStream_t (e.g. the framework's current stream) instead of the ctx's own
+ * non-blocking stream; NULL is HIP's default (null) stream.  Work the caller enqueued on that
+ * stream before a ukm_* call is ordered before the call's kernels. */
 int ukm_ctx_set_stream(ukm_ctx *ctx, void *hip_stream);
 int ukm_ctx_sync(ukm_ctx *ctx);
 /* pre-size the device workspace so that later calls do not allocate */

@@ -94,13 +94,9 @@ extern "C" int ukm_ctx_set_stream(ukm_ctx *c, void *hip_stream) {
     UKM_HIP(hipSetDevice(c->device));
     UKM_HIP(hipStreamSynchronize(c->stream));
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
-    if (hip_stream) {
-        c->stream = (hipStream_t)hip_stream;
-        c->own_stream = false;
-    } else {
-        UKM_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-        c->own_stream = true;
-    }
+    // NULL is HIP's default (null) stream of the device — a valid stream to borrow
+    c->stream = (hipStream_t)hip_stream;
+    c->own_stream = false;
     return UKM_OK;
 }
 

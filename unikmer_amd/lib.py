@@ -161,6 +161,9 @@ class Context:
     """One ukm_ctx: a HIP stream + device workspace.  Not thread-safe (one per thread)."""
 
     def __init__(self, device=0, stream=None):
+        """stream: a hipStream_t handle to borrow (0 = HIP's default stream, e.g.
+        torch.cuda.current_stream().cuda_stream); None = the ctx creates its own stream, in
+        which case the caller must synchronise its own producers before calling."""
         L = load()
         n = C.c_int(0)
         L.ukm_device_count(C.byref(n))
