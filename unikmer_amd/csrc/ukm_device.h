@@ -9,13 +9,16 @@
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
 
 // ---- wave64 scans ---------------------------------------------------------------------------
+// Inclusive scan across the 64 lanes with DPP row shifts / row broadcasts (gfx9 DPP controls:
+// row_shr:n = 0x110+n, row_bcast:15 = 0x142, row_bcast:31 = 0x143): six VALU adds, no LDS
+// round trip (__shfl_up lowers to ds_bpermute_b32 + s_waitcnt, ~100 cycles per step).
 __device__ __forceinline__ u32 wave_incl_scan_u32(u32 v) {
-    const int lane = lane_id();
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        u32 o = __shfl_up(v, d, 64);
-        if (lane >= d) v += o;
-    }
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, true);  // row_shr:1
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, true);  // row_shr:2
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, true);  // row_shr:4
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, true);  // row_shr:8
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false); // row_bcast:15 -> rows 1,3
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false); // row_bcast:31 -> rows 2,3
     return v;
 }
 

@@ -400,6 +400,9 @@ __global__ __launch_bounds__(NTH) void setop_tile_kernel(SetopArgs p) {
     PH(3);
     if (tid < 64) {
         bool timed_out = false;
+#ifdef LB_PRE_SLEEP
+        __builtin_amdgcn_s_sleep(LB_PRE_SLEEP);
+#endif
         const u64 base = lb_resolve(p.status, tile, (u64)tile_total, lane_id(), &timed_out);
         if (tid == 0) s_misc[1] = base;
         if (timed_out) bad |= FLAG_TIMEOUT;
