@@ -77,11 +77,20 @@ struct PassArgs {
     int shift;
     SW *status;  // [ntiles][256]
     u32 *ticket;
+    u32 *flags;        // bit0: look-back watchdog fired
     const u64 *gbase;  // [256] exclusive digit bases of this pass
     u64 ntiles;
 };
 
-template <typename SW, bool PAIRS>
+#ifndef SORT_LB_W
+#define SORT_LB_W 4
+#endif
+#ifndef SORT_TICKET
+#define SORT_TICKET 1
+#endif
+// TICKET = false: tile id = blockIdx.x (see ukm_setops.hip for the liveness argument and the
+// watchdog); TICKET = true: ids from an atomic counter, dispatch-order independent.
+template <typename SW, bool PAIRS, bool TICKET>
 __global__ __launch_bounds__(NT) void onesweep_kernel(PassArgs<SW> p) {
     using T = SWTraits<SW>;
     __shared__ u64 s_keys[TILE];
@@ -92,10 +101,10 @@ __global__ __launch_bounds__(NT) void onesweep_kernel(PassArgs<SW> p) {
     __shared__ u32 s_scan[NW + 1];
     __shared__ u32 s_tile;
     const int tid = (int)threadIdx.x, lane = lane_id(), wave = tid >> 6;
-    if (tid == 0) s_tile = atomicAdd(p.ticket, 1u);
+    if (TICKET && tid == 0) s_tile = atomicAdd(p.ticket, 1u);
     for (int i = tid; i < NW * RADIX; i += NT) (&s_whist[0][0])[i] = 0;
     __syncthreads();
-    const u64 tile = s_tile;
+    const u64 tile = TICKET ? (u64)s_tile : (u64)blockIdx.x;
     const u64 tbase = tile * (u64)TILE;
     const u32 valid_count = (u32)((p.n - tbase < (u64)TILE) ? (p.n - tbase) : (u64)TILE);
 
@@ -163,23 +172,44 @@ __global__ __launch_bounds__(NT) void onesweep_kernel(PassArgs<SW> p) {
         if (PAIRS) s_vals[pos] = val[j];
     }
 
-    // per-digit decoupled look-back (thread d walks back over tiles)
+    // per-digit decoupled look-back: thread d walks back over the tiles' counts of digit d,
+    // SORT_LB_W tiles per hop (independent loads in flight together; one hop is a ~1.5 us
+    // device-scope round trip, so a one-tile-per-hop walk was latency bound)
     u64 excl = 0;
+    bool timed_out = false;
     if (tile > 0) {
         long long t = (long long)tile - 1;
-        for (;;) {
-            SW w = __hip_atomic_load(p.status + (u64)t * RADIX + d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const u32 state = (u32)(w >> T::SHIFT);
-            if (state == 0) {
-                __builtin_amdgcn_s_sleep(1);
-                continue;
+        u32 spins = 0;
+        bool done = false;
+        while (!done) {
+            SW w[SORT_LB_W];
+#pragma unroll
+            for (int q = 0; q < SORT_LB_W; q++) {
+                const long long tq = t - q;
+                w[q] = (tq >= 0) ? __hip_atomic_load(p.status + (u64)tq * RADIX + d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                 : (SW)T::INCL;
             }
-            excl += (u64)(w & T::VAL);
-            if (state == 2) break;
-            t--;  // aggregate only: keep walking (tile 0 always publishes an inclusive value)
+            int used = 0;
+#pragma unroll
+            for (int q = 0; q < SORT_LB_W; q++) {
+                if (!done && used == q) {
+                    const u32 state = (u32)(w[q] >> T::SHIFT);
+                    if (state != 0) {
+                        excl += (u64)(w[q] & T::VAL);
+                        used = q + 1;
+                        if (state == 2) done = true;
+                    }
+                }
+            }
+            t -= used;
+            if (!done && used < SORT_LB_W) {  // hit an unpublished tile: back off, then re-read from it
+                if (++spins > LB_SPIN_LIMIT) { timed_out = true; break; }
+                __builtin_amdgcn_s_sleep(4);
+            }
         }
         __hip_atomic_store(st, (SW)(T::INCL | (SW)(excl + real_cnt)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+    if (timed_out) atomicOr(p.flags, 1u);
     s_gbase[d] = p.gbase[d] + excl - (u64)dex;
     __syncthreads();
 
@@ -197,23 +227,39 @@ int run_passes(ukm_ctx *c, u64 *keys, u32 *vals, u64 *tk, u32 *tv, u64 n, int np
                const int *shifts, const u64 *gbase_dev, bool *result_in_tmp) {
     const u64 ntiles = (n + TILE - 1) / TILE;
     SW *status = nullptr;
-    u64 *ticket = nullptr;
+    u64 *ctl = nullptr;  // [0] ticket, [1] flags
     UKM_TRY(ws_alloc_t(c, ntiles * RADIX, &status));
-    UKM_TRY(ws_alloc_t(c, 1, &ticket));
+    UKM_TRY(ws_alloc_t(c, 2, &ctl));
     u64 *src_k = keys, *dst_k = tk;
     u32 *src_v = vals, *dst_v = tv;
     for (int i = 0; i < npass; i++) {
-        UKM_HIP(hipMemsetAsync(status, 0, ntiles * RADIX * sizeof(SW), c->stream));
-        UKM_HIP(hipMemsetAsync(ticket, 0, sizeof(u64), c->stream));
-        PassArgs<SW> p;
-        p.kin = src_k; p.kout = dst_k; p.vin = src_v; p.vout = dst_v;
-        p.n = n; p.shift = shifts[i];
-        p.status = status; p.ticket = (u32 *)ticket;
-        p.gbase = gbase_dev + (size_t)i * RADIX;
-        p.ntiles = ntiles;
-        if (vals) hipLaunchKernelGGL((onesweep_kernel<SW, true>), dim3((unsigned)ntiles), dim3(NT), 0, c->stream, p);
-        else hipLaunchKernelGGL((onesweep_kernel<SW, false>), dim3((unsigned)ntiles), dim3(NT), 0, c->stream, p);
-        UKM_HIP(hipGetLastError());
+        // Pass i.  The blockIdx-ordered variant is checked per pass (its source buffer is still
+        // intact if the watchdog fired, so only that pass is repeated with tickets).
+        for (int attempt = (c->setop_force_ticket || SORT_TICKET) ? 1 : 0; attempt < 2; attempt++) {
+            const bool ticket = attempt == 1;
+            UKM_HIP(hipMemsetAsync(status, 0, ntiles * RADIX * sizeof(SW), c->stream));
+            UKM_HIP(hipMemsetAsync(ctl, 0, 2 * sizeof(u64), c->stream));
+            PassArgs<SW> p;
+            p.kin = src_k; p.kout = dst_k; p.vin = src_v; p.vout = dst_v;
+            p.n = n; p.shift = shifts[i];
+            p.status = status; p.ticket = (u32 *)ctl; p.flags = (u32 *)(ctl + 1);
+            p.gbase = gbase_dev + (size_t)i * RADIX;
+            p.ntiles = ntiles;
+            const dim3 grid((unsigned)ntiles), block(NT);
+            if (vals) {
+                if (ticket) hipLaunchKernelGGL((onesweep_kernel<SW, true, true>), grid, block, 0, c->stream, p);
+                else hipLaunchKernelGGL((onesweep_kernel<SW, true, false>), grid, block, 0, c->stream, p);
+            } else {
+                if (ticket) hipLaunchKernelGGL((onesweep_kernel<SW, false, true>), grid, block, 0, c->stream, p);
+                else hipLaunchKernelGGL((onesweep_kernel<SW, false, false>), grid, block, 0, c->stream, p);
+            }
+            UKM_HIP(hipGetLastError());
+            if (ticket) break;  // cannot stall
+            u64 fl = 0;
+            UKM_TRY(ukm_read_u64(c, ctl + 1, &fl));
+            if (!(fl & 1)) break;
+            c->setop_force_ticket = true;  // this device does not dispatch in order
+        }
         std::swap(src_k, dst_k);
         std::swap(src_v, dst_v);
     }
