@@ -52,6 +52,7 @@ extern "C" {
 #define UKM_UNIQUE 1
 #define UKM_REPEATED 2
 #define UKM_REPEATED_CHUNK 3
+#define UKM_SINGLETON 4      /* codes seen exactly once: `count -u` (count.go:424-432,475-486) */
 
 /* 2-way set operations */
 #define UKM_OP_UNION 0

@@ -12,7 +12,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, "libukm_oracle.so")
 
-PLAIN, UNIQUE, REPEATED, REPEATED_CHUNK = 0, 1, 2, 3
+PLAIN, UNIQUE, REPEATED, REPEATED_CHUNK, SINGLETON = 0, 1, 2, 3, 4
 F_TAXID, F_MIX_TAXID, F_CMP_TAXID = 1, 2, 4
 
 _u8p = C.POINTER(C.c_uint8)

@@ -431,6 +431,8 @@ uint64_t ukmo_unique(const uint64_t *keys, const uint32_t *taxids, uint64_t n, i
             EMIT(code, lca);
         } else if (mode == UKMO_REPEATED) { /* sort.go:508-532,551-565 */
             if (count > 1) EMIT(code, lca);
+        } else if (mode == UKMO_SINGLETON) { /* count.go:475-486: marks[code] == false */
+            if (count == 1) EMIT(code, lca);
         } else { /* UKMO_REPEATED_CHUNK, util-sort.go:61-91,145-179 */
             EMIT(code, lca);
             if (count > 1) EMIT(code, lca);

@@ -32,6 +32,7 @@ extern "C" {
 #define UKMO_UNIQUE 1         /* one record per distinct code, taxid = LCA fold */
 #define UKMO_REPEATED 2       /* codes seen >= 2 times, once each (sort -d / merge finalRound) */
 #define UKMO_REPEATED_CHUNK 3 /* chunk protocol: every code once, repeated ones twice */
+#define UKMO_SINGLETON 4      /* codes seen exactly once (count -u, count.go:424-432,475-486) */
 
 /* ---- kmers v0.1.0 ---- */
 int ukmo_encode(const uint8_t *kmer, int k, uint64_t *code); /* 0 ok, -1 illegal base, -2 bad k */

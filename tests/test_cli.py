@@ -1,0 +1,184 @@
+"""Tests of the `unikmer`-compatible C++ driver (unikmer_amd/bin/unikmer).
+
+CPU part: the commands that never touch the GPU (dump / view / num / info / concat / head /
+encode / decode) — `.unik` container round trips in every body encoding.
+GPU part (-m gpu): the README quick-start transcript (README.md:154-278) replayed through the
+binary on the three fixture genomes: count -> sort/union/inter/diff/common/merge -> num/view.
+"""
+import gzip
+import hashlib
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import AMUC, GOLDEN, IAI39, MG1655
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BIN = os.path.join(ROOT, "unikmer_amd", "bin", "unikmer")
+
+
+@pytest.fixture(scope="module")
+def cli():
+    from unikmer_amd import build
+    build.build()
+    assert os.path.exists(BIN)
+
+    def run(*args, stdin=None, ok=True):
+        p = subprocess.run([BIN] + [str(a) for a in args], input=stdin, capture_output=True)
+        if ok:
+            assert p.returncode == 0, p.stderr.decode()
+        return p
+    return run
+
+
+def _kmers(n, k, seed=0):
+    rng = np.random.default_rng(seed)
+    codes = np.unique(rng.integers(0, 4 ** k, n, dtype=np.uint64))
+    def dec(c):
+        return "".join("ACGT"[(int(c) >> (2 * (k - 1 - i))) & 3] for i in range(k))
+    return codes, [dec(c) for c in codes]
+
+
+@pytest.mark.parametrize("flags", [[], ["-s"], ["-c"], ["-C"], ["-s", "-C"]])
+def test_dump_view_roundtrip(cli, tmp_path, flags):
+    codes, kmers = _kmers(5001, 21)   # odd count exercises the trailing single record of sorted files
+    txt = ("\n".join(kmers) + "\n").encode()
+    out = tmp_path / "a"
+    cli("dump", *flags, "-o", out, stdin=txt)
+    f = str(out) + ".unik"
+    assert cli("view", f).stdout == txt
+    assert cli("view", "-N", f).stdout.decode().split() == [str(int(c)) for c in codes]
+    assert cli("num", "-f", f).stdout.strip() == b"5001"
+    raw = open(f, "rb").read()
+    assert (raw[:2] == b"\x1f\x8b") == ("-C" not in flags)      # gzip unless -C (util-io.go:57-64)
+    info = cli("info", "-a", "--symbol-true", "T", "--symbol-false", "F", f).stdout.decode().splitlines()[1].split("\t")
+    assert info[1] == "21" and info[7] == ("T" if "-s" in flags else "F") and info[8] == ("T" if "-c" in flags else "F")
+
+
+def test_dump_canonical_taxid_unique(cli, tmp_path):
+    lines = ["ACGTACGTAC\t5", "GTACGTACGT\t7", "AAAAAAAAAA\t9", "ACGTACGTAC\t5"]   # line 2 = revcomp of line 1
+    out = tmp_path / "t"
+    cli("dump", "-K", "-u", "-o", out, stdin=("\n".join(lines) + "\n").encode())
+    got = cli("view", "-t", str(out) + ".unik").stdout.decode().splitlines()
+    assert got == ["ACGTACGTAC\t5", "AAAAAAAAAA\t9"]
+    assert cli("view", "-T", str(out) + ".unik").stdout.split() == [b"5", b"9"]
+    # -O keeps only k-mers that are already canonical
+    cli("dump", "-O", "-o", out, stdin=b"GTACGTACGT\nACGTACGTAC\n")
+    assert cli("view", str(out) + ".unik").stdout == b"ACGTACGTAC\n"
+    # illegal base -> error exit like checkError (util-cli.go:39-44)
+    p = cli("dump", "-o", out, stdin=b"ACGTXCGTAC\n", ok=False)
+    assert p.returncode == 255 and b"fail to encode" in p.stderr
+
+
+def test_sorted_taxid_body_and_global_taxid(cli, tmp_path):
+    codes, kmers = _kmers(2000, 15, seed=3)
+    txt = "".join("%s\t%d\n" % (k, 1000 + i % 70000) for i, k in enumerate(kmers)).encode()
+    out = tmp_path / "st"
+    cli("dump", "-s", "--max-taxid", 100000, "-o", out, stdin=txt)
+    assert cli("view", "-t", str(out) + ".unik").stdout == txt
+    out2 = tmp_path / "g"
+    cli("dump", "-t", 511145, "-o", out2, stdin=("\n".join(kmers) + "\n").encode())
+    lines = cli("view", "-t", str(out2) + ".unik").stdout.decode().splitlines()
+    assert lines[0].endswith("\t511145") and len(lines) == len(kmers)
+    assert "511145" in cli("info", str(out2) + ".unik").stdout.decode()
+
+
+def test_concat_head_encode_decode(cli, tmp_path):
+    c1, k1 = _kmers(300, 11, seed=1)
+    c2, k2 = _kmers(200, 11, seed=2)
+    a, b = tmp_path / "a", tmp_path / "b"
+    cli("dump", "-o", a, stdin=("\n".join(k1) + "\n").encode())
+    cli("dump", "-o", b, stdin=("\n".join(k2) + "\n").encode())
+    cli("concat", "-o", tmp_path / "c", str(a) + ".unik", str(b) + ".unik")
+    assert cli("view", str(tmp_path / "c") + ".unik").stdout.decode().split() == k1 + k2
+    assert cli("num", str(tmp_path / "c") + ".unik").stdout.strip() == b"-1"     # README.md:269
+    cli("head", "-n", 7, "-o", tmp_path / "h", str(a) + ".unik")
+    assert cli("view", str(tmp_path / "h") + ".unik").stdout.decode().split() == k1[:7]
+    enc = cli("encode", stdin=b"AAAAAAAAACCATCCAAATCTGG\n").stdout.strip()
+    assert enc == b"87360378"                                                    # README.md:177-180 / SURVEY C-2
+    assert cli("decode", "-k", 23, stdin=enc + b"\n").stdout.strip() == b"AAAAAAAAACCATCCAAATCTGG"
+    assert cli("encode", "-K", stdin=b"TTTT\n").stdout.strip() == b"0"
+    # k mismatch between files -> error (util-binary-file.go:31-44)
+    cli("dump", "-o", tmp_path / "k9", stdin=b"ACGTACGTA\n")
+    p = cli("concat", "-o", tmp_path / "x", str(a) + ".unik", str(tmp_path / "k9") + ".unik", ok=False)
+    assert p.returncode == 255 and b"k-mer length not consistent" in p.stderr
+
+
+def test_unknown_command_and_flags(cli):
+    assert cli("frobnicate", ok=False).returncode == 255
+    assert cli("view", "--no-such-flag", ok=False).returncode == 255
+    assert b"unikmer v" in cli("version").stdout
+
+
+# --------------------------------------------------------------------------------------------- GPU
+def _fa(name):
+    return os.path.join(GOLDEN, name)
+
+
+@pytest.mark.gpu
+def test_readme_transcript_on_gpu(cli, tmp_path):
+    d = str(tmp_path)
+    mg, ia, am = d + "/mg", d + "/ia", d + "/am"
+    # count -k 23 -K -s with global taxids (README.md:167-171)
+    cli("count", "-k", 23, "-K", "-s", _fa(MG1655), "-o", mg, "-t", 511145)
+    cli("count", "-k", 23, "-K", "-s", _fa(IAI39), "-o", ia, "-t", 585057)
+    cli("count", "-k", 23, "-K", "-s", _fa(AMUC), "-o", am, "-t", 349741)
+    nums = cli("num", mg + ".unik", ia + ".unik", am + ".unik").stdout.split()
+    assert nums == [b"4546632", b"4902266", b"2630905"]                          # README.md:200-204
+    head = cli("view", "--show-taxid", mg + ".unik").stdout.decode().splitlines()[:3]
+    assert head == ["AAAAAAAAACCATCCAAATCTGG\t511145", "AAAAAAAAACCGCTAGTATATTC\t511145",
+                    "AAAAAAAAACCTGAAAAAAACGG\t511145"]                           # README.md:177-180
+    # unsorted + compact count gives the same set (README.md:154-158)
+    cli("count", "-k", 23, _fa(MG1655), "-o", d + "/mgc", "--canonical", "--compact")
+    assert cli("num", d + "/mgc.unik").stdout.strip() == b"4546632"
+    # set operations without taxonomy (-I ignores the global taxids; LCA needs NCBI nodes.dmp)
+    cli("union", "-I", "-s", ia + ".unik", mg + ".unik", "-o", d + "/union")
+    cli("inter", "-I", ia + ".unik", mg + ".unik", "-o", d + "/inter")
+    cli("diff", "-I", "-s", ia + ".unik", mg + ".unik", "-o", d + "/diff")
+    cli("common", "-I", ia + ".unik", mg + ".unik", "-o", d + "/common")
+    cli("concat", "-I", ia + ".unik", mg + ".unik", "-o", d + "/concat")
+    cli("sort", "-I", "-u", d + "/concat.unik", "-o", d + "/union2")
+    cli("sort", "-I", "-d", d + "/concat.unik", "-o", d + "/dup")
+    cli("merge", "-I", "-u", ia + ".unik", mg + ".unik", "-o", d + "/union3")
+    n = {k: int(cli("num", "-f", d + "/%s.unik" % k).stdout) for k in ("union", "inter", "diff", "common", "union2", "dup", "union3")}
+    assert n == {"union": 6872728, "inter": 2576170, "diff": 2326096, "common": 2576170,
+                 "union2": 6872728, "dup": 2576170, "union3": 6872728}            # README.md:270-278
+    # README.md:215-229: union -s == sort -u (same md5 of the text view)
+    md5 = {k: hashlib.md5(cli("view", d + "/%s.unik" % k).stdout).hexdigest() for k in ("union", "union2", "union3")}
+    assert md5["union"] == md5["union2"] == md5["union3"]
+    assert hashlib.md5(cli("view", d + "/inter.unik").stdout).hexdigest() == hashlib.md5(cli("view", d + "/dup.unik").stdout).hexdigest()
+
+
+@pytest.mark.gpu
+def test_count_modes_on_gpu(cli, tmp_path):
+    d = str(tmp_path)
+    seq = "ACGTTGCAAGGCTTAACCGGTTACGATCGATCGGCTAGCTAGGATCCGATCGTTAGC"
+    with gzip.open(d + "/x.fa.gz", "wt") as fh:
+        fh.write(">r1 taxid=9\n%s\n>r2 taxid=9\n%s\n>short\nACG\n" % (seq, seq[:30]))
+    k = 11
+    # -l linear: every window of every record with len >= k, in order (count.go:413-422)
+    cli("count", "-k", k, "-l", d + "/x.fa.gz", "-o", d + "/lin")
+    lin = cli("view", d + "/lin.unik").stdout.decode().split()
+    exp = [seq[i:i + k] for i in range(len(seq) - k + 1)] + [seq[i:i + k] for i in range(30 - k + 1)]
+    assert lin == exp
+    # -d / -u partition the distinct set (count.go:424-432)
+    cli("count", "-k", k, "-s", d + "/x.fa.gz", "-o", d + "/all")
+    cli("count", "-k", k, "-s", "-d", d + "/x.fa.gz", "-o", d + "/rep")
+    cli("count", "-k", k, "-s", "-u", d + "/x.fa.gz", "-o", d + "/uni")
+    allk = set(cli("view", d + "/all.unik").stdout.decode().split())
+    rep = set(cli("view", d + "/rep.unik").stdout.decode().split())
+    uni = set(cli("view", d + "/uni.unik").stdout.decode().split())
+    assert allk == set(exp) and rep == set(exp[len(seq) - k + 1:]) and rep | uni == allk and not (rep & uni)
+    # hashed + scaled (count.go:94-98,373-375): header carries the scale, values <= maxHash
+    cli("count", "-k", k, "-K", "-s", "-H", "-D", 3, d + "/x.fa.gz", "-o", d + "/sc")
+    info = cli("info", "--symbol-true", "T", "--symbol-false", "F", d + "/sc.unik").stdout.decode().splitlines()[1].split("\t")
+    assert info[3] == "T" and info[4] == "T"
+    vals = [int(x) for x in cli("view", d + "/sc.unik").stdout.split()]
+    assert vals == sorted(vals) and all(v <= (2 ** 64 - 1) // 3 + 1 for v in vals) and len(vals) > 0
+    # FASTQ input
+    with open(d + "/y.fq", "w") as fh:
+        fh.write("@q1\n%s\n+\n%s\n" % (seq, "I" * len(seq)))
+    cli("count", "-k", k, "-l", d + "/y.fq", "-o", d + "/fq")
+    assert cli("view", d + "/fq.unik").stdout.decode().split() == exp[:len(seq) - k + 1]

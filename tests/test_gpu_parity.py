@@ -263,7 +263,7 @@ def test_unique_modes(ctx, O, L, tree, n):
     rng = np.random.default_rng(n)
     keys = np.sort(rng.integers(0, max(1, n // 3) + 1, n).astype(np.uint64))
     tx = taxids_for(np.arange(n, dtype=np.uint64), T)
-    for mode in (L.PLAIN, L.UNIQUE, L.REPEATED, L.REPEATED_CHUNK):
+    for mode in (L.PLAIN, L.UNIQUE, L.REPEATED, L.REPEATED_CHUNK, L.SINGLETON):
         assert np.array_equal(ctx.unique(keys, mode=mode), O.unique(keys, mode=mode))
         gk, gt = ctx.unique(keys, tx, mode=mode)
         ok, ot = O.unique(keys, tx, mode=mode, tax=tax)

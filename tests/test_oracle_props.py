@@ -101,6 +101,8 @@ def test_repeated_protocol_two_rounds():
     assert np.array_equal(final, O.unique(O.sort_u64(x), mode=O.REPEATED))
     vals, cnt = np.unique(x, return_counts=True)
     assert np.array_equal(final, vals[cnt > 1])
+    # count -u / count -d partition the distinct set (count.go:424-432)
+    assert np.array_equal(O.unique(O.sort_u64(x), mode=O.SINGLETON), vals[cnt == 1])
 
 
 def test_inter_diff_multiset_and_quirks():

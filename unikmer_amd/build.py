@@ -54,7 +54,27 @@ def build(force=False, verbose=False):
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)
+    build_cli(force=force, verbose=verbose)
     return SO
+
+
+HOST = os.path.join(HERE, "host")
+CLI = os.path.join(HERE, "bin", "unikmer")
+
+
+def build_cli(force=False, verbose=False):
+    """the `unikmer`-compatible C++ driver (host side of the drop-in), linked against the C ABI"""
+    srcs = [os.path.join(HOST, "main.cpp"), os.path.join(HOST, "unik.hpp"),
+            os.path.join(HERE, "..", "include", "unikmer_hip.h")]
+    if not (force or _stale(CLI, srcs + [SO])):
+        return CLI
+    os.makedirs(os.path.dirname(CLI), exist_ok=True)
+    cmd = ["g++", "-O2", "-std=c++17", "-Wall", "-Wno-unused-function", os.path.join(HOST, "main.cpp"), "-o", CLI,
+           "-L" + HERE, "-lunikmer_hip", "-lz", "-Wl,-rpath,$ORIGIN/..", "-Wl,-rpath,/opt/rocm/lib"]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return CLI
 
 
 if __name__ == "__main__":

@@ -172,7 +172,7 @@ int ukm_dev_setop2(ukm_ctx *c, int op, const u64 *a, const u32 *ta, u64 na, cons
 int ukm_dev_sort(ukm_ctx *c, u64 *keys, u32 *vals, u64 n, int key_bits);
 int ukm_dev_unique(ukm_ctx *c, const u64 *keys, const u32 *taxids, u64 n, int mode, u64 *out,
                    u32 *tout, u64 out_cap, u64 *n_out);
-// mode 4 = UNIQUE_LAST (last record of each run), 5 = COMMON (run length >= threshold)
+// mode 5 = UNIQUE_LAST (last record of each run), 6 = COMMON (run length >= threshold)
 int ukm_dev_unique_ex(ukm_ctx *c, const u64 *keys, const u32 *taxids, u64 n, int mode, u32 threshold,
                       u64 *out, u32 *tout, u64 out_cap, u64 *n_out);
 int ukm_dev_check_sorted(ukm_ctx *c, const u64 *keys, u64 n, bool *sorted, bool *strict);

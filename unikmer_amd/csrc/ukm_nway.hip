@@ -297,7 +297,7 @@ extern "C" int ukm_diff(ukm_ctx *ctx, const uint64_t *const *keys, const uint32_
         if (!a_strict && acc.n) {
             // the survivor map collapses duplicate codes, last record wins (diff.go:449-453)
             u64 n = 0;
-            UKM_TRY(ukm_dev_unique_ex(ctx, acc.k, acc.t, acc.n, 4, 0, bk[2], tax ? bt[2] : nullptr, acc.n, &n));
+            UKM_TRY(ukm_dev_unique_ex(ctx, acc.k, acc.t, acc.n, 5, 0, bk[2], tax ? bt[2] : nullptr, acc.n, &n));
             acc = Stream{bk[2], tax ? bt[2] : nullptr, n};
         }
         return copy_result(ctx, acc, tax, o.k, o.t, out_cap, n_out);
@@ -339,7 +339,7 @@ extern "C" int ukm_common(ukm_ctx *ctx, const uint64_t *const *keys, const uint3
                 }
                 if (!sorted) UKM_TRY(ukm_dev_sort(ctx, k, t, ss[0].n, 64));
                 u64 nu = 0;
-                UKM_TRY(ukm_dev_unique_ex(ctx, k, t, ss[0].n, 4, 0, k2, t2, ss[0].n, &nu));
+                UKM_TRY(ukm_dev_unique_ex(ctx, k, t, ss[0].n, 5, 0, k2, t2, ss[0].n, &nu));
                 ss[0] = Stream{k2, t2, nu};
             }
         }
@@ -349,7 +349,7 @@ extern "C" int ukm_common(ukm_ctx *ctx, const uint64_t *const *keys, const uint3
         UKM_TRY(concat_streams(ctx, ss, tax, &k, &t, &total));
         if (total == 0) return UKM_OK;
         UKM_TRY(ukm_dev_sort(ctx, k, t, total, 64));
-        int r = ukm_dev_unique_ex(ctx, k, t, total, 5, threshold ? threshold : 0, o.k, o.t, out_cap, n_out);
+        int r = ukm_dev_unique_ex(ctx, k, t, total, 6, threshold ? threshold : 0, o.k, o.t, out_cap, n_out);
         return r;
     });
 }

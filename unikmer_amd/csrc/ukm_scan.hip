@@ -13,8 +13,8 @@
 
 #include "ukm_device.h"
 
-#define UKM_UNIQUE_LAST 4  // internal: one record per run, the LAST record of the run
-#define UKM_COMMON 5       // internal: run heads whose run length >= threshold (common.go:331-335)
+#define UKM_UNIQUE_LAST 5  // internal: one record per run, the LAST record of the run
+#define UKM_COMMON 6       // internal: run heads whose run length >= threshold (common.go:331-335)
 
 namespace {
 
@@ -92,6 +92,7 @@ __global__ __launch_bounds__(NT) void unique_tile_kernel(UniqArgs p) {
                 const bool repeated = !tail;
                 if (mode == UKM_UNIQUE) emit = 1;
                 else if (mode == UKM_REPEATED) emit = repeated ? 1 : 0;
+                else if (mode == UKM_SINGLETON) emit = repeated ? 0 : 1;
                 else emit = repeated ? 2 : 1;  // UKM_REPEATED_CHUNK
                 if (TAX && emit) {
                     tx = p.t[gi];
@@ -283,7 +284,7 @@ extern "C" int ukm_unique(ukm_ctx *ctx, const uint64_t *keys, const uint32_t *ta
                           uint64_t *n_out) {
     if (!ctx || !n_out || (!keys && n) || (!out_keys && out_cap))
         UKM_FAIL(UKM_ERR_INVALID, "ukm_unique: NULL argument");
-    if (mode < UKM_PLAIN || mode > UKM_REPEATED_CHUNK) UKM_FAIL(UKM_ERR_INVALID, "ukm_unique: unknown mode %d", mode);
+    if (mode < UKM_PLAIN || mode > UKM_SINGLETON) UKM_FAIL(UKM_ERR_INVALID, "ukm_unique: unknown mode %d", mode);
     CallScope s;
     UKM_TRY(ukm_begin(ctx, &s));
     int rc = [&]() -> int {

@@ -594,7 +594,7 @@ int ukm_dev_setop2(ukm_ctx *c, int op, const u64 *a, const u32 *ta, u64 na, cons
                 UKM_TRY(run_setop_pass(c, op, a, ta, ra, na, b, tb, rb, nb, tax, flags, tk, tt, na, res));
                 if (!(res[1] & FLAG_UNSORTED)) {
                     u64 nu = 0;
-                    UKM_TRY(ukm_dev_unique(c, tk, tax ? tt : nullptr, res[0], 4 /*UNIQUE_LAST*/, out, tout, out_cap, &nu));
+                    UKM_TRY(ukm_dev_unique(c, tk, tax ? tt : nullptr, res[0], 5 /*UNIQUE_LAST*/, out, tout, out_cap, &nu));
                     res[0] = nu;
                 }
             } else {

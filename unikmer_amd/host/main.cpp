@@ -1,0 +1,927 @@
+// main.cpp — `unikmer`-compatible command line driver over the C ABI of libunikmer_hip.so.
+//
+// The reference's L3/L4 layers (cobra sub-commands in /root/reference/unikmer/cmd/*.go) are
+// Go; there is no Go toolchain in this image, so the host side of the drop-in is C++ (the
+// INTEGRATION.md cgo shim documents the Go binding).  Commands keep the reference's names,
+// flags and output-naming rules; all k-mer arithmetic that the reference does per record on
+// the CPU goes through the HIP library:
+//   count  (count.go)   FASTA/Q -> ukm_encode_kmers | ukm_nthash -> ukm_sort_* -> ukm_unique
+//   sort   (sort.go)    ukm_sort_u64 | ukm_sort_pairs -> ukm_unique(-u/-d)
+//   union / inter / diff / common / merge -> ukm_union / ukm_inter / ukm_diff / ukm_common / ukm_merge_k
+// CPU-only commands (no GPU needed): view, dump, num, info/stats, concat, head, encode, decode.
+// Not implemented (SURVEY.md §2a out of scope): grep, filter, rfilter, tsplit, locate, map,
+// split, sample, autocompletion; count -W/-S (minimizer/syncmer sketches); sort -m chunking is
+// accepted and ignored (a whole set fits in 288 GB of HBM).
+#include <getopt.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdlib>
+#include <fstream>
+#include <iostream>
+#include <map>
+#include <memory>
+#include <regex>
+#include <set>
+#include <sstream>
+#include <string>
+#include <vector>
+
+#include "../../include/unikmer_hip.h"
+#include "unik.hpp"
+
+using std::string;
+using std::vector;
+typedef uint64_t u64;
+typedef uint32_t u32;
+
+static const char *VERSION = "0.21.0-hip";
+static const string EXT = ".unik";
+
+// ---- errors / logging (util-cli.go:39-44 checkError -> log + os.Exit(-1)) -------------------------
+[[noreturn]] static void die(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    fprintf(stderr, "[ERRO] ");
+    vfprintf(stderr, fmt, ap);
+    fprintf(stderr, "\n");
+    va_end(ap);
+    exit(255);
+}
+static bool g_verbose = false;
+static void info(const char *fmt, ...) {
+    if (!g_verbose) return;
+    va_list ap;
+    va_start(ap, fmt);
+    fprintf(stderr, "[INFO] ");
+    vfprintf(stderr, fmt, ap);
+    fprintf(stderr, "\n");
+    va_end(ap);
+}
+
+// ---- tiny flag parser -----------------------------------------------------------------------------
+struct FlagSpec {
+    char shortname;  // 0 = none
+    const char *longname;
+    bool takes_value;
+};
+struct Args {
+    std::map<string, string> val;
+    std::set<string> present;
+    vector<string> files;
+    bool has(const string &k) const { return present.count(k) > 0; }
+    string str(const string &k, const string &d = "") const { auto it = val.find(k); return it == val.end() ? d : it->second; }
+    long long num(const string &k, long long d) const { auto it = val.find(k); return it == val.end() ? d : atoll(it->second.c_str()); }
+    double real(const string &k, double d) const { auto it = val.find(k); return it == val.end() ? d : atof(it->second.c_str()); }
+};
+
+static const vector<FlagSpec> GLOBAL_FLAGS = {
+    {'j', "threads", true}, {0, "verbose", false}, {'C', "no-compress", false}, {0, "compression-level", true},
+    {'c', "compact", false}, {'i', "infile-list", true}, {0, "max-taxid", true}, {'I', "ignore-taxid", false},
+    {0, "data-dir", true}, {0, "skip-flag-check", false}, {0, "skip-file-check", false}, {0, "gpu", true},
+    {'h', "help", false},
+};
+
+static Args parse_args(int argc, char **argv, vector<FlagSpec> specs) {
+    specs.insert(specs.end(), GLOBAL_FLAGS.begin(), GLOBAL_FLAGS.end());
+    Args a;
+    for (int i = 0; i < argc; i++) {
+        string s = argv[i];
+        if (s == "-" || s.empty() || s[0] != '-') { a.files.push_back(s); continue; }
+        if (s == "--") { for (int j = i + 1; j < argc; j++) a.files.push_back(argv[j]); break; }
+        if (s[1] == '-') {
+            string name = s.substr(2), value;
+            bool has_eq = false;
+            size_t eq = name.find('=');
+            if (eq != string::npos) { value = name.substr(eq + 1); name = name.substr(0, eq); has_eq = true; }
+            const FlagSpec *f = nullptr;
+            for (auto &sp : specs) if (name == sp.longname) f = &sp;
+            if (!f) die("unknown flag: --%s", name.c_str());
+            a.present.insert(f->longname);
+            if (f->takes_value) {
+                if (!has_eq) { if (i + 1 >= argc) die("flag needs an argument: --%s", name.c_str()); value = argv[++i]; }
+                a.val[f->longname] = value;
+            }
+        } else {
+            for (size_t p = 1; p < s.size(); p++) {
+                const FlagSpec *f = nullptr;
+                for (auto &sp : specs) if (sp.shortname && sp.shortname == s[p]) f = &sp;
+                if (!f) die("unknown shorthand flag: '%c' in %s", s[p], s.c_str());
+                a.present.insert(f->longname);
+                if (f->takes_value) {
+                    string value = s.substr(p + 1);
+                    if (value.empty()) { if (i + 1 >= argc) die("flag needs an argument: -%c", s[p]); value = argv[++i]; }
+                    a.val[f->longname] = value;
+                    break;
+                }
+            }
+        }
+    }
+    return a;
+}
+
+// ---- options shared by all commands (util.go:52-109) -----------------------------------------------
+struct Options {
+    bool compress = true, compact = false, ignore_taxid = false, skip_file_check = false;
+    int level = -1, gpu = 0;
+    u32 max_taxid = 0xFFFFFFFFu;
+    string data_dir;
+};
+static Options get_options(const Args &a) {
+    Options o;
+    g_verbose = a.has("verbose");
+    o.compress = !a.has("no-compress");
+    o.level = (int)a.num("compression-level", -1);
+    o.compact = a.has("compact");
+    o.ignore_taxid = a.has("ignore-taxid");
+    o.skip_file_check = a.has("skip-file-check");
+    o.max_taxid = (u32)a.num("max-taxid", 0xFFFFFFFFLL);
+    const char *env = getenv("UNIKMER_DB");  // util.go:75-83
+    const char *home = getenv("HOME");
+    o.data_dir = a.has("data-dir") ? a.str("data-dir") : (env ? string(env) : (string(home ? home : ".") + "/.unikmer"));
+    const char *g = getenv("UNIKMER_GPU");
+    o.gpu = (int)a.num("gpu", g ? atoi(g) : 0);
+    return o;
+}
+
+static bool file_exists(const string &p) { struct stat st; return stat(p.c_str(), &st) == 0; }
+
+// util-cli.go:192-264 : files from the command line plus the optional list file; "-" = stdin
+static vector<string> get_files(const Args &a, const Options &o, bool allow_stdin_default = true) {
+    vector<string> files = a.files;
+    if (a.has("infile-list")) {
+        std::ifstream fh(a.str("infile-list"));
+        if (!fh) die("fail to read file list: %s", a.str("infile-list").c_str());
+        string line;
+        while (std::getline(fh, line)) {
+            while (!line.empty() && (line.back() == '\r' || line.back() == ' ')) line.pop_back();
+            if (!line.empty()) files.push_back(line);
+        }
+    }
+    if (files.empty() && allow_stdin_default) files.push_back("-");
+    if (!o.skip_file_check)
+        for (auto &f : files)
+            if (f != "-" && !file_exists(f)) die("file does not exist: %s", f.c_str());
+    return files;
+}
+static string out_name(const string &prefix) {  // union.go:79-81
+    if (prefix == "-") return prefix;
+    if (prefix.size() >= EXT.size() && prefix.compare(prefix.size() - EXT.size(), EXT.size(), EXT) == 0) return prefix;
+    return prefix + EXT;
+}
+
+// ---- GPU context + device buffers ---------------------------------------------------------------
+struct Gpu {
+    ukm_ctx *c = nullptr;
+    explicit Gpu(int device) {
+        if (ukm_ctx_create(device, &c) != UKM_OK) die("%s", ukm_last_error());
+    }
+    ~Gpu() { if (c) ukm_ctx_destroy(c); }
+};
+static void ck(int rc) { if (rc != UKM_OK) die("%s", ukm_last_error()); }
+
+// ---- taxonomy (util.go:119-171): nodes.dmp (+ merged.dmp) -> ukm_taxonomy_load ---------------------
+static bool parse_two_ids(const string &line, u32 &a, u32 &b) {
+    const char *p = line.c_str();
+    char *e = nullptr;
+    unsigned long x = strtoul(p, &e, 10);
+    if (e == p) return false;
+    const char *q = strchr(e, '|');
+    if (!q) return false;
+    q++;
+    unsigned long y = strtoul(q, &e, 10);
+    if (e == q) return false;
+    a = (u32)x; b = (u32)y;
+    return true;
+}
+static u32 load_taxonomy(Gpu &g, const Options &o) {
+    const string nodes = o.data_dir + "/nodes.dmp", merged = o.data_dir + "/merged.dmp";
+    if (!file_exists(nodes))
+        die("taxonomy file not found: %s (set --data-dir or UNIKMER_DB)", nodes.c_str());
+    info("loading Taxonomy from: %s", o.data_dir.c_str());
+    vector<u32> child, parent, mo, mn;
+    std::ifstream fh(nodes);
+    string line;
+    u32 a, b;
+    while (std::getline(fh, line)) if (parse_two_ids(line, a, b)) { child.push_back(a); parent.push_back(b); }
+    if (file_exists(merged)) {
+        std::ifstream mh(merged);
+        while (std::getline(mh, line)) if (parse_two_ids(line, a, b)) { mo.push_back(a); mn.push_back(b); }
+    }
+    info("%zu nodes loaded, %zu merged nodes loaded", child.size(), mo.size());
+    ck(ukm_taxonomy_load(g.c, child.data(), parent.data(), child.size(), mo.empty() ? nullptr : mo.data(),
+                         mn.empty() ? nullptr : mn.data(), mo.size()));
+    u32 mx = 0;
+    ck(ukm_taxonomy_max_taxid(g.c, &mx));
+    return mx;  // util.go:169: opt.MaxTaxid follows the taxonomy
+}
+
+// ---- one loaded .unik file ---------------------------------------------------------------------------
+struct Loaded {
+    unik::Header h;
+    vector<u64> codes;
+    vector<u32> taxids;  // filled when has_taxid
+    bool has_taxid = false;
+};
+static Loaded load_unik(const string &file, const Options &o) {
+    unik::Reader r(file);
+    Loaded L;
+    L.h = r.h;
+    L.has_taxid = !o.ignore_taxid && r.h.has_taxid_info();
+    r.read_all(L.codes, L.has_taxid ? &L.taxids : nullptr);
+    return L;
+}
+static void check_compat(const unik::Header &a, const unik::Header &b, const string &file) {  // util-binary-file.go:31-44
+    if (a.k != b.k) die("k-mer length not consistent (%d != %d), please check with \"unikmer stats\": %s", a.k, b.k, file.c_str());
+    if (a.is_canonical() != b.is_canonical()) die("'canonical' flags not consistent, please check with \"unikmer stats\": %s", file.c_str());
+    if (a.is_hashed() != b.is_hashed()) die("'hashed' flags not consistent, please check with \"unikmer stats\": %s", file.c_str());
+    if (a.is_scaled() != b.is_scaled()) die("'scaled' flags not consistent, please check with \"unikmer stats\": %s", file.c_str());
+}
+
+static void write_unik(const string &out_file, const Options &o, int k, u32 mode, u32 max_taxid, u32 global_taxid,
+                       const unik::Header *scale_from, const u64 *codes, const u32 *taxids, u64 n) {
+    unik::OutStream os(out_file, o.compress, o.level);
+    unik::Writer w(os, k, mode);
+    w.set_max_taxid(max_taxid);
+    if (global_taxid) w.set_global_taxid(global_taxid);
+    if (scale_from && scale_from->is_scaled()) w.set_scale(scale_from->scale, scale_from->max_hash);
+    w.set_number(n);
+    const bool tx = (mode & unik::UnikIncludeTaxID) != 0;
+    for (u64 i = 0; i < n; i++) {
+        if (tx) w.write_code_with_taxid(codes[i], taxids[i]);
+        else w.write_code(codes[i]);
+    }
+    w.flush();
+    os.close();
+    info("%llu k-mers saved to %s", (unsigned long long)n, out_file.c_str());
+}
+
+// kmers v0.1.0 text <-> code on the host (view / dump / encode / decode only; the throughput
+// path is ukm_encode_kmers)
+static int base2bit(unsigned char c) {
+    switch (c) {
+    case 'A': case 'a': case 'N': case 'n': case 'M': case 'm': case 'V': case 'v': case 'H': case 'h':
+    case 'R': case 'r': case 'D': case 'd': case 'W': case 'w': return 0;
+    case 'C': case 'c': case 'S': case 's': case 'B': case 'b': case 'Y': case 'y': return 1;
+    case 'G': case 'g': case 'K': case 'k': return 2;
+    case 'T': case 't': case 'U': case 'u': return 3;
+    default: return 4;
+    }
+}
+static bool encode_kmer(const string &s, u64 &code) {
+    if (s.empty() || s.size() > 32) return false;
+    u64 c = 0;
+    for (unsigned char ch : s) { int b = base2bit(ch); if (b > 3) return false; c = (c << 2) | (u64)b; }
+    code = c;
+    return true;
+}
+static u64 revcomp(u64 code, int k) {
+    u64 c = ~code, r = 0;
+    for (int i = 0; i < k; i++) { r = (r << 2) | (c & 3); c >>= 2; }
+    return r;
+}
+static string decode_kmer(u64 code, int k) {
+    string s((size_t)k, 'A');
+    for (int i = k - 1; i >= 0; i--) { s[(size_t)i] = "ACGT"[code & 3]; code >>= 2; }
+    return s;
+}
+
+// ---- FASTA/Q reader (bio/seqio/fastx as used by count.go:289-299) ----------------------------------
+struct SeqBatch {
+    vector<uint8_t> bases;
+    vector<u64> off{0};
+    vector<string> names;
+};
+static void read_fastx(const string &file, SeqBatch &b, bool keep_names) {
+    unik::InStream in(file);
+    vector<char> buf(1 << 20);
+    string line, name;
+    bool have = false, fastq = false;
+    int fq_state = 0;  // 0 header, 1 seq, 2 plus, 3 qual
+    u64 seq_len = 0, qual_len = 0;
+    auto finish = [&]() {
+        if (have) { b.off.push_back(b.bases.size()); if (keep_names) b.names.push_back(name); }
+        have = false;
+    };
+    string carry;
+    auto handle = [&](const string &l) {
+        if (fastq) {
+            if (fq_state == 0) { if (l.empty()) return; if (l[0] != '@') die("invalid FASTQ record in %s", file.c_str()); finish(); name = l.substr(1); have = true; seq_len = qual_len = 0; fq_state = 1; }
+            else if (fq_state == 1) { if (!l.empty() && l[0] == '+') fq_state = 3; else { b.bases.insert(b.bases.end(), l.begin(), l.end()); seq_len += l.size(); } }
+            else if (fq_state == 3) { qual_len += l.size(); if (qual_len >= seq_len) fq_state = 0; }
+            return;
+        }
+        if (!l.empty() && l[0] == '>') { finish(); name = l.substr(1); have = true; return; }
+        if (!have) { if (l.empty()) return; die("invalid FASTA/Q format: %s", file.c_str()); }
+        b.bases.insert(b.bases.end(), l.begin(), l.end());
+    };
+    bool first = true;
+    for (;;) {
+        size_t n = in.read(buf.data(), buf.size());
+        if (n == 0) break;
+        size_t s = 0;
+        for (size_t i = 0; i < n; i++) {
+            if (buf[i] == '\n') {
+                carry.append(buf.data() + s, i - s);
+                if (!carry.empty() && carry.back() == '\r') carry.pop_back();
+                if (first) { first = false; fastq = !carry.empty() && carry[0] == '@'; }
+                handle(carry);
+                carry.clear();
+                s = i + 1;
+            }
+        }
+        carry.append(buf.data() + s, n - s);
+    }
+    if (!carry.empty()) { if (first) fastq = carry[0] == '@'; handle(carry); }
+    finish();
+}
+
+// =================================================================================================
+// count (count.go:41-602)
+// =================================================================================================
+static int cmd_count(int argc, char **argv) {
+    Args a = parse_args(argc, argv, {{'o', "out-prefix", true}, {'k', "kmer-len", true}, {'K', "canonical", false},
+                                     {'s', "sort", false}, {'t', "taxid", true}, {'T', "parse-taxid", false},
+                                     {'r', "parse-taxid-regexp", true}, {'d', "repeated", false}, {'u', "unique", false},
+                                     {'V', "more-verbose", false}, {'H', "hash", false}, {0, "circular", false},
+                                     {'D', "scale", true}, {'W', "minimizer-w", true}, {'S', "syncmer-s", true},
+                                     {'l', "linear", false}, {'B', "seq-name-filter", true}});
+    Options o = get_options(a);
+    vector<string> files = get_files(a, o);
+    const int k = (int)a.num("kmer-len", 0);
+    if (k <= 0) die("value of flag -k/--kmer-len should be positive");
+    const bool canonical = a.has("canonical"), sortk = a.has("sort"), linear = a.has("linear");
+    bool hashed = a.has("hash");
+    const bool repeated = a.has("repeated"), unique = a.has("unique"), circular = a.has("circular");
+    if (k > 32 && !hashed) { hashed = true; fprintf(stderr, "[WARN] flag -H/--hash is switched on for k > 32\n"); }  // count.go:81-84
+    if (hashed && k > 64) die("k-mer size (%d) should be <=64", k);
+    const long long scale = a.num("scale", 1);
+    if (scale < 1 || scale > 0x7fffffffLL) die("value of flag --scale is too big");
+    const bool scaled = scale > 1;
+    if (scaled && !hashed) { hashed = true; fprintf(stderr, "[WARN] flag -H/--hash is switched on for scale > 1\n"); }
+    if (a.num("minimizer-w", 0) > 0 || a.num("syncmer-s", 0) > 0) die("-W/--minimizer-w and -S/--syncmer-s are not supported in this build");
+    if (repeated && unique) die("flag -d/--repeated and -u/--unique are not compatible");
+    const u32 gtaxid = (u32)a.num("taxid", 0);
+    const bool parse_taxid = a.has("parse-taxid");
+    if (parse_taxid && !a.has("parse-taxid-regexp")) die("flag -r/--parse-taxid-regexp needed when given flag -T/--parse-taxid");
+    if (parse_taxid && gtaxid) die("flag -t/--taxid and -T/--parse-taxid can not given simultaneously");
+    if (linear && (repeated || unique || sortk)) die("flag -l/--linear is not compatible with -s, -u and -d");
+    const string out_file = out_name(a.str("out-prefix", "-"));
+
+    SeqBatch sb;
+    for (auto &f : files) { info("reading sequence file: %s", f.c_str()); read_fastx(f, sb, parse_taxid || a.has("seq-name-filter")); }
+    const u64 n_rec = sb.off.size() - 1;
+    // -B name filter / -T taxid per record (count.go:300-344)
+    vector<u32> rec_taxid;
+    if (a.has("seq-name-filter") || parse_taxid) {
+        std::regex re_tax;
+        if (parse_taxid) re_tax = std::regex(a.str("parse-taxid-regexp"));
+        std::regex re_name;
+        if (a.has("seq-name-filter")) re_name = std::regex(a.str("seq-name-filter"), std::regex::icase);
+        SeqBatch kept;
+        for (u64 r = 0; r < n_rec; r++) {
+            if (a.has("seq-name-filter") && std::regex_search(sb.names[r], re_name)) continue;
+            if (parse_taxid) {
+                std::smatch m;
+                if (!std::regex_search(sb.names[r], m, re_tax) || m.size() < 2) die("failed to parse taxid in header: %s", sb.names[r].c_str());
+                rec_taxid.push_back((u32)strtoul(m[1].str().c_str(), nullptr, 10));
+            }
+            kept.bases.insert(kept.bases.end(), sb.bases.begin() + (long)sb.off[r], sb.bases.begin() + (long)sb.off[r + 1]);
+            kept.off.push_back(kept.bases.size());
+        }
+        sb.bases.swap(kept.bases);
+        sb.off.swap(kept.off);
+    }
+    const u64 nrec = sb.off.size() - 1;
+
+    Gpu g(o.gpu);
+    u32 max_taxid = o.max_taxid;
+    if (parse_taxid) max_taxid = load_taxonomy(g, o);
+    const u64 max_hash = scaled ? ukm_max_hash((u64)scale) : 0;
+    // every window of every record, in order
+    u64 cap = 0;
+    for (u64 r = 0; r < nrec; r++) { u64 len = sb.off[r + 1] - sb.off[r]; if (len >= (u64)k) cap += circular ? len : len - k + 1; }
+    vector<u64> codes(cap ? cap : 1);
+    u64 n = 0;
+    if (nrec) {
+        if (hashed) ck(ukm_nthash(g.c, sb.bases.data(), sb.off.data(), nrec, k, canonical, circular, max_hash, codes.data(), cap, &n));
+        else ck(ukm_encode_kmers(g.c, sb.bases.data(), sb.off.data(), nrec, k, canonical, circular, codes.data(), cap, &n));
+    }
+    codes.resize(n);
+    vector<u32> taxids;
+    if (parse_taxid) {  // per-window taxid = its record's taxid (only without the Scaled filter, whose survivors lose their record)
+        if (scaled) die("-T/--parse-taxid together with -D/--scale is not supported in this build");
+        taxids.reserve(n);
+        for (u64 r = 0; r < nrec; r++) {
+            u64 len = sb.off[r + 1] - sb.off[r];
+            if (len < (u64)k) continue;
+            u64 w = circular ? len : len - k + 1;
+            taxids.insert(taxids.end(), w, rec_taxid[r]);
+        }
+    }
+    u32 mode = 0;
+    if (canonical) mode |= unik::UnikCanonical;
+    if (parse_taxid) mode |= unik::UnikIncludeTaxID;
+    if (hashed) mode |= unik::UnikHashed;
+    unik::Header sh;
+    if (scaled) { sh.flag |= unik::UnikScaled; sh.scale = (u32)scale; sh.max_hash = max_hash; }
+    const int key_bits = hashed ? 64 : 2 * k;
+    if (!linear) {
+        // dedup: distinct set, or codes seen exactly once (-u), or at least twice (-d)  (count.go:424-436)
+        const int m = unique ? UKM_SINGLETON : (repeated ? UKM_REPEATED : UKM_UNIQUE);
+        vector<u64> out(n ? n : 1);
+        vector<u32> tout(parse_taxid ? (n ? n : 1) : 0);
+        u64 nu = 0;
+        if (n) {
+            if (parse_taxid) ck(ukm_sort_pairs(g.c, codes.data(), taxids.data(), n, key_bits));
+            else ck(ukm_sort_u64(g.c, codes.data(), n, key_bits));
+            ck(ukm_unique(g.c, codes.data(), parse_taxid ? taxids.data() : nullptr, n, m, out.data(),
+                          parse_taxid ? tout.data() : nullptr, n, &nu));
+        }
+        codes.swap(out);
+        taxids.swap(tout);
+        n = nu;
+        // without -s the reference writes Go-map order; any order is valid there, we keep the
+        // sorted order but only set the Sorted flag (and its encoding) when -s is given
+        if (sortk) mode |= unik::UnikSorted;
+        else if (o.compact && !hashed) mode |= unik::UnikCompact;
+    } else if (o.compact && !hashed) {
+        mode |= unik::UnikCompact;
+    }
+    write_unik(out_file, o, k, mode, max_taxid, gtaxid, scaled ? &sh : nullptr, codes.data(), taxids.data(), n);
+    return 0;
+}
+
+// =================================================================================================
+// n-way commands: sort / union / inter / diff / common / merge
+// =================================================================================================
+struct Inputs {
+    vector<Loaded> files;
+    int k = 0;
+    bool canonical = false, hashed = false, has_taxid = false, any_taxid = false;
+    unik::Header h0;
+    u64 total = 0;
+};
+static Inputs load_inputs(const vector<string> &files, const Options &o, bool require_sorted_all, bool require_sorted_first,
+                          bool allow_mix) {
+    Inputs in;
+    for (size_t i = 0; i < files.size(); i++) {
+        info("processing file (%zu/%zu): %s", i + 1, files.size(), files[i].c_str());
+        in.files.push_back(load_unik(files[i], o));
+        Loaded &L = in.files.back();
+        if (i == 0) {
+            in.h0 = L.h; in.k = L.h.k; in.canonical = L.h.is_canonical(); in.hashed = L.h.is_hashed();
+            in.has_taxid = L.has_taxid;
+        } else {
+            check_compat(in.h0, L.h, files[i]);
+            if (!allow_mix && !o.ignore_taxid && L.has_taxid != in.has_taxid)
+                die(L.has_taxid ? "taxid information not found in previous files, but found in this: %s"
+                                : "taxid information found in previous files, but missing in this: %s", files[i].c_str());
+        }
+        in.any_taxid |= L.has_taxid;
+        if ((require_sorted_all || (require_sorted_first && i == 0)) && !L.h.is_sorted())
+            die(require_sorted_all ? "input should be sorted: %s" : "the first file should be sorted: %s", files[i].c_str());
+        in.total += L.codes.size();
+    }
+    return in;
+}
+struct Ptrs {
+    vector<const u64 *> k;
+    vector<const u32 *> t;
+    vector<u64> n;
+};
+static Ptrs ptrs_of(const Inputs &in, bool tax) {
+    Ptrs p;
+    for (auto &L : in.files) {
+        p.k.push_back(L.codes.data());
+        p.t.push_back(tax && L.has_taxid ? L.taxids.data() : nullptr);
+        p.n.push_back(L.codes.size());
+    }
+    return p;
+}
+static u32 out_mode(const Inputs &in, bool sorted, bool tax, const Options &o) {
+    u32 mode = 0;
+    if (sorted) mode |= unik::UnikSorted;
+    else if (o.compact && !in.hashed) mode |= unik::UnikCompact;
+    if (in.canonical) mode |= unik::UnikCanonical;
+    if (tax) mode |= unik::UnikIncludeTaxID;
+    if (in.hashed) mode |= unik::UnikHashed;
+    return mode;
+}
+
+enum SetCmd { C_UNION, C_INTER, C_DIFF, C_COMMON, C_SORT, C_MERGE };
+
+static int cmd_setop(SetCmd which, int argc, char **argv) {
+    vector<FlagSpec> specs = {{'o', "out-prefix", true}};
+    if (which == C_UNION) specs.push_back({'s', "sort", false});
+    if (which == C_INTER) specs.push_back({'m', "mix-taxid", false});
+    if (which == C_DIFF) { specs.push_back({'s', "sort", false}); specs.push_back({'t', "compare-taxid", false}); }
+    if (which == C_COMMON) { specs.push_back({'m', "mix-taxid", false}); specs.push_back({'p', "proportion", true}); specs.push_back({'n', "number", true}); }
+    if (which == C_SORT || which == C_MERGE) {
+        specs.push_back({'u', "unique", false}); specs.push_back({'d', "repeated", false});
+        specs.push_back({'M', "max-open-files", true}); specs.push_back({'t', "tmp-dir", true});
+        specs.push_back({'k', "keep-tmp-dir", false}); specs.push_back({0, "force", false});
+        if (which == C_SORT) specs.push_back({'m', "chunk-size", true});
+        else { specs.push_back({'D', "is-dir", false}); specs.push_back({'p', "pattern", true}); }
+    }
+    Args a = parse_args(argc, argv, specs);
+    Options o = get_options(a);
+    vector<string> files = get_files(a, o);
+    const string out_file = out_name(a.str("out-prefix", "-"));
+    const bool mix = a.has("mix-taxid");
+    const bool uniq = a.has("unique"), rep = a.has("repeated");
+    if (uniq && rep) die("flag -u/--unique overides -d/--repeated, do not give both");
+    if (which == C_MERGE && a.has("is-dir")) die("-D/--is-dir is not supported in this build: list the chunk files");
+
+    // single-input fast path of union / inter: the file is copied byte for byte (union.go:97-112, inter.go:96-120)
+    if ((which == C_UNION || which == C_INTER) && files.size() == 1 && files[0] != "-") {
+        if (which == C_INTER) { unik::Reader r(files[0]); if (!r.h.is_sorted() && !a.has("skip-flag-check")) die("input should be sorted: %s", files[0].c_str()); }
+        std::ifstream src(files[0], std::ios::binary);
+        if (out_file == "-") std::cout << src.rdbuf();
+        else { std::ofstream dst(out_file, std::ios::binary); dst << src.rdbuf(); }
+        return 0;
+    }
+
+    Inputs in = load_inputs(files, o, which == C_INTER && !a.has("skip-flag-check"), which == C_DIFF, mix);
+    bool tax = in.has_taxid || (mix && in.any_taxid);
+    if (which == C_DIFF) tax = in.has_taxid;  // taxid always from file 1 (diff.go:496-515)
+    Gpu g(o.gpu);
+    u32 max_taxid = o.max_taxid;
+    const bool cmp_taxid = which == C_DIFF && a.has("compare-taxid");
+    if (cmp_taxid && !in.has_taxid) die("flag -t/--compare-taxid given but no taxid information found");
+    const bool need_lca = (tax && which != C_DIFF) || cmp_taxid;
+    if (need_lca) max_taxid = load_taxonomy(g, o);
+    Ptrs p = ptrs_of(in, tax || cmp_taxid);
+    const int ns = (int)in.files.size();
+    u64 cap = in.total;
+    if (which == C_INTER || which == C_DIFF) cap = in.files[0].codes.size();
+    if (which == C_MERGE || which == C_SORT) cap = 2 * in.total;
+    vector<u64> out(cap ? cap : 1);
+    vector<u32> tout((tax || cmp_taxid) ? (cap ? cap : 1) : 0);
+    u64 n = 0;
+    const bool with_t = tax || cmp_taxid;
+    const u32 *const *tp = with_t ? p.t.data() : nullptr;
+    bool sorted_out = true;
+    switch (which) {
+    case C_UNION:
+        ck(ukm_union(g.c, p.k.data(), tp, p.n.data(), ns, 0, out.data(), with_t ? tout.data() : nullptr, cap, &n));
+        sorted_out = a.has("sort");  // same stream; the flag/encoding follow -s (union.go:220-235)
+        break;
+    case C_INTER:
+        ck(ukm_inter(g.c, p.k.data(), tp, p.n.data(), ns, mix ? UKM_F_MIX_TAXID : 0, out.data(), with_t ? tout.data() : nullptr, cap, &n));
+        if (n == 0) info("no intersection found");
+        break;
+    case C_DIFF: {
+        vector<uint8_t> sf;
+        for (auto &L : in.files) sf.push_back(L.h.is_sorted() ? 1 : 0);
+        // files equal (by path) to the first one are skipped (diff.go:464-466)
+        Ptrs q; vector<uint8_t> sf2;
+        for (int i = 0; i < ns; i++) if (i == 0 || files[(size_t)i] != files[0]) { q.k.push_back(p.k[(size_t)i]); q.t.push_back(p.t[(size_t)i]); q.n.push_back(p.n[(size_t)i]); sf2.push_back(sf[(size_t)i]); }
+        ck(ukm_diff(g.c, q.k.data(), with_t ? q.t.data() : nullptr, q.n.data(), (int)q.k.size(), sf2.data(),
+                    cmp_taxid ? UKM_F_CMP_TAXID : 0, out.data(), with_t ? tout.data() : nullptr, cap, &n));
+        if (n == 0) fprintf(stderr, "[WARN] no set difference found\n");
+        sorted_out = a.has("sort");
+        tax = in.has_taxid;
+        break;
+    }
+    case C_COMMON: {
+        const double prop = a.real("proportion", 1.0);
+        if (prop <= 0 || prop > 1) die("value of -p/--proportion should be in range of (0, 1]");
+        if (ns > 65535) die("at most 65535 files supported");
+        const u32 thr = ukm_common_threshold((u32)ns, prop, (u32)a.num("number", 0));
+        info("searching k-mers shared by >= %u files ...", thr);
+        ck(ukm_common(g.c, p.k.data(), tp, p.n.data(), ns, thr, 0, out.data(), with_t ? tout.data() : nullptr, cap, &n));
+        break;
+    }
+    case C_SORT: {
+        // sort.go:227-572: everything in HBM; -m chunking is not needed and is ignored
+        vector<u64> all; vector<u32> allt;
+        all.reserve(in.total);
+        for (auto &L : in.files) { all.insert(all.end(), L.codes.begin(), L.codes.end()); if (tax) allt.insert(allt.end(), L.taxids.begin(), L.taxids.end()); }
+        const int key_bits = in.hashed ? 64 : 2 * in.k;
+        if (!all.empty()) {
+            if (tax) ck(ukm_sort_pairs(g.c, all.data(), allt.data(), all.size(), key_bits));
+            else ck(ukm_sort_u64(g.c, all.data(), all.size(), key_bits));
+            ck(ukm_unique(g.c, all.data(), tax ? allt.data() : nullptr, all.size(), uniq ? UKM_UNIQUE : (rep ? UKM_REPEATED : UKM_PLAIN),
+                          out.data(), tax ? tout.data() : nullptr, cap, &n));
+        }
+        break;
+    }
+    case C_MERGE:
+        for (size_t i = 0; i < in.files.size(); i++) if (!in.files[i].h.is_sorted()) die("chunk file should be sorted: %s", files[i].c_str());
+        ck(ukm_merge_k(g.c, p.k.data(), tp, p.n.data(), ns, uniq ? UKM_UNIQUE : (rep ? UKM_REPEATED : UKM_PLAIN), 1, out.data(),
+                       with_t ? tout.data() : nullptr, cap, &n));
+        break;
+    }
+    const u32 mode = out_mode(in, sorted_out, tax, o);
+    // a global taxid shared by every input survives as the header's global taxid when no per-record taxids are written
+    write_unik(out_file, o, in.k, mode, max_taxid, 0, &in.h0, out.data(), tax ? tout.data() : nullptr, n);
+    return 0;
+}
+
+// =================================================================================================
+// CPU-only commands
+// =================================================================================================
+static std::unique_ptr<unik::OutStream> text_out(const string &file) {
+    const bool gz = file.size() > 3 && file.compare(file.size() - 3, 3, ".gz") == 0;  // "suffix .gz for gzipped out"
+    return std::unique_ptr<unik::OutStream>(new unik::OutStream(file, gz, 6));
+}
+static void put(unik::OutStream &o, const string &s) { o.write(s.data(), s.size()); }
+
+static int cmd_view(int argc, char **argv) {  // view.go:163-218
+    Args a = parse_args(argc, argv, {{'o', "out-file", true}, {'n', "show-code", false}, {'N', "show-code-only", false}, {'a', "fasta", false},
+                                     {'q', "fastq", false}, {'t', "show-taxid", false}, {'T', "show-taxid-only", false}, {'g', "genome", true}});
+    Options o = get_options(a);
+    vector<string> files = get_files(a, o);
+    if (a.has("genome")) die("-g/--genome is not supported in this build (hashed k-mers are printed as integers)");
+    auto out = text_out(a.str("out-file", "-"));
+    string buf;
+    for (auto &f : files) {
+        unik::Reader r(f);
+        const int k = r.h.k;
+        const bool hashed = r.h.is_hashed();
+        const string qual((size_t)k, 'g');
+        u64 code; u32 taxid;
+        while (r.read(code, taxid)) {
+            const string kmer = hashed ? std::to_string(code) : decode_kmer(code, k);
+            if (a.has("fasta")) buf += ">" + std::to_string(code) + (a.has("show-taxid") ? " " + std::to_string(taxid) : "") + "\n" + kmer + "\n";
+            else if (a.has("fastq")) buf += "@" + std::to_string(code) + (a.has("show-taxid") ? " " + std::to_string(taxid) : "") + "\n" + kmer + "\n+\n" + qual + "\n";
+            else if (a.has("show-taxid")) buf += kmer + "\t" + std::to_string(taxid) + "\n";
+            else if (a.has("show-taxid-only")) buf += std::to_string(taxid) + "\n";
+            else if (a.has("show-code-only")) buf += std::to_string(code) + "\n";
+            else if (a.has("show-code")) buf += kmer + "\t" + std::to_string(code) + "\n";
+            else buf += kmer + "\n";
+            if (buf.size() > (1u << 20)) { put(*out, buf); buf.clear(); }
+        }
+    }
+    put(*out, buf);
+    return 0;
+}
+
+static int cmd_dump(int argc, char **argv) {  // dump.go:128-315
+    Args a = parse_args(argc, argv, {{'o', "out-prefix", true}, {'u', "unique", false}, {'K', "canonical", false}, {'O', "canonical-only", false},
+                                     {'s', "sorted", false}, {'t', "taxid", true}, {'H', "hash", false}, {0, "hashed", false}, {'k', "kmer-len", true}});
+    Options o = get_options(a);
+    vector<string> files = get_files(a, o);
+    if (a.has("hash")) die("-H/--hash is not supported by dump in this build (use count -H)");
+    const bool hashed_already = a.has("hashed");
+    bool canonical = a.has("canonical");
+    const bool canonical_only = a.has("canonical-only"), sorted = a.has("sorted"), unique = a.has("unique");
+    int k = -1;
+    if (hashed_already) { canonical = true; k = (int)a.num("kmer-len", 0); if (k == 0) die("flag -k/--kmer-len should be given when --hashed given"); }
+    const u32 gtaxid = (u32)a.num("taxid", 0);
+    const string out_file = out_name(a.str("out-prefix", "-"));
+    unik::OutStream os(out_file, o.compress, o.level);
+    std::unique_ptr<unik::Writer> w;
+    std::set<u64> seen;
+    u64 n = 0;
+    bool include_taxid = false;
+    for (auto &f : files) {
+        unik::InStream in(f);
+        string text, chunk(1 << 20, '\0');
+        for (;;) { size_t got = in.read(&chunk[0], chunk.size()); if (!got) break; text.append(chunk.data(), got); }
+        std::istringstream ss(text);
+        string line;
+        while (std::getline(ss, line)) {
+            while (!line.empty() && (line.back() == '\r' || line.back() == ' ')) line.pop_back();
+            if (line.empty()) continue;
+            u32 taxid = 0;
+            string kmer = line;
+            size_t tab = line.find_first_of("\t ");
+            bool has_t = false;
+            if (tab != string::npos) { kmer = line.substr(0, tab); taxid = (u32)strtoul(line.c_str() + tab + 1, nullptr, 10); has_t = true; }
+            if (!w) {  // the first line fixes k and whether taxids are included (dump.go:139-223)
+                if (!hashed_already) k = (int)kmer.size();
+                if (k > 32 && !hashed_already) die("k-mer size (%d) should be <= 32", k);
+                include_taxid = has_t;
+                u32 mode = 0;
+                if (sorted) mode |= unik::UnikSorted;
+                else if (o.compact && !hashed_already) mode |= unik::UnikCompact;
+                if (canonical || canonical_only) mode |= unik::UnikCanonical;
+                if (include_taxid) mode |= unik::UnikIncludeTaxID;
+                if (hashed_already) mode |= unik::UnikHashed;
+                w.reset(new unik::Writer(os, k, mode));
+                w->set_max_taxid(o.max_taxid);
+                if (gtaxid && !include_taxid) w->set_global_taxid(gtaxid);
+            }
+            u64 code;
+            if (hashed_already) code = strtoull(kmer.c_str(), nullptr, 10);
+            else {
+                if ((int)kmer.size() != k) die("K-mer length mismatch, previous: %d, current: %zu. %s", k, kmer.size(), kmer.c_str());
+                if (!encode_kmer(kmer, code)) die("fail to encode '%s': illegal base", kmer.c_str());
+                const u64 rc = revcomp(code, k);
+                if (canonical_only) { if (rc < code) continue; }
+                else if (canonical && rc < code) code = rc;
+            }
+            if (unique && !seen.insert(code).second) continue;
+            if (include_taxid) w->write_code_with_taxid(code, taxid); else w->write_code(code);
+            n++;
+        }
+    }
+    if (!w) die("no k-mers given");
+    w->flush();
+    os.close();
+    info("%llu unique k-mers saved to %s", (unsigned long long)n, out_file.c_str());
+    return 0;
+}
+
+static string basename_of(const string &p) { size_t s = p.find_last_of('/'); return s == string::npos ? p : p.substr(s + 1); }
+
+static int cmd_num(int argc, char **argv) {  // num.go:60-131
+    Args a = parse_args(argc, argv, {{'o', "out-file", true}, {'n', "file-name", false}, {'b', "basename", false}, {'f', "force", false}});
+    Options o = get_options(a);
+    vector<string> files = get_files(a, o);
+    auto out = text_out(a.str("out-file", "-"));
+    for (auto &f : files) {
+        unik::Reader r(f);
+        long long n = (r.h.number == ~0ull || r.h.number == 0) ? -1 : (long long)r.h.number;
+        if (n < 0 && a.has("force")) { u64 c; u32 t; n = 0; while (r.read(c, t)) n++; }
+        string line = std::to_string(n);
+        if (a.has("file-name")) line += "\t" + (a.has("basename") ? basename_of(f) : f);
+        put(*out, line + "\n");
+    }
+    return 0;
+}
+
+static int cmd_info(int argc, char **argv) {  // info.go:377-421 (tabular form)
+    Args a = parse_args(argc, argv, {{'o', "out-file", true}, {'a', "all", false}, {'T', "tabular", false}, {'e', "skip-err", false},
+                                     {0, "symbol-true", true}, {0, "symbol-false", true}, {'b', "basename", false}});
+    Options o = get_options(a);
+    vector<string> files = get_files(a, o);
+    auto out = text_out(a.str("out-file", "-"));
+    const string T = a.str("symbol-true", "✓"), F = a.str("symbol-false", "✕");
+    string hdr = "file\tk\tcanonical\thashed\tscaled\tinclude-taxid\tglobal-taxid\tsorted";
+    if (a.has("all")) hdr += "\tcompact\tgzipped\tversion\tnumber\tdescription";
+    put(*out, hdr + "\n");
+    for (auto &f : files) {
+        unik::Reader r(f);
+        auto b = [&](bool v) { return v ? T : F; };
+        string line = (a.has("basename") ? basename_of(f) : f) + "\t" + std::to_string(r.h.k) + "\t" + b(r.h.is_canonical()) + "\t" + b(r.h.is_hashed()) +
+                      "\t" + b(r.h.is_scaled()) + "\t" + b(r.h.is_include_taxid()) + "\t" + (r.h.has_global_taxid() ? std::to_string(r.h.global_taxid) : "") +
+                      "\t" + b(r.h.is_sorted());
+        if (a.has("all")) {
+            long long n = (r.h.number == ~0ull || r.h.number == 0) ? -1 : (long long)r.h.number;
+            if (n < 0) { u64 c; u32 t; n = 0; while (r.read(c, t)) n++; }
+            line += "\t" + b(r.h.is_compact()) + "\t" + b(r.gzipped()) + "\tv" + std::to_string(r.h.main_version) + "." + std::to_string(r.h.minor_version) +
+                    "\t" + std::to_string(n) + "\t" + r.h.description;
+        }
+        put(*out, line + "\n");
+    }
+    return 0;
+}
+
+static int cmd_concat(int argc, char **argv) {  // concat.go:60-206
+    Args a = parse_args(argc, argv, {{'o', "out-prefix", true}, {'s', "sorted", false}, {'t', "taxid", true}, {'n', "number", true}});
+    Options o = get_options(a);
+    vector<string> files = get_files(a, o);
+    const string out_file = out_name(a.str("out-prefix", "-"));
+    unik::OutStream os(out_file, o.compress, o.level);
+    std::unique_ptr<unik::Writer> w;
+    unik::Header h0;
+    bool tax = false;
+    u64 n = 0;
+    for (size_t i = 0; i < files.size(); i++) {
+        unik::Reader r(files[i]);
+        if (!w) {
+            h0 = r.h;
+            tax = !o.ignore_taxid && r.h.has_taxid_info();
+            u32 mode = 0;
+            if (a.has("sorted")) mode |= unik::UnikSorted;
+            else if (o.compact && !r.h.is_hashed()) mode |= unik::UnikCompact;
+            if (r.h.is_canonical()) mode |= unik::UnikCanonical;
+            if (tax) mode |= unik::UnikIncludeTaxID;
+            if (r.h.is_hashed()) mode |= unik::UnikHashed;
+            w.reset(new unik::Writer(os, r.h.k, mode));
+            w->set_max_taxid(o.max_taxid);
+            if (r.h.is_scaled()) w->set_scale(r.h.scale, r.h.max_hash);
+            const long long num = a.num("number", -1);
+            w->set_number(num < 0 ? ~0ull : (u64)num);  // concat.go:69,143-145: unknown unless given
+        } else {
+            check_compat(h0, r.h, files[i]);
+        }
+        u64 c; u32 t;
+        while (r.read(c, t)) { if (tax) w->write_code_with_taxid(c, t); else w->write_code(c); n++; }
+    }
+    if (!w) die("no input");
+    w->flush();
+    os.close();
+    info("%llu k-mers saved to %s", (unsigned long long)n, out_file.c_str());
+    return 0;
+}
+
+static int cmd_head(int argc, char **argv) {  // head.go:60-163
+    Args a = parse_args(argc, argv, {{'o', "out-prefix", true}, {'n', "number", true}});
+    Options o = get_options(a);
+    vector<string> files = get_files(a, o);
+    if (files.size() > 1) die("no more than one file should be given");
+    const long long number = a.num("number", 10);
+    if (number <= 0) die("value of flag -n/--number should be positive");
+    unik::Reader r(files[0]);
+    const string out_file = out_name(a.str("out-prefix", "-"));
+    unik::OutStream os(out_file, o.compress, o.level);
+    unik::Header h = r.h;
+    unik::Writer w(os, h.k, h.flag & ~(u32)unik::UnikScaled);
+    w.h.taxid_bytes = h.taxid_bytes; w.h.global_taxid = h.global_taxid; w.h.description = h.description;
+    if (h.is_scaled()) w.set_scale(h.scale, h.max_hash);
+    u64 c; u32 t; long long n = 0;
+    vector<std::pair<u64, u32>> recs;
+    while (n < number && r.read(c, t)) { recs.push_back({c, t}); n++; }
+    w.set_number((u64)n);
+    for (auto &x : recs) { if (h.is_include_taxid()) w.write_code_with_taxid(x.first, x.second); else w.write_code(x.first); }
+    w.flush();
+    os.close();
+    return 0;
+}
+
+static int cmd_encode(int argc, char **argv) {  // encode.go:60-136 (2-bit codes only)
+    Args a = parse_args(argc, argv, {{'o', "out-file", true}, {'a', "all", false}, {'K', "canonical", false}, {'H', "hash", false}});
+    Options o = get_options(a);
+    if (a.has("hash")) die("-H/--hash is not supported by encode in this build");
+    vector<string> files = get_files(a, o);
+    auto out = text_out(a.str("out-file", "-"));
+    for (auto &f : files) {
+        unik::InStream in(f);
+        string text, chunk(1 << 20, '\0');
+        for (;;) { size_t got = in.read(&chunk[0], chunk.size()); if (!got) break; text.append(chunk.data(), got); }
+        std::istringstream ss(text);
+        string line;
+        while (std::getline(ss, line)) {
+            while (!line.empty() && (line.back() == '\r' || line.back() == ' ')) line.pop_back();
+            if (line.empty()) continue;
+            u64 code;
+            if (!encode_kmer(line, code)) die("fail to encode '%s'", line.c_str());
+            const int k = (int)line.size();
+            if (a.has("canonical")) code = std::min(code, revcomp(code, k));
+            if (a.has("all")) put(*out, line + "\t" + decode_kmer(code, k) + "\t" + std::to_string(code) + "\n");
+            else put(*out, std::to_string(code) + "\n");
+        }
+    }
+    return 0;
+}
+
+static int cmd_decode(int argc, char **argv) {  // decode.go:60-124
+    Args a = parse_args(argc, argv, {{'o', "out-file", true}, {'k', "kmer-len", true}, {'a', "all", false}});
+    Options o = get_options(a);
+    const int k = (int)a.num("kmer-len", 0);
+    if (k <= 0 || k > 32) die("invalid k: %d", k);
+    vector<string> files = get_files(a, o);
+    auto out = text_out(a.str("out-file", "-"));
+    const u64 maxcode = k == 32 ? ~0ull : ((1ull << (2 * k)) - 1);
+    for (auto &f : files) {
+        unik::InStream in(f);
+        string text, chunk(1 << 20, '\0');
+        for (;;) { size_t got = in.read(&chunk[0], chunk.size()); if (!got) break; text.append(chunk.data(), got); }
+        std::istringstream ss(text);
+        string line;
+        while (std::getline(ss, line)) {
+            if (line.empty()) continue;
+            const u64 code = strtoull(line.c_str(), nullptr, 10);
+            if (code > maxcode) die("encode integer overflows for k=%d, max: %llu", k, (unsigned long long)maxcode);  // decode.go:102-104
+            if (a.has("all")) put(*out, std::to_string(code) + "\t" + decode_kmer(code, k) + "\n");
+            else put(*out, decode_kmer(code, k) + "\n");
+        }
+    }
+    return 0;
+}
+
+static void usage() {
+    fprintf(stderr,
+            "unikmer (HIP) - k-mer set operations on AMD MI355X behind the unikmer command line\n\n"
+            "Usage: unikmer <command> [flags] [files]\n\n"
+            "GPU commands : count sort union inter diff common merge\n"
+            "CPU commands : view dump num info(stats) concat head encode decode version\n"
+            "Global flags : -j --verbose -C --compression-level -c -i -I --max-taxid --data-dir --gpu\n");
+}
+
+int main(int argc, char **argv) {
+    if (argc < 2) { usage(); return 0; }
+    const string cmd = argv[1];
+    argc -= 2; argv += 2;
+    try {
+        if (cmd == "count") return cmd_count(argc, argv);
+        if (cmd == "sort") return cmd_setop(C_SORT, argc, argv);
+        if (cmd == "union") return cmd_setop(C_UNION, argc, argv);
+        if (cmd == "inter") return cmd_setop(C_INTER, argc, argv);
+        if (cmd == "diff") return cmd_setop(C_DIFF, argc, argv);
+        if (cmd == "common") return cmd_setop(C_COMMON, argc, argv);
+        if (cmd == "merge") return cmd_setop(C_MERGE, argc, argv);
+        if (cmd == "view") return cmd_view(argc, argv);
+        if (cmd == "dump") return cmd_dump(argc, argv);
+        if (cmd == "num") return cmd_num(argc, argv);
+        if (cmd == "info" || cmd == "stats") return cmd_info(argc, argv);
+        if (cmd == "concat") return cmd_concat(argc, argv);
+        if (cmd == "head") return cmd_head(argc, argv);
+        if (cmd == "encode") return cmd_encode(argc, argv);
+        if (cmd == "decode") return cmd_decode(argc, argv);
+        if (cmd == "version") { printf("unikmer v%s\n", VERSION); return 0; }
+        if (cmd == "-h" || cmd == "--help" || cmd == "help") { usage(); return 0; }
+        die("unknown command \"%s\" for \"unikmer\"", cmd.c_str());
+    } catch (const unik::Error &e) {
+        die("%s", e.what());
+    } catch (const std::exception &e) {
+        die("%s", e.what());
+    }
+}
