@@ -182,3 +182,60 @@ def test_count_modes_on_gpu(cli, tmp_path):
         fh.write("@q1\n%s\n+\n%s\n" % (seq, "I" * len(seq)))
     cli("count", "-k", k, "-l", d + "/y.fq", "-o", d + "/fq")
     assert cli("view", d + "/fq.unik").stdout.decode().split() == exp[:len(seq) - k + 1]
+
+
+@pytest.mark.gpu
+def test_taxonomy_lca_through_cli(cli, tmp_path):
+    """union / inter / sort -u / diff -t with per-record taxids and a synthetic nodes.dmp +
+    merged.dmp (util.go:119-171); expected values from the oracle."""
+    from conftest import synth_tree
+    from oracle import oracle as O
+    d = str(tmp_path)
+    child, parent = synth_tree(depth=4, arity=4)
+    os.makedirs(d + "/tax")
+    with open(d + "/tax/nodes.dmp", "w") as fh:
+        for c, p in zip(child, parent):
+            fh.write("%d\t|\t%d\t|\tno rank\t|\n" % (c, p))
+    with open(d + "/tax/merged.dmp", "w") as fh:
+        fh.write("9000\t|\t7\t|\n")
+    tax = O.Taxonomy(child, parent, [9000], [7])
+    T = len(child)
+    rng = np.random.default_rng(5)
+    k = 13
+    files, taxs = [], []
+    for f in range(3):
+        codes = np.unique(rng.integers(0, 3000, 1500).astype(np.uint64))
+        t = rng.integers(1, T + 1, len(codes)).astype(np.uint32)
+        t[::50] = 9000                                   # a merged id
+        files.append(codes)
+        taxs.append(t)
+        kmers = ["".join("ACGT"[(int(c) >> (2 * (k - 1 - i))) & 3] for i in range(k)) for c in codes]
+        txt = "".join("%s\t%d\n" % (km, tt) for km, tt in zip(kmers, t)).encode()
+        cli("dump", "-s", "-o", d + "/f%d" % f, stdin=txt)
+    fs = [d + "/f%d.unik" % f for f in range(3)]
+
+    def view(name):
+        out = cli("view", "-N", name).stdout.split()
+        tx = cli("view", "-T", name).stdout.split()
+        return np.array([int(x) for x in out], dtype=np.uint64), np.array([int(x) for x in tx], dtype=np.uint32)
+
+    cli("union", "-s", "--data-dir", d + "/tax", *fs, "-o", d + "/u")
+    gk, gt = view(d + "/u.unik")
+    ok, ot = O.union(files, taxs, tax)
+    assert np.array_equal(gk, ok) and np.array_equal(gt, ot)
+    cli("inter", "--data-dir", d + "/tax", *fs, "-o", d + "/i")
+    gk, gt = view(d + "/i.unik")
+    ok, ot = O.inter(files, taxs, tax)
+    assert np.array_equal(gk, ok) and np.array_equal(gt, ot)
+    cli("diff", "-s", "-t", "--data-dir", d + "/tax", *fs, "-o", d + "/d")
+    gk, gt = view(d + "/d.unik")
+    ok, ot = O.diff(files, taxs, tax, compare_taxid=True)
+    assert np.array_equal(gk, ok) and np.array_equal(gt, ot)
+    cli("concat", *fs, "-o", d + "/c")
+    cli("sort", "-u", "--data-dir", d + "/tax", d + "/c.unik", "-o", d + "/su")
+    gk, gt = view(d + "/su.unik")
+    ok, ot = O.union(files, taxs, tax)                   # README.md:215-229 equivalence
+    assert np.array_equal(gk, ok) and np.array_equal(gt, ot)
+    # missing taxonomy directory -> error, not a silent zero
+    p = cli("union", "-s", "--data-dir", d + "/nope", *fs, "-o", d + "/x", ok=False)
+    assert p.returncode == 255 and b"taxonomy file not found" in p.stderr
