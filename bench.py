@@ -114,7 +114,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--n", type=float, default=1e9, help="k-mers per set per GPU")
+    ap.add_argument("--set-size", dest="n", type=float, default=1e9, help="k-mers per set per GPU")
     ap.add_argument("--cpu-sample", type=float, default=2e7, help="k-mers per set for the CPU baseline (0 = skip)")
     ap.add_argument("--no-exchange", action="store_true", help="skip the separate all-to-all timing at N>1")
     args = ap.parse_args()

@@ -95,6 +95,12 @@ struct TileGeom {
     u64 a0, b0;
     int na_t, nb_t;
     bool has_prev_a, has_prev_b, has_next_a, has_next_b;
+    // LDS slots:  [sa0] prevA | A items [base_a, end_a) | [end_a] nextA | pad | [sb0] prevB |
+    //             B items [base_b, end_b) | [end_b] nextB
+    // sa0 / sb0 carry a one-slot parity offset so that an EVEN slot always holds an element
+    // whose global address is 16-byte aligned: pairs of slots then move with one dwordx4 load,
+    // one ds_write_b128 and (on the way out) one dwordx4 store.
+    int sa0, base_a, end_a, sb0, base_b, end_b, split;  // split = first (even) slot of region B
 };
 
 template <int NTH, int VT>
@@ -110,89 +116,129 @@ __device__ __forceinline__ TileGeom tile_geom(const SetopArgs &p, u64 tile) {
     g.na_t = (int)(a1 - a0); g.nb_t = (int)(b1 - b0);
     g.has_prev_a = a0 > 0; g.has_prev_b = b0 > 0;
     g.has_next_a = a1 < p.na; g.has_next_b = b1 < p.nb;
+    // parity (in 8-byte units) of the address of a[a0 - 1] / b[b0 - 1]
+    g.sa0 = (int)((((uintptr_t)p.a >> 3) + a0 + 1) & 1);
+    g.base_a = g.sa0 + 1;
+    g.end_a = g.base_a + g.na_t;
+    g.split = (g.end_a + 2) & ~1;
+    g.sb0 = g.split + (int)((((uintptr_t)p.b >> 3) + b0 + 1) & 1);
+    g.base_b = g.sb0 + 1;
+    g.end_b = g.base_b + g.nb_t;
     return g;
 }
 
-// LDS slots: [0] prevA | A items [1, 1+na_t) | nextA | prevB | B items | nextB
-// Missing halos are filled with 0 (prev) / ~0 (next) so that the order check cannot fire on them.
-// Coalesced global loads of the tile (+halos) into registers; nothing is waited for here.
+// pairs of LDS slots each thread moves: ceil((TILE + 8) / 2 / NTH)
+template <int NTH, int VT> struct TilePairs { static constexpr int NP = ((NTH * VT + 8) / 2 + NTH - 1) / NTH; };
+
+// Coalesced global loads of the tile (+halos) into registers, two slots per load; nothing is
+// waited for here.
 template <bool TAX, bool RANK, int NTH, int VT>
-__device__ __forceinline__ void tile_load(const SetopArgs &p, const TileGeom &g, int tid, u64 (&rk)[VT + 1],
-                                          u32 (&rt)[VT + 1], u32 (&rr)[VT + 1]) {
-    const int split = g.na_t + 2;  // first slot of the B region (prevB halo)
-    const int alo = g.has_prev_a ? 0 : 1;
-    const int ahi = g.na_t + 1 + (g.has_next_a ? 1 : 0);
-    const int blo = split + (g.has_prev_b ? 0 : 1);
-    const int bhi = split + g.nb_t + 1 + (g.has_next_b ? 1 : 0);
-    // slot i of region A is a[a0 - 1 + i]; slot i of region B is b[b0 - 1 + i - split]
-    const u64 *pa = p.a + g.a0 - 1;
-    const u64 *pb = p.b + g.b0 - 1 - split;
-    const u32 *pta = TAX && p.ta ? p.ta + g.a0 - 1 : nullptr;
-    const u32 *ptb = TAX && p.tb ? p.tb + g.b0 - 1 - split : nullptr;
-    const u32 *pra = RANK ? p.ra + g.a0 - 1 : nullptr;
-    const u32 *prb = RANK ? p.rb + g.b0 - 1 - split : nullptr;
+__device__ __forceinline__ void tile_load(const SetopArgs &p, const TileGeom &g, int tid,
+                                          u64 (&rk)[2 * TilePairs<NTH, VT>::NP], u32 (&rt)[2 * TilePairs<NTH, VT>::NP],
+                                          u32 (&rr)[2 * TilePairs<NTH, VT>::NP]) {
+    constexpr int NP = TilePairs<NTH, VT>::NP;
+    const int alo = g.sa0 + (g.has_prev_a ? 0 : 1), ahi = g.end_a + (g.has_next_a ? 1 : 0);
+    const int blo = g.sb0 + (g.has_prev_b ? 0 : 1), bhi = g.end_b + (g.has_next_b ? 1 : 0);
+    // slot s of region A is a[a0 - 1 + (s - sa0)]; slot s of region B is b[b0 - 1 + (s - sb0)]
+    const u64 *pa = p.a + g.a0 - 1 - g.sa0;
+    const u64 *pb = p.b + g.b0 - 1 - g.sb0;
+    const u32 *pta = TAX && p.ta ? p.ta + g.a0 - 1 - g.sa0 : nullptr;
+    const u32 *ptb = TAX && p.tb ? p.tb + g.b0 - 1 - g.sb0 : nullptr;
+    const u32 *pra = RANK ? p.ra + g.a0 - 1 - g.sa0 : nullptr;
+    const u32 *prb = RANK ? p.rb + g.b0 - 1 - g.sb0 : nullptr;
+    // Every load below is UNCONDITIONAL (idle lanes read a harmless aligned word of the control
+    // block): a branch around a load makes the compiler wait for the previous one at the join
+    // (measured: vmcnt(0) in front of every dwordx4, kernel 30 % slower).
+    const u64 *safe = p.result;  // 256-byte aligned, always mapped
+    const u32 *safe32 = reinterpret_cast<const u32 *>(p.result);
 #pragma unroll
-    for (int j = 0; j < VT + 1; j++) {
-        const int i = tid + j * NTH;
-        const bool in_a = i < split;
+    for (int j = 0; j < NP; j++) {
+        const int s0 = 2 * (tid + j * NTH), s1 = s0 + 1;
+        const bool in_a = s0 < g.split;
         const int lo = in_a ? alo : blo, hi = in_a ? ahi : bhi;
-        const bool valid = i >= lo && i < hi;
+        const bool v0 = s0 >= lo && s0 < hi, v1 = s1 >= lo && s1 < hi;
+        const bool both = v0 && v1;
         const u64 *src = in_a ? pa : pb;
-        u64 v = (i >= hi) ? ~0ull : 0ull;
-        u32 tv = 0, rv = 0;
-        if (valid) {
-            v = src[i];
-            if (TAX) {
-                const u32 *ts = in_a ? pta : ptb;
-                if (ts) tv = ts[i];
-            }
-            if (RANK) rv = (in_a ? pra : prb)[i];
+        const ulonglong2 q = *reinterpret_cast<const ulonglong2 *>(both ? src + s0 : safe);  // aligned by construction
+        rk[2 * j] = q.x;      // slots without a real element keep whatever was read: they are
+        rk[2 * j + 1] = q.y;  // never compared (order check and merge only touch real slots)
+        u32 t0 = 0, t1 = 0, r0 = 0, r1 = 0;
+        if (TAX) {
+            const u32 *ts = in_a ? pta : ptb;
+            const bool h0 = ts && v0, h1 = ts && v1;
+            t0 = *(h0 ? ts + s0 : safe32);
+            t1 = *(h1 ? ts + s1 : safe32);
+            t0 = ts ? t0 : 0u;  // a stream without taxids contributes taxid 0 (mix-taxid)
+            t1 = ts ? t1 : 0u;
         }
-        rk[j] = v;
-        rt[j] = tv;
-        rr[j] = rv;
+        if (RANK) {
+            const u32 *rs = in_a ? pra : prb;
+            r0 = *(v0 ? rs + s0 : safe32);
+            r1 = *(v1 ? rs + s1 : safe32);
+        }
+        rt[2 * j] = t0; rt[2 * j + 1] = t1;
+        rr[2 * j] = r0; rr[2 * j + 1] = r1;
+    }
+    // the (at most four) pairs per tile with exactly one real element, at the region edges
+#pragma unroll
+    for (int j = 0; j < NP; j++) {
+        const int s0 = 2 * (tid + j * NTH), s1 = s0 + 1;
+        const bool in_a = s0 < g.split;
+        const int lo = in_a ? alo : blo, hi = in_a ? ahi : bhi;
+        const bool v0 = s0 >= lo && s0 < hi, v1 = s1 >= lo && s1 < hi;
+        if (v0 != v1) {
+            const u64 *src = in_a ? pa : pb;
+            if (v0) rk[2 * j] = src[s0]; else rk[2 * j + 1] = src[s1];
+        }
     }
 }
 
 template <bool TAX, bool RANK, int NTH, int VT>
-__device__ __forceinline__ void tile_to_lds(int tid, const u64 (&rk)[VT + 1], const u32 (&rt)[VT + 1],
-                                            const u32 (&rr)[VT + 1], u64 *s_keys, u32 *s_tax, u32 *s_rank) {
-    constexpr int SLOTS = NTH * VT + 4;
+__device__ __forceinline__ void tile_to_lds(int tid, const u64 (&rk)[2 * TilePairs<NTH, VT>::NP],
+                                            const u32 (&rt)[2 * TilePairs<NTH, VT>::NP],
+                                            const u32 (&rr)[2 * TilePairs<NTH, VT>::NP], u64 *s_keys, u32 *s_tax,
+                                            u32 *s_rank) {
+    constexpr int NP = TilePairs<NTH, VT>::NP;
+    constexpr int SLOTS = NTH * VT + 8;
 #pragma unroll
-    for (int j = 0; j < VT + 1; j++) {
-        const int i = tid + j * NTH;
-        if (i < SLOTS) {
-            s_keys[i] = rk[j];
-            if (TAX) s_tax[i] = rt[j];
-            if (RANK) s_rank[i] = rr[j];
+    for (int j = 0; j < NP; j++) {
+        const int s0 = 2 * (tid + j * NTH);
+        if (s0 < SLOTS) {
+            *reinterpret_cast<ulonglong2 *>(s_keys + s0) = make_ulonglong2(rk[2 * j], rk[2 * j + 1]);
+            if (TAX) *reinterpret_cast<uint2 *>(s_tax + s0) = make_uint2(rt[2 * j], rt[2 * j + 1]);
+            if (RANK) *reinterpret_cast<uint2 *>(s_rank + s0) = make_uint2(rr[2 * j], rr[2 * j + 1]);
         }
     }
 }
 
-// Strict-order check of both inputs as one vector pass over the LDS tile (call after the
-// barrier that follows tile_to_lds): slot i against slot i-1, skipping the seam between the
-// two regions and the missing-halo slots.  Replaces two 64-bit compares per merge step.
+// Strict-order check of both inputs as one vector pass (call after the barrier that follows
+// tile_to_lds).  A slot is compared with its predecessor only when both hold real elements of
+// the same input; the in-pair comparison uses the registers, the cross-pair one a single LDS
+// read.  Replaces two 64-bit compares per merge step.
 template <bool RANK, int NTH, int VT>
-__device__ __forceinline__ u32 tile_check_order(const TileGeom &g, int tid, const u64 (&rk)[VT + 1],
-                                                const u32 (&rr)[VT + 1], const u64 *s_keys, const u32 *s_rank) {
-    const int split = g.na_t + 2;
-    const int total4 = g.na_t + g.nb_t + 4;
-    const int skip_a = g.has_prev_a ? -1 : 1;          // slot 1 has no real predecessor
-    const int skip_b = g.has_prev_b ? -1 : split + 1;  // first B item has no real predecessor
+__device__ __forceinline__ u32 tile_check_order(const TileGeom &g, int tid, const u64 (&rk)[2 * TilePairs<NTH, VT>::NP],
+                                                const u32 (&rr)[2 * TilePairs<NTH, VT>::NP], const u64 *s_keys,
+                                                const u32 *s_rank) {
+    constexpr int NP = TilePairs<NTH, VT>::NP;
+    const int alo = g.sa0 + (g.has_prev_a ? 0 : 1), ahi = g.end_a + (g.has_next_a ? 1 : 0);
+    const int blo = g.sb0 + (g.has_prev_b ? 0 : 1), bhi = g.end_b + (g.has_next_b ? 1 : 0);
     u32 bad = 0;
 #pragma unroll
-    for (int j = 0; j < VT + 1; j++) {
-        const int i = tid + j * NTH;
-        // branch-free: always read a valid slot, fold the predicate into the flag
-        const bool chk = (i >= 1) & (i < total4) & (i != split) & (i != skip_a) & (i != skip_b);
-        const int ip = chk ? i - 1 : 0;
-        const u64 pk = s_keys[ip], ck = rk[j];
+    for (int j = 0; j < NP; j++) {
+        const int s0 = 2 * (tid + j * NTH), s1 = s0 + 1;
+        const bool in_a = s0 < g.split;
+        const int lo = in_a ? alo : blo, hi = in_a ? ahi : bhi;
+        // (s-1, s) is a real adjacent pair of one input iff lo < s < hi
+        const bool c0 = s0 > lo && s0 < hi, c1 = s1 > lo && s1 < hi;
+        const int ip = c0 ? s0 - 1 : 0;
+        const u64 pk = s_keys[ip], k0 = rk[2 * j], k1 = rk[2 * j + 1];
         if (RANK) {
-            const u32 pr = s_rank[ip], cr = rr[j];
-            bad |= (chk & ((pk > ck) | ((pk == ck) & (pr >= cr) & (ck != ~0ull)))) ? FLAG_UNSORTED : 0u;
+            const u32 pr = s_rank[ip], r0 = rr[2 * j], r1 = rr[2 * j + 1];
+            bad |= (c0 & ((pk > k0) | ((pk == k0) & (pr >= r0)))) ? FLAG_UNSORTED : 0u;
+            bad |= (c1 & ((k0 > k1) | ((k0 == k1) & (r0 >= r1)))) ? FLAG_UNSORTED : 0u;
         } else {
-            bad |= (chk & (pk > ck)) ? FLAG_UNSORTED : 0u;
-            bad |= (chk & (pk == ck) & (ck != ~0ull)) ? FLAG_DUP : 0u;
+            bad |= ((c0 & (pk > k0)) | (c1 & (k0 > k1))) ? FLAG_UNSORTED : 0u;
+            bad |= ((c0 & (pk == k0)) | (c1 & (k0 == k1))) ? FLAG_DUP : 0u;
         }
     }
     return bad;
@@ -212,9 +258,7 @@ template <int OP, bool TAX, bool RANK, bool INTERIOR, int VT>
 __device__ __forceinline__ void tile_merge_loop(const SetopArgs &p, const TileGeom &g, int pa, int pb,
                                                 const u64 *s_keys, const u32 *s_tax, const u32 *s_rank,
                                                 u64 (&ok)[VT], u32 (&ot)[VT], u32 &mask) {
-    const int na_t = g.na_t, nb_t = g.nb_t;
-    const int base_a = 1, end_a = 1 + na_t;
-    const int base_b = na_t + 3, end_b = base_b + nb_t;
+    const int base_a = g.base_a, end_a = g.end_a, end_b = g.end_b;
     const int end_bx = end_b + (g.has_next_b ? 1 : 0);
     u64 ak = s_keys[pa], bk = s_keys[pb];
     u32 ar = 0, br = 0;
@@ -290,7 +334,7 @@ __device__ __forceinline__ void tile_merge(const SetopArgs &p, const TileGeom &g
                                            const u32 *s_tax, const u32 *s_rank, u64 (&ok)[VT], u32 (&ot)[VT],
                                            u32 &mask) {
     const int na_t = g.na_t, nb_t = g.nb_t, total = na_t + nb_t;
-    const int base_a = 1, base_b = na_t + 3;
+    const int base_a = g.base_a, base_b = g.base_b;
     int diag = tid * VT;
     if (diag > total) diag = total;
     int lo = diag > nb_t ? diag - nb_t : 0;
@@ -324,16 +368,26 @@ __device__ __forceinline__ void tile_compact(u32 excl, u32 mask, const u64 (&ok)
     }
 }
 
-// LDS -> HBM: contiguous coalesced run of `count` records at out[base ...)
+// LDS -> HBM: contiguous coalesced run of `count` records at out[base ...), 16 bytes per store
+// where the global address allows it (the first/last record may go out alone).
 template <bool TAX, int NTH>
 __device__ __forceinline__ void tile_flush(const SetopArgs &p, int tid, u64 base, u32 count, const u64 *s_keys,
                                            const u32 *s_tax) {
     if (base + count <= p.out_cap) {
         u64 *o = p.out + base;
-        u32 *to = TAX ? p.tout + base : nullptr;
-        for (u32 i = (u32)tid; i < count; i += NTH) {
-            o[i] = s_keys[i];
-            if (TAX) to[i] = s_tax[i];
+        const int sh = (int)(((uintptr_t)o >> 3) & 1);  // 1: o[0] sits on an odd 8-byte slot
+        const int npairs = ((int)count + sh + 1) >> 1;
+        for (int m = tid; m < npairs; m += NTH) {
+            const int i0 = 2 * m - sh, i1 = i0 + 1;
+            const bool v0 = i0 >= 0, v1 = i1 < (int)count;
+            const u64 k0 = s_keys[v0 ? i0 : 0], k1 = s_keys[v1 ? i1 : 0];
+            if (v0 && v1) *reinterpret_cast<ulonglong2 *>(o + i0) = make_ulonglong2(k0, k1);
+            else if (v0) o[i0] = k0;
+            else if (v1) o[i1] = k1;
+        }
+        if (TAX) {
+            u32 *to = p.tout + base;
+            for (u32 i = (u32)tid; i < count; i += NTH) to[i] = s_tax[i];
         }
     } else {  // capacity overflow: guarded stores; the host reports UKM_ERR_CAPACITY
         for (u32 i = (u32)tid; i < count; i += NTH) {
@@ -358,10 +412,11 @@ __device__ __forceinline__ void tile_flush(const SetopArgs &p, int tid, u64 base
 template <int OP, bool TAX, bool RANK, bool TICKET, int NTH, int VT>
 __global__ __launch_bounds__(NTH) void setop_tile_kernel(SetopArgs p) {
     constexpr int TILE = NTH * VT;
-    constexpr int SLOTS = TILE + 4;
-    __shared__ u64 s_keys[SLOTS];
-    __shared__ u32 s_tax[TAX ? SLOTS : 1];
-    __shared__ u32 s_rank[RANK ? SLOTS : 1];
+    constexpr int SLOTS = TILE + 8;
+    constexpr int NP = TilePairs<NTH, VT>::NP;
+    __shared__ __attribute__((aligned(16))) u64 s_keys[SLOTS];
+    __shared__ __attribute__((aligned(16))) u32 s_tax[TAX ? SLOTS : 2];
+    __shared__ __attribute__((aligned(16))) u32 s_rank[RANK ? SLOTS : 2];
     __shared__ u32 s_scan[NTH / 64 + 1];
     __shared__ u64 s_misc[2];
     const int tid = (int)threadIdx.x;
@@ -379,8 +434,8 @@ __global__ __launch_bounds__(NTH) void setop_tile_kernel(SetopArgs p) {
     const TileGeom g = tile_geom<NTH, VT>(p, tile);
     u32 bad;
     {
-        u64 rk[VT + 1];
-        u32 rt[VT + 1], rr[VT + 1];
+        u64 rk[2 * NP];
+        u32 rt[2 * NP], rr[2 * NP];
         tile_load<TAX, RANK, NTH, VT>(p, g, tid, rk, rt, rr);
         tile_to_lds<TAX, RANK, NTH, VT>(tid, rk, rt, rr, s_keys, s_tax, s_rank);
         __syncthreads();
