@@ -3,12 +3,14 @@
 // (util-sort.go:35-190).  Plus two small primitives used across the library: sortedness check
 // and a single-pass exclusive scan of uint64.
 //
-// Unique kernel: one 256-thread workgroup per tile of NT*VT records; keys are loaded coalesced
-// into LDS with a one-element halo on both sides; run heads are found by adjacent comparison;
-// each head emits 0, 1 or 2 records according to the mode; the per-code taxid is the LCA fold
-// over the run (associative + commutative on a tree, so fold order is immaterial); output
-// offsets come from the same single-pass decoupled look-back as the set operations, so the
-// stream is read once and written once: 8n (+4n) bytes in, 8u (+4u) bytes out.
+// Unique kernel: one 512-thread workgroup per tile of 8192 records, striped across the threads;
+// keys are loaded coalesced into LDS with a one-element halo on both sides; run heads are found
+// by adjacent comparison (conflict-free neighbour reads); each head emits 0, 1 or 2 records
+// according to the mode; the per-code taxid is the LCA fold over the run (associative +
+// commutative on a tree, so fold order is immaterial); positions come from one wave64 ballot
+// per round plus a 128-entry prefix per tile, compaction is in place, and the global offset
+// from the same single-pass decoupled look-back as the set operations: the stream is read
+// once and written once: 8n (+4n) bytes in, 8u (+4u) bytes out.
 #include <algorithm>
 
 #include "ukm_device.h"
@@ -18,9 +20,9 @@
 
 namespace {
 
-constexpr int NT = 256;
-constexpr int VT = 8;
-constexpr int TILE = NT * VT;
+constexpr int NT = 256;   // exclusive-scan kernel
+constexpr int UNT = 512;  // unique kernel: threads per workgroup
+constexpr int UVT = 16;   // records per thread (8192-record tiles; 8 for the chunk protocol)
 
 struct UniqArgs {
     const u64 *k;
@@ -38,92 +40,165 @@ struct UniqArgs {
     u32 threshold;
 };
 
-template <bool TAX>
-__global__ __launch_bounds__(NT) void unique_tile_kernel(UniqArgs p) {
-    __shared__ u64 s_keys[TILE + 2];
-    __shared__ u64 s_outk[2 * TILE];  // REPEATED_CHUNK can emit two records per input
-    __shared__ u32 s_outt[TAX ? 2 * TILE : 1];
-    __shared__ u32 s_scan[NT / 64 + 1];
+// Striped layout: thread t handles records t, t+NT, t+2NT, ... of the tile, so that
+//   * global loads are coalesced and the prev/next neighbours of a record sit in the adjacent
+//     LDS slots read by the adjacent lanes (bank-conflict free; the first version read 16-slot
+//     strided blocks per thread: 8-16-way conflicts),
+//   * an emitted record's position is (records emitted in earlier (round, wave) groups) +
+//     (emitting lower lanes in its own wave) = one wave64 ballot per round plus one 128-entry
+//     prefix per tile — no per-thread output arrays, compaction in place over the input tile.
+// CHUNK = the REPEATED_CHUNK protocol (up to two output records per input record).
+template <bool TAX, bool CHUNK, int VTU>
+__global__ __launch_bounds__(UNT) void unique_tile_kernel(UniqArgs p) {
+    constexpr int TILE_U = UNT * VTU;
+    constexpr int NWU = UNT / 64;
+    constexpr int OUT_SLOTS = CHUNK ? 2 * TILE_U : TILE_U;
+    __shared__ __attribute__((aligned(16))) u64 s_keys[(OUT_SLOTS > TILE_U + 2 ? OUT_SLOTS : TILE_U + 2)];
+    __shared__ u32 s_tax[TAX ? OUT_SLOTS : 1];
+    __shared__ u32 s_cnt[VTU * NWU + 1];
     __shared__ u64 s_misc[2];
-    const int tid = (int)threadIdx.x;
+    const int tid = (int)threadIdx.x, lane = lane_id(), wave = tid >> 6;
     if (tid == 0) s_misc[0] = (u64)atomicAdd(p.ticket, 1u);
     __syncthreads();
     const u64 tile = s_misc[0];
-    const u64 i0 = tile * (u64)TILE;
-    const int cnt_t = (int)((p.n - i0 < (u64)TILE) ? (p.n - i0) : (u64)TILE);
+    const u64 i0 = tile * (u64)TILE_U;
+    const int cnt_t = (int)((p.n - i0 < (u64)TILE_U) ? (p.n - i0) : (u64)TILE_U);
 
-    // slot j holds k[i0 + j - 1]
-    for (int j = tid; j < cnt_t + 2; j += NT) {
-        long long g = (long long)i0 + j - 1;
-        s_keys[j] = (g >= 0 && (u64)g < p.n) ? p.k[g] : 0;
+    // slot j holds k[i0 + j - 1]: halo | tile | halo
+    u64 key[VTU];
+#pragma unroll
+    for (int s = 0; s < VTU; s++) {
+        const int j = tid + s * UNT;
+        key[s] = (j < cnt_t) ? p.k[i0 + j] : 0;
+    }
+    if (tid == 0) s_keys[0] = (i0 > 0) ? p.k[i0 - 1] : 0;
+    if (tid == 64) s_keys[cnt_t + 1] = (i0 + cnt_t < p.n) ? p.k[i0 + cnt_t] : 0;
+#pragma unroll
+    for (int s = 0; s < VTU; s++) {
+        const int j = tid + s * UNT;
+        if (j < cnt_t) s_keys[j + 1] = key[s];
     }
     __syncthreads();
 
-    u64 ok[2 * VT];
-    u32 ot[2 * VT];
-    int ne = 0;
-    u32 bad = 0;
     const int mode = p.mode;
+    u32 bad = 0;
+    u32 emit1 = 0, emit2 = 0;  // bit s: record of round s is emitted once / a second time
+    u32 tx[TAX ? VTU : 1];
 #pragma unroll
-    for (int s = 0; s < VT; s++) {
-        const int j = tid * VT + s;  // local index
-        if (j < cnt_t) {
-            const u64 gi = i0 + j;
-            const u64 key = s_keys[j + 1];
-            const bool has_prev = gi > 0, has_next = gi + 1 < p.n;
-            const u64 prev = s_keys[j], next = s_keys[j + 2];
-            if (has_prev && prev > key) bad |= 2;
-            const bool head = !has_prev || prev != key;
-            const bool tail = !has_next || next != key;
-            int emit = 0;
-            u32 tx = 0;
-            if (mode == UKM_UNIQUE_LAST) {
-                emit = tail ? 1 : 0;
-                if (TAX && tail) tx = p.t[gi];
-            } else if (head && mode == UKM_COMMON) {
+    for (int s = 0; s < VTU; s++) {
+        const int j = tid + s * UNT;
+        const bool in = j < cnt_t;
+        const u64 gi = i0 + (u64)j;
+        const u64 k = key[s];
+        const u64 prev = s_keys[in ? j : 0], next = s_keys[in ? j + 2 : 0];
+        const bool has_prev = gi > 0, has_next = gi + 1 < p.n;
+        if (in && has_prev && prev > k) bad |= 2;
+        const bool head = in && (!has_prev || prev != k);
+        const bool tail = in && (!has_next || next != k);
+        const bool repeated = !tail;
+        bool e1 = false, e2 = false;
+        if (mode == UKM_UNIQUE) e1 = head;
+        else if (mode == UKM_REPEATED) e1 = head && repeated;
+        else if (mode == UKM_SINGLETON) e1 = head && !repeated;
+        else if (mode == UKM_REPEATED_CHUNK) { e1 = head; e2 = head && repeated; }
+        else if (mode == UKM_UNIQUE_LAST) e1 = tail;
+        u32 t = 0;
+        if (mode == UKM_COMMON) {
+            if (head) {  // run length against the threshold (common.go:331-335), LCA over the run
                 u64 len = 1;
-                for (u64 q = gi + 1; q < p.n && p.k[q] == key && (TAX || len < p.threshold); q++) len++;
-                emit = (len >= p.threshold) ? 1 : 0;
-                if (TAX && emit) {
-                    tx = p.t[gi];
-                    for (u64 q = gi + 1; q < gi + len; q++) tx = lca_dev(p.tax, tx, p.t[q]);  // common.go:265
-                }
-            } else if (head) {
-                const bool repeated = !tail;
-                if (mode == UKM_UNIQUE) emit = 1;
-                else if (mode == UKM_REPEATED) emit = repeated ? 1 : 0;
-                else if (mode == UKM_SINGLETON) emit = repeated ? 0 : 1;
-                else emit = repeated ? 2 : 1;  // UKM_REPEATED_CHUNK
-                if (TAX && emit) {
-                    tx = p.t[gi];
-                    for (u64 q = gi + 1; q < p.n && p.k[q] == key; q++)
-                        tx = lca_dev(p.tax, p.t[q], tx);  // sort.go:491 lca = LCA(taxid, lca)
+                for (u64 q = gi + 1; q < p.n && p.k[q] == k && (TAX || len < p.threshold); q++) len++;
+                e1 = len >= p.threshold;
+                if (TAX && e1) {
+                    t = p.t[gi];
+                    for (u64 q = gi + 1; q < gi + len; q++) t = lca_dev(p.tax, t, p.t[q]);  // common.go:265
                 }
             }
-            if (emit >= 1) { ok[ne] = key; ot[ne] = tx; ne++; }
-            if (emit == 2) { ok[ne] = key; ot[ne] = tx; ne++; }
+        } else if (TAX) {
+            if (mode == UKM_UNIQUE_LAST) {
+                if (e1) t = p.t[gi];
+            } else if (e1) {
+                t = p.t[gi];
+                if (repeated)
+                    for (u64 q = gi + 1; q < p.n && p.k[q] == k; q++) t = lca_dev(p.tax, p.t[q], t);  // sort.go:491
+            }
+        }
+        if (TAX) tx[s] = t;
+        emit1 |= e1 ? (1u << s) : 0u;
+        emit2 |= e2 ? (1u << s) : 0u;
+    }
+    // per (round, wave) output counts; records are ordered round-major, then wave, then lane
+    u32 pos_in_group[VTU];
+#pragma unroll
+    for (int s = 0; s < VTU; s++) {
+        const bool e1 = (emit1 >> s) & 1u, e2 = (emit2 >> s) & 1u;
+        const u64 m1 = __ballot(e1);
+        const u64 lt = (1ull << lane) - 1;
+        u32 before = (u32)__popcll(m1 & lt), total = (u32)__popcll(m1);
+        if (CHUNK) {
+            const u64 m2 = __ballot(e2);
+            before += (u32)__popcll(m2 & lt);
+            total += (u32)__popcll(m2);
+        }
+        pos_in_group[s] = before;
+        if (lane == 0) s_cnt[s * NWU + wave] = total;
+    }
+    __syncthreads();  // also: every thread is done reading the input tile from LDS
+    if (tid < 64) {   // exclusive prefix over the VTU*NWU groups (<= 128 entries: two per lane)
+        constexpr int NG = VTU * NWU;
+        const int e0 = 2 * lane, e1i = 2 * lane + 1;
+        const u32 c0 = e0 < NG ? s_cnt[e0] : 0, c1 = e1i < NG ? s_cnt[e1i] : 0;
+        const u32 incl = wave_incl_scan_u32(c0 + c1);
+        const u32 ex = incl - (c0 + c1);
+        if (e0 < NG) s_cnt[e0] = ex;
+        if (e1i < NG) s_cnt[e1i] = ex + c0;
+        if (lane == 63) s_cnt[NG] = incl;
+    }
+    __syncthreads();
+    const u32 tile_total = s_cnt[VTU * NWU];
+    if (tid == 0) lb_publish(p.status, tile, (u64)tile_total);
+#pragma unroll
+    for (int s = 0; s < VTU; s++) {
+        const bool e1 = (emit1 >> s) & 1u, e2 = (emit2 >> s) & 1u;
+        if (e1) {
+            const u32 w = s_cnt[s * NWU + wave] + pos_in_group[s];
+            s_keys[w] = key[s];
+            if (TAX) s_tax[w] = tx[s];
+            if (CHUNK && e2) {
+                s_keys[w + 1] = key[s];
+                if (TAX) s_tax[w + 1] = tx[s];
+            }
         }
     }
-    u32 tile_total;
-    const u32 excl = block_excl_scan_u32<NT>((u32)ne, s_scan, &tile_total);
-#pragma unroll
-    for (int s = 0; s < 2 * VT; s++)
-        if (s < ne) {
-            s_outk[excl + s] = ok[s];
-            if (TAX) s_outt[excl + s] = ot[s];
-        }
     if (tid < 64) {
-        u64 base = lb_lookback(p.status, tile, (u64)tile_total);
+        const u64 base = lb_resolve(p.status, tile, (u64)tile_total, lane, nullptr);
         if (tid == 0) s_misc[1] = base;
     }
     if (bad) atomicOr((unsigned long long *)&p.result[1], (unsigned long long)bad);
     __syncthreads();
     const u64 base = s_misc[1];
-    for (u32 i = (u32)tid; i < tile_total; i += NT) {
-        u64 pos = base + i;
-        if (pos < p.out_cap) {
-            p.out[pos] = s_outk[i];
-            if (TAX) p.tout[pos] = s_outt[i];
+    if (base + tile_total <= p.out_cap) {
+        u64 *o = p.out + base;
+        const int sh = (int)(((uintptr_t)o >> 3) & 1);
+        const int npairs = ((int)tile_total + sh + 1) >> 1;
+        for (int m = tid; m < npairs; m += UNT) {
+            const int j0 = 2 * m - sh, j1 = j0 + 1;
+            const bool v0 = j0 >= 0, v1 = j1 < (int)tile_total;
+            const u64 k0 = s_keys[v0 ? j0 : 0], k1 = s_keys[v1 ? j1 : 0];
+            if (v0 && v1) *reinterpret_cast<ulonglong2 *>(o + j0) = make_ulonglong2(k0, k1);
+            else if (v0) o[j0] = k0;
+            else if (v1) o[j1] = k1;
+        }
+        if (TAX) {
+            u32 *to = p.tout + base;
+            for (u32 i = (u32)tid; i < tile_total; i += UNT) to[i] = s_tax[i];
+        }
+    } else {
+        for (u32 i = (u32)tid; i < tile_total; i += UNT) {
+            const u64 pos = base + i;
+            if (pos < p.out_cap) {
+                p.out[pos] = s_keys[i];
+                if (TAX) p.tout[pos] = s_tax[i];
+            }
         }
     }
     if (tid == 0 && tile == p.ntiles - 1) p.result[0] = base + tile_total;
@@ -255,7 +330,9 @@ int ukm_dev_unique_ex(ukm_ctx *c, const u64 *keys, const u32 *taxids, u64 n, int
     memset(&p, 0, sizeof(p));
     p.k = keys; p.t = taxids; p.n = n;
     p.out = out; p.tout = tout; p.out_cap = out_cap;
-    p.ntiles = (n + TILE - 1) / TILE;
+    const bool chunk = mode == UKM_REPEATED_CHUNK;
+    const u64 tile_items = (u64)UNT * (chunk ? UVT / 2 : UVT);
+    p.ntiles = (n + tile_items - 1) / tile_items;
     p.tax = ukm_taxdev(c);
     p.mode = mode;
     p.threshold = threshold;
@@ -266,8 +343,14 @@ int ukm_dev_unique_ex(ukm_ctx *c, const u64 *keys, const u32 *taxids, u64 n, int
     p.result = ctl;
     p.ticket = (u32 *)(ctl + 2);
     p.status = ctl + 8;
-    if (tax) hipLaunchKernelGGL(unique_tile_kernel<true>, dim3((unsigned)p.ntiles), dim3(NT), 0, c->stream, p);
-    else hipLaunchKernelGGL(unique_tile_kernel<false>, dim3((unsigned)p.ntiles), dim3(NT), 0, c->stream, p);
+    const dim3 grid((unsigned)p.ntiles), block(UNT);
+    if (chunk) {
+        if (tax) hipLaunchKernelGGL((unique_tile_kernel<true, true, UVT / 2>), grid, block, 0, c->stream, p);
+        else hipLaunchKernelGGL((unique_tile_kernel<false, true, UVT / 2>), grid, block, 0, c->stream, p);
+    } else {
+        if (tax) hipLaunchKernelGGL((unique_tile_kernel<true, false, UVT>), grid, block, 0, c->stream, p);
+        else hipLaunchKernelGGL((unique_tile_kernel<false, false, UVT>), grid, block, 0, c->stream, p);
+    }
     UKM_HIP(hipGetLastError());
     u64 res[2];
     UKM_TRY(ukm_read_u64(c, p.result, res, 2));
