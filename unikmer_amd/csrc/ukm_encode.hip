@@ -6,12 +6,23 @@
 //     (count.go:319,361) / nthash.Hasher.Next (dump.go:253-260), fused with the Scaled-MinHash
 //     filter `code > maxHash -> skip` (count.go:98,373-375).
 //
-// Kernel shape: one 256-thread workgroup per tile of 4096 consecutive base positions of the
-// concatenated records.  The tile (+k-1 bases of overlap) is loaded coalesced into LDS once;
-// each thread then ROLLS over a strip of 16 consecutive windows (k-1 warm-up steps, then one
-// base per window), so a window costs ~3 base steps instead of k.  Record boundaries only
-// decide validity and the output index (out_off[r] + p - rec_off[r]); the rolling state is
-// boundary-agnostic.  Windows that wrap (circular genomes) are recomputed directly.
+// Kernel shape (both value kinds): one 256-thread workgroup per tile of WT = 2048 window start
+// positions of the concatenated records (+64 bases of overlap), staged once in LDS.
+//   phase 1 (blocked over positions): record lookup -> per-position info byte (bases left in
+//            the record, "record long enough" bit) and record index; the per-position
+//            ingredients of the value:
+//              codes : 2-bit packed tile + illegal-base bit mask (16 bases per 32-bit word)
+//              ntHash: XOR-prefix sums  P[n] = xor_{m<n} ror(seed[s_m], m),
+//                                       Q[n] = xor_{m<n} rol(cseed[s_m], m)   (block XOR scan)
+//   phase 2 (striped over windows, so stores are coalesced): window i is computed in O(1),
+//            with no rolling dependency and no k-1 warm-up:
+//              code(i)  = 2k-bit field at bit 2i of the packed tile; revcomp by bit reversal
+//              fwd(i)   = rol(P[i+k] ^ P[i], i+k-1),  rev(i) = ror(Q[i+k] ^ Q[i], i)
+//            (the first version rolled 16 windows per thread: (16+k-1)/16 = 4x redundant work
+//            at k = 51 and 128-byte-strided stores; ntHash ran at 3.5e10 bases/s).
+//   Scaled filter: survivors are compacted in window order with one wave64 ballot per round, a
+//   per-tile prefix and the library's decoupled look-back.
+// Windows that wrap (circular genomes) are recomputed directly from the record.
 // Algorithmic bytes: 1 B/base read, 8 B/window written (8/scale with the Scaled filter).
 #include <algorithm>
 
@@ -20,9 +31,11 @@
 namespace {
 
 constexpr int NT = 256;
-constexpr int WPT = 16;            // windows per thread
-constexpr int TB = NT * WPT;       // base positions per tile
-constexpr int SB = TB + 64;        // LDS bytes for bases (k <= 64)
+constexpr int WT = 2048;        // window start positions per tile
+constexpr int TBX = WT + 64;    // base positions staged per tile (k <= 64)
+constexpr int WPT = WT / NT;    // windows per thread (striped)
+constexpr int PPT = 9;          // positions per thread in the blocked phase (256 * 9 >= TBX)
+constexpr int NWV = NT / 64;
 
 // kmers v0.1.0 base table; 4 = illegal base
 __device__ __forceinline__ u32 base2bit(u32 c) {
@@ -78,7 +91,12 @@ struct WinArgs {
     u32 *ticket;  // FILTER only
     u64 *result;  // [0] total (FILTER), [1] flags: bit0 = illegal base inside an emitted window
     u64 ntiles;
+    const u64 *tile_rec;  // [ntiles + 3]: record containing position min(t * WT, total_bases - 1)
 };
+
+// One thread per tile boundary: the record that contains the tile's first position.  Doing the
+// two ~27-step binary searches inside the tile kernel stalled every workgroup for ~25 us.
+__global__ void tile_first_rec_kernel(const u64 *rec_off, u64 n_rec, u64 total_bases, u64 ntiles, u64 *tile_rec);
 
 __global__ void window_count_kernel(const u64 *rec_off, u64 n_rec, int k, int circular, u64 *cnt) {
     u64 r = (u64)blockIdx.x * blockDim.x + threadIdx.x;
@@ -96,14 +114,55 @@ __device__ __forceinline__ u64 upper_bound_u64(const u64 *a, u64 lo, u64 hi, u64
     return lo;
 }
 
+__global__ void tile_first_rec_kernel(const u64 *rec_off, u64 n_rec, u64 total_bases, u64 ntiles, u64 *tile_rec) {
+    const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= ntiles + 3) return;
+    u64 pos = t * (u64)WT;
+    if (pos > total_bases - 1) pos = total_bases - 1;
+    tile_rec[t] = upper_bound_u64(rec_off, 0, n_rec + 1, pos) - 1;
+}
+
+// 64-bit XOR inclusive scan across the wave (DPP row shifts / broadcasts, cf. wave_incl_scan_u32)
+__device__ __forceinline__ u32 dpp_xor_step(u32 v, const int ctrl_id) {
+    switch (ctrl_id) {
+    case 0: return v ^ (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, true);
+    case 1: return v ^ (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, true);
+    case 2: return v ^ (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, true);
+    case 3: return v ^ (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, true);
+    case 4: return v ^ (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false);
+    default: return v ^ (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false);
+    }
+}
+__device__ __forceinline__ u64 wave_incl_xor_scan_u64(u64 v) {
+    u32 lo = (u32)v, hi = (u32)(v >> 32);
+#pragma unroll
+    for (int s = 0; s < 6; s++) { lo = dpp_xor_step(lo, s); hi = dpp_xor_step(hi, s); }
+    return ((u64)hi << 32) | lo;
+}
+
+// reverse the 2-bit groups of the low 2k bits of ~code (revcomp of kmers v0.1.0)
+__device__ __forceinline__ u64 revcomp2(u64 code, int k) {
+    u64 x = ~code;
+    x = ((u64)__builtin_bitreverse32((u32)x) << 32) | (u64)__builtin_bitreverse32((u32)(x >> 32));  // bit reversal
+    x = ((x & 0xAAAAAAAAAAAAAAAAull) >> 1) | ((x & 0x5555555555555555ull) << 1);                     // restore pair order
+    return x >> (64 - 2 * k);
+}
+
 // HASH: false = 2-bit codes, true = ntHash.  FILTER: Scaled filter + order-preserving compaction.
 template <bool HASH, bool FILTER>
 __global__ __launch_bounds__(NT) void window_kernel(WinArgs p) {
-    __shared__ u8 s_b[SB];
+    __shared__ __attribute__((aligned(16))) u8 s_b[TBX + 16];
+    __shared__ u8 s_info[NT * PPT];                     // low 7 bits: min(bases left in record, 127); bit 7: record length >= k
+    __shared__ u32 s_rr[NT * PPT];                      // record index of the position, relative to s_r[0]
+    __shared__ u64 s_P[HASH ? NT * PPT + 1 : 1];        // XOR prefixes (ntHash)
+    __shared__ u64 s_Q[HASH ? NT * PPT + 1 : 1];
+    __shared__ u32 s_pk[HASH ? 1 : NT * PPT / 16 + 4];  // 2-bit packed bases, 16 per word (codes)
+    __shared__ u32 s_bad[HASH ? 1 : NT * PPT / 32 + 4]; // illegal-base bit per position (codes)
+    __shared__ u64 s_wtot[2 * NWV];
+    __shared__ u32 s_cnt[WPT * NWV + 1];
     __shared__ u64 s_r[2];
-    __shared__ u32 s_scan[NT / 64 + 1];
     __shared__ u64 s_misc[2];
-    const int tid = (int)threadIdx.x;
+    const int tid = (int)threadIdx.x, lane = lane_id(), wave = tid >> 6;
     u64 tile;
     if (FILTER) {
         if (tid == 0) s_misc[0] = (u64)atomicAdd(p.ticket, 1u);
@@ -112,141 +171,203 @@ __global__ __launch_bounds__(NT) void window_kernel(WinArgs p) {
     } else {
         tile = blockIdx.x;
     }
-    const u64 P0 = tile * (u64)TB;
+    const u64 P0 = tile * (u64)WT;
     const int k = p.k;
-    // stage bases [P0, P0 + TB + k - 1) into LDS
+    // ---- stage bases [P0, P0 + TBX) into LDS -----------------------------------------------------
     {
         const u64 lim = p.total_bases;
-        const int need = TB + k - 1;
         if ((((uintptr_t)p.bases) & 3) == 0) {
-            const u32 *b4 = (const u32 *)(p.bases + P0);  // P0 is a multiple of 4096
-            for (int i = tid; i * 4 < need; i += NT) {
-                u64 g = P0 + (u64)i * 4;
+            const u32 *b4 = (const u32 *)(p.bases + P0);  // P0 is a multiple of 2048
+            for (int i = tid; i * 4 < TBX; i += NT) {
+                const u64 g = P0 + (u64)i * 4;
                 u32 w = 0;
                 if (g + 4 <= lim) w = b4[i];
-                else {
+                else
                     for (int q = 0; q < 4; q++)
                         if (g + q < lim) w |= (u32)p.bases[g + q] << (8 * q);
-                }
                 ((u32 *)s_b)[i] = w;
             }
         } else {
-            for (int i = tid; i < need; i += NT) s_b[i] = (P0 + i < lim) ? p.bases[P0 + i] : 0;
+            for (int i = tid; i < TBX; i += NT) s_b[i] = (P0 + i < lim) ? p.bases[P0 + i] : 0;
         }
     }
-    if (tid == 0) s_r[0] = upper_bound_u64(p.rec_off, 0, p.n_rec + 1, P0);            // first rec_off > P0
-    if (tid == 1) s_r[1] = upper_bound_u64(p.rec_off, 0, p.n_rec + 1, P0 + TB - 1);   // first rec_off > last pos
+    if (tid == 0) {
+        s_r[0] = p.tile_rec[tile];          // record of P0
+        s_r[1] = p.tile_rec[tile + 2] + 1;  // every position of the tile lies in a record <= this - 1
+    }
+    if (!HASH) {
+        for (int i = tid; i < NT * PPT / 16 + 4; i += NT) s_pk[i] = 0;
+        for (int i = tid; i < NT * PPT / 32 + 4; i += NT) s_bad[i] = 0;
+    }
     __syncthreads();
 
-    const u64 p_first = P0 + (u64)tid * WPT;
-    // record containing p_first: last r with rec_off[r] <= p_first
-    u64 r = 0;
-    bool in_rec = false;
-    u64 rs = 0, re = 0;  // current record [rs, re)
-    if (p_first < p.total_bases && p.n_rec > 0) {
-        u64 ub = upper_bound_u64(p.rec_off, s_r[0] ? s_r[0] - 1 : 0, s_r[1] < p.n_rec + 1 ? s_r[1] + 1 : p.n_rec + 1, p_first);
-        if (ub > 0 && ub <= p.n_rec) {
-            r = ub - 1;
-            rs = p.rec_off[r];
-            re = p.rec_off[r + 1];
-            in_rec = true;
-        }
-    }
-
-    u64 fwd = 0, rev = 0;
-    const u64 mask = (k >= 32) ? ~0ull : ((1ull << (2 * k)) - 1);
-    int since_bad = k;  // steps since the last illegal base (saturates at k)
-    u64 hv[WPT];
-    u32 keep = 0, illegal = 0;
-
-#pragma unroll 1
-    for (int step = 0; step < WPT + k - 1; step++) {
-        const int li = tid * WPT + step;  // LDS index of the incoming base
-        const u32 c = s_b[li];
-        if (HASH) {
-            fwd = rol64(fwd, 1) ^ nt_seed(c);
-            rev = ror64(rev, 1) ^ rol64(nt_cseed(c), (u32)(k - 1));
-            if (step >= k) {
-                const u32 co = s_b[li - k];
-                fwd ^= rol64(nt_seed(co), (u32)k);
-                rev ^= ror64(nt_cseed(co), 1);
+    // ---- phase 1: blocked over positions [tid*PPT, tid*PPT + PPT) -----------------------------------
+    {
+        const int m0 = tid * PPT;
+        const u64 p_first = P0 + (u64)m0;
+        const u64 r_first = s_r[0];
+        u64 r = 0, rs = 0, re = 0;
+        bool in_rec = false;
+        if (p_first < p.total_bases && p.n_rec > 0) {
+            const u64 hi = (s_r[1] + 1 < p.n_rec + 1) ? s_r[1] + 1 : p.n_rec + 1;
+            const u64 ub = upper_bound_u64(p.rec_off, r_first, hi, p_first);  // a few steps, L2-resident
+            if (ub > 0 && ub <= p.n_rec) {
+                r = ub - 1;
+                rs = p.rec_off[r];
+                re = p.rec_off[r + 1];
+                in_rec = true;
             }
-        } else {
-            const u32 b = base2bit(c);
-            since_bad = (b > 3) ? 0 : (since_bad < k ? since_bad + 1 : k);
-            fwd = ((fwd << 2) | (u64)(b & 3)) & mask;
-            rev = (rev >> 2) | ((u64)(3 - (b & 3)) << (2 * (k - 1)));
         }
-        if (step >= k - 1) {
-            const int w = step - (k - 1);      // window index inside the strip
-            const u64 pos = p_first + (u64)w;  // global start position of the window
-            // advance the record cursor
-            while (in_rec && pos >= re) {
+        u64 accP = 0, accQ = 0;
+        u64 lp[PPT], lq[PPT];
+#pragma unroll
+        for (int s = 0; s < PPT; s++) {
+            const int m = m0 + s;
+            const u64 pos = p_first + (u64)s;
+            while (in_rec && pos >= re) {  // advance the record cursor (skips empty records)
                 r++;
                 if (r >= p.n_rec) { in_rec = false; break; }
                 rs = re;
                 re = p.rec_off[r + 1];
             }
-            if (in_rec && pos < p.total_bases) {
-                const u64 len = re - rs;
-                const bool fits = pos + (u64)k <= re;
-                const bool emit = len >= (u64)k && (fits || p.circular);
-                if (emit) {
-                    u64 f = fwd, rv = rev;
-                    bool bad = !HASH && since_bad < k;
-                    if (!fits) {  // circular wrap: recompute from the record itself
-                        f = 0; rv = 0; bad = false;
-                        const u64 o = pos - rs;
-                        for (int j = 0; j < k; j++) {
-                            u64 q = o + (u64)j;
-                            if (q >= len) q -= len;
-                            const u32 cc = p.bases[rs + q];
-                            if (HASH) {
-                                f ^= rol64(nt_seed(cc), (u32)(k - 1 - j));
-                                rv ^= rol64(nt_cseed(cc), (u32)j);
-                            } else {
-                                const u32 bb = base2bit(cc);
-                                if (bb > 3) bad = true;
-                                f = (f << 2) | (u64)(bb & 3);
-                                rv |= (u64)(3 - (bb & 3)) << (2 * j);
-                            }
-                        }
-                    }
-                    if (bad) illegal = 1;
-                    u64 v = (p.canonical && rv < f) ? rv : f;
-                    if (FILTER) {
-                        if (v <= p.max_hash) { keep |= 1u << w; }
-                        // static indexing only: select into the unrolled slot below
+            const bool live = in_rec && pos < p.total_bases && m < TBX;
+            const u64 rem = live ? re - pos : 0;
+            const u32 info = (u32)(rem > 127 ? 127 : rem) | ((live && (re - rs) >= (u64)k) ? 128u : 0u);
+            s_info[m] = (u8)info;
+            s_rr[m] = live ? (u32)(r - r_first) : 0u;
+            const u32 c = (m < TBX) ? s_b[m] : 0;
+            if (HASH) {
+                // position m contributes ror(seed, m) to P and rol(cseed, m) to Q
+                accP ^= ror64(nt_seed(c), (u32)m);
+                accQ ^= rol64(nt_cseed(c), (u32)m);
+                lp[s] = accP;
+                lq[s] = accQ;
+            } else {
+                const u32 b = base2bit(c);
+                // first base of a k-mer is most significant: pack position m at bits [2*(15 - m%16)] of word m/16
+                atomicOr(&s_pk[m >> 4], (b & 3u) << (2 * (15 - (m & 15))));
+                if (b > 3) atomicOr(&s_bad[m >> 5], 1u << (m & 31));
+            }
+        }
+        if (HASH) {
+            // block-wide exclusive XOR scan of the per-thread totals
+            const u64 iP = wave_incl_xor_scan_u64(accP), iQ = wave_incl_xor_scan_u64(accQ);
+            if (lane == 63) { s_wtot[wave] = iP; s_wtot[NWV + wave] = iQ; }
+            __syncthreads();
+            u64 eP = iP ^ accP, eQ = iQ ^ accQ;
 #pragma unroll
-                        for (int q = 0; q < WPT; q++)
-                            if (q == w) hv[q] = v;
+            for (int w = 0; w < NWV; w++)
+                if (w < wave) { eP ^= s_wtot[w]; eQ ^= s_wtot[NWV + w]; }
+            if (tid == 0) { s_P[0] = 0; s_Q[0] = 0; }
+#pragma unroll
+            for (int s = 0; s < PPT; s++) {
+                s_P[m0 + s + 1] = eP ^ lp[s];
+                s_Q[m0 + s + 1] = eQ ^ lq[s];
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- phase 2: striped over windows i = tid + j*NT ---------------------------------------------------
+    const u64 r_first = s_r[0];
+    u64 hv[WPT];
+    u32 keep = 0, illegal = 0;
+#pragma unroll
+    for (int j = 0; j < WPT; j++) {
+        const int i = tid + j * NT;
+        const u32 info = s_info[i];
+        const bool long_enough = (info & 128u) != 0;
+        const bool fits = (int)(info & 127u) >= k;
+        const bool emit = long_enough && (fits || p.circular);
+        u64 v = 0;
+        if (emit) {
+            u64 f, rv;
+            bool bad = false;
+            if (fits) {
+                if (HASH) {
+                    f = rol64(s_P[i + k] ^ s_P[i], (u32)(i + k - 1));
+                    rv = ror64(s_Q[i + k] ^ s_Q[i], (u32)i);
+                } else {
+                    // 2k-bit field starting at packed bit offset 2i (big-endian within 32-bit words)
+                    const int w0 = i >> 4, sh = 2 * (i & 15);
+                    const u64 hi = ((u64)s_pk[w0] << 32) | s_pk[w0 + 1];
+                    const u64 lo = ((u64)s_pk[w0 + 2] << 32);
+                    const u64 x = sh ? ((hi << sh) | (lo >> (64 - sh))) : hi;  // 64 bits = 32 bases from position i
+                    f = x >> (64 - 2 * k);
+                    rv = revcomp2(f, k);
+                    // any illegal base among positions [i, i+k)?
+                    const int b0 = i >> 5, bs = i & 31;
+                    const u64 mlo = ((u64)s_bad[b0 + 1] << 32) | s_bad[b0];
+                    const u64 mhi = s_bad[b0 + 2];
+                    const u64 mbits = bs ? ((mlo >> bs) | (mhi << (64 - bs))) : mlo;
+                    bad = (mbits & (k == 64 ? ~0ull : ((1ull << k) - 1))) != 0;
+                }
+            } else {  // circular wrap: recompute from the record itself (k-1 windows per record)
+                const u64 r = r_first + s_rr[i];
+                const u64 rs = p.rec_off[r], len = p.rec_off[r + 1] - rs;
+                const u64 o = P0 + (u64)i - rs;
+                f = 0; rv = 0;
+                for (int q = 0; q < k; q++) {
+                    u64 z = o + (u64)q;
+                    if (z >= len) z -= len;
+                    const u32 cc = p.bases[rs + z];
+                    if (HASH) {
+                        f ^= rol64(nt_seed(cc), (u32)(k - 1 - q));
+                        rv ^= rol64(nt_cseed(cc), (u32)q);
                     } else {
-                        const u64 oi = p.out_off[r] + (pos - rs);
-                        if (oi < p.out_cap) p.out[oi] = v;
+                        const u32 bb = base2bit(cc);
+                        if (bb > 3) bad = true;
+                        f = (f << 2) | (u64)(bb & 3);
+                        rv |= (u64)(3 - (bb & 3)) << (2 * q);
                     }
                 }
             }
+            if (bad) illegal = 1;
+            v = (p.canonical && rv < f) ? rv : f;
+        }
+        if (FILTER) {
+            hv[j] = v;
+            if (emit && v <= p.max_hash) keep |= 1u << j;
+        } else if (emit) {
+            const u64 r = r_first + s_rr[i];
+            const u64 oi = p.out_off[r] + (P0 + (u64)i - p.rec_off[r]);
+            if (oi < p.out_cap) p.out[oi] = v;
         }
     }
     if (illegal) atomicOr((unsigned long long *)&p.result[1], 1ull);
 
     if (FILTER) {
-        const u32 cnt = (u32)__popc(keep);
-        u32 tile_total;
-        const u32 excl = block_excl_scan_u32<NT>(cnt, s_scan, &tile_total);
+        // survivors in window order: (round j, wave, lane)
+        u32 before[WPT];
+#pragma unroll
+        for (int j = 0; j < WPT; j++) {
+            const u64 m = __ballot((keep >> j) & 1u);
+            before[j] = (u32)__popcll(m & ((1ull << lane) - 1));
+            if (lane == 0) s_cnt[j * NWV + wave] = (u32)__popcll(m);
+        }
+        __syncthreads();
         if (tid < 64) {
-            u64 base = lb_lookback(p.status, tile, (u64)tile_total);
+            constexpr int NG = WPT * NWV;
+            const u32 c = lane < NG ? s_cnt[lane] : 0;
+            const u32 incl = wave_incl_scan_u32(c);
+            if (lane < NG) s_cnt[lane] = incl - c;
+            if (lane == 63) s_cnt[NG] = incl;
+        }
+        __syncthreads();
+        const u32 tile_total = s_cnt[WPT * NWV];
+        if (tid < 64) {
+            const u64 base = lb_lookback(p.status, tile, (u64)tile_total);
             if (tid == 0) s_misc[1] = base;
         }
         __syncthreads();
-        u64 pos = s_misc[1] + excl;
+        const u64 base = s_misc[1];
 #pragma unroll
-        for (int q = 0; q < WPT; q++)
-            if (keep & (1u << q)) {
-                if (pos < p.out_cap) p.out[pos] = hv[q];
-                pos++;
+        for (int j = 0; j < WPT; j++)
+            if ((keep >> j) & 1u) {
+                const u64 pos = base + s_cnt[j * NWV + wave] + before[j];
+                if (pos < p.out_cap) p.out[pos] = hv[j];
             }
-        if (tid == 0 && tile == p.ntiles - 1) p.result[0] = s_misc[1] + tile_total;
+        if (tid == 0 && tile == p.ntiles - 1) p.result[0] = base + tile_total;
     }
 }
 
@@ -261,7 +382,7 @@ int run_windows(ukm_ctx *c, bool hash, const u8 *bases, const u64 *rec_off, u64 
     UKM_TRY(ws_alloc_t(c, n_rec, &off));
     hipLaunchKernelGGL(window_count_kernel, dim3((unsigned)((n_rec + 255) / 256)), dim3(256), 0, c->stream,
                        rec_off, n_rec, k, circular, cnt);
-    const u64 ntiles = (total_bases + TB - 1) / TB;
+    const u64 ntiles = (total_bases + WT - 1) / WT;
     const bool filter = hash && max_hash != 0;
     const size_t nctl = 8 + (filter ? lb_status_words(ntiles) : 0);
     UKM_TRY(ws_alloc_t(c, nctl, &ctl));
@@ -281,9 +402,17 @@ int run_windows(ukm_ctx *c, bool hash, const u8 *bases, const u64 *rec_off, u64 
     p.total_bases = total_bases; p.k = k; p.canonical = canonical; p.circular = circular;
     p.max_hash = max_hash; p.out = out; p.out_cap = out_cap;
     p.result = ctl; p.ticket = (u32 *)(ctl + 2); p.status = ctl + 8; p.ntiles = ntiles;
+    u64 *tile_rec = nullptr;
+    UKM_TRY(ws_alloc_t(c, ntiles + 3, &tile_rec));
+    hipLaunchKernelGGL(tile_first_rec_kernel, dim3((unsigned)((ntiles + 3 + 255) / 256)), dim3(256), 0, c->stream,
+                       rec_off, n_rec, total_bases, ntiles, tile_rec);
+    p.tile_rec = tile_rec;
+    (void)hipEventRecord(c->ev_k0, c->stream);
     if (!hash) hipLaunchKernelGGL((window_kernel<false, false>), dim3((unsigned)ntiles), dim3(NT), 0, c->stream, p);
     else if (!filter) hipLaunchKernelGGL((window_kernel<true, false>), dim3((unsigned)ntiles), dim3(NT), 0, c->stream, p);
     else hipLaunchKernelGGL((window_kernel<true, true>), dim3((unsigned)ntiles), dim3(NT), 0, c->stream, p);
+    (void)hipEventRecord(c->ev_k1, c->stream);
+    c->evk_valid = true;
     UKM_HIP(hipGetLastError());
     u64 res[2];
     UKM_TRY(ukm_read_u64(c, ctl, res, 2));
