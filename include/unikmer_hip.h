@@ -116,6 +116,16 @@ int ukm_encode_kmers(ukm_ctx *ctx, const uint8_t *bases, const uint64_t *rec_off
 int ukm_nthash(ukm_ctx *ctx, const uint8_t *bases, const uint64_t *rec_off, uint64_t n_rec,
                int k, int canonical, int circular, uint64_t max_hash, uint64_t *out,
                uint64_t out_cap, uint64_t *n_out);
+/* ---- minimizer sketch: replaces sketches.NewMinimizerSketch(seq,k,w,circular).NextMinimizer()
+ *      (count.go:316,357; bio v0.13.3, SURVEY.md B3, KATs C-7/C-8): canonical ntHash of every
+ *      window; for each group of w consecutive windows of a record the LEFTMOST minimum, emitted
+ *      when the arg-min position differs from the previous group's.  Records with fewer than w
+ *      windows give nothing.  max_hash != 0 applies the Scaled filter to the emitted values
+ *      (count.go:373-375).  out_pos (may be NULL) = window index of each minimizer inside its
+ *      record (sketch.Index()).  1 <= w <= 1024.  Output keeps record/group order. */
+int ukm_minimizer(ukm_ctx *ctx, const uint8_t *bases, const uint64_t *rec_off, uint64_t n_rec,
+                  int k, int w, int circular, uint64_t max_hash, uint64_t *out,
+                  uint64_t *out_pos, uint64_t out_cap, uint64_t *n_out);
 /* count.go:98  maxHash = uint64(float64(^uint64(0)) / float64(scale)) */
 uint64_t ukm_max_hash(uint64_t scale);
 

@@ -79,6 +79,9 @@ def lib():
         for f in (L.ukmo_time_union2, L.ukmo_time_inter2):
             f.argtypes = [_u64p, C.c_uint64, _u64p, C.c_uint64, _u64p, _u64p]
             f.restype = C.c_double
+        L.ukmo_time_setop2_allcores.argtypes = [C.c_int, _u64p, C.c_uint64, _u64p, C.c_uint64, _u64p, _u64p,
+                                                C.POINTER(C.c_int)]
+        L.ukmo_time_setop2_allcores.restype = C.c_double
         _lib = L
     return _lib
 
@@ -296,6 +299,19 @@ def time_union2(a, b):
     t = lib().ukmo_time_union2(_p(a, _u64p), len(a), _p(b, _u64p), len(b), _p(out, _u64p),
                                C.byref(n))
     return t, out[: n.value]
+
+
+def time_setop2_allcores(op, a, b):
+    """All-cores 2-pass sorted merge; op 0 union, 1 inter, 2 diff.
+    Returns (seconds, result, threads)."""
+    a = np.ascontiguousarray(a, dtype=np.uint64)
+    b = np.ascontiguousarray(b, dtype=np.uint64)
+    out = np.empty(len(a) + len(b) + 1, dtype=np.uint64)
+    n = C.c_uint64()
+    th = C.c_int()
+    t = lib().ukmo_time_setop2_allcores(op, _p(a, _u64p), len(a), _p(b, _u64p), len(b), _p(out, _u64p),
+                                        C.byref(n), C.byref(th))
+    return t, out[: n.value], th.value
 
 
 def time_inter2(a, b):

@@ -798,3 +798,54 @@ double ukmo_time_inter2(const uint64_t *a, uint64_t na, const uint64_t *b, uint6
     *n_out = ukmo_inter(ks, NULL, ls, 2, 0, NULL, out, NULL);
     return now_s() - t0;
 }
+
+
+/* ---- all-cores CPU bar: NOT the reference's algorithm (its set-op loops are
+ * single-threaded, union.go:186-208 / inter.go:205-267) but the honest best a CPU does on the same
+ * sorted inputs: value-range partitioned 2-pointer merges on every core, two passes (count, write).
+ * op: 0 union, 1 inter, 2 diff.  Inputs strictly increasing.  Returns seconds. */
+#include <omp.h>
+static uint64_t lower_bound_u64(const uint64_t *a, uint64_t n, uint64_t x) {
+    uint64_t lo = 0, hi = n;
+    while (lo < hi) { uint64_t m = (lo + hi) >> 1; if (a[m] < x) lo = m + 1; else hi = m; }
+    return lo;
+}
+static uint64_t merge_range(int op, const uint64_t *a, uint64_t i, uint64_t ie, const uint64_t *b, uint64_t j,
+                            uint64_t je, uint64_t *out) {
+    uint64_t n = 0;
+    while (i < ie && j < je) {
+        uint64_t x = a[i], y = b[j];
+        if (x < y) { if (op != 1) { if (out) out[n] = x; n++; } i++; }
+        else if (y < x) { if (op == 0) { if (out) out[n] = y; n++; } j++; }
+        else { if (op != 2) { if (out) out[n] = x; n++; } i++; j++; }
+    }
+    if (op != 1) for (; i < ie; i++) { if (out) out[n] = a[i]; n++; }
+    if (op == 0) for (; j < je; j++) { if (out) out[n] = b[j]; n++; }
+    return n;
+}
+double ukmo_time_setop2_allcores(int op, const uint64_t *a, uint64_t na, const uint64_t *b, uint64_t nb,
+                                 uint64_t *out, uint64_t *n_out, int *threads_used) {
+    int T = omp_get_max_threads();
+    int P = T * 8; /* more parts than threads: load balance */
+    if ((uint64_t)P > na + 1) P = (int)(na + 1);
+    if (P < 1) P = 1;
+    uint64_t *ai = (uint64_t *)malloc((size_t)(P + 1) * sizeof(uint64_t));
+    uint64_t *bi = (uint64_t *)malloc((size_t)(P + 1) * sizeof(uint64_t));
+    uint64_t *cnt = (uint64_t *)malloc((size_t)(P + 1) * sizeof(uint64_t));
+    double t0 = now_s();
+    for (int p = 0; p <= P; p++) {
+        ai[p] = (p == P) ? na : na / (uint64_t)P * (uint64_t)p;
+        bi[p] = (p == P) ? nb : (p == 0 ? 0 : lower_bound_u64(b, nb, a[ai[p]]));
+    }
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int p = 0; p < P; p++) cnt[p] = merge_range(op, a, ai[p], ai[p + 1], b, bi[p], bi[p + 1], NULL);
+    uint64_t tot = 0;
+    for (int p = 0; p < P; p++) { uint64_t c = cnt[p]; cnt[p] = tot; tot += c; }
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int p = 0; p < P; p++) merge_range(op, a, ai[p], ai[p + 1], b, bi[p], bi[p + 1], out + cnt[p]);
+    double dt = now_s() - t0;
+    *n_out = tot;
+    if (threads_used) *threads_used = T;
+    free(ai); free(bi); free(cnt);
+    return dt;
+}

@@ -111,6 +111,10 @@ double ukmo_time_union2(const uint64_t *a, uint64_t na, const uint64_t *b, uint6
 double ukmo_time_inter2(const uint64_t *a, uint64_t na, const uint64_t *b, uint64_t nb,
                         uint64_t *out, uint64_t *n_out);
 
+/* all-cores sorted merge (SURVEY.md 8(d)(ii) "honest best-CPU bar"; not the reference's algorithm) */
+double ukmo_time_setop2_allcores(int op, const uint64_t *a, uint64_t na, const uint64_t *b, uint64_t nb,
+                                 uint64_t *out, uint64_t *n_out, int *threads_used);
+
 #ifdef __cplusplus
 }
 #endif

@@ -130,6 +130,11 @@ def test_readme_transcript_on_gpu(cli, tmp_path):
     head = cli("view", "--show-taxid", mg + ".unik").stdout.decode().splitlines()[:3]
     assert head == ["AAAAAAAAACCATCCAAATCTGG\t511145", "AAAAAAAAACCGCTAGTATATTC\t511145",
                     "AAAAAAAAACCTGAAAAAAACGG\t511145"]                           # README.md:177-180
+    # minimizers in linear order (README.md:173-174,199: 860,900) and their three smallest hashes (README.md:183-186)
+    cli("count", "-k", 23, "-W", 5, "-H", "-K", "-l", _fa(AMUC), "-o", d + "/am.m")
+    assert cli("num", d + "/am.m.unik").stdout.strip() == b"860900"
+    mins = sorted(int(x) for x in cli("view", d + "/am.m.unik").stdout.split())
+    assert mins[:3] == [1210726578792, 2286899379883, 3542156397282]
     # unsorted + compact count gives the same set (README.md:154-158)
     cli("count", "-k", 23, _fa(MG1655), "-o", d + "/mgc", "--canonical", "--compact")
     assert cli("num", d + "/mgc.unik").stdout.strip() == b"4546632"

@@ -351,6 +351,54 @@ def test_illegal_and_degenerate_bases(ctx, O, L):
         ctx.encode_kmers(bad, np.array([0, len(bad)], dtype=np.uint64), 4)
 
 
+def _oracle_minimizer_records(O, bases, cuts, k, w, circular=False, max_hash=0):
+    hs, ps = [], []
+    for r in range(len(cuts) - 1):
+        seq = bases[int(cuts[r]):int(cuts[r + 1])]
+        try:
+            h, p = O.minimizer(seq, k, w, circular=circular)
+        except ValueError:     # ErrShortSeq: record skipped (count.go:323-328)
+            continue
+        if max_hash:
+            keep = h <= np.uint64(max_hash)
+            h, p = h[keep], p[keep]
+        hs.append(h); ps.append(p)
+    if not hs:
+        return np.empty(0, np.uint64), np.empty(0, np.uint64)
+    return np.concatenate(hs), np.concatenate(ps)
+
+
+@pytest.mark.parametrize("k,w", [(23, 5), (31, 15), (5, 1), (7, 2), (51, 40), (11, 300), (21, 1024)])
+def test_minimizer(ctx, O, k, w):
+    bases = _synth_fasta(120_000, SEED + 4)
+    cuts = np.array([0, 150, 300, 301, 1024, 2047, 2048 + w, 5000, 5000, 77_777, 120_000], dtype=np.uint64)
+    for circular in (False, True):
+        got, gpos = ctx.minimizer(bases, cuts, k, w, circular=circular, with_pos=True)
+        exp, epos = _oracle_minimizer_records(O, bases, cuts, k, w, circular=circular)
+        assert np.array_equal(got, exp)
+        assert np.array_equal(gpos, epos)
+    mh = O.max_hash(7)
+    got = ctx.minimizer(bases, cuts, k, w, max_hash=mh)
+    exp, _ = _oracle_minimizer_records(O, bases, cuts, k, w, max_hash=mh)
+    assert np.array_equal(got, exp)
+
+
+def test_minimizer_low_complexity_ties(ctx, O):
+    """Runs of equal hashes (homopolymers, short repeats) exercise the leftmost-minimum rule."""
+    seq = np.frombuffer((b"A" * 300 + b"ACACACACAC" * 40 + b"T" * 200 + b"ACGTTGCA" * 50), dtype=np.uint8)
+    off = np.array([0, len(seq)], dtype=np.uint64)
+    for k, w in ((5, 3), (9, 8), (15, 20)):
+        got, gpos = ctx.minimizer(seq, off, k, w, with_pos=True)
+        exp, epos = O.minimizer(seq, k, w)
+        assert np.array_equal(got, exp) and np.array_equal(gpos, epos)
+
+
+def test_minimizer_rejects_large_w(ctx, L):
+    seq = np.frombuffer(b"ACGT" * 1000, dtype=np.uint8)
+    with pytest.raises(L.UkmError):
+        ctx.minimizer(seq, np.array([0, len(seq)], dtype=np.uint64), 21, 5000)
+
+
 # ---------------------------------------------------------------------------------- KATs through the GPU
 def test_kat_count_sort_unique_genomes(ctx, L, genomes):
     """README.md:200-204,270-278 through the HIP path: count -k 23 -K -s, then union/inter/diff."""
@@ -376,6 +424,20 @@ def test_kat_scaled_minhash(ctx, L, genomes):
     h = ctx.nthash(bases, off, 31, canonical=True, max_hash=ctx.max_hash(15))
     ctx.sort_u64(h)
     assert len(ctx.unique(h)) == 586734
+
+
+def test_kat_minimizer(ctx, L, genomes):
+    """README.md:174,189-199 (count -k 23 -W 5 -H -K -l -> 860,900 minimizers, first positions 2,5,6,9,13)
+    and analysis/distance/README.md:8 (MG1655 -k 31 -W 15 -> 549,963 distinct)."""
+    bases, off = genomes(AMUC)
+    h, pos = ctx.minimizer(bases, off, 23, 5, with_pos=True)
+    assert len(h) == 860900
+    assert [int(p) for p in pos[:5]] == [2, 5, 6, 9, 13]
+    assert [int(x) for x in np.sort(h)[:3]] == [1210726578792, 2286899379883, 3542156397282]
+    bases, off = genomes(MG1655)
+    h = ctx.minimizer(bases, off, 31, 15)
+    ctx.sort_u64(h)
+    assert len(ctx.unique(h)) == 549963
 
 
 # ---------------------------------------------------------------------------------- device-resident tensors

@@ -114,3 +114,19 @@ def test_inter_diff_multiset_and_quirks():
     assert O.inter([a, e, b]).tolist() == a.tolist()         # inter.go:211-217 quirk
     assert O.inter([e, a]).tolist() == []
     assert O.diff([a, e]).tolist() == [1, 2, 5, 9]
+
+
+def test_allcores_sorted_merge_matches_reference_algorithms():
+    """bench.py's second CPU bar gives the same sets as the restated
+    reference loops on strictly increasing inputs, including empty and one-element inputs."""
+    rng = np.random.default_rng(3)
+    for na, nb in ((0, 0), (0, 7), (5, 0), (1, 1), (1000, 3), (50_000, 60_000)):
+        a = np.unique(rng.integers(0, 200_000, na).astype(np.uint64))
+        b = np.unique(rng.integers(0, 200_000, nb).astype(np.uint64))
+        for op, ref in ((0, O.union), (1, O.inter), (2, O.diff)):
+            if op == 1 and len(b) == 0 and len(a):
+                continue  # the reference's inter keeps the first set when a later file is empty (inter.go quirk)
+            _, got, threads = O.time_setop2_allcores(op, a, b)
+            exp = ref([a, b])
+            assert threads >= 1
+            assert np.array_equal(got, np.sort(exp))

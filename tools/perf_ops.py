@@ -147,6 +147,12 @@ def main():
             f()
             t, _ = best(f)
             res["nthash_k51_scaled1000_reads150"] = {"call_ms": t, "bases_per_s": nb_ / t * 1e3}
+            for kk, ww in ((31, 15), (23, 5), (21, 200)):
+                def f():
+                    return ctx.minimizer(bases, off, kk, ww)
+                f()
+                t, _ = best(f)
+                res["minimizer_k%d_w%d" % (kk, ww)] = {"call_ms": t, "bases_per_s": nb_ / t * 1e3, "emitted": int(f().numel())}
     print(json.dumps(res, indent=1))
 
 

@@ -96,11 +96,14 @@ struct WinArgs {
 
 // One thread per tile boundary: the record that contains the tile's first position.  Doing the
 // two ~27-step binary searches inside the tile kernel stalled every workgroup for ~25 us.
-__global__ void tile_first_rec_kernel(const u64 *rec_off, u64 n_rec, u64 total_bases, u64 ntiles, u64 *tile_rec);
+__global__ void tile_first_rec_kernel(const u64 *rec_off, u64 n_rec, u64 total_bases, u64 ntiles, u64 tile_size,
+                                      u64 *tile_rec);
 
+// cnt[n_rec] = 0, so the exclusive scan over n_rec + 1 entries ends with the total
 __global__ void window_count_kernel(const u64 *rec_off, u64 n_rec, int k, int circular, u64 *cnt) {
     u64 r = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= n_rec) return;
+    if (r > n_rec) return;
+    if (r == n_rec) { cnt[r] = 0; return; }
     u64 len = rec_off[r + 1] - rec_off[r];
     cnt[r] = (len < (u64)k) ? 0 : (circular ? len : len - (u64)k + 1);
 }
@@ -114,10 +117,11 @@ __device__ __forceinline__ u64 upper_bound_u64(const u64 *a, u64 lo, u64 hi, u64
     return lo;
 }
 
-__global__ void tile_first_rec_kernel(const u64 *rec_off, u64 n_rec, u64 total_bases, u64 ntiles, u64 *tile_rec) {
+__global__ void tile_first_rec_kernel(const u64 *rec_off, u64 n_rec, u64 total_bases, u64 ntiles, u64 tile_size,
+                                      u64 *tile_rec) {
     const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= ntiles + 3) return;
-    u64 pos = t * (u64)WT;
+    u64 pos = t * tile_size;
     if (pos > total_bases - 1) pos = total_bases - 1;
     tile_rec[t] = upper_bound_u64(rec_off, 0, n_rec + 1, pos) - 1;
 }
@@ -373,21 +377,23 @@ __global__ __launch_bounds__(NT) void window_kernel(WinArgs p) {
 
 int run_windows(ukm_ctx *c, bool hash, const u8 *bases, const u64 *rec_off, u64 n_rec, int k,
                 int canonical, int circular, u64 max_hash, u64 *out, u64 out_cap, u64 *n_out,
-                u64 total_bases) {
+                u64 total_bases, const u64 **win_off = nullptr) {
     *n_out = 0;
+    if (win_off) *win_off = nullptr;
     if (n_rec == 0 || total_bases == 0) return UKM_OK;
-    // per-record window counts -> exclusive scan
+    // per-record window counts -> exclusive scan (n_rec + 1 entries: off[n_rec] = total)
     u64 *cnt = nullptr, *off = nullptr, *ctl = nullptr;
-    UKM_TRY(ws_alloc_t(c, n_rec, &cnt));
-    UKM_TRY(ws_alloc_t(c, n_rec, &off));
-    hipLaunchKernelGGL(window_count_kernel, dim3((unsigned)((n_rec + 255) / 256)), dim3(256), 0, c->stream,
+    UKM_TRY(ws_alloc_t(c, n_rec + 1, &cnt));
+    UKM_TRY(ws_alloc_t(c, n_rec + 1, &off));
+    if (win_off) *win_off = off;
+    hipLaunchKernelGGL(window_count_kernel, dim3((unsigned)((n_rec + 1 + 255) / 256)), dim3(256), 0, c->stream,
                        rec_off, n_rec, k, circular, cnt);
     const u64 ntiles = (total_bases + WT - 1) / WT;
     const bool filter = hash && max_hash != 0;
     const size_t nctl = 8 + (filter ? lb_status_words(ntiles) : 0);
     UKM_TRY(ws_alloc_t(c, nctl, &ctl));
     UKM_HIP(hipMemsetAsync(ctl, 0, nctl * sizeof(u64), c->stream));
-    UKM_TRY(ukm_dev_exclusive_scan_u64(c, cnt, off, n_rec, ctl + 3));
+    UKM_TRY(ukm_dev_exclusive_scan_u64(c, cnt, off, n_rec + 1, ctl + 3));
     u64 total_windows = 0;
     UKM_TRY(ukm_read_u64(c, ctl + 3, &total_windows));
     if (total_windows == 0) return UKM_OK;
@@ -405,7 +411,7 @@ int run_windows(ukm_ctx *c, bool hash, const u8 *bases, const u64 *rec_off, u64 
     u64 *tile_rec = nullptr;
     UKM_TRY(ws_alloc_t(c, ntiles + 3, &tile_rec));
     hipLaunchKernelGGL(tile_first_rec_kernel, dim3((unsigned)((ntiles + 3 + 255) / 256)), dim3(256), 0, c->stream,
-                       rec_off, n_rec, total_bases, ntiles, tile_rec);
+                       rec_off, n_rec, total_bases, ntiles, (u64)WT, tile_rec);
     p.tile_rec = tile_rec;
     (void)hipEventRecord(c->ev_k0, c->stream);
     if (!hash) hipLaunchKernelGGL((window_kernel<false, false>), dim3((unsigned)ntiles), dim3(NT), 0, c->stream, p);
@@ -421,6 +427,164 @@ int run_windows(ukm_ctx *c, bool hash, const u8 *bases, const u64 *rec_off, u64 
     if (*n_out > out_cap)
         UKM_FAIL(UKM_ERR_CAPACITY, "output needs %llu values, capacity is %llu",
                  (unsigned long long)*n_out, (unsigned long long)out_cap);
+    return UKM_OK;
+}
+
+
+// ---- minimizer sketch (bio/sketches MinimizerSketch; count.go:316,357) ------------------
+// Input: the canonical ntHash of every window (h, per-record offsets off[n_rec+1]).  Group g of a
+// record = windows [g, g+w); its minimizer is the LEFTMOST minimum; it is emitted when the arg-min
+// position differs from the previous group's.  With m = min h[g .. g+w-2] (leftmost):
+//   arg(g-1) == g-1        <=>  h[g-1] <= m
+//   arg(g)   == g+w-1      <=>  h[g+w-1] <  m
+// and otherwise arg(g-1) == arg(g), so  emit(g) = g==0 || h[g-1] <= m || h[g+w-1] < m  -- every
+// group is decided independently of the others (no serial scan over the record).
+constexpr int MT = 1024;        // window indices per tile
+constexpr int MPT = MT / NT;    // per thread, striped
+constexpr int MW_MAX = 1024;    // largest supported w (LDS halo)
+
+struct MinArgs {
+    const u64 *h;
+    const u64 *off;  // [n_rec + 1]
+    u64 n_rec;
+    u64 total;
+    int w;
+    u64 max_hash;
+    u64 *out;
+    u64 *out_pos;  // may be NULL
+    u64 out_cap;
+    u64 *status;
+    u32 *ticket;
+    u64 *result;
+    u64 ntiles;
+    const u64 *tile_rec;
+};
+
+__global__ __launch_bounds__(NT) void minimizer_kernel(MinArgs p) {
+    __shared__ u64 s_h[MT + MW_MAX + 1];  // s_h[i] = h[J0 - 1 + i]
+    __shared__ u32 s_cnt[MPT * NWV + 1];
+    __shared__ u64 s_r[2];
+    __shared__ u64 s_misc[2];
+    const int tid = (int)threadIdx.x, lane = lane_id(), wave = tid >> 6;
+    if (tid == 0) s_misc[0] = (u64)atomicAdd(p.ticket, 1u);
+    __syncthreads();
+    const u64 tile = s_misc[0];
+    const u64 J0 = tile * (u64)MT;
+    const int w = p.w;
+    for (int i = tid; i < MT + w; i += NT) {
+        const u64 g = J0 + (u64)i;
+        s_h[i] = (g >= 1 && g - 1 < p.total) ? p.h[g - 1] : ~0ull;
+    }
+    if (tid == 0) {
+        s_r[0] = p.tile_rec[tile];
+        s_r[1] = p.tile_rec[tile + 2] + 1;
+    }
+    __syncthreads();
+    const u64 r_lo = s_r[0];
+    const u64 r_hi = (s_r[1] + 1 < p.n_rec + 1) ? s_r[1] + 1 : p.n_rec + 1;
+    u64 val[MPT], apos[MPT];
+    u32 keep = 0;
+#pragma unroll
+    for (int jj = 0; jj < MPT; jj++) {
+        const int i = tid + jj * NT;
+        const u64 j = J0 + (u64)i;
+        val[jj] = 0; apos[jj] = 0;
+        if (j >= p.total) continue;
+        const u64 ub = upper_bound_u64(p.off, r_lo, r_hi, j);
+        if (ub == 0 || ub > p.n_rec) continue;
+        const u64 rs = p.off[ub - 1], nwin = p.off[ub] - rs, g = j - rs;
+        if (g + (u64)w > nwin) continue;
+        const u64 last = s_h[i + w];  // h[j + w - 1]
+        bool e;
+        u64 v, a;
+        if (w == 1) {
+            e = true; v = last; a = g;
+        } else {
+            u64 m = s_h[i + 1];
+            int am = 0;
+            for (int q = 1; q < w - 1; q++) {
+                const u64 x = s_h[i + 1 + q];
+                if (x < m) { m = x; am = q; }
+            }
+            e = (g == 0) || (s_h[i] <= m) || (last < m);
+            v = last < m ? last : m;
+            a = last < m ? g + (u64)w - 1 : g + (u64)am;
+        }
+        if (e && (p.max_hash == 0 || v <= p.max_hash)) {
+            keep |= 1u << jj;
+            val[jj] = v; apos[jj] = a;
+        }
+    }
+    u32 before[MPT];
+#pragma unroll
+    for (int jj = 0; jj < MPT; jj++) {
+        const u64 m = __ballot((keep >> jj) & 1u);
+        before[jj] = (u32)__popcll(m & ((1ull << lane) - 1));
+        if (lane == 0) s_cnt[jj * NWV + wave] = (u32)__popcll(m);
+    }
+    __syncthreads();
+    if (tid < 64) {
+        constexpr int NG = MPT * NWV;
+        const u32 c = lane < NG ? s_cnt[lane] : 0;
+        const u32 incl = wave_incl_scan_u32(c);
+        if (lane < NG) s_cnt[lane] = incl - c;
+        if (lane == 63) s_cnt[NG] = incl;
+    }
+    __syncthreads();
+    const u32 tile_total = s_cnt[MPT * NWV];
+    if (tid < 64) {
+        const u64 base = lb_lookback(p.status, tile, (u64)tile_total);
+        if (tid == 0) s_misc[1] = base;
+    }
+    __syncthreads();
+    const u64 base = s_misc[1];
+#pragma unroll
+    for (int jj = 0; jj < MPT; jj++)
+        if ((keep >> jj) & 1u) {
+            const u64 pos = base + s_cnt[jj * NWV + wave] + before[jj];
+            if (pos < p.out_cap) {
+                p.out[pos] = val[jj];
+                if (p.out_pos) p.out_pos[pos] = apos[jj];
+            }
+        }
+    if (tid == 0 && tile == p.ntiles - 1) p.result[0] = base + tile_total;
+}
+
+int run_minimizer(ukm_ctx *c, const u8 *bases, const u64 *rec_off, u64 n_rec, int k, int w, int circular,
+                  u64 max_hash, u64 *out, u64 *out_pos, u64 out_cap, u64 *n_out, u64 total_bases) {
+    *n_out = 0;
+    if (n_rec == 0 || total_bases == 0) return UKM_OK;
+    // every canonical hash, in a workspace buffer (windows <= bases, also when circular)
+    u64 *h = nullptr;
+    UKM_TRY(ws_alloc_t(c, total_bases, &h));
+    u64 n_h = 0;
+    const u64 *off = nullptr;
+    UKM_TRY(run_windows(c, true, bases, rec_off, n_rec, k, 1, circular, 0, h, total_bases, &n_h, total_bases, &off));
+    if (n_h == 0) return UKM_OK;
+    const u64 ntiles = (n_h + MT - 1) / MT;
+    u64 *ctl = nullptr, *tile_rec = nullptr;
+    const size_t nctl = 8 + lb_status_words(ntiles);
+    UKM_TRY(ws_alloc_t(c, nctl, &ctl));
+    UKM_HIP(hipMemsetAsync(ctl, 0, nctl * sizeof(u64), c->stream));
+    UKM_TRY(ws_alloc_t(c, ntiles + 3, &tile_rec));
+    hipLaunchKernelGGL(tile_first_rec_kernel, dim3((unsigned)((ntiles + 3 + 255) / 256)), dim3(256), 0, c->stream,
+                       off, n_rec, n_h, ntiles, (u64)MT, tile_rec);
+    MinArgs p;
+    memset(&p, 0, sizeof(p));
+    p.h = h; p.off = off; p.n_rec = n_rec; p.total = n_h; p.w = w; p.max_hash = max_hash;
+    p.out = out; p.out_pos = out_pos; p.out_cap = out_cap;
+    p.result = ctl; p.ticket = (u32 *)(ctl + 2); p.status = ctl + 8; p.ntiles = ntiles; p.tile_rec = tile_rec;
+    (void)hipEventRecord(c->ev_k0, c->stream);
+    hipLaunchKernelGGL(minimizer_kernel, dim3((unsigned)ntiles), dim3(NT), 0, c->stream, p);
+    (void)hipEventRecord(c->ev_k1, c->stream);
+    c->evk_valid = true;
+    UKM_HIP(hipGetLastError());
+    u64 res = 0;
+    UKM_TRY(ukm_read_u64(c, ctl, &res));
+    *n_out = res;
+    if (res > out_cap)
+        UKM_FAIL(UKM_ERR_CAPACITY, "output needs %llu values, capacity is %llu", (unsigned long long)res,
+                 (unsigned long long)out_cap);
     return UKM_OK;
 }
 
@@ -474,6 +638,45 @@ extern "C" int ukm_nthash(ukm_ctx *ctx, const uint8_t *bases, const uint64_t *re
                           uint64_t out_cap, uint64_t *n_out) {
     return windows_entry(ctx, true, bases, rec_off, n_rec, k, canonical, circular, max_hash, out, out_cap, n_out,
                          "ukm_nthash");
+}
+
+// sketches.NewMinimizerSketch(seq, k, w, circular).NextMinimizer() (count.go:316,357) + the Scaled
+// filter applied to the emitted minimizers (count.go:373-375)
+extern "C" int ukm_minimizer(ukm_ctx *ctx, const uint8_t *bases, const uint64_t *rec_off, uint64_t n_rec,
+                             int k, int w, int circular, uint64_t max_hash, uint64_t *out,
+                             uint64_t *out_pos, uint64_t out_cap, uint64_t *n_out) {
+    const char *name = "ukm_minimizer";
+    if (!ctx || !n_out || (!out && out_cap) || (n_rec && (!rec_off || !bases)))
+        UKM_FAIL(UKM_ERR_INVALID, "%s: NULL argument", name);
+    if (k < 1 || k > 64) UKM_FAIL(UKM_ERR_K, "%s: k = %d out of range", name, k);
+    if (w < 1 || w > MW_MAX) UKM_FAIL(UKM_ERR_INVALID, "%s: w = %d out of range [1, %d]", name, w, MW_MAX);
+    *n_out = 0;
+    if (n_rec == 0) return UKM_OK;
+    CallScope s;
+    UKM_TRY(ukm_begin(ctx, &s));
+    int rc = [&]() -> int {
+        const u64 *off = nullptr;
+        UKM_TRY(ukm_in_t(ctx, rec_off, n_rec + 1, &off));
+        u64 total_bases = 0, first = 0;
+        if (ukm_is_device_ptr(rec_off)) {
+            UKM_TRY(ukm_read_u64(ctx, off + n_rec, &total_bases));
+            UKM_TRY(ukm_read_u64(ctx, off, &first));
+        } else {
+            total_bases = rec_off[n_rec];
+            first = rec_off[0];
+        }
+        if (first != 0) UKM_FAIL(UKM_ERR_INVALID, "%s: rec_off[0] must be 0", name);
+        const u8 *b = nullptr;
+        u64 *o = nullptr, *op = nullptr;
+        UKM_TRY(ukm_in_t(ctx, bases, total_bases, &b));
+        UKM_TRY(ukm_out_t(ctx, out, out_cap, &o));
+        if (out_pos) UKM_TRY(ukm_out_t(ctx, out_pos, out_cap, &op));
+        int r = run_minimizer(ctx, b, off, n_rec, k, w, circular, max_hash, o, op, out_cap, n_out, total_bases);
+        ukm_out_resize(ctx, out, (r == UKM_OK ? *n_out : 0) * sizeof(u64));
+        if (out_pos) ukm_out_resize(ctx, out_pos, (r == UKM_OK ? *n_out : 0) * sizeof(u64));
+        return r;
+    }();
+    return ukm_finish(&s, rc);
 }
 
 // count.go:98  maxHash := uint64(float64(^uint64(0)) / float64(scale))

@@ -362,7 +362,15 @@ static int cmd_count(int argc, char **argv) {
     if (scale < 1 || scale > 0x7fffffffLL) die("value of flag --scale is too big");
     const bool scaled = scale > 1;
     if (scaled && !hashed) { hashed = true; fprintf(stderr, "[WARN] flag -H/--hash is switched on for scale > 1\n"); }
-    if (a.num("minimizer-w", 0) > 0 || a.num("syncmer-s", 0) > 0) die("-W/--minimizer-w and -S/--syncmer-s are not supported in this build");
+    const long long minimizer_w = a.num("minimizer-w", 0);
+    if (minimizer_w < 0 || minimizer_w > 0x7fffffffLL) die("value of flag --minimizer-w is too big");
+    const bool minimizer = minimizer_w > 0;
+    if (minimizer) {  // count.go:100-113 (the sketch itself is always canonical; the -K file flag stays as given)
+        if (!hashed) { hashed = true; fprintf(stderr, "[WARN] flag -H/--hash is switched on for minimizer-w > 1\n"); }
+        if (!canonical) fprintf(stderr, "[WARN] flag -K/--canonical is switched on for minimizer-w > 1\n");
+        if (k > 64) die("k-mer size (%d) should be <=64", k);
+    }
+    if (a.num("syncmer-s", 0) > 0) die("-S/--syncmer-s is not supported in this build");
     if (repeated && unique) die("flag -d/--repeated and -u/--unique are not compatible");
     const u32 gtaxid = (u32)a.num("taxid", 0);
     const bool parse_taxid = a.has("parse-taxid");
@@ -407,13 +415,14 @@ static int cmd_count(int argc, char **argv) {
     vector<u64> codes(cap ? cap : 1);
     u64 n = 0;
     if (nrec) {
-        if (hashed) ck(ukm_nthash(g.c, sb.bases.data(), sb.off.data(), nrec, k, canonical, circular, max_hash, codes.data(), cap, &n));
+        if (minimizer) ck(ukm_minimizer(g.c, sb.bases.data(), sb.off.data(), nrec, k, (int)minimizer_w, circular, max_hash, codes.data(), nullptr, cap, &n));
+        else if (hashed) ck(ukm_nthash(g.c, sb.bases.data(), sb.off.data(), nrec, k, canonical, circular, max_hash, codes.data(), cap, &n));
         else ck(ukm_encode_kmers(g.c, sb.bases.data(), sb.off.data(), nrec, k, canonical, circular, codes.data(), cap, &n));
     }
     codes.resize(n);
     vector<u32> taxids;
     if (parse_taxid) {  // per-window taxid = its record's taxid (only without the Scaled filter, whose survivors lose their record)
-        if (scaled) die("-T/--parse-taxid together with -D/--scale is not supported in this build");
+        if (scaled || minimizer) die("-T/--parse-taxid together with -D/--scale or -W/--minimizer-w is not supported in this build");
         taxids.reserve(n);
         for (u64 r = 0; r < nrec; r++) {
             u64 len = sb.off[r + 1] - sb.off[r];

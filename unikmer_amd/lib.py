@@ -25,7 +25,7 @@ SYMBOLS = [
     "ukm_last_error", "ukm_version", "ukm_device_count", "ukm_ctx_create", "ukm_ctx_destroy",
     "ukm_ctx_set_stream", "ukm_ctx_sync", "ukm_ctx_reserve", "ukm_dev_alloc", "ukm_dev_free",
     "ukm_copy", "ukm_last_kernel_ms", "ukm_last_call_ms", "ukm_taxonomy_load", "ukm_taxonomy_max_taxid", "ukm_lca",
-    "ukm_encode_kmers", "ukm_nthash", "ukm_max_hash", "ukm_sort_u64", "ukm_sort_pairs",
+    "ukm_encode_kmers", "ukm_nthash", "ukm_minimizer", "ukm_max_hash", "ukm_sort_u64", "ukm_sort_pairs",
     "ukm_unique", "ukm_merge_k", "ukm_setop2", "ukm_union", "ukm_inter", "ukm_diff",
     "ukm_common", "ukm_common_threshold", "ukm_partition_points",
 ]
@@ -103,6 +103,7 @@ def load():
     L.ukm_lca.argtypes = [vp, vp, vp, u64, vp]
     L.ukm_encode_kmers.argtypes = [vp, vp, vp, u64, i32, i32, i32, vp, u64, pu64]
     L.ukm_nthash.argtypes = [vp, vp, vp, u64, i32, i32, i32, u64, vp, u64, pu64]
+    L.ukm_minimizer.argtypes = [vp, vp, vp, u64, i32, i32, i32, u64, vp, vp, u64, pu64]
     L.ukm_max_hash.argtypes = [u64]
     L.ukm_max_hash.restype = u64
     L.ukm_sort_u64.argtypes = [vp, vp, u64, i32]
@@ -260,6 +261,21 @@ class Context:
 
     def nthash(self, bases, rec_off, k, canonical=True, circular=False, max_hash=0, out=None):
         return self._windows("nt", bases, rec_off, k, canonical, circular, max_hash, out)
+
+    def minimizer(self, bases, rec_off, k, w, circular=False, max_hash=0, with_pos=False):
+        """Minimizer sketch of every record (sketches.NewMinimizerSketch, count.go:316).  Returns the
+        emitted canonical ntHash values in record/group order (and their window indices)."""
+        pb, nb, _ = _ptr(bases, np.uint8)
+        poff, noff, _ = _ptr(rec_off, np.uint64)
+        cap = nb
+        out = _empty_like_kind(bases, cap, np.uint64)
+        pos = _empty_like_kind(bases, cap, np.uint64) if with_pos else None
+        po, _, _ = _ptr(out, np.uint64)
+        pp = _ptr(pos, np.uint64)[0] if with_pos else None
+        n = C.c_uint64()
+        _check(self.L.ukm_minimizer(self.h, pb, poff, noff - 1, k, w, int(circular), max_hash, po, pp, cap,
+                                    C.byref(n)))
+        return (out[: n.value], pos[: n.value]) if with_pos else out[: n.value]
 
     def max_hash(self, scale):
         return self.L.ukm_max_hash(scale)
