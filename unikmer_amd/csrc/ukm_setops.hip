@@ -244,6 +244,57 @@ __device__ __forceinline__ u32 tile_check_order(const TileGeom &g, int tid, cons
     return bad;
 }
 
+// ---- fast load / order check for tiles well inside both inputs (plain keys only) ---------------------
+// When a0 >= 2, a1 + 2 <= na, b0 >= 2 and b1 + 5 <= nb, every slot of region A [0, split) and of
+// region B [split, SLOTS) can be filled from the input itself: the slots that are padding in the
+// generic layout (slot 0 under odd parity, the gap in front of region B, the tail) then hold the
+// real neighbours a[a0-2], a[a1+1], b[b0-2], b[b1+1 ...].  Each region is a run of adjacent input
+// elements, so neither the loads nor the order check need per-slot validity logic (about 200 of
+// the 1200 VALU instructions a wave spends on a tile).  A violation seen in an over-read element
+// is a real violation of the input (the neighbouring tile reports it too).
+template <int NTH, int VT>
+__device__ __forceinline__ bool tile_is_fast(const SetopArgs &p, const TileGeom &g) {
+    return g.na_t + g.nb_t == NTH * VT && g.a0 >= 2 && g.a0 + (u64)g.na_t + 2 <= p.na && g.b0 >= 2 &&
+           g.b0 + (u64)g.nb_t + 5 <= p.nb;
+}
+
+template <int NTH, int VT>
+__device__ __forceinline__ void tile_load_fast(const SetopArgs &p, const TileGeom &g, int tid,
+                                               u64 (&rk)[2 * TilePairs<NTH, VT>::NP]) {
+    constexpr int NP = TilePairs<NTH, VT>::NP;
+    constexpr int SLOTS = NTH * VT + 8;
+    const u64 *pa = p.a + g.a0 - 1 - g.sa0;  // slot s of region A is pa[s]
+    const u64 *pb = p.b + g.b0 - 1 - g.sb0;  // slot s of region B is pb[s]
+    const u64 *safe = p.result;
+#pragma unroll
+    for (int j = 0; j < NP; j++) {
+        const int s0 = 2 * (tid + j * NTH);
+        const u64 *src = (s0 < g.split ? pa : pb) + s0;
+        if (2 * (NTH - 1 + j * NTH) + 1 >= SLOTS) src = (s0 < SLOTS) ? src : safe;  // last round only (compile time)
+        const ulonglong2 q = *reinterpret_cast<const ulonglong2 *>(src);
+        rk[2 * j] = q.x;
+        rk[2 * j + 1] = q.y;
+    }
+}
+
+template <int NTH, int VT>
+__device__ __forceinline__ u32 tile_check_order_fast(const TileGeom &g, int tid,
+                                                     const u64 (&rk)[2 * TilePairs<NTH, VT>::NP], const u64 *s_keys) {
+    constexpr int NP = TilePairs<NTH, VT>::NP;
+    constexpr int SLOTS = NTH * VT + 8;
+    bool unsorted = false, dup = false;
+#pragma unroll
+    for (int j = 0; j < NP; j++) {
+        const int s0 = 2 * (tid + j * NTH);
+        bool c0 = (s0 != 0) & (s0 != g.split), c1 = true;  // slot s0 - 1 belongs to the same region
+        if (2 * (NTH - 1 + j * NTH) + 1 >= SLOTS) { c1 = s0 < SLOTS; c0 &= c1; }
+        const u64 pk = s_keys[s0 > 0 ? s0 - 1 : 0], k0 = rk[2 * j], k1 = rk[2 * j + 1];
+        unsorted |= (c0 & (pk > k0)) | (c1 & (k0 > k1));
+        dup |= (c0 & (pk == k0)) | (c1 & (k0 == k1));
+    }
+    return (unsorted ? FLAG_UNSORTED : 0u) | (dup ? FLAG_DUP : 0u);
+}
+
 // Per-thread merge-path search inside the LDS tile, then a VT-step serial merge that decides
 // emit/skip for each merged item.  Outputs stay in registers (ok/ot + bit mask).
 // Sets are strictly increasing, so an equal (A[i], B[j]) pair is adjacent in merge order (A
@@ -410,7 +461,12 @@ __device__ __forceinline__ void tile_flush(const SetopArgs &p, int tid, u64 base
 //   and the host re-runs with TICKET = true, where tile ids come from an atomic counter and
 //   forward progress holds for any dispatch order.
 template <int OP, bool TAX, bool RANK, bool TICKET, int NTH, int VT>
-__global__ __launch_bounds__(NTH) void setop_tile_kernel(SetopArgs p) {
+#ifndef SETOP_WAVES_PER_EU
+#define SETOP_WAVES_ATTR
+#else
+#define SETOP_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(SETOP_WAVES_PER_EU, SETOP_WAVES_PER_EU)))
+#endif
+__global__ __launch_bounds__(NTH) SETOP_WAVES_ATTR void setop_tile_kernel(SetopArgs p) {
     constexpr int TILE = NTH * VT;
     constexpr int SLOTS = TILE + 8;
     constexpr int NP = TilePairs<NTH, VT>::NP;
@@ -436,29 +492,47 @@ __global__ __launch_bounds__(NTH) void setop_tile_kernel(SetopArgs p) {
     {
         u64 rk[2 * NP];
         u32 rt[2 * NP], rr[2 * NP];
-        tile_load<TAX, RANK, NTH, VT>(p, g, tid, rk, rt, rr);
+        bool fast = false;
+#ifndef SETOP_NO_FAST
+        if (!TAX && !RANK) fast = tile_is_fast<NTH, VT>(p, g);  // workgroup-uniform
+#endif
+        if (fast) tile_load_fast<NTH, VT>(p, g, tid, rk);
+        else tile_load<TAX, RANK, NTH, VT>(p, g, tid, rk, rt, rr);
         tile_to_lds<TAX, RANK, NTH, VT>(tid, rk, rt, rr, s_keys, s_tax, s_rank);
         __syncthreads();
         PH(1);
-        bad = tile_check_order<RANK, NTH, VT>(g, tid, rk, rr, s_keys, s_rank);
+        if (fast) bad = tile_check_order_fast<NTH, VT>(g, tid, rk, s_keys);
+        else bad = tile_check_order<RANK, NTH, VT>(g, tid, rk, rr, s_keys, s_rank);
     }
     u64 ok[VT];
     u32 ot[VT];
     u32 mask;
+#ifdef SETOP_ABL_NOMERGE  // experiment only: timing without the search + serial merge
+    mask = 0xAAAAu | (u32)(tid & 1);
+#pragma unroll
+    for (int s = 0; s < VT; s++) { ok[s] = s_keys[tid * VT + s]; ot[s] = 0; }
+#else
     tile_merge<OP, TAX, RANK, NTH, VT>(p, g, tid, s_keys, s_tax, s_rank, ok, ot, mask);
+#endif
     PH(2);
     u32 tile_total;
     const u32 excl = block_excl_scan_u32<NTH>((u32)__popc(mask), s_scan, &tile_total);
     // (the scan's barriers also guarantee every thread finished reading the tile from LDS)
     if (tid == 0) lb_publish(p.status, tile, (u64)tile_total);
+#ifndef SETOP_ABL_NOCOMPACT
     tile_compact<TAX, VT>(excl, mask, ok, ot, s_keys, s_tax);
+#endif
     PH(3);
     if (tid < 64) {
         bool timed_out = false;
 #ifdef LB_PRE_SLEEP
         __builtin_amdgcn_s_sleep(LB_PRE_SLEEP);
 #endif
+#ifdef SETOP_ABL_NOLB  // experiment only: wrong output positions, no look-back
+        const u64 base = tile * (u64)TILE;
+#else
         const u64 base = lb_resolve(p.status, tile, (u64)tile_total, lane_id(), &timed_out);
+#endif
         if (tid == 0) s_misc[1] = base;
         if (timed_out) bad |= FLAG_TIMEOUT;
     }
@@ -466,7 +540,9 @@ __global__ __launch_bounds__(NTH) void setop_tile_kernel(SetopArgs p) {
     if (bad) atomicOr((unsigned long long *)&p.result[1], (unsigned long long)bad);
     __syncthreads();
     const u64 base = s_misc[1];
+#ifndef SETOP_ABL_NOFLUSH
     tile_flush<TAX, NTH>(p, tid, base, tile_total, s_keys, s_tax);
+#endif
     if (tid == 0 && tile == p.ntiles - 1) p.result[0] = base + tile_total;
     PH(5);
 #ifdef UKM_PROFILE_PHASES
