@@ -96,6 +96,17 @@ def main():
         assert bool((work[1:] >= work[:-1]).all())
         res["sort_u64_62bit"] = {"call_ms": t, "median_ms": med, "keys_per_s": n / t * 1e3,
                                  "GBps_algorithmic(8n+8*16n)": (8 * n + 8 * 16 * n) / t / 1e6}
+        # library reference on the same box: torch.sort -> rocPRIM radix sort (64-bit keys, all 8 bytes)
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ts = []
+        for _ in range(4):
+            ev0.record()
+            sk = torch.sort(keys).values
+            ev1.record()
+            torch.cuda.synchronize()
+            ts.append(ev0.elapsed_time(ev1))
+            del sk
+        res["torch_sort_rocprim_int64"] = {"ms": min(ts), "keys_per_s": n / min(ts) * 1e3}
         vals = torch.arange(n, dtype=torch.int32, device=dev)
         wv = torch.empty_like(vals)
 

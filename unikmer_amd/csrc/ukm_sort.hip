@@ -8,7 +8,7 @@
 //     serialise on one bin); the host turns them into per-pass digit bases and drops passes
 //     whose digit is constant (k=31 -> 62 significant bits; top bits of k=21 codes are zero);
 //   * per executed pass ONE "onesweep" kernel: each 256-thread workgroup takes a ticketed tile
-//     of 4096 keys, ranks them stably with wave64 ballot match-any (8 ballots per key) into
+//     of 6144 keys (256 threads x 24), ranks them stably with wave64 ballot match-any (8 ballots per key) into
 //     per-wave LDS digit counters, resolves the tile's global digit offsets by a per-digit
 //     decoupled look-back over the previous tiles' counts (thread d owns digit d), reorders
 //     the tile through LDS so that global stores are contiguous per digit, and scatters.
@@ -19,9 +19,15 @@
 
 namespace {
 
-constexpr int NT = 256;
+#ifndef SORT_NT
+#define SORT_NT 256
+#endif
+#ifndef SORT_VT
+#define SORT_VT 24
+#endif
+constexpr int NT = SORT_NT;  // >= RADIX: thread d < 256 owns digit d
 constexpr int NW = NT / 64;
-constexpr int VT = 16;
+constexpr int VT = SORT_VT;
 constexpr int TILE = NT * VT;
 constexpr int RADIX = 256;
 constexpr int MAX_PASSES = 8;
@@ -32,20 +38,30 @@ __global__ __launch_bounds__(NT) void radix_hist_kernel(const u64 *k, u64 n, int
     const int tid = (int)threadIdx.x;
     for (int i = tid; i < MAX_PASSES * RADIX; i += NT) s_h[i] = 0;
     __syncthreads();
-    const u64 per_block = ((n + gridDim.x - 1) / gridDim.x + 63) / 64 * 64;
+    constexpr int U = 4;  // independent loads in flight per thread (one load per iteration was latency bound: 1.6 TB/s)
+    const u64 per_block = ((n + gridDim.x - 1) / gridDim.x + (u64)(NT * U) - 1) / (u64)(NT * U) * (u64)(NT * U);
     const u64 beg = (u64)blockIdx.x * per_block;
     const u64 end = (beg + per_block < n) ? beg + per_block : n;
-    for (u64 i = beg + tid; i < ((end + NT - 1) / NT) * NT && beg < end; i += NT) {
-        const bool valid = i < end;
-        const u64 key = valid ? k[i] : 0;
-        for (int p = 0; p < passes; p++) {
-            const u32 d = (u32)(key >> (8 * p)) & 255u;
-            const u32 d0 = __builtin_amdgcn_readfirstlane(d);
-            const u64 vm = __ballot(valid);
-            if (vm == ~0ull && __all(d == d0)) {
-                if (lane_id() == 0) atomicAdd(&s_h[p * RADIX + d0], 64u);
-            } else if (valid) {
-                atomicAdd(&s_h[p * RADIX + d], 1u);
+    for (u64 i0 = beg; i0 < end; i0 += (u64)NT * U) {
+        u64 key[U];
+        bool valid[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const u64 i = i0 + (u64)u * NT + tid;
+            valid[u] = i < end;
+            key[u] = k[valid[u] ? i : end - 1];  // unconditional load (a branch around it would serialise the loads)
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const u64 vm = __ballot(valid[u]);
+            for (int p = 0; p < passes; p++) {
+                const u32 d = (u32)(key[u] >> (8 * p)) & 255u;
+                const u32 d0 = __builtin_amdgcn_readfirstlane(d);
+                if (vm == ~0ull && __all(d == d0)) {
+                    if (lane_id() == 0) atomicAdd(&s_h[p * RADIX + d0], 64u);
+                } else if (valid[u]) {
+                    atomicAdd(&s_h[p * RADIX + d], 1u);
+                }
             }
         }
     }
@@ -82,6 +98,54 @@ struct PassArgs {
     u64 ntiles;
 };
 
+// "match any" on an 8-bit digit: on return (phi:plo) is the 64-bit mask of the lanes whose digit
+// equals this lane's.  Per bit: sign-extended bit x (0 / -1), ballot m = (x != 0), peers &= ~(m ^ x)
+// with gfx950's three-input v_bitop3_b32 (truth table 0x90 = a & ~(b ^ c)) on each 32-bit half:
+// 4 VALU instructions per bit.  Hand-scheduled because a VALU read of an SGPR needs 2 wait states
+// after the VALU write: three ballot registers rotate so that every v_cmp is at least 2
+// instructions ahead of its first reader (the compiler's version spent s_nops or extra shifts
+// here and the ranking made the kernel VALU bound: 85 -> 36 instructions per key).
+__device__ __forceinline__ void match_any8(u32 d, u32 &plo, u32 &phi) {
+    u32 x, y, z;
+    plo = ~0u;
+    phi = ~0u;
+    asm("v_bfe_i32 %2, %5, 0, 1\n\t"
+        "v_bfe_i32 %3, %5, 1, 1\n\t"
+        "v_bfe_i32 %4, %5, 2, 1\n\t"
+        "v_cmp_ne_u32_e64 vcc, 0, %2\n\t"
+        "v_cmp_ne_u32_e64 s[98:99], 0, %3\n\t"
+        "v_cmp_ne_u32_e64 s[100:101], 0, %4\n\t"
+        "v_bitop3_b32 %0, %0, vcc_lo, %2 bitop3:0x90\n\t"
+        "v_bitop3_b32 %1, %1, vcc_hi, %2 bitop3:0x90\n\t"
+        "v_bfe_i32 %2, %5, 3, 1\n\t"
+        "v_cmp_ne_u32_e64 vcc, 0, %2\n\t"
+        "v_bitop3_b32 %0, %0, s98, %3 bitop3:0x90\n\t"
+        "v_bitop3_b32 %1, %1, s99, %3 bitop3:0x90\n\t"
+        "v_bfe_i32 %3, %5, 4, 1\n\t"
+        "v_cmp_ne_u32_e64 s[98:99], 0, %3\n\t"
+        "v_bitop3_b32 %0, %0, s100, %4 bitop3:0x90\n\t"
+        "v_bitop3_b32 %1, %1, s101, %4 bitop3:0x90\n\t"
+        "v_bfe_i32 %4, %5, 5, 1\n\t"
+        "v_cmp_ne_u32_e64 s[100:101], 0, %4\n\t"
+        "v_bitop3_b32 %0, %0, vcc_lo, %2 bitop3:0x90\n\t"
+        "v_bitop3_b32 %1, %1, vcc_hi, %2 bitop3:0x90\n\t"
+        "v_bfe_i32 %2, %5, 6, 1\n\t"
+        "v_cmp_ne_u32_e64 vcc, 0, %2\n\t"
+        "v_bitop3_b32 %0, %0, s98, %3 bitop3:0x90\n\t"
+        "v_bitop3_b32 %1, %1, s99, %3 bitop3:0x90\n\t"
+        "v_bfe_i32 %3, %5, 7, 1\n\t"
+        "v_cmp_ne_u32_e64 s[98:99], 0, %3\n\t"
+        "v_bitop3_b32 %0, %0, s100, %4 bitop3:0x90\n\t"
+        "v_bitop3_b32 %1, %1, s101, %4 bitop3:0x90\n\t"
+        "v_bitop3_b32 %0, %0, vcc_lo, %2 bitop3:0x90\n\t"
+        "v_bitop3_b32 %1, %1, vcc_hi, %2 bitop3:0x90\n\t"
+        "v_bitop3_b32 %0, %0, s98, %3 bitop3:0x90\n\t"
+        "v_bitop3_b32 %1, %1, s99, %3 bitop3:0x90"
+        : "+v"(plo), "+v"(phi), "=&v"(x), "=&v"(y), "=&v"(z)
+        : "v"(d)
+        : "vcc", "s98", "s99", "s100", "s101");
+}
+
 #ifndef SORT_LB_W
 #define SORT_LB_W 4
 #endif
@@ -90,8 +154,13 @@ struct PassArgs {
 #endif
 // TICKET = false: tile id = blockIdx.x (see ukm_setops.hip for the liveness argument and the
 // watchdog); TICKET = true: ids from an atomic counter, dispatch-order independent.
+#ifdef SORT_WAVES_PER_EU
+#define SORT_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(SORT_WAVES_PER_EU, SORT_WAVES_PER_EU)))
+#else
+#define SORT_WAVES_ATTR
+#endif
 template <typename SW, bool PAIRS, bool TICKET>
-__global__ __launch_bounds__(NT) void onesweep_kernel(PassArgs<SW> p) {
+__global__ __launch_bounds__(NT) SORT_WAVES_ATTR void onesweep_kernel(PassArgs<SW> p) {
     using T = SWTraits<SW>;
     __shared__ u64 s_keys[TILE];
     __shared__ u32 s_vals[PAIRS ? TILE : 1];
@@ -120,46 +189,55 @@ __global__ __launch_bounds__(NT) void onesweep_kernel(PassArgs<SW> p) {
         key[j] = v ? p.kin[tbase + li] : ~0ull;
         if (PAIRS) val[j] = v ? p.vin[tbase + li] : 0;
     }
-    const u64 lt_mask = (1ull << lane) - 1;
+    // Stable ranking inside the wave by "match any": after 8 ballots `peers` holds the lanes whose
+    // digit equals this lane's.  Written on 32-bit halves with a sign-extended bit (0 / -1) and gfx950's
+    // three-input v_bitop3_b32 (peers & ~(ballot ^ bit) in ONE instruction), so that a digit bit costs
+    // v_bfe_i32 + v_cmp + 2 x v_bitop3: the 64-bit `bit ? m : ~m` form compiled to 9 VALU
+    // instructions per bit and made the kernel VALU bound.
+    const u32 lt_lo = lane < 32 ? ((1u << lane) - 1u) : ~0u;
+    const u32 lt_hi = lane < 32 ? 0u : ((1u << (lane - 32)) - 1u);
 #pragma unroll
     for (int j = 0; j < VT; j++) {
         const u32 li = wbase_idx + j * 64;
         // padding items take digit 255; they sit at the end of the tile order, so they rank
         // after every real key of that digit and are dropped at write-out
         const u32 d = (li < valid_count) ? ((u32)(key[j] >> p.shift) & 255u) : 255u;
-        u64 peers = ~0ull;
-#pragma unroll
-        for (int b = 0; b < 8; b++) {
-            const bool bit = (d >> b) & 1u;
-            const u64 m = __ballot(bit);
-            peers &= bit ? m : ~m;
-        }
+        u32 plo, phi;
+        match_any8(d, plo, phi);
         const u32 pre = s_whist[wave][d];
-        const u32 r = (u32)__popcll(peers & lt_mask);
+        const u32 r = (u32)__popc(plo & lt_lo) + (u32)__popc(phi & lt_hi);
+        const u32 tot = (u32)__popc(plo) + (u32)__popc(phi);
         rank[j] = pre + r;
-        if (r == (u32)__popcll(peers) - 1) s_whist[wave][d] = pre + r + 1;  // highest peer lane
+        // every peer stores the same new count (same address, same value): no branch, so the 16 keys'
+        // ranking stays one basic block that the scheduler can interleave
+        s_whist[wave][d] = pre + tot;
     }
     __syncthreads();
 
     // thread d: exclusive scan over the waves, tile count of digit d
-    const int d = tid;
+    const int d = tid & (RADIX - 1);
+    const bool owner = tid < RADIX;  // workgroup-size independent: the first 256 threads own the digits
     u32 cnt = 0;
+    if (owner) {
 #pragma unroll
-    for (int w = 0; w < NW; w++) {
-        u32 c = s_whist[w][d];
-        s_whist[w][d] = cnt;
-        cnt += c;
+        for (int w = 0; w < NW; w++) {
+            u32 c = s_whist[w][d];
+            s_whist[w][d] = cnt;
+            cnt += c;
+        }
     }
     u32 real_cnt = cnt;
     if (d == 255) real_cnt -= (u32)TILE - valid_count;
     // publish the tile's count of digit d, then look back
     SW *st = p.status + tile * RADIX + d;
-    if (tile == 0) __hip_atomic_store(st, (SW)(T::INCL | (SW)real_cnt), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    else __hip_atomic_store(st, (SW)(T::AGG | (SW)real_cnt), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (owner) {
+        if (tile == 0) __hip_atomic_store(st, (SW)(T::INCL | (SW)real_cnt), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else __hip_atomic_store(st, (SW)(T::AGG | (SW)real_cnt), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 
     u32 tile_total;
     const u32 dex = block_excl_scan_u32<NT>(cnt, s_scan, &tile_total);  // contains barriers
-    s_dexcl[d] = dex;
+    if (owner) s_dexcl[d] = dex;
     __syncthreads();
 
     // local reorder: tile becomes digit-sorted (stable) in LDS
@@ -177,7 +255,13 @@ __global__ __launch_bounds__(NT) void onesweep_kernel(PassArgs<SW> p) {
     // device-scope round trip, so a one-tile-per-hop walk was latency bound)
     u64 excl = 0;
     bool timed_out = false;
-    if (tile > 0) {
+#ifdef SORT_ABL_NOLB  // experiment only: plausible but wrong offsets, no look-back
+    excl = tile * (u64)real_cnt;
+    if (p.gbase[d] + excl + real_cnt > p.n) excl = 0;
+    if (false) {
+#else
+    if (tile > 0 && owner) {
+#endif
         long long t = (long long)tile - 1;
         u32 spins = 0;
         bool done = false;
@@ -210,7 +294,7 @@ __global__ __launch_bounds__(NT) void onesweep_kernel(PassArgs<SW> p) {
         __hip_atomic_store(st, (SW)(T::INCL | (SW)(excl + real_cnt)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     if (timed_out) atomicOr(p.flags, 1u);
-    s_gbase[d] = p.gbase[d] + excl - (u64)dex;
+    if (owner) s_gbase[d] = p.gbase[d] + excl - (u64)dex;
     __syncthreads();
 
     for (u32 i = (u32)tid; i < valid_count; i += NT) {
