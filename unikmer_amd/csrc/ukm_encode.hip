@@ -38,7 +38,7 @@ constexpr int PPT = 9;          // positions per thread in the blocked phase (25
 constexpr int NWV = NT / 64;
 
 // kmers v0.1.0 base table; 4 = illegal base
-__device__ __forceinline__ u32 base2bit(u32 c) {
+constexpr u32 base2bit(u32 c) {
     switch (c) {
     case 'A': case 'a': case 'N': case 'n': case 'M': case 'm': case 'V': case 'v':
     case 'H': case 'h': case 'R': case 'r': case 'D': case 'd': case 'W': case 'w': return 0;
@@ -54,26 +54,49 @@ __device__ __forceinline__ u32 base2bit(u32 c) {
 #define SEED_G 0x20323ed082572324ULL
 #define SEED_T 0x295549f54be24456ULL
 
-__device__ __forceinline__ u64 nt_seed(u32 c) {
+// branch-free rotates: for s = 0 both shifts are by 0 and x | x = x
+__device__ __forceinline__ u64 rol64(u64 x, u32 s) { return (x << (s & 63)) | (x >> ((0u - s) & 63)); }
+__device__ __forceinline__ u64 ror64(u64 x, u32 s) { return (x >> (s & 63)) | (x << ((0u - s) & 63)); }
+
+// The switches above compile to chains of exec-mask branches (measured: 2050 SALU + 1100 VALU
+// instructions per wave per tile, instruction-issue bound).  Every workgroup therefore builds a
+// 256-entry byte table once (one entry per thread) and the per-base work becomes LDS lookups:
+// low nibble = 2-bit code (4 = illegal base), high nibble = ntHash seed index (A0 C1 G2 T3, 4 = the
+// zero seed of every other byte); seeds come from two 5-entry tables (forward / complement).
+constexpr u32 nt_index(u32 c) {
     switch (c) {
-    case 'A': case 'a': return SEED_A;
-    case 'C': case 'c': return SEED_C;
-    case 'G': case 'g': return SEED_G;
-    case 'T': case 't': case 'U': case 'u': return SEED_T;
-    default: return 0;
+    case 'A': case 'a': return 0;
+    case 'C': case 'c': return 1;
+    case 'G': case 'g': return 2;
+    case 'T': case 't': case 'U': case 'u': return 3;
+    default: return 4;
     }
 }
-__device__ __forceinline__ u64 nt_cseed(u32 c) {
-    switch (c) {
-    case 'A': case 'a': return SEED_T;
-    case 'C': case 'c': return SEED_G;
-    case 'G': case 'g': return SEED_C;
-    case 'T': case 't': case 'U': case 'u': return SEED_A;
-    default: return 0;
+struct ByteTable {
+    u8 v[256];
+};
+constexpr ByteTable make_byte_table() {
+    ByteTable t{};
+    for (u32 c = 0; c < 256; c++) t.v[c] = (u8)(base2bit(c) | (nt_index(c) << 4));
+    return t;
+}
+__device__ const ByteTable g_byte_table = make_byte_table();  // built at compile time
+
+struct BaseTables {
+    u8 lut[256];
+    u64 seed[8];   // [0..4] forward seeds
+    u64 cseed[8];  // [0..4] seeds of the complement
+};
+__device__ __forceinline__ void base_tables_init(BaseTables &t, int tid) {
+    static_assert(NT == 256, "one table entry per thread");
+    t.lut[tid] = g_byte_table.v[tid];
+    if (tid < 5) {
+        const u64 f = tid == 0 ? SEED_A : tid == 1 ? SEED_C : tid == 2 ? SEED_G : tid == 3 ? SEED_T : 0ull;
+        const u64 c = tid == 0 ? SEED_T : tid == 1 ? SEED_G : tid == 2 ? SEED_C : tid == 3 ? SEED_A : 0ull;
+        t.seed[tid] = f;
+        t.cseed[tid] = c;
     }
 }
-__device__ __forceinline__ u64 rol64(u64 x, u32 s) { s &= 63; return s ? (x << s) | (x >> (64 - s)) : x; }
-__device__ __forceinline__ u64 ror64(u64 x, u32 s) { s &= 63; return s ? (x >> s) | (x << (64 - s)) : x; }
 
 struct WinArgs {
     const u8 *bases;
@@ -157,16 +180,18 @@ template <bool HASH, bool FILTER>
 __global__ __launch_bounds__(NT) void window_kernel(WinArgs p) {
     __shared__ __attribute__((aligned(16))) u8 s_b[TBX + 16];
     __shared__ u8 s_info[NT * PPT];                     // low 7 bits: min(bases left in record, 127); bit 7: record length >= k
-    __shared__ u32 s_rr[NT * PPT];                      // record index of the position, relative to s_r[0]
+    __shared__ u32 s_dl[FILTER ? 1 : NT * PPT];         // (bases - windows) in front of the position's record, relative to s_r[2]
     __shared__ u64 s_P[HASH ? NT * PPT + 1 : 1];        // XOR prefixes (ntHash)
     __shared__ u64 s_Q[HASH ? NT * PPT + 1 : 1];
     __shared__ u32 s_pk[HASH ? 1 : NT * PPT / 16 + 4];  // 2-bit packed bases, 16 per word (codes)
     __shared__ u32 s_bad[HASH ? 1 : NT * PPT / 32 + 4]; // illegal-base bit per position (codes)
     __shared__ u64 s_wtot[2 * NWV];
     __shared__ u32 s_cnt[WPT * NWV + 1];
-    __shared__ u64 s_r[2];
+    __shared__ u64 s_r[3];
     __shared__ u64 s_misc[2];
+    __shared__ BaseTables s_t;
     const int tid = (int)threadIdx.x, lane = lane_id(), wave = tid >> 6;
+    base_tables_init(s_t, tid);  // visible after the first barrier below
     u64 tile;
     if (FILTER) {
         if (tid == 0) s_misc[0] = (u64)atomicAdd(p.ticket, 1u);
@@ -198,6 +223,9 @@ __global__ __launch_bounds__(NT) void window_kernel(WinArgs p) {
     if (tid == 0) {
         s_r[0] = p.tile_rec[tile];          // record of P0
         s_r[1] = p.tile_rec[tile + 2] + 1;  // every position of the tile lies in a record <= this - 1
+        // output index of a window = its base position - gap(record), gap = rec_off[r] - out_off[r]
+        // (bases minus windows in front of the record; non-decreasing in r); s_r[2] = gap of the first record
+        if (!FILTER) { const u64 r0 = p.tile_rec[tile]; s_r[2] = p.rec_off[r0] - p.out_off[r0]; }
     }
     if (!HASH) {
         for (int i = tid; i < NT * PPT / 16 + 4; i += NT) s_pk[i] = 0;
@@ -211,6 +239,8 @@ __global__ __launch_bounds__(NT) void window_kernel(WinArgs p) {
         const u64 p_first = P0 + (u64)m0;
         const u64 r_first = s_r[0];
         u64 r = 0, rs = 0, re = 0;
+        u32 dl = 0;
+        const u64 gap0 = FILTER ? 0 : s_r[2];
         bool in_rec = false;
         if (p_first < p.total_bases && p.n_rec > 0) {
             const u64 hi = (s_r[1] + 1 < p.n_rec + 1) ? s_r[1] + 1 : p.n_rec + 1;
@@ -219,6 +249,7 @@ __global__ __launch_bounds__(NT) void window_kernel(WinArgs p) {
                 r = ub - 1;
                 rs = p.rec_off[r];
                 re = p.rec_off[r + 1];
+                if (!FILTER) dl = (u32)(rs - p.out_off[r] - gap0);
                 in_rec = true;
             }
         }
@@ -233,21 +264,23 @@ __global__ __launch_bounds__(NT) void window_kernel(WinArgs p) {
                 if (r >= p.n_rec) { in_rec = false; break; }
                 rs = re;
                 re = p.rec_off[r + 1];
+                if (!FILTER) dl = (u32)(rs - p.out_off[r] - gap0);
             }
             const bool live = in_rec && pos < p.total_bases && m < TBX;
             const u64 rem = live ? re - pos : 0;
             const u32 info = (u32)(rem > 127 ? 127 : rem) | ((live && (re - rs) >= (u64)k) ? 128u : 0u);
             s_info[m] = (u8)info;
-            s_rr[m] = live ? (u32)(r - r_first) : 0u;
+            if (!FILTER) s_dl[m] = dl;
             const u32 c = (m < TBX) ? s_b[m] : 0;
             if (HASH) {
                 // position m contributes ror(seed, m) to P and rol(cseed, m) to Q
-                accP ^= ror64(nt_seed(c), (u32)m);
-                accQ ^= rol64(nt_cseed(c), (u32)m);
+                const u32 si = (u32)s_t.lut[c] >> 4;
+                accP ^= ror64(s_t.seed[si], (u32)m);
+                accQ ^= rol64(s_t.cseed[si], (u32)m);
                 lp[s] = accP;
                 lq[s] = accQ;
             } else {
-                const u32 b = base2bit(c);
+                const u32 b = (u32)s_t.lut[c] & 15u;
                 // first base of a k-mer is most significant: pack position m at bits [2*(15 - m%16)] of word m/16
                 atomicOr(&s_pk[m >> 4], (b & 3u) << (2 * (15 - (m & 15))));
                 if (b > 3) atomicOr(&s_bad[m >> 5], 1u << (m & 31));
@@ -273,68 +306,69 @@ __global__ __launch_bounds__(NT) void window_kernel(WinArgs p) {
     __syncthreads();
 
     // ---- phase 2: striped over windows i = tid + j*NT ---------------------------------------------------
-    const u64 r_first = s_r[0];
+    const u64 out0 = FILTER ? 0 : P0 - s_r[2];
     u64 hv[WPT];
     u32 keep = 0, illegal = 0;
+    const u64 kmask = (k == 64) ? ~0ull : ((1ull << k) - 1);
 #pragma unroll
     for (int j = 0; j < WPT; j++) {
         const int i = tid + j * NT;
         const u32 info = s_info[i];
         const bool long_enough = (info & 128u) != 0;
         const bool fits = (int)(info & 127u) >= k;
-        const bool emit = long_enough && (fits || p.circular);
-        u64 v = 0;
-        if (emit) {
-            u64 f, rv;
-            bool bad = false;
-            if (fits) {
+        bool emit = long_enough && fits;
+        // the common case is computed unconditionally (no exec-mask branches around it)
+        u64 f, rv;
+        bool bad = false;
+        if (HASH) {
+            f = rol64(s_P[i + k] ^ s_P[i], (u32)(i + k - 1));
+            rv = ror64(s_Q[i + k] ^ s_Q[i], (u32)i);
+        } else {
+            // 2k-bit field starting at packed bit offset 2i (big-endian within 32-bit words)
+            const int w0 = i >> 4, sh = 2 * (i & 15);
+            const u64 hi = ((u64)s_pk[w0] << 32) | s_pk[w0 + 1];
+            const u64 lo = ((u64)s_pk[w0 + 2] << 32);
+            const u64 x = (hi << sh) | ((lo >> 1) >> (63 - sh));  // 64 bits = 32 bases from position i (sh may be 0)
+            f = x >> (64 - 2 * k);
+            rv = revcomp2(f, k);
+            // any illegal base among positions [i, i+k)?
+            const int b0 = i >> 5, bs = i & 31;
+            const u64 mlo = ((u64)s_bad[b0 + 1] << 32) | s_bad[b0];
+            const u64 mhi = s_bad[b0 + 2];
+            const u64 mbits = (mlo >> bs) | ((mhi << 1) << (63 - bs));
+            bad = (mbits & kmask) != 0;
+        }
+        if (long_enough && !fits && p.circular) {  // wrapped window: recompute from the record (k-1 per record)
+            const u64 pos = P0 + (u64)i;
+            const u64 hi_r = (s_r[1] + 1 < p.n_rec + 1) ? s_r[1] + 1 : p.n_rec + 1;
+            const u64 r = upper_bound_u64(p.rec_off, s_r[0], hi_r, pos) - 1;
+            const u64 rs = p.rec_off[r], len = p.rec_off[r + 1] - rs;
+            const u64 o = pos - rs;
+            f = 0; rv = 0; bad = false;
+            for (int q = 0; q < k; q++) {
+                u64 z = o + (u64)q;
+                if (z >= len) z -= len;
+                const u32 cc = p.bases[rs + z];
                 if (HASH) {
-                    f = rol64(s_P[i + k] ^ s_P[i], (u32)(i + k - 1));
-                    rv = ror64(s_Q[i + k] ^ s_Q[i], (u32)i);
+                    const u32 si = (u32)s_t.lut[cc] >> 4;
+                    f ^= rol64(s_t.seed[si], (u32)(k - 1 - q));
+                    rv ^= rol64(s_t.cseed[si], (u32)q);
                 } else {
-                    // 2k-bit field starting at packed bit offset 2i (big-endian within 32-bit words)
-                    const int w0 = i >> 4, sh = 2 * (i & 15);
-                    const u64 hi = ((u64)s_pk[w0] << 32) | s_pk[w0 + 1];
-                    const u64 lo = ((u64)s_pk[w0 + 2] << 32);
-                    const u64 x = sh ? ((hi << sh) | (lo >> (64 - sh))) : hi;  // 64 bits = 32 bases from position i
-                    f = x >> (64 - 2 * k);
-                    rv = revcomp2(f, k);
-                    // any illegal base among positions [i, i+k)?
-                    const int b0 = i >> 5, bs = i & 31;
-                    const u64 mlo = ((u64)s_bad[b0 + 1] << 32) | s_bad[b0];
-                    const u64 mhi = s_bad[b0 + 2];
-                    const u64 mbits = bs ? ((mlo >> bs) | (mhi << (64 - bs))) : mlo;
-                    bad = (mbits & (k == 64 ? ~0ull : ((1ull << k) - 1))) != 0;
-                }
-            } else {  // circular wrap: recompute from the record itself (k-1 windows per record)
-                const u64 r = r_first + s_rr[i];
-                const u64 rs = p.rec_off[r], len = p.rec_off[r + 1] - rs;
-                const u64 o = P0 + (u64)i - rs;
-                f = 0; rv = 0;
-                for (int q = 0; q < k; q++) {
-                    u64 z = o + (u64)q;
-                    if (z >= len) z -= len;
-                    const u32 cc = p.bases[rs + z];
-                    if (HASH) {
-                        f ^= rol64(nt_seed(cc), (u32)(k - 1 - q));
-                        rv ^= rol64(nt_cseed(cc), (u32)q);
-                    } else {
-                        const u32 bb = base2bit(cc);
-                        if (bb > 3) bad = true;
-                        f = (f << 2) | (u64)(bb & 3);
-                        rv |= (u64)(3 - (bb & 3)) << (2 * q);
-                    }
+                    const u32 bb = (u32)s_t.lut[cc] & 15u;
+                    if (bb > 3) bad = true;
+                    f = (f << 2) | (u64)(bb & 3);
+                    rv |= (u64)(3 - (bb & 3)) << (2 * q);
                 }
             }
-            if (bad) illegal = 1;
-            v = (p.canonical && rv < f) ? rv : f;
+            emit = true;
         }
+        if (bad && emit) illegal = 1;
+        const u64 v = (p.canonical && rv < f) ? rv : f;
         if (FILTER) {
             hv[j] = v;
             if (emit && v <= p.max_hash) keep |= 1u << j;
         } else if (emit) {
-            const u64 r = r_first + s_rr[i];
-            const u64 oi = p.out_off[r] + (P0 + (u64)i - p.rec_off[r]);
+            const u64 oi = out0 + (u64)i - (u64)s_dl[i];
             if (oi < p.out_cap) p.out[oi] = v;
         }
     }
