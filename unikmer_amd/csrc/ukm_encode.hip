@@ -30,11 +30,14 @@
 
 namespace {
 
-constexpr int NT = 256;
+#ifndef ENC_NT
+#define ENC_NT 512
+#endif
+constexpr int NT = ENC_NT;
 constexpr int WT = 2048;        // window start positions per tile
 constexpr int TBX = WT + 64;    // base positions staged per tile (k <= 64)
 constexpr int WPT = WT / NT;    // windows per thread (striped)
-constexpr int PPT = 9;          // positions per thread in the blocked phase (256 * 9 >= TBX)
+constexpr int PPT = (TBX + NT - 1) / NT;  // positions per thread in the blocked phase (NT * PPT >= TBX)
 constexpr int NWV = NT / 64;
 
 // kmers v0.1.0 base table; 4 = illegal base
@@ -88,8 +91,8 @@ struct BaseTables {
     u64 cseed[8];  // [0..4] seeds of the complement
 };
 __device__ __forceinline__ void base_tables_init(BaseTables &t, int tid) {
-    static_assert(NT == 256, "one table entry per thread");
-    t.lut[tid] = g_byte_table.v[tid];
+    static_assert(NT >= 256, "one table entry per thread");
+    if (tid < 256) t.lut[tid] = g_byte_table.v[tid];
     if (tid < 5) {
         const u64 f = tid == 0 ? SEED_A : tid == 1 ? SEED_C : tid == 2 ? SEED_G : tid == 3 ? SEED_T : 0ull;
         const u64 c = tid == 0 ? SEED_T : tid == 1 ? SEED_G : tid == 2 ? SEED_C : tid == 3 ? SEED_A : 0ull;
@@ -179,12 +182,12 @@ __device__ __forceinline__ u64 revcomp2(u64 code, int k) {
 template <bool HASH, bool FILTER>
 __global__ __launch_bounds__(NT) void window_kernel(WinArgs p) {
     __shared__ __attribute__((aligned(16))) u8 s_b[TBX + 16];
-    __shared__ u8 s_info[NT * PPT];                     // low 7 bits: min(bases left in record, 127); bit 7: record length >= k
-    __shared__ u32 s_dl[FILTER ? 1 : NT * PPT];         // (bases - windows) in front of the position's record, relative to s_r[2]
-    __shared__ u64 s_P[HASH ? NT * PPT + 1 : 1];        // XOR prefixes (ntHash)
-    __shared__ u64 s_Q[HASH ? NT * PPT + 1 : 1];
-    __shared__ u32 s_pk[HASH ? 1 : NT * PPT / 16 + 4];  // 2-bit packed bases, 16 per word (codes)
-    __shared__ u32 s_bad[HASH ? 1 : NT * PPT / 32 + 4]; // illegal-base bit per position (codes)
+    __shared__ u8 s_info[TBX];                     // low 7 bits: min(bases left in record, 127); bit 7: record length >= k
+    __shared__ u32 s_dl[FILTER ? 1 : TBX];         // (bases - windows) in front of the position's record, relative to s_r[2]
+    __shared__ u64 s_P[HASH ? TBX + 1 : 1];        // XOR prefixes (ntHash)
+    __shared__ u64 s_Q[HASH ? TBX + 1 : 1];
+    __shared__ u32 s_pk[HASH ? 1 : TBX / 16 + 4];  // 2-bit packed bases, 16 per word (codes)
+    __shared__ u32 s_bad[HASH ? 1 : TBX / 32 + 4]; // illegal-base bit per position (codes)
     __shared__ u64 s_wtot[2 * NWV];
     __shared__ u32 s_cnt[WPT * NWV + 1];
     __shared__ u64 s_r[3];
@@ -228,8 +231,8 @@ __global__ __launch_bounds__(NT) void window_kernel(WinArgs p) {
         if (!FILTER) { const u64 r0 = p.tile_rec[tile]; s_r[2] = p.rec_off[r0] - p.out_off[r0]; }
     }
     if (!HASH) {
-        for (int i = tid; i < NT * PPT / 16 + 4; i += NT) s_pk[i] = 0;
-        for (int i = tid; i < NT * PPT / 32 + 4; i += NT) s_bad[i] = 0;
+        for (int i = tid; i < TBX / 16 + 4; i += NT) s_pk[i] = 0;
+        for (int i = tid; i < TBX / 32 + 4; i += NT) s_bad[i] = 0;
     }
     __syncthreads();
 
@@ -269,8 +272,10 @@ __global__ __launch_bounds__(NT) void window_kernel(WinArgs p) {
             const bool live = in_rec && pos < p.total_bases && m < TBX;
             const u64 rem = live ? re - pos : 0;
             const u32 info = (u32)(rem > 127 ? 127 : rem) | ((live && (re - rs) >= (u64)k) ? 128u : 0u);
-            s_info[m] = (u8)info;
-            if (!FILTER) s_dl[m] = dl;
+            if (m < TBX) {
+                s_info[m] = (u8)info;
+                if (!FILTER) s_dl[m] = dl;
+            }
             const u32 c = (m < TBX) ? s_b[m] : 0;
             if (HASH) {
                 // position m contributes ror(seed, m) to P and rol(cseed, m) to Q
@@ -282,8 +287,10 @@ __global__ __launch_bounds__(NT) void window_kernel(WinArgs p) {
             } else {
                 const u32 b = (u32)s_t.lut[c] & 15u;
                 // first base of a k-mer is most significant: pack position m at bits [2*(15 - m%16)] of word m/16
-                atomicOr(&s_pk[m >> 4], (b & 3u) << (2 * (15 - (m & 15))));
-                if (b > 3) atomicOr(&s_bad[m >> 5], 1u << (m & 31));
+                if (m < TBX) {
+                    atomicOr(&s_pk[m >> 4], (b & 3u) << (2 * (15 - (m & 15))));
+                    if (b > 3) atomicOr(&s_bad[m >> 5], 1u << (m & 31));
+                }
             }
         }
         if (HASH) {
@@ -297,10 +304,11 @@ __global__ __launch_bounds__(NT) void window_kernel(WinArgs p) {
                 if (w < wave) { eP ^= s_wtot[w]; eQ ^= s_wtot[NWV + w]; }
             if (tid == 0) { s_P[0] = 0; s_Q[0] = 0; }
 #pragma unroll
-            for (int s = 0; s < PPT; s++) {
-                s_P[m0 + s + 1] = eP ^ lp[s];
-                s_Q[m0 + s + 1] = eQ ^ lq[s];
-            }
+            for (int s = 0; s < PPT; s++)
+                if (m0 + s < TBX) {
+                    s_P[m0 + s + 1] = eP ^ lp[s];
+                    s_Q[m0 + s + 1] = eQ ^ lq[s];
+                }
         }
     }
     __syncthreads();
