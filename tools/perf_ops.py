@@ -69,6 +69,21 @@ def main():
             tk, _ = best(f, kernel=True)
             byt = 12 * (na + nb) + 12 * r[0]
             res[name] = {"kernel_ms": tk, "GBps_kernel": byt / tk / 1e6, "kmers_per_s": (na + nb) / tk * 1e3}
+        # the realistic shapes: (i) each file carries ONE taxid (a genome's k-mers: `count -t`), (ii) taxids
+        # clustered by code prefix over 4096 leaves (k-mers of one clade sit together after LCA assignment)
+        leaves = T - 8 ** 7 + 1
+        shapes = {
+            "one_taxid_per_file": (torch.full_like(ta, leaves + 5), torch.full_like(tb, leaves + 77)),
+            "clustered_4096_leaves": ((leaves + ((A >> 50) & 4095)).to(torch.int32), (leaves + (((B >> 50) + 1) & 4095)).to(torch.int32)),
+        }
+        for sname, (xa, xb) in shapes.items():
+            for name, op in (("union_tax", lib.OP_UNION), ("inter_tax", lib.OP_INTER)):
+                def f():
+                    r[0] = ctx.setop2(op, A, B, xa, xb, out=out, out_taxids=outt)[0].numel()
+                f()
+                tk, _ = best(f, kernel=True)
+                byt = 12 * (na + nb) + 12 * r[0]
+                res[name + ":" + sname] = {"kernel_ms": tk, "GBps_kernel": byt / tk / 1e6, "kmers_per_s": (na + nb) / tk * 1e3}
     if "unique" in ops:
         cat = torch.cat([A, B])
         ctx.sort_u64(cat, 62)

@@ -321,6 +321,17 @@ __device__ __forceinline__ void tile_merge_loop(const SetopArgs &p, const TileGe
     }
     const bool mix = (p.flags & UKM_F_MIX_TAXID) != 0;
     const bool cmp = (p.flags & UKM_F_CMP_TAXID) != 0;
+    // Files carry few distinct taxids over long stretches (one per genome, or one per clade after LCA
+    // assignment), so consecutive matches of a thread mostly ask for the same pair: remember the last one.
+    u32 memo_a = 0, memo_b = 0, memo_l = 0;  // LCA(0, 0) = 0
+    auto lca_memo = [&](u32 a, u32 b) -> u32 {
+        if (a != memo_a || b != memo_b) {
+            memo_l = lca_dev(p.tax, a, b);
+            memo_a = a;
+            memo_b = b;
+        }
+        return memo_l;
+    };
     mask = 0;
 #pragma unroll
     for (int s = 0; s < VT; s++) {
@@ -351,15 +362,15 @@ __device__ __forceinline__ void tile_merge_loop(const SetopArgs &p, const TileGe
             const u32 ta = s_tax[pa], tb = s_tax[pb];
             if (OP == UKM_OP_UNION) {
                 et = take_a ? ta : tb;
-                if (match) et = lca_dev(p.tax, ta, tb);
+                if (match) et = lca_memo(ta, tb);
             } else if (OP == UKM_OP_INTER) {
                 if (match) {
-                    if (mix) et = (ta == 0) ? tb : ((tb == 0) ? ta : lca_dev(p.tax, ta, tb));
-                    else et = lca_dev(p.tax, ta, tb);
+                    if (mix) et = (ta == 0) ? tb : ((tb == 0) ? ta : lca_memo(ta, tb));
+                    else et = lca_memo(ta, tb);
                 }
             } else {
                 et = ta;
-                if (match && cmp && (ta == tb || lca_dev(p.tax, tb, ta) == ta)) emit = true;
+                if (match && cmp && (ta == tb || lca_memo(tb, ta) == ta)) emit = true;
             }
         }
         ok[s] = ek;
