@@ -54,7 +54,7 @@ def tree(ctx, O):
 
 
 # ---------------------------------------------------------------------------------- set ops
-@pytest.mark.parametrize("n", [0, 1, 5, 4095, 4096, 4097, 100_000, 1_333_000])
+@pytest.mark.parametrize("n", [0, 1, 5, 4095, 4096, 4097, 100_000, 1_333_000, 3_100_000])
 def test_setop2_matches_oracle(ctx, O, L, n):
     A, B = synth_sets(n, 22) if n else (np.empty(0, np.uint64), np.empty(0, np.uint64))
     u = ctx.setop2(L.OP_UNION, A, B)
