@@ -241,6 +241,64 @@ def test_taxonomy_lca_through_cli(cli, tmp_path):
     gk, gt = view(d + "/su.unik")
     ok, ot = O.union(files, taxs, tax)                   # README.md:215-229 equivalence
     assert np.array_equal(gk, ok) and np.array_equal(gt, ot)
+    # the same through the chunk protocol (per-chunk LCA fold, then LCA fold in both merge rounds)
+    cli("sort", "-u", "-m", 500, "-M", 3, "-t", d, "--data-dir", d + "/tax", d + "/c.unik", "-o", d + "/su2")
+    gk, gt = view(d + "/su2.unik")
+    assert np.array_equal(gk, ok) and np.array_equal(gt, ot)
+    cli("sort", "-d", "--data-dir", d + "/tax", d + "/c.unik", "-o", d + "/sd")
+    cli("sort", "-d", "-m", 500, "-M", 3, "-t", d, "--data-dir", d + "/tax", d + "/c.unik", "-o", d + "/sd2")
+    k1, t1 = view(d + "/sd.unik")
+    k2, t2 = view(d + "/sd2.unik")
+    assert len(k1) > 0 and np.array_equal(k1, k2) and np.array_equal(t1, t2)
     # missing taxonomy directory -> error, not a silent zero
     p = cli("union", "-s", "--data-dir", d + "/nope", *fs, "-o", d + "/x", ok=False)
     assert p.returncode == 255 and b"taxonomy file not found" in p.stderr
+
+
+@pytest.mark.gpu
+def test_sort_chunk_protocol_split_merge_on_gpu(cli, tmp_path):
+    """SURVEY C-9 / README.md:215-229: `sort -u` == `sort -u -m N` == `split -u -m N` + `merge -u -D`, and the
+    same for -d (two-copy chunk protocol, util-sort.go:70-91,377-388) and for the plain sort; small
+    --max-open-files forces the two merge rounds of sort.go:365-420."""
+    d = str(tmp_path)
+    rng = np.random.default_rng(11)
+    k = 15
+    a = rng.integers(0, 3000, 5000)     # many duplicates, also across chunk borders
+    b = rng.integers(1000, 6000, 4000)
+    for name, arr in (("a", a), ("b", b)):
+        txt = "\n".join("".join("ACGT"[(int(c) >> (2 * (k - 1 - i))) & 3] for i in range(k)) for c in arr) + "\n"
+        cli("dump", "-o", d + "/" + name, stdin=txt.encode())
+    ins = [d + "/a.unik", d + "/b.unik"]
+    view = lambda f: cli("view", f).stdout
+    for flag in ("-u", "-d", None):
+        fl = [flag] if flag else []
+        tag = (flag or "p").strip("-")
+        cli("sort", *fl, *ins, "-o", d + "/whole_" + tag)
+        ref = view(d + "/whole_%s.unik" % tag)
+        assert len(ref) > 0
+        # chunked: 700 k-mers per chunk -> 13 chunks; 2 rounds when --max-open-files 4
+        for mo in (400, 4):
+            cli("sort", *fl, "-m", 700, "-M", mo, "-t", d, *ins, "-o", d + "/chunk_%s_%d" % (tag, mo))
+            assert view(d + "/chunk_%s_%d.unik" % (tag, mo)) == ref
+            assert not os.path.exists(d + "/chunk_%s_%d.tmp" % (tag, mo))          # tmp dir removed
+        # split + merge
+        cli("split", *fl, "-m", "1K", "-O", d + "/split_" + tag, *ins)
+        chunks = sorted(os.listdir(d + "/split_" + tag))
+        assert chunks[0] == "chunk_001.unik" and len(chunks) == 9                  # 9000 k-mers / 1024
+        cli("merge", *fl, "-D", d + "/split_" + tag, "-o", d + "/merged_" + tag)
+        assert view(d + "/merged_%s.unik" % tag) == ref
+        cli("merge", *fl, "-M", 3, "-t", d, *[d + "/split_%s/%s" % (tag, c) for c in chunks], "-o", d + "/merged2_" + tag)
+        assert view(d + "/merged2_%s.unik" % tag) == ref
+    # expected contents from first principles
+    allc = np.concatenate([a, b])
+    vals, cnt = np.unique(allc, return_counts=True)
+    dec = lambda f: [int(x) for x in cli("view", "--show-code-only", f).stdout.split()]
+    assert dec(d + "/whole_u.unik") == [int(v) for v in vals]
+    assert dec(d + "/whole_d.unik") == [int(v) for v in vals[cnt > 1]]
+    assert dec(d + "/whole_p.unik") == sorted(int(v) for v in allc)
+    # a non-empty tmp dir needs --force (sort.go:119-132)
+    os.makedirs(d + "/x.tmp"); open(d + "/x.tmp/junk", "w").close()
+    p = cli("sort", "-m", 700, "-t", d, *ins, "-o", d + "/x", ok=False)
+    assert p.returncode == 255 and b"not empty" in p.stderr
+    cli("sort", "-m", 700, "-t", d, "--force", *ins, "-o", d + "/x")
+    assert view(d + "/x.unik") == view(d + "/whole_p.unik")

@@ -12,6 +12,7 @@
 // Not implemented (SURVEY.md §2a out of scope): grep, filter, rfilter, tsplit, locate, map,
 // split, sample, autocompletion; count -W/-S (minimizer/syncmer sketches); sort -m chunking is
 // accepted and ignored (a whole set fits in 288 GB of HBM).
+#include <dirent.h>
 #include <getopt.h>
 #include <sys/stat.h>
 #include <unistd.h>
@@ -19,7 +20,9 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdarg>
+#include <cerrno>
 #include <cstdlib>
+#include <cstring>
 #include <fstream>
 #include <iostream>
 #include <map>
@@ -257,6 +260,86 @@ static void write_unik(const string &out_file, const Options &o, int k, u32 mode
     w.flush();
     os.close();
     info("%llu k-mers saved to %s", (unsigned long long)n, out_file.c_str());
+}
+
+// ---- out-of-core protocol of sort -m / split / merge (sort.go:241-447, split.go:288-401, merge.go:228-341) ----
+// util.go:291-335 ParseByteSize: plain number, or B/K/M/G suffix (powers of 1024); "" = 0
+static long long parse_byte_size(string v) {
+    while (!v.empty() && strchr(" \t\r\n", v.back())) v.pop_back();
+    while (!v.empty() && strchr(" \t\r\n", v.front())) v.erase(v.begin());
+    if (v.empty()) return 0;
+    double unit = 0;
+    switch (v.back()) {
+    case 'B': case 'b': unit = 1; break;
+    case 'K': case 'k': unit = 1 << 10; break;
+    case 'M': case 'm': unit = 1 << 20; break;
+    case 'G': case 'g': unit = 1 << 30; break;
+    default: break;
+    }
+    if (unit != 0) {
+        v.pop_back();
+        if (v.empty()) return 0;
+    } else {
+        unit = 1;
+    }
+    char *e = nullptr;
+    const double x = strtod(v.c_str(), &e);
+    if (e == v.c_str() || *e) die("parsing byte size: invalid byte size: %s", v.c_str());
+    return x < 0 ? 0 : (long long)(x * unit);
+}
+static bool dir_exists(const string &p) { struct stat st; return stat(p.c_str(), &st) == 0 && S_ISDIR(st.st_mode); }
+static vector<string> list_dir(const string &d) {
+    vector<string> names;
+    DIR *dh = opendir(d.c_str());
+    if (!dh) die("check given directory '%s': %s", d.c_str(), strerror(errno));
+    while (struct dirent *e = readdir(dh)) { string n = e->d_name; if (n != "." && n != "..") names.push_back(n); }
+    closedir(dh);
+    std::sort(names.begin(), names.end());
+    return names;
+}
+// sort.go:113-137 / split.go:108-126: a non-empty directory needs --force; it is then emptied
+static void prepare_dir(const string &d, bool force, const char *what) {
+    if (dir_exists(d)) {
+        vector<string> names = list_dir(d);
+        if (!names.empty() && !force) die("%s not empty: %s, choose another one or use --force to overwrite", what, d.c_str());
+        for (auto &n : names) if (remove((d + "/" + n).c_str()) != 0) die("fail to remove %s/%s", d.c_str(), n.c_str());
+    } else if (mkdir(d.c_str(), 0777) != 0) {
+        // parents (mkdir -p)
+        string acc;
+        for (size_t i = 0; i <= d.size(); i++)
+            if (i == d.size() || d[i] == '/') { acc = d.substr(0, i); if (!acc.empty() && !dir_exists(acc) && mkdir(acc.c_str(), 0777) != 0) die("fail to create directory: %s", acc.c_str()); }
+    }
+}
+static string chunk_file_name(const string &dir, int i) {  // util-sort.go:192-194
+    char b[64];
+    snprintf(b, sizeof b, "chunk_%03d", i);
+    return dir + "/" + b + EXT;
+}
+static string base_of(const string &p) { size_t s = p.find_last_of('/'); return s == string::npos ? p : p.substr(s + 1); }
+
+struct ChunkJob {
+    int k = 0;
+    u32 mode = 0;  // includes UnikSorted
+    bool tax = false, uniq = false, rep = false;
+    int key_bits = 64;
+    u32 max_taxid = 0xFFFFFFFFu;
+    const unik::Header *h0 = nullptr;
+};
+// one chunk: device sort + the scan of dumpCodes2File / dumpCodesTaxids2File (util-sort.go:35-190):
+// -u collapses runs (LCA of their taxids), -d writes every code once and repeated ones twice, else plain
+static u64 sort_chunk_to_file(Gpu &g, const Options &o, const ChunkJob &j, vector<u64> &codes, vector<u32> &taxids, const string &file) {
+    const u64 n = codes.size();
+    vector<u64> out(2 * n + 1);
+    vector<u32> tout(j.tax ? 2 * n + 1 : 0);
+    u64 m = 0;
+    if (n) {
+        if (j.tax) ck(ukm_sort_pairs(g.c, codes.data(), taxids.data(), n, j.key_bits));
+        else ck(ukm_sort_u64(g.c, codes.data(), n, j.key_bits));
+        ck(ukm_unique(g.c, codes.data(), j.tax ? taxids.data() : nullptr, n, j.uniq ? UKM_UNIQUE : (j.rep ? UKM_REPEATED_CHUNK : UKM_PLAIN),
+                      out.data(), j.tax ? tout.data() : nullptr, 2 * n + 1, &m));
+    }
+    write_unik(file, o, j.k, j.mode, j.max_taxid, 0, j.h0, out.data(), j.tax ? tout.data() : nullptr, m);
+    return m;
 }
 
 // kmers v0.1.0 text <-> code on the host (view / dump / encode / decode only; the throughput
@@ -521,7 +604,69 @@ static u32 out_mode(const Inputs &in, bool sorted, bool tax, const Options &o) {
     return mode;
 }
 
-enum SetCmd { C_UNION, C_INTER, C_DIFF, C_COMMON, C_SORT, C_MERGE };
+// mergeChunksFile (util-sort.go:227-606) over sorted chunk files, on the device.  Files are loaded
+// whole (HBM holds far more than the reference's open-file budget); when there are at least
+// `max_open` of them the reference's two rounds are kept: groups of max_open files are merged with
+// finalRound = false into new chunk files, then those are merged with finalRound = true.
+static u64 merge_files_once(Gpu &g, const Options &o, const ChunkJob &j, const vector<string> &files, const string &out_file, bool final_round) {
+    vector<Loaded> ls;
+    u64 total = 0;
+    Options oo = o;
+    oo.ignore_taxid = !j.tax;
+    for (auto &f : files) {
+        ls.push_back(load_unik(f, oo));
+        if (j.h0) check_compat(*j.h0, ls.back().h, f);
+        if (!ls.back().h.is_sorted()) die("chunk file should be sorted: %s", f.c_str());
+        if (j.tax && !ls.back().has_taxid) die("taxid information found in previous files, but missing in this: %s", f.c_str());
+        total += ls.back().codes.size();
+    }
+    vector<const u64 *> pk; vector<const u32 *> pt; vector<u64> pn;
+    for (auto &L : ls) { pk.push_back(L.codes.data()); pt.push_back(j.tax ? L.taxids.data() : nullptr); pn.push_back(L.codes.size()); }
+    const u64 cap = 2 * total + 1;
+    vector<u64> out(cap);
+    vector<u32> tout(j.tax ? cap : 0);
+    u64 n = 0;
+    if (!ls.empty())
+        ck(ukm_merge_k(g.c, pk.data(), j.tax ? pt.data() : nullptr, pn.data(), (int)ls.size(), j.uniq ? UKM_UNIQUE : (j.rep ? UKM_REPEATED : UKM_PLAIN),
+                       final_round ? 1 : 0, out.data(), j.tax ? tout.data() : nullptr, cap, &n));
+    write_unik(out_file, o, j.k, j.mode, j.max_taxid, 0, j.h0, out.data(), j.tax ? tout.data() : nullptr, n);
+    return n;
+}
+static u64 merge_rounds(Gpu &g, const Options &o, const ChunkJob &j, vector<string> files, const string &out_file, int max_open,
+                        const string &tmp_dir, int &i_tmp, vector<string> &made) {
+    if ((int)files.size() < max_open) {
+        info("======= Stage 2: merging from %zu chunks =======", files.size());
+        return merge_files_once(g, o, j, files, out_file, true);
+    }
+    info("======= Stage 2: merging from %zu chunks (round: 1/2) =======", files.size());
+    vector<string> next, group;
+    auto flush = [&]() {
+        if (group.empty()) return;
+        const string f = chunk_file_name(tmp_dir, ++i_tmp);
+        info("[chunk %d] sorting k-mers from %zu tmp files", i_tmp, group.size());
+        merge_files_once(g, o, j, group, f, false);
+        next.push_back(f);
+        made.push_back(f);
+        group.clear();
+    };
+    for (auto &f : files) { group.push_back(f); if ((int)group.size() == max_open) flush(); }
+    flush();
+    info("======= Stage 3: merging from %zu chunks (round: 2/2) =======", next.size());
+    return merge_files_once(g, o, j, next, out_file, true);
+}
+static string tmp_dir_for(const string &tmp_root, const string &out_prefix) {  // sort.go:113-118
+    const string root = tmp_root.empty() ? string("./") : tmp_root;
+    return root + (root.back() == '/' ? "" : "/") + (out_prefix == "-" ? string("stdout.tmp") : base_of(out_prefix) + ".tmp");
+}
+static void cleanup_tmp(const vector<string> &files, const string &dir, bool keep) {  // sort.go:425-446
+    if (keep) return;
+    info("removing %zu intermediate files", files.size());
+    for (auto &f : files) if (remove(f.c_str()) != 0) die("fail to remove intermediate file: %s", f.c_str());
+    info("removing tmp dir: %s", dir.c_str());
+    if (rmdir(dir.c_str()) != 0) die("fail to remove temp directory, please manually delete it: %s", dir.c_str());
+}
+
+enum SetCmd { C_UNION, C_INTER, C_DIFF, C_COMMON, C_SORT, C_MERGE, C_SPLIT };
 
 static int cmd_setop(SetCmd which, int argc, char **argv) {
     vector<FlagSpec> specs = {{'o', "out-prefix", true}};
@@ -536,14 +681,36 @@ static int cmd_setop(SetCmd which, int argc, char **argv) {
         if (which == C_SORT) specs.push_back({'m', "chunk-size", true});
         else { specs.push_back({'D', "is-dir", false}); specs.push_back({'p', "pattern", true}); }
     }
+    if (which == C_SPLIT) {
+        specs = {{'O', "out-dir", true}, {'m', "chunk-size", true}, {0, "force", false}, {'u', "unique", false}, {'d', "repeated", false}};
+    }
     Args a = parse_args(argc, argv, specs);
     Options o = get_options(a);
     vector<string> files = get_files(a, o);
-    const string out_file = out_name(a.str("out-prefix", "-"));
+    const string out_prefix = a.str("out-prefix", "-");
+    const string out_file = out_name(out_prefix);
     const bool mix = a.has("mix-taxid");
     const bool uniq = a.has("unique"), rep = a.has("repeated");
     if (uniq && rep) die("flag -u/--unique overides -d/--repeated, do not give both");
-    if (which == C_MERGE && a.has("is-dir")) die("-D/--is-dir is not supported in this build: list the chunk files");
+    const int max_open = (int)a.num("max-open-files", 400);
+    if (max_open <= 0) die("value of flag --max-open-files should be positive");
+    if (which == C_MERGE && a.has("is-dir")) {  // merge.go:77-130: chunk files of the given directories
+        std::regex re(a.str("pattern", "^chunk_\\d+\\.unik$"));
+        vector<string> found;
+        for (auto d : files) {
+            if (d == "-") d = "./";
+            if (!dir_exists(d)) { fprintf(stderr, "[WARN] skip unexisted dir: %s\n", d.c_str()); continue; }
+            size_t nf = 0;
+            for (auto &nme : list_dir(d)) {
+                if (nme[0] == '.' || dir_exists(d + "/" + nme) || !std::regex_search(nme, re)) continue;
+                found.push_back(d + (d.back() == '/' ? "" : "/") + nme);
+                nf++;
+            }
+            info("%zu chunk files found in dir: %s", nf, d.c_str());
+        }
+        if (found.empty()) { fprintf(stderr, "[WARN] 0 chunk files found in %zu dir(s)\n", files.size()); return 0; }
+        files = found;
+    }
 
     // single-input fast path of union / inter: the file is copied byte for byte (union.go:97-112, inter.go:96-120)
     if ((which == C_UNION || which == C_INTER) && files.size() == 1 && files[0] != "-") {
@@ -554,6 +721,29 @@ static int cmd_setop(SetCmd which, int argc, char **argv) {
         return 0;
     }
 
+    if (which == C_MERGE) {  // merge.go:228-341
+        unik::Reader r0(files[0]);
+        ChunkJob j;
+        j.k = r0.h.k; j.h0 = &r0.h; j.uniq = uniq; j.rep = rep;
+        j.tax = !o.ignore_taxid && r0.h.has_taxid_info();
+        j.key_bits = r0.h.is_hashed() ? 64 : 2 * r0.h.k;
+        j.mode = unik::UnikSorted | (r0.h.is_canonical() ? unik::UnikCanonical : 0) | (r0.h.is_hashed() ? unik::UnikHashed : 0) |
+                 (j.tax ? unik::UnikIncludeTaxID : 0);
+        Gpu g(o.gpu);
+        if (j.tax && (uniq || rep)) j.max_taxid = load_taxonomy(g, o);
+        else j.max_taxid = o.max_taxid;
+        vector<string> made;
+        int i_tmp = 0;
+        string tmp_dir;
+        if ((int)files.size() >= max_open) {
+            tmp_dir = tmp_dir_for(a.str("tmp-dir", "./"), out_prefix);
+            prepare_dir(tmp_dir, a.has("force"), "tmp dir");
+        }
+        merge_rounds(g, o, j, files, out_file, max_open, tmp_dir, i_tmp, made);
+        if (!tmp_dir.empty()) cleanup_tmp(made, tmp_dir, a.has("keep-tmp-dir"));
+        return 0;
+    }
+
     Inputs in = load_inputs(files, o, which == C_INTER && !a.has("skip-flag-check"), which == C_DIFF, mix);
     bool tax = in.has_taxid || (mix && in.any_taxid);
     if (which == C_DIFF) tax = in.has_taxid;  // taxid always from file 1 (diff.go:496-515)
@@ -561,13 +751,14 @@ static int cmd_setop(SetCmd which, int argc, char **argv) {
     u32 max_taxid = o.max_taxid;
     const bool cmp_taxid = which == C_DIFF && a.has("compare-taxid");
     if (cmp_taxid && !in.has_taxid) die("flag -t/--compare-taxid given but no taxid information found");
-    const bool need_lca = (tax && which != C_DIFF) || cmp_taxid;
+    bool need_lca = (tax && which != C_DIFF) || cmp_taxid;
+    if (which == C_SORT || which == C_SPLIT) need_lca = tax && (uniq || rep);  // sort.go:196-198
     if (need_lca) max_taxid = load_taxonomy(g, o);
     Ptrs p = ptrs_of(in, tax || cmp_taxid);
     const int ns = (int)in.files.size();
     u64 cap = in.total;
     if (which == C_INTER || which == C_DIFF) cap = in.files[0].codes.size();
-    if (which == C_MERGE || which == C_SORT) cap = 2 * in.total;
+    if (which == C_SORT || which == C_SPLIT) cap = 2 * in.total;
     vector<u64> out(cap ? cap : 1);
     vector<u32> tout((tax || cmp_taxid) ? (cap ? cap : 1) : 0);
     u64 n = 0;
@@ -605,8 +796,56 @@ static int cmd_setop(SetCmd which, int argc, char **argv) {
         ck(ukm_common(g.c, p.k.data(), tp, p.n.data(), ns, thr, 0, out.data(), with_t ? tout.data() : nullptr, cap, &n));
         break;
     }
+    case C_SPLIT:
     case C_SORT: {
-        // sort.go:227-572: everything in HBM; -m chunking is not needed and is ignored
+        // sort.go:227-572.  Without -m (or when the input is smaller than one chunk) everything is
+        // sorted in HBM in one go; with -m N the reference's chunk protocol runs: stage 1 sorts
+        // chunks of N k-mers into tmp files (-u: deduplicated, -d: every code once and repeated ones
+        // twice), stage 2/3 merge them (merge_rounds).  `split` is stage 1 alone (split.go).
+        const long long max_elem = parse_byte_size(a.str("chunk-size", ""));
+        const bool limit = max_elem > 0 && (in.total >= (u64)max_elem || which == C_SPLIT);
+        if (limit || which == C_SPLIT) {
+            ChunkJob j;
+            j.k = in.k; j.h0 = &in.h0; j.uniq = uniq; j.rep = rep; j.tax = tax;
+            j.key_bits = in.hashed ? 64 : 2 * in.k;
+            j.mode = out_mode(in, true, tax, o);
+            j.max_taxid = max_taxid;
+            string dir;
+            if (which == C_SPLIT) {
+                dir = a.str("out-dir", "");
+                if (dir.empty()) dir = (files[0] == "-" ? string("stdin") : files[0]) + ".split";
+                if (dir != "./" && dir != ".") prepare_dir(dir, a.has("force"), "outDir");
+            } else {
+                dir = tmp_dir_for(a.str("tmp-dir", "./"), out_prefix);
+                prepare_dir(dir, a.has("force"), "tmp dir");
+                info("======= Stage 1: spliting k-mers into chunks =======");
+            }
+            const u64 step = max_elem > 0 ? (u64)max_elem : (in.total ? in.total : 1);
+            vector<string> chunks;
+            vector<u64> cc; vector<u32> ct;
+            int i_tmp = 0;
+            auto flush_chunk = [&]() {
+                if (cc.empty()) return;
+                const string f = chunk_file_name(dir, ++i_tmp);
+                info("[chunk %d] sorting %zu k-mers", i_tmp, cc.size());
+                const u64 m = sort_chunk_to_file(g, o, j, cc, ct, f);
+                info("[chunk %d] %llu k-mers saved to tmp file: %s", i_tmp, (unsigned long long)m, f.c_str());
+                chunks.push_back(f);
+                cc.clear(); ct.clear();
+            };
+            for (auto &L : in.files)
+                for (size_t i = 0; i < L.codes.size(); i++) {
+                    cc.push_back(L.codes[i]);
+                    if (tax) ct.push_back(L.taxids[i]);
+                    if (cc.size() >= step) flush_chunk();
+                }
+            flush_chunk();
+            if (which == C_SPLIT) { info("%llu k-mers saved to %zu chunk files in %s", (unsigned long long)in.total, chunks.size(), dir.c_str()); return 0; }
+            vector<string> made = chunks;
+            merge_rounds(g, o, j, chunks, out_file, max_open, dir, i_tmp, made);
+            cleanup_tmp(made, dir, a.has("keep-tmp-dir"));
+            return 0;
+        }
         vector<u64> all; vector<u32> allt;
         all.reserve(in.total);
         for (auto &L : in.files) { all.insert(all.end(), L.codes.begin(), L.codes.end()); if (tax) allt.insert(allt.end(), L.taxids.begin(), L.taxids.end()); }
@@ -620,10 +859,7 @@ static int cmd_setop(SetCmd which, int argc, char **argv) {
         break;
     }
     case C_MERGE:
-        for (size_t i = 0; i < in.files.size(); i++) if (!in.files[i].h.is_sorted()) die("chunk file should be sorted: %s", files[i].c_str());
-        ck(ukm_merge_k(g.c, p.k.data(), tp, p.n.data(), ns, uniq ? UKM_UNIQUE : (rep ? UKM_REPEATED : UKM_PLAIN), 1, out.data(),
-                       with_t ? tout.data() : nullptr, cap, &n));
-        break;
+        break;  // handled above
     }
     const u32 mode = out_mode(in, sorted_out, tax, o);
     // a global taxid shared by every input survives as the header's global taxid when no per-record taxids are written
@@ -900,7 +1136,7 @@ static void usage() {
     fprintf(stderr,
             "unikmer (HIP) - k-mer set operations on AMD MI355X behind the unikmer command line\n\n"
             "Usage: unikmer <command> [flags] [files]\n\n"
-            "GPU commands : count sort union inter diff common merge\n"
+            "GPU commands : count sort split merge union inter diff common\n"
             "CPU commands : view dump num info(stats) concat head encode decode version\n"
             "Global flags : -j --verbose -C --compression-level -c -i -I --max-taxid --data-dir --gpu\n");
 }
@@ -917,6 +1153,7 @@ int main(int argc, char **argv) {
         if (cmd == "diff") return cmd_setop(C_DIFF, argc, argv);
         if (cmd == "common") return cmd_setop(C_COMMON, argc, argv);
         if (cmd == "merge") return cmd_setop(C_MERGE, argc, argv);
+        if (cmd == "split") return cmd_setop(C_SPLIT, argc, argv);
         if (cmd == "view") return cmd_view(argc, argv);
         if (cmd == "dump") return cmd_dump(argc, argv);
         if (cmd == "num") return cmd_num(argc, argv);
