@@ -139,13 +139,23 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # UKM_BENCH_ONE_GPU=1 is a TEST HOOK for 1-GPU boxes: all ranks share cuda:0 and the control-plane
+    # collectives go over gloo, so the N>1 code path (sharded generation, max-over-ranks timing, sums)
+    # can be exercised without a multi-GPU node.  Its numbers mean nothing; the exchange leg is skipped.
+    one_gpu = world > 1 and os.environ.get("UKM_BENCH_ONE_GPU") == "1"
+    if one_gpu:
+        local_rank = 0
+        args.no_exchange = True
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local_rank)
         import datetime
-        dist.init_process_group("nccl", rank=rank, world_size=world, timeout=datetime.timedelta(minutes=10),
-                                device_id=torch.device("cuda", local_rank))
+        if one_gpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(minutes=10))
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, timeout=datetime.timedelta(minutes=10),
+                                    device_id=torch.device("cuda", local_rank))
     else:
         torch.cuda.set_device(0)
     assert args.gpus == world, "--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world)
@@ -203,10 +213,11 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        cdev = torch.device("cpu") if one_gpu else dev
+        t = torch.tensor([dt], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-        cnt = torch.tensor([na + nb, nu, ni], dtype=torch.int64, device=dev)
+        cnt = torch.tensor([na + nb, nu, ni], dtype=torch.int64, device=cdev)
         dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
         tot_in, tot_u, tot_i = (int(x) for x in cnt.cpu())
     else:
