@@ -35,7 +35,7 @@ def main():
             ts.append(ctx.last_kernel_ms() if kernel else ctx.last_call_ms())
         return min(ts), float(np.median(ts))
 
-    if "setop" in ops or "unique" in ops or "tax" in ops:
+    if "setop" in ops or "unique" in ops or "tax" in ops or "pcie" in ops:
         A, B = bench.gen_sets_device((4 * n + 2) // 3, 32 if n > 2e8 else 30, 0, bench.SEED, dev)
         na, nb = A.numel(), B.numel()
     if "setop" in ops:
@@ -51,6 +51,19 @@ def main():
             byt = 8 * (na + nb) + 8 * r[0]
             res[name] = {"kernel_ms": tk, "call_ms": tc, "GBps_kernel": byt / tk / 1e6,
                          "kmers_per_s": (na + nb) / tk * 1e3}
+    if "pcie" in ops:
+        # the boundary handed HOST buffers (what a cgo caller with Go slices does): H2D + kernel + D2H
+        Ah, Bh = A.cpu().numpy().view(np.uint64), B.cpu().numpy().view(np.uint64)
+        outh = np.empty(na + nb, dtype=np.uint64)
+        import time as _t
+        ts = []
+        for _ in range(3):
+            t0 = _t.perf_counter()
+            r = ctx.setop2(lib.OP_UNION, Ah, Bh, out=outh)
+            ts.append(_t.perf_counter() - t0)
+        byt = 8 * (na + nb) + 8 * len(r)
+        res["union_host_buffers"] = {"wall_ms": min(ts) * 1e3, "kmers_per_s": (na + nb) / min(ts), "GBps_over_pcie": byt / min(ts) / 1e9,
+                                     "note": "pageable numpy buffers in, pageable out"}
     if "tax" in ops:
         from conftest import synth_tree
         child, parent = synth_tree(7, 8)
