@@ -166,6 +166,8 @@ static inline TaxDev ukm_taxdev(const ukm_ctx *c) {
 }
 
 // ---- internal device-pointer entry points (all pointers are device pointers) ------------------
+// internal fourth 2-way operation: merge keeping every record (k-way merge tree of ukm_merge_k)
+#define UKM_OP_MERGE_INTERNAL 3
 int ukm_dev_setop2(ukm_ctx *c, int op, const u64 *a, const u32 *ta, u64 na, const u64 *b,
                    const u32 *tb, u64 nb, u32 flags, u64 *out, u32 *tout, u64 out_cap,
                    u64 *n_out);

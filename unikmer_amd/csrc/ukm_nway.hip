@@ -147,6 +147,56 @@ int run_entry(ukm_ctx *ctx, uint64_t *out_keys, uint32_t *out_taxids, uint64_t o
     return ukm_finish(&s, rc);
 }
 
+// Pairwise reduction tree over >= 2 non-empty sorted streams with a 2-way operation (UNION: LCA is
+// associative and commutative, so the tree equals the reference's arrival-order fold; MERGE: every
+// record kept).  Levels ping-pong between two workspace buffers; the last level writes (fk, ft).
+int tree_reduce(ukm_ctx *ctx, std::vector<Stream> ss, int op, u32 flags, bool tax, u64 *fk, u32 *ft, u64 fcap, u64 *n_out) {
+    u64 total = 0;
+    for (auto &s : ss) total += s.n;
+    u64 *bk[2] = {nullptr, nullptr};
+    u32 *bt[2] = {nullptr, nullptr};
+    if (ss.size() > 2) {
+        for (int i = 0; i < 2; i++) {
+            UKM_TRY(ws_alloc_t(ctx, total + 1, &bk[i]));
+            if (tax) UKM_TRY(ws_alloc_t(ctx, total + 1, &bt[i]));
+        }
+    }
+    int level = 0;
+    while (ss.size() > 1) {
+        std::vector<Stream> next;
+        const bool last = ss.size() == 2;
+        u64 off = 0;
+        for (size_t i = 0; i + 1 < ss.size(); i += 2) {
+            const Stream &a = ss[i], &b = ss[i + 1];
+            u64 *ok = last ? fk : bk[level & 1] + off;
+            u32 *ot = tax ? (last ? ft : bt[level & 1] + off) : nullptr;
+            const u64 cap = last ? fcap : a.n + b.n;
+            u64 n = 0;
+            int r = ukm_dev_setop2(ctx, op, a.k, a.t, a.n, b.k, b.t, b.n, flags, ok, ot, cap, &n);
+            if (last) *n_out = n;
+            UKM_TRY(r);
+            next.push_back(Stream{ok, ot, n});
+            off += a.n + b.n;
+        }
+        if (ss.size() & 1) {
+            // carry the odd stream INTO this level's buffer, so that the next level (which
+            // writes the other buffer) never overwrites something it still has to read
+            const Stream &z = ss.back();
+            u64 *zk = bk[level & 1] + off;
+            u32 *zt = tax ? bt[level & 1] + off : nullptr;
+            UKM_HIP(hipMemcpyAsync(zk, z.k, z.n * sizeof(u64), hipMemcpyDeviceToDevice, ctx->stream));
+            if (tax) {
+                if (z.t) UKM_HIP(hipMemcpyAsync(zt, z.t, z.n * sizeof(u32), hipMemcpyDeviceToDevice, ctx->stream));
+                else UKM_HIP(hipMemsetAsync(zt, 0, z.n * sizeof(u32), ctx->stream));
+            }
+            next.push_back(Stream{zk, zt, z.n});
+        }
+        ss.swap(next);
+        level++;
+    }
+    return UKM_OK;
+}
+
 }  // namespace
 
 extern "C" int ukm_union(ukm_ctx *ctx, const uint64_t *const *keys, const uint32_t *const *taxids,
@@ -166,51 +216,7 @@ extern "C" int ukm_union(ukm_ctx *ctx, const uint64_t *const *keys, const uint32
             }
         if (ss.empty()) return UKM_OK;
         if (ss.size() == 1) return copy_result(ctx, ss[0], tax, o.k, o.t, out_cap, n_out);
-        u64 total = 0;
-        for (auto &s : ss) total += s.n;
-        // ping-pong level buffers, each able to hold the worst case of a whole level
-        u64 *bk[2] = {nullptr, nullptr};
-        u32 *bt[2] = {nullptr, nullptr};
-        if (ss.size() > 2) {
-            for (int i = 0; i < 2; i++) {
-                UKM_TRY(ws_alloc_t(ctx, total + 1, &bk[i]));
-                if (tax) UKM_TRY(ws_alloc_t(ctx, total + 1, &bt[i]));
-            }
-        }
-        int level = 0;
-        while (ss.size() > 1) {
-            std::vector<Stream> next;
-            const bool last = ss.size() == 2;
-            u64 off = 0;
-            for (size_t i = 0; i + 1 < ss.size(); i += 2) {
-                const Stream &a = ss[i], &b = ss[i + 1];
-                u64 *ok = last ? o.k : bk[level & 1] + off;
-                u32 *ot = tax ? (last ? o.t : bt[level & 1] + off) : nullptr;
-                const u64 cap = last ? out_cap : a.n + b.n;
-                u64 n = 0;
-                int r = ukm_dev_setop2(ctx, UKM_OP_UNION, a.k, a.t, a.n, b.k, b.t, b.n, flags, ok, ot, cap, &n);
-                if (last) *n_out = n;
-                UKM_TRY(r);
-                next.push_back(Stream{ok, ot, n});
-                off += a.n + b.n;
-            }
-            if (ss.size() & 1) {
-                // carry the odd stream INTO this level's buffer, so that the next level (which
-                // writes the other buffer) never overwrites something it still has to read
-                const Stream &z = ss.back();
-                u64 *zk = bk[level & 1] + off;
-                u32 *zt = tax ? bt[level & 1] + off : nullptr;
-                UKM_HIP(hipMemcpyAsync(zk, z.k, z.n * sizeof(u64), hipMemcpyDeviceToDevice, ctx->stream));
-                if (tax) {
-                    if (z.t) UKM_HIP(hipMemcpyAsync(zt, z.t, z.n * sizeof(u32), hipMemcpyDeviceToDevice, ctx->stream));
-                    else UKM_HIP(hipMemsetAsync(zt, 0, z.n * sizeof(u32), ctx->stream));
-                }
-                next.push_back(Stream{zk, zt, z.n});
-            }
-            ss.swap(next);
-            level++;
-        }
-        return UKM_OK;
+        return tree_reduce(ctx, ss, UKM_OP_UNION, flags, tax, o.k, o.t, out_cap, n_out);
     });
 }
 
@@ -360,21 +366,42 @@ extern "C" int ukm_merge_k(ukm_ctx *ctx, const uint64_t *const *keys, const uint
     UKM_TRY(check_common_args(ctx, keys, lens, nstreams, out_keys, out_cap, n_out, "ukm_merge_k"));
     if (mode != UKM_PLAIN && mode != UKM_UNIQUE && mode != UKM_REPEATED)
         UKM_FAIL(UKM_ERR_INVALID, "ukm_merge_k: mode must be UKM_PLAIN, UKM_UNIQUE or UKM_REPEATED");
+    // -u over sorted streams is the union (distinct codes, LCA over every occurrence): the merge tree
+    // moves 24 B per record and level instead of the 8 radix passes of concat + sort
+    if (mode == UKM_UNIQUE && nstreams > 1)
+        return ukm_union(ctx, keys, taxids, lens, nstreams, 0, out_keys, out_taxids, out_cap, n_out);
     const bool tax = any_taxids(taxids, nstreams);
     return run_entry(ctx, out_keys, out_taxids, out_cap, n_out, tax, [&](OutBufs &o) -> int {
+        std::vector<Stream> all;
+        UKM_TRY(stage_streams(ctx, keys, taxids, lens, nstreams, tax, all));
         std::vector<Stream> ss;
-        UKM_TRY(stage_streams(ctx, keys, taxids, lens, nstreams, tax, ss));
-        u64 *k = nullptr;
-        u32 *t = nullptr;
         u64 total = 0;
-        UKM_TRY(concat_streams(ctx, ss, tax, &k, &t, &total));
+        bool all_sorted = true;
+        for (auto &s : all)
+            if (s.n) {
+                bool sorted = true, strict = true;
+                UKM_TRY(ukm_dev_check_sorted(ctx, s.k, s.n, &sorted, &strict));
+                all_sorted = all_sorted && sorted;
+                ss.push_back(s);
+                total += s.n;
+            }
         if (total == 0) return UKM_OK;
-        int live = 0;
-        for (auto &s : ss) live += s.n ? 1 : 0;
-        if (live > 1) UKM_TRY(ukm_dev_sort(ctx, k, t, total, 64));
         // util-sort.go:377-388,519-530: in a non-final round the one/two-copy protocol is kept
         int m = mode;
         if (mode == UKM_REPEATED && !final_round) m = UKM_REPEATED_CHUNK;
+        u64 *k = nullptr;
+        u32 *t = nullptr;
+        if (all_sorted && ss.size() > 1) {
+            // sorted chunk files (the protocol's input): k-way merge = tree of 2-way merges that keep every
+            // record, 16(+8) B per record and level instead of the radix passes of concat + sort
+            UKM_TRY(ws_alloc_t(ctx, total + 1, &k));
+            if (tax) UKM_TRY(ws_alloc_t(ctx, total + 1, &t));
+            u64 nm = 0;
+            UKM_TRY(tree_reduce(ctx, ss, UKM_OP_MERGE_INTERNAL, 0, tax, k, t, total, &nm));
+        } else {
+            UKM_TRY(concat_streams(ctx, ss, tax, &k, &t, &total));
+            if (ss.size() > 1 || !all_sorted) UKM_TRY(ukm_dev_sort(ctx, k, t, total, 64));
+        }
         return ukm_dev_unique(ctx, k, t, total, m, o.k, o.t, out_cap, n_out);
     });
 }

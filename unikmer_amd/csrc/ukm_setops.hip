@@ -108,6 +108,9 @@ __global__ void setop_partition_kernel(SetopArgs p, int tile_items) {
     p.mp[t] = lo;
 }
 
+// UKM_OP_MERGE_INTERNAL (ukm_internal.h): plain 2-way MERGE of two non-decreasing streams, every record
+// kept (A first on ties).  Output size is known (|A| + |B|), so the tile kernel needs no look-back for it.
+
 // ---- tile building blocks (shared by the kernels below) -------------------------------------------
 // Everything here is written branch-free on purpose: the first version of the merge step
 // compiled to ~80 instructions (exec-mask juggling, phi copies, 64-bit selects) and the kernel
@@ -376,6 +379,9 @@ __device__ __forceinline__ void tile_merge_loop(const SetopArgs &p, const TileGe
             eq_prev = match;
         } else if (OP == UKM_OP_INTER) {
             emit = match;
+        } else if (OP == UKM_OP_MERGE_INTERNAL) {
+            emit = take_a || take_b;
+            ek = take_a ? ak : bk;
         } else {
             emit = take_a && !match;
         }
@@ -389,6 +395,8 @@ __device__ __forceinline__ void tile_merge_loop(const SetopArgs &p, const TileGe
                     if (mix) et = (ta == 0) ? tb : ((tb == 0) ? ta : lca_memo(ta, tb));
                     else et = lca_memo(ta, tb);
                 }
+            } else if (OP == UKM_OP_MERGE_INTERNAL) {
+                et = take_a ? ta : tb;
             } else {
                 et = ta;
                 if (match && cmp && (ta == tb || lca_memo(tb, ta) == ta)) emit = true;
@@ -550,12 +558,14 @@ __global__ __launch_bounds__(NTH) SETOP_WAVES_ATTR void setop_tile_kernel(SetopA
     u32 tile_total;
     const u32 excl = block_excl_scan_u32<NTH>((u32)__popc(mask), s_scan, &tile_total);
     // (the scan's barriers also guarantee every thread finished reading the tile from LDS)
-    if (tid == 0) lb_publish(p.status, tile, (u64)tile_total);
+    if (OP != UKM_OP_MERGE_INTERNAL && tid == 0) lb_publish(p.status, tile, (u64)tile_total);
 #ifndef SETOP_ABL_NOCOMPACT
     tile_compact<TAX, VT>(excl, mask, ok, ot, s_keys, s_tax);
 #endif
     PH(3);
-    if (tid < 64) {
+    if (OP == UKM_OP_MERGE_INTERNAL) {
+        if (tid == 0) s_misc[1] = tile * (u64)TILE;  // every record is kept: the tile's output offset is known
+    } else if (tid < 64) {
         bool timed_out = false;
 #ifdef LB_PRE_SLEEP
         __builtin_amdgcn_s_sleep(LB_PRE_SLEEP);
@@ -569,7 +579,16 @@ __global__ __launch_bounds__(NTH) SETOP_WAVES_ATTR void setop_tile_kernel(SetopA
         if (timed_out) bad |= FLAG_TIMEOUT;
     }
     PH(4);
-    if (bad) atomicOr((unsigned long long *)&p.result[1], (unsigned long long)bad);
+    if (OP == UKM_OP_MERGE_INTERNAL) bad &= ~FLAG_DUP;  // duplicates are legal in a plain merge
+    {
+        // one atomic per wave at most (a stream full of duplicates would otherwise send one per thread
+        // to the same word)
+        u32 wbad = 0;
+#pragma unroll
+        for (u32 f = 1; f <= FLAG_TIMEOUT; f <<= 1)
+            if (__ballot((bad & f) != 0)) wbad |= f;
+        if (wbad && lane_id() == 0) atomicOr((unsigned long long *)&p.result[1], (unsigned long long)wbad);
+    }
     __syncthreads();
     const u64 base = s_misc[1];
 #ifndef SETOP_ABL_NOFLUSH
@@ -626,7 +645,9 @@ template <bool TAX, bool RANK, int NTH, int VT>
 void launch_op(int op, const SetopArgs &p, hipStream_t st, bool ticket) {
     if (op == UKM_OP_UNION) launch_tile<UKM_OP_UNION, TAX, RANK, NTH, VT>(p, st, ticket);
     else if (op == UKM_OP_INTER) launch_tile<UKM_OP_INTER, TAX, RANK, NTH, VT>(p, st, ticket);
-    else launch_tile<UKM_OP_DIFF, TAX, RANK, NTH, VT>(p, st, ticket);
+    else if (op == UKM_OP_MERGE_INTERNAL) {
+        if constexpr (!RANK) launch_tile<UKM_OP_MERGE_INTERNAL, TAX, false, NTH, VT>(p, st, ticket);
+    } else launch_tile<UKM_OP_DIFF, TAX, RANK, NTH, VT>(p, st, ticket);
 }
 
 constexpr int NTS = SETOP_NT;       // threads per workgroup (512: two workgroups per CU)
@@ -721,11 +742,11 @@ int run_setop_pass(ukm_ctx *c, int op, const u64 *a, const u32 *ta, const u32 *r
 // internal entry: all pointers are device pointers
 int ukm_dev_setop2(ukm_ctx *c, int op, const u64 *a, const u32 *ta, u64 na, const u64 *b,
                    const u32 *tb, u64 nb, u32 flags, u64 *out, u32 *tout, u64 out_cap, u64 *n_out) {
-    if (op != UKM_OP_UNION && op != UKM_OP_INTER && op != UKM_OP_DIFF)
+    if (op != UKM_OP_UNION && op != UKM_OP_INTER && op != UKM_OP_DIFF && op != UKM_OP_MERGE_INTERNAL)
         UKM_FAIL(UKM_ERR_INVALID, "ukm_setop2: unknown op %d", op);
     const bool tax = (ta != nullptr) || (tb != nullptr);
     if (tax && !tout) UKM_FAIL(UKM_ERR_INVALID, "ukm_setop2: taxids given but out_taxids is NULL");
-    const bool need_lca = tax && (op != UKM_OP_DIFF || (flags & UKM_F_CMP_TAXID));
+    const bool need_lca = tax && op != UKM_OP_MERGE_INTERNAL && (op != UKM_OP_DIFF || (flags & UKM_F_CMP_TAXID));
     if (need_lca && c->tax_parent == nullptr)
         UKM_FAIL(UKM_ERR_NO_TAXONOMY, "ukm_setop2: records carry taxids but no taxonomy is loaded");
     *n_out = 0;
@@ -736,7 +757,7 @@ int ukm_dev_setop2(ukm_ctx *c, int op, const u64 *a, const u32 *ta, u64 na, cons
     UKM_TRY(run_setop_pass(c, op, a, ta, nullptr, na, b, tb, nullptr, nb, tax, flags, out, tout,
                            out_cap, res));
     if (res[1] & FLAG_UNSORTED) UKM_FAIL(UKM_ERR_UNSORTED, "ukm_setop2: an input stream is not sorted");
-    if (res[1] & FLAG_DUP) {
+    if ((res[1] & FLAG_DUP) && op != UKM_OP_MERGE_INTERNAL) {
         // multiset inputs: redo with the exact reference semantics
         if (op == UKM_OP_UNION) {
             // union is a set: fold duplicates (LCA) inside each input first, then merge
@@ -790,6 +811,8 @@ extern "C" int ukm_setop2(ukm_ctx *ctx, int op, const uint64_t *a_keys, const ui
                           uint64_t out_cap, uint64_t *n_out) {
     if (!ctx || !n_out || (!a_keys && na) || (!b_keys && nb) || (!out_keys && out_cap))
         UKM_FAIL(UKM_ERR_INVALID, "ukm_setop2: NULL argument");
+    if (op != UKM_OP_UNION && op != UKM_OP_INTER && op != UKM_OP_DIFF)
+        UKM_FAIL(UKM_ERR_INVALID, "ukm_setop2: unknown op %d", op);
     CallScope s;
     UKM_TRY(ukm_begin(ctx, &s));
     int rc = [&]() -> int {
