@@ -197,6 +197,36 @@ int tree_reduce(ukm_ctx *ctx, std::vector<Stream> ss, int op, u32 flags, bool ta
     return UKM_OK;
 }
 
+// All records of the (non-empty) streams as ONE sequence ordered by code, equal codes in stream
+// order (= a stable sort of the concatenation).  Sorted streams (chunk files, .unik sets) go through
+// the keep-everything merge tree; anything else is concatenated and radix sorted.
+int merged_sequence(ukm_ctx *ctx, const std::vector<Stream> &all, bool tax, u64 **k, u32 **t, u64 *total) {
+    std::vector<Stream> ss;
+    u64 n = 0;
+    bool all_sorted = true;
+    for (auto &s : all)
+        if (s.n) {
+            bool sorted = true, strict = true;
+            UKM_TRY(ukm_dev_check_sorted(ctx, s.k, s.n, &sorted, &strict));
+            all_sorted = all_sorted && sorted;
+            ss.push_back(s);
+            n += s.n;
+        }
+    *total = n;
+    *k = nullptr;
+    *t = nullptr;
+    if (n == 0) return UKM_OK;
+    if (all_sorted && ss.size() > 1) {
+        UKM_TRY(ws_alloc_t(ctx, n + 1, k));
+        if (tax) UKM_TRY(ws_alloc_t(ctx, n + 1, t));
+        u64 nm = 0;
+        return tree_reduce(ctx, ss, UKM_OP_MERGE_INTERNAL, 0, tax, *k, *t, n, &nm);
+    }
+    UKM_TRY(concat_streams(ctx, ss, tax, k, t, total));
+    if (!all_sorted) UKM_TRY(ukm_dev_sort(ctx, *k, *t, n, 64));
+    return UKM_OK;
+}
+
 }  // namespace
 
 extern "C" int ukm_union(ukm_ctx *ctx, const uint64_t *const *keys, const uint32_t *const *taxids,
@@ -352,9 +382,8 @@ extern "C" int ukm_common(ukm_ctx *ctx, const uint64_t *const *keys, const uint3
         u64 *k = nullptr;
         u32 *t = nullptr;
         u64 total = 0;
-        UKM_TRY(concat_streams(ctx, ss, tax, &k, &t, &total));
+        UKM_TRY(merged_sequence(ctx, ss, tax, &k, &t, &total));
         if (total == 0) return UKM_OK;
-        UKM_TRY(ukm_dev_sort(ctx, k, t, total, 64));
         int r = ukm_dev_unique_ex(ctx, k, t, total, 6, threshold ? threshold : 0, o.k, o.t, out_cap, n_out);
         return r;
     });
@@ -374,34 +403,14 @@ extern "C" int ukm_merge_k(ukm_ctx *ctx, const uint64_t *const *keys, const uint
     return run_entry(ctx, out_keys, out_taxids, out_cap, n_out, tax, [&](OutBufs &o) -> int {
         std::vector<Stream> all;
         UKM_TRY(stage_streams(ctx, keys, taxids, lens, nstreams, tax, all));
-        std::vector<Stream> ss;
-        u64 total = 0;
-        bool all_sorted = true;
-        for (auto &s : all)
-            if (s.n) {
-                bool sorted = true, strict = true;
-                UKM_TRY(ukm_dev_check_sorted(ctx, s.k, s.n, &sorted, &strict));
-                all_sorted = all_sorted && sorted;
-                ss.push_back(s);
-                total += s.n;
-            }
-        if (total == 0) return UKM_OK;
         // util-sort.go:377-388,519-530: in a non-final round the one/two-copy protocol is kept
         int m = mode;
         if (mode == UKM_REPEATED && !final_round) m = UKM_REPEATED_CHUNK;
         u64 *k = nullptr;
         u32 *t = nullptr;
-        if (all_sorted && ss.size() > 1) {
-            // sorted chunk files (the protocol's input): k-way merge = tree of 2-way merges that keep every
-            // record, 16(+8) B per record and level instead of the radix passes of concat + sort
-            UKM_TRY(ws_alloc_t(ctx, total + 1, &k));
-            if (tax) UKM_TRY(ws_alloc_t(ctx, total + 1, &t));
-            u64 nm = 0;
-            UKM_TRY(tree_reduce(ctx, ss, UKM_OP_MERGE_INTERNAL, 0, tax, k, t, total, &nm));
-        } else {
-            UKM_TRY(concat_streams(ctx, ss, tax, &k, &t, &total));
-            if (ss.size() > 1 || !all_sorted) UKM_TRY(ukm_dev_sort(ctx, k, t, total, 64));
-        }
+        u64 total = 0;
+        UKM_TRY(merged_sequence(ctx, all, tax, &k, &t, &total));
+        if (total == 0) return UKM_OK;
         return ukm_dev_unique(ctx, k, t, total, m, o.k, o.t, out_cap, n_out);
     });
 }
