@@ -1,0 +1,132 @@
+"""Size-independent parity properties at sizes the CPU oracle cannot reach in test time
+(SURVEY.md §8(c)/(d)): inclusion-exclusion, checksum-of-checksums, sortedness, idempotence,
+permutation invariance.  Inputs come from bench.py's device generator (verified against numpy
+there and in test_dist_gloo / bench itself)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+pytestmark = pytest.mark.gpu
+
+N = 50_000_000  # per set
+
+
+@pytest.fixture(scope="module")
+def env():
+    import torch
+    import bench
+    from unikmer_amd import lib
+    dev = torch.device("cuda", 0)
+    ctx = lib.Context(0, stream=torch.cuda.current_stream(dev).cuda_stream)
+    A, B = bench.gen_sets_device((4 * N + 2) // 3, 32, 0, bench.SEED, dev)
+    return torch, bench, lib, ctx, A, B
+
+
+def _xor(torch, t):
+    # XOR checksum of an int64 tensor (bit patterns of the uint64 codes)
+    x = t
+    while x.numel() > 1:
+        if x.numel() & 1:
+            x = torch.cat([x, torch.zeros(1, dtype=x.dtype, device=x.device)])
+        h = x.numel() // 2
+        x = x[:h] ^ x[h:]
+    return int(x.item()) if x.numel() else 0
+
+
+def _strict(t):
+    return bool((t[1:] > t[:-1]).all())
+
+
+def test_set_algebra_identities(env):
+    torch, bench, lib, ctx, A, B = env
+    U = ctx.setop2(lib.OP_UNION, A, B)
+    I = ctx.setop2(lib.OP_INTER, A, B)
+    D = ctx.setop2(lib.OP_DIFF, A, B)
+    D2 = ctx.setop2(lib.OP_DIFF, B, A)
+    na, nb = A.numel(), B.numel()
+    assert U.numel() + I.numel() == na + nb                      # inclusion-exclusion
+    assert D.numel() == na - I.numel() and D2.numel() == nb - I.numel()
+    assert U.numel() == D.numel() + D2.numel() + I.numel()
+    for t in (U, I, D, D2):
+        assert _strict(t)
+    xa, xb, xu, xi, xd, xd2 = (_xor(torch, t) for t in (A, B, U, I, D, D2))
+    assert xu == xa ^ xb ^ xi                                    # checksum of checksums
+    assert xd == xa ^ xi and xd2 == xb ^ xi
+    # idempotence / absorption
+    assert torch.equal(ctx.setop2(lib.OP_UNION, U, A), U)
+    assert torch.equal(ctx.setop2(lib.OP_INTER, U, A), A)
+    assert torch.equal(ctx.setop2(lib.OP_INTER, I, A), I)
+    assert ctx.setop2(lib.OP_DIFF, I, A).numel() == 0
+    assert torch.equal(ctx.setop2(lib.OP_UNION, D, I), A)         # A = (A \\ B) u (A n B)
+    # n-way entry points agree with the 2-way kernel
+    assert torch.equal(ctx.union([A, B]), U) and torch.equal(ctx.inter([A, B]), I) and torch.equal(ctx.diff([A, B]), D)
+    assert torch.equal(ctx.common([A, B], 2), I) and torch.equal(ctx.common([A, B], 1), U)
+    assert torch.equal(ctx.merge_k([A, B], mode=lib.UNIQUE), U) and torch.equal(ctx.merge_k([A, B], mode=lib.REPEATED), I)
+    M = ctx.merge_k([A, B], mode=lib.PLAIN)
+    assert M.numel() == na + nb and bool((M[1:] >= M[:-1]).all()) and _xor(torch, M) == xa ^ xb
+
+
+def test_sort_is_a_sorted_permutation(env):
+    torch, bench, lib, ctx, A, B = env
+    g = torch.Generator(device=A.device)
+    g.manual_seed(3)
+    perm = torch.randperm(A.numel(), device=A.device, generator=g)
+    shuffled = A[perm].contiguous()
+    work = shuffled.clone()
+    ctx.sort_u64(work, 62)
+    assert torch.equal(work, A)                                  # A is strictly increasing: the sort must restore it
+    # pairs: the payload follows its key
+    work = shuffled.clone()
+    vals = perm.to(torch.int32).contiguous()
+    ctx.sort_pairs(work, vals, 62)
+    assert torch.equal(work, A) and torch.equal(vals.long(), torch.arange(A.numel(), device=A.device))
+    # multiset: sort(cat(A, B)) then unique == union; repeated == inter; singleton == symmetric difference
+    cat = torch.cat([B, A])
+    ctx.sort_u64(cat, 62)
+    U = ctx.setop2(lib.OP_UNION, A, B)
+    I = ctx.setop2(lib.OP_INTER, A, B)
+    assert torch.equal(ctx.unique(cat, mode=lib.UNIQUE), U)
+    assert torch.equal(ctx.unique(cat, mode=lib.REPEATED), I)
+    assert ctx.unique(cat, mode=lib.SINGLETON).numel() == U.numel() - I.numel()
+    two = ctx.unique(cat, mode=lib.REPEATED_CHUNK)               # every code once, repeated ones twice
+    assert two.numel() == U.numel() + I.numel() and torch.equal(ctx.unique(two, mode=lib.REPEATED), I)
+    assert torch.equal(ctx.unique(U, mode=lib.UNIQUE), U)         # idempotent
+
+
+def test_encode_and_hash_window_counts(env):
+    torch, bench, lib, ctx, A, B = env
+    nb = 40_000_000
+    i = torch.arange(nb, dtype=torch.int64, device=A.device)
+    w = bench.splitmix64_torch((i >> 5) ^ bench._i64(bench.SEED))
+    bases = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=A.device)[(w >> (2 * (i & 31))) & 3]
+    reads = torch.arange(0, nb + 1, 150, dtype=torch.int64, device=A.device)
+    if int(reads[-1]) != nb:
+        reads = torch.cat([reads, torch.tensor([nb], dtype=torch.int64, device=A.device)])
+    k = 31
+    n_rec = reads.numel() - 1
+    lens = reads[1:] - reads[:-1]
+    expect = int((lens - (k - 1)).clamp(min=0).sum())
+    codes = ctx.encode_kmers(bases, reads, k, canonical=False)
+    assert codes.numel() == expect and int(codes.max()) < (1 << 62)
+    canon = ctx.encode_kmers(bases, reads, k, canonical=True)
+    assert bool((canon <= codes).all())                          # canonical = min(fwd, revcomp) as unsigned (< 2^62)
+    # neighbouring windows of one read overlap in k-1 bases: code[i+1] == ((code[i] << 2) & mask) | next base
+    first = codes[: 150 - k + 1]
+    mask = (1 << (2 * k)) - 1
+    assert bool((((first[:-1] << 2) & mask) >> 2 == (first[1:] >> 2)).all())
+    h = ctx.nthash(bases, reads, k, canonical=True)
+    assert h.numel() == expect
+    mh = ctx.max_hash(100)
+    hs = ctx.nthash(bases, reads, k, canonical=True, max_hash=mh)
+    # the fused Scaled filter keeps exactly the hashes <= maxHash, in window order
+    keep = (h >= 0) & (h <= mh)                                  # maxHash < 2^63, so signed compare on the non-negative half
+    assert torch.equal(hs, h[keep])
+    frac = hs.numel() / h.numel()
+    assert 0.019 < frac < 0.021                                  # canonical = min of two uniform hashes: ~2/scale
+    mins = ctx.minimizer(bases, reads, k, 15)
+    assert 0 < mins.numel() < h.numel() and bool(torch.isin(mins[:1000], h).all())
