@@ -477,3 +477,33 @@ def test_ticketed_fallback_kernel(O, L, monkeypatch):
     assert np.array_equal(c.setop2(L.OP_INTER, A, B), O.inter([A, B]))
     assert np.array_equal(c.setop2(L.OP_DIFF, A, B), O.diff([A, B]))
     c.close()
+
+
+def test_two_contexts_from_two_threads(O, L):
+    """The boundary is re-entrant (SURVEY.md §8(b) Threading): one ukm_ctx per calling OS thread, no global
+    mutable state.  Two threads hammer set operations / sorts through their own contexts concurrently."""
+    import threading
+    results, errors = {}, []
+
+    def work(tid):
+        try:
+            c = L.Context(0)
+            rng = np.random.default_rng(100 + tid)
+            for it in range(6):
+                a = np.unique(rng.integers(0, 1 << 40, 300_000).astype(np.uint64))
+                b = np.unique(rng.integers(0, 1 << 40, 200_000).astype(np.uint64))
+                u, i = c.setop2(L.OP_UNION, a, b), c.setop2(L.OP_INTER, a, b)
+                x = rng.integers(0, 1 << 62, 250_000).astype(np.uint64)
+                s = c.sort_u64(x.copy(), 62)
+                results[(tid, it)] = (np.array_equal(u, np.union1d(a, b)) and np.array_equal(i, np.intersect1d(a, b))
+                                      and np.array_equal(s, np.sort(x)))
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+
+    ts = [threading.Thread(target=work, args=(t,)) for t in range(2)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errors, errors
+    assert len(results) == 12 and all(results.values())
