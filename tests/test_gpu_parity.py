@@ -507,3 +507,21 @@ def test_two_contexts_from_two_threads(O, L):
         t.join()
     assert not errors, errors
     assert len(results) == 12 and all(results.values())
+
+
+def test_full_64bit_keys_unsigned_order(ctx, O, L):
+    """Hashed k-mers (ntHash, -H) use all 64 bits: every comparison must be unsigned."""
+    rng = np.random.default_rng(9)
+    a = np.unique(rng.integers(0, 1 << 64, 200_000, dtype=np.uint64))
+    b = np.unique(np.concatenate([rng.integers(0, 1 << 64, 150_000, dtype=np.uint64), a[::3]]))
+    assert (a >> np.uint64(63)).any() and (b >> np.uint64(63)).any()
+    assert np.array_equal(ctx.setop2(L.OP_UNION, a, b), np.union1d(a, b))
+    assert np.array_equal(ctx.setop2(L.OP_INTER, a, b), np.intersect1d(a, b))
+    assert np.array_equal(ctx.setop2(L.OP_DIFF, a, b), np.setdiff1d(a, b))
+    cat = np.concatenate([b, a])
+    assert np.array_equal(ctx.sort_u64(cat.copy(), 64), np.sort(cat))
+    assert np.array_equal(ctx.merge_k([a, b], mode=L.PLAIN), np.sort(cat))
+    assert np.array_equal(ctx.merge_k([a, b], mode=L.REPEATED), np.intersect1d(a, b))
+    assert np.array_equal(ctx.common([a, b, a], 3), np.intersect1d(a, b))
+    pts = ctx.partition_points(a, np.array([0, 1 << 63, (1 << 64) - 1], dtype=np.uint64))
+    assert [int(x) for x in pts] == [int(np.searchsorted(a, np.uint64(v))) for v in (0, 1 << 63, (1 << 64) - 1)]
