@@ -34,7 +34,10 @@ namespace {
 #define ENC_NT 512
 #endif
 constexpr int NT = ENC_NT;
-constexpr int WT = 2048;        // window start positions per tile
+#ifndef ENC_WT
+#define ENC_WT 2048
+#endif
+constexpr int WT = ENC_WT;      // window start positions per tile
 constexpr int TBX = WT + 64;    // base positions staged per tile (k <= 64)
 constexpr int WPT = WT / NT;    // windows per thread (striped)
 constexpr int PPT = (TBX + NT - 1) / NT;  // positions per thread in the blocked phase (NT * PPT >= TBX)
@@ -179,7 +182,11 @@ __device__ __forceinline__ u64 revcomp2(u64 code, int k) {
 }
 
 // HASH: false = 2-bit codes, true = ntHash.  FILTER: Scaled filter + order-preserving compaction.
-template <bool HASH, bool FILTER>
+// TICKET (FILTER only): tile ids from an atomic counter instead of blockIdx.  The counter is ONE address
+// that every workgroup hits: measured 3-4 ns per tile of pure serialisation (0.15 of 0.68 ms per 1e8 bases),
+// so the default takes blockIdx and relies on in-order dispatch for look-back liveness, exactly like the
+// set-op kernel (watchdog -> flag -> the host re-runs this ticketed instantiation).
+template <bool HASH, bool FILTER, bool TICKET = false>
 __global__ __launch_bounds__(NT) void window_kernel(WinArgs p) {
     __shared__ __attribute__((aligned(16))) u8 s_b[TBX + 16];
     __shared__ u8 s_info[TBX];                     // low 7 bits: min(bases left in record, 127); bit 7: record length >= k
@@ -195,13 +202,11 @@ __global__ __launch_bounds__(NT) void window_kernel(WinArgs p) {
     __shared__ BaseTables s_t;
     const int tid = (int)threadIdx.x, lane = lane_id(), wave = tid >> 6;
     base_tables_init(s_t, tid);  // visible after the first barrier below
-    u64 tile;
-    if (FILTER) {
+    u64 tile = blockIdx.x;
+    if (TICKET) {
         if (tid == 0) s_misc[0] = (u64)atomicAdd(p.ticket, 1u);
         __syncthreads();
         tile = s_misc[0];
-    } else {
-        tile = blockIdx.x;
     }
     const u64 P0 = tile * (u64)WT;
     const int k = p.k;
@@ -402,8 +407,11 @@ __global__ __launch_bounds__(NT) void window_kernel(WinArgs p) {
         __syncthreads();
         const u32 tile_total = s_cnt[WPT * NWV];
         if (tid < 64) {
-            const u64 base = lb_lookback(p.status, tile, (u64)tile_total);
+            bool timed_out = false;
+            if (lane == 0) lb_publish(p.status, tile, (u64)tile_total);
+            const u64 base = lb_resolve(p.status, tile, (u64)tile_total, lane, &timed_out);
             if (tid == 0) s_misc[1] = base;
+            if (timed_out && lane == 0) atomicOr((unsigned long long *)&p.result[1], 2ull);
         }
         __syncthreads();
         const u64 base = s_misc[1];
@@ -455,15 +463,22 @@ int run_windows(ukm_ctx *c, bool hash, const u8 *bases, const u64 *rec_off, u64 
     hipLaunchKernelGGL(tile_first_rec_kernel, dim3((unsigned)((ntiles + 3 + 255) / 256)), dim3(256), 0, c->stream,
                        rec_off, n_rec, total_bases, ntiles, (u64)WT, tile_rec);
     p.tile_rec = tile_rec;
-    (void)hipEventRecord(c->ev_k0, c->stream);
-    if (!hash) hipLaunchKernelGGL((window_kernel<false, false>), dim3((unsigned)ntiles), dim3(NT), 0, c->stream, p);
-    else if (!filter) hipLaunchKernelGGL((window_kernel<true, false>), dim3((unsigned)ntiles), dim3(NT), 0, c->stream, p);
-    else hipLaunchKernelGGL((window_kernel<true, true>), dim3((unsigned)ntiles), dim3(NT), 0, c->stream, p);
-    (void)hipEventRecord(c->ev_k1, c->stream);
-    c->evk_valid = true;
-    UKM_HIP(hipGetLastError());
-    u64 res[2];
-    UKM_TRY(ukm_read_u64(c, ctl, res, 2));
+    u64 res[2] = {0, 0};
+    for (int attempt = (filter && c->setop_force_ticket) ? 1 : 0; attempt < 2; attempt++) {
+        if (attempt == 1) UKM_HIP(hipMemsetAsync(ctl, 0, nctl * sizeof(u64), c->stream));  // second try: ticketed
+        (void)hipEventRecord(c->ev_k0, c->stream);
+        if (!hash) hipLaunchKernelGGL((window_kernel<false, false>), dim3((unsigned)ntiles), dim3(NT), 0, c->stream, p);
+        else if (!filter) hipLaunchKernelGGL((window_kernel<true, false>), dim3((unsigned)ntiles), dim3(NT), 0, c->stream, p);
+        else if (attempt == 0) hipLaunchKernelGGL((window_kernel<true, true, false>), dim3((unsigned)ntiles), dim3(NT), 0, c->stream, p);
+        else hipLaunchKernelGGL((window_kernel<true, true, true>), dim3((unsigned)ntiles), dim3(NT), 0, c->stream, p);
+        (void)hipEventRecord(c->ev_k1, c->stream);
+        c->evk_valid = true;
+        UKM_HIP(hipGetLastError());
+        UKM_TRY(ukm_read_u64(c, ctl, res, 2));
+        if (!(res[1] & 2)) break;  // no look-back watchdog
+        if (attempt == 1) UKM_FAIL(UKM_ERR_HIP, "window kernel: look-back watchdog fired in the ticketed kernel");
+        c->setop_force_ticket = true;  // this device does not dispatch workgroups in order
+    }
     if (res[1] & 1) UKM_FAIL(UKM_ERR_ILLEGAL_BASE, "illegal base in sequence (kmers.ErrIllegalBase)");
     *n_out = filter ? res[0] : total_windows;
     if (*n_out > out_cap)
@@ -502,15 +517,19 @@ struct MinArgs {
     const u64 *tile_rec;
 };
 
+template <bool TICKET>
 __global__ __launch_bounds__(NT) void minimizer_kernel(MinArgs p) {
     __shared__ u64 s_h[MT + MW_MAX + 1];  // s_h[i] = h[J0 - 1 + i]
     __shared__ u32 s_cnt[MPT * NWV + 1];
     __shared__ u64 s_r[2];
     __shared__ u64 s_misc[2];
     const int tid = (int)threadIdx.x, lane = lane_id(), wave = tid >> 6;
-    if (tid == 0) s_misc[0] = (u64)atomicAdd(p.ticket, 1u);
-    __syncthreads();
-    const u64 tile = s_misc[0];
+    u64 tile = blockIdx.x;  // see window_kernel: a ticket counter serialises every workgroup on one address
+    if (TICKET) {
+        if (tid == 0) s_misc[0] = (u64)atomicAdd(p.ticket, 1u);
+        __syncthreads();
+        tile = s_misc[0];
+    }
     const u64 J0 = tile * (u64)MT;
     const int w = p.w;
     for (int i = tid; i < MT + w; i += NT) {
@@ -575,8 +594,11 @@ __global__ __launch_bounds__(NT) void minimizer_kernel(MinArgs p) {
     __syncthreads();
     const u32 tile_total = s_cnt[MPT * NWV];
     if (tid < 64) {
-        const u64 base = lb_lookback(p.status, tile, (u64)tile_total);
+        bool timed_out = false;
+        if (lane == 0) lb_publish(p.status, tile, (u64)tile_total);
+        const u64 base = lb_resolve(p.status, tile, (u64)tile_total, lane, &timed_out);
         if (tid == 0) s_misc[1] = base;
+        if (timed_out && lane == 0) atomicOr((unsigned long long *)&p.result[1], 2ull);
     }
     __syncthreads();
     const u64 base = s_misc[1];
@@ -616,13 +638,22 @@ int run_minimizer(ukm_ctx *c, const u8 *bases, const u64 *rec_off, u64 n_rec, in
     p.h = h; p.off = off; p.n_rec = n_rec; p.total = n_h; p.w = w; p.max_hash = max_hash;
     p.out = out; p.out_pos = out_pos; p.out_cap = out_cap;
     p.result = ctl; p.ticket = (u32 *)(ctl + 2); p.status = ctl + 8; p.ntiles = ntiles; p.tile_rec = tile_rec;
-    (void)hipEventRecord(c->ev_k0, c->stream);
-    hipLaunchKernelGGL(minimizer_kernel, dim3((unsigned)ntiles), dim3(NT), 0, c->stream, p);
-    (void)hipEventRecord(c->ev_k1, c->stream);
-    c->evk_valid = true;
-    UKM_HIP(hipGetLastError());
     u64 res = 0;
-    UKM_TRY(ukm_read_u64(c, ctl, &res));
+    for (int attempt = c->setop_force_ticket ? 1 : 0; attempt < 2; attempt++) {
+        if (attempt == 1) UKM_HIP(hipMemsetAsync(ctl, 0, nctl * sizeof(u64), c->stream));
+        (void)hipEventRecord(c->ev_k0, c->stream);
+        if (attempt == 0) hipLaunchKernelGGL(minimizer_kernel<false>, dim3((unsigned)ntiles), dim3(NT), 0, c->stream, p);
+        else hipLaunchKernelGGL(minimizer_kernel<true>, dim3((unsigned)ntiles), dim3(NT), 0, c->stream, p);
+        (void)hipEventRecord(c->ev_k1, c->stream);
+        c->evk_valid = true;
+        UKM_HIP(hipGetLastError());
+        u64 r2[2];
+        UKM_TRY(ukm_read_u64(c, ctl, r2, 2));
+        res = r2[0];
+        if (!(r2[1] & 2)) break;
+        if (attempt == 1) UKM_FAIL(UKM_ERR_HIP, "minimizer kernel: look-back watchdog fired in the ticketed kernel");
+        c->setop_force_ticket = true;
+    }
     *n_out = res;
     if (res > out_cap)
         UKM_FAIL(UKM_ERR_CAPACITY, "output needs %llu values, capacity is %llu", (unsigned long long)res,
