@@ -1,5 +1,6 @@
 """GPU parity tests: the HIP path (through the C ABI) against the CPU oracle, bit-exact.
 Run on the MI355X box with `pytest -m gpu`."""
+import os
 import numpy as np
 import pytest
 
@@ -525,3 +526,30 @@ def test_full_64bit_keys_unsigned_order(ctx, O, L):
     assert np.array_equal(ctx.common([a, b, a], 3), np.intersect1d(a, b))
     pts = ctx.partition_points(a, np.array([0, 1 << 63, (1 << 64) - 1], dtype=np.uint64))
     assert [int(x) for x in pts] == [int(np.searchsorted(a, np.uint64(v))) for v in (0, 1 << 63, (1 << 64) - 1)]
+
+
+def test_sharded_setop_over_rccl_world1(ctx, O, L):
+    """unikmer_amd/dist.py end to end on the GPU with the `nccl` (= RCCL) backend and a world of one
+    rank: the all-to-all-v of int64 device tensors, the GPU cut points (ukm_partition_points) and the
+    per-rank n-way op all run; the 2-rank behaviour of the same code is covered on CPU over gloo."""
+    import socket
+    import torch
+    import torch.distributed as dist
+    from unikmer_amd import dist as ud
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        rng = np.random.default_rng(21)
+        files = [np.unique(rng.integers(0, 1 << 42, 60_000, dtype=np.uint64)) for _ in range(3)]
+        dfiles = [torch.from_numpy(f.view(np.int64)).to(dev) for f in files]
+        dctx = L.Context(0, stream=torch.cuda.current_stream(dev).cuda_stream)
+        for op, ref in (("union", O.union), ("inter", O.inter), ("diff", O.diff)):
+            got = ud.sharded_setop(dctx, op, dfiles, 42)
+            got = got[0] if isinstance(got, tuple) else got
+            assert np.array_equal(got.cpu().numpy().view(np.uint64), np.sort(ref(files)))
+    finally:
+        dist.destroy_process_group()
