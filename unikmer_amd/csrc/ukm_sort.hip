@@ -8,7 +8,7 @@
 //     serialise on one bin); the host turns them into per-pass digit bases and drops passes
 //     whose digit is constant (k=31 -> 62 significant bits; top bits of k=21 codes are zero);
 //   * per executed pass ONE "onesweep" kernel: each 256-thread workgroup takes a ticketed tile
-//     of 6144 keys (256 threads x 24), ranks them stably with wave64 ballot match-any (8 ballots per key) into
+//     of 6144 keys (512 threads x 12; 10240 = 512 x 20 with taxids), ranks them stably with wave64 ballot match-any (8 ballots per key) into
 //     per-wave LDS digit counters, resolves the tile's global digit offsets by a per-digit
 //     decoupled look-back over the previous tiles' counts (thread d owns digit d), reorders
 //     the tile through LDS so that global stores are contiguous per digit, and scatters.
@@ -19,16 +19,21 @@
 
 namespace {
 
-#ifndef SORT_NT
-#define SORT_NT 256
+// onesweep tile shapes (threads x keys per thread), measured on MI355X at 1e8 keys (profiles/r01_notes.md):
+// keys only 512x12 (4.2 ms; 256x24 4.6, 512x20 4.6, 1024x8 4.75), key + taxid 512x20 (5.3 ms; 512x12 6.4)
+#ifndef SORT_NT_KEYS
+#define SORT_NT_KEYS 512
 #endif
-#ifndef SORT_VT
-#define SORT_VT 24
+#ifndef SORT_VT_KEYS
+#define SORT_VT_KEYS 12
 #endif
-constexpr int NT = SORT_NT;  // >= RADIX: thread d < 256 owns digit d
-constexpr int NW = NT / 64;
-constexpr int VT = SORT_VT;
-constexpr int TILE = NT * VT;
+#ifndef SORT_NT_PAIRS
+#define SORT_NT_PAIRS 512
+#endif
+#ifndef SORT_VT_PAIRS
+#define SORT_VT_PAIRS 20
+#endif
+constexpr int NT = 256;  // histogram kernel
 constexpr int RADIX = 256;
 constexpr int MAX_PASSES = 8;
 
@@ -159,8 +164,10 @@ __device__ __forceinline__ void match_any8(u32 d, u32 &plo, u32 &phi) {
 #else
 #define SORT_WAVES_ATTR
 #endif
-template <typename SW, bool PAIRS, bool TICKET>
-__global__ __launch_bounds__(NT) SORT_WAVES_ATTR void onesweep_kernel(PassArgs<SW> p) {
+template <typename SW, bool PAIRS, bool TICKET, int NT_, int VT_>
+__global__ __launch_bounds__(NT_) SORT_WAVES_ATTR void onesweep_kernel(PassArgs<SW> p) {
+    constexpr int NT = NT_, NW = NT_ / 64, VT = VT_, TILE = NT_ * VT_;  // NT >= RADIX: thread d < 256 owns digit d
+    static_assert(NT_ >= RADIX && NT_ % 64 == 0, "workgroup must cover the 256 digits");
     using T = SWTraits<SW>;
     __shared__ u64 s_keys[TILE];
     __shared__ u32 s_vals[PAIRS ? TILE : 1];
@@ -306,9 +313,10 @@ __global__ __launch_bounds__(NT) SORT_WAVES_ATTR void onesweep_kernel(PassArgs<S
     }
 }
 
-template <typename SW>
+template <typename SW, bool PAIRS, int NT_, int VT_>
 int run_passes(ukm_ctx *c, u64 *keys, u32 *vals, u64 *tk, u32 *tv, u64 n, int npass,
                const int *shifts, const u64 *gbase_dev, bool *result_in_tmp) {
+    constexpr int TILE = NT_ * VT_;
     const u64 ntiles = (n + TILE - 1) / TILE;
     SW *status = nullptr;
     u64 *ctl = nullptr;  // [0] ticket, [1] flags
@@ -329,14 +337,9 @@ int run_passes(ukm_ctx *c, u64 *keys, u32 *vals, u64 *tk, u32 *tv, u64 n, int np
             p.status = status; p.ticket = (u32 *)ctl; p.flags = (u32 *)(ctl + 1);
             p.gbase = gbase_dev + (size_t)i * RADIX;
             p.ntiles = ntiles;
-            const dim3 grid((unsigned)ntiles), block(NT);
-            if (vals) {
-                if (ticket) hipLaunchKernelGGL((onesweep_kernel<SW, true, true>), grid, block, 0, c->stream, p);
-                else hipLaunchKernelGGL((onesweep_kernel<SW, true, false>), grid, block, 0, c->stream, p);
-            } else {
-                if (ticket) hipLaunchKernelGGL((onesweep_kernel<SW, false, true>), grid, block, 0, c->stream, p);
-                else hipLaunchKernelGGL((onesweep_kernel<SW, false, false>), grid, block, 0, c->stream, p);
-            }
+            const dim3 grid((unsigned)ntiles), block(NT_);
+            if (ticket) hipLaunchKernelGGL((onesweep_kernel<SW, PAIRS, true, NT_, VT_>), grid, block, 0, c->stream, p);
+            else hipLaunchKernelGGL((onesweep_kernel<SW, PAIRS, false, NT_, VT_>), grid, block, 0, c->stream, p);
             UKM_HIP(hipGetLastError());
             if (ticket) break;  // cannot stall
             u64 fl = 0;
@@ -365,7 +368,7 @@ int ukm_dev_sort(ukm_ctx *c, u64 *keys, u32 *vals, u64 n, int key_bits) {
     u64 *ghist = nullptr;
     UKM_TRY(ws_alloc_t(c, MAX_PASSES * RADIX, &ghist));
     UKM_HIP(hipMemsetAsync(ghist, 0, MAX_PASSES * RADIX * sizeof(u64), c->stream));
-    unsigned hblocks = (unsigned)std::min<u64>((n + TILE - 1) / TILE, (u64)c->num_cu * 8);
+    unsigned hblocks = (unsigned)std::min<u64>((n + 4095) / 4096, (u64)c->num_cu * 8);
     hipLaunchKernelGGL(radix_hist_kernel, dim3(hblocks), dim3(NT), 0, c->stream, keys, n, passes, ghist);
     UKM_HIP(hipGetLastError());
     std::vector<u64> h((size_t)passes * RADIX);
@@ -398,8 +401,13 @@ int ukm_dev_sort(ukm_ctx *c, u64 *keys, u32 *vals, u64 n, int key_bits) {
     UKM_TRY(ws_alloc_t(c, n, &tk));
     if (vals) UKM_TRY(ws_alloc_t(c, n, &tv));
     bool in_tmp = false;
-    if (n < (1ull << 30)) UKM_TRY(run_passes<u32>(c, keys, vals, tk, tv, n, npass, shifts, gbase_dev, &in_tmp));
-    else UKM_TRY(run_passes<u64>(c, keys, vals, tk, tv, n, npass, shifts, gbase_dev, &in_tmp));
+    if (vals) {
+        if (n < (1ull << 30)) UKM_TRY((run_passes<u32, true, SORT_NT_PAIRS, SORT_VT_PAIRS>(c, keys, vals, tk, tv, n, npass, shifts, gbase_dev, &in_tmp)));
+        else UKM_TRY((run_passes<u64, true, SORT_NT_PAIRS, SORT_VT_PAIRS>(c, keys, vals, tk, tv, n, npass, shifts, gbase_dev, &in_tmp)));
+    } else {
+        if (n < (1ull << 30)) UKM_TRY((run_passes<u32, false, SORT_NT_KEYS, SORT_VT_KEYS>(c, keys, vals, tk, tv, n, npass, shifts, gbase_dev, &in_tmp)));
+        else UKM_TRY((run_passes<u64, false, SORT_NT_KEYS, SORT_VT_KEYS>(c, keys, vals, tk, tv, n, npass, shifts, gbase_dev, &in_tmp)));
+    }
     if (in_tmp) {
         UKM_HIP(hipMemcpyAsync(keys, tk, n * sizeof(u64), hipMemcpyDeviceToDevice, c->stream));
         if (vals) UKM_HIP(hipMemcpyAsync(vals, tv, n * sizeof(u32), hipMemcpyDeviceToDevice, c->stream));
