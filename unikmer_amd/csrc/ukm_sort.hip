@@ -8,7 +8,7 @@
 //     serialise on one bin); the host turns them into per-pass digit bases and drops passes
 //     whose digit is constant (k=31 -> 62 significant bits; top bits of k=21 codes are zero);
 //   * per executed pass ONE "onesweep" kernel: each 256-thread workgroup takes a ticketed tile
-//     of 6144 keys (512 threads x 12; 10240 = 512 x 20 with taxids), ranks them stably with wave64 ballot match-any (8 ballots per key) into
+//     of 7168 keys (512 threads x 14; 11264 = 1024 x 11 with taxids), ranks them stably with wave64 ballot match-any (8 ballots per key) into
 //     per-wave LDS digit counters, resolves the tile's global digit offsets by a per-digit
 //     decoupled look-back over the previous tiles' counts (thread d owns digit d), reorders
 //     the tile through LDS so that global stores are contiguous per digit, and scatters.
@@ -20,18 +20,19 @@
 namespace {
 
 // onesweep tile shapes (threads x keys per thread), measured on MI355X at 1e8 keys (profiles/r01_notes.md):
-// keys only 512x12 (4.2 ms; 256x24 4.6, 512x20 4.6, 1024x8 4.75), key + taxid 512x20 (5.3 ms; 512x12 6.4)
+// keys only 512x14 (4.15 ms; 512x12 4.3, 512x15 5.3, 256x24 4.6, 768x10 4.9, 1024x7 5.1),
+// key + taxid 1024x11 (5.1 ms; 768x14 5.1, 512x20 5.4, 512x12 6.4)
 #ifndef SORT_NT_KEYS
 #define SORT_NT_KEYS 512
 #endif
 #ifndef SORT_VT_KEYS
-#define SORT_VT_KEYS 12
+#define SORT_VT_KEYS 14
 #endif
 #ifndef SORT_NT_PAIRS
-#define SORT_NT_PAIRS 512
+#define SORT_NT_PAIRS 1024
 #endif
 #ifndef SORT_VT_PAIRS
-#define SORT_VT_PAIRS 20
+#define SORT_VT_PAIRS 11
 #endif
 constexpr int NT = 256;  // histogram kernel
 constexpr int RADIX = 256;
