@@ -30,7 +30,7 @@ enum { FLAG_DUP = 1, FLAG_UNSORTED = 2, FLAG_TIMEOUT = 4 };
 #define SETOP_NT 512
 #endif
 #ifndef SETOP_VT
-#define SETOP_VT 16
+#define SETOP_VT 19
 #endif
 
 
@@ -651,7 +651,7 @@ void launch_op(int op, const SetopArgs &p, hipStream_t st, bool ticket) {
 }
 
 constexpr int NTS = SETOP_NT;       // threads per workgroup (512: two workgroups per CU)
-constexpr int VT_PLAIN = SETOP_VT;  // 16 items per thread: 64 KiB of keys in LDS per workgroup
+constexpr int VT_PLAIN = SETOP_VT;  // 19 items per thread: 76 KiB of keys in LDS per workgroup (2 x 78 KB fit the CU's 160 KB)
 constexpr int VT_TAX = 12;     // fewer when taxids/ranks ride along
 
 // One pass of the tiled set operation.  result_host[0] = total, [1] = flags.
