@@ -652,7 +652,10 @@ void launch_op(int op, const SetopArgs &p, hipStream_t st, bool ticket) {
 
 constexpr int NTS = SETOP_NT;       // threads per workgroup (512: two workgroups per CU)
 constexpr int VT_PLAIN = SETOP_VT;  // 19 items per thread: 76 KiB of keys in LDS per workgroup (2 x 78 KB fit the CU's 160 KB)
-constexpr int VT_TAX = 12;     // fewer when taxids/ranks ride along
+#ifndef SETOP_VT_TAX
+#define SETOP_VT_TAX 12
+#endif
+constexpr int VT_TAX = SETOP_VT_TAX;     // fewer when taxids/ranks ride along
 
 // One pass of the tiled set operation.  result_host[0] = total, [1] = flags.
 int run_setop_pass(ukm_ctx *c, int op, const u64 *a, const u32 *ta, const u32 *ra, u64 na,
