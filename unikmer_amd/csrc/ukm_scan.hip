@@ -21,8 +21,14 @@
 namespace {
 
 constexpr int NT = 256;   // exclusive-scan kernel
-constexpr int UNT = 512;  // unique kernel: threads per workgroup
-constexpr int UVT = 16;   // records per thread (8192-record tiles; 8 for the chunk protocol)
+#ifndef UNIQ_NT
+#define UNIQ_NT 512
+#endif
+#ifndef UNIQ_VT
+#define UNIQ_VT 16
+#endif
+constexpr int UNT = UNIQ_NT;  // unique kernel: threads per workgroup
+constexpr int UVT = UNIQ_VT;  // records per thread (half of it for the chunk protocol)
 
 struct UniqArgs {
     const u64 *k;
