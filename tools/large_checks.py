@@ -1,0 +1,52 @@
+#!/usr/bin/env python
+"""One-off validation at sizes beyond the test suite: the 64-bit look-back status path of the
+radix sort (n >= 2^30) and set operations over more than 2^32 records in total."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+import bench
+from unikmer_amd import lib
+
+dev = torch.device("cuda", 0)
+ctx = lib.Context(0, stream=torch.cuda.current_stream(dev).cuda_stream)
+
+
+def xor_all(t):
+    x = t
+    while x.numel() > 1:
+        if x.numel() & 1:
+            x = torch.cat([x, torch.zeros(1, dtype=x.dtype, device=x.device)])
+        h = x.numel() // 2
+        x = x[:h] ^ x[h:]
+    return int(x.item())
+
+
+# 1. sort of 1.2e9 keys (status words are 64-bit from 2^30 keys on)
+n = 1_600_000_000
+A, _ = bench.gen_sets_device(n, 31, 0, bench.SEED, dev)   # strictly increasing, ~0.75 n elements
+A = A[: min(A.numel(), 1_100_000_000)].contiguous()
+assert A.numel() > (1 << 30)
+g = torch.Generator(device=dev); g.manual_seed(5)
+perm = torch.randperm(A.numel(), device=dev, generator=g)
+S = A[perm].contiguous()
+del perm
+ctx.sort_u64(S, 62)
+assert torch.equal(S, A), "sort of >2^30 keys failed"
+print("sort n=%d ok (%.1f ms)" % (A.numel(), ctx.last_call_ms()))
+del S, A
+# 2. set ops with |A|+|B| > 2^32
+n = 2_300_000_000
+A, B = bench.gen_sets_device((4 * n + 2) // 3, 29, 0, bench.SEED + 3, dev)
+na, nb = A.numel(), B.numel()
+assert na + nb > (1 << 32)
+out = torch.empty(na + nb, dtype=torch.int64, device=dev)
+U = ctx.setop2(lib.OP_UNION, A, B, out=out)
+nu = U.numel(); xu = xor_all(U); su = bool((U[1:] > U[:-1]).all())
+I = ctx.setop2(lib.OP_INTER, A, B, out=out)
+ni = I.numel(); xi = xor_all(I); si = bool((I[1:] > I[:-1]).all())
+assert nu + ni == na + nb and su and si
+assert xu == xor_all(A) ^ xor_all(B) ^ xi
+print("setop |A|+|B|=%d ok: union %d inter %d" % (na + nb, nu, ni))

@@ -75,7 +75,10 @@ __device__ __forceinline__ bool key_eq(u64 ka, u32 ra, u64 kb, u32 rb) {
 // one) with a full search, LEVEL 2 searches the others only between their two coarse neighbours
 // (the path is monotone), i.e. inside a few MB that the group's threads share in cache.
 // LEVEL 0 = single-level search of every boundary (small inputs).
-constexpr int PART_COARSE = 64;
+#ifndef SETOP_PART_COARSE
+#define SETOP_PART_COARSE 64
+#endif
+constexpr int PART_COARSE = SETOP_PART_COARSE;
 template <bool RANK, int LEVEL>
 __global__ void setop_partition_kernel(SetopArgs p, int tile_items) {
     u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
