@@ -54,3 +54,22 @@ def test_null_arguments_return_error_codes(lib):
     assert L.ukm_setop2(None, 0, None, None, 0, None, None, 0, 0, None, None, 0, C.byref(n)) == lib.ERR_INVALID
     assert L.ukm_sort_u64(None, None, 0, 64) == lib.ERR_INVALID
     assert L.ukm_ctx_destroy(None) == 0
+
+
+def test_header_is_plain_c_and_links(lib, tmp_path):
+    """include/unikmer_hip.h must be usable from C (cgo compiles it as C): the example client builds
+    with gcc -std=c99 -Wall -Werror and links against the shared library without any HIP header."""
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    exe = str(tmp_path / "count_union")
+    libdir = os.path.join(ROOT, "unikmer_amd")
+    cmd = ["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(ROOT, "include"),
+           os.path.join(ROOT, "examples", "count_union.c"), "-L", libdir, "-lunikmer_hip", "-Wl,-rpath," + libdir,
+           "-Wl,-rpath-link,/opt/rocm/lib", "-o", exe]
+    p = subprocess.run(cmd, capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr
+    r = subprocess.run([exe], capture_output=True, text=True)
+    # exit code 2 = "no HIP device" (this container); 0 = ran on a GPU and inclusion-exclusion held
+    assert r.returncode in (0, 2), (r.returncode, r.stdout, r.stderr)
