@@ -211,6 +211,13 @@ def test_nway_edge_cases(ctx, O, L):
     rng = np.random.default_rng(5)
     shuffled = [rng.permutation(np.concatenate([f, f[:100]])) for f in files]
     assert np.array_equal(ctx.union(shuffled), O.union(shuffled))
+    # the order check is lazy (done by the merges themselves): mixtures of clean, multiset and unsorted
+    # streams, an odd count (one stream is carried up the tree unchecked), taxids along
+    five = _files(5, 4000, 0.5, seed=23)
+    mix5 = [five[0], rng.permutation(five[1]), np.sort(np.concatenate([five[2], five[2][:50]])), five[3], rng.permutation(five[4])]
+    assert np.array_equal(ctx.union(mix5), O.union(mix5))
+    assert np.array_equal(ctx.union(mix5[:3]), O.union(mix5[:3]))
+    assert np.array_equal(ctx.merge_k([five[0], five[1], five[2]], mode=L.UNIQUE), O.union(five[:3]))
     # inter: an empty LATER file stops the fold and keeps the running result (inter.go:211-217)
     assert np.array_equal(ctx.inter([files[0], files[1], e, files[2]]), O.inter([files[0], files[1], e, files[2]]))
     assert np.array_equal(ctx.inter([files[0], files[1], e, files[2]]), np.intersect1d(files[0], files[1]))
