@@ -218,6 +218,12 @@ def test_nway_edge_cases(ctx, O, L):
     assert np.array_equal(ctx.union(mix5), O.union(mix5))
     assert np.array_equal(ctx.union(mix5[:3]), O.union(mix5[:3]))
     assert np.array_equal(ctx.merge_k([five[0], five[1], five[2]], mode=L.UNIQUE), O.union(five[:3]))
+    # k-way merge / common with an unsorted stream: the optimistic merge tree reports it and the call falls
+    # back to concatenate + sort
+    um = [five[0], rng.permutation(five[1]), five[2]]
+    assert np.array_equal(ctx.merge_k(um, mode=L.PLAIN), np.sort(np.concatenate(um)))
+    assert np.array_equal(ctx.merge_k(um, mode=L.REPEATED), O.merge_k([five[0], np.sort(five[1]), five[2]], mode=O.REPEATED))
+    assert np.array_equal(ctx.common(um, 2), O.common(um, 2))
     # inter: an empty LATER file stops the fold and keeps the running result (inter.go:211-217)
     assert np.array_equal(ctx.inter([files[0], files[1], e, files[2]]), O.inter([files[0], files[1], e, files[2]]))
     assert np.array_equal(ctx.inter([files[0], files[1], e, files[2]]), np.intersect1d(files[0], files[1]))

@@ -219,12 +219,8 @@ int tree_reduce(ukm_ctx *ctx, std::vector<Stream> ss, int op, u32 flags, bool ta
 int merged_sequence(ukm_ctx *ctx, const std::vector<Stream> &all, bool tax, u64 **k, u32 **t, u64 *total) {
     std::vector<Stream> ss;
     u64 n = 0;
-    bool all_sorted = true;
     for (auto &s : all)
         if (s.n) {
-            bool sorted = true, strict = true;
-            UKM_TRY(ukm_dev_check_sorted(ctx, s.k, s.n, &sorted, &strict));
-            all_sorted = all_sorted && sorted;
             ss.push_back(s);
             n += s.n;
         }
@@ -232,14 +228,24 @@ int merged_sequence(ukm_ctx *ctx, const std::vector<Stream> &all, bool tax, u64 
     *k = nullptr;
     *t = nullptr;
     if (n == 0) return UKM_OK;
-    if (all_sorted && ss.size() > 1) {
+    bool need_sort = false;
+    if (ss.size() > 1) {
+        // optimistic: the merges check the order of what they read; an unsorted stream makes the tree fail
+        // with UKM_ERR_UNSORTED and the whole input takes the concatenate + sort route instead
         UKM_TRY(ws_alloc_t(ctx, n + 1, k));
         if (tax) UKM_TRY(ws_alloc_t(ctx, n + 1, t));
         u64 nm = 0;
-        return tree_reduce(ctx, ss, UKM_OP_MERGE_INTERNAL, 0, tax, *k, *t, n, &nm);
+        const int r = tree_reduce(ctx, ss, UKM_OP_MERGE_INTERNAL, 0, tax, *k, *t, n, &nm);
+        if (r == UKM_OK) return UKM_OK;
+        if (r != UKM_ERR_UNSORTED) return r;
+        need_sort = true;
+    } else {
+        bool sorted = true, strict = true;
+        UKM_TRY(ukm_dev_check_sorted(ctx, ss[0].k, ss[0].n, &sorted, &strict));
+        need_sort = !sorted;
     }
     UKM_TRY(concat_streams(ctx, ss, tax, k, t, total));
-    if (!all_sorted) UKM_TRY(ukm_dev_sort(ctx, *k, *t, n, 64));
+    if (need_sort) UKM_TRY(ukm_dev_sort(ctx, *k, *t, n, 64));
     return UKM_OK;
 }
 
