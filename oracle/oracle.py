@@ -231,7 +231,7 @@ def _streams(keys_list, taxids_list):
     lens = np.array([len(k) for k in ks], dtype=np.uint64)
     ts, tp = None, None
     if taxids_list is not None:
-        ts = [np.ascontiguousarray(t, dtype=np.uint32) for t in taxids_list]
+        ts = [None if t is None else np.ascontiguousarray(t, dtype=np.uint32) for t in taxids_list]  # None -> NULL (stream without taxids)
         tp = (_u32p * n)(*[_p(t, _u32p) for t in ts])
     return ks, ts, kp, tp, lens
 

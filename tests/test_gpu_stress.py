@@ -1,0 +1,170 @@
+"""Seeded randomised parity sweep on the GPU: many small / medium shapes around the tile geometry
+(tile = 9728 merged items, 6144 with taxids or ranks), with duplicates, empty sides, taxids on
+one or both sides and all three operations, each compared bit-exactly with the CPU oracle."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from conftest import synth_tree  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def env():
+    from oracle import oracle as O
+    from unikmer_amd import lib as L
+    ctx = L.Context(0)
+    child, parent = synth_tree(5, 4)
+    ctx.taxonomy_load(child, parent)
+    tax = O.Taxonomy(child, parent)
+    return O, L, ctx, tax, len(child)
+
+
+def _draw(rng, n, universe, dup_rate):
+    if n == 0:
+        return np.empty(0, np.uint64)
+    a = np.sort(rng.choice(universe, size=n, replace=False)) if n <= len(universe) else np.sort(rng.choice(universe, size=n))
+    if dup_rate > 0 and n > 1:
+        m = rng.random(n) < dup_rate
+        a[1:][m[1:]] = a[:-1][m[1:]]          # copy the left neighbour: runs of equal codes
+        a = np.sort(a)
+    return a.astype(np.uint64)
+
+
+SIZES = [0, 1, 2, 63, 64, 65, 511, 512, 6143, 6144, 6145, 9727, 9728, 9729, 19456, 30000, 100_000]
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_random_setops_plain_and_multiset(env, seed):
+    O, L, ctx, tax, T = env
+    rng = np.random.default_rng(1000 + seed)
+    for it in range(40):
+        na, nb = int(rng.choice(SIZES)), int(rng.choice(SIZES))
+        span = max(4, int((na + nb) * rng.choice([0.6, 1.0, 3.0, 50.0])))
+        universe = np.sort(rng.choice(1 << 40, size=span, replace=False)).astype(np.uint64) if span < (1 << 20) else \
+            rng.integers(0, 1 << 62, span, dtype=np.uint64)
+        universe = np.unique(universe)
+        dup = float(rng.choice([0.0, 0.0, 0.02, 0.3]))
+        a = _draw(rng, min(na, len(universe)), universe, dup)
+        b = _draw(rng, min(nb, len(universe)), universe, dup)
+        for op, ref in ((L.OP_UNION, O.union), (L.OP_INTER, O.inter), (L.OP_DIFF, O.diff)):
+            if op == L.OP_INTER and len(b) == 0 and len(a):
+                continue                       # the reference keeps the running result (quirk covered elsewhere)
+            got = ctx.setop2(op, a, b)
+            exp = ref([a, b])
+            exp = np.sort(exp) if op == L.OP_UNION else exp
+            assert np.array_equal(got, exp), (seed, it, op, na, nb, dup)
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_random_setops_with_taxids(env, seed):
+    O, L, ctx, tax, T = env
+    rng = np.random.default_rng(2000 + seed)
+    for it in range(25):
+        na, nb = int(rng.choice(SIZES[:-1])), int(rng.choice(SIZES[:-1]))
+        universe = np.unique(rng.integers(0, 1 << 44, max(8, int((na + nb) * rng.choice([0.7, 2.0]))), dtype=np.uint64))
+        a = _draw(rng, min(na, len(universe)), universe, 0.0)
+        b = _draw(rng, min(nb, len(universe)), universe, 0.0)
+        ta = rng.integers(0, T + 1, len(a)).astype(np.uint32)       # includes taxid 0
+        tb = rng.integers(0, T + 1, len(b)).astype(np.uint32)
+        which = int(rng.integers(0, 3))                              # both / only A / only B carry taxids
+        xa, xb = (ta, tb) if which == 0 else ((ta, None) if which == 1 else (None, tb))
+        # union / inter (mix-taxid when one side has none)
+        gk, gt = ctx.setop2(L.OP_UNION, a, b, xa, xb)
+        za = xa if xa is not None else np.zeros(len(a), np.uint32)   # a stream without taxids counts as taxid 0
+        zb = xb if xb is not None else np.zeros(len(b), np.uint32)
+        ek, et = O.union([a, b], [za, zb], tax)
+        o = np.argsort(ek, kind="stable")
+        assert np.array_equal(gk, ek[o]) and np.array_equal(gt, et[o]), (seed, it, "union", which)
+        if len(b) or not len(a):
+            mix = which != 0
+            gk, gt = ctx.setop2(L.OP_INTER, a, b, xa, xb, flags=L.F_MIX_TAXID if mix else 0)
+            ek, et = O.inter([a, b], [xa, xb], tax, mix_taxid=mix)
+            assert np.array_equal(gk, ek) and np.array_equal(gt, et), (seed, it, "inter", which)
+        if which == 0:
+            gk, gt = ctx.setop2(L.OP_DIFF, a, b, ta, tb, flags=L.F_CMP_TAXID)
+            ek, et = O.diff([a, b], [ta, tb], tax, compare_taxid=True)
+            assert np.array_equal(gk, ek) and np.array_equal(gt, et), (seed, it, "diff -t")
+
+
+@pytest.mark.parametrize("seed", range(3))
+def test_random_sort_scan_nway(env, seed):
+    O, L, ctx, tax, T = env
+    rng = np.random.default_rng(3000 + seed)
+    for it in range(12):
+        n = int(rng.choice([0, 1, 2, 100, 7167, 7168, 7169, 11264, 11265, 50_000, 200_000]))
+        bits = int(rng.choice([8, 20, 42, 62, 64]))
+        x = rng.integers(0, 1 << bits, n, dtype=np.uint64) if bits < 64 else rng.integers(0, 1 << 64, n, dtype=np.uint64)
+        assert np.array_equal(ctx.sort_u64(x.copy(), bits), np.sort(x)), (seed, it, n, bits)
+        v = rng.integers(0, T + 1, n).astype(np.uint32)
+        k2, v2 = ctx.sort_pairs(x.copy(), v.copy(), bits)
+        o = np.argsort(x, kind="stable")
+        assert np.array_equal(k2, x[o]) and np.array_equal(v2, v[o]), (seed, it, "pairs")
+        srt = x[o]
+        for mode in (L.UNIQUE, L.REPEATED, L.SINGLETON, L.REPEATED_CHUNK, L.PLAIN):
+            assert np.array_equal(ctx.unique(srt, mode=mode), O.unique(srt, mode=mode)), (seed, it, "unique", mode)
+        if n:
+            gk, gt = ctx.unique(srt, v2, mode=L.UNIQUE)
+            ek, et = O.unique(srt, v2, mode=O.UNIQUE, tax=tax)
+            assert np.array_equal(gk, ek) and np.array_equal(gt, et), (seed, it, "unique+lca")
+    for it in range(6):
+        nf = int(rng.integers(1, 9))
+        files = []
+        for f in range(nf):
+            m = int(rng.choice([0, 1, 500, 9728, 20_000]))
+            files.append(np.unique(rng.integers(0, 60_000, m).astype(np.uint64)))
+        assert np.array_equal(ctx.union(files), np.sort(O.union(files))), (seed, it, "union", nf)
+        assert np.array_equal(ctx.merge_k(files, mode=L.PLAIN), O.merge_k(files, mode=O.PLAIN)), (seed, it, "merge")
+        assert np.array_equal(ctx.merge_k(files, mode=L.REPEATED), O.merge_k(files, mode=O.REPEATED))
+        assert np.array_equal(ctx.merge_k(files, mode=L.REPEATED, final_round=False), O.merge_k(files, mode=O.REPEATED, final_round=False))
+        thr = int(rng.integers(1, nf + 1))
+        assert np.array_equal(ctx.common(files, thr), O.common(files, thr)), (seed, it, "common", thr)
+        if len(files[0]):
+            assert np.array_equal(ctx.diff(files), O.diff(files)), (seed, it, "diff")
+        if all(len(f) for f in files):
+            assert np.array_equal(ctx.inter(files), O.inter(files)), (seed, it, "inter")
+
+
+@pytest.mark.parametrize("seed", range(3))
+def test_random_windows(env, seed):
+    """encode / ntHash / Scaled filter / minimizer over random ragged record layouts (empty records, records
+    shorter than k, records across tile borders of 2048 windows, IUPAC and lower-case bases, circular)."""
+    O, L, ctx, tax, T = env
+    rng = np.random.default_rng(4000 + seed)
+    alphabet = np.frombuffer(b"ACGTACGTACGTACGTacgtNRYKMn", dtype=np.uint8)
+    for it in range(10):
+        nrec = int(rng.choice([1, 2, 7, 40, 300]))
+        lens = rng.choice([0, 1, 5, 31, 32, 150, 151, 2047, 2048, 2049, 5000], size=nrec)
+        cuts = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+        bases = alphabet[rng.integers(0, len(alphabet), int(cuts[-1]))]
+        k = int(rng.choice([1, 5, 21, 31, 32]))
+        circ = bool(rng.integers(0, 2))
+        canon = bool(rng.integers(0, 2))
+        if cuts[-1] == 0:
+            continue
+        assert np.array_equal(ctx.encode_kmers(bases, cuts, k, canonical=canon, circular=circ),
+                              O.count_windows(bases, cuts, k, canonical=canon, circular=circ)), (seed, it, "encode", k, circ)
+        kh = int(rng.choice([1, 16, 31, 51, 64]))
+        assert np.array_equal(ctx.nthash(bases, cuts, kh, canonical=canon, circular=circ),
+                              O.count_windows(bases, cuts, kh, hashed=True, canonical=canon, circular=circ)), (seed, it, "nthash", kh)
+        mh = O.max_hash(int(rng.choice([2, 7, 100])))
+        assert np.array_equal(ctx.nthash(bases, cuts, kh, canonical=True, circular=circ, max_hash=mh),
+                              O.count_windows(bases, cuts, kh, hashed=True, canonical=True, circular=circ, max_hash=mh)), (seed, it, "scaled")
+        w = int(rng.choice([1, 3, 15, 100]))
+        hs, ps = [], []
+        for r in range(nrec):
+            seq = bases[int(cuts[r]):int(cuts[r + 1])]
+            try:
+                h, p = O.minimizer(seq, kh, w, circular=circ)
+            except ValueError:
+                continue
+            hs.append(h); ps.append(p)
+        eh = np.concatenate(hs) if hs else np.empty(0, np.uint64)
+        ep = np.concatenate(ps) if ps else np.empty(0, np.uint64)
+        gh, gp = ctx.minimizer(bases, cuts, kh, w, circular=circ, with_pos=True)
+        assert np.array_equal(gh, eh) and np.array_equal(gp, ep), (seed, it, "minimizer", kh, w, circ)

@@ -834,6 +834,9 @@ extern "C" int ukm_setop2(ukm_ctx *ctx, int op, const uint64_t *a_keys, const ui
         UKM_TRY(ukm_out_t(ctx, out_taxids, out_cap, &tout));
         int r = ukm_dev_setop2(ctx, op, a, ta, na, b, tb, nb, flags, out, tout, out_cap, n_out);
         u64 n = (r == UKM_OK) ? *n_out : 0;
+        // the caller asked for taxids but no record carries one (e.g. the only stream with taxids is
+        // empty): records without a taxid have taxid 0
+        if (r == UKM_OK && tout && !ta && !tb && n) UKM_HIP(hipMemsetAsync(tout, 0, n * sizeof(u32), ctx->stream));
         ukm_out_resize(ctx, out_keys, n * sizeof(u64));
         if (out_taxids) ukm_out_resize(ctx, out_taxids, n * sizeof(u32));
         return r;
