@@ -168,3 +168,53 @@ def test_random_windows(env, seed):
         ep = np.concatenate(ps) if ps else np.empty(0, np.uint64)
         gh, gp = ctx.minimizer(bases, cuts, kh, w, circular=circ, with_pos=True)
         assert np.array_equal(gh, eh) and np.array_equal(gp, ep), (seed, it, "minimizer", kh, w, circ)
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_random_nway_with_taxids(env, seed):
+    """n-way union / inter (-m) / diff (-t) / common / merge (-u, -d, chunk rounds) with per-record taxids,
+    some files without taxids (mix), taxid 0 records, empty files in the middle."""
+    O, L, ctx, tax, T = env
+    rng = np.random.default_rng(5000 + seed)
+    for it in range(10):
+        nf = int(rng.integers(2, 7))
+        files, taxs = [], []
+        for f in range(nf):
+            m = int(rng.choice([0, 3, 700, 6144, 6145, 15_000])) if f else int(rng.choice([700, 6144, 15_000]))
+            k = np.unique(rng.integers(0, 40_000, m).astype(np.uint64))
+            files.append(k)
+            taxs.append(rng.integers(0, T + 1, len(k)).astype(np.uint32))
+        # all files with taxids
+        gk, gt = ctx.union(files, taxs)
+        ek, et = O.union(files, taxs, tax)
+        o = np.argsort(ek, kind="stable")
+        assert np.array_equal(gk, ek[o]) and np.array_equal(gt, et[o]), (seed, it, "union")
+        for mode, om in ((L.UNIQUE, O.UNIQUE), (L.REPEATED, O.REPEATED), (L.PLAIN, O.PLAIN)):
+            for fr in (True, False):
+                gk, gt = ctx.merge_k(files, taxs, mode=mode, final_round=fr)
+                ek, et = O.merge_k(files, taxs, mode=om, final_round=fr, tax=tax)
+                assert np.array_equal(gk, ek), (seed, it, "merge keys", mode, fr)
+                if mode != L.PLAIN:   # plain keeps every record: the order of equal codes' taxids is the stream order
+                    assert np.array_equal(gt, et), (seed, it, "merge taxids", mode, fr)
+                else:
+                    assert np.array_equal(np.sort(gt), np.sort(et))
+        thr = int(rng.integers(1, nf + 1))
+        gk, gt = ctx.common(files, thr, taxs)
+        ek, et = O.common(files, thr, taxs, tax)
+        assert np.array_equal(gk, ek) and np.array_equal(gt, et), (seed, it, "common", thr)
+        gk, gt = ctx.diff(files, taxs, compare_taxid=True)
+        ek, et = O.diff(files, taxs, tax, compare_taxid=True)
+        assert np.array_equal(gk, ek) and np.array_equal(gt, et), (seed, it, "diff -t")
+        gk, gt = ctx.diff(files, taxs)
+        ek, et = O.diff(files, taxs, tax)
+        assert np.array_equal(gk, ek) and np.array_equal(gt, et), (seed, it, "diff")
+        if all(len(f) for f in files):
+            gk, gt = ctx.inter(files, taxs)
+            ek, et = O.inter(files, taxs, tax)
+            assert np.array_equal(gk, ek) and np.array_equal(gt, et), (seed, it, "inter")
+            # mix: drop the taxids of one later file
+            drop = int(rng.integers(1, nf))
+            mixed = [t if i != drop else None for i, t in enumerate(taxs)]
+            gk, gt = ctx.inter(files, mixed, mix_taxid=True)
+            ek, et = O.inter(files, mixed, tax, mix_taxid=True)
+            assert np.array_equal(gk, ek) and np.array_equal(gt, et), (seed, it, "inter -m", drop)
