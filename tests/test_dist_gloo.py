@@ -93,3 +93,84 @@ def test_splitters_and_counts():
     s64 = ud.prefix_splitters(64, 4)
     assert s64[-1] == (1 << 64) - 1 and s64[1] == 1 << 62
     assert ud.cuts_to_counts([0, 3, 3, 10], 12) == [3, 0, 7, 2]
+
+
+class _NumpyCtx:
+    """Stand-in for unikmer_amd.lib.Context in the CPU tests of the distributed plumbing: the four calls
+    dist.sharded_sort / sharded_count make, on torch CPU tensors (test infrastructure only; on the GPU the
+    same calls go to libunikmer_hip.so)."""
+
+    @staticmethod
+    def _u(t):
+        return t.numpy().view(np.uint64)
+
+    def sort_u64(self, keys, key_bits=64):
+        keys.copy_(torch.from_numpy(np.sort(self._u(keys)).view(np.int64)))
+        return keys
+
+    def sort_pairs(self, keys, vals, key_bits=64):
+        o = np.argsort(self._u(keys), kind="stable")
+        k2, v2 = self._u(keys)[o].copy(), vals.numpy()[o].copy()
+        keys.copy_(torch.from_numpy(k2.view(np.int64)))
+        vals.copy_(torch.from_numpy(v2))
+        return keys, vals
+
+    def partition_points(self, keys, splitters):
+        return np.searchsorted(self._u(keys), np.array(splitters, dtype=np.uint64), side="left")
+
+    def merge_k(self, pieces, tpieces=None):
+        cat = np.concatenate([self._u(p) for p in pieces]) if pieces else np.empty(0, np.uint64)
+        o = np.argsort(cat, kind="stable")
+        k = torch.from_numpy(cat[o].view(np.int64))
+        if tpieces is None:
+            return k
+        t = np.concatenate([p.numpy() for p in tpieces])[o]
+        return k, torch.from_numpy(t)
+
+    def unique(self, keys, taxids=None, mode=1):
+        assert taxids is None and mode == 1
+        return torch.from_numpy(np.unique(self._u(keys)).view(np.int64))
+
+
+def _sort_worker(rank, world, port, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        rng = np.random.default_rng(77 + rank)
+        x = rng.integers(0, 1 << 42, 30000 + 1000 * rank, dtype=np.uint64)
+        x[:500] = x[500:1000]                                  # duplicates, also across ranks below
+        if rank == 1:
+            x[1000:1500] = np.random.default_rng(77).integers(0, 1 << 42, 30000, dtype=np.uint64)[1000:1500]
+        keys = torch.from_numpy(x.copy().view(np.int64))
+        tax = torch.arange(len(x), dtype=torch.int32) + 1000000 * rank
+        ctx = _NumpyCtx()
+        sk, st = ud.sharded_sort(ctx, keys.clone(), 42, tax.clone())
+        su = ud.sharded_count(ctx, keys.clone(), 42)
+        ret[rank] = (x, sk.numpy().view(np.uint64).copy(), st.numpy().copy(), su.numpy().view(np.uint64).copy())
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_sort_and_count_world2():
+    world = 2
+    port = _free_port()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_sort_worker, args=(world, port, ret), nprocs=world, join=True)
+    allx = np.concatenate([ret[r][0] for r in range(world)])
+    gk = np.concatenate([ret[r][1] for r in range(world)])
+    gt = np.concatenate([ret[r][2] for r in range(world)])
+    assert np.array_equal(gk, np.sort(allx))                  # concatenation in rank order = global sort
+    # every payload still sits next to its key: taxid encodes (rank, position)
+    src = gt // 1000000
+    pos = gt % 1000000
+    assert all(np.array_equal(ret[r][0][pos[src == r]], gk[src == r]) for r in range(world))
+    # equal codes keep rank order (stable w.r.t. ranks)
+    same = gk[1:] == gk[:-1]
+    assert np.all(src[1:][same] >= src[:-1][same])
+    assert np.array_equal(np.concatenate([ret[r][3] for r in range(world)]), np.unique(allx))
+    spl = ud.prefix_splitters(42, world)
+    for r in range(world):
+        v = ret[r][1]
+        assert np.all(v >= np.uint64(spl[r])) and (r == world - 1 or np.all(v < np.uint64(spl[r + 1])))

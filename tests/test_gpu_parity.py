@@ -564,6 +564,15 @@ def test_sharded_setop_over_rccl_world1(ctx, O, L):
             got = ud.sharded_setop(dctx, op, dfiles, 42)
             got = got[0] if isinstance(got, tuple) else got
             assert np.array_equal(got.cpu().numpy().view(np.uint64), np.sort(ref(files)))
+        # the count path: unsorted codes -> distributed sort / distinct set
+        x = rng.integers(0, 1 << 42, 200_000, dtype=np.uint64)
+        x[:1000] = x[1000:2000]
+        dk = torch.from_numpy(x.copy().view(np.int64)).to(dev)
+        assert np.array_equal(ud.sharded_sort(dctx, dk.clone(), 42).cpu().numpy().view(np.uint64), np.sort(x))
+        assert np.array_equal(ud.sharded_count(dctx, dk.clone(), 42).cpu().numpy().view(np.uint64), np.unique(x))
+        tv = torch.arange(len(x), dtype=torch.int32, device=dev)
+        sk, st = ud.sharded_sort(dctx, dk.clone(), 42, tv.clone())
+        assert np.array_equal(x[st.cpu().numpy()], sk.cpu().numpy().view(np.uint64))
     finally:
         dist.destroy_process_group()
 

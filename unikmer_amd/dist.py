@@ -99,3 +99,36 @@ def sharded_setop(ctx, op, files_keys, key_bits, files_taxids=None, group=None, 
     if op == "common":
         return fn(local, kw["threshold"], local_t)
     return fn(local, local_t)
+
+
+def sharded_sort(ctx, keys, key_bits, taxids=None, group=None):
+    """Distributed `sort` of UNSORTED codes that are spread over the ranks in any way (the count path:
+    every rank encoded its own reads).  Each rank sorts what it holds, cuts the sorted stream at the
+    prefix splitters, one all-to-all-v moves slice g to rank g, and the received sorted slices (one per
+    source rank, all inside this rank's value range) are combined by the k-way merge.  Returns this
+    rank's range, sorted; the concatenation over ranks in rank order is the global sort.  Records with
+    equal codes keep (source rank, local position) order, i.e. the sort is stable w.r.t. rank order.
+
+    keys: 1-D int64 device tensor (uint64 bit patterns), modified in place by the local sort.
+    """
+    world = dist.get_world_size(group)
+    if taxids is not None:
+        ctx.sort_pairs(keys, taxids, key_bits)
+    else:
+        ctx.sort_u64(keys, key_bits)
+    spl = prefix_splitters(key_bits, world)[:-1]
+    cuts = ctx.partition_points(keys, spl)
+    counts = cuts_to_counts(cuts, keys.numel())
+    rk, rt, rc = exchange_sorted(keys, counts, taxids, group)
+    pieces = split_by_counts(rk, rc)
+    tpieces = split_by_counts(rt, rc) if rt is not None else None
+    return ctx.merge_k(pieces, tpieces)          # PLAIN: every record kept
+
+
+def sharded_count(ctx, keys, key_bits, mode=1, taxids=None, group=None):
+    """`count` after the per-rank encode: distinct codes (mode 1 = UNIQUE; 2 = repeated, 4 = singleton as
+    in include/unikmer_hip.h) of everything all ranks hold, range-partitioned by prefix."""
+    merged = sharded_sort(ctx, keys, key_bits, taxids, group)
+    if taxids is not None:
+        return ctx.unique(merged[0], merged[1], mode=mode)
+    return ctx.unique(merged, mode=mode)
