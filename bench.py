@@ -281,10 +281,13 @@ def main():
                 traffic = None
         roofline = {"bound": "hbm", "kernel": "setop_tile_kernel<UNION>", "achieved": bytes_u / ku / 1e9,
                     "peak": peak, "unit": "GB/s", "frac": bytes_u / ku / 1e9 / peak, "traffic": traffic,
-                    "algorithmic_bytes": bytes_u, "kernel_ms": ku * 1e3}
+                    "algorithmic_bytes": bytes_u, "kernel_ms": ku * 1e3,
+                    # SURVEY §8(d) also asks for the read side alone (8(|A|+|B|) bytes over the same time)
+                    "read_only_achieved": 8 * (na + nb) / ku / 1e9, "read_only_frac": 8 * (na + nb) / ku / 1e9 / peak}
         roofline_inter = {"bound": "hbm", "kernel": "setop_tile_kernel<INTER>", "achieved": bytes_i / ki / 1e9,
                           "peak": peak, "unit": "GB/s", "frac": bytes_i / ki / 1e9 / peak,
-                          "algorithmic_bytes": bytes_i, "kernel_ms": ki * 1e3}
+                          "algorithmic_bytes": bytes_i, "kernel_ms": ki * 1e3,
+                          "read_only_achieved": 8 * (na + nb) / ki / 1e9, "read_only_frac": 8 * (na + nb) / ki / 1e9 / peak}
         cpu = None
         if world == 1 and args.cpu_sample > 0:
             cpu = cpu_baseline((4 * int(args.cpu_sample) + 2) // 3, 32)
