@@ -62,8 +62,6 @@ extern "C" {
 /* flags */
 #define UKM_F_MIX_TAXID 2u   /* inter --mix-taxid, inter.go:229-236 */
 #define UKM_F_CMP_TAXID 4u   /* diff -t/--compare-taxid, diff.go:361-362,406-407 */
-#define UKM_F_ASSUME_SET 8u  /* caller guarantees strictly increasing inputs (skips nothing;
-                                duplicates are still detected and handled) */
 
 typedef struct ukm_ctx ukm_ctx;
 

@@ -18,7 +18,7 @@ ERR_INVALID, ERR_HIP, ERR_NOMEM, ERR_ILLEGAL_BASE = -1, -2, -3, -4
 ERR_UNSORTED, ERR_NO_TAXONOMY, ERR_CAPACITY, ERR_K = -5, -6, -7, -8
 PLAIN, UNIQUE, REPEATED, REPEATED_CHUNK, SINGLETON = 0, 1, 2, 3, 4
 OP_UNION, OP_INTER, OP_DIFF = 0, 1, 2
-F_MIX_TAXID, F_CMP_TAXID, F_ASSUME_SET = 2, 4, 8
+F_MIX_TAXID, F_CMP_TAXID = 2, 4
 
 # every symbol include/unikmer_hip.h declares (checked by tests/test_abi.py)
 SYMBOLS = [
