@@ -130,7 +130,9 @@ uint64_t ukm_max_hash(uint64_t scale);
 /* ---- sorts: replace sortutil.Uint64s (count.go:581, union.go:274,295, sort.go:463 ...) and
  *      sorts.Quicksort(CodeTaxidSlice) (sort.go:268,331,457).  In place, ascending by code;
  *      pairs are sorted by code only, stably.  key_bits = number of significant low bits
- *      (2k for k-mer codes, 0 or 64 for hashes): higher radix passes are skipped. */
+ *      (2k for k-mer codes, 0 or 64 for hashes): higher radix passes are skipped.
+ *      n < 2^32 records per call; larger inputs: sort chunks and combine them with ukm_merge_k
+ *      (the reference's own `sort -m` protocol). */
 int ukm_sort_u64(ukm_ctx *ctx, uint64_t *keys, uint64_t n, int key_bits);
 int ukm_sort_pairs(ukm_ctx *ctx, uint64_t *keys, uint32_t *taxids, uint64_t n, int key_bits);
 
@@ -140,8 +142,10 @@ int ukm_unique(ukm_ctx *ctx, const uint64_t *keys, const uint32_t *taxids, uint6
                int mode, uint64_t *out_keys, uint32_t *out_taxids, uint64_t out_cap,
                uint64_t *n_out);
 
-/* ---- k-way merge: replaces mergeChunksFile (util-sort.go:227-606).  Streams must be
- *      sorted.  mode/final_round as the reference's unique/repeated/finalRound arguments. */
+/* ---- k-way merge: replaces mergeChunksFile (util-sort.go:227-606).  Streams are expected
+ *      to be sorted (chunk files); an unsorted one is tolerated (the call then sorts the
+ *      concatenation instead of merging).  mode/final_round as the reference's
+ *      unique/repeated/finalRound arguments; equal codes keep stream order. */
 int ukm_merge_k(ukm_ctx *ctx, const uint64_t *const *keys, const uint32_t *const *taxids,
                 const uint64_t *lens, int nstreams, int mode, int final_round,
                 uint64_t *out_keys, uint32_t *out_taxids, uint64_t out_cap, uint64_t *n_out);
