@@ -131,8 +131,8 @@ uint64_t ukm_max_hash(uint64_t scale);
  *      sorts.Quicksort(CodeTaxidSlice) (sort.go:268,331,457).  In place, ascending by code;
  *      pairs are sorted by code only, stably.  key_bits = number of significant low bits
  *      (2k for k-mer codes, 0 or 64 for hashes): higher radix passes are skipped.
- *      n < 2^32 records per call; larger inputs: sort chunks and combine them with ukm_merge_k
- *      (the reference's own `sort -m` protocol). */
+ *      Inputs of 2^32 records or more are sorted as 2^31-record chunks and merged on the
+ *      device (the reference's own `sort -m` protocol, in HBM). */
 int ukm_sort_u64(ukm_ctx *ctx, uint64_t *keys, uint64_t n, int key_bits);
 int ukm_sort_pairs(ukm_ctx *ctx, uint64_t *keys, uint32_t *taxids, uint64_t n, int key_bits);
 

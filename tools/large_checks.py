@@ -50,3 +50,18 @@ ni = I.numel(); xi = xor_all(I); si = bool((I[1:] > I[:-1]).all())
 assert nu + ni == na + nb and su and si
 assert xu == xor_all(A) ^ xor_all(B) ^ xi
 print("setop |A|+|B|=%d ok: union %d inter %d" % (na + nb, nu, ni))
+# 3. sort of more than 2^32 records (chunk sort + device merge)
+del A, B, out, U, I
+torch.cuda.empty_cache()
+n = (1 << 32) + 123_456_789
+g = torch.Generator(device=dev); g.manual_seed(9)
+K = torch.randint(0, 1 << 62, (n,), dtype=torch.int64, device=dev, generator=g)
+x0 = xor_all(K)
+ctx.sort_u64(K, 62)
+ok = True
+step = 1 << 30
+for lo in range(0, n - 1, step):                          # sortedness in slices (bounds torch temporaries)
+    hi = min(n, lo + step + 1)
+    ok = ok and bool((K[lo + 1:hi] >= K[lo:hi - 1]).all())
+assert ok and xor_all(K) == x0, "sort of > 2^32 keys failed"
+print("sort n=%d ok (%.1f ms, %.2e keys/s)" % (n, ctx.last_call_ms(), n / ctx.last_call_ms() * 1e3))

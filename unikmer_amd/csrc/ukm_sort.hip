@@ -361,9 +361,49 @@ int run_passes(ukm_ctx *c, u64 *keys, u32 *vals, u64 *tk, u32 *tv, u64 n, int np
 int ukm_dev_sort(ukm_ctx *c, u64 *keys, u32 *vals, u64 n, int key_bits) {
     if (n < 2) return UKM_OK;
     if (key_bits <= 0 || key_bits > 64) key_bits = 64;
-    if (n >= (1ull << 32))
-        UKM_FAIL(UKM_ERR_INVALID, "ukm_sort: n = %llu exceeds 2^32-1 records per call; sort chunks and "
-                 "combine them with ukm_merge_k (the reference's `sort -m` protocol)", (unsigned long long)n);
+    if (n >= (1ull << 32)) {
+        // The onesweep tile / status arithmetic is 32-bit: larger inputs are sorted as chunks of 2^31 records
+        // and combined by the keep-everything 2-way merge (pairwise tree, ping-pong between the input and a
+        // scratch copy) -- the reference's `sort -m` protocol, in HBM.
+        const u64 CH = 1ull << 31;
+        const u64 nch = (n + CH - 1) / CH;
+        for (u64 i = 0; i < nch; i++) {
+            const u64 m = std::min<u64>(CH, n - i * CH);
+            WsMark mark = ws_mark(c);
+            UKM_TRY(ukm_dev_sort(c, keys + i * CH, vals ? vals + i * CH : nullptr, m, key_bits));
+            ws_release(c, mark);
+        }
+        u64 *tk = nullptr;
+        u32 *tv = nullptr;
+        UKM_TRY(ws_alloc_t(c, n, &tk));
+        if (vals) UKM_TRY(ws_alloc_t(c, n, &tv));
+        u64 *src_k = keys, *dst_k = tk;
+        u32 *src_v = vals, *dst_v = tv;
+        for (u64 run = CH; run < n; run *= 2) {  // runs of `run` records are sorted; merge neighbours
+            for (u64 lo = 0; lo < n; lo += 2 * run) {
+                const u64 na = std::min<u64>(run, n - lo);
+                const u64 nb = (lo + run < n) ? std::min<u64>(run, n - lo - run) : 0;
+                if (nb == 0) {
+                    UKM_HIP(hipMemcpyAsync(dst_k + lo, src_k + lo, na * sizeof(u64), hipMemcpyDeviceToDevice, c->stream));
+                    if (vals) UKM_HIP(hipMemcpyAsync(dst_v + lo, src_v + lo, na * sizeof(u32), hipMemcpyDeviceToDevice, c->stream));
+                    continue;
+                }
+                u64 nm = 0;
+                WsMark mark = ws_mark(c);
+                UKM_TRY(ukm_dev_setop2(c, UKM_OP_MERGE_INTERNAL, src_k + lo, vals ? src_v + lo : nullptr, na, src_k + lo + run,
+                                       vals ? src_v + lo + run : nullptr, nb, 0, dst_k + lo, vals ? dst_v + lo : nullptr,
+                                       na + nb, &nm));
+                ws_release(c, mark);
+            }
+            std::swap(src_k, dst_k);
+            std::swap(src_v, dst_v);
+        }
+        if (src_k != keys) {
+            UKM_HIP(hipMemcpyAsync(keys, src_k, n * sizeof(u64), hipMemcpyDeviceToDevice, c->stream));
+            if (vals) UKM_HIP(hipMemcpyAsync(vals, src_v, n * sizeof(u32), hipMemcpyDeviceToDevice, c->stream));
+        }
+        return UKM_OK;
+    }
     const int passes = (key_bits + 7) / 8;
 
     u64 *ghist = nullptr;
