@@ -35,7 +35,12 @@ namespace {
 #define SORT_VT_PAIRS 11
 #endif
 constexpr int NT = 256;  // histogram kernel
-constexpr int RADIX = 256;
+#ifndef SORT_RADIX_BITS
+#define SORT_RADIX_BITS 8
+#endif
+constexpr int RB = SORT_RADIX_BITS;  // digit width: 8 -> 8 passes for 62..64 bits; 9 -> 7 passes for k=31 codes (62 bits), 5 for k=21
+constexpr int RADIX = 1 << RB;
+constexpr u32 DMASK = RADIX - 1;
 constexpr int MAX_PASSES = 8;
 
 // ---- histogram of all digits -------------------------------------------------------------------
@@ -61,7 +66,7 @@ __global__ __launch_bounds__(NT) void radix_hist_kernel(const u64 *k, u64 n, int
         for (int u = 0; u < U; u++) {
             const u64 vm = __ballot(valid[u]);
             for (int p = 0; p < passes; p++) {
-                const u32 d = (u32)(key[u] >> (8 * p)) & 255u;
+                const u32 d = (u32)(key[u] >> (RB * p)) & DMASK;
                 const u32 d0 = __builtin_amdgcn_readfirstlane(d);
                 if (vm == ~0ull && __all(d == d0)) {
                     if (lane_id() == 0) atomicAdd(&s_h[p * RADIX + d0], 64u);
@@ -119,37 +124,48 @@ __device__ __forceinline__ void match_any8(u32 d, u32 &plo, u32 &phi) {
         "v_bfe_i32 %3, %5, 1, 1\n\t"
         "v_bfe_i32 %4, %5, 2, 1\n\t"
         "v_cmp_ne_u32_e64 vcc, 0, %2\n\t"
-        "v_cmp_ne_u32_e64 s[98:99], 0, %3\n\t"
-        "v_cmp_ne_u32_e64 s[100:101], 0, %4\n\t"
+        "v_cmp_ne_u32_e64 s[80:81], 0, %3\n\t"
+        "v_cmp_ne_u32_e64 s[82:83], 0, %4\n\t"
         "v_bitop3_b32 %0, %0, vcc_lo, %2 bitop3:0x90\n\t"
         "v_bitop3_b32 %1, %1, vcc_hi, %2 bitop3:0x90\n\t"
         "v_bfe_i32 %2, %5, 3, 1\n\t"
         "v_cmp_ne_u32_e64 vcc, 0, %2\n\t"
-        "v_bitop3_b32 %0, %0, s98, %3 bitop3:0x90\n\t"
-        "v_bitop3_b32 %1, %1, s99, %3 bitop3:0x90\n\t"
+        "v_bitop3_b32 %0, %0, s80, %3 bitop3:0x90\n\t"
+        "v_bitop3_b32 %1, %1, s81, %3 bitop3:0x90\n\t"
         "v_bfe_i32 %3, %5, 4, 1\n\t"
-        "v_cmp_ne_u32_e64 s[98:99], 0, %3\n\t"
-        "v_bitop3_b32 %0, %0, s100, %4 bitop3:0x90\n\t"
-        "v_bitop3_b32 %1, %1, s101, %4 bitop3:0x90\n\t"
+        "v_cmp_ne_u32_e64 s[80:81], 0, %3\n\t"
+        "v_bitop3_b32 %0, %0, s82, %4 bitop3:0x90\n\t"
+        "v_bitop3_b32 %1, %1, s83, %4 bitop3:0x90\n\t"
         "v_bfe_i32 %4, %5, 5, 1\n\t"
-        "v_cmp_ne_u32_e64 s[100:101], 0, %4\n\t"
+        "v_cmp_ne_u32_e64 s[82:83], 0, %4\n\t"
         "v_bitop3_b32 %0, %0, vcc_lo, %2 bitop3:0x90\n\t"
         "v_bitop3_b32 %1, %1, vcc_hi, %2 bitop3:0x90\n\t"
         "v_bfe_i32 %2, %5, 6, 1\n\t"
         "v_cmp_ne_u32_e64 vcc, 0, %2\n\t"
-        "v_bitop3_b32 %0, %0, s98, %3 bitop3:0x90\n\t"
-        "v_bitop3_b32 %1, %1, s99, %3 bitop3:0x90\n\t"
+        "v_bitop3_b32 %0, %0, s80, %3 bitop3:0x90\n\t"
+        "v_bitop3_b32 %1, %1, s81, %3 bitop3:0x90\n\t"
         "v_bfe_i32 %3, %5, 7, 1\n\t"
-        "v_cmp_ne_u32_e64 s[98:99], 0, %3\n\t"
-        "v_bitop3_b32 %0, %0, s100, %4 bitop3:0x90\n\t"
-        "v_bitop3_b32 %1, %1, s101, %4 bitop3:0x90\n\t"
+        "v_cmp_ne_u32_e64 s[80:81], 0, %3\n\t"
+        "v_bitop3_b32 %0, %0, s82, %4 bitop3:0x90\n\t"
+        "v_bitop3_b32 %1, %1, s83, %4 bitop3:0x90\n\t"
         "v_bitop3_b32 %0, %0, vcc_lo, %2 bitop3:0x90\n\t"
         "v_bitop3_b32 %1, %1, vcc_hi, %2 bitop3:0x90\n\t"
-        "v_bitop3_b32 %0, %0, s98, %3 bitop3:0x90\n\t"
-        "v_bitop3_b32 %1, %1, s99, %3 bitop3:0x90"
+        "v_bitop3_b32 %0, %0, s80, %3 bitop3:0x90\n\t"
+        "v_bitop3_b32 %1, %1, s81, %3 bitop3:0x90"
         : "+v"(plo), "+v"(phi), "=&v"(x), "=&v"(y), "=&v"(z)
         : "v"(d)
-        : "vcc", "s98", "s99", "s100", "s101");
+        : "vcc", "s80", "s81", "s82", "s83");  // ordinary SGPRs: the top ones (s100, s101 ...) are reserved by the compiler
+}
+
+// 9-bit digits: the eight low bits through match_any8, the ninth with one more bfe / cmp / 2 x bitop3 step
+__device__ __forceinline__ void match_any_digit(u32 d, u32 &plo, u32 &phi) {
+    match_any8(d, plo, phi);
+    if (RB == 9) {
+        int sb = __builtin_amdgcn_sbfe((int)d, 8u, 1u);
+        const u64 m = __ballot(sb != 0);
+        plo = __builtin_amdgcn_bitop3_b32(plo, (u32)m, (u32)sb, 0x90);
+        phi = __builtin_amdgcn_bitop3_b32(phi, (u32)(m >> 32), (u32)sb, 0x90);
+    }
 }
 
 #ifndef SORT_LB_W
@@ -168,18 +184,19 @@ __device__ __forceinline__ void match_any8(u32 d, u32 &plo, u32 &phi) {
 template <typename SW, bool PAIRS, bool TICKET, int NT_, int VT_>
 __global__ __launch_bounds__(NT_) SORT_WAVES_ATTR void onesweep_kernel(PassArgs<SW> p) {
     constexpr int NT = NT_, NW = NT_ / 64, VT = VT_, TILE = NT_ * VT_;  // NT >= RADIX: thread d < 256 owns digit d
-    static_assert(NT_ >= RADIX && NT_ % 64 == 0, "workgroup must cover the 256 digits");
+    static_assert(NT_ >= RADIX && NT_ % 64 == 0, "workgroup must cover all digits");
+    static_assert(64 * VT_ < 65536, "per-wave digit counts are 16-bit");
     using T = SWTraits<SW>;
     __shared__ u64 s_keys[TILE];
     __shared__ u32 s_vals[PAIRS ? TILE : 1];
-    __shared__ u32 s_whist[NW][RADIX];
+    __shared__ unsigned short s_whist[NW][RADIX];  // per-wave digit counts (<= 64 * VT)
     __shared__ u32 s_dexcl[RADIX];
     __shared__ u64 s_gbase[RADIX];
     __shared__ u32 s_scan[NW + 1];
     __shared__ u32 s_tile;
     const int tid = (int)threadIdx.x, lane = lane_id(), wave = tid >> 6;
     if (TICKET && tid == 0) s_tile = atomicAdd(p.ticket, 1u);
-    for (int i = tid; i < NW * RADIX; i += NT) (&s_whist[0][0])[i] = 0;
+    for (int i = tid; i < NW * RADIX / 2; i += NT) reinterpret_cast<u32 *>(&s_whist[0][0])[i] = 0;
     __syncthreads();
     const u64 tile = TICKET ? (u64)s_tile : (u64)blockIdx.x;
     const u64 tbase = tile * (u64)TILE;
@@ -207,18 +224,18 @@ __global__ __launch_bounds__(NT_) SORT_WAVES_ATTR void onesweep_kernel(PassArgs<
 #pragma unroll
     for (int j = 0; j < VT; j++) {
         const u32 li = wbase_idx + j * 64;
-        // padding items take digit 255; they sit at the end of the tile order, so they rank
+        // padding items take the highest digit; they sit at the end of the tile order, so they rank
         // after every real key of that digit and are dropped at write-out
-        const u32 d = (li < valid_count) ? ((u32)(key[j] >> p.shift) & 255u) : 255u;
+        const u32 d = (li < valid_count) ? ((u32)(key[j] >> p.shift) & DMASK) : DMASK;
         u32 plo, phi;
-        match_any8(d, plo, phi);
+        match_any_digit(d, plo, phi);
         const u32 pre = s_whist[wave][d];
         const u32 r = (u32)__popc(plo & lt_lo) + (u32)__popc(phi & lt_hi);
         const u32 tot = (u32)__popc(plo) + (u32)__popc(phi);
         rank[j] = pre + r;
         // every peer stores the same new count (same address, same value): no branch, so the 16 keys'
         // ranking stays one basic block that the scheduler can interleave
-        s_whist[wave][d] = pre + tot;
+        s_whist[wave][d] = (unsigned short)(pre + tot);
     }
     __syncthreads();
 
@@ -230,12 +247,12 @@ __global__ __launch_bounds__(NT_) SORT_WAVES_ATTR void onesweep_kernel(PassArgs<
 #pragma unroll
         for (int w = 0; w < NW; w++) {
             u32 c = s_whist[w][d];
-            s_whist[w][d] = cnt;
+            s_whist[w][d] = (unsigned short)cnt;
             cnt += c;
         }
     }
     u32 real_cnt = cnt;
-    if (d == 255) real_cnt -= (u32)TILE - valid_count;
+    if (d == (int)DMASK) real_cnt -= (u32)TILE - valid_count;
     // publish the tile's count of digit d, then look back
     SW *st = p.status + tile * RADIX + d;
     if (owner) {
@@ -252,7 +269,7 @@ __global__ __launch_bounds__(NT_) SORT_WAVES_ATTR void onesweep_kernel(PassArgs<
 #pragma unroll
     for (int j = 0; j < VT; j++) {
         const u32 li = wbase_idx + j * 64;
-        const u32 dd = (li < valid_count) ? ((u32)(key[j] >> p.shift) & 255u) : 255u;
+        const u32 dd = (li < valid_count) ? ((u32)(key[j] >> p.shift) & DMASK) : DMASK;
         const u32 pos = s_dexcl[dd] + s_whist[wave][dd] + rank[j];
         s_keys[pos] = key[j];
         if (PAIRS) s_vals[pos] = val[j];
@@ -307,7 +324,7 @@ __global__ __launch_bounds__(NT_) SORT_WAVES_ATTR void onesweep_kernel(PassArgs<
 
     for (u32 i = (u32)tid; i < valid_count; i += NT) {
         const u64 kk = s_keys[i];
-        const u32 dd = (u32)(kk >> p.shift) & 255u;
+        const u32 dd = (u32)(kk >> p.shift) & DMASK;
         const u64 pos = s_gbase[dd] + i;
         p.kout[pos] = kk;
         if (PAIRS) p.vout[pos] = s_vals[i];
@@ -404,7 +421,7 @@ int ukm_dev_sort(ukm_ctx *c, u64 *keys, u32 *vals, u64 n, int key_bits) {
         }
         return UKM_OK;
     }
-    const int passes = (key_bits + 7) / 8;
+    const int passes = (key_bits + RB - 1) / RB;
 
     u64 *ghist = nullptr;
     UKM_TRY(ws_alloc_t(c, MAX_PASSES * RADIX, &ghist));
@@ -425,7 +442,7 @@ int ukm_dev_sort(ukm_ctx *c, u64 *keys, u32 *vals, u64 n, int key_bits) {
         for (int d = 0; d < RADIX; d++)
             if (hp[d] == n) constant = true;
         if (constant) continue;  // every key has the same digit: the pass is the identity
-        shifts[npass++] = 8 * p;
+        shifts[npass++] = RB * p;
         u64 sum = 0;
         for (int d = 0; d < RADIX; d++) {
             gb.push_back(sum);
