@@ -151,7 +151,9 @@ __device__ __forceinline__ u64 lb_resolve(u64 *status, u64 tile, u64 agg, int la
         int ok = 1;
         if (lane == 0) {
             while ((lb_load(&status[base * LB_STRIDE]) >> 62) == 0) {
-                if (++spins > LB_SPIN_LIMIT) { ok = 0; break; }
+                // the watchdog is for tile ids taken from blockIdx; with ticketed ids (timed_out == nullptr)
+                // every predecessor is running and the wait always ends
+                if (timed_out && ++spins > LB_SPIN_LIMIT) { ok = 0; break; }
                 __builtin_amdgcn_s_sleep(LB_POLL_SLEEP);
             }
         }

@@ -409,7 +409,7 @@ __global__ __launch_bounds__(NT) void window_kernel(WinArgs p) {
         if (tid < 64) {
             bool timed_out = false;
             if (lane == 0) lb_publish(p.status, tile, (u64)tile_total);
-            const u64 base = lb_resolve(p.status, tile, (u64)tile_total, lane, &timed_out);
+            const u64 base = lb_resolve(p.status, tile, (u64)tile_total, lane, TICKET ? nullptr : &timed_out);
             if (tid == 0) s_misc[1] = base;
             if (timed_out && lane == 0) atomicOr((unsigned long long *)&p.result[1], 2ull);
         }
@@ -596,7 +596,7 @@ __global__ __launch_bounds__(NT) void minimizer_kernel(MinArgs p) {
     if (tid < 64) {
         bool timed_out = false;
         if (lane == 0) lb_publish(p.status, tile, (u64)tile_total);
-        const u64 base = lb_resolve(p.status, tile, (u64)tile_total, lane, &timed_out);
+        const u64 base = lb_resolve(p.status, tile, (u64)tile_total, lane, TICKET ? nullptr : &timed_out);
         if (tid == 0) s_misc[1] = base;
         if (timed_out && lane == 0) atomicOr((unsigned long long *)&p.result[1], 2ull);
     }

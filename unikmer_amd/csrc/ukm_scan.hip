@@ -54,7 +54,10 @@ struct UniqArgs {
 //     (emitting lower lanes in its own wave) = one wave64 ballot per round plus one 128-entry
 //     prefix per tile — no per-thread output arrays, compaction in place over the input tile.
 // CHUNK = the REPEATED_CHUNK protocol (up to two output records per input record).
-template <bool TAX, bool CHUNK, int VTU>
+// TICKET: tile ids from an atomic counter (always live) instead of blockIdx (no single-address atomic in front
+// of every tile, but look-back liveness then relies on in-order dispatch: watchdog -> flag 4 -> the host re-runs
+// the ticketed instantiation, see ukm_setops.hip).
+template <bool TAX, bool CHUNK, int VTU, bool TICKET>
 __global__ __launch_bounds__(UNT) void unique_tile_kernel(UniqArgs p) {
     constexpr int TILE_U = UNT * VTU;
     constexpr int NWU = UNT / 64;
@@ -64,9 +67,12 @@ __global__ __launch_bounds__(UNT) void unique_tile_kernel(UniqArgs p) {
     __shared__ u32 s_cnt[VTU * NWU + 1];
     __shared__ u64 s_misc[2];
     const int tid = (int)threadIdx.x, lane = lane_id(), wave = tid >> 6;
-    if (tid == 0) s_misc[0] = (u64)atomicAdd(p.ticket, 1u);
-    __syncthreads();
-    const u64 tile = s_misc[0];
+    u64 tile = blockIdx.x;
+    if (TICKET) {
+        if (tid == 0) s_misc[0] = (u64)atomicAdd(p.ticket, 1u);
+        __syncthreads();
+        tile = s_misc[0];
+    }
     const u64 i0 = tile * (u64)TILE_U;
     const int cnt_t = (int)((p.n - i0 < (u64)TILE_U) ? (p.n - i0) : (u64)TILE_U);
 
@@ -176,8 +182,10 @@ __global__ __launch_bounds__(UNT) void unique_tile_kernel(UniqArgs p) {
         }
     }
     if (tid < 64) {
-        const u64 base = lb_resolve(p.status, tile, (u64)tile_total, lane, nullptr);
+        bool timed_out = false;
+        const u64 base = lb_resolve(p.status, tile, (u64)tile_total, lane, TICKET ? nullptr : &timed_out);
         if (tid == 0) s_misc[1] = base;
+        if (timed_out) bad |= 4u;
     }
     if (bad) atomicOr((unsigned long long *)&p.result[1], (unsigned long long)bad);
     __syncthreads();
@@ -350,16 +358,35 @@ int ukm_dev_unique_ex(ukm_ctx *c, const u64 *keys, const u32 *taxids, u64 n, int
     p.ticket = (u32 *)(ctl + 2);
     p.status = ctl + 8;
     const dim3 grid((unsigned)p.ntiles), block(UNT);
-    if (chunk) {
-        if (tax) hipLaunchKernelGGL((unique_tile_kernel<true, true, UVT / 2>), grid, block, 0, c->stream, p);
-        else hipLaunchKernelGGL((unique_tile_kernel<false, true, UVT / 2>), grid, block, 0, c->stream, p);
-    } else {
-        if (tax) hipLaunchKernelGGL((unique_tile_kernel<true, false, UVT>), grid, block, 0, c->stream, p);
-        else hipLaunchKernelGGL((unique_tile_kernel<false, false, UVT>), grid, block, 0, c->stream, p);
+    // a first attempt that times out may already have written part of the output: when the output aliases
+    // the input the retry would read damaged data, so in-place calls take the ticketed kernel straight away
+    const bool in_place = (out <= keys && keys < out + out_cap) || (keys <= out && out < keys + n);
+    u64 res[2] = {0, 0};
+    for (int attempt = (c->setop_force_ticket || in_place) ? 1 : 0; attempt < 2; attempt++) {
+        if (attempt == 1) UKM_HIP(hipMemsetAsync(ctl, 0, nctl * sizeof(u64), c->stream));
+        if (attempt == 0) {
+            if (chunk) {
+                if (tax) hipLaunchKernelGGL((unique_tile_kernel<true, true, UVT / 2, false>), grid, block, 0, c->stream, p);
+                else hipLaunchKernelGGL((unique_tile_kernel<false, true, UVT / 2, false>), grid, block, 0, c->stream, p);
+            } else {
+                if (tax) hipLaunchKernelGGL((unique_tile_kernel<true, false, UVT, false>), grid, block, 0, c->stream, p);
+                else hipLaunchKernelGGL((unique_tile_kernel<false, false, UVT, false>), grid, block, 0, c->stream, p);
+            }
+        } else {
+            if (chunk) {
+                if (tax) hipLaunchKernelGGL((unique_tile_kernel<true, true, UVT / 2, true>), grid, block, 0, c->stream, p);
+                else hipLaunchKernelGGL((unique_tile_kernel<false, true, UVT / 2, true>), grid, block, 0, c->stream, p);
+            } else {
+                if (tax) hipLaunchKernelGGL((unique_tile_kernel<true, false, UVT, true>), grid, block, 0, c->stream, p);
+                else hipLaunchKernelGGL((unique_tile_kernel<false, false, UVT, true>), grid, block, 0, c->stream, p);
+            }
+        }
+        UKM_HIP(hipGetLastError());
+        UKM_TRY(ukm_read_u64(c, p.result, res, 2));
+        if (!(res[1] & 4)) break;
+        if (attempt == 1) UKM_FAIL(UKM_ERR_HIP, "ukm_unique: look-back watchdog fired in the ticketed kernel");
+        c->setop_force_ticket = true;
     }
-    UKM_HIP(hipGetLastError());
-    u64 res[2];
-    UKM_TRY(ukm_read_u64(c, p.result, res, 2));
     if (res[1] & 2) UKM_FAIL(UKM_ERR_UNSORTED, "ukm_unique: input stream is not sorted");
     *n_out = res[0];
     if (res[0] > out_cap)

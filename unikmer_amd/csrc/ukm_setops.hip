@@ -576,7 +576,7 @@ __global__ __launch_bounds__(NTH) SETOP_WAVES_ATTR void setop_tile_kernel(SetopA
 #ifdef SETOP_ABL_NOLB  // experiment only: wrong output positions, no look-back
         const u64 base = tile * (u64)TILE;
 #else
-        const u64 base = lb_resolve(p.status, tile, (u64)tile_total, lane_id(), &timed_out);
+        const u64 base = lb_resolve(p.status, tile, (u64)tile_total, lane_id(), TICKET ? nullptr : &timed_out);
 #endif
         if (tid == 0) s_misc[1] = base;
         if (timed_out) bad |= FLAG_TIMEOUT;
