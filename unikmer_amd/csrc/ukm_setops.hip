@@ -656,7 +656,7 @@ void launch_op(int op, const SetopArgs &p, hipStream_t st, bool ticket) {
 constexpr int NTS = SETOP_NT;       // threads per workgroup (512: two workgroups per CU)
 constexpr int VT_PLAIN = SETOP_VT;  // 19 items per thread: 76 KiB of keys in LDS per workgroup (2 x 78 KB fit the CU's 160 KB)
 #ifndef SETOP_VT_TAX
-#define SETOP_VT_TAX 12
+#define SETOP_VT_TAX 13
 #endif
 constexpr int VT_TAX = SETOP_VT_TAX;     // fewer when taxids/ranks ride along
 
