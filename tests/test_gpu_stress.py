@@ -1,5 +1,5 @@
 """Seeded randomised parity sweep on the GPU: many small / medium shapes around the tile geometry
-(tile = 9728 merged items, 6144 with taxids or ranks), with duplicates, empty sides, taxids on
+(tile = 9728 merged items, 6656 with taxids or ranks), with duplicates, empty sides, taxids on
 one or both sides and all three operations, each compared bit-exactly with the CPU oracle."""
 import os
 import sys
@@ -36,7 +36,7 @@ def _draw(rng, n, universe, dup_rate):
     return a.astype(np.uint64)
 
 
-SIZES = [0, 1, 2, 63, 64, 65, 511, 512, 6143, 6144, 6145, 9727, 9728, 9729, 19456, 30000, 100_000]
+SIZES = [0, 1, 2, 63, 64, 65, 511, 512, 6143, 6144, 6145, 6655, 6656, 6657, 9727, 9728, 9729, 13312, 19456, 30000, 100_000]
 
 
 @pytest.mark.parametrize("seed", range(6))
