@@ -131,6 +131,34 @@ class _NumpyCtx:
         assert taxids is None and mode == 1
         return torch.from_numpy(np.unique(self._u(keys)).view(np.int64))
 
+    # n-way set operations on sorted sets (no taxids in these plumbing tests)
+    @staticmethod
+    def _t(a):
+        return torch.from_numpy(np.ascontiguousarray(a).view(np.int64))
+
+    def union(self, files, taxids=None):
+        out = np.empty(0, np.uint64)
+        for f in files:
+            out = np.union1d(out, self._u(f))
+        return self._t(out)
+
+    def inter(self, files, taxids=None):
+        out = self._u(files[0])
+        for f in files[1:]:
+            out = np.intersect1d(out, self._u(f))
+        return self._t(out)
+
+    def diff(self, files, taxids=None):
+        out = self._u(files[0])
+        for f in files[1:]:
+            out = np.setdiff1d(out, self._u(f))
+        return self._t(out)
+
+    def common(self, files, threshold, taxids=None):
+        cat = np.concatenate([np.unique(self._u(f)) for f in files])
+        v, c = np.unique(cat, return_counts=True)
+        return self._t(v[c >= threshold])
+
 
 def _sort_worker(rank, world, port, ret):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -174,3 +202,37 @@ def test_sharded_sort_and_count_world2():
     for r in range(world):
         v = ret[r][1]
         assert np.all(v >= np.uint64(spl[r])) and (r == world - 1 or np.all(v < np.uint64(spl[r + 1])))
+
+
+def _setop_worker(rank, world, port, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        files = [torch.from_numpy(f.view(np.int64)) for f in _files(rank)]
+        ctx = _NumpyCtx()
+        out = {}
+        for op in ("union", "inter", "diff"):
+            out[op] = ud.sharded_setop(ctx, op, files, 42).numpy().view(np.uint64).copy()
+        out["common"] = ud.sharded_setop(ctx, "common", files, 42, threshold=2).numpy().view(np.uint64).copy()
+        ret[rank] = out
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_setop_pipelined_world2():
+    """dist.sharded_setop end to end over gloo: batched count exchange, asynchronous per-file all-to-all-v
+    overlapped with the merges, per-rank n-way op; concatenation in rank order == the global result."""
+    world = 2
+    port = _free_port()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_setop_worker, args=(world, port, ret), nprocs=world, join=True)
+    logical = [np.unique(np.concatenate([_files(r)[f] for r in range(world)])) for f in range(3)]
+    gu, gi, gd = logical[0], logical[0], logical[0]
+    for m in logical[1:]:
+        gu, gi, gd = np.union1d(gu, m), np.intersect1d(gi, m), np.setdiff1d(gd, m)
+    v, c = np.unique(np.concatenate(logical), return_counts=True)
+    cat = lambda op: np.concatenate([ret[r][op] for r in range(world)])
+    assert np.array_equal(cat("union"), gu) and np.array_equal(cat("inter"), gi) and np.array_equal(cat("diff"), gd)
+    assert np.array_equal(cat("common"), v[c >= 2])

@@ -75,26 +75,59 @@ def sharded_setop(ctx, op, files_keys, key_bits, files_taxids=None, group=None, 
     globally sorted output, bit-identical to the 1-GPU result.
 
     files_keys: list of 1-D int64 device tensors; every rank must pass the SAME number of
-    files (file i of every rank are the per-rank chunks of logical input i).
+    files (file i of every rank are the per-rank chunks of logical input i).  `ctx` must run on
+    torch's current stream (lib.Context(device, stream=torch.cuda.current_stream().cuda_stream)):
+    the exchange of file i+1 is issued asynchronously and overlaps the merge of file i.
     """
     world = dist.get_world_size(group)
     spl = prefix_splitters(key_bits, world)[:-1]
+    nfiles = len(files_keys)
+    dev = files_keys[0].device if nfiles else None
+    # slice sizes of every file for every destination; ONE small all-to-all carries all of them
+    counts_all = []
+    for k in files_keys:
+        counts_all.append(cuts_to_counts(ctx.partition_points(k, spl), k.numel()))
+    recv_counts_all = [[0] * world for _ in range(nfiles)]
+    if nfiles:
+        send = torch.tensor(counts_all, dtype=torch.int64, device=dev).t().contiguous()   # [world, nfiles]
+        recv = torch.empty_like(send)
+        dist.all_to_all_single(recv, send, group=group)
+        rc = recv.cpu().tolist()                                                            # [source rank][file]
+        recv_counts_all = [[int(rc[src][i]) for src in range(world)] for i in range(nfiles)]
+
+    def issue(i):
+        """start the all-to-all-v of file i (asynchronous: it overlaps the merge of file i - 1)"""
+        k = files_keys[i]
+        rcv = recv_counts_all[i]
+        out = torch.empty(sum(rcv), dtype=k.dtype, device=k.device)
+        works = [dist.all_to_all_single(out, k, output_split_sizes=rcv, input_split_sizes=list(counts_all[i]),
+                                        group=group, async_op=True)]
+        out_t = None
+        if files_taxids is not None:
+            t = files_taxids[i]
+            out_t = torch.empty(sum(rcv), dtype=t.dtype, device=t.device)
+            works.append(dist.all_to_all_single(out_t, t, output_split_sizes=rcv, input_split_sizes=list(counts_all[i]),
+                                                group=group, async_op=True))
+        return works, out, out_t
+
     local = []
     local_t = [] if files_taxids is not None else None
-    for i, k in enumerate(files_keys):
-        cuts = ctx.partition_points(k, spl)
-        counts = cuts_to_counts(cuts, k.numel())
-        t = files_taxids[i] if files_taxids is not None else None
-        rk, rt, rc = exchange_sorted(k, counts, t, group)
+    pending = issue(0) if nfiles else None
+    for i in range(nfiles):
+        nxt = issue(i + 1) if i + 1 < nfiles else None      # file i+1 travels while file i is merged
+        works, rk, rt = pending
+        for w in works:
+            w.wait()   # nccl: makes torch's current stream (= the ctx stream) wait, the host does not block
         # pieces from different source ranks overlap in value -> merge them into one sorted set
-        pieces = split_by_counts(rk, rc)
-        tpieces = split_by_counts(rt, rc) if rt is not None else None
+        pieces = split_by_counts(rk, recv_counts_all[i])
+        tpieces = split_by_counts(rt, recv_counts_all[i]) if rt is not None else None
         merged = ctx.union(pieces, tpieces)
         if tpieces is not None:
             local.append(merged[0])
             local_t.append(merged[1])
         else:
             local.append(merged)
+        pending = nxt
     fn = {"union": ctx.union, "inter": ctx.inter, "diff": ctx.diff, "common": ctx.common}[op]
     if op == "common":
         return fn(local, kw["threshold"], local_t)
