@@ -305,6 +305,13 @@ int ukm_finish(CallScope *s, int rc) {
     return rc;
 }
 
+void ukm_switch_to_tickets(ukm_ctx *c, const char *where) {
+    if (!c->setop_force_ticket)
+        fprintf(stderr, "[unikmer_hip] look-back watchdog fired in %s: workgroups were not dispatched in order on device %d; "
+                        "switching this context to ticketed tile ids\n", where, c->device);
+    c->setop_force_ticket = true;
+}
+
 int ukm_read_u64(ukm_ctx *c, const u64 *dev, u64 *host, int n) {
     if (n > 64) UKM_FAIL(UKM_ERR_INVALID, "ukm_read_u64: n too large");
     UKM_HIP(hipMemcpyAsync(c->h_scratch, dev, n * sizeof(u64), hipMemcpyDeviceToHost, c->stream));

@@ -477,7 +477,7 @@ int run_windows(ukm_ctx *c, bool hash, const u8 *bases, const u64 *rec_off, u64 
         UKM_TRY(ukm_read_u64(c, ctl, res, 2));
         if (!(res[1] & 2)) break;  // no look-back watchdog
         if (attempt == 1) UKM_FAIL(UKM_ERR_HIP, "window kernel: look-back watchdog fired in the ticketed kernel");
-        c->setop_force_ticket = true;  // this device does not dispatch workgroups in order
+        ukm_switch_to_tickets(c, "ntHash filter kernel");  // this device does not dispatch workgroups in order
     }
     if (res[1] & 1) UKM_FAIL(UKM_ERR_ILLEGAL_BASE, "illegal base in sequence (kmers.ErrIllegalBase)");
     *n_out = filter ? res[0] : total_windows;
@@ -652,7 +652,7 @@ int run_minimizer(ukm_ctx *c, const u8 *bases, const u64 *rec_off, u64 n_rec, in
         res = r2[0];
         if (!(r2[1] & 2)) break;
         if (attempt == 1) UKM_FAIL(UKM_ERR_HIP, "minimizer kernel: look-back watchdog fired in the ticketed kernel");
-        c->setop_force_ticket = true;
+        ukm_switch_to_tickets(c, "minimizer kernel");
     }
     *n_out = res;
     if (res > out_cap)

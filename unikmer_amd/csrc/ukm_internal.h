@@ -168,6 +168,9 @@ static inline TaxDev ukm_taxdev(const ukm_ctx *c) {
 // ---- internal device-pointer entry points (all pointers are device pointers) ------------------
 // internal fourth 2-way operation: merge keeping every record (k-way merge tree of ukm_merge_k)
 #define UKM_OP_MERGE_INTERNAL 3
+// a look-back watchdog fired in a blockIdx-ordered kernel: from now on this context uses the ticketed
+// instantiations (one warning on stderr per context, so that an operator sees the slower mode)
+void ukm_switch_to_tickets(ukm_ctx *c, const char *where);
 int ukm_dev_setop2(ukm_ctx *c, int op, const u64 *a, const u32 *ta, u64 na, const u64 *b,
                    const u32 *tb, u64 nb, u32 flags, u64 *out, u32 *tout, u64 out_cap,
                    u64 *n_out);

@@ -385,7 +385,7 @@ int ukm_dev_unique_ex(ukm_ctx *c, const u64 *keys, const u32 *taxids, u64 n, int
         UKM_TRY(ukm_read_u64(c, p.result, res, 2));
         if (!(res[1] & 4)) break;
         if (attempt == 1) UKM_FAIL(UKM_ERR_HIP, "ukm_unique: look-back watchdog fired in the ticketed kernel");
-        c->setop_force_ticket = true;
+        ukm_switch_to_tickets(c, "unique kernel");
     }
     if (res[1] & 2) UKM_FAIL(UKM_ERR_UNSORTED, "ukm_unique: input stream is not sorted");
     *n_out = res[0];

@@ -726,7 +726,7 @@ int run_setop_pass(ukm_ctx *c, int op, const u64 *a, const u32 *ta, const u32 *r
         UKM_TRY(ukm_read_u64(c, p.result, result_host, 2));
         if (!(result_host[1] & FLAG_TIMEOUT)) break;
         if (ticket) UKM_FAIL(UKM_ERR_HIP, "setop: look-back watchdog fired in the ticketed kernel");
-        c->setop_force_ticket = true;  // this device does not dispatch in order: stay on tickets
+        ukm_switch_to_tickets(c, "set-op kernel");  // this device does not dispatch in order: stay on tickets
     }
 #ifdef UKM_PROFILE_PHASES
     {

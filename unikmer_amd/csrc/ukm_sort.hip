@@ -363,7 +363,7 @@ int run_passes(ukm_ctx *c, u64 *keys, u32 *vals, u64 *tk, u32 *tv, u64 n, int np
             u64 fl = 0;
             UKM_TRY(ukm_read_u64(c, ctl + 1, &fl));
             if (!(fl & 1)) break;
-            c->setop_force_ticket = true;  // this device does not dispatch in order
+            ukm_switch_to_tickets(c, "radix sort pass");  // this device does not dispatch in order
         }
         std::swap(src_k, dst_k);
         std::swap(src_v, dst_v);
