@@ -13,6 +13,13 @@ from conftest import synth_tree  # noqa: E402
 
 pytestmark = pytest.mark.gpu
 
+# UKM_STRESS_SEEDS=N widens every sweep below to N seeds (default: the small fixed sets used in CI)
+_EXTRA = int(os.environ.get("UKM_STRESS_SEEDS", "0"))
+
+
+def _seeds(n):
+    return range(max(n, _EXTRA))
+
 
 @pytest.fixture(scope="module")
 def env():
@@ -39,7 +46,7 @@ def _draw(rng, n, universe, dup_rate):
 SIZES = [0, 1, 2, 63, 64, 65, 511, 512, 6143, 6144, 6145, 6655, 6656, 6657, 9727, 9728, 9729, 13312, 19456, 30000, 100_000]
 
 
-@pytest.mark.parametrize("seed", range(6))
+@pytest.mark.parametrize("seed", _seeds(6))
 def test_random_setops_plain_and_multiset(env, seed):
     O, L, ctx, tax, T = env
     rng = np.random.default_rng(1000 + seed)
@@ -61,7 +68,7 @@ def test_random_setops_plain_and_multiset(env, seed):
             assert np.array_equal(got, exp), (seed, it, op, na, nb, dup)
 
 
-@pytest.mark.parametrize("seed", range(4))
+@pytest.mark.parametrize("seed", _seeds(4))
 def test_random_setops_with_taxids(env, seed):
     O, L, ctx, tax, T = env
     rng = np.random.default_rng(2000 + seed)
@@ -92,7 +99,7 @@ def test_random_setops_with_taxids(env, seed):
             assert np.array_equal(gk, ek) and np.array_equal(gt, et), (seed, it, "diff -t")
 
 
-@pytest.mark.parametrize("seed", range(3))
+@pytest.mark.parametrize("seed", _seeds(3))
 def test_random_sort_scan_nway(env, seed):
     O, L, ctx, tax, T = env
     rng = np.random.default_rng(3000 + seed)
@@ -130,7 +137,7 @@ def test_random_sort_scan_nway(env, seed):
             assert np.array_equal(ctx.inter(files), O.inter(files)), (seed, it, "inter")
 
 
-@pytest.mark.parametrize("seed", range(3))
+@pytest.mark.parametrize("seed", _seeds(3))
 def test_random_windows(env, seed):
     """encode / ntHash / Scaled filter / minimizer over random ragged record layouts (empty records, records
     shorter than k, records across tile borders of 2048 windows, IUPAC and lower-case bases, circular)."""
@@ -170,7 +177,7 @@ def test_random_windows(env, seed):
         assert np.array_equal(gh, eh) and np.array_equal(gp, ep), (seed, it, "minimizer", kh, w, circ)
 
 
-@pytest.mark.parametrize("seed", range(4))
+@pytest.mark.parametrize("seed", _seeds(4))
 def test_random_nway_with_taxids(env, seed):
     """n-way union / inter (-m) / diff (-t) / common / merge (-u, -d, chunk rounds) with per-record taxids,
     some files without taxids (mix), taxid 0 records, empty files in the middle."""
