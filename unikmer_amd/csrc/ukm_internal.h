@@ -174,6 +174,10 @@ void ukm_switch_to_tickets(ukm_ctx *c, const char *where);
 int ukm_dev_setop2(ukm_ctx *c, int op, const u64 *a, const u32 *ta, u64 na, const u64 *b,
                    const u32 *tb, u64 nb, u32 flags, u64 *out, u32 *tout, u64 out_cap,
                    u64 *n_out);
+int ukm_dev_setop2_link(ukm_ctx *c, int op, const u64 *a, const u32 *ta, u64 na_max, const u64 *na_dev, const u64 *b,
+                        const u32 *tb, u64 nb, u32 flags, u64 *out, u32 *tout, u64 out_cap, u64 *ctl);
+// flag bits of the set-op result word [1]
+enum { UKM_SETOP_FLAG_DUP = 1, UKM_SETOP_FLAG_UNSORTED = 2, UKM_SETOP_FLAG_TIMEOUT = 4 };
 int ukm_dev_sort(ukm_ctx *c, u64 *keys, u32 *vals, u64 n, int key_bits);
 int ukm_dev_unique(ukm_ctx *c, const u64 *keys, const u32 *taxids, u64 n, int mode, u64 *out,
                    u32 *tout, u64 out_cap, u64 *n_out);

@@ -249,6 +249,78 @@ int merged_sequence(ukm_ctx *ctx, const std::vector<Stream> &all, bool tax, u64 
     return UKM_OK;
 }
 
+// ---- chained fold (inter / diff over many files) -----------------------------------------------------------
+// The reference folds the files one after the other into a running result.  Done naively every link costs a
+// host round trip for the running size (~40 us: with 1000 files of 1e6 codes that IS the run time).  Here the
+// size stays on the device: link i reads |acc| from link i-1's result word, launches with the upper bound
+// (the first file's size) and tiles beyond the real size exit at once.  The host looks at a count only every
+// a few links (4, 8, 16, ... then every 64: early exit when the running result is empty: inter.go:283-286, diff.go:457-459) and reads all
+// flags once at the end.  A duplicate code inside an input (multiset semantics need the rank path) or a
+// look-back watchdog makes the caller fall back to the synchronous fold.
+constexpr int CHAIN_MIN_STREAMS = 4;
+constexpr int CHAIN_PEEK_FIRST = 4;   // the host looks at the running size after 4, 8, 16, ... links (then every 64)
+constexpr int CHAIN_PEEK_MAX = 64;
+
+struct ChainResult {
+    Stream acc;           // device buffers of the final running result
+    u64 n = 0;            // its size
+    bool fallback = false;
+    bool unsorted = false;
+};
+
+// streams[1..] are folded into acc0 with `op`; unsorted later files of diff must already be sorted copies.
+// stop_at_empty_later: inter.go:211-217 (an empty later file ends the fold, the running result is kept).
+int fold_chained(ukm_ctx *ctx, int op, const std::vector<Stream> &ss, u32 flags, bool tax, bool stop_at_empty_later,
+                 u64 *bk[2], u32 *bt[2], ChainResult *res) {
+    const int nlinks_max = (int)ss.size() - 1;
+    u64 *ctl = nullptr;  // 8 words per link, alive until the end
+    UKM_TRY(ws_alloc_t(ctx, (size_t)nlinks_max * 8 + 8, &ctl));
+    UKM_HIP(hipMemsetAsync(ctl, 0, ((size_t)nlinks_max * 8 + 8) * sizeof(u64), ctx->stream));
+    const u64 na_max = ss[0].n;
+    Stream acc = ss[0];
+    const u64 *na_dev = nullptr;  // first link: the size is the first file's
+    int flip = 0, links = 0, next_peek = CHAIN_PEEK_FIRST;
+    bool empty = false;
+    for (size_t i = 1; i < ss.size(); i++) {
+        const Stream &q = ss[i];
+        if (q.n == 0) {
+            if (stop_at_empty_later) break;
+            continue;
+        }
+        u64 *c8 = ctl + (size_t)links * 8;
+        WsMark mark = ws_mark(ctx);
+        UKM_TRY(ukm_dev_setop2_link(ctx, op, acc.k, acc.t, na_max, na_dev, q.k, q.t, q.n, flags, bk[flip],
+                                    tax ? bt[flip] : nullptr, na_max, c8));
+        ws_release(ctx, mark);
+        acc = Stream{bk[flip], tax ? bt[flip] : nullptr, na_max};
+        na_dev = c8;
+        flip ^= 1;
+        links++;
+        if (links == next_peek) {
+            next_peek += (next_peek < CHAIN_PEEK_MAX) ? next_peek : CHAIN_PEEK_MAX;
+            u64 r2[2];
+            UKM_TRY(ukm_read_u64(ctx, c8, r2, 2));
+            if (r2[1] & (UKM_SETOP_FLAG_DUP | UKM_SETOP_FLAG_TIMEOUT | UKM_SETOP_FLAG_UNSORTED)) break;
+            if (r2[0] == 0) { empty = true; break; }
+        }
+    }
+    res->acc = acc;
+    if (links == 0) {
+        res->n = ss[0].n;
+        return UKM_OK;
+    }
+    std::vector<u64> h((size_t)links * 8);
+    UKM_HIP(hipMemcpyAsync(h.data(), ctl, h.size() * sizeof(u64), hipMemcpyDeviceToHost, ctx->stream));
+    UKM_HIP(hipStreamSynchronize(ctx->stream));
+    u64 fl = 0;
+    for (int l = 0; l < links; l++) fl |= h[(size_t)l * 8 + 1];
+    res->unsorted = (fl & UKM_SETOP_FLAG_UNSORTED) != 0;
+    res->fallback = (fl & (UKM_SETOP_FLAG_DUP | UKM_SETOP_FLAG_TIMEOUT)) != 0;
+    if (fl & UKM_SETOP_FLAG_TIMEOUT) ukm_switch_to_tickets(ctx, "chained set-op fold");
+    res->n = empty ? 0 : h[(size_t)(links - 1) * 8];
+    return UKM_OK;
+}
+
 }  // namespace
 
 extern "C" int ukm_union(ukm_ctx *ctx, const uint64_t *const *keys, const uint32_t *const *taxids,
@@ -290,6 +362,15 @@ extern "C" int ukm_inter(ukm_ctx *ctx, const uint64_t *const *keys, const uint32
                 if (tax) UKM_TRY(ws_alloc_t(ctx, acc.n + 1, &bt[i]));
             }
         }
+        if (nstreams >= CHAIN_MIN_STREAMS && acc.n) {
+            ChainResult cr;
+            UKM_TRY(fold_chained(ctx, UKM_OP_INTER, ss, flags, tax, true, bk, bt, &cr));
+            if (cr.unsorted) UKM_FAIL(UKM_ERR_UNSORTED, "ukm_setop2: an input stream is not sorted");
+            if (!cr.fallback) {
+                cr.acc.n = cr.n;
+                return copy_result(ctx, cr.acc, tax, o.k, o.t, out_cap, n_out);
+            }
+        }
         int flip = 0;
         for (int i = 1; i < nstreams && acc.n > 0; i++) {
             const Stream &q = ss[(size_t)i];
@@ -324,6 +405,33 @@ extern "C" int ukm_diff(ukm_ctx *ctx, const uint64_t *const *keys, const uint32_
             for (int i = 0; i < 3; i++) {
                 UKM_TRY(ws_alloc_t(ctx, acc.n + 1, &bk[i]));
                 if (tax) UKM_TRY(ws_alloc_t(ctx, acc.n + 1, &bt[i]));
+            }
+        }
+        if (nstreams >= CHAIN_MIN_STREAMS && acc.n && a_strict) {
+            // chained fold: sorted copies of the unsorted files first (diff.go:341-378), then one link per file
+            std::vector<Stream> ss2 = ss;
+            for (int i = 1; i < nstreams; i++) {
+                Stream &q = ss2[(size_t)i];
+                if (q.n == 0 || !sorted_flags || sorted_flags[i]) continue;
+                u64 *k = nullptr;
+                u32 *t = nullptr;
+                UKM_TRY(ws_alloc_t(ctx, q.n, &k));
+                UKM_HIP(hipMemcpyAsync(k, q.k, q.n * sizeof(u64), hipMemcpyDeviceToDevice, ctx->stream));
+                if (tax) {
+                    UKM_TRY(ws_alloc_t(ctx, q.n, &t));
+                    if (q.t) UKM_HIP(hipMemcpyAsync(t, q.t, q.n * sizeof(u32), hipMemcpyDeviceToDevice, ctx->stream));
+                    else UKM_HIP(hipMemsetAsync(t, 0, q.n * sizeof(u32), ctx->stream));
+                }
+                UKM_TRY(ukm_dev_sort(ctx, k, t, q.n, 64));
+                q.k = k;
+                q.t = t;
+            }
+            ChainResult cr;
+            UKM_TRY(fold_chained(ctx, UKM_OP_DIFF, ss2, flags, tax, false, bk, bt, &cr));
+            if (cr.unsorted) UKM_FAIL(UKM_ERR_UNSORTED, "ukm_setop2: an input stream is not sorted");
+            if (!cr.fallback) {
+                cr.acc.n = cr.n;
+                return copy_result(ctx, cr.acc, tax, o.k, o.t, out_cap, n_out);
             }
         }
         int flip = 0;

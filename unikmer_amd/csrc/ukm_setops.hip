@@ -50,7 +50,19 @@ struct SetopArgs {
     TaxDev tax;
     u32 flags;
     u64 *dbg;  // UKM_PROFILE_PHASES only
+    // chained folds (ukm_inter / ukm_diff over many files): |A| is the previous call's result count and stays
+    // on the device; na / ntiles above are then upper bounds used for the launch geometry only
+    const u64 *na_dev;
+    u32 zero_status;  // chained links with few tiles: the partition kernel clears the status words (one launch less)
 };
+
+// the actual sizes of a chained call (workgroup-uniform: one scalar load)
+__device__ __forceinline__ void setop_resolve_sizes(SetopArgs &p, u64 tile_items) {
+    if (p.na_dev) {
+        p.na = *p.na_dev;
+        p.ntiles = (p.na + p.nb + tile_items - 1) / tile_items;
+    }
+}
 
 #ifdef UKM_PROFILE_PHASES
 #define PH(i) do { if (tid == 0) { u64 _t = clock64(); ph[i] += _t - tlast; tlast = _t; } } while (0)
@@ -81,12 +93,14 @@ __device__ __forceinline__ bool key_eq(u64 ka, u32 ra, u64 kb, u32 rb) {
 constexpr int PART_COARSE = SETOP_PART_COARSE;
 template <bool RANK, int LEVEL>
 __global__ void setop_partition_kernel(SetopArgs p, int tile_items) {
+    setop_resolve_sizes(p, (u64)tile_items);
     u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (LEVEL == 1) {
         t *= PART_COARSE;
         if (t > p.ntiles + PART_COARSE - 1) return;
         if (t > p.ntiles) t = p.ntiles;
     } else {
+        if (LEVEL == 0 && p.zero_status) p.status[t * LB_STRIDE] = 0;  // grid covers the upper bound of tiles (+1 spare line)
         if (t > p.ntiles) return;
         if (LEVEL == 2 && (t % PART_COARSE == 0 || t == p.ntiles)) return;  // placed by level 1
     }
@@ -530,6 +544,8 @@ __global__ __launch_bounds__(NTH) SETOP_WAVES_ATTR void setop_tile_kernel(SetopA
         tile = s_misc[0];
     }
     PH(0);
+    setop_resolve_sizes(p, (u64)TILE);
+    if (tile >= p.ntiles) return;  // chained call: the launch covers the upper bound of |A|
     const TileGeom g = tile_geom<NTH, VT>(p, tile);
     u32 bad;
     {
@@ -746,6 +762,50 @@ int run_setop_pass(ukm_ctx *c, int op, const u64 *a, const u32 *ta, const u32 *r
 }  // namespace
 
 // internal entry: all pointers are device pointers
+// One link of a chained fold: A's size is *na_dev (<= na_max), nothing is read back.  `ctl` = 8 zeroed words
+// owned by the caller ([0] result count, [1] flags, [2] ticket) that stay valid until the chain is read;
+// status lines and partition points come from the arena (the caller marks / releases around the call: the
+// stream orders the next link's memset after this link's kernels).  Plain sets only (no rank path).
+int ukm_dev_setop2_link(ukm_ctx *c, int op, const u64 *a, const u32 *ta, u64 na_max, const u64 *na_dev, const u64 *b,
+                        const u32 *tb, u64 nb, u32 flags, u64 *out, u32 *tout, u64 out_cap, u64 *ctl) {
+    const bool tax = (ta != nullptr) || (tb != nullptr);
+    const int vt = tax ? VT_TAX : VT_PLAIN;
+    const u64 tile_items = (u64)NTS * vt;
+    SetopArgs p;
+    memset(&p, 0, sizeof(p));
+    p.a = a; p.b = b; p.ta = ta; p.tb = tb;
+    p.na = na_max; p.nb = nb; p.na_dev = na_dev;
+    p.out = out; p.tout = tout; p.out_cap = out_cap;
+    p.ntiles = (na_max + nb + tile_items - 1) / tile_items;
+    p.tax = ukm_taxdev(c);
+    p.flags = flags;
+    if (p.ntiles == 0) return UKM_OK;
+    u64 *st = nullptr;
+    const unsigned pblocks = (unsigned)((p.ntiles + 1 + 255) / 256);
+    const bool small = p.ntiles < 4 * PART_COARSE;
+    // small: every thread of the single-level partition kernel clears one status line, so the array is sized to
+    // the partition grid; otherwise a memset does it
+    const size_t nstat = small ? lb_status_words((u64)pblocks * 256) : lb_status_words(p.ntiles);
+    UKM_TRY(ws_alloc_t(c, nstat + p.ntiles + 1, &st));
+    if (small) p.zero_status = 1;
+    else UKM_HIP(hipMemsetAsync(st, 0, nstat * sizeof(u64), c->stream));
+    p.result = ctl;
+    p.ticket = (u32 *)(ctl + 2);
+    p.status = st;
+    p.mp = st + nstat;
+    if (!small) {
+        const unsigned cblocks = (unsigned)((p.ntiles / PART_COARSE + 2 + 255) / 256);
+        hipLaunchKernelGGL((setop_partition_kernel<false, 1>), dim3(cblocks), dim3(256), 0, c->stream, p, (int)tile_items);
+        hipLaunchKernelGGL((setop_partition_kernel<false, 2>), dim3(pblocks), dim3(256), 0, c->stream, p, (int)tile_items);
+    } else {
+        hipLaunchKernelGGL((setop_partition_kernel<false, 0>), dim3(pblocks), dim3(256), 0, c->stream, p, (int)tile_items);
+    }
+    if (tax) launch_op<true, false, NTS, VT_TAX>(op, p, c->stream, c->setop_force_ticket);
+    else launch_op<false, false, NTS, VT_PLAIN>(op, p, c->stream, c->setop_force_ticket);
+    UKM_HIP(hipGetLastError());
+    return UKM_OK;
+}
+
 int ukm_dev_setop2(ukm_ctx *c, int op, const u64 *a, const u32 *ta, u64 na, const u64 *b,
                    const u32 *tb, u64 nb, u32 flags, u64 *out, u32 *tout, u64 out_cap, u64 *n_out) {
     if (op != UKM_OP_UNION && op != UKM_OP_INTER && op != UKM_OP_DIFF && op != UKM_OP_MERGE_INTERNAL)
