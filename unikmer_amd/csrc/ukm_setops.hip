@@ -53,7 +53,7 @@ struct SetopArgs {
     // chained folds (ukm_inter / ukm_diff over many files): |A| is the previous call's result count and stays
     // on the device; na / ntiles above are then upper bounds used for the launch geometry only
     const u64 *na_dev;
-    u32 zero_status;  // chained links with few tiles: the partition kernel clears the status words (one launch less)
+    u32 zero_status;  // chained links with few tiles: the partition kernel clears this many status lines (one launch less)
 };
 
 // the actual sizes of a chained call (workgroup-uniform: one scalar load)
@@ -100,7 +100,7 @@ __global__ void setop_partition_kernel(SetopArgs p, int tile_items) {
         if (t > p.ntiles + PART_COARSE - 1) return;
         if (t > p.ntiles) t = p.ntiles;
     } else {
-        if (LEVEL == 0 && p.zero_status) p.status[t * LB_STRIDE] = 0;  // grid covers the upper bound of tiles (+1 spare line)
+        if (LEVEL == 0 && t < p.zero_status) p.status[t * LB_STRIDE] = 0;
         if (t > p.ntiles) return;
         if (LEVEL == 2 && (t % PART_COARSE == 0 || t == p.ntiles)) return;  // placed by level 1
     }
@@ -123,6 +123,61 @@ __global__ void setop_partition_kernel(SetopArgs p, int tile_items) {
         if (le) lo = mid + 1; else hi = mid;
     }
     p.mp[t] = lo;
+}
+
+// Wave-cooperative variant of levels 0 and 1: ONE WAVE per boundary, 64-ary search.  Each round the 64 lanes
+// probe 64 split candidates at once (the predicate is monotone along the diagonal, so the true lanes form a
+// prefix and a ballot + popcount narrows [lo, hi) to one of 65 sub-ranges): log64 instead of log2 dependent
+// round trips -- 4-5 instead of 20-30 for the few boundaries of a small input or of the coarse level, whose
+// cost is pure latency (measured: level 1 at 2 x 1e9 40 us, the single-level kernel of a 2 x 1e6 call 12 us).
+template <bool RANK, int LEVEL>
+__global__ void setop_partition_coop_kernel(SetopArgs p, int tile_items) {
+    static_assert(LEVEL == 0 || LEVEL == 1, "bulk level 2 stays one thread per boundary");
+    setop_resolve_sizes(p, (u64)tile_items);
+    const u64 gid = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (LEVEL == 0 && p.zero_status) {
+        // status lines of the launch's upper bound of tiles: 64 per wave
+        const u64 line = gid;
+        if (line < p.zero_status) p.status[line * LB_STRIDE] = 0;
+    }
+    u64 t = gid >> 6;
+    const int lane = (int)(threadIdx.x & 63);
+    if (LEVEL == 1) {
+        t *= PART_COARSE;
+        if (t > p.ntiles + PART_COARSE - 1) return;
+        if (t > p.ntiles) t = p.ntiles;
+    } else if (t > p.ntiles) {
+        return;
+    }
+    const u64 N = p.na + p.nb;
+    u64 diag = t * (u64)tile_items;
+    if (diag > N) diag = N;
+    u64 lo = diag > p.nb ? diag - p.nb : 0;
+    u64 hi = diag < p.na ? diag : p.na;
+    while (lo < hi) {  // wave-uniform
+        const u64 span = hi - lo;
+        // candidates: strictly increasing positions in [lo, hi); fewer than 64 when the span is short
+        const u64 step_n = span <= 64 ? 1 : 0;
+        const u64 cand = step_n ? lo + (u64)lane
+                                : lo + (span / 65) * (u64)(lane + 1) + ((span % 65) * (u64)(lane + 1)) / 65;  // = lo + span*(lane+1)/65, no overflow
+        const bool active = cand < hi;
+        bool le = false;
+        if (active) {
+            const u64 j = diag - 1 - cand;
+            le = key_le<RANK>(p.a[cand], RANK ? p.ra[cand] : 0, p.b[j], RANK ? p.rb[j] : 0);
+        }
+        const u64 m_le = __ballot(le), m_act = __ballot(active);
+        const int n_true = __popcll(m_le);            // lanes 0 .. n_true-1 are true (monotone)
+        const int n_act = __popcll(m_act);
+        // first false candidate = lane n_true (if active) -> new hi; last true candidate -> new lo
+        const u64 c_last_true = __shfl(cand, n_true > 0 ? n_true - 1 : 0, 64);
+        const u64 c_first_false = __shfl(cand, n_true < 64 ? n_true : 63, 64);
+        const u64 nlo = n_true > 0 ? c_last_true + 1 : lo;
+        const u64 nhi = n_true < n_act ? c_first_false : hi;
+        lo = nlo;
+        hi = nhi;
+    }
+    if (lane == 0) p.mp[t] = lo;
 }
 
 // UKM_OP_MERGE_INTERNAL (ukm_internal.h): plain 2-way MERGE of two non-decreasing streams, every record
@@ -714,18 +769,18 @@ int run_setop_pass(ukm_ctx *c, int op, const u64 *a, const u32 *ta, const u32 *r
         UKM_HIP(hipMemsetAsync(ctl, 0, nzero * sizeof(u64), c->stream));
         if (attempt == (c->setop_force_ticket ? 1 : 0)) {
             if (p.ntiles >= 4 * PART_COARSE) {
-                const unsigned cblocks = (unsigned)((p.ntiles / PART_COARSE + 2 + 255) / 256);
+                const unsigned cblocks = (unsigned)((p.ntiles / PART_COARSE + 2 + 3) / 4);  // one wave per coarse boundary
                 if (rank) {
-                    hipLaunchKernelGGL((setop_partition_kernel<true, 1>), dim3(cblocks), dim3(256), 0, c->stream, p, (int)tile_items);
+                    hipLaunchKernelGGL((setop_partition_coop_kernel<true, 1>), dim3(cblocks), dim3(256), 0, c->stream, p, (int)tile_items);
                     hipLaunchKernelGGL((setop_partition_kernel<true, 2>), dim3(pblocks), dim3(256), 0, c->stream, p, (int)tile_items);
                 } else {
-                    hipLaunchKernelGGL((setop_partition_kernel<false, 1>), dim3(cblocks), dim3(256), 0, c->stream, p, (int)tile_items);
+                    hipLaunchKernelGGL((setop_partition_coop_kernel<false, 1>), dim3(cblocks), dim3(256), 0, c->stream, p, (int)tile_items);
                     hipLaunchKernelGGL((setop_partition_kernel<false, 2>), dim3(pblocks), dim3(256), 0, c->stream, p, (int)tile_items);
                 }
-            } else if (rank) {
-                hipLaunchKernelGGL((setop_partition_kernel<true, 0>), dim3(pblocks), dim3(256), 0, c->stream, p, (int)tile_items);
             } else {
-                hipLaunchKernelGGL((setop_partition_kernel<false, 0>), dim3(pblocks), dim3(256), 0, c->stream, p, (int)tile_items);
+                const unsigned wblocks = (unsigned)((p.ntiles + 1 + 3) / 4);  // one wave per boundary
+                if (rank) hipLaunchKernelGGL((setop_partition_coop_kernel<true, 0>), dim3(wblocks), dim3(256), 0, c->stream, p, (int)tile_items);
+                else hipLaunchKernelGGL((setop_partition_coop_kernel<false, 0>), dim3(wblocks), dim3(256), 0, c->stream, p, (int)tile_items);
             }
         }
         (void)hipEventRecord(c->ev_k0, c->stream);
@@ -783,22 +838,21 @@ int ukm_dev_setop2_link(ukm_ctx *c, int op, const u64 *a, const u32 *ta, u64 na_
     u64 *st = nullptr;
     const unsigned pblocks = (unsigned)((p.ntiles + 1 + 255) / 256);
     const bool small = p.ntiles < 4 * PART_COARSE;
-    // small: every thread of the single-level partition kernel clears one status line, so the array is sized to
-    // the partition grid; otherwise a memset does it
-    const size_t nstat = small ? lb_status_words((u64)pblocks * 256) : lb_status_words(p.ntiles);
+    const size_t nstat = lb_status_words(p.ntiles + 1);
     UKM_TRY(ws_alloc_t(c, nstat + p.ntiles + 1, &st));
-    if (small) p.zero_status = 1;
+    if (small) p.zero_status = (u32)(p.ntiles + 1);  // cleared by the partition kernel: one launch less
     else UKM_HIP(hipMemsetAsync(st, 0, nstat * sizeof(u64), c->stream));
     p.result = ctl;
     p.ticket = (u32 *)(ctl + 2);
     p.status = st;
     p.mp = st + nstat;
     if (!small) {
-        const unsigned cblocks = (unsigned)((p.ntiles / PART_COARSE + 2 + 255) / 256);
-        hipLaunchKernelGGL((setop_partition_kernel<false, 1>), dim3(cblocks), dim3(256), 0, c->stream, p, (int)tile_items);
+        const unsigned cblocks = (unsigned)((p.ntiles / PART_COARSE + 2 + 3) / 4);  // one wave per coarse boundary
+        hipLaunchKernelGGL((setop_partition_coop_kernel<false, 1>), dim3(cblocks), dim3(256), 0, c->stream, p, (int)tile_items);
         hipLaunchKernelGGL((setop_partition_kernel<false, 2>), dim3(pblocks), dim3(256), 0, c->stream, p, (int)tile_items);
     } else {
-        hipLaunchKernelGGL((setop_partition_kernel<false, 0>), dim3(pblocks), dim3(256), 0, c->stream, p, (int)tile_items);
+        const unsigned wblocks = (unsigned)((p.ntiles + 1 + 3) / 4);  // one wave per boundary
+        hipLaunchKernelGGL((setop_partition_coop_kernel<false, 0>), dim3(wblocks), dim3(256), 0, c->stream, p, (int)tile_items);
     }
     if (tax) launch_op<true, false, NTS, VT_TAX>(op, p, c->stream, c->setop_force_ticket);
     else launch_op<false, false, NTS, VT_PLAIN>(op, p, c->stream, c->setop_force_ticket);
