@@ -263,6 +263,8 @@ __global__ __launch_bounds__(NT) void window_kernel(WinArgs p) {
         }
         u64 accP = 0, accQ = 0;
         u64 lp[PPT], lq[PPT];
+        u32 pk_w0 = 0, pk_w1 = 0, bad_w0 = 0, bad_w1 = 0;  // codes only
+        static_assert(PPT <= 16, "a thread's positions must span at most two packed words");
 #pragma unroll
         for (int s = 0; s < PPT; s++) {
             const int m = m0 + s;
@@ -291,12 +293,22 @@ __global__ __launch_bounds__(NT) void window_kernel(WinArgs p) {
                 lq[s] = accQ;
             } else {
                 const u32 b = (u32)s_t.lut[c] & 15u;
-                // first base of a k-mer is most significant: pack position m at bits [2*(15 - m%16)] of word m/16
+                // first base of a k-mer is most significant: position m goes to bits [2*(15 - m%16)] of word m/16.
+                // A thread's PPT consecutive positions touch at most two words: accumulate in registers and
+                // issue one LDS atomic per touched word (not one per position)
                 if (m < TBX) {
-                    atomicOr(&s_pk[m >> 4], (b & 3u) << (2 * (15 - (m & 15))));
-                    if (b > 3) atomicOr(&s_bad[m >> 5], 1u << (m & 31));
+                    const u32 bits = (b & 3u) << (2 * (15 - (m & 15)));
+                    if ((m >> 4) == (m0 >> 4)) pk_w0 |= bits; else pk_w1 |= bits;
+                    const u32 bb = (b > 3) ? (1u << (m & 31)) : 0u;
+                    if ((m >> 5) == (m0 >> 5)) bad_w0 |= bb; else bad_w1 |= bb;
                 }
             }
+        }
+        if (!HASH) {
+            if (pk_w0) atomicOr(&s_pk[m0 >> 4], pk_w0);
+            if (pk_w1) atomicOr(&s_pk[(m0 >> 4) + 1], pk_w1);
+            if (bad_w0) atomicOr(&s_bad[m0 >> 5], bad_w0);
+            if (bad_w1) atomicOr(&s_bad[(m0 >> 5) + 1], bad_w1);
         }
         if (HASH) {
             // block-wide exclusive XOR scan of the per-thread totals
