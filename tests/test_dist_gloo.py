@@ -143,8 +143,12 @@ class _NumpyCtx:
         return self._t(out)
 
     def inter(self, files, taxids=None):
+        # ukm_inter's semantics incl. the reference quirk: an EMPTY later stream ends the fold and the running
+        # result is kept (inter.go:211-217); an empty first stream gives nothing
         out = self._u(files[0])
         for f in files[1:]:
+            if len(out) == 0 or f.numel() == 0:
+                break
             out = np.intersect1d(out, self._u(f))
         return self._t(out)
 
@@ -236,3 +240,42 @@ def test_sharded_setop_pipelined_world2():
     cat = lambda op: np.concatenate([ret[r][op] for r in range(world)])
     assert np.array_equal(cat("union"), gu) and np.array_equal(cat("inter"), gi) and np.array_equal(cat("diff"), gd)
     assert np.array_equal(cat("common"), v[c >= 2])
+
+
+def _inter_quirk_worker(rank, world, port, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        ctx = _NumpyCtx()
+        hi = np.uint64((1 << 41) + 1)       # belongs to rank 1's prefix range of a 42-bit code space
+        mk = lambda *v: torch.from_numpy(np.array(v, dtype=np.uint64).view(np.int64))
+        out = {}
+        # case 1: A = {1, 2^41+1}, B = {1}: rank 1's slice of B is empty, B is not -> rank 1 returns nothing
+        A = mk(1, hi) if rank == 0 else mk()
+        B = mk(1) if rank == 0 else mk()
+        out["slice_empty"] = ud.sharded_setop(ctx, "inter", [A, B], 42).numpy().view(np.uint64).copy()
+        # case 2: B is GLOBALLY empty -> the reference stops and keeps A (every rank keeps its range of A), C is never looked at
+        C3 = mk(7) if rank == 1 else mk()
+        out["file_empty"] = ud.sharded_setop(ctx, "inter", [A, mk(), C3], 42).numpy().view(np.uint64).copy()
+        # case 3: the chunks of B live on the OTHER rank
+        A2 = mk(1, 5, hi) if rank == 0 else mk(9)
+        B2 = mk() if rank == 0 else mk(5, 9, hi)
+        out["cross"] = ud.sharded_setop(ctx, "inter", [A2, B2], 42).numpy().view(np.uint64).copy()
+        ret[rank] = out
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_inter_empty_slice_vs_empty_file_world2():
+    """`inter` stops at an empty later FILE (inter.go:211-217), not at an empty per-rank slice of a file."""
+    world = 2
+    port = _free_port()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_inter_quirk_worker, args=(world, port, ret), nprocs=world, join=True)
+    cat = lambda key: np.concatenate([ret[r][key] for r in range(world)])
+    hi = (1 << 41) + 1
+    assert cat("slice_empty").tolist() == [1]
+    assert cat("file_empty").tolist() == [1, hi]
+    assert cat("cross").tolist() == [5, 9, hi]

@@ -1,0 +1,208 @@
+"""BASELINE.json configs 3 and 4 at their real FILE COUNTS (100-stream merge tree with odd carries;
+1000-link chained inter / diff fold with taxids, host peeks, early exits), bit-exact against the CPU
+oracle at per-file sizes the oracle finishes in seconds.  Reference semantics: union.go:186-305,
+util-sort.go:227-606 (mergeChunksFile), inter.go:205-286, diff.go:379-454.
+
+Every case also runs with UKM_FORCE_TICKET=1 (the dispatch-order independent kernels)."""
+import numpy as np
+import pytest
+
+from conftest import splitmix64, synth_tree
+
+pytestmark = pytest.mark.gpu
+
+SEED = 0x756E696B6D6572
+
+
+@pytest.fixture(scope="module", params=["blockidx", "ticket"])
+def env(request):
+    import os
+    from oracle import oracle as O
+    from unikmer_amd import lib as L
+    old = os.environ.get("UKM_FORCE_TICKET")
+    if request.param == "ticket":
+        os.environ["UKM_FORCE_TICKET"] = "1"   # read by ukm_ctx_create
+    else:
+        os.environ.pop("UKM_FORCE_TICKET", None)
+    ctx = L.Context(0)
+    if old is None:
+        os.environ.pop("UKM_FORCE_TICKET", None)
+    else:
+        os.environ["UKM_FORCE_TICKET"] = old
+    child, parent = synth_tree(5, 8)
+    ctx.taxonomy_load(child, parent)
+    tax = O.Taxonomy(child, parent)
+    yield O, L, ctx, tax, len(child)
+    ctx.close()
+
+
+def _universe(n, gap_bits=24, seed=SEED):
+    j = np.arange(n, dtype=np.uint64)
+    gaps = np.uint64(1) + (splitmix64(np.uint64(seed) ^ j) & np.uint64((1 << gap_bits) - 1))
+    return np.cumsum(gaps, dtype=np.uint64)
+
+
+def _member(n, f, p, seed):
+    """membership draw of file f over a universe of n codes (independent draws per file)"""
+    h = splitmix64(np.uint64(seed + 1000 * (f + 1)) ^ np.arange(n, dtype=np.uint64))
+    return (h >> np.uint64(11)).astype(np.float64) / float(1 << 53) < p
+
+
+def _taxids(codes, T, salt):
+    return (np.uint64(1) + splitmix64(np.uint64(SEED + 2 + salt) ^ codes) % np.uint64(T)).astype(np.uint32)
+
+
+# ------------------------------------------------------------------------------------------- config 3
+@pytest.mark.parametrize("nfiles", [100, 101, 37])
+def test_config3_union_and_merge_many_files(env, nfiles):
+    """union of 100 sorted files (p = 0.5 draws over one universe) and mergeChunksFile -u / -d / plain over
+    the same streams; 101 and 37 files give odd carries at several tree levels."""
+    O, L, ctx, tax, T = env
+    U = _universe(40_000)
+    files = [U[_member(len(U), f, 0.5, 11)] for f in range(nfiles)]
+    assert np.array_equal(ctx.union(files), O.union(files))
+    for mode in (L.UNIQUE, L.REPEATED, L.PLAIN):
+        for final in (True, False):
+            assert np.array_equal(ctx.merge_k(files, mode=mode, final_round=final),
+                                  O.merge_k(files, mode=mode, final_round=final)), (mode, final)
+    # with taxids: the LCA fold over up to `nfiles` occurrences of a code
+    taxs = [_taxids(f, T, i) for i, f in enumerate(files)]
+    gk, gt = ctx.union(files, taxs)
+    ok, ot = O.union(files, taxs, tax)
+    assert np.array_equal(gk, ok) and np.array_equal(gt, ot)
+    gk, gt = ctx.merge_k(files, taxs, mode=L.UNIQUE)
+    assert np.array_equal(gk, ok) and np.array_equal(gt, ot)
+    gk, gt = ctx.merge_k(files, taxs, mode=L.REPEATED)
+    ok, ot = O.merge_k(files, taxs, mode=O.REPEATED, tax=tax)
+    assert np.array_equal(gk, ok) and np.array_equal(gt, ot)
+
+
+def test_config3_union_100_files_dirty_inputs(env):
+    """the reference's hash-map union accepts anything (union.go:186-208): one multiset file, one unsorted
+    file and one empty file among 100, at positions that land in different tree levels"""
+    O, L, ctx, tax, T = env
+    rng = np.random.default_rng(3)
+    U = _universe(30_000)
+    files = [U[_member(len(U), f, 0.5, 29)] for f in range(100)]
+    files[17] = np.sort(np.concatenate([files[17], files[17][:500]]))     # duplicates inside a file
+    files[64] = rng.permutation(files[64])                                # unsorted
+    files[99] = np.empty(0, np.uint64)                                    # empty (and the odd one out)
+    files[3] = rng.permutation(np.concatenate([files[3], files[3][-50:]]))  # unsorted AND duplicated
+    assert np.array_equal(ctx.union(files), O.union(files))
+    taxs = [_taxids(f, T, i) for i, f in enumerate(files)]
+    gk, gt = ctx.union(files, taxs)
+    ok, ot = O.union(files, taxs, tax)
+    assert np.array_equal(gk, ok) and np.array_equal(gt, ot)
+
+
+def test_config3_merge_uneven_stream_sizes(env):
+    """sorted chunk files of very different sizes (a real `sort -m` leaves a short last chunk), some empty"""
+    O, L, ctx, tax, T = env
+    rng = np.random.default_rng(5)
+    sizes = [50_000, 0, 3, 20_000, 1, 9728, 9729, 0, 70_000, 64, 65, 19456, 5, 30_000, 12, 7, 40_000]
+    streams = [np.sort(rng.integers(0, 1 << 30, n).astype(np.uint64)) for n in sizes]
+    taxs = [_taxids(s + np.uint64(i), T, i) for i, s in enumerate(streams)]
+    for mode in (L.PLAIN, L.UNIQUE, L.REPEATED):
+        for final in (True, False):
+            assert np.array_equal(ctx.merge_k(streams, mode=mode, final_round=final),
+                                  O.merge_k(streams, mode=mode, final_round=final)), (mode, final)
+            gk, gt = ctx.merge_k(streams, taxs, mode=mode, final_round=final)
+            ok, ot = O.merge_k(streams, taxs, mode=mode, final_round=final, tax=tax)
+            assert np.array_equal(gk, ok), (mode, final)
+            if mode != L.PLAIN:   # plain: equal codes keep stream order in both, but check it explicitly below
+                assert np.array_equal(gt, ot), (mode, final)
+    # plain merge is stable: equal codes keep (stream, position) order
+    gk, gt = ctx.merge_k(streams, taxs, mode=L.PLAIN)
+    cat = np.concatenate(streams)
+    o = np.argsort(cat, kind="stable")
+    assert np.array_equal(gk, cat[o]) and np.array_equal(gt, np.concatenate(taxs)[o])
+
+
+# ------------------------------------------------------------------------------------------- config 4
+def _chain_files(nfiles, n_universe, p, core_frac, seed, T):
+    """config 4 shape: `nfiles` draws with probability p over one universe; a `core_frac` share of the
+    universe is in EVERY file so that the 1000-fold intersection stays non-empty (p alone: 0.9^1000 = 0)."""
+    U = _universe(n_universe, 24, SEED + seed)
+    core = _member(n_universe, 10_000, core_frac, seed) if core_frac > 0 else np.zeros(n_universe, bool)
+    files, taxs = [], []
+    for f in range(nfiles):
+        m = _member(n_universe, f, p, seed) | core
+        files.append(U[m])
+        taxs.append(_taxids(files[-1], T, f))
+    return files, taxs
+
+
+def _check_all(O, L, ctx, tax, files, taxs, expect_nonempty_inter=None):
+    gk, gt = ctx.inter(files, taxs)
+    ok, ot = O.inter(files, taxs, tax)
+    assert np.array_equal(gk, ok) and np.array_equal(gt, ot)
+    if expect_nonempty_inter is not None:
+        assert (len(ok) > 0) == expect_nonempty_inter
+    assert np.array_equal(ctx.inter(files), O.inter(files))
+    gk, gt = ctx.inter(files, taxs, mix_taxid=True)
+    ok, ot = O.inter(files, taxs, tax, mix_taxid=True)
+    assert np.array_equal(gk, ok) and np.array_equal(gt, ot)
+    gk, gt = ctx.diff(files, taxs)
+    ok, ot = O.diff(files, taxs, tax)
+    assert np.array_equal(gk, ok) and np.array_equal(gt, ot)
+    assert np.array_equal(ctx.diff(files), O.diff(files))
+    gk, gt = ctx.diff(files, taxs, compare_taxid=True)
+    ok, ot = O.diff(files, taxs, tax, compare_taxid=True)
+    assert np.array_equal(gk, ok) and np.array_equal(gt, ot)
+
+
+def test_config4_chain_1000_files_nonempty(env):
+    """inter / diff / diff -t over 1000 files with taxids: the running result survives all 999 links (every
+    host peek at 4, 8, ..., 64, 128, ... sees a non-zero count; the small-link path clears its own status)"""
+    O, L, ctx, tax, T = env
+    files, taxs = _chain_files(1000, 2_400, 0.9, 0.15, 41, T)
+    # give the first file private codes so that diff over 999 files is non-empty as well
+    U2 = _universe(300, 24, SEED + 99) + np.uint64(1 << 40)
+    files[0] = np.sort(np.concatenate([files[0], U2]))
+    taxs[0] = _taxids(files[0], T, 0)
+    _check_all(O, L, ctx, tax, files, taxs, expect_nonempty_inter=True)
+    assert len(ctx.diff(files)) >= 300
+
+
+def test_config4_chain_empties_midway(env):
+    """p = 0.8 without a core: the intersection runs empty near link 40 (between two host peeks); the fold
+    must stop there (inter.go:283-286) and diff must still visit every file"""
+    O, L, ctx, tax, T = env
+    files, taxs = _chain_files(1000, 2_500, 0.8, 0.0, 43, T)
+    _check_all(O, L, ctx, tax, files, taxs, expect_nonempty_inter=False)
+
+
+def test_config4_chain_empty_file_mid_chain(env):
+    """an EMPTY later file: inter keeps the running result and stops (inter.go:211-217, flagBreak); diff
+    skips it and goes on"""
+    O, L, ctx, tax, T = env
+    files, taxs = _chain_files(300, 2_400, 0.9, 0.2, 47, T)
+    for pos in (150, 5, 299):
+        f2, t2 = list(files), list(taxs)
+        f2[pos] = np.empty(0, np.uint64)
+        t2[pos] = np.empty(0, np.uint32)
+        _check_all(O, L, ctx, tax, f2, t2)
+
+
+def test_config4_chain_multi_tile_links(env):
+    """links of several hundred tiles (first file 1.2e6 codes: the separate-memset, two-level partition path
+    of ukm_dev_setop2_link) chained over 48 files with taxids"""
+    O, L, ctx, tax, T = env
+    files, taxs = _chain_files(48, 1_400_000, 0.9, 0.3, 53, T)
+    _check_all(O, L, ctx, tax, files, taxs, expect_nonempty_inter=True)
+
+
+def test_config4_chain_with_duplicates_falls_back(env):
+    """a multiset file inside a long chain: the chained fold reports it and the synchronous fold (rank path,
+    'equality advances both cursors') takes over"""
+    O, L, ctx, tax, T = env
+    files, taxs = _chain_files(40, 3_000, 0.9, 0.3, 59, T)
+    files[20] = np.sort(np.concatenate([files[20], files[20][::7]]))
+    taxs[20] = _taxids(files[20], T, 20)
+    files[0] = np.sort(np.concatenate([files[0], files[0][::11]]))
+    taxs[0] = _taxids(files[0], T, 0)
+    for fn, ofn in ((ctx.inter, O.inter), (ctx.diff, O.diff)):
+        gk, gt = fn(files, taxs)
+        ok, ot = ofn(files, taxs, tax)
+        assert np.array_equal(gk, ok) and np.array_equal(gt, ot)
+        assert np.array_equal(fn(files), ofn(files))

@@ -1,0 +1,125 @@
+"""The multi-GPU path (unikmer_amd/dist.py) with the REAL HIP context under it and a world of two ranks.
+A gpurun box has one GPU, so both ranks share cuda:0 and the collectives run over gloo (dist._all_to_all
+stages device tensors through the host for that backend only); everything else — ukm_partition_points, the
+per-rank k-way merges and n-way set operations — is the product path on the device.  The same code runs
+over `nccl` (= RCCL) with one rank per GPU; test_gpu_parity.py has the world-1 nccl run."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+KEY_BITS = 42
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _files(rank, nfiles=4, n=150_000):
+    out = []
+    for f in range(nfiles):
+        rng = np.random.default_rng(1000 * f + rank)
+        # the two ranks' chunks of one logical file overlap in value and share some codes
+        base = np.random.default_rng(500 + f).integers(0, 1 << KEY_BITS, n // 3, dtype=np.uint64)
+        out.append(np.unique(np.concatenate([rng.integers(0, 1 << KEY_BITS, n, dtype=np.uint64), base])))
+    return out
+
+
+def _taxids(keys, salt, T):
+    """a taxid per CODE (the same on both ranks), different per file"""
+    with np.errstate(over="ignore"):
+        h = (keys + np.uint64(salt)) * np.uint64(0x9E3779B97F4A7C15)
+    return ((h >> np.uint64(40)) % np.uint64(T) + np.uint64(1)).astype(np.uint32)
+
+
+def _worker(rank, world, port, ret):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    sys.path.insert(0, os.path.join(root, "tests"))
+    import torch
+    import torch.distributed as dist
+    from conftest import synth_tree
+    from unikmer_amd import dist as ud
+    from unikmer_amd import lib
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        dev = torch.device("cuda", 0)
+        torch.cuda.set_device(dev)
+        ctx = lib.Context(0, stream=torch.cuda.current_stream(dev).cuda_stream)
+        child, parent = synth_tree(4, 8)
+        ctx.taxonomy_load(child, parent)
+        T = len(child)
+        up = lambda a, dt=np.int64: torch.from_numpy(np.ascontiguousarray(a).view(dt)).to(dev)
+        down = lambda t: t.cpu().numpy().view(np.uint64).copy()
+        files = _files(rank)
+        dfiles = [up(f) for f in files]
+        dtax = [up(_taxids(f, i, T), np.int32) for i, f in enumerate(files)]
+        out = {}
+        for op in ("union", "inter", "diff"):
+            out[op] = down(ud.sharded_setop(ctx, op, dfiles, KEY_BITS))
+            k, t = ud.sharded_setop(ctx, op, dfiles, KEY_BITS, files_taxids=dtax)
+            out[op + "_t"] = (down(k), t.cpu().numpy().view(np.uint32).copy())
+        out["common"] = down(ud.sharded_setop(ctx, "common", dfiles, KEY_BITS, threshold=3))
+        # inter: empty per-rank slice vs globally empty later file (inter.go:211-217)
+        hi = (1 << (KEY_BITS - 1)) + 1
+        mk = lambda *v: up(np.array(v, dtype=np.uint64))
+        A = mk(1, hi) if rank == 0 else mk()
+        B = mk(1) if rank == 0 else mk()
+        out["slice_empty"] = down(ud.sharded_setop(ctx, "inter", [A, B], KEY_BITS))
+        out["file_empty"] = down(ud.sharded_setop(ctx, "inter", [A, mk(), mk(7) if rank else mk()], KEY_BITS))
+        # the count path: unsorted codes on both ranks -> distributed sort / distinct set
+        rng = np.random.default_rng(77 + rank)
+        x = rng.integers(0, 1 << KEY_BITS, 200_000 + 999 * rank, dtype=np.uint64)
+        x[:2000] = np.random.default_rng(5).integers(0, 1 << KEY_BITS, 2000, dtype=np.uint64)   # shared across ranks
+        out["x"] = x
+        out["sorted"] = down(ud.sharded_sort(ctx, up(x.copy()), KEY_BITS))
+        out["distinct"] = down(ud.sharded_count(ctx, up(x.copy()), KEY_BITS))
+        ret[rank] = out
+        ctx.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_ops_two_ranks_real_context():
+    import torch.multiprocessing as mp
+    from conftest import synth_tree
+    from oracle import oracle as O
+    world = 2
+    port = _free_port()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(world, port, ret), nprocs=world, join=True)
+    child, parent = synth_tree(4, 8)
+    tax = O.Taxonomy(child, parent)
+    T = len(child)
+    nfiles = 4
+    # logical file f = union over ranks of the rank-local chunks (LCA-folded where both ranks hold a code)
+    logical, logical_t = [], []
+    for f in range(nfiles):
+        chunks = [_files(r)[f] for r in range(world)]
+        k, t = O.union(chunks, [_taxids(c, f, T) for c in chunks], tax)
+        logical.append(k)
+        logical_t.append(t)
+    cat = lambda key: np.concatenate([ret[r][key] for r in range(world)])
+    catt = lambda key, j: np.concatenate([ret[r][key][j] for r in range(world)])
+    for op, ofn in (("union", O.union), ("inter", O.inter), ("diff", O.diff)):
+        assert np.array_equal(cat(op), ofn(logical)), op
+        ek, et = ofn(logical, logical_t, tax)
+        assert np.array_equal(catt(op + "_t", 0), ek) and np.array_equal(catt(op + "_t", 1), et), op
+    assert np.array_equal(cat("common"), O.common(logical, 3))
+    hi = (1 << (KEY_BITS - 1)) + 1
+    assert cat("slice_empty").tolist() == [1]
+    assert cat("file_empty").tolist() == [1, hi]
+    allx = np.concatenate([ret[r]["x"] for r in range(world)])
+    assert np.array_equal(cat("sorted"), np.sort(allx))
+    assert np.array_equal(cat("distinct"), np.unique(allx))

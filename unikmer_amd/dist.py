@@ -14,6 +14,27 @@ import torch
 import torch.distributed as dist
 
 
+class _Done:
+    """stand-in for an async Work handle of an exchange that has already completed"""
+
+    def wait(self):
+        return True
+
+
+def _all_to_all(out, inp, out_splits=None, in_splits=None, group=None, async_op=False):
+    """dist.all_to_all_single, plus ONE extra case: device tensors over the `gloo` backend (1-GPU boxes where
+    several ranks share cuda:0 and the control plane is gloo — tests and bench.py's UKM_BENCH_ONE_GPU hook) are
+    staged through host memory, because gloo's all-to-all only takes CPU tensors.  On `nccl` (= RCCL) the
+    tensors go to the collective as they are."""
+    if inp.is_cuda and dist.get_backend(group) == "gloo":
+        h_out = torch.empty(out.shape, dtype=out.dtype)
+        dist.all_to_all_single(h_out, inp.cpu(), output_split_sizes=out_splits, input_split_sizes=in_splits, group=group)
+        out.copy_(h_out)
+        return _Done() if async_op else None
+    return dist.all_to_all_single(out, inp, output_split_sizes=out_splits, input_split_sizes=in_splits, group=group,
+                                  async_op=async_op)
+
+
 def prefix_splitters(key_bits, world):
     """world+1 boundaries of the code space [0, 2^key_bits): rank g owns
     [s[g], s[g+1]).  key_bits = 2k for k-mer codes, 64 for hashes."""
@@ -40,16 +61,14 @@ def exchange_sorted(keys, counts, taxids=None, group=None):
     assert len(counts) == world and sum(counts) == keys.numel()
     send = torch.tensor(counts, dtype=torch.int64, device=keys.device)
     recv = torch.empty(world, dtype=torch.int64, device=keys.device)
-    dist.all_to_all_single(recv, send, group=group)
+    _all_to_all(recv, send, group=group)
     recv_counts = [int(x) for x in recv.cpu()]
     out = torch.empty(sum(recv_counts), dtype=keys.dtype, device=keys.device)
-    dist.all_to_all_single(out, keys, output_split_sizes=recv_counts, input_split_sizes=list(counts),
-                           group=group)
+    _all_to_all(out, keys, recv_counts, list(counts), group)
     out_t = None
     if taxids is not None:
         out_t = torch.empty(sum(recv_counts), dtype=taxids.dtype, device=taxids.device)
-        dist.all_to_all_single(out_t, taxids, output_split_sizes=recv_counts,
-                               input_split_sizes=list(counts), group=group)
+        _all_to_all(out_t, taxids, recv_counts, list(counts), group)
     return out, out_t, recv_counts
 
 
@@ -72,7 +91,8 @@ def sharded_setop(ctx, op, files_keys, key_bits, files_taxids=None, group=None, 
        so the received pieces of one logical file position are concatenated by rank order),
     4. the single-GPU n-way op runs on the rank's range.
     Returns this rank's part of the result; concatenating the parts in rank order gives the
-    globally sorted output, bit-identical to the 1-GPU result.
+    globally sorted output, bit-identical to the 1-GPU result (including `inter`'s empty-later-file rule, which
+    is decided on the global file sizes, not on a rank's slice).
 
     files_keys: list of 1-D int64 device tensors; every rank must pass the SAME number of
     files (file i of every rank are the per-rank chunks of logical input i).  `ctx` must run on
@@ -91,23 +111,28 @@ def sharded_setop(ctx, op, files_keys, key_bits, files_taxids=None, group=None, 
     if nfiles:
         send = torch.tensor(counts_all, dtype=torch.int64, device=dev).t().contiguous()   # [world, nfiles]
         recv = torch.empty_like(send)
-        dist.all_to_all_single(recv, send, group=group)
+        _all_to_all(recv, send, group=group)
         rc = recv.cpu().tolist()                                                            # [source rank][file]
         recv_counts_all = [[int(rc[src][i]) for src in range(world)] for i in range(nfiles)]
+    # GLOBAL size of every logical file (`inter` needs it: see below); same small-message pattern
+    global_sizes = [0] * nfiles
+    if nfiles:
+        gs = torch.tensor([k.numel() for k in files_keys], dtype=torch.int64,
+                          device=dev if dist.get_backend(group) != "gloo" else "cpu")
+        dist.all_reduce(gs, op=dist.ReduceOp.SUM, group=group)
+        global_sizes = [int(x) for x in gs.cpu()]
 
     def issue(i):
         """start the all-to-all-v of file i (asynchronous: it overlaps the merge of file i - 1)"""
         k = files_keys[i]
         rcv = recv_counts_all[i]
         out = torch.empty(sum(rcv), dtype=k.dtype, device=k.device)
-        works = [dist.all_to_all_single(out, k, output_split_sizes=rcv, input_split_sizes=list(counts_all[i]),
-                                        group=group, async_op=True)]
+        works = [_all_to_all(out, k, rcv, list(counts_all[i]), group, async_op=True)]
         out_t = None
         if files_taxids is not None:
             t = files_taxids[i]
             out_t = torch.empty(sum(rcv), dtype=t.dtype, device=t.device)
-            works.append(dist.all_to_all_single(out_t, t, output_split_sizes=rcv, input_split_sizes=list(counts_all[i]),
-                                                group=group, async_op=True))
+            works.append(_all_to_all(out_t, t, rcv, list(counts_all[i]), group, async_op=True))
         return works, out, out_t
 
     local = []
@@ -131,6 +156,18 @@ def sharded_setop(ctx, op, files_keys, key_bits, files_taxids=None, group=None, 
     fn = {"union": ctx.union, "inter": ctx.inter, "diff": ctx.diff, "common": ctx.common}[op]
     if op == "common":
         return fn(local, kw["threshold"], local_t)
+    if op == "inter" and nfiles > 1:
+        # The reference's `inter` stops at an EMPTY later file and keeps the running result (inter.go:211-217;
+        # ukm_inter reproduces it).  That decision is about the GLOBAL file: a rank whose slice of file i is
+        # empty while the file is not must return nothing for its range, and every rank must stop at the
+        # first globally empty later file.
+        stop = next((i for i in range(1, nfiles) if global_sizes[i] == 0), nfiles)
+        local = local[:stop]
+        if local_t is not None:
+            local_t = local_t[:stop]
+        if any(local[i].numel() == 0 for i in range(1, stop)):
+            empty = local[0][:0]
+            return (empty, local_t[0][:0]) if local_t is not None else empty
     return fn(local, local_t)
 
 
