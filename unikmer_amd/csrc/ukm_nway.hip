@@ -15,6 +15,7 @@
 #include <vector>
 
 #include "ukm_device.h"
+#include "ukm_kway.h"
 
 namespace {
 
@@ -213,6 +214,30 @@ int tree_reduce(ukm_ctx *ctx, std::vector<Stream> ss, int op, u32 flags, bool ta
     return UKM_OK;
 }
 
+// k-way streaming merge (ukm_kway.hip) over >= 3 non-empty sorted streams.  *done = false: the inputs need the
+// general route (an unsorted stream, a very long run of one code); the workspace it used is given back.
+int try_kway(ukm_ctx *ctx, int op, const std::vector<Stream> &ss, bool tax, u64 *fk, u32 *ft, u64 fcap, u64 *n_out,
+             bool *done) {
+    *done = false;
+    if (ss.size() < 3 || !ukm_kway_enabled()) return UKM_OK;
+    std::vector<const u64 *> kp(ss.size());
+    std::vector<const u32 *> tp(ss.size());
+    std::vector<u64> ln(ss.size());
+    for (size_t i = 0; i < ss.size(); i++) {
+        kp[i] = ss[i].k;
+        tp[i] = ss[i].t;
+        ln[i] = ss[i].n;
+    }
+    WsMark mark = ws_mark(ctx);
+    bool fallback = false;
+    const int rc = ukm_dev_kway(ctx, op, kp.data(), tax ? tp.data() : nullptr, ln.data(), (int)ss.size(), tax, fk, ft, fcap,
+                                n_out, &fallback);
+    ws_release(ctx, mark);
+    UKM_TRY(rc);
+    *done = !fallback;
+    return UKM_OK;
+}
+
 // All records of the (non-empty) streams as ONE sequence ordered by code, equal codes in stream
 // order (= a stable sort of the concatenation).  Sorted streams (chunk files, .unik sets) go through
 // the keep-everything merge tree; anything else is concatenated and radix sorted.
@@ -235,6 +260,9 @@ int merged_sequence(ukm_ctx *ctx, const std::vector<Stream> &all, bool tax, u64 
         UKM_TRY(ws_alloc_t(ctx, n + 1, k));
         if (tax) UKM_TRY(ws_alloc_t(ctx, n + 1, t));
         u64 nm = 0;
+        bool done = false;
+        UKM_TRY(try_kway(ctx, UKM_KWAY_MERGE, ss, tax, *k, *t, n, &nm, &done));
+        if (done) return UKM_OK;
         const int r = tree_reduce(ctx, ss, UKM_OP_MERGE_INTERNAL, 0, tax, *k, *t, n, &nm);
         if (r == UKM_OK) return UKM_OK;
         if (r != UKM_ERR_UNSORTED) return r;
@@ -340,6 +368,9 @@ extern "C" int ukm_union(ukm_ctx *ctx, const uint64_t *const *keys, const uint32
             UKM_TRY(normalise_set(ctx, ss[0], tax));
             return copy_result(ctx, ss[0], tax, o.k, o.t, out_cap, n_out);
         }
+        bool done = false;
+        UKM_TRY(try_kway(ctx, UKM_KWAY_UNION, ss, tax, o.k, o.t, out_cap, n_out, &done));
+        if (done) return UKM_OK;
         return tree_reduce(ctx, ss, UKM_OP_UNION, flags, tax, o.k, o.t, out_cap, n_out, true);
     });
 }
