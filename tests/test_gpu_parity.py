@@ -339,6 +339,55 @@ def test_nthash(ctx, O, k):
     assert np.array_equal(got, exp)
 
 
+@pytest.mark.parametrize("force", ["1", None])
+def test_nthash_scaled_strip_kernel(ctx, O, monkeypatch, force):
+    """The rolling strip kernel behind `count -H --scale N` (count.go:361,373-375): every k phase (k mod 4),
+    ragged records incl. empty / shorter-than-k ones and record ends inside a strip's warm-up, non-ACGT bytes
+    (zero seed), several tiles, canonical and forward hashes.  force=1 runs it at every scale (a small scale
+    overflows its candidate list and must fall back); None = the library's own choice."""
+    if force is None:
+        monkeypatch.delenv("UKM_NTHASH_STRIP", raising=False)
+    else:
+        monkeypatch.setenv("UKM_NTHASH_STRIP", force)
+    bases = _synth_fasta(1_200_000, SEED + 17).copy()
+    bases[1000:1100] = ord("N")
+    bases[70_000] = ord("n")
+    bases[500_001:500_004] = np.frombuffer(b"acg", dtype=np.uint8)
+    bases[900_000] = ord("R")
+    cuts = np.array([0, 0, 150, 300, 301, 333, 5000, 5000, 65_535, 65_536, 65_600, 262_144, 262_145, 700_000, 1_199_950,
+                     1_200_000], dtype=np.uint64)
+    reads = np.arange(0, 1_200_001, 150, dtype=np.uint64)
+    for k in (1, 2, 23, 31, 50, 51, 64):
+        for scale in (3, 300, 1000, 20000):
+            mh = O.max_hash(scale)
+            for canonical in (True, False):
+                if scale == 3 and (k not in (23, 51) or not canonical):
+                    continue
+                got = ctx.nthash(bases, cuts, k, canonical=canonical, max_hash=mh)
+                exp = O.count_windows(bases, cuts, k, hashed=True, canonical=canonical, max_hash=mh)
+                assert np.array_equal(got, exp), (k, scale, canonical)
+        mh = O.max_hash(1000)
+        assert np.array_equal(ctx.nthash(bases, reads, k, max_hash=mh), O.count_windows(bases, reads, k, hashed=True, max_hash=mh))
+    # tiny inputs, a record exactly k long, an input shorter than one strip
+    for n in (1, 50, 51, 52, 64, 255, 256, 257, 16_384):
+        b = _synth_fasta(n, SEED + n)
+        off = np.array([0, n], dtype=np.uint64)
+        mh = O.max_hash(4)
+        assert np.array_equal(ctx.nthash(b, off, 51, max_hash=mh), O.count_windows(b, off, 51, hashed=True, max_hash=mh)), n
+    # low-complexity sequence: every window has the same hash -> all or nothing, far beyond the candidate list
+    poly = np.full(300_000, ord("A"), dtype=np.uint8)
+    off = np.array([0, 300_000], dtype=np.uint64)
+    h0 = O.count_windows(poly[:31], np.array([0, 31], dtype=np.uint64), 31, hashed=True)[0]
+    for mh in (int(h0), int(h0) - 1):
+        assert np.array_equal(ctx.nthash(poly, off, 31, max_hash=mh), O.count_windows(poly, off, 31, hashed=True, max_hash=mh))
+    # a misaligned base pointer (view shifted by one byte)
+    buf = np.concatenate([np.zeros(1, np.uint8), bases[:300_000]])
+    sh = buf[1:]
+    off = np.array([0, 300_000], dtype=np.uint64)
+    mh = O.max_hash(500)
+    assert np.array_equal(ctx.nthash(sh, off, 31, max_hash=mh), O.count_windows(sh, off, 31, hashed=True, max_hash=mh))
+
+
 def test_circular_and_reads(ctx, O):
     bases = _synth_fasta(50_000, SEED + 1)
     one = np.array([0, 50_000], dtype=np.uint64)

@@ -24,6 +24,8 @@
 //   per-tile prefix and the library's decoupled look-back.
 // Windows that wrap (circular genomes) are recomputed directly from the record.
 // Algorithmic bytes: 1 B/base read, 8 B/window written (8/scale with the Scaled filter).
+#include <stdlib.h>
+
 #include <algorithm>
 
 #include "ukm_device.h"
@@ -437,12 +439,315 @@ __global__ __launch_bounds__(NT) void window_kernel(WinArgs p) {
     }
 }
 
+// ---- Scaled-MinHash sketch of reads: per-lane ROLLING ntHash over strips ------------------------------------
+// The prefix-XOR kernel above spends ~160 lane-operations per window (per-position prefix words, a block
+// scan, two 64-bit variable rotates per window) although with `--scale 1000` only one window in a thousand
+// is ever written.  Here every lane rolls the hash along its own strip of L window starts:
+//     fwd' = rol(fwd, 1) ^ rol(seed[out], k) ^ seed[in]
+//     rev' = ror(rev, 1) ^ ror(seed[comp(out)], 1) ^ rol(seed[comp(in)], k - 1)          
+// The hash of a window is a function of its k bytes only, so the rolling runs straight across record
+// boundaries of the concatenated base array; whether a window lies inside one record is decided for the few
+// values that pass `<= max_hash` (a binary search per CANDIDATE, not per position).  Per step: two byte
+// extracts, two 16-byte LDS table reads (tables indexed by the raw byte: no base translation at all), four
+// 32-bit funnel shifts, four 3-input XORs, two 32-bit compares: ~16 lane-operations per base.  Bases are read
+// straight from global memory, 64 bytes per lane at a time (each lane walks its own strip; a lane's 64-byte
+// piece is one cache line, fetched once).  A strip starts cold at its first window start, i.e. it processes
+// L + k - 1 bases for L windows.
+// Candidates are appended to an LDS list (owner lane, sequence number in the lane), ordered by (lane,
+// sequence) = window order with one block scan, validated against the record table, compacted with
+// ballots and placed with the library's look-back: the output keeps window order, as the reference's
+// iterator does (count.go:361,373-375).  More candidates than the list holds (a tiny --scale, pathological
+// repeats) -> flag, and the caller takes the prefix-XOR kernel.
+constexpr int ST_NT = 256;
+constexpr int ST_CAP = 1024;             // candidate list entries per tile
+constexpr int ST_RND = ST_CAP / ST_NT;   // compaction rounds
+constexpr int ST_NWV = ST_NT / 64;
+
+struct StripArgs {
+    const u8 *bases;
+    const u64 *rec_off;
+    u64 n_rec;
+    u64 total_bases;
+    int k;
+    int canonical;
+    int L;  // window starts per lane, multiple of 64
+    u64 max_hash;
+    u64 *out;
+    u64 out_cap;
+    u64 *status;
+    u32 *ticket;
+    u64 *result;  // [0] total, [1] flags: bit1 = look-back watchdog, bit2 = candidate list overflow
+    u64 ntiles;
+    const u64 *tile_rec;
+};
+
+typedef uint4 uint4_a4 __attribute__((aligned(4)));
+
+// n dwords of the base array starting at byte offset `off` (may be negative or run past the end: such
+// bytes read as 0).  Fast path: plain vector loads.
+template <int N>
+__device__ __forceinline__ void strip_load(const u8 *bases, long long off, u64 total, bool active, u32 (&w)[N]) {
+    const bool fast = active && off >= 0 && (u64)off + 4ull * N <= total;
+    if (fast) {
+        const u8 *src = bases + off;
+#pragma unroll
+        for (int g = 0; g + 4 <= N; g += 4) {
+            const uint4 q = *reinterpret_cast<const uint4_a4 *>(src + 4 * g);
+            w[g] = q.x; w[g + 1] = q.y; w[g + 2] = q.z; w[g + 3] = q.w;
+        }
+#pragma unroll
+        for (int g = N & ~3; g < N; g++) w[g] = *reinterpret_cast<const u32 __attribute__((aligned(4))) *>(src + 4 * g);
+    } else {
+#pragma unroll
+        for (int g = 0; g < N; g++) {
+            u32 x = 0;
+            if (active) {
+                for (int q = 0; q < 4; q++) {
+                    const long long z = off + 4 * g + q;
+                    if (z >= 0 && (u64)z < total) x |= (u32)bases[z] << (8 * q);
+                }
+            }
+            w[g] = x;
+        }
+    }
+}
+
+template <bool TICKET>
+__global__ __launch_bounds__(ST_NT) void nthash_strip_kernel(StripArgs p) {
+    __shared__ __attribute__((aligned(16))) uint4 s_tin[256];   // [byte] = { seed, rol(cseed, k-1) }
+    __shared__ __attribute__((aligned(16))) uint4 s_tout[256];  // [byte] = { rol(seed, k), ror(cseed, 1) }
+    __shared__ u64 s_ch[ST_CAP];   // candidates in arrival order
+    __shared__ u32 s_ci[ST_CAP];   // owner lane << 24 | sequence number << 11 | window index in the strip
+    __shared__ u64 s_oh[ST_CAP];   // candidates in window order
+    __shared__ u32 s_op[ST_CAP];   // tile-local window start
+    __shared__ u32 s_base[ST_NT];
+    __shared__ u32 s_scan[ST_NWV + 1];
+    __shared__ u32 s_cnt[ST_RND * ST_NWV + 1];
+    __shared__ u32 s_n;
+    __shared__ u64 s_misc[2];
+    const int tid = (int)threadIdx.x, lane = lane_id(), wave = tid >> 6;
+    const int k = p.k, L = p.L;
+    {
+        const u32 si = (u32)g_byte_table.v[tid] >> 4;  // 0..3 = A C G T/U, 4 = anything else (zero seed)
+        const u64 f = si == 0 ? SEED_A : si == 1 ? SEED_C : si == 2 ? SEED_G : si == 3 ? SEED_T : 0ull;
+        const u64 cs = si == 0 ? SEED_T : si == 1 ? SEED_G : si == 2 ? SEED_C : si == 3 ? SEED_A : 0ull;
+        const u64 a = f, b = rol64(cs, (u32)(k - 1)), c2 = rol64(f, (u32)k), d = ror64(cs, 1);
+        s_tin[tid] = make_uint4((u32)a, (u32)(a >> 32), (u32)b, (u32)(b >> 32));
+        s_tout[tid] = make_uint4((u32)c2, (u32)(c2 >> 32), (u32)d, (u32)(d >> 32));
+        if (tid == 0) s_n = 0;
+    }
+    u64 tile = blockIdx.x;
+    if (TICKET) {
+        if (tid == 0) s_misc[0] = (u64)atomicAdd(p.ticket, 1u);
+        __syncthreads();
+        tile = s_misc[0];
+    }
+    __syncthreads();
+    const u64 P0 = tile * (u64)ST_NT * (u64)L;
+    const u64 s0 = P0 + (u64)tid * (u64)L;  // first window start of this lane
+    const bool active = s0 < p.total_bases;
+    const u32 mh_hi = (u32)(p.max_hash >> 32);
+    const bool canon = p.canonical != 0;
+    u32 flo = 0, fhi = 0, rlo = 0, rhi = 0;  // fwd / rev hash of the k bases ending at the current position
+    u32 myseq = 0;
+    const int nsteps = L + k - 1;
+    const int kp = (int)((0u - (u32)k) & 3u);  // byte phase of the `out` stream inside its dwords
+    for (int c0 = 0; c0 < nsteps; c0 += 64) {
+        u32 iw[16], ow[17];
+        strip_load<16>(p.bases, (long long)(s0 + (u64)c0), p.total_bases, active, iw);
+        // out bytes of this chunk = base[s0 + c0 - k ...]; the dword-aligned window that holds them
+        const long long ooff = (long long)(s0 + (u64)c0) - (long long)k;
+        strip_load<17>(p.bases, ooff - (long long)kp, p.total_bases, active, ow);
+        if (c0 == 0) {
+            // a strip starts cold: the first k steps have no outgoing base (byte 0 has a zero table entry)
+#pragma unroll
+            for (int g = 0; g < 17; g++) {
+                const int b0 = 4 * g - kp;        // out-stream step of the dword's first byte
+                const int nz = k - b0;            // bytes of this dword that belong to steps < k
+                const u32 m = nz <= 0 ? 0xFFFFFFFFu : (nz >= 4 ? 0u : (0xFFFFFFFFu << (8 * nz)));
+                ow[g] &= m;
+            }
+        }
+#pragma unroll
+        for (int g = 0; g < 16; g++) {
+            // the four out bytes of steps 4g .. 4g+3
+            const u32 o4 = __builtin_amdgcn_alignbyte(ow[g + 1], ow[g], (u32)kp);
+            const u32 i4 = iw[g];
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int i = c0 + 4 * g + q;  // step: the base at s0 + i enters
+                const uint4 ein = s_tin[(i4 >> (8 * q)) & 0xFFu];
+                const uint4 eout = s_tout[(o4 >> (8 * q)) & 0xFFu];
+                // fwd = rol(fwd, 1) ^ seed[in] ^ rol(seed[out], k)
+                const u32 nflo = __builtin_amdgcn_alignbit(flo, fhi, 31) ^ ein.x ^ eout.x;
+                const u32 nfhi = __builtin_amdgcn_alignbit(fhi, flo, 31) ^ ein.y ^ eout.y;
+                // rev = ror(rev, 1) ^ rol(cseed[in], k - 1) ^ ror(cseed[out], 1)
+                const u32 nrlo = __builtin_amdgcn_alignbit(rhi, rlo, 1) ^ ein.z ^ eout.z;
+                const u32 nrhi = __builtin_amdgcn_alignbit(rlo, rhi, 1) ^ ein.w ^ eout.w;
+                flo = nflo; fhi = nfhi; rlo = nrlo; rhi = nrhi;
+                // coarse test on the high words; everything else only for the rare hit
+                const bool hit = (fhi <= mh_hi) || (canon && rhi <= mh_hi);
+                if (hit && i >= k - 1 && i < nsteps) {
+                    const u64 f = ((u64)fhi << 32) | flo, rv = ((u64)rhi << 32) | rlo;
+                    const u64 h = (canon && rv < f) ? rv : f;
+                    const u32 w = (u32)(i - (k - 1));  // window index inside the strip
+                    if (h <= p.max_hash && s0 + (u64)w + (u64)k <= p.total_bases) {
+                        const u32 e = atomicAdd(&s_n, 1u);
+                        if (e < (u32)ST_CAP) {
+                            s_ch[e] = h;
+                            s_ci[e] = ((u32)tid << 24) | ((myseq & 0x1FFFu) << 11) | w;
+                        }
+                        myseq++;
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    const u32 n_all = s_n;
+    const u32 n = n_all < (u32)ST_CAP ? n_all : (u32)ST_CAP;
+    if (n_all > (u32)ST_CAP && tid == 0) atomicOr((unsigned long long *)&p.result[1], 4ull);
+    // window order = (owner lane, sequence number)
+    {
+        u32 tot;
+        const u32 excl = block_excl_scan_u32<ST_NT>(myseq, s_scan, &tot);
+        s_base[tid] = excl;
+    }
+    __syncthreads();
+    for (u32 e = (u32)tid; e < n; e += ST_NT) {
+        const u32 ci = s_ci[e];
+        const u32 owner = ci >> 24, seq = (ci >> 11) & 0x1FFFu, w = ci & 0x7FFu;
+        const u32 slot = s_base[owner] + seq;
+        if (slot < (u32)ST_CAP) {
+            s_oh[slot] = s_ch[e];
+            s_op[slot] = owner * (u32)L + w;
+        }
+    }
+    __syncthreads();
+    // is the window inside one record?  (records shorter than k never hold one)
+    u64 hv[ST_RND];
+    u32 keep = 0;
+    {
+        const u64 r_lo = p.tile_rec[tile];
+        u64 r_hi = p.tile_rec[tile + 1] + 2;
+        r_hi = r_hi < p.n_rec + 1 ? r_hi : p.n_rec + 1;
+#pragma unroll
+        for (int m = 0; m < ST_RND; m++) {
+            const u32 slot = (u32)tid + (u32)m * ST_NT;
+            hv[m] = 0;
+            if (slot < n && n_all <= (u32)ST_CAP) {
+                const u64 pos = P0 + (u64)s_op[slot];
+                const u64 ub = upper_bound_u64(p.rec_off, r_lo, r_hi, pos);  // first record starting behind pos
+                if (ub > 0 && ub <= p.n_rec && pos + (u64)k <= p.rec_off[ub]) {
+                    keep |= 1u << m;
+                    hv[m] = s_oh[slot];
+                }
+            }
+        }
+    }
+    u32 before[ST_RND];
+#pragma unroll
+    for (int m = 0; m < ST_RND; m++) {
+        const u64 b = __ballot((keep >> m) & 1u);
+        before[m] = (u32)__popcll(b & ((1ull << lane) - 1));
+        if (lane == 0) s_cnt[m * ST_NWV + wave] = (u32)__popcll(b);
+    }
+    __syncthreads();
+    if (tid < 64) {
+        constexpr int NG = ST_RND * ST_NWV;
+        const u32 c = lane < NG ? s_cnt[lane] : 0;
+        const u32 incl = wave_incl_scan_u32(c);
+        if (lane < NG) s_cnt[lane] = incl - c;
+        if (lane == 63) s_cnt[NG] = incl;
+    }
+    __syncthreads();
+    const u32 tile_total = s_cnt[ST_RND * ST_NWV];
+    if (tid < 64) {
+        bool timed_out = false;
+        if (lane == 0) lb_publish(p.status, tile, (u64)tile_total);
+        const u64 base = lb_resolve(p.status, tile, (u64)tile_total, lane, TICKET ? nullptr : &timed_out);
+        if (tid == 0) s_misc[1] = base;
+        if (timed_out && lane == 0) atomicOr((unsigned long long *)&p.result[1], 2ull);
+    }
+    __syncthreads();
+    const u64 base = s_misc[1];
+#pragma unroll
+    for (int m = 0; m < ST_RND; m++)
+        if ((keep >> m) & 1u) {
+            const u64 pos = base + s_cnt[m * ST_NWV + wave] + before[m];
+            if (pos < p.out_cap) p.out[pos] = hv[m];
+        }
+    if (tid == 0 && tile == p.ntiles - 1) p.result[0] = base + tile_total;
+}
+
+// returns UKM_OK with *done = false when the strip kernel does not apply (or overflowed): the caller then
+// runs the general kernel
+int run_strip_filter(ukm_ctx *c, const u8 *bases, const u64 *rec_off, u64 n_rec, int k, int canonical, u64 max_hash,
+                     u64 *out, u64 out_cap, u64 *n_out, u64 total_bases, bool *done) {
+    *done = false;
+    // developer / test knob: UKM_NTHASH_STRIP=0 never, =1 always (whatever the scale; overflow still falls back)
+    const char *fe = getenv("UKM_NTHASH_STRIP");
+    const int force = fe ? atoi(fe) : -1;
+    if (force == 0) return UKM_OK;
+    if (((uintptr_t)bases & 3) != 0) return UKM_OK;
+    // expected candidates per tile = NT * L * (max_hash / 2^64), twice that when canonical (min(f, r) <= m iff
+    // f <= m or r <= m); keep it below a third of the list
+    const double frac = ((double)max_hash + 1.0) / 18446744073709551616.0 * (canonical ? 2.0 : 1.0);
+    int L = 1024;
+    // enough tiles to fill the chip
+    while (L > 256 && total_bases / ((u64)ST_NT * (u64)L) < 2048) L >>= 1;
+    while (L > 64 && (double)ST_NT * L * frac > ST_CAP / 3.0) L >>= 1;
+    if (force != 1 && ((double)ST_NT * L * frac > ST_CAP / 3.0 || L < 256)) return UKM_OK;  // small --scale: general kernel
+    const u64 tile_pos = (u64)ST_NT * (u64)L;
+    const u64 ntiles = (total_bases + tile_pos - 1) / tile_pos;
+    if (ntiles > 0x7FFFFFFFull) return UKM_OK;
+    u64 *ctl = nullptr, *tile_rec = nullptr;
+    const size_t nctl = 8 + lb_status_words(ntiles);
+    UKM_TRY(ws_alloc_t(c, nctl, &ctl));
+    UKM_TRY(ws_alloc_t(c, ntiles + 3, &tile_rec));
+    hipLaunchKernelGGL(tile_first_rec_kernel, dim3((unsigned)((ntiles + 3 + 255) / 256)), dim3(256), 0, c->stream, rec_off,
+                       n_rec, total_bases, ntiles, tile_pos, tile_rec);
+    StripArgs p;
+    memset(&p, 0, sizeof(p));
+    p.bases = bases; p.rec_off = rec_off; p.n_rec = n_rec; p.total_bases = total_bases; p.k = k;
+    p.canonical = canonical; p.L = L; p.max_hash = max_hash; p.out = out; p.out_cap = out_cap;
+    p.result = ctl; p.ticket = (u32 *)(ctl + 2); p.status = ctl + 8; p.ntiles = ntiles; p.tile_rec = tile_rec;
+    u64 res[2] = {0, 0};
+    for (int attempt = c->setop_force_ticket ? 1 : 0; attempt < 2; attempt++) {
+        UKM_HIP(hipMemsetAsync(ctl, 0, nctl * sizeof(u64), c->stream));
+        (void)hipEventRecord(c->ev_k0, c->stream);
+        if (attempt == 0) hipLaunchKernelGGL(nthash_strip_kernel<false>, dim3((unsigned)ntiles), dim3(ST_NT), 0, c->stream, p);
+        else hipLaunchKernelGGL(nthash_strip_kernel<true>, dim3((unsigned)ntiles), dim3(ST_NT), 0, c->stream, p);
+        (void)hipEventRecord(c->ev_k1, c->stream);
+        c->evk_valid = true;
+        UKM_HIP(hipGetLastError());
+        UKM_TRY(ukm_read_u64(c, ctl, res, 2));
+        if (!(res[1] & 2)) break;
+        if (attempt == 1) UKM_FAIL(UKM_ERR_HIP, "ntHash strip kernel: look-back watchdog fired in the ticketed kernel");
+        ukm_switch_to_tickets(c, "ntHash strip kernel");
+    }
+    if (res[1] & 4) return UKM_OK;  // candidate list overflow: general kernel
+    *n_out = res[0];
+    if (*n_out > out_cap)
+        UKM_FAIL(UKM_ERR_CAPACITY, "output needs %llu values, capacity is %llu", (unsigned long long)*n_out,
+                 (unsigned long long)out_cap);
+    *done = true;
+    return UKM_OK;
+}
+
 int run_windows(ukm_ctx *c, bool hash, const u8 *bases, const u64 *rec_off, u64 n_rec, int k,
                 int canonical, int circular, u64 max_hash, u64 *out, u64 out_cap, u64 *n_out,
                 u64 total_bases, const u64 **win_off = nullptr) {
     *n_out = 0;
     if (win_off) *win_off = nullptr;
     if (n_rec == 0 || total_bases == 0) return UKM_OK;
+    if (hash && max_hash != 0 && !circular && !win_off) {
+        // Scaled-MinHash sketch: the rolling strip kernel when the filter is selective enough
+        bool done = false;
+        UKM_TRY(run_strip_filter(c, bases, rec_off, n_rec, k, canonical, max_hash, out, out_cap, n_out, total_bases, &done));
+        if (done) return UKM_OK;
+        *n_out = 0;
+    }
     // per-record window counts -> exclusive scan (n_rec + 1 entries: off[n_rec] = total)
     u64 *cnt = nullptr, *off = nullptr, *ctl = nullptr;
     UKM_TRY(ws_alloc_t(c, n_rec + 1, &cnt));
