@@ -81,7 +81,19 @@ int ukm_ctx_reserve(ukm_ctx *ctx, uint64_t bytes);
 /* device-memory helpers for hosts without their own allocator (the cgo shim) */
 int ukm_dev_alloc(ukm_ctx *ctx, uint64_t bytes, void **dptr);
 int ukm_dev_free(ukm_ctx *ctx, void *dptr);
-int ukm_copy(ukm_ctx *ctx, void *dst, const void *src, uint64_t bytes); /* any direction */
+int ukm_copy(ukm_ctx *ctx, void *dst, const void *src, uint64_t bytes); /* any direction, synchronous */
+/* Streaming uploads / downloads (the host side of count.go:285-299: FASTA/Q is read in chunks while the device
+ * works on the previous chunk).  ukm_host_alloc gives page-locked host memory; ukm_copy_async enqueues a copy
+ * (any direction) on the context's TRANSFER stream and returns at once: it starts after the compute work the
+ * context was given before the call and then runs beside later compute calls.  ukm_copy_fence orders every
+ * LATER compute call behind the transfers issued so far (device-side wait, the host does not block);
+ * ukm_copy_sync blocks the host until they are done (before a host source buffer is reused or a host
+ * destination is read).  Double buffering: copy_async(chunk i+1) ; compute(chunk i) ; copy_fence ; ... */
+int ukm_host_alloc(ukm_ctx *ctx, uint64_t bytes, void **hptr);
+int ukm_host_free(ukm_ctx *ctx, void *hptr);
+int ukm_copy_async(ukm_ctx *ctx, void *dst, const void *src, uint64_t bytes);
+int ukm_copy_fence(ukm_ctx *ctx);
+int ukm_copy_sync(ukm_ctx *ctx);
 /* ms between hipEvents recorded on the ctx stream (a) around the DOMINANT kernel of the most
  * recent compute call (the tiled set-op kernel for ukm_setop2; falls back to (b) when a call
  * records none) and (b) around all device work of the call */

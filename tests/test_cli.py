@@ -190,6 +190,41 @@ def test_count_modes_on_gpu(cli, tmp_path):
 
 
 @pytest.mark.gpu
+def test_count_device_pipeline_chunked(cli, tmp_path, monkeypatch):
+    """`count` keeps the window values on the device (chunked, double-buffered upload; sort + unique there):
+    with 1 MB chunks a 6 Mbp multi-record FASTA goes through several chunks, incl. a record longer than a chunk,
+    an empty record and records shorter than k.  Result = the oracle's count on the same records."""
+    from oracle import oracle as O
+    rng = np.random.default_rng(5)
+    lens = [1_500_000, 0, 20, 700_000, 31, 30, 2_000_000] + [150] * 4000 + [1_200_000]
+    seqs = ["".join(np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, n)].tobytes().decode()) for n in lens]
+    d = str(tmp_path)
+    with open(d + "/m.fa", "w") as fh:
+        for i, q in enumerate(seqs):
+            fh.write(">r%d\n" % i)
+            for j in range(0, len(q), 70):
+                fh.write(q[j:j + 70] + "\n")
+    bases = np.frombuffer("".join(seqs).encode(), dtype=np.uint8)
+    off = np.zeros(len(seqs) + 1, dtype=np.uint64)
+    off[1:] = np.cumsum(lens)
+    monkeypatch.setenv("UNIKMER_CHUNK_MB", "1")
+    k = 31
+    p = cli("count", "-k", k, "-K", "-s", "--verbose", d + "/m.fa", "-o", d + "/c")
+    assert b"device pipeline:" in p.stderr and b" 1 chunk(s)" not in p.stderr
+    got = np.array([int(x) for x in cli("view", "-N", d + "/c.unik").stdout.split()], dtype=np.uint64)
+    exp = O.unique(O.sort_u64(O.count_windows(bases, off, k, canonical=True)))
+    assert np.array_equal(got, exp)
+    # linear output keeps window order across chunk boundaries; hashed + scaled goes through the same pipeline
+    cli("count", "-k", k, "-l", d + "/m.fa", "-o", d + "/l")
+    got = np.array([int(x) for x in cli("view", "-N", d + "/l.unik").stdout.split()], dtype=np.uint64)
+    assert np.array_equal(got, O.count_windows(bases, off, k, canonical=False))
+    cli("count", "-k", 51, "-K", "-H", "-s", "-D", 200, d + "/m.fa", "-o", d + "/h")
+    got = np.array([int(x) for x in cli("view", "-N", d + "/h.unik").stdout.split()], dtype=np.uint64)
+    exp = O.unique(O.sort_u64(O.count_windows(bases, off, 51, hashed=True, canonical=True, max_hash=O.max_hash(200))))
+    assert np.array_equal(got, exp)
+
+
+@pytest.mark.gpu
 def test_taxonomy_lca_through_cli(cli, tmp_path):
     """union / inter / sort -u / diff -t with per-record taxids and a synthetic nodes.dmp +
     merged.dmp (util.go:119-171); expected values from the oracle."""

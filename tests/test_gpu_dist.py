@@ -123,3 +123,25 @@ def test_sharded_ops_two_ranks_real_context():
     allx = np.concatenate([ret[r]["x"] for r in range(world)])
     assert np.array_equal(cat("sorted"), np.sort(allx))
     assert np.array_equal(cat("distinct"), np.unique(allx))
+
+
+def test_bench_two_ranks_incl_exchange():
+    """bench.py's N > 1 path end to end (launched exactly as the driver launches it), two ranks sharing the one
+    GPU over gloo: the pre-partitioned `value`, the bare all-to-all-v and `value_incl_exchange` (file-sharded
+    start -> dist.sharded_setop) are all produced and agree on the result sizes."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, UKM_BENCH_ONE_GPU="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--set-size", "1e6", "--cpu-sample", "0"]
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, cwd=root, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+    res = json.loads(line)
+    assert res["n_gpus"] == 2 and res["value"] > 0 and res["scaling"] == "weak"
+    assert "error" not in res.get("exchange", {}), res.get("exchange")
+    assert res["value_incl_exchange"] > 0 and res["incl_exchange"]["steps"] >= 1
+    assert res["roofline"]["frac"] > 0 and res["cpu_baseline"] is None

@@ -84,6 +84,12 @@ extern "C" int ukm_ctx_destroy(ukm_ctx *c) {
     if (c->ev_stop) (void)hipEventDestroy(c->ev_stop);
     if (c->ev_k0) (void)hipEventDestroy(c->ev_k0);
     if (c->ev_k1) (void)hipEventDestroy(c->ev_k1);
+    if (c->xfer) {
+        (void)hipStreamSynchronize(c->xfer);
+        (void)hipStreamDestroy(c->xfer);
+    }
+    if (c->ev_xfer) (void)hipEventDestroy(c->ev_xfer);
+    if (c->ev_comp) (void)hipEventDestroy(c->ev_comp);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return UKM_OK;
@@ -357,6 +363,70 @@ extern "C" int ukm_dev_free(ukm_ctx *c, void *dptr) {
     UKM_HIP(hipSetDevice(c->device));
     UKM_HIP(hipStreamSynchronize(c->stream));
     UKM_HIP(hipFree(dptr));
+    return UKM_OK;
+}
+
+// ---- pinned host memory + asynchronous transfers on a second stream -------------------------------------------
+extern "C" int ukm_host_alloc(ukm_ctx *c, uint64_t bytes, void **hptr) {
+    if (!c || !hptr) UKM_FAIL(UKM_ERR_INVALID, "ukm_host_alloc: NULL argument");
+    UKM_HIP(hipSetDevice(c->device));
+    void *p = nullptr;
+    hipError_t e = hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        UKM_FAIL(UKM_ERR_NOMEM, "ukm_host_alloc(%llu): %s", (unsigned long long)bytes, hipGetErrorString(e));
+    }
+    *hptr = p;
+    return UKM_OK;
+}
+
+extern "C" int ukm_host_free(ukm_ctx *c, void *hptr) {
+    if (!c) UKM_FAIL(UKM_ERR_INVALID, "ukm_host_free: ctx is NULL");
+    if (!hptr) return UKM_OK;
+    UKM_HIP(hipSetDevice(c->device));
+    if (c->xfer) UKM_HIP(hipStreamSynchronize(c->xfer));
+    UKM_HIP(hipHostFree(hptr));
+    return UKM_OK;
+}
+
+static int xfer_init(ukm_ctx *c) {
+    if (c->xfer) return UKM_OK;
+    UKM_HIP(hipStreamCreateWithFlags(&c->xfer, hipStreamNonBlocking));
+    UKM_HIP(hipEventCreateWithFlags(&c->ev_xfer, hipEventDisableTiming));
+    UKM_HIP(hipEventCreateWithFlags(&c->ev_comp, hipEventDisableTiming));
+    return UKM_OK;
+}
+
+extern "C" int ukm_copy_async(ukm_ctx *c, void *dst, const void *src, uint64_t bytes) {
+    if (!c || (!dst && bytes) || (!src && bytes)) UKM_FAIL(UKM_ERR_INVALID, "ukm_copy_async: NULL argument");
+    if (bytes == 0) return UKM_OK;
+    UKM_HIP(hipSetDevice(c->device));
+    UKM_TRY(xfer_init(c));
+    // the transfer starts after everything the compute stream has been given so far (it may read a result,
+    // or overwrite a buffer an earlier kernel still reads) ...
+    UKM_HIP(hipEventRecord(c->ev_comp, c->stream));
+    UKM_HIP(hipStreamWaitEvent(c->xfer, c->ev_comp, 0));
+    UKM_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDefault, c->xfer));
+    c->xfer_pending = true;
+    return UKM_OK;
+}
+
+extern "C" int ukm_copy_fence(ukm_ctx *c) {
+    if (!c) UKM_FAIL(UKM_ERR_INVALID, "ukm_copy_fence: ctx is NULL");
+    if (!c->xfer || !c->xfer_pending) return UKM_OK;
+    UKM_HIP(hipSetDevice(c->device));
+    // ... and compute calls issued after this fence start after the transfers issued before it
+    UKM_HIP(hipEventRecord(c->ev_xfer, c->xfer));
+    UKM_HIP(hipStreamWaitEvent(c->stream, c->ev_xfer, 0));
+    return UKM_OK;
+}
+
+extern "C" int ukm_copy_sync(ukm_ctx *c) {
+    if (!c) UKM_FAIL(UKM_ERR_INVALID, "ukm_copy_sync: ctx is NULL");
+    if (!c->xfer) return UKM_OK;
+    UKM_HIP(hipSetDevice(c->device));
+    UKM_HIP(hipStreamSynchronize(c->xfer));
+    c->xfer_pending = false;
     return UKM_OK;
 }
 

@@ -481,7 +481,9 @@ struct StripArgs {
     const u64 *tile_rec;
 };
 
-typedef uint4 uint4_a4 __attribute__((aligned(4)));
+struct __attribute__((packed, aligned(4))) U4a4 {  // 16 bytes at 4-byte alignment
+    u32 x, y, z, w;
+};
 
 // n dwords of the base array starting at byte offset `off` (may be negative or run past the end: such
 // bytes read as 0).  Fast path: plain vector loads.
@@ -492,11 +494,11 @@ __device__ __forceinline__ void strip_load(const u8 *bases, long long off, u64 t
         const u8 *src = bases + off;
 #pragma unroll
         for (int g = 0; g + 4 <= N; g += 4) {
-            const uint4 q = *reinterpret_cast<const uint4_a4 *>(src + 4 * g);
+            const U4a4 q = *reinterpret_cast<const U4a4 *>(src + 4 * g);
             w[g] = q.x; w[g + 1] = q.y; w[g + 2] = q.z; w[g + 3] = q.w;
         }
 #pragma unroll
-        for (int g = N & ~3; g < N; g++) w[g] = *reinterpret_cast<const u32 __attribute__((aligned(4))) *>(src + 4 * g);
+        for (int g = N & ~3; g < N; g++) w[g] = *reinterpret_cast<const u32 *>(src + 4 * g);
     } else {
 #pragma unroll
         for (int g = 0; g < N; g++) {

@@ -64,6 +64,10 @@ struct ukm_ctx {
     bool ev_valid = false;
     hipEvent_t ev_k0 = nullptr, ev_k1 = nullptr;  // dominant kernel of the call
     bool evk_valid = false;
+    // transfer stream (ukm_copy_async): created on first use
+    hipStream_t xfer = nullptr;
+    hipEvent_t ev_xfer = nullptr, ev_comp = nullptr;
+    bool xfer_pending = false;
     int depth = 0;  // nesting depth of API calls (n-way ops call 2-way ops)
 
     std::vector<WsBlock> blocks;

@@ -9,9 +9,9 @@
 //   sort   (sort.go)    ukm_sort_u64 | ukm_sort_pairs -> ukm_unique(-u/-d)
 //   union / inter / diff / common / merge -> ukm_union / ukm_inter / ukm_diff / ukm_common / ukm_merge_k
 // CPU-only commands (no GPU needed): view, dump, num, info/stats, concat, head, encode, decode.
-// Not implemented (SURVEY.md §2a out of scope): grep, filter, rfilter, tsplit, locate, map,
-// split, sample, autocompletion; count -W/-S (minimizer/syncmer sketches); sort -m chunking is
-// accepted and ignored (a whole set fits in 288 GB of HBM).
+// `count` keeps the window values on the device from encode to the final set (chunked, double-buffered upload).
+// Not implemented (SURVEY.md §2a out of scope): grep, filter, rfilter, tsplit, locate, map, sample,
+// autocompletion; count -S (syncmer sketch: third-party rule not reconstructable from the tree).
 #include <dirent.h>
 #include <getopt.h>
 #include <sys/stat.h>
@@ -23,6 +23,7 @@
 #include <cerrno>
 #include <cstdlib>
 #include <cstring>
+#include <ctime>
 #include <fstream>
 #include <iostream>
 #include <map>
@@ -390,16 +391,22 @@ static void read_fastx(const string &file, SeqBatch &b, bool keep_names) {
         have = false;
     };
     string carry;
+    auto append_seq = [&](const string &l) -> size_t {  // bio/fastx drops blanks inside sequence lines
+        size_t added = 0;
+        for (char ch : l)
+            if (ch != ' ' && ch != '\t') { b.bases.push_back((uint8_t)ch); added++; }
+        return added;
+    };
     auto handle = [&](const string &l) {
         if (fastq) {
             if (fq_state == 0) { if (l.empty()) return; if (l[0] != '@') die("invalid FASTQ record in %s", file.c_str()); finish(); name = l.substr(1); have = true; seq_len = qual_len = 0; fq_state = 1; }
-            else if (fq_state == 1) { if (!l.empty() && l[0] == '+') fq_state = 3; else { b.bases.insert(b.bases.end(), l.begin(), l.end()); seq_len += l.size(); } }
+            else if (fq_state == 1) { if (!l.empty() && l[0] == '+') fq_state = 3; else { seq_len += append_seq(l); } }
             else if (fq_state == 3) { qual_len += l.size(); if (qual_len >= seq_len) fq_state = 0; }
             return;
         }
         if (!l.empty() && l[0] == '>') { finish(); name = l.substr(1); have = true; return; }
         if (!have) { if (l.empty()) return; die("invalid FASTA/Q format: %s", file.c_str()); }
-        b.bases.insert(b.bases.end(), l.begin(), l.end());
+        append_seq(l);
     };
     bool first = true;
     for (;;) {
@@ -420,6 +427,97 @@ static void read_fastx(const string &file, SeqBatch &b, bool keep_names) {
     }
     if (!carry.empty()) { if (first) fastq = carry[0] == '@'; handle(carry); }
     finish();
+}
+
+// ---- count: device-resident pipeline ------------------------------------------------------------------------
+// FASTA/Q bases go to the GPU in record-aligned chunks through two page-locked staging buffers: chunk i+1 is
+// uploaded on the context's transfer stream while chunk i is encoded / hashed (count.go:285-299 reads record
+// by record; here a "record batch" is a chunk).  The window values never come back to the host: they are
+// written to ONE device array, sorted and reduced there (count.go:424-436, 571-581), and only the final set
+// crosses PCIe.  Returns the result in `codes`.
+struct DevMem {
+    ukm_ctx *c;
+    void *p = nullptr;
+    DevMem(ukm_ctx *ctx, u64 bytes) : c(ctx) { ck(ukm_dev_alloc(c, bytes ? bytes : 8, &p)); }
+    ~DevMem() { if (p) ukm_dev_free(c, p); }
+    DevMem(const DevMem &) = delete;
+};
+struct PinMem {
+    ukm_ctx *c;
+    void *p = nullptr;
+    PinMem(ukm_ctx *ctx, u64 bytes) : c(ctx) { ck(ukm_host_alloc(c, bytes ? bytes : 8, &p)); }
+    ~PinMem() { if (p) ukm_host_free(c, p); }
+    PinMem(const PinMem &) = delete;
+};
+static double now_ms() {
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6;
+}
+static u64 count_on_device(Gpu &g, const SeqBatch &sb, int k, bool canonical, bool circular, bool hashed, u64 max_hash,
+                           bool linear, int uniq_mode, int key_bits, u64 cap, vector<u64> &codes) {
+    const u64 nrec = sb.off.size() - 1;
+    codes.clear();
+    if (nrec == 0 || cap == 0) return 0;
+    const char *ce = getenv("UNIKMER_CHUNK_MB");
+    const u64 CH = (u64)(ce ? std::max(1, atoi(ce)) : 64) << 20;
+    // record-aligned chunks of at most CH bases (a longer record is a chunk of its own)
+    vector<std::pair<u64, u64>> chunks;
+    u64 max_b = 0, max_r = 0;
+    for (u64 r = 0; r < nrec;) {
+        u64 e = r + 1;
+        while (e < nrec && sb.off[e + 1] - sb.off[r] <= CH) e++;
+        chunks.emplace_back(r, e);
+        max_b = std::max(max_b, sb.off[e] - sb.off[r]);
+        max_r = std::max(max_r, e - r);
+        r = e;
+    }
+    const double t0 = now_ms();
+    PinMem hb0(g.c, max_b), hb1(g.c, max_b), ho0(g.c, (max_r + 1) * 8), ho1(g.c, (max_r + 1) * 8);
+    DevMem db0(g.c, max_b), db1(g.c, max_b), do0(g.c, (max_r + 1) * 8), do1(g.c, (max_r + 1) * 8);
+    DevMem dcodes(g.c, cap * 8);
+    void *hb[2] = {hb0.p, hb1.p}, *ho[2] = {ho0.p, ho1.p}, *db[2] = {db0.p, db1.p}, *dof[2] = {do0.p, do1.p};
+    auto stage = [&](size_t ci) {
+        const int s = (int)(ci & 1);
+        const u64 r0 = chunks[ci].first, r1 = chunks[ci].second, b0 = sb.off[r0], nb = sb.off[r1] - b0;
+        memcpy(hb[s], sb.bases.data() + b0, nb);
+        u64 *o = (u64 *)ho[s];
+        for (u64 r = r0; r <= r1; r++) o[r - r0] = sb.off[r] - b0;
+        ck(ukm_copy_async(g.c, db[s], hb[s], nb));
+        ck(ukm_copy_async(g.c, dof[s], ho[s], (r1 - r0 + 1) * 8));
+    };
+    stage(0);
+    u64 n = 0;
+    for (size_t ci = 0; ci < chunks.size(); ci++) {
+        const int s = (int)(ci & 1);
+        ck(ukm_copy_fence(g.c));                       // chunk ci is (or will be) on the device before its kernels start
+        if (ci + 1 < chunks.size()) stage(ci + 1);     // travels while chunk ci is processed
+        const u64 nr = chunks[ci].second - chunks[ci].first;
+        u64 m = 0;
+        u64 *dst = (u64 *)dcodes.p + n;
+        if (hashed) ck(ukm_nthash(g.c, (const uint8_t *)db[s], (const u64 *)dof[s], nr, k, canonical, circular, max_hash, dst, cap - n, &m));
+        else ck(ukm_encode_kmers(g.c, (const uint8_t *)db[s], (const u64 *)dof[s], nr, k, canonical, circular, dst, cap - n, &m));
+        n += m;
+    }
+    const double t1 = now_ms();
+    u64 nout = n;
+    if (!linear && n) {
+        ck(ukm_sort_u64(g.c, (u64 *)dcodes.p, n, key_bits));
+        DevMem dout(g.c, n * 8);
+        ck(ukm_unique(g.c, (const u64 *)dcodes.p, nullptr, n, uniq_mode, (u64 *)dout.p, nullptr, n, &nout));
+        const double t2 = now_ms();
+        codes.resize(nout ? nout : 1);
+        ck(ukm_copy(g.c, codes.data(), dout.p, nout * 8));
+        info("device pipeline: %zu chunk(s), upload+encode %.2f ms, sort+unique %.2f ms, download of %llu codes %.2f ms",
+             chunks.size(), t1 - t0, t2 - t1, (unsigned long long)nout, now_ms() - t2);
+    } else {
+        codes.resize(n ? n : 1);
+        ck(ukm_copy(g.c, codes.data(), dcodes.p, n * 8));
+        info("device pipeline: %zu chunk(s), upload+encode %.2f ms, download of %llu codes %.2f ms", chunks.size(), t1 - t0,
+             (unsigned long long)n, now_ms() - t1);
+    }
+    codes.resize(nout);
+    return nout;
 }
 
 // =================================================================================================
@@ -475,6 +573,7 @@ static int cmd_count(int argc, char **argv) {
         SeqBatch kept;
         for (u64 r = 0; r < n_rec; r++) {
             if (a.has("seq-name-filter") && std::regex_search(sb.names[r], re_name)) continue;
+            if (sb.off[r + 1] - sb.off[r] < (u64)k) continue;  // ErrShortSeq -> skipped before its header is parsed (count.go:323-344)
             if (parse_taxid) {
                 std::smatch m;
                 if (!std::regex_search(sb.names[r], m, re_tax) || m.size() < 2) die("failed to parse taxid in header: %s", sb.names[r].c_str());
@@ -495,14 +594,22 @@ static int cmd_count(int argc, char **argv) {
     // every window of every record, in order
     u64 cap = 0;
     for (u64 r = 0; r < nrec; r++) { u64 len = sb.off[r + 1] - sb.off[r]; if (len >= (u64)k) cap += circular ? len : len - k + 1; }
-    vector<u64> codes(cap ? cap : 1);
+    const int key_bits = hashed ? 64 : 2 * k;
+    const int uniq_mode = unique ? UKM_SINGLETON : (repeated ? UKM_REPEATED : UKM_UNIQUE);
+    const bool device_pipeline = !parse_taxid && !minimizer;
+    vector<u64> codes;
     u64 n = 0;
-    if (nrec) {
-        if (minimizer) ck(ukm_minimizer(g.c, sb.bases.data(), sb.off.data(), nrec, k, (int)minimizer_w, circular, max_hash, codes.data(), nullptr, cap, &n));
-        else if (hashed) ck(ukm_nthash(g.c, sb.bases.data(), sb.off.data(), nrec, k, canonical, circular, max_hash, codes.data(), cap, &n));
-        else ck(ukm_encode_kmers(g.c, sb.bases.data(), sb.off.data(), nrec, k, canonical, circular, codes.data(), cap, &n));
+    if (device_pipeline) {
+        n = count_on_device(g, sb, k, canonical, circular, hashed, max_hash, linear, uniq_mode, key_bits, cap, codes);
+    } else {
+        codes.assign(cap ? cap : 1, 0);
+        if (nrec) {
+            if (minimizer) ck(ukm_minimizer(g.c, sb.bases.data(), sb.off.data(), nrec, k, (int)minimizer_w, circular, max_hash, codes.data(), nullptr, cap, &n));
+            else if (hashed) ck(ukm_nthash(g.c, sb.bases.data(), sb.off.data(), nrec, k, canonical, circular, max_hash, codes.data(), cap, &n));
+            else ck(ukm_encode_kmers(g.c, sb.bases.data(), sb.off.data(), nrec, k, canonical, circular, codes.data(), cap, &n));
+        }
+        codes.resize(n);
     }
-    codes.resize(n);
     vector<u32> taxids;
     if (parse_taxid) {  // per-window taxid = its record's taxid (only without the Scaled filter, whose survivors lose their record)
         if (scaled || minimizer) die("-T/--parse-taxid together with -D/--scale or -W/--minimizer-w is not supported in this build");
@@ -520,10 +627,9 @@ static int cmd_count(int argc, char **argv) {
     if (hashed) mode |= unik::UnikHashed;
     unik::Header sh;
     if (scaled) { sh.flag |= unik::UnikScaled; sh.scale = (u32)scale; sh.max_hash = max_hash; }
-    const int key_bits = hashed ? 64 : 2 * k;
-    if (!linear) {
+    if (!linear && !device_pipeline) {
         // dedup: distinct set, or codes seen exactly once (-u), or at least twice (-d)  (count.go:424-436)
-        const int m = unique ? UKM_SINGLETON : (repeated ? UKM_REPEATED : UKM_UNIQUE);
+        const int m = uniq_mode;
         vector<u64> out(n ? n : 1);
         vector<u32> tout(parse_taxid ? (n ? n : 1) : 0);
         u64 nu = 0;
@@ -536,6 +642,8 @@ static int cmd_count(int argc, char **argv) {
         codes.swap(out);
         taxids.swap(tout);
         n = nu;
+    }
+    if (!linear) {
         // without -s the reference writes Go-map order; any order is valid there, we keep the
         // sorted order but only set the Sorted flag (and its encoding) when -s is given
         if (sortk) mode |= unik::UnikSorted;
@@ -749,8 +857,11 @@ static int cmd_setop(SetCmd which, int argc, char **argv) {
     if (which == C_DIFF) tax = in.has_taxid;  // taxid always from file 1 (diff.go:496-515)
     Gpu g(o.gpu);
     u32 max_taxid = o.max_taxid;
-    const bool cmp_taxid = which == C_DIFF && a.has("compare-taxid");
-    if (cmp_taxid && !in.has_taxid) die("flag -t/--compare-taxid given but no taxid information found");
+    bool cmp_taxid = which == C_DIFF && a.has("compare-taxid");
+    if (cmp_taxid && !in.has_taxid) {  // diff.go:124-133: a warning, the flag is ignored
+        fprintf(stderr, "[WARN] no taxids found in the first file, flag -t/--compare-taxid ignored\n");
+        cmp_taxid = false;
+    }
     bool need_lca = (tax && which != C_DIFF) || cmp_taxid;
     if (which == C_SORT || which == C_SPLIT) need_lca = tax && (uniq || rep);  // sort.go:196-198
     if (need_lca) max_taxid = load_taxonomy(g, o);
