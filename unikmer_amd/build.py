@@ -70,7 +70,7 @@ def build_cli(force=False, verbose=False):
         return CLI
     os.makedirs(os.path.dirname(CLI), exist_ok=True)
     cmd = ["g++", "-O2", "-std=c++17", "-Wall", "-Wno-unused-function", os.path.join(HOST, "main.cpp"), "-o", CLI,
-           "-L" + HERE, "-lunikmer_hip", "-lz", "-Wl,-rpath,$ORIGIN/..", "-Wl,-rpath,/opt/rocm/lib"]
+           "-L" + HERE, "-lunikmer_hip", "-lz", "-pthread", "-Wl,-rpath,$ORIGIN/..", "-Wl,-rpath,/opt/rocm/lib"]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

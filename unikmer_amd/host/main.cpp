@@ -22,16 +22,20 @@
 #include <cstdarg>
 #include <cerrno>
 #include <cstdlib>
+#include <condition_variable>
 #include <cstring>
 #include <ctime>
+#include <deque>
 #include <fstream>
 #include <iostream>
 #include <map>
 #include <memory>
+#include <mutex>
 #include <regex>
 #include <set>
 #include <sstream>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/unikmer_hip.h"
@@ -379,54 +383,78 @@ struct SeqBatch {
     vector<u64> off{0};
     vector<string> names;
 };
-static void read_fastx(const string &file, SeqBatch &b, bool keep_names) {
+// FASTA/Q (+gzip) parser (bio/seqio/fastx, count.go:289-299).  The sink decides per record whether it is kept
+// (begin_record) and receives the sequence line by line; blanks inside sequence lines are dropped as
+// bio/fastx does.
+struct FastxSink {
+    virtual ~FastxSink() {}
+    virtual bool begin_record(const string &name) = 0;  // false: skip this record
+    virtual void add_seq(const char *p, size_t n) = 0;
+    virtual void end_record() = 0;
+};
+static void parse_fastx(const string &file, FastxSink &sink) {
     unik::InStream in(file);
     vector<char> buf(1 << 20);
-    string line, name;
-    bool have = false, fastq = false;
-    int fq_state = 0;  // 0 header, 1 seq, 2 plus, 3 qual
+    bool have = false, keep = false, fastq = false;
+    int fq_state = 0;  // 0 header, 1 seq, 3 qual
     u64 seq_len = 0, qual_len = 0;
     auto finish = [&]() {
-        if (have) { b.off.push_back(b.bases.size()); if (keep_names) b.names.push_back(name); }
+        if (have && keep) sink.end_record();
         have = false;
     };
-    string carry;
-    auto append_seq = [&](const string &l) -> size_t {  // bio/fastx drops blanks inside sequence lines
-        size_t added = 0;
-        for (char ch : l)
-            if (ch != ' ' && ch != '\t') { b.bases.push_back((uint8_t)ch); added++; }
-        return added;
+    auto seq_line = [&](const string &l) -> size_t {
+        size_t cnt = 0, s0 = 0;
+        for (size_t i = 0; i <= l.size(); i++) {
+            if (i == l.size() || l[i] == ' ' || l[i] == '\t') {
+                if (i > s0) { if (keep) sink.add_seq(l.data() + s0, i - s0); cnt += i - s0; }
+                s0 = i + 1;
+            }
+        }
+        return cnt;
     };
+    string carry;
     auto handle = [&](const string &l) {
         if (fastq) {
-            if (fq_state == 0) { if (l.empty()) return; if (l[0] != '@') die("invalid FASTQ record in %s", file.c_str()); finish(); name = l.substr(1); have = true; seq_len = qual_len = 0; fq_state = 1; }
-            else if (fq_state == 1) { if (!l.empty() && l[0] == '+') fq_state = 3; else { seq_len += append_seq(l); } }
+            if (fq_state == 0) { if (l.empty()) return; if (l[0] != '@') die("invalid FASTQ record in %s", file.c_str()); finish(); have = true; keep = sink.begin_record(l.substr(1)); seq_len = qual_len = 0; fq_state = 1; }
+            else if (fq_state == 1) { if (!l.empty() && l[0] == '+') fq_state = 3; else seq_len += seq_line(l); }
             else if (fq_state == 3) { qual_len += l.size(); if (qual_len >= seq_len) fq_state = 0; }
             return;
         }
-        if (!l.empty() && l[0] == '>') { finish(); name = l.substr(1); have = true; return; }
+        if (!l.empty() && l[0] == '>') { finish(); have = true; keep = sink.begin_record(l.substr(1)); return; }
         if (!have) { if (l.empty()) return; die("invalid FASTA/Q format: %s", file.c_str()); }
-        append_seq(l);
+        seq_line(l);
     };
     bool first = true;
     for (;;) {
         size_t n = in.read(buf.data(), buf.size());
         if (n == 0) break;
-        size_t s = 0;
+        size_t s0 = 0;
         for (size_t i = 0; i < n; i++) {
             if (buf[i] == '\n') {
-                carry.append(buf.data() + s, i - s);
+                carry.append(buf.data() + s0, i - s0);
                 if (!carry.empty() && carry.back() == '\r') carry.pop_back();
                 if (first) { first = false; fastq = !carry.empty() && carry[0] == '@'; }
                 handle(carry);
                 carry.clear();
-                s = i + 1;
+                s0 = i + 1;
             }
         }
-        carry.append(buf.data() + s, n - s);
+        carry.append(buf.data() + s0, n - s0);
     }
     if (!carry.empty()) { if (first) fastq = carry[0] == '@'; handle(carry); }
     finish();
+}
+struct BatchSink : FastxSink {
+    SeqBatch &b;
+    bool keep_names;
+    BatchSink(SeqBatch &bb, bool kn) : b(bb), keep_names(kn) {}
+    bool begin_record(const string &name) override { if (keep_names) b.names.push_back(name); return true; }
+    void add_seq(const char *p, size_t n) override { b.bases.insert(b.bases.end(), p, p + n); }
+    void end_record() override { b.off.push_back(b.bases.size()); }
+};
+static void read_fastx(const string &file, SeqBatch &b, bool keep_names) {
+    BatchSink sink(b, keep_names);
+    parse_fastx(file, sink);
 }
 
 // ---- count: device-resident pipeline ------------------------------------------------------------------------
@@ -454,67 +482,167 @@ static double now_ms() {
     clock_gettime(CLOCK_MONOTONIC, &ts);
     return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6;
 }
-static u64 count_on_device(Gpu &g, const SeqBatch &sb, int k, bool canonical, bool circular, bool hashed, u64 max_hash,
-                           bool linear, int uniq_mode, int key_bits, u64 cap, vector<u64> &codes) {
-    const u64 nrec = sb.off.size() - 1;
-    codes.clear();
-    if (nrec == 0 || cap == 0) return 0;
+// One staging chunk: page-locked bases + record boundaries (relative to the chunk).
+struct HostChunk {
+    ukm_ctx *c = nullptr;
+    uint8_t *bases = nullptr;
+    u64 cap = 0, nb = 0;
+    vector<u64> off{0};
+    void reserve(u64 want) {  // grows the page-locked buffer (a record longer than a chunk)
+        if (want <= cap) return;
+        u64 ncap = std::max<u64>(want, cap + cap / 2);
+        void *p = nullptr;
+        ck(ukm_host_alloc(c, ncap, &p));
+        if (nb) memcpy(p, bases, nb);
+        if (bases) ukm_host_free(c, bases);
+        bases = (uint8_t *)p;
+        cap = ncap;
+    }
+    void reset() { nb = 0; off.assign(1, 0); }
+};
+// parser thread -> device thread hand-off: three chunks go round (one being filled, one travelling, one in the kernels)
+struct ChunkPipe {
+    std::mutex mu;
+    std::condition_variable cv;
+    std::deque<int> full, free_;
+    bool done = false;
+    string error;
+    int get_free() { std::unique_lock<std::mutex> l(mu); cv.wait(l, [&] { return !free_.empty(); }); int i = free_.front(); free_.pop_front(); return i; }
+    void put_full(int i) { { std::lock_guard<std::mutex> l(mu); full.push_back(i); } cv.notify_all(); }
+    int get_full() { std::unique_lock<std::mutex> l(mu); cv.wait(l, [&] { return !full.empty() || done; }); if (full.empty()) return -1; int i = full.front(); full.pop_front(); return i; }
+    void put_free(int i) { { std::lock_guard<std::mutex> l(mu); free_.push_back(i); } cv.notify_all(); }
+    void finish() { { std::lock_guard<std::mutex> l(mu); done = true; } cv.notify_all(); }
+};
+struct ChunkSink : FastxSink {
+    ChunkPipe &pipe;
+    HostChunk *ch;
+    u64 chunk_bytes;
+    int cur;
+    const std::regex *skip_name;
+    ChunkSink(ChunkPipe &p, HostChunk *c, u64 cb, const std::regex *skip) : pipe(p), ch(c), chunk_bytes(cb), skip_name(skip) { cur = pipe.get_free(); ch[cur].reset(); }
+    bool begin_record(const string &name) override { return !(skip_name && std::regex_search(name, *skip_name)); }  // -B (count.go:300-312)
+    void add_seq(const char *p, size_t n) override {
+        HostChunk &h = ch[cur];
+        h.reserve(h.nb + n);
+        memcpy(h.bases + h.nb, p, n);
+        h.nb += n;
+    }
+    void end_record() override {
+        HostChunk &h = ch[cur];
+        h.off.push_back(h.nb);
+        if (h.nb >= chunk_bytes) flush();
+    }
+    void flush() {
+        if (ch[cur].off.size() > 1) { pipe.put_full(cur); cur = pipe.get_free(); ch[cur].reset(); }
+    }
+};
+
+// device array that grows (the number of windows is unknown while the file is still being read)
+struct DevArray {
+    ukm_ctx *c;
+    u64 *p = nullptr;
+    u64 cap = 0;
+    explicit DevArray(ukm_ctx *ctx) : c(ctx) {}
+    ~DevArray() { if (p) ukm_dev_free(c, p); }
+    void ensure(u64 used, u64 want) {
+        if (want <= cap) return;
+        const u64 ncap = std::max<u64>(want, cap * 2);
+        void *q = nullptr;
+        ck(ukm_dev_alloc(c, ncap * 8, &q));
+        if (used) ck(ukm_copy(c, q, p, used * 8));
+        if (p) ukm_dev_free(c, p);
+        p = (u64 *)q;
+        cap = ncap;
+    }
+};
+
+static u64 count_on_device(Gpu &g, int device, const vector<string> &files, const std::regex *skip_name, int k, bool canonical, bool circular,
+                           bool hashed, u64 max_hash, bool linear, int uniq_mode, int key_bits, vector<u64> &codes) {
     const char *ce = getenv("UNIKMER_CHUNK_MB");
-    const u64 CH = (u64)(ce ? std::max(1, atoi(ce)) : 64) << 20;
-    // record-aligned chunks of at most CH bases (a longer record is a chunk of its own)
-    vector<std::pair<u64, u64>> chunks;
-    u64 max_b = 0, max_r = 0;
-    for (u64 r = 0; r < nrec;) {
-        u64 e = r + 1;
-        while (e < nrec && sb.off[e + 1] - sb.off[r] <= CH) e++;
-        chunks.emplace_back(r, e);
-        max_b = std::max(max_b, sb.off[e] - sb.off[r]);
-        max_r = std::max(max_r, e - r);
-        r = e;
-    }
+    const u64 CH = (u64)(ce ? std::max(1, atoi(ce)) : 32) << 20;
     const double t0 = now_ms();
-    PinMem hb0(g.c, max_b), hb1(g.c, max_b), ho0(g.c, (max_r + 1) * 8), ho1(g.c, (max_r + 1) * 8);
-    DevMem db0(g.c, max_b), db1(g.c, max_b), do0(g.c, (max_r + 1) * 8), do1(g.c, (max_r + 1) * 8);
-    DevMem dcodes(g.c, cap * 8);
-    void *hb[2] = {hb0.p, hb1.p}, *ho[2] = {ho0.p, ho1.p}, *db[2] = {db0.p, db1.p}, *dof[2] = {do0.p, do1.p};
-    auto stage = [&](size_t ci) {
-        const int s = (int)(ci & 1);
-        const u64 r0 = chunks[ci].first, r1 = chunks[ci].second, b0 = sb.off[r0], nb = sb.off[r1] - b0;
-        memcpy(hb[s], sb.bases.data() + b0, nb);
-        u64 *o = (u64 *)ho[s];
-        for (u64 r = r0; r <= r1; r++) o[r - r0] = sb.off[r] - b0;
-        ck(ukm_copy_async(g.c, db[s], hb[s], nb));
-        ck(ukm_copy_async(g.c, dof[s], ho[s], (r1 - r0 + 1) * 8));
+    Gpu gp(device);  // the parser thread's own context (page-locked allocations only)
+    HostChunk ch[3];
+    ChunkPipe pipe;
+    for (int i = 0; i < 3; i++) { ch[i].c = gp.c; ch[i].reserve(CH + (1 << 20)); pipe.free_.push_back(i); }
+    std::thread parser([&]() {
+        try {
+            ChunkSink sink(pipe, ch, CH, skip_name);
+            for (auto &f : files) { info("reading sequence file: %s", f.c_str()); parse_fastx(f, sink); }
+            sink.flush();
+        } catch (const std::exception &e) {
+            std::lock_guard<std::mutex> l(pipe.mu);
+            pipe.error = e.what();
+        }
+        pipe.finish();
+    });
+    // device side: chunk i+1 travels (transfer stream) while chunk i is encoded / hashed
+    struct Slot { void *bases = nullptr; u64 bcap = 0; void *off = nullptr; u64 ocap = 0; int host = -1; u64 nrec = 0; };
+    Slot sl[2];
+    DevArray dcodes(g.c);
+    u64 n = 0, total_bases = 0, nchunks = 0;
+    auto upload = [&](Slot &d, int hi) {
+        HostChunk &h = ch[hi];
+        if (h.nb > d.bcap) { if (d.bases) ukm_dev_free(g.c, d.bases); d.bcap = h.nb + h.nb / 8; ck(ukm_dev_alloc(g.c, d.bcap, &d.bases)); }
+        const u64 ob = h.off.size() * 8;
+        if (ob > d.ocap) { if (d.off) ukm_dev_free(g.c, d.off); d.ocap = ob + ob / 8; ck(ukm_dev_alloc(g.c, d.ocap, &d.off)); }
+        ck(ukm_copy_async(g.c, d.bases, h.bases, h.nb));
+        ck(ukm_copy_async(g.c, d.off, h.off.data(), ob));   // (pageable source: staged by the runtime)
+        d.host = hi;
+        d.nrec = h.off.size() - 1;
+        total_bases += h.nb;
+        nchunks++;
     };
-    stage(0);
-    u64 n = 0;
-    for (size_t ci = 0; ci < chunks.size(); ci++) {
-        const int s = (int)(ci & 1);
-        ck(ukm_copy_fence(g.c));                       // chunk ci is (or will be) on the device before its kernels start
-        if (ci + 1 < chunks.size()) stage(ci + 1);     // travels while chunk ci is processed
-        const u64 nr = chunks[ci].second - chunks[ci].first;
+    auto compute = [&](Slot &d) {
+        HostChunk &h = ch[d.host];
+        dcodes.ensure(n, n + h.nb);  // windows <= bases
         u64 m = 0;
-        u64 *dst = (u64 *)dcodes.p + n;
-        if (hashed) ck(ukm_nthash(g.c, (const uint8_t *)db[s], (const u64 *)dof[s], nr, k, canonical, circular, max_hash, dst, cap - n, &m));
-        else ck(ukm_encode_kmers(g.c, (const uint8_t *)db[s], (const u64 *)dof[s], nr, k, canonical, circular, dst, cap - n, &m));
+        if (hashed) ck(ukm_nthash(g.c, (const uint8_t *)d.bases, (const u64 *)d.off, d.nrec, k, canonical, circular, max_hash, dcodes.p + n, dcodes.cap - n, &m));
+        else ck(ukm_encode_kmers(g.c, (const uint8_t *)d.bases, (const u64 *)d.off, d.nrec, k, canonical, circular, dcodes.p + n, dcodes.cap - n, &m));
         n += m;
+        pipe.put_free(d.host);  // its upload is complete (the kernels waited for it): the parser may refill it
+        d.host = -1;
+    };
+    int cur = 0;
+    int hi = pipe.get_full();
+    if (hi >= 0) upload(sl[cur], hi);
+    while (hi >= 0) {
+        ck(ukm_copy_fence(g.c));            // kernels of the current chunk start after its upload
+        const int nxt = pipe.get_full();    // (blocks while the parser is still filling it)
+        if (nxt >= 0) upload(sl[cur ^ 1], nxt);
+        compute(sl[cur]);
+        cur ^= 1;
+        hi = nxt;
     }
+    parser.join();
+    ck(ukm_copy_sync(g.c));
+    for (auto &d : sl) { if (d.bases) ukm_dev_free(g.c, d.bases); if (d.off) ukm_dev_free(g.c, d.off); }
+    for (auto &h : ch) if (h.bases) ukm_host_free(gp.c, h.bases);
+    if (!pipe.error.empty()) die("%s", pipe.error.c_str());
     const double t1 = now_ms();
+    codes.clear();
     u64 nout = n;
     if (!linear && n) {
-        ck(ukm_sort_u64(g.c, (u64 *)dcodes.p, n, key_bits));
+        float ms_sort = 0, ms_uniq = 0;
+        ck(ukm_sort_u64(g.c, dcodes.p, n, key_bits));
+        ukm_last_call_ms(g.c, &ms_sort);
+        const double t1b = now_ms();
         DevMem dout(g.c, n * 8);
-        ck(ukm_unique(g.c, (const u64 *)dcodes.p, nullptr, n, uniq_mode, (u64 *)dout.p, nullptr, n, &nout));
+        const double t1c = now_ms();
+        ck(ukm_unique(g.c, dcodes.p, nullptr, n, uniq_mode, (u64 *)dout.p, nullptr, n, &nout));
+        ukm_last_call_ms(g.c, &ms_uniq);
         const double t2 = now_ms();
+        info("  sort: %.2f ms wall (%.2f ms on the device), output allocation %.2f ms, unique: %.2f ms wall (%.2f ms on the device)",
+             t1b - t1, ms_sort, t1c - t1b, t2 - t1c, ms_uniq);
         codes.resize(nout ? nout : 1);
         ck(ukm_copy(g.c, codes.data(), dout.p, nout * 8));
-        info("device pipeline: %zu chunk(s), upload+encode %.2f ms, sort+unique %.2f ms, download of %llu codes %.2f ms",
-             chunks.size(), t1 - t0, t2 - t1, (unsigned long long)nout, now_ms() - t2);
+        info("device pipeline: %llu bases in %llu chunk(s); parse+upload+encode %.2f ms (overlapped), sort+unique %.2f ms, download of %llu codes %.2f ms",
+             (unsigned long long)total_bases, (unsigned long long)nchunks, t1 - t0, t2 - t1, (unsigned long long)nout, now_ms() - t2);
     } else {
         codes.resize(n ? n : 1);
-        ck(ukm_copy(g.c, codes.data(), dcodes.p, n * 8));
-        info("device pipeline: %zu chunk(s), upload+encode %.2f ms, download of %llu codes %.2f ms", chunks.size(), t1 - t0,
-             (unsigned long long)n, now_ms() - t1);
+        if (n) ck(ukm_copy(g.c, codes.data(), dcodes.p, n * 8));
+        info("device pipeline: %llu bases in %llu chunk(s); parse+upload+encode %.2f ms (overlapped), download of %llu codes %.2f ms",
+             (unsigned long long)total_bases, (unsigned long long)nchunks, t1 - t0, (unsigned long long)n, now_ms() - t1);
     }
     codes.resize(nout);
     return nout;
@@ -560,12 +688,14 @@ static int cmd_count(int argc, char **argv) {
     if (linear && (repeated || unique || sortk)) die("flag -l/--linear is not compatible with -s, -u and -d");
     const string out_file = out_name(a.str("out-prefix", "-"));
 
+    const bool device_pipeline = !parse_taxid && !minimizer;
     SeqBatch sb;
-    for (auto &f : files) { info("reading sequence file: %s", f.c_str()); read_fastx(f, sb, parse_taxid || a.has("seq-name-filter")); }
+    if (!device_pipeline)
+        for (auto &f : files) { info("reading sequence file: %s", f.c_str()); read_fastx(f, sb, parse_taxid || a.has("seq-name-filter")); }
     const u64 n_rec = sb.off.size() - 1;
     // -B name filter / -T taxid per record (count.go:300-344)
     vector<u32> rec_taxid;
-    if (a.has("seq-name-filter") || parse_taxid) {
+    if (!device_pipeline && (a.has("seq-name-filter") || parse_taxid)) {
         std::regex re_tax;
         if (parse_taxid) re_tax = std::regex(a.str("parse-taxid-regexp"));
         std::regex re_name;
@@ -596,11 +726,13 @@ static int cmd_count(int argc, char **argv) {
     for (u64 r = 0; r < nrec; r++) { u64 len = sb.off[r + 1] - sb.off[r]; if (len >= (u64)k) cap += circular ? len : len - k + 1; }
     const int key_bits = hashed ? 64 : 2 * k;
     const int uniq_mode = unique ? UKM_SINGLETON : (repeated ? UKM_REPEATED : UKM_UNIQUE);
-    const bool device_pipeline = !parse_taxid && !minimizer;
     vector<u64> codes;
     u64 n = 0;
     if (device_pipeline) {
-        n = count_on_device(g, sb, k, canonical, circular, hashed, max_hash, linear, uniq_mode, key_bits, cap, codes);
+        std::regex re_skip;
+        if (a.has("seq-name-filter")) re_skip = std::regex(a.str("seq-name-filter"), std::regex::icase);
+        n = count_on_device(g, o.gpu, files, a.has("seq-name-filter") ? &re_skip : nullptr, k, canonical, circular, hashed, max_hash, linear,
+                            uniq_mode, key_bits, codes);
     } else {
         codes.assign(cap ? cap : 1, 0);
         if (nrec) {
