@@ -130,3 +130,23 @@ def test_encode_and_hash_window_counts(env):
     assert 0.019 < frac < 0.021                                  # canonical = min of two uniform hashes: ~2/scale
     mins = ctx.minimizer(bases, reads, k, 15)
     assert 0 < mins.numel() < h.numel() and bool(torch.isin(mins[:1000], h).all())
+
+
+def test_sort_pairs_large_is_a_stable_permutation(env):
+    """3e7 (code, taxid) records with many equal codes through the fused-histogram radix passes (the next pass's
+    digit counts are accumulated while a pass scatters): sorted by code, payloads follow their codes, equal codes
+    keep input order (sorts.Quicksort is unstable in the reference; stable is a valid refinement)."""
+    torch, bench, lib, ctx, A, B = env
+    n = 30_000_000
+    g = torch.Generator(device=A.device)
+    g.manual_seed(7)
+    keys = torch.randint(0, 1 << 22, (n,), dtype=torch.int64, device=A.device, generator=g) << 20
+    vals = torch.arange(n, dtype=torch.int32, device=A.device)
+    k2, v2 = keys.clone(), vals.clone()
+    torch.cuda.synchronize()
+    ctx.sort_pairs(k2, v2, 62)
+    assert bool((k2[1:] >= k2[:-1]).all())
+    assert bool((keys[v2.long()] == k2).all())                      # every payload still sits next to its code
+    same = k2[1:] == k2[:-1]
+    assert bool((v2[1:][same] > v2[:-1][same]).all())               # stable
+    assert _xor(torch, v2.long()) == _xor(torch, vals.long())       # a permutation of the payloads

@@ -459,7 +459,10 @@ __global__ __launch_bounds__(NT) void window_kernel(WinArgs p) {
 // iterator does (count.go:361,373-375).  More candidates than the list holds (a tiny --scale, pathological
 // repeats) -> flag, and the caller takes the prefix-XOR kernel.
 constexpr int ST_NT = 256;
-constexpr int ST_CAP = 1024;             // candidate list entries per tile
+#ifndef ST_CAP_N
+#define ST_CAP_N 1024
+#endif
+constexpr int ST_CAP = ST_CAP_N;         // candidate list entries per tile
 constexpr int ST_RND = ST_CAP / ST_NT;   // compaction rounds
 constexpr int ST_NWV = ST_NT / 64;
 
@@ -520,8 +523,7 @@ __global__ __launch_bounds__(ST_NT) void nthash_strip_kernel(StripArgs p) {
     __shared__ __attribute__((aligned(16))) uint4 s_tout[256];  // [byte] = { rol(seed, k), ror(cseed, 1) }
     __shared__ u64 s_ch[ST_CAP];   // candidates in arrival order
     __shared__ u32 s_ci[ST_CAP];   // owner lane << 24 | sequence number << 11 | window index in the strip
-    __shared__ u64 s_oh[ST_CAP];   // candidates in window order
-    __shared__ u32 s_op[ST_CAP];   // tile-local window start
+    __shared__ unsigned short s_ord[ST_CAP];  // window order -> arrival order (an index, so that the list is not copied)
     __shared__ u32 s_base[ST_NT];
     __shared__ u32 s_scan[ST_NWV + 1];
     __shared__ u32 s_cnt[ST_RND * ST_NWV + 1];
@@ -620,10 +622,8 @@ __global__ __launch_bounds__(ST_NT) void nthash_strip_kernel(StripArgs p) {
         const u32 ci = s_ci[e];
         const u32 owner = ci >> 24, seq = (ci >> 11) & 0x1FFFu, w = ci & 0x7FFu;
         const u32 slot = s_base[owner] + seq;
-        if (slot < (u32)ST_CAP) {
-            s_oh[slot] = s_ch[e];
-            s_op[slot] = owner * (u32)L + w;
-        }
+        (void)w;
+        if (slot < (u32)ST_CAP) s_ord[slot] = (unsigned short)e;
     }
     __syncthreads();
     // is the window inside one record?  (records shorter than k never hold one)
@@ -638,11 +638,13 @@ __global__ __launch_bounds__(ST_NT) void nthash_strip_kernel(StripArgs p) {
             const u32 slot = (u32)tid + (u32)m * ST_NT;
             hv[m] = 0;
             if (slot < n && n_all <= (u32)ST_CAP) {
-                const u64 pos = P0 + (u64)s_op[slot];
+                const u32 e = s_ord[slot];
+                const u32 ci = s_ci[e];
+                const u64 pos = P0 + (u64)(ci >> 24) * (u64)L + (u64)(ci & 0x7FFu);
                 const u64 ub = upper_bound_u64(p.rec_off, r_lo, r_hi, pos);  // first record starting behind pos
                 if (ub > 0 && ub <= p.n_rec && pos + (u64)k <= p.rec_off[ub]) {
                     keep |= 1u << m;
-                    hv[m] = s_oh[slot];
+                    hv[m] = s_ch[e];
                 }
             }
         }
@@ -693,13 +695,15 @@ int run_strip_filter(ukm_ctx *c, const u8 *bases, const u64 *rec_off, u64 n_rec,
     if (force == 0) return UKM_OK;
     if (((uintptr_t)bases & 3) != 0) return UKM_OK;
     // expected candidates per tile = NT * L * (max_hash / 2^64), twice that when canonical (min(f, r) <= m iff
-    // f <= m or r <= m); keep it below a third of the list
+    // f <= m or r <= m); keep it below 0.6 of the list
     const double frac = ((double)max_hash + 1.0) / 18446744073709551616.0 * (canonical ? 2.0 : 1.0);
     int L = 1024;
     // enough tiles to fill the chip
     while (L > 256 && total_bases / ((u64)ST_NT * (u64)L) < 2048) L >>= 1;
-    while (L > 64 && (double)ST_NT * L * frac > ST_CAP / 3.0) L >>= 1;
-    if (force != 1 && ((double)ST_NT * L * frac > ST_CAP / 3.0 || L < 256)) return UKM_OK;  // small --scale: general kernel
+    // (the count is Poisson: 0.6 x capacity leaves more than ten standard deviations of head room)
+    while (L > 64 && (double)ST_NT * L * frac > ST_CAP * 0.6) L >>= 1;
+    if (force != 1 && ((double)ST_NT * L * frac > ST_CAP * 0.6 || L < 256)) return UKM_OK;  // small --scale: general kernel
+    if (const char *le = getenv("UKM_STRIP_L")) L = std::max(64, atoi(le) / 64 * 64);  // developer knob
     const u64 tile_pos = (u64)ST_NT * (u64)L;
     const u64 ntiles = (total_bases + tile_pos - 1) / tile_pos;
     if (ntiles > 0x7FFFFFFFull) return UKM_OK;

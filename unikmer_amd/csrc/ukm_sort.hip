@@ -23,7 +23,7 @@ namespace {
 // keys only 512x14 (4.15 ms; 512x12 4.3, 512x15 5.3, 256x24 4.6, 768x10 4.9, 1024x7 5.1),
 // key + taxid 1024x11 (5.1 ms; 768x14 5.1, 512x20 5.4, 512x12 6.4)
 #ifndef SORT_NT_KEYS
-#define SORT_NT_KEYS 512
+#define SORT_NT_KEYS 1024
 #endif
 #ifndef SORT_VT_KEYS
 #define SORT_VT_KEYS 14
@@ -107,7 +107,28 @@ struct PassArgs {
     u32 *flags;        // bit0: look-back watchdog fired
     const u64 *gbase;  // [256] exclusive digit bases of this pass
     u64 ntiles;
+    u64 *next_hist;    // fused mode: [256] digit counts of the NEXT pass, accumulated while this pass scatters (or nullptr)
+    int next_shift;
 };
+
+// exclusive digit bases of one pass from its histogram (fused mode: runs on the stream between two passes, so the
+// host never sees the histograms)
+__global__ void radix_bases_kernel(const u64 *hist, u64 *gbase) {
+    __shared__ u64 s[RADIX];
+    const int d = (int)threadIdx.x;
+    s[d] = hist[d];
+    __syncthreads();
+    if (d == 0) {
+        u64 sum = 0;
+        for (int i = 0; i < RADIX; i++) {
+            const u64 v = s[i];
+            s[i] = sum;
+            sum += v;
+        }
+    }
+    __syncthreads();
+    gbase[d] = s[d];
+}
 
 // "match any" on an 8-bit digit: on return (phi:plo) is the 64-bit mask of the lanes whose digit
 // equals this lane's.  Per bit: sign-extended bit x (0 / -1), ballot m = (x != 0), peers &= ~(m ^ x)
@@ -194,8 +215,10 @@ __global__ __launch_bounds__(NT_) SORT_WAVES_ATTR void onesweep_kernel(PassArgs<
     __shared__ u64 s_gbase[RADIX];
     __shared__ u32 s_scan[NW + 1];
     __shared__ u32 s_tile;
+    __shared__ u32 s_nh[RADIX];
     const int tid = (int)threadIdx.x, lane = lane_id(), wave = tid >> 6;
     if (TICKET && tid == 0) s_tile = atomicAdd(p.ticket, 1u);
+    if (tid < RADIX) s_nh[tid] = 0;
     for (int i = tid; i < NW * RADIX / 2; i += NT) reinterpret_cast<u32 *>(&s_whist[0][0])[i] = 0;
     __syncthreads();
     const u64 tile = TICKET ? (u64)s_tile : (u64)blockIdx.x;
@@ -233,6 +256,9 @@ __global__ __launch_bounds__(NT_) SORT_WAVES_ATTR void onesweep_kernel(PassArgs<
         const u32 r = (u32)__popc(plo & lt_lo) + (u32)__popc(phi & lt_hi);
         const u32 tot = (u32)__popc(plo) + (u32)__popc(phi);
         rank[j] = pre + r;
+        // fused mode: this key's digit of the NEXT pass is counted here, so that no separate pass over the keys is
+        // needed for it (the pre-pass builds the first histogram only)
+        if (p.next_hist && li < valid_count) atomicAdd(&s_nh[(u32)(key[j] >> p.next_shift) & DMASK], 1u);
         // every peer stores the same new count (same address, same value): no branch, so the 16 keys'
         // ranking stays one basic block that the scheduler can interleave
         s_whist[wave][d] = (unsigned short)(pre + tot);
@@ -320,6 +346,10 @@ __global__ __launch_bounds__(NT_) SORT_WAVES_ATTR void onesweep_kernel(PassArgs<
     }
     if (timed_out) atomicOr(p.flags, 1u);
     if (owner) s_gbase[d] = p.gbase[d] + excl - (u64)dex;
+    if (p.next_hist && owner) {
+        const u32 c = s_nh[d];  // (complete: at least one barrier lies between the counting and here)
+        if (c) atomicAdd((unsigned long long *)&p.next_hist[d], (unsigned long long)c);
+    }
     __syncthreads();
 
     for (u32 i = (u32)tid; i < valid_count; i += NT) {
@@ -333,7 +363,7 @@ __global__ __launch_bounds__(NT_) SORT_WAVES_ATTR void onesweep_kernel(PassArgs<
 
 template <typename SW, bool PAIRS, int NT_, int VT_>
 int run_passes(ukm_ctx *c, u64 *keys, u32 *vals, u64 *tk, u32 *tv, u64 n, int npass,
-               const int *shifts, const u64 *gbase_dev, bool *result_in_tmp) {
+               const int *shifts, const u64 *gbase_dev, bool *result_in_tmp, u64 *fused_hist = nullptr) {
     constexpr int TILE = NT_ * VT_;
     const u64 ntiles = (n + TILE - 1) / TILE;
     SW *status = nullptr;
@@ -355,6 +385,18 @@ int run_passes(ukm_ctx *c, u64 *keys, u32 *vals, u64 *tk, u32 *tv, u64 n, int np
             p.status = status; p.ticket = (u32 *)ctl; p.flags = (u32 *)(ctl + 1);
             p.gbase = gbase_dev + (size_t)i * RADIX;
             p.ntiles = ntiles;
+            p.next_hist = nullptr;
+            p.next_shift = 0;
+            if (fused_hist) {
+                // bases of this pass from its histogram (built by the pre-pass for i = 0, by pass i - 1 otherwise)
+                if (attempt == ((c->setop_force_ticket || SORT_TICKET) ? 1 : 0))
+                    hipLaunchKernelGGL(radix_bases_kernel, dim3(1), dim3(RADIX), 0, c->stream, fused_hist + (size_t)i * RADIX,
+                                       const_cast<u64 *>(p.gbase));
+                if (i + 1 < npass) {
+                    p.next_hist = fused_hist + (size_t)(i + 1) * RADIX;
+                    p.next_shift = shifts[i + 1];
+                }
+            }
             const dim3 grid((unsigned)ntiles), block(NT_);
             if (ticket) hipLaunchKernelGGL((onesweep_kernel<SW, PAIRS, true, NT_, VT_>), grid, block, 0, c->stream, p);
             else hipLaunchKernelGGL((onesweep_kernel<SW, PAIRS, false, NT_, VT_>), grid, block, 0, c->stream, p);
@@ -364,6 +406,8 @@ int run_passes(ukm_ctx *c, u64 *keys, u32 *vals, u64 *tk, u32 *tv, u64 n, int np
             UKM_TRY(ukm_read_u64(c, ctl + 1, &fl));
             if (!(fl & 1)) break;
             ukm_switch_to_tickets(c, "radix sort pass");  // this device does not dispatch in order
+            if (fused_hist && i + 1 < npass)  // the repeated pass counts the next digit again
+                UKM_HIP(hipMemsetAsync(fused_hist + (size_t)(i + 1) * RADIX, 0, RADIX * sizeof(u64), c->stream));
         }
         std::swap(src_k, dst_k);
         std::swap(src_v, dst_v);
@@ -422,6 +466,40 @@ int ukm_dev_sort(ukm_ctx *c, u64 *keys, u32 *vals, u64 n, int key_bits) {
         return UKM_OK;
     }
     const int passes = (key_bits + RB - 1) / RB;
+#ifndef SORT_FUSED_MIN
+#define SORT_FUSED_MIN (1ull << 24)
+#endif
+    if (n >= SORT_FUSED_MIN && RB == 8) {
+        // Large inputs: only the FIRST digit's histogram is built by a pass over the keys; every scatter pass counts
+        // the next digit on the fly and a 256-thread kernel turns the counts into bases between two passes.  No
+        // host round trip at all (the histograms never leave the device), at the price of not seeing digits that
+        // happen to be constant beyond what key_bits says.
+        u64 *fh = nullptr, *gb = nullptr, *tk = nullptr;
+        u32 *tv = nullptr;
+        UKM_TRY(ws_alloc_t(c, (size_t)MAX_PASSES * RADIX, &fh));
+        UKM_TRY(ws_alloc_t(c, (size_t)MAX_PASSES * RADIX, &gb));
+        UKM_HIP(hipMemsetAsync(fh, 0, MAX_PASSES * RADIX * sizeof(u64), c->stream));
+        unsigned hb = (unsigned)std::min<u64>((n + 4095) / 4096, (u64)c->num_cu * 8);
+        hipLaunchKernelGGL(radix_hist_kernel, dim3(hb), dim3(NT), 0, c->stream, keys, n, 1, fh);
+        UKM_HIP(hipGetLastError());
+        int sh[MAX_PASSES];
+        for (int p = 0; p < passes; p++) sh[p] = RB * p;
+        UKM_TRY(ws_alloc_t(c, n, &tk));
+        if (vals) UKM_TRY(ws_alloc_t(c, n, &tv));
+        bool in_tmp = false;
+        if (vals) {
+            if (n < (1ull << 30)) UKM_TRY((run_passes<u32, true, SORT_NT_PAIRS, SORT_VT_PAIRS>(c, keys, vals, tk, tv, n, passes, sh, gb, &in_tmp, fh)));
+            else UKM_TRY((run_passes<u64, true, SORT_NT_PAIRS, SORT_VT_PAIRS>(c, keys, vals, tk, tv, n, passes, sh, gb, &in_tmp, fh)));
+        } else {
+            if (n < (1ull << 30)) UKM_TRY((run_passes<u32, false, SORT_NT_KEYS, SORT_VT_KEYS>(c, keys, vals, tk, tv, n, passes, sh, gb, &in_tmp, fh)));
+            else UKM_TRY((run_passes<u64, false, SORT_NT_KEYS, SORT_VT_KEYS>(c, keys, vals, tk, tv, n, passes, sh, gb, &in_tmp, fh)));
+        }
+        if (in_tmp) {
+            UKM_HIP(hipMemcpyAsync(keys, tk, n * sizeof(u64), hipMemcpyDeviceToDevice, c->stream));
+            if (vals) UKM_HIP(hipMemcpyAsync(vals, tv, n * sizeof(u32), hipMemcpyDeviceToDevice, c->stream));
+        }
+        return UKM_OK;
+    }
 
     u64 *ghist = nullptr;
     UKM_TRY(ws_alloc_t(c, MAX_PASSES * RADIX, &ghist));
