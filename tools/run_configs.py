@@ -108,7 +108,9 @@ def main():
         assert u.numel() <= nu and bool((u[1:] > u[:-1]).all())
         res["config3_union_%d_files_x_%.0e" % (nfiles, per)] = {"ms": ms, "input_kmers": total, "kmers_per_s": total / ms * 1e3,
                                                                   "out": u.numel(), "gpus": 1,
-                                                                  "note": "pairwise merge tree of 2-way unions, all on one GPU"}
+                                                                  "algorithmic_GB": (8 * total + 8 * u.numel()) / 1e9,
+                                                                  "note": "k-way streaming merge (ukm_kway.hip): 3 levels of 8-way merges over shared value "
+                                                                          "ranges, all on one GPU (round 1: 7-level pairwise tree, 78.7 ms)"}
         del files, U, out
 
     if "4" in want:
@@ -138,8 +140,36 @@ def main():
             "inter_ms": ms_i, "inter_out": n_inter, "diff_ms": ms_d, "diff_out": rd[0].numel(),
             "diff_compare_taxid_ms": ms_dt, "diff_compare_taxid_out": rdt[0].numel(), "input_kmers": total,
             "inter_kmers_per_s": total / ms_i * 1e3,
-            "note": "sequential fold (reference algorithm): inter stops early when empty; diff visits all files; "
-                    "random taxids over a 2.4M-node tree (adversarial for LCA)"}
+            "note": "SURVEY 8(d) generator (independent p = 0.9 draws): 0.9^n empties the running result after ~130 files, so "
+                    "inter and plain diff are EARLY-EXIT dominated (inter.go:283-286, diff.go:457-459); only diff -t visits all "
+                    "files.  The `_core` entry below is the same job with a result that survives every file."}
+        # the same shape with a shared core (30 % of the universe is in every file) and private codes in the first
+        # file: inter, diff and diff -t all fold over ALL files
+        core = ((bench.splitmix64_torch(j ^ bench._i64(bench.SEED + 77)) >> 11) & ((1 << 20) - 1)) < int(0.3 * (1 << 20))
+        files2, taxs2 = [], []
+        for f in range(nfiles):
+            h = bench.splitmix64_torch(j ^ bench._i64(bench.SEED + 1000 * (f + 1)))
+            m = (((h >> 11) & ((1 << 20) - 1)) < thr) | core
+            if f == 0:
+                k = torch.cat([U[m], U[-1] + 1 + torch.arange(per // 10, dtype=torch.int64, device=dev) * 3])
+            else:
+                k = U[m]
+            files2.append(k)
+            taxs2.append((1 + (bench.splitmix64_torch(k ^ bench._i64(bench.SEED + 2 + f)) & ((1 << 40) - 1)) % T).to(torch.int32))
+        total2 = sum(x.numel() for x in files2)
+        ok = torch.empty(files2[0].numel() + 8, dtype=torch.int64, device=dev)
+        ot = torch.empty(files2[0].numel() + 8, dtype=torch.int32, device=dev)
+        ms_i, ri = wall(lambda: ctx.inter(files2, taxs2, out=ok, out_taxids=ot), reps=max(1, args.reps - 1))
+        n_inter = ri[0].numel()
+        ms_d, rd = wall(lambda: ctx.diff(files2, taxs2, out=ok, out_taxids=ot), reps=max(1, args.reps - 1))
+        n_diff = rd[0].numel()
+        ms_dt, rdt = wall(lambda: ctx.diff(files2, taxs2, compare_taxid=True, out=ok, out_taxids=ot), reps=max(1, args.reps - 1))
+        res["config4_core_inter_diff_%d_files_taxids" % nfiles] = {
+            "inter_ms": ms_i, "inter_out": n_inter, "diff_ms": ms_d, "diff_out": n_diff,
+            "diff_compare_taxid_ms": ms_dt, "diff_compare_taxid_out": rdt[0].numel(), "input_kmers": total2,
+            "inter_kmers_per_s": total2 / ms_i * 1e3, "diff_kmers_per_s": total2 / ms_d * 1e3,
+            "note": "no early exit: every one of the %d links runs (result sizes above are non-zero)" % (nfiles - 1)}
+        del files2, taxs2
         del files, taxs, U
 
     if "5" in want:
