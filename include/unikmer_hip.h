@@ -194,6 +194,27 @@ uint32_t ukm_common_threshold(uint32_t nfiles, double proportion, uint32_t numbe
 int ukm_partition_points(ukm_ctx *ctx, const uint64_t *keys, uint64_t n,
                          const uint64_t *splitters, int n_split, uint64_t *cuts);
 
+/* ---- multi-GPU exchange over RCCL / xGMI (new): one process and one ukm_ctx per GPU.
+ *      The reference is single-process; this is the step that lets a host shard the code space by high-bits prefix:
+ *        ukm_prefix_splitters -> ukm_partition_points (cuts of every local sorted file) -> ukm_shard_exchange (slice g
+ *        of every rank travels to rank g) -> ukm_union / ukm_merge_k of the received slices -> the 1-GPU operation on
+ *        the rank's range; the ranks' results concatenated in rank order are the global sorted result.
+ *      ukm_comm_get_unique_id: 128 opaque bytes (ncclUniqueId) made by ONE rank and handed to the others by the host
+ *      (file, socket, MPI ...).  ukm_comm_init is collective.  RCCL is loaded on first use (dlopen): a single-GPU host
+ *      needs no RCCL at all.
+ *      ukm_shard_exchange: send_counts[nranks] (host) = number of consecutive records of keys/taxids for each rank in
+ *      rank order (their sum is the stream length); recv_counts[nranks] (host, out) = records received from each rank;
+ *      the received slices are stored back to back in source-rank order (each is sorted; together they are this rank's
+ *      range of the logical file).  keys / taxids / out_* may be host or device pointers. */
+#define UKM_COMM_ID_BYTES 128
+int ukm_comm_get_unique_id(void *id);
+int ukm_comm_init(ukm_ctx *ctx, int nranks, int rank, const void *id);
+int ukm_comm_destroy(ukm_ctx *ctx);
+int ukm_comm_info(ukm_ctx *ctx, int *nranks, int *rank);
+int ukm_prefix_splitters(int key_bits, int nranks, uint64_t *splitters);
+int ukm_shard_exchange(ukm_ctx *ctx, const uint64_t *keys, const uint32_t *taxids, const uint64_t *send_counts,
+                       uint64_t *out_keys, uint32_t *out_taxids, uint64_t out_cap, uint64_t *recv_counts, uint64_t *n_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -145,3 +145,40 @@ def test_bench_two_ranks_incl_exchange():
     assert "error" not in res.get("exchange", {}), res.get("exchange")
     assert res["value_incl_exchange"] > 0 and res["incl_exchange"]["steps"] >= 1
     assert res["roofline"]["frac"] > 0 and res["cpu_baseline"] is None
+
+
+def test_c_abi_rccl_exchange_one_rank():
+    """The exchange step behind the C ABI (ukm_comm_* / ukm_shard_exchange: RCCL loaded by the library itself, no
+    torch.distributed): a communicator of one rank — the only size a one-GPU box allows (RCCL refuses two ranks on
+    one device) — moves host arrays and device tensors through grouped ncclSend / ncclRecv and back."""
+    import torch
+    from unikmer_amd import dist as ud
+    from unikmer_amd import lib
+    ctx = lib.Context(0)
+    assert ctx.comm_info() == (0, 0)
+    uid = lib.Context.comm_unique_id()
+    assert len(uid) == 128
+    ctx.comm_init(1, 0, uid)
+    assert ctx.comm_info() == (1, 0)
+    rng = np.random.default_rng(3)
+    keys = np.unique(rng.integers(0, 1 << 62, 300_000, dtype=np.uint64))
+    tax = rng.integers(1, 1000, len(keys)).astype(np.uint32)
+    out, out_t, rc = ctx.shard_exchange(keys, [len(keys)], tax)
+    assert rc.tolist() == [len(keys)] and np.array_equal(out, keys) and np.array_equal(out_t, tax)
+    out, out_t, rc = ctx.shard_exchange(keys, [len(keys)])
+    assert out_t is None and np.array_equal(out, keys)
+    dk = torch.from_numpy(keys.view(np.int64)).cuda()
+    torch.cuda.synchronize()
+    dout, _, rc = ctx.shard_exchange(dk, [len(keys)])
+    assert dout.is_cuda and np.array_equal(dout.cpu().numpy().view(np.uint64), keys)
+    out, _, rc = ctx.shard_exchange(np.empty(0, np.uint64), [0])
+    assert len(out) == 0 and rc.tolist() == [0]
+    # the library's splitters are dist.py's
+    for bits, world in ((62, 8), (42, 3), (64, 4), (2, 5)):
+        assert ctx.prefix_splitters(bits, world).tolist() == ud.prefix_splitters(bits, world)[:-1]
+    with pytest.raises(lib.UkmError):
+        ctx.comm_init(1, 0, uid)            # one communicator per context
+    ctx.comm_destroy()
+    with pytest.raises(lib.UkmError):
+        ctx.shard_exchange(keys, [len(keys)])
+    ctx.close()

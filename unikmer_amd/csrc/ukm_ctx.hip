@@ -75,6 +75,7 @@ extern "C" int ukm_ctx_destroy(ukm_ctx *c) {
     if (!c) return UKM_OK;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
+    if (c->comm) (void)ukm_comm_destroy(c);
     ws_free_all(c);
     if (c->tax_parent) (void)hipFree(c->tax_parent);
     if (c->tax_depth) (void)hipFree(c->tax_depth);

@@ -68,6 +68,9 @@ struct ukm_ctx {
     hipStream_t xfer = nullptr;
     hipEvent_t ev_xfer = nullptr, ev_comp = nullptr;
     bool xfer_pending = false;
+    // RCCL communicator of the multi-GPU exchange (ukm_comm.hip); nullptr until ukm_comm_init
+    void *comm = nullptr;
+    int comm_size = 0, comm_rank = 0;
     int depth = 0;  // nesting depth of API calls (n-way ops call 2-way ops)
 
     std::vector<WsBlock> blocks;

@@ -28,6 +28,8 @@ SYMBOLS = [
     "ukm_encode_kmers", "ukm_nthash", "ukm_minimizer", "ukm_max_hash", "ukm_sort_u64", "ukm_sort_pairs",
     "ukm_unique", "ukm_merge_k", "ukm_setop2", "ukm_union", "ukm_inter", "ukm_diff",
     "ukm_common", "ukm_common_threshold", "ukm_partition_points",
+    "ukm_comm_get_unique_id", "ukm_comm_init", "ukm_comm_destroy", "ukm_comm_info", "ukm_prefix_splitters",
+    "ukm_shard_exchange",
 ]
 
 
@@ -123,6 +125,12 @@ def load():
     L.ukm_common_threshold.argtypes = [u32, C.c_double, u32]
     L.ukm_common_threshold.restype = u32
     L.ukm_partition_points.argtypes = [vp, vp, u64, vp, i32, vp]
+    L.ukm_comm_get_unique_id.argtypes = [vp]
+    L.ukm_comm_init.argtypes = [vp, i32, i32, vp]
+    L.ukm_comm_destroy.argtypes = [vp]
+    L.ukm_comm_info.argtypes = [vp, C.POINTER(i32), C.POINTER(i32)]
+    L.ukm_prefix_splitters.argtypes = [i32, i32, vp]
+    L.ukm_shard_exchange.argtypes = [vp, vp, vp, vp, vp, vp, u64, vp, pu64]
     _lib = L
     return L
 
@@ -410,6 +418,48 @@ class Context:
 
     def common_threshold(self, nfiles, proportion=1.0, number=0):
         return self.L.ukm_common_threshold(nfiles, proportion, number)
+
+    # ---- multi-GPU exchange through the C ABI (RCCL inside the library; dist.py is the torch.distributed twin) ----
+    @staticmethod
+    def comm_unique_id():
+        buf = (C.c_char * 128)()
+        _check(load().ukm_comm_get_unique_id(buf))
+        return bytes(buf)
+
+    def comm_init(self, nranks, rank, uid):
+        assert len(uid) == 128
+        _check(self.L.ukm_comm_init(self.h, nranks, rank, C.c_char_p(uid)))
+
+    def comm_destroy(self):
+        _check(self.L.ukm_comm_destroy(self.h))
+
+    def comm_info(self):
+        n, r = C.c_int(), C.c_int()
+        _check(self.L.ukm_comm_info(self.h, C.byref(n), C.byref(r)))
+        return n.value, r.value
+
+    def prefix_splitters(self, key_bits, nranks):
+        sp = np.empty(nranks, dtype=np.uint64)
+        _check(self.L.ukm_prefix_splitters(key_bits, nranks, sp.ctypes.data))
+        return sp
+
+    def shard_exchange(self, keys, send_counts, taxids=None):
+        """all-to-all-v of the contiguous slices of one sorted stream; returns (keys, taxids | None, recv_counts)"""
+        pk, n, k1 = _ptr(keys, np.uint64)
+        pt, _, k2 = _ptr(taxids, np.uint32)
+        sc = np.ascontiguousarray(send_counts, dtype=np.uint64)
+        assert int(sc.sum()) == n
+        rc = np.zeros(len(sc), dtype=np.uint64)
+        # capacity: the counts are not known before the call; size for the worst case of this job (callers that know
+        # better pass device tensors of their own through the C ABI directly)
+        cap = max(1, int(n) * len(sc))
+        out = _empty_like_kind(keys, cap, np.uint64)
+        out_t = _empty_like_kind(keys, cap, np.uint32) if taxids is not None else None
+        po, _, _ = _ptr(out, np.uint64)
+        pot, _, _ = _ptr(out_t, np.uint32)
+        m = C.c_uint64()
+        _check(self.L.ukm_shard_exchange(self.h, pk, pt, sc.ctypes.data, po, pot, cap, rc.ctypes.data, C.byref(m)))
+        return out[: m.value], (out_t[: m.value] if out_t is not None else None), rc
 
     def partition_points(self, keys, splitters):
         pk, n, k1 = _ptr(keys, np.uint64)
