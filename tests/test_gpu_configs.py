@@ -206,3 +206,60 @@ def test_config4_chain_with_duplicates_falls_back(env):
         ok, ot = ofn(files, taxs, tax)
         assert np.array_equal(gk, ok) and np.array_equal(gt, ot)
         assert np.array_equal(fn(files), ofn(files))
+
+
+# ------------------------------------------------------------------------------------------- k-way kernel edges
+@pytest.mark.parametrize("nstreams", [3, 4, 5, 8, 9, 17, 64, 65])
+def test_kway_stream_counts_and_extreme_codes(env, nstreams):
+    """fan-in 4 (<= 4 streams) and 8, one / two / three levels, nodes with a single child, and the codes 0 and
+    2^64-1 (the in-LDS merges use 2^64-1 as their sentinel: a real one takes the bounds-checked loop)"""
+    O, L, ctx, tax, T = env
+    rng = np.random.default_rng(nstreams)
+    streams = []
+    for i in range(nstreams):
+        n = int(rng.choice([0, 1, 7, 600, 5000, 40_000]))
+        s = np.unique(rng.integers(0, 1 << 64, n, dtype=np.uint64))
+        if i % 3 == 0:
+            s = np.unique(np.concatenate([s, np.array([0, 2**64 - 1], dtype=np.uint64)]))
+        if i % 5 == 1:
+            s = np.unique(np.concatenate([s, np.array([2**64 - 1], dtype=np.uint64)]))
+        streams.append(s)
+    taxs = [_taxids(s, T, i) for i, s in enumerate(streams)]
+    assert np.array_equal(ctx.union(streams), O.union(streams))
+    gk, gt = ctx.union(streams, taxs)
+    ok, ot = O.union(streams, taxs, tax)
+    assert np.array_equal(gk, ok) and np.array_equal(gt, ot)
+    for mode in (L.PLAIN, L.REPEATED):
+        assert np.array_equal(ctx.merge_k(streams, mode=mode), O.merge_k(streams, mode=mode))
+    gk, gt = ctx.merge_k(streams, taxs, mode=L.PLAIN)
+    cat, tcat = np.concatenate(streams), np.concatenate(taxs)
+    o = np.argsort(cat, kind="stable")
+    assert np.array_equal(gk, cat[o]) and np.array_equal(gt, tcat[o])
+    thr = max(1, nstreams // 3)
+    assert np.array_equal(ctx.common(streams, thr), O.common(streams, thr))
+
+
+def test_kway_long_runs_and_multisets(env):
+    """runs of one code longer than a chunk inside a stream (the k-way kernel gives up and the pairwise / sort route
+    answers), shorter runs (handled in the kernel: all copies of a consumed code are in LDS), all streams equal"""
+    O, L, ctx, tax, T = env
+    rng = np.random.default_rng(11)
+    base = np.sort(rng.integers(0, 1 << 40, 30_000).astype(np.uint64))
+    long_run = np.sort(np.concatenate([base, np.full(5000, base[100], dtype=np.uint64)]))
+    short_runs = np.sort(np.concatenate([base, np.repeat(base[::50], 40)]))
+    streams = [base, long_run, short_runs, base.copy(), np.sort(rng.integers(0, 1 << 40, 10).astype(np.uint64))]
+    taxs = [_taxids(np.arange(len(s), dtype=np.uint64) + np.uint64(i), T, i) for i, s in enumerate(streams)]
+    assert np.array_equal(ctx.union(streams), O.union(streams))
+    gk, gt = ctx.union(streams, taxs)
+    ok, ot = O.union(streams, taxs, tax)
+    assert np.array_equal(gk, ok) and np.array_equal(gt, ot)
+    assert np.array_equal(ctx.merge_k(streams, mode=L.PLAIN), np.sort(np.concatenate(streams)))
+    assert np.array_equal(ctx.merge_k(streams, mode=L.REPEATED), O.merge_k(streams, mode=L.REPEATED))
+    ssub = [short_runs, base, short_runs.copy()]          # no long run: stays in the k-way kernel
+    gk, gt = ctx.merge_k(ssub, [taxs[2], taxs[0], taxs[2]], mode=L.PLAIN)
+    cat, tcat = np.concatenate(ssub), np.concatenate([taxs[2], taxs[0], taxs[2]])
+    o = np.argsort(cat, kind="stable")
+    assert np.array_equal(gk, cat[o]) and np.array_equal(gt, tcat[o])
+    same = [base] * 9
+    assert np.array_equal(ctx.union(same), np.unique(base))
+    assert np.array_equal(ctx.common(same, 9), np.unique(base))
