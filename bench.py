@@ -229,6 +229,71 @@ def main():
     ms_per_step = dt * 1e3 / args.steps
     value = 2.0 * tot_in * args.steps / dt  # each op consumes |A|+|B| input k-mers
 
+    res = None
+    if rank == 0:
+        # roofline of the dominant kernel (union tile kernel): algorithmic bytes per launch
+        # = 8(|A|+|B|) read + 8|A∪B| written (SURVEY.md §8(d)), rank 0's launch
+        ku = ku_sum / args.steps * 1e-3
+        ki = ki_sum / args.steps * 1e-3
+        bytes_u = 8.0 * (na + nb) + 8.0 * nu
+        bytes_i = 8.0 * (na + nb) + 8.0 * ni
+        peak = 8000.0
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            try:
+                tj = json.load(open(tpath))
+                if int(tj.get("n", 0)) == n:
+                    traffic = tj.get("union_traffic_bytes_per_launch")
+            except Exception:
+                traffic = None
+        roofline = {"bound": "hbm", "kernel": "setop_tile_kernel<UNION>", "achieved": bytes_u / ku / 1e9,
+                    "peak": peak, "unit": "GB/s", "frac": bytes_u / ku / 1e9 / peak, "traffic": traffic,
+                    "algorithmic_bytes": bytes_u, "kernel_ms": ku * 1e3,
+                    # SURVEY §8(d) also asks for the read side alone (8(|A|+|B|) bytes over the same time)
+                    "read_only_achieved": 8 * (na + nb) / ku / 1e9, "read_only_frac": 8 * (na + nb) / ku / 1e9 / peak,
+                    "note": "frac = (8(|A|+|B|) read + 8|out| written) / kernel time / 8 TB/s.  north_star's '>= 50 % of "
+                            "HBM-read roofline' is read_only_frac >= 0.5, i.e. kernel <= 4.0 ms at this size: reachable for "
+                            "inter (21.3 GB total), not for union, whose 10.7 GB of output make 4.0 ms = 6.7 TB/s of mixed "
+                            "traffic, above the ~6.3 TB/s this part sustains on a plain copy"}
+        roofline_inter = {"bound": "hbm", "kernel": "setop_tile_kernel<INTER>", "achieved": bytes_i / ki / 1e9,
+                          "peak": peak, "unit": "GB/s", "frac": bytes_i / ki / 1e9 / peak,
+                          "algorithmic_bytes": bytes_i, "kernel_ms": ki * 1e3,
+                          "read_only_achieved": 8 * (na + nb) / ki / 1e9, "read_only_frac": 8 * (na + nb) / ki / 1e9 / peak}
+        cpu = None
+        if world == 1 and args.cpu_sample > 0:
+            cpu = cpu_baseline((4 * int(args.cpu_sample) + 2) // 3, 32)
+        res = {
+            "metric": "k-mers/sec for union+inter of 1e9-k-mer k=31 sets",
+            "value": value, "unit": "k-mers/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u64", "data": "synthetic",
+            "config": {"workload": "union+inter of two sorted k=31 sets of %d uint64 codes per GPU "
+                                   "(|A|=%d |B|=%d |A∪B|=%d |A∩B|=%d on rank 0)" % (n, na, nb, nu, ni),
+                       "k": 31, "per_gpu_set_size": n, "parallelism": "prefix-sharded x%d" % world,
+                       "ops_per_step": ["ukm_setop2(UNION)", "ukm_setop2(INTER)"]},
+            "roofline": roofline, "roofline_inter": roofline_inter, "cpu_baseline": cpu,
+            "union_kmers_per_s_kernel": (na + nb) / ku, "inter_kmers_per_s_kernel": (na + nb) / ki,
+        }
+    # The leg below talks to the other ranks.  If one of them fails there (out of memory, an RCCL error) the
+    # others would wait in a collective for ever and the headline measured above would be lost with them: a
+    # watchdog prints the line without the leg and ends the process instead.
+    import threading
+    leg_done = threading.Event()
+
+    def _bail():
+        if leg_done.is_set():
+            return
+        if rank == 0 and res is not None:
+            res["exchange"] = {"error": "the end-to-end leg did not finish within %d s; headline numbers are unaffected" % LEG_TIMEOUT}
+            print(json.dumps(res), flush=True)
+        os._exit(0)
+    LEG_TIMEOUT = int(os.environ.get("UKM_BENCH_LEG_TIMEOUT", "240"))
+    watchdog = None
+    if world > 1 and not args.no_exchange:
+        watchdog = threading.Timer(LEG_TIMEOUT, _bail)
+        watchdog.daemon = True
+        watchdog.start()
     # ---- N > 1: the same job END TO END from a file-sharded start ("including exchange") ----
     # Every rank holds a 1/world stride sample of the GLOBAL A and of the global B (sorted, spanning the whole code
     # space: what a rank has after reading its share of the input files).  One step = `union` + `inter` through
@@ -292,51 +357,10 @@ def main():
         except Exception as e:  # the headline numbers above never depend on this leg
             exchange = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
 
+    leg_done.set()
+    if watchdog is not None:
+        watchdog.cancel()
     if rank == 0:
-        # roofline of the dominant kernel (union tile kernel): algorithmic bytes per launch
-        # = 8(|A|+|B|) read + 8|A∪B| written (SURVEY.md §8(d)), rank 0's launch
-        ku = ku_sum / args.steps * 1e-3
-        ki = ki_sum / args.steps * 1e-3
-        bytes_u = 8.0 * (na + nb) + 8.0 * nu
-        bytes_i = 8.0 * (na + nb) + 8.0 * ni
-        peak = 8000.0
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath):
-            try:
-                tj = json.load(open(tpath))
-                if int(tj.get("n", 0)) == n:
-                    traffic = tj.get("union_traffic_bytes_per_launch")
-            except Exception:
-                traffic = None
-        roofline = {"bound": "hbm", "kernel": "setop_tile_kernel<UNION>", "achieved": bytes_u / ku / 1e9,
-                    "peak": peak, "unit": "GB/s", "frac": bytes_u / ku / 1e9 / peak, "traffic": traffic,
-                    "algorithmic_bytes": bytes_u, "kernel_ms": ku * 1e3,
-                    # SURVEY §8(d) also asks for the read side alone (8(|A|+|B|) bytes over the same time)
-                    "read_only_achieved": 8 * (na + nb) / ku / 1e9, "read_only_frac": 8 * (na + nb) / ku / 1e9 / peak,
-                    "note": "frac = (8(|A|+|B|) read + 8|out| written) / kernel time / 8 TB/s.  north_star's '>= 50 % of "
-                            "HBM-read roofline' is read_only_frac >= 0.5, i.e. kernel <= 4.0 ms at this size: reachable for "
-                            "inter (21.3 GB total), not for union, whose 10.7 GB of output make 4.0 ms = 6.7 TB/s of mixed "
-                            "traffic, above the ~6.3 TB/s this part sustains on a plain copy"}
-        roofline_inter = {"bound": "hbm", "kernel": "setop_tile_kernel<INTER>", "achieved": bytes_i / ki / 1e9,
-                          "peak": peak, "unit": "GB/s", "frac": bytes_i / ki / 1e9 / peak,
-                          "algorithmic_bytes": bytes_i, "kernel_ms": ki * 1e3,
-                          "read_only_achieved": 8 * (na + nb) / ki / 1e9, "read_only_frac": 8 * (na + nb) / ki / 1e9 / peak}
-        cpu = None
-        if world == 1 and args.cpu_sample > 0:
-            cpu = cpu_baseline((4 * int(args.cpu_sample) + 2) // 3, 32)
-        res = {
-            "metric": "k-mers/sec for union+inter of 1e9-k-mer k=31 sets",
-            "value": value, "unit": "k-mers/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "u64", "data": "synthetic",
-            "config": {"workload": "union+inter of two sorted k=31 sets of %d uint64 codes per GPU "
-                                   "(|A|=%d |B|=%d |A∪B|=%d |A∩B|=%d on rank 0)" % (n, na, nb, nu, ni),
-                       "k": 31, "per_gpu_set_size": n, "parallelism": "prefix-sharded x%d" % world,
-                       "ops_per_step": ["ukm_setop2(UNION)", "ukm_setop2(INTER)"]},
-            "roofline": roofline, "roofline_inter": roofline_inter, "cpu_baseline": cpu,
-            "union_kmers_per_s_kernel": (na + nb) / ku, "inter_kmers_per_s_kernel": (na + nb) / ki,
-        }
         if exchange:
             res["exchange"] = exchange
         if incl:
@@ -345,10 +369,18 @@ def main():
         if cpu:
             res["speedup_vs_cpu_port"] = value / cpu["value"]
             res["speedup_vs_cpu_allcores_merge"] = value / cpu["allcores_sorted_merge"]["value"]
-        print(json.dumps(res))
+        print(json.dumps(res), flush=True)
     if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+        # teardown must not hang either (a rank that failed inside the leg is not where the others are)
+        t = threading.Timer(60, lambda: os._exit(0))
+        t.daemon = True
+        t.start()
+        try:
+            dist.barrier()
+            dist.destroy_process_group()
+        except Exception:
+            pass
+        t.cancel()
 
 
 if __name__ == "__main__":

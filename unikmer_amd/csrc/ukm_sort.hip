@@ -469,7 +469,7 @@ int ukm_dev_sort(ukm_ctx *c, u64 *keys, u32 *vals, u64 n, int key_bits) {
 #ifndef SORT_FUSED_MIN
 #define SORT_FUSED_MIN (1ull << 24)
 #endif
-    if (n >= SORT_FUSED_MIN && RB == 8) {
+    if (n >= SORT_FUSED_MIN) {
         // Large inputs: only the FIRST digit's histogram is built by a pass over the keys; every scatter pass counts
         // the next digit on the fly and a 256-thread kernel turns the counts into bases between two passes.  No
         // host round trip at all (the histograms never leave the device), at the price of not seeing digits that
