@@ -113,18 +113,53 @@ __device__ __forceinline__ void kw_merge_round(const u64 *in, const u32 *tin, u6
     if (mine) out[obase + L] = KW_MAX;
 }
 
+// The same merge with the VT outputs kept in REGISTERS (single LDS buffer: the caller stores them after a barrier).
+template <bool TAX, bool CHECKED, int VT>
+__device__ __forceinline__ void kw_merge_round_regs(const u64 *in, const u32 *tin, int abase, int la, int bbase, int lb, int lt,
+                                                    u64 (&ro)[VT], u32 (&rt)[VT]) {
+    const int L = la + lb;
+    int diag = lt * VT;
+    diag = diag < L ? diag : L;
+    int lo = diag > lb ? diag - lb : 0;
+    int hi = diag < la ? diag : la;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        const bool le = in[abase + mid] <= in[bbase + diag - 1 - mid];
+        lo = le ? mid + 1 : lo;
+        hi = le ? hi : mid;
+    }
+    int pa = abase + lo, pb = bbase + diag - lo;
+    const int ea = abase + la, eb = bbase + lb;
+    u64 ak = in[pa], bk = in[pb];
+#pragma unroll
+    for (int s = 0; s < VT; s++) {
+        bool take_a;
+        if (CHECKED) take_a = (pa < ea) && (pb >= eb || ak <= bk);
+        else take_a = ak <= bk;
+        ro[s] = take_a ? ak : bk;
+        if (TAX) rt[s] = tin[take_a ? pa : pb];
+        pa += take_a ? 1 : 0;
+        pb += take_a ? 0 : 1;
+        const u64 nk = in[take_a ? pa : pb];
+        ak = take_a ? nk : ak;
+        bk = take_a ? bk : nk;
+    }
+}
+
 // Which record of the K x C chunk layout does thread t hold as its i-th element?
-// VT == K + 1 (the plain-key shape): element i < K is record t of child i, element K is one of the NT / K
+// VT == M * K + 1: element i < M * K is record (i / K) * NT + t of child i % K, the last element is one of the NT / K
 // records behind them (child t / (NT / K)) — the child is a compile-time constant or a shift, no division.
 // Other shapes: record (t + i * NT) of the row-major layout.
 template <int K, int NT, int VT>
 struct KwMap {
     static constexpr int C = NT * VT / K;
-    static constexpr bool NICE = (VT == K + 1);
+    static constexpr int M = (VT - 1) / K;               // whole rows of NT records per child
+    static constexpr bool NICE = (VT == M * K + 1) && M >= 1;
+    static constexpr int UNIFORM = NICE ? M * K : 0;     // elements i < UNIFORM: the whole workgroup holds records of child i % K
     static __device__ __forceinline__ void at(unsigned t, int i, unsigned &slot, unsigned &e) {
         if (NICE) {
-            if (i < K) { slot = (unsigned)i; e = t; }
-            else { slot = t / (NT / K); e = NT + t % (NT / K); }
+            if (i < M * K) { slot = (unsigned)(i % K); e = (unsigned)(i / K) * NT + t; }
+            else { slot = t / (NT / K); e = (unsigned)M * NT + t % (NT / K); }
         } else {
             const unsigned idx = t + (unsigned)i * NT;
             slot = idx / C;
@@ -140,8 +175,16 @@ struct KwMap {
 // Per iteration: [chunk in registers, prefetched] -> LDS | barrier | v, per-child counts of records < v by
 // ballots | barrier | cursors, sentinels | barrier | PREFETCH of the next chunk (its loads fly during the
 // merges) | log2(K) merge rounds | emit.
-template <int K, int LOGK, bool TAX, bool UNION, bool LEAF, int NT, int VT>
-__global__ __launch_bounds__(NT, 4) void kway_kernel(KwArgs p) {
+// ONEBUF: one LDS buffer; a merge round keeps its VT outputs in registers and stores them after a barrier (twice the
+// records per thread at the same LDS footprint: every round's merge-path search is amortised over 17 instead of 9).
+template <int K, int LOGK, bool TAX, bool UNION, bool LEAF, int NT, int VT, bool ONEBUF>
+// occupancy target (waves per SIMD): the single-buffer VT = 9 shape fits 64 VGPRs and 19 KB of LDS, i.e. 8 workgroups
+// of 256 threads per CU; the kernel is bound by LDS latency and barriers, so more waves in flight is what pays
+// (measured per 2e9 input records of level 0: VT 17 / 4 waves 9.0 ms, VT 9 / 5, 6, 8 waves 9.1, 8.5, 8.1 ms)
+#ifndef KW_WAVES
+#define KW_WAVES ((ONEBUF && VT <= 9) ? (TAX ? 5 : 8) : 4)
+#endif
+__global__ __launch_bounds__(NT, KW_WAVES) void kway_kernel(KwArgs p) {
     constexpr int TIN = NT * VT;
     constexpr int C = TIN / K;
     constexpr int CS = C + 1;
@@ -151,9 +194,9 @@ __global__ __launch_bounds__(NT, 4) void kway_kernel(KwArgs p) {
     static_assert(C >= 64, "a wave's 64 consecutive slots touch at most two children");
     static_assert((NT / (K / 2)) % 64 == 0, "a merge pair is handled by whole waves");
     __shared__ __attribute__((aligned(16))) u64 s_a[BUF];
-    __shared__ __attribute__((aligned(16))) u64 s_b[BUF];
+    __shared__ __attribute__((aligned(16))) u64 s_b[ONEBUF ? 2 : BUF];
     __shared__ __attribute__((aligned(16))) u32 s_ta[TAX ? BUF : 2];
-    __shared__ __attribute__((aligned(16))) u32 s_tb[TAX ? BUF : 2];
+    __shared__ __attribute__((aligned(16))) u32 s_tb[(TAX && !ONEBUF) ? BUF : 2];
     __shared__ const u64 *s_ptr[K];
     __shared__ const u32 *s_tptr[K];
     __shared__ u64 s_rem[K];
@@ -244,9 +287,12 @@ __global__ __launch_bounds__(NT, 4) void kway_kernel(KwArgs p) {
             vmask |= valid ? (1u << i) : 0u;
         }
     };
-    load_chunk();
+    if (!ONEBUF) load_chunk();
 
     for (;;) {
+        // (single-buffer shape: 17 staged outputs + 17 prefetched records do not fit 128 VGPRs, so the chunk is loaded
+        //  here and the other three workgroups of the CU cover its latency)
+        if (ONEBUF) load_chunk();
         // ---- A. chunk -> LDS -------------------------------------------------------------------------
         unsigned ta = (unsigned)tid;
         asm volatile("" : "+v"(ta));
@@ -291,9 +337,9 @@ __global__ __launch_bounds__(NT, 4) void kway_kernel(KwArgs p) {
                     const u64 pk = e > 0 ? s_a[slot * CS + e - 1] : s_prev[slot];
                     unsorted |= (valid && pk > kk[i]) ? 1u : 0u;
                 }
-                if (KwMap<K, NT, VT>::NICE && i < K) {
-                    const u64 b0 = __ballot(pred);  // the whole wave holds records of child i
-                    if (lane_id() == 0 && b0) atomicAdd(&s_cnt[i], (u32)__popcll(b0));
+                if (i < KwMap<K, NT, VT>::UNIFORM) {
+                    const u64 b0 = __ballot(pred);  // the whole wave holds records of child i % K
+                    if (lane_id() == 0 && b0) atomicAdd(&s_cnt[i % K], (u32)__popcll(b0));
                 } else {
                     // the 64 records of a wave lie in at most two children
                     const unsigned slot0 = (unsigned)__builtin_amdgcn_readfirstlane((int)slot);
@@ -348,7 +394,7 @@ __global__ __launch_bounds__(NT, 4) void kway_kernel(KwArgs p) {
             break;
         }
         // ---- D. the next chunk's loads are issued now and land while the merges run -----------------------
-        if (more) load_chunk();
+        if (!ONEBUF && more) load_chunk();
         // ---- E. log2(K) rounds of pairwise merges, ping-pong between the two LDS buffers -----------------
 #ifdef KW_ABL_ROUNDS  // experiment only: run fewer merge rounds (wrong results)
         constexpr int NRD = KW_ABL_ROUNDS;
@@ -357,10 +403,6 @@ __global__ __launch_bounds__(NT, 4) void kway_kernel(KwArgs p) {
 #endif
 #pragma unroll
         for (int rd = 1; rd <= NRD; rd++) {
-            const u64 *in = (rd & 1) ? s_a : s_b;
-            u64 *out = (rd & 1) ? s_b : s_a;
-            const u32 *tin = (rd & 1) ? s_ta : s_tb;
-            u32 *tout = (rd & 1) ? s_tb : s_ta;
             const int half = 1 << (rd - 1);       // child slots per input run
             const int npairs = K >> rd;
             const int tpp = NT / npairs;          // threads per pair; tpp * VT = capacity of the output slot
@@ -369,14 +411,33 @@ __global__ __launch_bounds__(NT, 4) void kway_kernel(KwArgs p) {
             const int pr = (int)(te / (unsigned)tpp), lt = (int)(te % (unsigned)tpp);
             const int sa = 2 * pr * half, sb = sa + half;
             const int la = s_pre[sb] - s_pre[sa], lb = s_pre[sb + half] - s_pre[sb];
-            if (danger) kw_merge_round<TAX, true, VT>(in, tin, out, tout, sa * CS, la, sb * CS, lb, sa * CS, lt, tpp);
-            else kw_merge_round<TAX, false, VT>(in, tin, out, tout, sa * CS, la, sb * CS, lb, sa * CS, lt, tpp);
+            if (ONEBUF) {
+                u64 ro[VT];
+                u32 rt[VT];
+                if (danger) kw_merge_round_regs<TAX, true, VT>(s_a, s_ta, sa * CS, la, sb * CS, lb, lt, ro, rt);
+                else kw_merge_round_regs<TAX, false, VT>(s_a, s_ta, sa * CS, la, sb * CS, lb, lt, ro, rt);
+                __syncthreads();  // every thread has read its inputs: the run is rewritten in place
+                const int o0 = sa * CS + lt * VT, L = la + lb;
+#pragma unroll
+                for (int q = 0; q < VT; q++) {
+                    s_a[o0 + q] = ro[q];
+                    if (TAX) s_ta[o0 + q] = rt[q];
+                }
+                if ((L >= lt * VT && L < lt * VT + VT) || (lt == tpp - 1 && L == tpp * VT)) s_a[sa * CS + L] = KW_MAX;
+            } else {
+                const u64 *in = (rd & 1) ? s_a : s_b;
+                u64 *out = (rd & 1) ? s_b : s_a;
+                const u32 *tin = (rd & 1) ? s_ta : s_tb;
+                u32 *tout = (rd & 1) ? s_tb : s_ta;
+                if (danger) kw_merge_round<TAX, true, VT>(in, tin, out, tout, sa * CS, la, sb * CS, lb, sa * CS, lt, tpp);
+                else kw_merge_round<TAX, false, VT>(in, tin, out, tout, sa * CS, la, sb * CS, lb, sa * CS, lt, tpp);
+            }
             __syncthreads();
         }
-        u64 *fin = (LOGK & 1) ? s_b : s_a;  // merged run [0, M)
-        u32 *tfin = (LOGK & 1) ? s_tb : s_ta;
-        u64 *oth = (LOGK & 1) ? s_a : s_b;
-        u32 *toth = (LOGK & 1) ? s_ta : s_tb;
+        u64 *fin = (ONEBUF || !(LOGK & 1)) ? s_a : s_b;  // merged run [0, M)
+        u32 *tfin = (ONEBUF || !(LOGK & 1)) ? s_ta : s_tb;
+        u64 *oth = ONEBUF ? s_a : ((LOGK & 1) ? s_a : s_b);
+        u32 *toth = ONEBUF ? s_ta : ((LOGK & 1) ? s_ta : s_tb);
         // ---- F. emit ------------------------------------------------------------------------------------------
         const u64 *flush_k = fin;
         const u32 *flush_t = tfin;
@@ -403,6 +464,36 @@ __global__ __launch_bounds__(NT, 4) void kway_kernel(KwArgs p) {
             }
             u32 tot;
             const u32 excl = block_excl_scan_u32<NT>((u32)__popc(mask), s_scan, &tot);
+            if (ONEBUF) {
+                // compaction in place: heads (and their folded TaxIds) go to registers first
+                u64 hk[VT];
+                u32 ht[VT];
+#pragma unroll
+                for (int s = 0; s < VT; s++) {
+                    hk[s] = 0;
+                    ht[s] = 0;
+                    if (mask & (1u << s)) {
+                        const int i = i0 + s;
+                        const u64 k = fin[i];
+                        hk[s] = k;
+                        if (TAX) {
+                            u32 tx = tfin[i];
+                            for (int q = i + 1; q < M && fin[q] == k; q++) tx = lca_dev(p.tax, tfin[q], tx);
+                            ht[s] = tx;
+                        }
+                    }
+                }
+                __syncthreads();
+                u32 w = excl;
+#pragma unroll
+                for (int s = 0; s < VT; s++) {
+                    if (mask & (1u << s)) {
+                        oth[w] = hk[s];
+                        if (TAX) toth[w] = ht[s];
+                        w++;
+                    }
+                }
+            } else {
             u32 w = excl;
 #pragma unroll
             for (int s = 0; s < VT; s++) {
@@ -417,6 +508,7 @@ __global__ __launch_bounds__(NT, 4) void kway_kernel(KwArgs p) {
                     }
                     w++;
                 }
+            }
             }
             __syncthreads();
             flush_k = oth;
@@ -506,28 +598,37 @@ __global__ void kw_compact_kernel(const u64 *src, const u32 *tsrc, const u64 *P,
         for (u64 i = lo + threadIdx.x; i < hi; i += blockDim.x) tdst[d0 + i] = tsrc[off + i];
 }
 
-// records per thread and iteration: LDS holds two buffers of NT x VT records, so a CU takes about 156 / VT
-// waves whatever NT is (VT = 9: 16 waves); VT is odd so that the threads' consecutive 8-byte LDS stores of a
-// merge round fall into different banks
-constexpr int KW_VT_PLAIN = 9;
-constexpr int KW_VT_TAX = 5;
-#ifndef KW_NT
-#define KW_NT 256
-#endif
-
+// Shapes.  ONE LDS buffer, 256 threads, VT = 9 records per thread for K = 4 and 8 (19 KB plain / 28 KB with TaxIds);
+// K = 16 (UKM_KWAY_K=16, plain keys only): 512 threads, VT = 17, 70 KB.  VT is odd so that the threads' consecutive
+// 8-byte LDS accesses fall into different banks, and VT = M * K + 1 gives the division-free chunk layout.
+// KW_TWOBUF (developer knob): the round-2 first version, two buffers and VT = 9.
 template <int K, int LOGK, bool TAX, bool UNION>
 void kw_launch(const KwArgs &a, bool leaf, unsigned grid, hipStream_t st) {
-    constexpr int VT = TAX ? KW_VT_TAX : KW_VT_PLAIN;
-    constexpr int NT = (K == 16 && KW_NT < 512) ? 512 : KW_NT;  // a merge pair needs whole waves
-    if (leaf) hipLaunchKernelGGL((kway_kernel<K, LOGK, TAX, UNION, true, NT, VT>), dim3(grid), dim3(NT), 0, st, a);
-    else hipLaunchKernelGGL((kway_kernel<K, LOGK, TAX, UNION, false, NT, VT>), dim3(grid), dim3(NT), 0, st, a);
+#ifdef KW_TWOBUF
+    constexpr int VT = TAX ? 5 : 9;
+    constexpr bool ONE = false;
+#else
+#ifndef KW_VT_PLAIN
+#define KW_VT_PLAIN 9
+#endif
+#ifndef KW_NT_SMALLK
+#define KW_NT_SMALLK 256
+#endif
+    constexpr int VT = TAX ? 9 : ((KW_VT_PLAIN - 1) % K == 0 ? KW_VT_PLAIN : 17);
+    constexpr bool ONE = true;
+#endif
+    constexpr int NT = (K == 16) ? 512 : KW_NT_SMALLK;  // a merge pair is handled by whole waves
+    if (leaf) hipLaunchKernelGGL((kway_kernel<K, LOGK, TAX, UNION, true, NT, VT, ONE>), dim3(grid), dim3(NT), 0, st, a);
+    else hipLaunchKernelGGL((kway_kernel<K, LOGK, TAX, UNION, false, NT, VT, ONE>), dim3(grid), dim3(NT), 0, st, a);
 }
 
 template <int K, int LOGK>
 void kw_launch_k(const KwArgs &a, bool tax, bool uni, bool leaf, unsigned grid, hipStream_t st) {
     if (tax) {
-        if (uni) kw_launch<K, LOGK, true, true>(a, leaf, grid, st);
-        else kw_launch<K, LOGK, true, false>(a, leaf, grid, st);
+        if constexpr (K <= 8) {
+            if (uni) kw_launch<K, LOGK, true, true>(a, leaf, grid, st);
+            else kw_launch<K, LOGK, true, false>(a, leaf, grid, st);
+        }
     } else {
         if (uni) kw_launch<K, LOGK, false, true>(a, leaf, grid, st);
         else kw_launch<K, LOGK, false, false>(a, leaf, grid, st);
@@ -536,12 +637,12 @@ void kw_launch_k(const KwArgs &a, bool tax, bool uni, bool leaf, unsigned grid, 
 
 }  // namespace
 
-int ukm_kway_fanin() {
+int ukm_kway_fanin() {  // 0 = automatic
     static int k = -1;
     if (k < 0) {
         const char *e = getenv("UKM_KWAY_K");
-        k = e ? atoi(e) : 8;
-        if (k != 4 && k != 8 && k != 16) k = 8;
+        k = e ? atoi(e) : 0;
+        if (k != 8 && k != 16) k = 0;
     }
     return k;
 }
@@ -577,8 +678,16 @@ int ukm_dev_kway(ukm_ctx *c, int op, const u64 *const *keys, const u32 *const *t
         UKM_FAIL(UKM_ERR_CAPACITY, "k-way merge: output needs %llu records, capacity is %llu", (unsigned long long)N,
                  (unsigned long long)out_cap);
     }
-    int K = ukm_kway_fanin();
-    if (S <= 4) K = 4;
+    // fan-in per level: 4 for <= 4 children, else 8.  (16 — one level less for 100 files — was measured slower: its
+    // level 0 costs 12.6 ms per 2e9 records against 9.1 ms, more than the saved level; UKM_KWAY_K=16 selects it for plain
+    // keys, the TaxId shape does not fit LDS at that fan-in.)
+    const int kpref = ukm_kway_fanin();
+    auto pick_k = [&](u64 nchildren) -> int {
+        if (nchildren <= 4) return 4;
+        if (nchildren <= 8 || tax) return 8;
+        return kpref == 16 ? 16 : 8;
+    };
+    int K = pick_k((u64)S);
     // UKM_KWAY_DEBUG=1: per-phase device times on stderr (developer knob; adds events + one sync)
     static const bool dbg = getenv("UKM_KWAY_DEBUG") != nullptr;
     std::vector<std::pair<const char *, hipEvent_t>> marks;
@@ -591,8 +700,8 @@ int ukm_dev_kway(ukm_ctx *c, int op, const u64 *const *keys, const u32 *const *t
         }
     };
     mark("start");
-    int levels = 1;
-    for (u64 cap = (u64)K; cap < (u64)S; cap *= (u64)K) levels++;
+    int levels = 0;
+    for (u64 nn = (u64)S; ; ) { const int kk = pick_k(nn); levels++; nn = (nn + kk - 1) / kk; if (nn <= 1) break; }
 
     // ---- ranges -------------------------------------------------------------------------------------------
     // about one range per 2048 records of an average stream (a child's share of a range should be several
@@ -666,6 +775,7 @@ int ukm_dev_kway(ukm_ctx *c, int op, const u64 *const *keys, const u32 *const *t
     const u64 *last_k = nullptr;
     const u32 *last_t = nullptr;
     for (int lv = 0; lv < levels; lv++) {
+        K = pick_k(nprev);
         const u64 nodes = (nprev + (u64)K - 1) / (u64)K;
         const bool final_lv = lv == levels - 1;
         u64 *ok;
