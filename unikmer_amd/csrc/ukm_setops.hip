@@ -837,7 +837,12 @@ int ukm_dev_setop2_link(ukm_ctx *c, int op, const u64 *a, const u32 *ta, u64 na_
     if (p.ntiles == 0) return UKM_OK;
     u64 *st = nullptr;
     const unsigned pblocks = (unsigned)((p.ntiles + 1 + 255) / 256);
-    const bool small = p.ntiles < 4 * PART_COARSE;
+#ifndef SETOP_LINK_SMALL_TILES
+#define SETOP_LINK_SMALL_TILES 2048
+#endif
+    // links of up to a few thousand tiles: ONE wave-cooperative partition kernel that also clears the status lines
+    // (three launches less per link than memset + two-level partition; a 1000-file fold is launch bound)
+    const bool small = p.ntiles < SETOP_LINK_SMALL_TILES;
     const size_t nstat = lb_status_words(p.ntiles + 1);
     UKM_TRY(ws_alloc_t(c, nstat + p.ntiles + 1, &st));
     if (small) p.zero_status = (u32)(p.ntiles + 1);  // cleared by the partition kernel: one launch less
