@@ -42,11 +42,22 @@ def build(force=False, verbose=False):
     failed = False
     for src, p in procs:
         out, _ = p.communicate()
+        text = out.decode(errors="replace")
         if p.returncode != 0:
             failed = True
-            sys.stderr.write("hipcc failed for %s:\n%s\n" % (src, out.decode(errors="replace")))
+            sys.stderr.write("hipcc failed for %s:\n%s\n" % (src, text))
+        elif "reserved registers" in text or "failed to meet occupancy target" in text:
+            # ukm_sort.hip's hand-scheduled match-any names s80..s83 in its clobber list: if a change of register
+            # budget ever makes the compiler reserve them (or miss a declared occupancy) the build must not go on
+            failed = True
+            first = [ln for ln in text.splitlines() if "reserved registers" in ln or "occupancy target" in ln][:3]
+            sys.stderr.write("register-budget check failed for %s:\n%s\n" % (src, "\n".join(first)))
+            try:
+                os.remove(os.path.join(CSRC, src.replace(".hip", ".o")))
+            except OSError:
+                pass
         elif verbose and out:
-            sys.stderr.write(out.decode(errors="replace"))
+            sys.stderr.write(text)
     if failed:
         raise RuntimeError("building libunikmer_hip.so failed")
     if force or procs or _stale(SO, objs):
