@@ -150,3 +150,54 @@ def test_sort_pairs_large_is_a_stable_permutation(env):
     same = k2[1:] == k2[:-1]
     assert bool((v2[1:][same] > v2[:-1][same]).all())               # stable
     assert _xor(torch, v2.long()) == _xor(torch, vals.long())       # a permutation of the payloads
+
+
+def test_kway_union_equals_chained_two_way_unions_large(env):
+    """12 files x 4e7 codes (4.8e8 records): the k-way streaming union (ukm_union) against a chain of 2-way unions
+    through the tile kernel (ukm_setop2) — two independent device paths must give the same stream; the keep-everything
+    k-way merge has the same multiset as the inputs (size + XOR checksum) and is sorted."""
+    torch, bench, lib, ctx, A, B = env
+    dev = A.device
+    nu = 80_000_000
+    j = torch.arange(nu, dtype=torch.int64, device=dev)
+    U = torch.cumsum(1 + (bench.splitmix64_torch(j ^ bench._i64(bench.SEED + 5)) & ((1 << 30) - 1)), 0)
+    files = [U[(bench.splitmix64_torch(j ^ bench._i64(bench.SEED + 1000 * (f + 1))) & 1) == 1] for f in range(12)]
+    del j
+    torch.cuda.synchronize()
+    got = ctx.union(files)
+    acc = files[0]
+    for f in files[1:]:
+        acc = ctx.setop2(lib.OP_UNION, acc, f)
+    assert got.numel() == acc.numel() and bool((got == acc).all())
+    assert _strict(got)
+    del acc, got
+    m = ctx.merge_k(files[:6])
+    assert m.numel() == sum(f.numel() for f in files[:6])
+    assert bool((m[1:] >= m[:-1]).all())
+    x = 0
+    for f in files[:6]:
+        x ^= _xor(torch, f)
+    assert _xor(torch, m) == x
+
+
+def test_nthash_sketch_strip_kernel_equals_general_kernel_large(env, monkeypatch):
+    """1e9 bases of 150-bp reads, k = 51, scale 1000: the rolling strip kernel and the prefix-XOR kernel (two
+    different algorithms for the same hash) must keep exactly the same windows in the same order."""
+    torch, bench, lib, ctx, A, B = env
+    dev = A.device
+    nb = 1_000_000_050
+    i = torch.arange(nb, dtype=torch.int64, device=dev)
+    w = bench.splitmix64_torch((i >> 5) ^ bench._i64(bench.SEED))
+    code = ((w >> (2 * (i & 31))) & 3)
+    del i, w
+    bases = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=dev)[code]
+    del code
+    bases[123_456_789:123_456_889] = ord("N")
+    reads = torch.arange(0, nb + 1, 150, dtype=torch.int64, device=dev)
+    mh = ctx.max_hash(1000)
+    torch.cuda.synchronize()
+    monkeypatch.setenv("UKM_NTHASH_STRIP", "1")
+    a = ctx.nthash(bases, reads, 51, canonical=True, max_hash=mh).clone()
+    monkeypatch.setenv("UKM_NTHASH_STRIP", "0")
+    b = ctx.nthash(bases, reads, 51, canonical=True, max_hash=mh)
+    assert a.numel() == b.numel() and a.numel() > 1_000_000 and bool((a == b).all())
