@@ -388,6 +388,75 @@ def test_nthash_scaled_strip_kernel(ctx, O, monkeypatch, force):
     assert np.array_equal(ctx.nthash(sh, off, 31, max_hash=mh), O.count_windows(sh, off, 31, hashed=True, max_hash=mh))
 
 
+@pytest.mark.parametrize("force", ["1", None])
+def test_windows_strip_kernel_long_records(ctx, O, L, monkeypatch, force):
+    """The rolling strip kernel for every window of long records (count.go's per-record k-mer loop over a
+    chromosome): codes and ntHash, every k phase, canonical / forward, ragged records incl. empty and
+    shorter-than-k ones, record ends inside a row block and inside a strip's warm-up, degenerate and lower-case
+    bases, several tiles and strip lengths.  force=1 also runs it on record mixes the library would hand to the
+    general kernel; None = the library's own choice (the general kernel at this size; the strip kernel from
+    3.4e7 bases on: tests/test_gpu_properties.py)."""
+    if force is None:
+        monkeypatch.delenv("UKM_WIN_STRIP", raising=False)
+    else:
+        monkeypatch.setenv("UKM_WIN_STRIP", force)
+    n = 4_500_000
+    bases = _synth_fasta(n, SEED + 23).copy()
+    bases[1000:1100] = ord("N")
+    bases[70_000] = ord("n")
+    bases[500_001:500_004] = np.frombuffer(b"acg", dtype=np.uint8)
+    bases[900_000] = ord("R")
+    bases[2_000_000:2_000_040] = np.frombuffer(b"MVHRDWSBYKmvhrdwsbykUuACGTacgtNnACGTACGT", dtype=np.uint8)
+    long_cuts = np.array([0, 1_000_003, 1_000_003, 1_000_020, 2_500_001, 4_499_990, n], dtype=np.uint64)
+    ragged = np.array([0, 0, 3, 40, 41, 333, 5000, 5000, 65_535, 65_536, 65_543, 65_600, 262_144, 262_145, 700_000,
+                       1_199_950, 3_000_000, n - 7, n], dtype=np.uint64)
+    cases = [long_cuts] + ([ragged] if force else [])
+    for Ls in (None, "64", "128"):
+        if Ls is None:
+            monkeypatch.delenv("UKM_WIN_STRIP_L", raising=False)
+        else:
+            monkeypatch.setenv("UKM_WIN_STRIP_L", Ls)
+        for cuts in cases:
+            for k in ((1, 2, 7, 8, 9, 21, 31, 32) if Ls is None else (31,)):
+                for canonical in (True, False):
+                    got = ctx.encode_kmers(bases, cuts, k, canonical=canonical)
+                    exp = O.count_windows(bases, cuts, k, hashed=False, canonical=canonical)
+                    assert np.array_equal(got, exp), ("codes", Ls, k, canonical, len(cuts))
+            for k in ((1, 2, 23, 32, 33, 50, 51, 64) if Ls is None else (51,)):
+                for canonical in (True, False):
+                    got = ctx.nthash(bases, cuts, k, canonical=canonical)
+                    exp = O.count_windows(bases, cuts, k, hashed=True, canonical=canonical)
+                    assert np.array_equal(got, exp), ("nthash", Ls, k, canonical, len(cuts))
+    monkeypatch.delenv("UKM_WIN_STRIP_L", raising=False)
+    # an illegal base is an error only when an emitted window holds it (kmers.ErrIllegalBase)
+    bad = bases.copy()
+    bad[3_333_333] = ord("*")
+    with pytest.raises(L.IllegalBaseError):
+        ctx.encode_kmers(bad, long_cuts, 31)
+    assert np.array_equal(ctx.nthash(bad, long_cuts, 31), O.count_windows(bad, long_cuts, 31, hashed=True))
+    # ... inside a record shorter than k, or in a block next to a record boundary whose windows are not emitted
+    bad = bases.copy()
+    bad[1_000_010] = ord("*")
+    assert np.array_equal(ctx.encode_kmers(bad, long_cuts, 31), O.count_windows(bad, long_cuts, 31))
+    bad[1_000_019] = ord("*")
+    assert np.array_equal(ctx.encode_kmers(bad, long_cuts, 31), O.count_windows(bad, long_cuts, 31))
+    bad[1_000_020] = ord("*")
+    with pytest.raises(L.IllegalBaseError):
+        ctx.encode_kmers(bad, long_cuts, 31)
+    # the minimizer sketch reads the strip kernel's hashes (count.go:316,357)
+    for k, w in ((23, 5), (31, 15)):
+        got, gpos = ctx.minimizer(bases, long_cuts, k, w, with_pos=True)
+        exp, epos = _oracle_minimizer_records(O, bases, long_cuts, k, w)
+        assert np.array_equal(got, exp) and np.array_equal(gpos, epos)
+    # more records under one tile than the kernel's table holds: falls back to the general kernel
+    many = np.concatenate([np.arange(0, 40_000, 100, dtype=np.uint64), np.array([n], dtype=np.uint64)])
+    assert np.array_equal(ctx.encode_kmers(bases, many, 21), O.count_windows(bases, many, 21))
+    # a misaligned base pointer
+    buf = np.concatenate([np.zeros(1, np.uint8), bases])
+    off = np.array([0, n], dtype=np.uint64)
+    assert np.array_equal(ctx.encode_kmers(buf[1:], off, 31), O.count_windows(buf[1:], off, 31))
+
+
 def test_circular_and_reads(ctx, O):
     bases = _synth_fasta(50_000, SEED + 1)
     one = np.array([0, 50_000], dtype=np.uint64)

@@ -201,3 +201,40 @@ def test_nthash_sketch_strip_kernel_equals_general_kernel_large(env, monkeypatch
     monkeypatch.setenv("UKM_NTHASH_STRIP", "0")
     b = ctx.nthash(bases, reads, 51, canonical=True, max_hash=mh)
     assert a.numel() == b.numel() and a.numel() > 1_000_000 and bool((a == b).all())
+
+
+def test_window_strip_kernel_equals_general_kernel_large(env, monkeypatch):
+    """1e9 bases in 37 chromosome-sized records of uneven length: the rolling strip kernel (long records) and the
+    prefix-word kernel — two different algorithms — must produce identical codes (k = 31) and hashes (k = 51) for
+    every window; neighbouring windows of the codes overlap in k - 1 bases."""
+    torch, bench, lib, ctx, A, B = env
+    dev = A.device
+    nb = 1_000_000_007
+    i = torch.arange(nb, dtype=torch.int64, device=dev)
+    w = bench.splitmix64_torch((i >> 5) ^ bench._i64(bench.SEED + 3))
+    code = ((w >> (2 * (i & 31))) & 3)
+    del i, w
+    bases = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=dev)[code]
+    del code
+    bases[500_000_000:500_000_200] = ord("N")
+    bases[777_777_777] = ord("y")
+    cuts = sorted(set([0, nb] + [int(nb * (r * r + 3 * r)) // (37 * 37 + 3 * 37) for r in range(1, 37)] + [123_456_789, 123_456_790, 123_456_800]))
+    off = torch.tensor(cuts, dtype=torch.int64, device=dev)
+    torch.cuda.synchronize()
+    for fn, k in ((ctx.encode_kmers, 31), (ctx.nthash, 51)):
+        for canonical in (True, False):
+            monkeypatch.setenv("UKM_WIN_STRIP", "1")
+            a = fn(bases, off, k, canonical=canonical).clone()
+            monkeypatch.setenv("UKM_WIN_STRIP", "0")
+            b = fn(bases, off, k, canonical=canonical)
+            assert a.numel() == b.numel() and a.numel() > 990_000_000 and bool((a == b).all()), (k, canonical)
+            if fn == ctx.encode_kmers and not canonical:
+                first = a[: cuts[1] - k + 1]
+                mask = (1 << (2 * k)) - 1
+                assert bool((((first[:-1] << 2) & mask) >> 2 == (first[1:] >> 2)).all())
+            if canonical:
+                monkeypatch.delenv("UKM_WIN_STRIP", raising=False)   # the library's own choice (the strip kernel here)
+                c = fn(bases, off, k, canonical=canonical)
+                assert bool((c == a).all())
+                del c
+            del a, b

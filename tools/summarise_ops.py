@@ -11,7 +11,7 @@ import os
 import sys
 from collections import defaultdict
 
-KEEP = ("onesweep_kernel", "radix_hist_kernel", "unique_tile_kernel", "window_kernel", "nthash_strip_kernel", "kway_kernel",
+KEEP = ("onesweep_kernel", "radix_hist_kernel", "unique_tile_kernel", "window_kernel", "stripwin_kernel", "nthash_strip_kernel", "kway_kernel",
         "kw_compact_kernel", "setop_tile_kernel")
 
 

@@ -503,15 +503,17 @@ __device__ __forceinline__ void strip_load(const u8 *bases, long long off, u64 t
 #pragma unroll
         for (int g = N & ~3; g < N; g++) w[g] = *reinterpret_cast<const u32 *>(src + 4 * g);
     } else {
+        // byte by byte; the valid byte indices [ilo, ihi) as two ints so that nothing 64-bit is kept per byte
+        const long long lo = -off, hi = (long long)total - off;
+        const int ilo = lo < 0 ? 0 : (lo > 4 * N ? 4 * N : (int)lo);
+        const int ihi = !active || hi < 0 ? 0 : (hi > 4 * N ? 4 * N : (int)hi);
+        const u8 *src = bases + off;
 #pragma unroll
         for (int g = 0; g < N; g++) {
             u32 x = 0;
-            if (active) {
-                for (int q = 0; q < 4; q++) {
-                    const long long z = off + 4 * g + q;
-                    if (z >= 0 && (u64)z < total) x |= (u32)bases[z] << (8 * q);
-                }
-            }
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+                if (4 * g + q >= ilo && 4 * g + q < ihi) x |= (u32)src[4 * g + q] << (8 * q);
             w[g] = x;
         }
     }
@@ -741,6 +743,260 @@ int run_strip_filter(ukm_ctx *c, const u8 *bases, const u64 *rec_off, u64 n_rec,
     return UKM_OK;
 }
 
+// ---- every window of long records: per-lane rolling 2-bit codes / ntHash over strips ----------------------------
+// window_kernel above stages 2048 positions per tile and re-derives every window from per-position prefix
+// words: ~45 (codes) to ~160 (ntHash) lane-operations per window, 30 % of the HBM roofline.  For inputs made of
+// long records (genomes, contigs: count.go's per-record loop over a chromosome) every lane instead rolls along
+// its own strip of L positions:  code' = ((code << 2) | c) & mask,  rc' = (rc >> 2) | ((3 - c) << (2k - 2)),
+// or the ntHash recurrence of nthash_strip_kernel.  A lane owns the windows that END inside its strip, so
+// step i of the unrolled loop always fills slot i & 15 of the lane's LDS row whatever k is.  Every 16 steps
+// the wave turns its 64 rows x 16 values around: eight lanes write one row's 128 bytes with 16-byte stores.
+// Neighbouring lanes work 8L bytes apart, so what matters is that every row is one whole, ALIGNED cache line
+// of the output (measured: rows that straddle lines cost 2.3 x): the tile's strips start `sh` (< 16)
+// positions early so that the first record's output index of a row start is a multiple of 16; the first lane
+// skips what belongs to the previous tile, the last wave runs 16 steps longer to reach the tile's end.
+// All record logic (is the window inside one record, where does it go) happens once per row, not per window:
+// a row that lies inside one record gets its output index published; a row that touches a record or strip
+// boundary (rare for long records) is written by its owner lane value by value.
+// Not for circular records; more than SW_REC records under one tile -> flag, the caller runs window_kernel.
+constexpr int SW_NT = 256;
+constexpr int SW_NWV = SW_NT / 64;
+constexpr int SW_REC = 126;   // records one tile may touch
+constexpr int SW_B = 16;      // values per row = one 128-byte line
+constexpr int SW_ROW = 17;    // u64 per LDS row: 16 values + 1 pad (bank spread)
+#ifndef SW_ABL
+#define SW_ABL 0              // developer ablations: 1 = no row stores
+#endif
+
+struct SwArgs {
+    const u8 *bases;
+    const u64 *rec_off;   // [n_rec + 1]
+    const u64 *out_off;   // [n_rec + 1] exclusive scan of the per-record window counts
+    u64 n_rec;
+    u64 total_bases;
+    int k;
+    int canonical;
+    int L;                // positions per lane, multiple of 64
+    u64 *out;
+    u64 *result;          // [1] flags: bit0 illegal base in an emitted window, bit2 record table overflow
+    const u64 *tile_rec;  // [ntiles + 3]
+};
+
+template <bool HASH>
+__global__ __launch_bounds__(SW_NT) __attribute__((amdgpu_waves_per_eu(HASH ? 3 : 4, HASH ? 3 : 4))) void stripwin_kernel(SwArgs p) {
+    __shared__ __attribute__((aligned(16))) uint4 s_tin[HASH ? 256 : 1];
+    __shared__ __attribute__((aligned(16))) uint4 s_tout[HASH ? 256 : 1];
+    __shared__ u8 s_lut[HASH ? 1 : 256];
+    __shared__ u64 s_ro[SW_REC + 2];
+    __shared__ u64 s_gap[SW_REC + 2];
+    __shared__ u64 s_row[SW_NWV][64 * SW_ROW];
+    __shared__ u64 s_desc[SW_NWV][64];
+    const int tid = (int)threadIdx.x, lane = lane_id(), wave = tid >> 6;
+    const int k = p.k, L = p.L;
+    if constexpr (HASH) {
+        const u32 si = (u32)g_byte_table.v[tid] >> 4;
+        const u64 f = si == 0 ? SEED_A : si == 1 ? SEED_C : si == 2 ? SEED_G : si == 3 ? SEED_T : 0ull;
+        const u64 cs = si == 0 ? SEED_T : si == 1 ? SEED_G : si == 2 ? SEED_C : si == 3 ? SEED_A : 0ull;
+        const u64 a = f, b = rol64(cs, (u32)(k - 1)), c2 = rol64(f, (u32)k), d = ror64(cs, 1);
+        s_tin[tid] = make_uint4((u32)a, (u32)(a >> 32), (u32)b, (u32)(b >> 32));
+        s_tout[tid] = make_uint4((u32)c2, (u32)(c2 >> 32), (u32)d, (u32)(d >> 32));
+    } else {
+        s_lut[tid] = g_byte_table.v[tid] & 0xF;
+    }
+    const u64 tile = blockIdx.x;
+    const u64 TS = (u64)SW_NT * (u64)L;
+    const u64 P0 = tile * TS;
+    const u64 r0 = p.tile_rec[tile];
+    const u64 r1 = p.tile_rec[tile + 1];
+    const u64 nr = r1 - r0 + 1;  // records r0 .. r1 may hold positions of the tile
+    if (nr > (u64)SW_REC) {
+        if (tid == 0) atomicOr((unsigned long long *)&p.result[1], 4ull);
+        return;
+    }
+    for (u64 j = (u64)tid; j <= nr; j += SW_NT) {
+        const u64 ro = p.rec_off[r0 + j];
+        s_ro[j] = ro;
+        s_gap[j] = ro - p.out_off[r0 + j];
+    }
+    __syncthreads();
+    // output index of the window that ends at e (inside record r) = e + 1 - k - gap[r]; shift the strips so that it
+    // is a multiple of 16 at every row start of the tile's first record
+    const u32 sh = (u32)(P0 + 1 - (u64)k - s_gap[0]) & (u32)(SW_B - 1);
+    const long long s0 = (long long)P0 - (long long)sh + (long long)tid * L;  // first END position of this lane's rows
+    const u64 e_lo = s0 < (long long)P0 ? P0 : (u64)s0;                       // the lane emits END positions [e_lo, e_hi)
+    const u64 e_hi = tid == SW_NT - 1 ? P0 + TS : (u64)(s0 + L);
+    const bool active = e_lo < p.total_bases;
+    u32 j = 0;
+    u64 rec_start = ~0ull, rec_end = 0, gap = 0;
+    bool dead = !active;
+    if (active) {
+        u32 lo = 0, hi = (u32)nr + 1;  // first index with s_ro > e_lo (records of length 0 are skipped)
+        while (lo < hi) {
+            const u32 mid = (lo + hi) >> 1;
+            if (s_ro[mid] <= e_lo) lo = mid + 1; else hi = mid;
+        }
+        if (lo == 0 || lo > (u32)nr) dead = true;
+        else { j = lo - 1; rec_start = s_ro[j]; rec_end = s_ro[j + 1]; gap = s_gap[j]; }
+        if (dead) { rec_start = ~0ull; rec_end = 0; }
+    }
+    const bool canon = p.canonical != 0;
+    const int WU = k <= 32 ? 32 : 64;     // warm-up steps in front of the strip (>= k)
+    const int i_start = 64 - WU;          // step i reads the base at s0 - 64 + i
+    const int nsteps = 64 + L + (wave == SW_NWV - 1 ? SW_B : 0);
+    u64 fwd = 0, rc = 0, hist = 0;
+    u32 flo = 0, fhi = 0, rlo = 0, rhi = 0;
+    const u64 kmask = k >= 32 ? ~0ull : ((1ull << (2 * k)) - 1);
+    const u32 rcs = (u32)(2 * k - 2);
+    const u32 ipa = (u32)(s0 - 64) & 3u;                    // byte phase of the in / out streams in their dwords
+    const u32 opa = (u32)(s0 - 64 - (long long)k) & 3u;
+    u64 *row = &s_row[wave][lane * SW_ROW];
+    bool illegal = false;
+#define SW_NEXT_RECORD()                                                                  \
+    do {                                                                                  \
+        if (j + 1 >= (u32)nr) { dead = true; rec_start = ~0ull; rec_end = 0; }            \
+        else { j++; rec_start = rec_end; rec_end = s_ro[j + 1]; gap = s_gap[j]; }         \
+    } while (0)
+    for (int c0 = 0; c0 < nsteps; c0 += 64) {
+        u32 iw[17];
+        u32 ow[HASH ? 17 : 1];
+        const long long cpos = s0 + (long long)c0 - 64;
+        strip_load<17>(p.bases, cpos - (long long)ipa, p.total_bases, active, iw);
+        if constexpr (HASH) {
+            u32 t17[17];
+            strip_load<17>(p.bases, cpos - (long long)k - (long long)opa, p.total_bases, active, t17);
+#pragma unroll
+            for (int g = 0; g < 17; g++) ow[g] = t17[g];
+        }
+#pragma unroll
+        for (int g = 0; g < 16; g++) {
+            if (c0 == 0 && 4 * g < i_start) continue;
+            if (c0 + 4 * g >= nsteps) continue;
+            u32 o4 = 0;
+            if constexpr (HASH) {
+                o4 = __builtin_amdgcn_alignbyte(ow[g + 1], ow[g], opa);
+                if (c0 == 0) {
+                    // cold start: steps < i_start + k have no outgoing base (byte 0 has a zero table entry)
+                    const int nz = i_start + k - 4 * g;
+                    const u32 m = nz <= 0 ? 0xFFFFFFFFu : (nz >= 4 ? 0u : (0xFFFFFFFFu << (8 * nz)));
+                    o4 &= m;
+                }
+            }
+            const u32 i4 = __builtin_amdgcn_alignbyte(iw[g + 1], iw[g], ipa);
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                u64 v;
+                if constexpr (HASH) {
+                    const uint4 ein = s_tin[(i4 >> (8 * q)) & 0xFFu];
+                    const uint4 eout = s_tout[(o4 >> (8 * q)) & 0xFFu];
+                    const u32 nflo = __builtin_amdgcn_alignbit(flo, fhi, 31) ^ ein.x ^ eout.x;
+                    const u32 nfhi = __builtin_amdgcn_alignbit(fhi, flo, 31) ^ ein.y ^ eout.y;
+                    const u32 nrlo = __builtin_amdgcn_alignbit(rhi, rlo, 1) ^ ein.z ^ eout.z;
+                    const u32 nrhi = __builtin_amdgcn_alignbit(rlo, rhi, 1) ^ ein.w ^ eout.w;
+                    flo = nflo; fhi = nfhi; rlo = nrlo; rhi = nrhi;
+                    const u64 f = ((u64)fhi << 32) | flo, rv = ((u64)rhi << 32) | rlo;
+                    v = (canon && rv < f) ? rv : f;
+                } else {
+                    const u32 e = s_lut[(i4 >> (8 * q)) & 0xFFu];
+                    const u32 code = e & 3u;
+                    hist = (hist << 1) | (u64)(e >> 2);
+                    fwd = ((fwd << 2) | (u64)code) & kmask;
+                    rc = (rc >> 2) | ((u64)(code ^ 3u) << rcs);
+                    v = (canon && rc < fwd) ? rc : fwd;
+                }
+                row[(4 * g + q) & (SW_B - 1)] = v;
+            }
+            __builtin_amdgcn_sched_barrier(0);  // keep the scheduler from hoisting a whole chunk's table reads
+            if ((g & 3) == 3 && c0 > 0) {
+                // ---- one row: END positions e0 .. e0 + 15 ----
+                const long long e0s = s0 + (long long)(c0 - 64 + 4 * (g - 3));
+                const u64 e0 = (u64)e0s;
+                bool ok = false;
+                if (!dead && e0s >= (long long)e_lo) {
+                    while (!dead && e0 >= rec_end) SW_NEXT_RECORD();
+                    ok = !dead && e0 + (SW_B - 1) < rec_end && e0 + (SW_B - 1) < e_hi && e0 + 1 >= rec_start + (u64)k;
+                }
+                s_desc[wave][lane] = ok ? (e0 + 1 - (u64)k - gap) : ~0ull;
+                if (!HASH && ok && (hist & ((1ull << (k + SW_B - 1)) - 1)) != 0) illegal = true;
+                if (!ok && !dead && e0s + (SW_B - 1) >= (long long)e_lo && e0s < (long long)e_hi) {
+                    // the row touches a record or strip boundary: the owner writes what is valid, value by value
+                    for (int q = 0; q < SW_B; q++) {
+                        const long long es = e0s + q;
+                        if (es < (long long)e_lo || es >= (long long)e_hi) continue;
+                        const u64 e = (u64)es;
+                        while (!dead && e >= rec_end) SW_NEXT_RECORD();
+                        if (!dead && e + 1 >= rec_start + (u64)k) {
+                            p.out[e + 1 - (u64)k - gap] = row[q];
+                            if (!HASH && ((hist >> (SW_B - 1 - q)) & ((1ull << k) - 1)) != 0) illegal = true;
+                        }
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int m = 0; m < 8; m++) {
+                    const int strip = m * 8 + (lane >> 3), pr = lane & 7;
+                    const u64 d = s_desc[wave][strip];
+                    if (d != ~0ull && (SW_ABL != 1 || d == 12345ull)) {
+                        const u64 *src = &s_row[wave][strip * SW_ROW + 2 * pr];
+                        const u64 v0 = src[0], v1 = src[1];
+                        U4a4 st;
+                        st.x = (u32)v0; st.y = (u32)(v0 >> 32); st.z = (u32)v1; st.w = (u32)(v1 >> 32);
+                        *reinterpret_cast<U4a4 *>(p.out + d + 2 * pr) = st;
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+    }
+#undef SW_NEXT_RECORD
+    if (!HASH && illegal) atomicOr((unsigned long long *)&p.result[1], 1ull);
+}
+
+// returns UKM_OK with *done = false when the strip kernel does not apply (short records, tiny input, a tile
+// with too many records): the caller then runs window_kernel.  `ctl` is the zeroed control block.
+int run_strip_windows(ukm_ctx *c, bool hash, const u8 *bases, const u64 *rec_off, const u64 *out_off, u64 n_rec, int k,
+                      int canonical, u64 *out, u64 total_bases, u64 *ctl, bool *done) {
+    *done = false;
+    const char *fe = getenv("UKM_WIN_STRIP");  // developer / test knob: 0 never, 1 whenever it is correct
+    const int force = fe ? atoi(fe) : -1;
+    if (force == 0) return UKM_OK;
+    if (((uintptr_t)bases & 3) != 0 || (!hash && k > 32)) return UKM_OK;
+    // below ~3e7 bases there are too few strips to fill the chip (4.6 Mbp: 0.032 ms against 0.023 ms for the general
+    // kernel); short records spend their time in the value-by-value path of rows that touch a record boundary
+    if (force != 1 && (total_bases < (1ull << 25) || n_rec * 32768ull > total_bases)) return UKM_OK;
+    // several rounds of workgroups per CU matter more than the k - 1 warm-up steps per strip (measured at 1e8
+    // bases, codes: L = 64 / 128 / 256 / 512 -> 0.178 / 0.185 / 0.21 / 0.22 ms; ntHash k = 51: 0.242 / 0.230 / 0.244)
+    int L = 256;
+    const u64 want_tiles = hash ? 3000 : 5000;
+    while (L > (hash ? 128 : 64) && total_bases / ((u64)SW_NT * (u64)L) < want_tiles) L >>= 1;
+    if (const char *le = getenv("UKM_WIN_STRIP_L")) L = std::max(64, atoi(le) / 64 * 64);
+    const u64 tile_pos = (u64)SW_NT * (u64)L;
+    const u64 ntiles = (total_bases + tile_pos - 1) / tile_pos;
+    if (ntiles > 0x7FFFFFFFull) return UKM_OK;
+    u64 *tile_rec = nullptr;
+    UKM_TRY(ws_alloc_t(c, ntiles + 3, &tile_rec));
+    hipLaunchKernelGGL(tile_first_rec_kernel, dim3((unsigned)((ntiles + 3 + 255) / 256)), dim3(256), 0, c->stream, rec_off,
+                       n_rec, total_bases, ntiles, tile_pos, tile_rec);
+    SwArgs p;
+    memset(&p, 0, sizeof(p));
+    p.bases = bases; p.rec_off = rec_off; p.out_off = out_off; p.n_rec = n_rec; p.total_bases = total_bases;
+    p.k = k; p.canonical = canonical; p.L = L; p.out = out; p.result = ctl; p.tile_rec = tile_rec;
+    (void)hipEventRecord(c->ev_k0, c->stream);
+    if (hash) hipLaunchKernelGGL(stripwin_kernel<true>, dim3((unsigned)ntiles), dim3(SW_NT), 0, c->stream, p);
+    else hipLaunchKernelGGL(stripwin_kernel<false>, dim3((unsigned)ntiles), dim3(SW_NT), 0, c->stream, p);
+    (void)hipEventRecord(c->ev_k1, c->stream);
+    c->evk_valid = true;
+    UKM_HIP(hipGetLastError());
+    u64 res[2] = {0, 0};
+    UKM_TRY(ukm_read_u64(c, ctl, res, 2));
+    if (res[1] & 4) {  // a tile with more records than the table holds: general kernel
+        UKM_HIP(hipMemsetAsync(ctl, 0, 2 * sizeof(u64), c->stream));
+        return UKM_OK;
+    }
+    if (res[1] & 1) UKM_FAIL(UKM_ERR_ILLEGAL_BASE, "illegal base in sequence (kmers.ErrIllegalBase)");
+    *done = true;
+    return UKM_OK;
+}
+
 int run_windows(ukm_ctx *c, bool hash, const u8 *bases, const u64 *rec_off, u64 n_rec, int k,
                 int canonical, int circular, u64 max_hash, u64 *out, u64 out_cap, u64 *n_out,
                 u64 total_bases, const u64 **win_off = nullptr) {
@@ -774,6 +1030,12 @@ int run_windows(ukm_ctx *c, bool hash, const u8 *bases, const u64 *rec_off, u64 
         *n_out = total_windows;
         UKM_FAIL(UKM_ERR_CAPACITY, "output needs %llu values, capacity is %llu",
                  (unsigned long long)total_windows, (unsigned long long)out_cap);
+    }
+    if (!circular && !filter) {
+        // long records: the rolling strip kernel
+        bool done = false;
+        UKM_TRY(run_strip_windows(c, hash, bases, rec_off, off, n_rec, k, canonical, out, total_bases, ctl, &done));
+        if (done) { *n_out = total_windows; return UKM_OK; }
     }
     WinArgs p;
     memset(&p, 0, sizeof(p));
