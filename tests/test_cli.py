@@ -337,3 +337,56 @@ def test_sort_chunk_protocol_split_merge_on_gpu(cli, tmp_path):
     assert p.returncode == 255 and b"not empty" in p.stderr
     cli("sort", "-m", 700, "-t", d, "--force", *ins, "-o", d + "/x")
     assert view(d + "/x.unik") == view(d + "/whole_p.unik")
+
+
+@pytest.mark.gpu
+def test_hashed_text_paths_on_gpu(cli, tmp_path):
+    """encode -H / dump -H (encode.go:106-113, dump.go:250-275: the ntHash of whole k-mers given as text) and
+    view -g (view.go:139-183 + loadHash2Loc util.go:344-393: hashed canonical k-mers decoded back to sequence
+    through the genomes, first occurrence in circular records wins) — all computed by the HIP library."""
+    import sys
+    sys.path.insert(0, ROOT)
+    from oracle import oracle as O
+    d = str(tmp_path)
+    rng = np.random.default_rng(5)
+    k = 41
+    seqs = ["".join("ACGT"[i] for i in rng.integers(0, 4, k)) for _ in range(300)]
+    seqs[7] = seqs[7][:10] + "N" + seqs[7][11:]          # a non-ACGT base hashes with the zero seed
+    seqs[9] = seqs[3]                                     # a repeated k-mer
+    txt = "\n".join(seqs) + "\n"
+    open(d + "/k.txt", "w").write(txt)
+
+    def oracle_hash(s, canonical):
+        b = np.frombuffer(s.encode(), dtype=np.uint8)
+        return int(O.count_windows(b, np.array([0, len(b)], dtype=np.uint64), len(b), hashed=True, canonical=canonical)[0])
+    for canonical in (False, True):
+        flags = ["-K"] if canonical else []
+        got = [int(x) for x in cli("encode", "-H", *flags, d + "/k.txt").stdout.split()]
+        assert got == [oracle_hash(s, canonical) for s in seqs]
+    # dump -H -K -u -> hashed canonical .unik; view prints the hashes
+    cli("dump", "-H", "-K", "-u", d + "/k.txt", "-o", d + "/h")
+    info = cli("info", "-a", d + "/h.unik").stdout.decode()
+    assert "41" in info
+    hashes = [int(x) for x in cli("view", d + "/h.unik").stdout.split()]
+    exp = []
+    for s in seqs:
+        h = oracle_hash(s, True)
+        if h not in exp:
+            exp.append(h)
+    assert hashes == exp and len(exp) == len(seqs) - 1
+    # mismatching lengths are an error (encode.go:101-103)
+    open(d + "/bad.txt", "w").write(seqs[0] + "\n" + seqs[1][:-1] + "\n")
+    assert cli("encode", "-H", d + "/bad.txt", ok=False).returncode != 0
+    # view -g: a minimizer sketch of a genome decoded back to k-mers of that genome
+    cli("count", "-k", 31, "-W", 50, "-H", "-K", "-s", _fa(AMUC), "-o", d + "/m")
+    codes = [int(x) for x in cli("view", d + "/m.unik").stdout.split()]
+    both = cli("view", "-n", "-g", _fa(AMUC), d + "/m.unik").stdout.decode().splitlines()
+    assert len(both) == len(codes) > 1000
+    for line, c in list(zip(both, codes))[:2000]:
+        km, cc = line.split("\t")
+        assert int(cc) == c and len(km) == 31 and oracle_hash(km, True) == c
+    # a code that is in no genome is printed as the integer (view.go:176-181)
+    open(d + "/one.txt", "w").write("12345\n")
+    cli("dump", "--hashed", "-k", 31, d + "/one.txt", "-o", d + "/one")
+    p = cli("view", "-g", _fa(AMUC), d + "/one.unik")
+    assert p.stdout.decode().strip() == "12345" and b"not found in given genomes" in p.stderr

@@ -70,6 +70,15 @@ static void info(const char *fmt, ...) {
     va_end(ap);
 }
 
+static void warn(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    fprintf(stderr, "[WARN] ");
+    vfprintf(stderr, fmt, ap);
+    fprintf(stderr, "\n");
+    va_end(ap);
+}
+
 // ---- tiny flag parser -----------------------------------------------------------------------------
 struct FlagSpec {
     char shortname;  // 0 = none
@@ -1124,17 +1133,86 @@ static int cmd_view(int argc, char **argv) {  // view.go:163-218
                                      {'q', "fastq", false}, {'t', "show-taxid", false}, {'T', "show-taxid-only", false}, {'g', "genome", true}});
     Options o = get_options(a);
     vector<string> files = get_files(a, o);
-    if (a.has("genome")) die("-g/--genome is not supported in this build (hashed k-mers are printed as integers)");
+    vector<string> genomes;
+    if (a.has("genome")) {  // comma-separated list (a StringSlice flag in view.go:235)
+        std::istringstream gs(a.str("genome", ""));
+        string gfile;
+        while (std::getline(gs, gfile, ',')) if (!gfile.empty()) genomes.push_back(gfile);
+    }
     auto out = text_out(a.str("out-file", "-"));
     string buf;
+    // -g: hash -> first location in the genomes (loadHash2Loc, util.go:344-393: canonical ntHash of every window of
+    // every CIRCULAR record, the first occurrence wins).  On the device: ukm_nthash of all records, a stable sort of
+    // (hash, window index), one lower bound per queried code.
+    SeqBatch gb;
+    vector<u64> gh, gwoff;  // sorted hashes; first window index of every record
+    vector<u32> gpos;       // window index of gh[i]
+    std::unique_ptr<Gpu> gpu;
+    bool g_loaded = false;
+    auto load_genomes = [&](int k) {
+        for (auto &gf : genomes) read_fastx(gf, gb, false);
+        const u64 nrec = gb.off.size() - 1;
+        gwoff.assign(nrec + 1, 0);
+        for (u64 r = 0; r < nrec; r++) { const u64 len = gb.off[r + 1] - gb.off[r]; gwoff[r + 1] = gwoff[r] + (len >= (u64)k ? len : 0); }
+        const u64 nw = gwoff[nrec];
+        if (nw > 0xFFFFFFFFull) die("-g/--genome: more than 2^32 k-mers in the genomes");
+        gh.resize(nw); gpos.resize(nw);
+        if (nw == 0) return;
+        gpu.reset(new Gpu(o.gpu));
+        u64 m = 0;
+        ck(ukm_nthash(gpu->c, gb.bases.data(), gb.off.data(), nrec, k, 1, 1, 0, gh.data(), nw, &m));
+        if (m != nw) die("-g/--genome: %llu hashes for %llu windows", (unsigned long long)m, (unsigned long long)nw);
+        for (u64 i = 0; i < nw; i++) gpos[i] = (u32)i;
+        ck(ukm_sort_pairs(gpu->c, gh.data(), gpos.data(), nw, 64));
+        info("%llu hash-k-mers pairs from %llu sequences loaded", (unsigned long long)nw, (unsigned long long)nrec);
+    };
     for (auto &f : files) {
         unik::Reader r(f);
         const int k = r.h.k;
         const bool hashed = r.h.is_hashed();
         const string qual((size_t)k, 'g');
+        bool use_genomes = false;
+        if (!genomes.empty()) {
+            if (!hashed) warn("-g/--genome ignored since k-mers not hashed");
+            else if (!r.h.is_canonical()) warn("-g/--genome ignored since 'canonical' flag is off");
+            else { if (!g_loaded) { load_genomes(k); g_loaded = true; } use_genomes = true; }
+        }
+        vector<u64> qcodes;
+        vector<u32> qtax;
+        vector<string> qkmer;
+        if (use_genomes) {  // all codes of the file first, then one batch of lower bounds on the device
+            u64 c; u32 t;
+            while (r.read(c, t)) { qcodes.push_back(c); qtax.push_back(t); }
+            qkmer.resize(qcodes.size());
+            vector<u64> cuts;
+            const size_t batch = 1u << 28;
+            for (size_t b0 = 0; b0 < qcodes.size(); b0 += batch) {
+                const size_t nq = std::min(batch, qcodes.size() - b0);
+                cuts.resize(nq);
+                if (!gh.empty()) ck(ukm_partition_points(gpu->c, gh.data(), gh.size(), qcodes.data() + b0, (int)nq, cuts.data()));
+                for (size_t i = 0; i < nq; i++) {
+                    const u64 code = qcodes[b0 + i];
+                    const u64 lb = gh.empty() ? 0 : cuts[i];
+                    if (lb < gh.size() && gh[lb] == code) {
+                        const u64 w = gpos[lb];
+                        const u64 rec = (u64)(std::upper_bound(gwoff.begin(), gwoff.end(), w) - gwoff.begin()) - 1;
+                        const u64 len = gb.off[rec + 1] - gb.off[rec], idx = w - gwoff[rec];
+                        string km((size_t)k, 'N');
+                        for (int j = 0; j < k; j++) km[(size_t)j] = (char)gb.bases[gb.off[rec] + (idx + (u64)j) % len];
+                        qkmer[b0 + i] = km;
+                    } else {
+                        qkmer[b0 + i] = std::to_string(code);
+                        warn("fail to decode hash: %llu, which is not found in given genomes", (unsigned long long)code);
+                    }
+                }
+            }
+        }
         u64 code; u32 taxid;
-        while (r.read(code, taxid)) {
-            const string kmer = hashed ? std::to_string(code) : decode_kmer(code, k);
+        size_t qi = 0;
+        for (;;) {
+            if (use_genomes) { if (qi >= qcodes.size()) break; code = qcodes[qi]; taxid = qtax[qi]; }
+            else if (!r.read(code, taxid)) break;
+            const string kmer = use_genomes ? qkmer[qi++] : (hashed ? std::to_string(code) : decode_kmer(code, k));
             if (a.has("fasta")) buf += ">" + std::to_string(code) + (a.has("show-taxid") ? " " + std::to_string(taxid) : "") + "\n" + kmer + "\n";
             else if (a.has("fastq")) buf += "@" + std::to_string(code) + (a.has("show-taxid") ? " " + std::to_string(taxid) : "") + "\n" + kmer + "\n+\n" + qual + "\n";
             else if (a.has("show-taxid")) buf += kmer + "\t" + std::to_string(taxid) + "\n";
@@ -1149,12 +1227,35 @@ static int cmd_view(int argc, char **argv) {  // view.go:163-218
     return 0;
 }
 
+// ntHash of whole k-mers given as text (dump -H, encode -H: dump.go:250-275, encode.go:106-113): every line is one
+// record of k bases with exactly one window, hashed on the device in batches
+static void hash_kmers_on_device(Gpu &g, const vector<string> &kmers, int k, bool canonical, vector<u64> &out) {
+    out.resize(kmers.size());
+    const size_t batch = 1u << 22;
+    vector<uint8_t> bases;
+    vector<u64> off;
+    for (size_t b0 = 0; b0 < kmers.size(); b0 += batch) {
+        const size_t n = std::min(batch, kmers.size() - b0);
+        bases.resize(n * (size_t)k);
+        off.resize(n + 1);
+        for (size_t i = 0; i < n; i++) {
+            memcpy(&bases[i * (size_t)k], kmers[b0 + i].data(), (size_t)k);
+            off[i] = (u64)i * (u64)k;
+        }
+        off[n] = (u64)n * (u64)k;
+        u64 m = 0;
+        ck(ukm_nthash(g.c, bases.data(), off.data(), n, k, canonical ? 1 : 0, 0, 0, out.data() + b0, n, &m));
+        if (m != n) die("ntHash: %llu hashes for %zu k-mers", (unsigned long long)m, n);
+    }
+}
+
 static int cmd_dump(int argc, char **argv) {  // dump.go:128-315
     Args a = parse_args(argc, argv, {{'o', "out-prefix", true}, {'u', "unique", false}, {'K', "canonical", false}, {'O', "canonical-only", false},
                                      {'s', "sorted", false}, {'t', "taxid", true}, {'H', "hash", false}, {0, "hashed", false}, {'k', "kmer-len", true}});
     Options o = get_options(a);
     vector<string> files = get_files(a, o);
-    if (a.has("hash")) die("-H/--hash is not supported by dump in this build (use count -H)");
+    const bool hashed = a.has("hash");  // compute the ntHash of the given k-mers (dump.go:73)
+    if (hashed && a.has("canonical-only")) die("flag -H/--hash and -k/--canonical-only are not compatible");  // dump.go:76-78
     const bool hashed_already = a.has("hashed");
     bool canonical = a.has("canonical");
     const bool canonical_only = a.has("canonical-only"), sorted = a.has("sorted"), unique = a.has("unique");
@@ -1167,6 +1268,8 @@ static int cmd_dump(int argc, char **argv) {  // dump.go:128-315
     std::set<u64> seen;
     u64 n = 0;
     bool include_taxid = false;
+    vector<string> hk;  // -H: the k-mers of all files, hashed on the device after the last line
+    vector<u32> ht;
     for (auto &f : files) {
         unik::InStream in(f);
         string text, chunk(1 << 20, '\0');
@@ -1183,19 +1286,26 @@ static int cmd_dump(int argc, char **argv) {  // dump.go:128-315
             if (tab != string::npos) { kmer = line.substr(0, tab); taxid = (u32)strtoul(line.c_str() + tab + 1, nullptr, 10); has_t = true; }
             if (!w) {  // the first line fixes k and whether taxids are included (dump.go:139-223)
                 if (!hashed_already) k = (int)kmer.size();
-                if (k > 32 && !hashed_already) die("k-mer size (%d) should be <= 32", k);
+                if (k > 32 && !hashed_already && !hashed) die("k-mer size (%d) should be <= 32", k);
+                if (k > 64) die("k-mer size (%d) should be <= 64", k);
                 include_taxid = has_t;
                 u32 mode = 0;
                 if (sorted) mode |= unik::UnikSorted;
-                else if (o.compact && !hashed_already) mode |= unik::UnikCompact;
+                else if (o.compact && !hashed_already && !hashed) mode |= unik::UnikCompact;
                 if (canonical || canonical_only) mode |= unik::UnikCanonical;
                 if (include_taxid) mode |= unik::UnikIncludeTaxID;
-                if (hashed_already) mode |= unik::UnikHashed;
+                if (hashed_already || hashed) mode |= unik::UnikHashed;
                 w.reset(new unik::Writer(os, k, mode));
                 w->set_max_taxid(o.max_taxid);
                 if (gtaxid && !include_taxid) w->set_global_taxid(gtaxid);
             }
             u64 code;
+            if (hashed) {
+                if ((int)kmer.size() != k) die("K-mer length mismatch, previous: %d, current: %zu. %s", k, kmer.size(), kmer.c_str());
+                hk.push_back(kmer);
+                ht.push_back(taxid);
+                continue;
+            }
             if (hashed_already) code = strtoull(kmer.c_str(), nullptr, 10);
             else {
                 if ((int)kmer.size() != k) die("K-mer length mismatch, previous: %d, current: %zu. %s", k, kmer.size(), kmer.c_str());
@@ -1210,6 +1320,16 @@ static int cmd_dump(int argc, char **argv) {  // dump.go:128-315
         }
     }
     if (!w) die("no k-mers given");
+    if (hashed) {
+        Gpu g(o.gpu);
+        vector<u64> hv;
+        hash_kmers_on_device(g, hk, k, canonical, hv);
+        for (size_t i = 0; i < hv.size(); i++) {
+            if (unique && !seen.insert(hv[i]).second) continue;
+            if (include_taxid) w->write_code_with_taxid(hv[i], ht[i]); else w->write_code(hv[i]);
+            n++;
+        }
+    }
     w->flush();
     os.close();
     info("%llu unique k-mers saved to %s", (unsigned long long)n, out_file.c_str());
@@ -1324,12 +1444,38 @@ static int cmd_head(int argc, char **argv) {  // head.go:60-163
     return 0;
 }
 
-static int cmd_encode(int argc, char **argv) {  // encode.go:60-136 (2-bit codes only)
+static int cmd_encode(int argc, char **argv) {  // encode.go:60-136
     Args a = parse_args(argc, argv, {{'o', "out-file", true}, {'a', "all", false}, {'K', "canonical", false}, {'H', "hash", false}});
     Options o = get_options(a);
-    if (a.has("hash")) die("-H/--hash is not supported by encode in this build");
+    const bool hashed = a.has("hash");
     vector<string> files = get_files(a, o);
     auto out = text_out(a.str("out-file", "-"));
+    if (hashed) {  // encode.go:106-113: one ntHash per line, the first line fixes k (<= 64)
+        vector<string> kmers;
+        int k = -1;
+        for (auto &f : files) {
+            unik::InStream in(f);
+            string text, chunk(1 << 20, '\0');
+            for (;;) { size_t got = in.read(&chunk[0], chunk.size()); if (!got) break; text.append(chunk.data(), got); }
+            std::istringstream ss(text);
+            string line;
+            while (std::getline(ss, line)) {
+                while (!line.empty() && (line.back() == '\r' || line.back() == ' ')) line.pop_back();
+                if (line.empty()) continue;
+                if (k == -1) { k = (int)line.size(); if (k > 64) die("k-mer size (%d) should be <=64", k); }
+                else if ((int)line.size() != k) die("K-mer length mismatch, previous: %d, current: %zu. %s", k, line.size(), line.c_str());
+                kmers.push_back(line);
+            }
+        }
+        if (kmers.empty()) return 0;
+        Gpu g(o.gpu);
+        vector<u64> hv;
+        hash_kmers_on_device(g, kmers, k, a.has("canonical"), hv);
+        string buf;
+        for (u64 h : hv) { buf += std::to_string(h) + "\n"; if (buf.size() > (1u << 20)) { put(*out, buf); buf.clear(); } }
+        put(*out, buf);
+        return 0;
+    }
     for (auto &f : files) {
         unik::InStream in(f);
         string text, chunk(1 << 20, '\0');
