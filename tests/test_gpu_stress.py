@@ -178,6 +178,57 @@ def test_random_windows(env, seed):
 
 
 @pytest.mark.parametrize("seed", _seeds(4))
+def test_random_windows_strip_kernels(env, seed, monkeypatch):
+    """The rolling strip kernels forced on (UKM_WIN_STRIP=1: every window; UKM_NTHASH_STRIP=1: Scaled sketch) over
+    random layouts: a few long records mixed with empty / short / k-sized ones, cuts next to row (16) and strip
+    boundaries, random strip lengths, IUPAC / lower-case / N runs, and sizes from a fraction of a tile to several."""
+    O, L, ctx, tax, T = env
+    rng = np.random.default_rng(9000 + seed)
+    alphabet = np.frombuffer(b"ACGTACGTACGTACGTACGTACGTacgtNRYKMn", dtype=np.uint8)
+    monkeypatch.setenv("UKM_WIN_STRIP", "1")
+    monkeypatch.setenv("UKM_NTHASH_STRIP", "1")
+    for it in range(6):
+        n = int(rng.choice([700, 16_384, 70_000, 300_000, 1_100_000]))
+        ncut = int(rng.choice([0, 1, 3, 12, 60]))
+        inner = rng.integers(0, n + 1, ncut)
+        near = []
+        for c in inner[: 6]:   # cuts that leave records of 0, 1, k-1, k, 15..17 bases
+            near += [int(c) + d for d in (0, 1, 15, 16, 17, 30, 31, 32) if int(c) + d <= n]
+        cuts = np.unique(np.concatenate([[0, n], inner, near])).astype(np.uint64)
+        if rng.integers(0, 2):
+            cuts = np.sort(np.concatenate([cuts, cuts[rng.integers(0, len(cuts), 3)]]))   # empty records
+        bases = alphabet[rng.integers(0, len(alphabet), n)]
+        if rng.integers(0, 2):
+            a = int(rng.integers(0, n))
+            bases[a:a + int(rng.integers(1, 200))] = ord("N")
+        Ls = str(int(rng.choice([64, 128, 192, 256])))
+        monkeypatch.setenv("UKM_WIN_STRIP_L", Ls)
+        k = int(rng.choice([1, 3, 15, 16, 17, 21, 31, 32]))
+        canon = bool(rng.integers(0, 2))
+        assert np.array_equal(ctx.encode_kmers(bases, cuts, k, canonical=canon),
+                              O.count_windows(bases, cuts, k, canonical=canon)), (seed, it, "codes", k, canon, Ls, n)
+        kh = int(rng.choice([1, 2, 16, 31, 32, 33, 51, 63, 64]))
+        assert np.array_equal(ctx.nthash(bases, cuts, kh, canonical=canon),
+                              O.count_windows(bases, cuts, kh, hashed=True, canonical=canon)), (seed, it, "nthash", kh, canon, Ls, n)
+        mh = O.max_hash(int(rng.choice([50, 300, 2000])))
+        assert np.array_equal(ctx.nthash(bases, cuts, kh, canonical=canon, max_hash=mh),
+                              O.count_windows(bases, cuts, kh, hashed=True, canonical=canon, max_hash=mh)), (seed, it, "scaled", kh)
+        w = int(rng.choice([3, 15]))
+        hs, ps = [], []
+        for r in range(len(cuts) - 1):
+            seq = bases[int(cuts[r]):int(cuts[r + 1])]
+            try:
+                h, p = O.minimizer(seq, kh, w)
+            except ValueError:
+                continue
+            hs.append(h); ps.append(p)
+        eh = np.concatenate(hs) if hs else np.empty(0, np.uint64)
+        ep = np.concatenate(ps) if ps else np.empty(0, np.uint64)
+        gh, gp = ctx.minimizer(bases, cuts, kh, w, with_pos=True)
+        assert np.array_equal(gh, eh) and np.array_equal(gp, ep), (seed, it, "minimizer", kh, w)
+
+
+@pytest.mark.parametrize("seed", _seeds(4))
 def test_random_nway_with_taxids(env, seed):
     """n-way union / inter (-m) / diff (-t) / common / merge (-u, -d, chunk rounds) with per-record taxids,
     some files without taxids (mix), taxid 0 records, empty files in the middle."""
