@@ -965,9 +965,9 @@ int run_strip_windows(ukm_ctx *c, bool hash, const u8 *bases, const u64 *rec_off
     if (force != 1 && (total_bases < (1ull << 25) || n_rec * 32768ull > total_bases)) return UKM_OK;
     // several rounds of workgroups per CU matter more than the k - 1 warm-up steps per strip (measured at 1e8
     // bases, codes: L = 64 / 128 / 256 / 512 -> 0.178 / 0.185 / 0.21 / 0.22 ms; ntHash k = 51: 0.242 / 0.230 / 0.244)
-    int L = 256;
-    const u64 want_tiles = hash ? 3000 : 5000;
-    while (L > (hash ? 128 : 64) && total_bases / ((u64)SW_NT * (u64)L) < want_tiles) L >>= 1;
+    // (1e9 bases: codes 1.71 / 1.84 / 1.94 ms, ntHash k = 51 2.23 / 1.89 / 1.96 ms: short strips keep a wave's 64 output
+    // rows close together in memory, which is worth more than the shorter warm-up of long ones)
+    int L = (k <= 32) ? 64 : 128;  // twice the warm-up
     if (const char *le = getenv("UKM_WIN_STRIP_L")) L = std::max(64, atoi(le) / 64 * 64);
     const u64 tile_pos = (u64)SW_NT * (u64)L;
     const u64 ntiles = (total_bases + tile_pos - 1) / tile_pos;
