@@ -394,13 +394,13 @@ def test_windows_strip_kernel_long_records(ctx, O, L, monkeypatch, force):
     chromosome): codes and ntHash, every k phase, canonical / forward, ragged records incl. empty and
     shorter-than-k ones, record ends inside a row block and inside a strip's warm-up, degenerate and lower-case
     bases, several tiles and strip lengths.  force=1 also runs it on record mixes the library would hand to the
-    general kernel; None = the library's own choice (the general kernel at this size; the strip kernel from
-    3.4e7 bases on: tests/test_gpu_properties.py)."""
+    general kernel; None = the library's own choice (9e6 bases of long records: the strip kernel for k <= 32, the
+    general kernel for larger k, which switches at 1.7e7 bases)."""
     if force is None:
         monkeypatch.delenv("UKM_WIN_STRIP", raising=False)
     else:
         monkeypatch.setenv("UKM_WIN_STRIP", force)
-    n = 4_500_000
+    n = 9_000_000
     bases = _synth_fasta(n, SEED + 23).copy()
     bases[1000:1100] = ord("N")
     bases[70_000] = ord("n")

@@ -960,9 +960,11 @@ int run_strip_windows(ukm_ctx *c, bool hash, const u8 *bases, const u64 *rec_off
     const int force = fe ? atoi(fe) : -1;
     if (force == 0) return UKM_OK;
     if (((uintptr_t)bases & 3) != 0 || (!hash && k > 32)) return UKM_OK;
-    // below ~3e7 bases there are too few strips to fill the chip (4.6 Mbp: 0.032 ms against 0.023 ms for the general
-    // kernel); short records spend their time in the value-by-value path of rows that touch a record boundary
-    if (force != 1 && (total_bases < (1ull << 25) || n_rec * 32768ull > total_bases)) return UKM_OK;
+    // small inputs have too few strips to fill the chip (measured cross-over: 8e6 bases for L = 64, 1.6e7 for L = 128;
+    // 1.6e7 bases: codes 0.042 ms against 0.060 ms for the general kernel); short records spend their time in the
+    // value-by-value path of rows that touch a record boundary
+    const u64 min_bases = (k <= 32) ? (1ull << 23) : (1ull << 24);
+    if (force != 1 && (total_bases < min_bases || n_rec * 32768ull > total_bases)) return UKM_OK;
     // several rounds of workgroups per CU matter more than the k - 1 warm-up steps per strip (measured at 1e8
     // bases, codes: L = 64 / 128 / 256 / 512 -> 0.178 / 0.185 / 0.21 / 0.22 ms; ntHash k = 51: 0.242 / 0.230 / 0.244)
     // (1e9 bases: codes 1.71 / 1.84 / 1.94 ms, ntHash k = 51 2.23 / 1.89 / 1.96 ms: short strips keep a wave's 64 output
