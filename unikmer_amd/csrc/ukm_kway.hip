@@ -131,6 +131,26 @@ __device__ __forceinline__ void kw_merge_round_regs(const u64 *in, const u32 *ti
     int pa = abase + lo, pb = bbase + diag - lo;
     const int ea = abase + la, eb = bbase + lb;
     u64 ak = in[pa], bk = in[pb];
+    if (!CHECKED && !TAX) {
+        // the kernel is bound by VALU issue: only the A cursor is tracked (pa + pb grows by one per step), which
+        // takes the step from 16 to 12 instructions
+        // cursors in BYTES (no shift per LDS address); only the B cursor is tracked: pa + pb grows by one per step
+        const int sum8 = (pa + pb) * 8;
+        int pb8 = pb * 8;
+        const char *inb = reinterpret_cast<const char *>(in);
+#pragma unroll
+        for (int s = 0; s < VT; s++) {
+            const bool take_b = bk < ak;  // ONE compare per step: the minimum and the cursor choice share it
+            ro[s] = take_b ? bk : ak;
+            asm volatile("" : "+v"(ro[s]));
+            pb8 += take_b ? 8 : 0;
+            const int idx8 = take_b ? pb8 : sum8 + 8 * (s + 1) - pb8;
+            const u64 nk = *reinterpret_cast<const u64 *>(inb + idx8);
+            ak = take_b ? ak : nk;
+            bk = take_b ? nk : bk;
+        }
+        return;
+    }
 #pragma unroll
     for (int s = 0; s < VT; s++) {
         bool take_a;
@@ -642,7 +662,7 @@ int ukm_kway_fanin() {  // 0 = automatic
     if (k < 0) {
         const char *e = getenv("UKM_KWAY_K");
         k = e ? atoi(e) : 0;
-        if (k != 8 && k != 16) k = 0;
+        if (k != 4 && k != 8 && k != 16) k = 0;
     }
     return k;
 }
@@ -683,7 +703,7 @@ int ukm_dev_kway(ukm_ctx *c, int op, const u64 *const *keys, const u32 *const *t
     // keys, the TaxId shape does not fit LDS at that fan-in.)
     const int kpref = ukm_kway_fanin();
     auto pick_k = [&](u64 nchildren) -> int {
-        if (nchildren <= 4) return 4;
+        if (nchildren <= 4 || kpref == 4) return 4;
         if (nchildren <= 8 || tax) return 8;
         return kpref == 16 ? 16 : 8;
     };
