@@ -120,27 +120,26 @@ __device__ __forceinline__ void kw_merge_round_regs(const u64 *in, const u32 *ti
     const int L = la + lb;
     int diag = lt * VT;
     diag = diag < L ? diag : L;
-    int lo = diag > lb ? diag - lb : 0;
-    int hi = diag < la ? diag : la;
-    while (lo < hi) {
-        const int mid = (lo + hi) >> 1;
-        const bool le = in[abase + mid] <= in[bbase + diag - 1 - mid];
-        lo = le ? mid + 1 : lo;
-        hi = le ? hi : mid;
+    // merge-path search with BYTE offsets (two adds per probe instead of shifts and index arithmetic)
+    const char *inb = reinterpret_cast<const char *>(in);
+    const char *a8 = inb + abase * 8, *b8 = inb + (bbase + diag - 1) * 8;
+    int lo8 = (diag > lb ? diag - lb : 0) * 8;
+    int hi8 = (diag < la ? diag : la) * 8;
+    while (lo8 < hi8) {
+        const int mid8 = ((lo8 + hi8) >> 1) & ~7;
+        const bool le = *reinterpret_cast<const u64 *>(a8 + mid8) <= *reinterpret_cast<const u64 *>(b8 - mid8);
+        lo8 = le ? mid8 + 8 : lo8;
+        hi8 = le ? hi8 : mid8;
     }
-    int pa = abase + lo, pb = bbase + diag - lo;
-    const int ea = abase + la, eb = bbase + lb;
-    u64 ak = in[pa], bk = in[pb];
     if (!CHECKED && !TAX) {
-        // the kernel is bound by VALU issue: only the A cursor is tracked (pa + pb grows by one per step), which
-        // takes the step from 16 to 12 instructions
-        // cursors in BYTES (no shift per LDS address); only the B cursor is tracked: pa + pb grows by one per step
-        const int sum8 = (pa + pb) * 8;
-        int pb8 = pb * 8;
-        const char *inb = reinterpret_cast<const char *>(in);
+        // the kernel is bound by VALU issue: ONE compare per step feeds the minimum, the cursor and the head update;
+        // only the B cursor is tracked, in bytes (pa + pb grows by one record per step): 12 instructions instead of 16
+        const int sum8 = (abase + bbase + diag) * 8;
+        int pb8 = (bbase + diag) * 8 - lo8;
+        u64 ak = *reinterpret_cast<const u64 *>(a8 + lo8), bk = *reinterpret_cast<const u64 *>(inb + pb8);
 #pragma unroll
         for (int s = 0; s < VT; s++) {
-            const bool take_b = bk < ak;  // ONE compare per step: the minimum and the cursor choice share it
+            const bool take_b = bk < ak;
             ro[s] = take_b ? bk : ak;
             asm volatile("" : "+v"(ro[s]));
             pb8 += take_b ? 8 : 0;
@@ -151,6 +150,10 @@ __device__ __forceinline__ void kw_merge_round_regs(const u64 *in, const u32 *ti
         }
         return;
     }
+    const int lo = lo8 >> 3;
+    int pa = abase + lo, pb = bbase + diag - lo;
+    const int ea = abase + la, eb = bbase + lb;
+    u64 ak = in[pa], bk = in[pb];
 #pragma unroll
     for (int s = 0; s < VT; s++) {
         bool take_a;
@@ -192,9 +195,8 @@ struct KwMap {
 // UNION: one record per distinct code, TaxId = LCA over every occurrence.  !UNION: every record kept.
 // LEAF: the children are the caller's streams (cut table, order check); otherwise the previous level's output.
 //
-// Per iteration: [chunk in registers, prefetched] -> LDS | barrier | v, per-child counts of records < v by
-// ballots | barrier | cursors, sentinels | barrier | PREFETCH of the next chunk (its loads fly during the
-// merges) | log2(K) merge rounds | emit.
+// Per iteration: chunk -> registers -> LDS | barrier | (leaf level: order check | barrier) | wave 0: v, per-child
+// lower bound of v in its sorted chunk, cursors, sentinels | barrier | log2(K) merge rounds | emit.
 // ONEBUF: one LDS buffer; a merge round keeps its VT outputs in registers and stores them after a barrier (twice the
 // records per thread at the same LDS footprint: every round's merge-path search is amortised over 17 instead of 9).
 template <int K, int LOGK, bool TAX, bool UNION, bool LEAF, int NT, int VT, bool ONEBUF>
@@ -221,7 +223,6 @@ __global__ __launch_bounds__(NT, KW_WAVES) void kway_kernel(KwArgs p) {
     __shared__ const u32 *s_tptr[K];
     __shared__ u64 s_rem[K];
     __shared__ u64 s_prev[K];
-    __shared__ u32 s_cnt[K];
     __shared__ int s_pre[K + 1];
     __shared__ int s_ctl[4];  // [0] M, [1] danger, [2] more
     __shared__ u32 s_scan[NT / 64 + 1];
@@ -260,7 +261,6 @@ __global__ __launch_bounds__(NT, KW_WAVES) void kway_kernel(KwArgs p) {
         s_tptr[tid] = tptr;
         s_rem[tid] = len;
         s_prev[tid] = prev;
-        s_cnt[tid] = 0;
         if (bad) atomicOr((unsigned long long *)&p.result[1], (unsigned long long)bad);
     }
     // output slot of (node, range): rank of the range's first record among the node's leaves
@@ -281,14 +281,14 @@ __global__ __launch_bounds__(NT, KW_WAVES) void kway_kernel(KwArgs p) {
             return;
         }
     }
-    const u64 *safe = p.result;  // always mapped: idle lanes load from here
+    // always mapped and all ones: lanes without a record load KW_MAX from here (no validity mask, no select
+    // afterwards: the kernel is bound by VALU issue)
+    const u64 *safe = p.result + 4;
 
     // the chunk of the coming iteration, in registers: record (tid + i * NT) of the K x C layout
     u64 kk[VT];
     u32 tt[VT];
-    u32 vmask = 0;  // bit i: kk[i] is a real record
     auto load_chunk = [&]() {
-        vmask = 0;
         unsigned t = (unsigned)tid;
         asm volatile("" : "+v"(t));  // index math of this phase is recomputed, not kept live across the loop
 #pragma unroll
@@ -304,7 +304,6 @@ __global__ __launch_bounds__(NT, KW_WAVES) void kway_kernel(KwArgs p) {
                 tt[i] = *(tv ? ts + e : reinterpret_cast<const u32 *>(safe));
                 tt[i] = tv ? tt[i] : 0u;
             }
-            vmask |= valid ? (1u << i) : 0u;
         }
     };
     if (!ONEBUF) load_chunk();
@@ -320,30 +319,12 @@ __global__ __launch_bounds__(NT, KW_WAVES) void kway_kernel(KwArgs p) {
         for (int i = 0; i < VT; i++) {
             unsigned slot, e;
             KwMap<K, NT, VT>::at(ta, i, slot, e);
-            kk[i] = (vmask >> i) & 1u ? kk[i] : KW_MAX;
             s_a[slot * CS + e] = kk[i];
             if (TAX) s_ta[slot * CS + e] = tt[i];
         }
         __syncthreads();
-        // ---- B. v = min over children with more to come of their last loaded code; records < v are
-        //         consumed (every copy of such a code is in LDS); counts per child by ballots ---------------
-        {
-            // every wave computes v with its first K lanes (one LDS read each) and a K-lane butterfly
-            u64 v;
-            bool any_full;
-            {
-                const int j = lane_id() & (K - 1);
-                const bool full = s_rem[j] > (u64)C;
-                u64 cand = s_a[j * CS + C - 1];
-                cand = full ? cand : KW_MAX;
-#pragma unroll
-                for (int d = K / 2; d >= 1; d >>= 1) {
-                    const u64 o = __shfl_xor(cand, d, 64);
-                    cand = o < cand ? o : cand;
-                }
-                v = cand;
-                any_full = __ballot(full) != 0;
-            }
+        // ---- B. (leaf level) every stream must be sorted: each record against its predecessor -----------------
+        if (LEAF) {
             u32 unsorted = 0;
             unsigned tb = (unsigned)tid;
             asm volatile("" : "+v"(tb));
@@ -351,41 +332,45 @@ __global__ __launch_bounds__(NT, KW_WAVES) void kway_kernel(KwArgs p) {
             for (int i = 0; i < VT; i++) {
                 unsigned slot, e;
                 KwMap<K, NT, VT>::at(tb, i, slot, e);
-                const bool valid = (vmask >> i) & 1u;
-                const bool pred = valid && (!any_full || kk[i] < v);
-                if (LEAF) {
-                    const u64 pk = e > 0 ? s_a[slot * CS + e - 1] : s_prev[slot];
-                    unsorted |= (valid && pk > kk[i]) ? 1u : 0u;
-                }
-                if (i < KwMap<K, NT, VT>::UNIFORM) {
-                    const u64 b0 = __ballot(pred);  // the whole wave holds records of child i % K
-                    if (lane_id() == 0 && b0) atomicAdd(&s_cnt[i % K], (u32)__popcll(b0));
-                } else {
-                    // the 64 records of a wave lie in at most two children
-                    const unsigned slot0 = (unsigned)__builtin_amdgcn_readfirstlane((int)slot);
-                    const u64 b0 = __ballot(pred && slot == slot0), b1 = __ballot(pred && slot != slot0);
-                    if (lane_id() == 0) {
-                        if (b0) atomicAdd(&s_cnt[slot0], (u32)__popcll(b0));
-                        if (b1) atomicAdd(&s_cnt[slot0 + 1], (u32)__popcll(b1));
-                    }
-                }
+                const u64 pk = e > 0 ? s_a[slot * CS + e - 1] : s_prev[slot];
+                unsorted |= (pk > kk[i]) ? 1u : 0u;  // (a lane without a record holds KW_MAX)
             }
-            if (LEAF && __ballot(unsorted != 0) && lane_id() == 0)
+            if (__ballot(unsorted != 0) && lane_id() == 0)
                 atomicOr((unsigned long long *)&p.result[1], (unsigned long long)KW_FLAG_UNSORTED);
+            __syncthreads();  // phase C overwrites a record of every chunk with a sentinel
         }
-        __syncthreads();
-        // ---- C. cursors, sentinels, run lengths ------------------------------------------------------------
+        // ---- C. v = min over children with more to come of their last loaded code; records < v are consumed
+        //         (every copy of such a code is in LDS): per child a lower bound in its sorted chunk; cursors,
+        //         sentinels, run lengths ----------------------------------------------------------------------
         if (tid < 64) {
             const int j = tid;
             const bool act = j < K;
-            const u64 rem = act ? s_rem[j] : 0;
+            const int jj = j & (K - 1);
+            const u64 rem = act ? s_rem[jj] : 0;
             const int avail = rem < (u64)C ? (int)rem : C;
-            int cnt = act ? (int)s_cnt[j] : 0;
-            cnt = cnt < avail ? cnt : avail;  // (only an unsorted chunk can count more)
-            const u32 incl = wave_incl_scan_u32((u32)cnt);
             const bool full = act && rem > (u64)C;
+            u64 v = full ? s_a[jj * CS + C - 1] : KW_MAX;
+#pragma unroll
+            for (int d = K / 2; d >= 1; d >>= 1) {
+                const u64 o = __shfl_xor(v, d, 64);
+                v = o < v ? o : v;
+            }
             const bool any_full = __ballot(full) != 0;
-            const bool dng = act && !any_full && avail > 0 && s_a[j * CS + avail - 1] == KW_MAX;
+            int cnt = avail;
+            if (any_full) {  // first record >= v
+                int lo = 0, hi = avail;
+                const u64 *ch = s_a + jj * CS;
+                while (lo < hi) {
+                    const int mid = (lo + hi) >> 1;
+                    const bool lt = ch[mid] < v;
+                    lo = lt ? mid + 1 : lo;
+                    hi = lt ? hi : mid;
+                }
+                cnt = lo;
+            }
+            cnt = act ? cnt : 0;
+            const u32 incl = wave_incl_scan_u32((u32)cnt);
+            const bool dng = act && !any_full && avail > 0 && s_a[jj * CS + avail - 1] == KW_MAX;
             const bool any_dng = __ballot(dng) != 0;
             const u64 left = wave_reduce_sum_u64(act ? rem - (u64)cnt : 0);
             if (act) {
@@ -395,7 +380,6 @@ __global__ __launch_bounds__(NT, KW_WAVES) void kway_kernel(KwArgs p) {
                 s_ptr[j] += cnt;
                 if (TAX && s_tptr[j]) s_tptr[j] += cnt;
                 s_rem[j] = rem - (u64)cnt;
-                s_cnt[j] = 0;
             }
             if (j == 0) {
                 s_pre[0] = 0;
@@ -471,64 +455,44 @@ __global__ __launch_bounds__(NT, KW_WAVES) void kway_kernel(KwArgs p) {
             asm volatile("" : "+v"(tf));
             const int i0 = tf * VT;
             u32 mask = 0;
+            u64 hk[VT];  // the thread's VT merged records: read once, the heads are written from these registers
+            u32 ht[VT];
             {
                 u64 prevk = (i0 > 0 && i0 <= M) ? fin[i0 - 1] : 0;
 #pragma unroll
                 for (int s = 0; s < VT; s++) {
                     const int i = i0 + s;
                     const u64 k = fin[i];  // (slots behind M hold garbage inside the buffer)
+                    hk[s] = k;
                     const bool head = i < M && (i == 0 || k != prevk);
                     prevk = k;
                     mask |= head ? (1u << s) : 0u;
                 }
             }
-            u32 tot;
-            const u32 excl = block_excl_scan_u32<NT>((u32)__popc(mask), s_scan, &tot);
-            if (ONEBUF) {
-                // compaction in place: heads (and their folded TaxIds) go to registers first
-                u64 hk[VT];
-                u32 ht[VT];
+            if (TAX) {
 #pragma unroll
                 for (int s = 0; s < VT; s++) {
-                    hk[s] = 0;
                     ht[s] = 0;
                     if (mask & (1u << s)) {
                         const int i = i0 + s;
-                        const u64 k = fin[i];
-                        hk[s] = k;
-                        if (TAX) {
-                            u32 tx = tfin[i];
-                            for (int q = i + 1; q < M && fin[q] == k; q++) tx = lca_dev(p.tax, tfin[q], tx);
-                            ht[s] = tx;
-                        }
+                        u32 tx = tfin[i];
+                        for (int q = i + 1; q < M && fin[q] == hk[s]; q++) tx = lca_dev(p.tax, tfin[q], tx);
+                        ht[s] = tx;
                     }
                 }
-                __syncthreads();
-                u32 w = excl;
-#pragma unroll
-                for (int s = 0; s < VT; s++) {
-                    if (mask & (1u << s)) {
-                        oth[w] = hk[s];
-                        if (TAX) toth[w] = ht[s];
-                        w++;
-                    }
-                }
-            } else {
+            }
+            u32 tot;
+            const u32 excl = block_excl_scan_u32<NT>((u32)__popc(mask), s_scan, &tot);
+            // (ONEBUF: compaction in place; the scan's barriers lie between every thread's last read of fin / tfin and
+            //  these writes)
             u32 w = excl;
 #pragma unroll
             for (int s = 0; s < VT; s++) {
                 if (mask & (1u << s)) {
-                    const int i = i0 + s;
-                    const u64 k = fin[i];
-                    oth[w] = k;
-                    if (TAX) {
-                        u32 tx = tfin[i];
-                        for (int q = i + 1; q < M && fin[q] == k; q++) tx = lca_dev(p.tax, tfin[q], tx);
-                        toth[w] = tx;
-                    }
+                    oth[w] = hk[s];
+                    if (TAX) toth[w] = ht[s];
                     w++;
                 }
-            }
             }
             __syncthreads();
             flush_k = oth;
@@ -766,6 +730,7 @@ int ukm_dev_kway(ukm_ctx *c, int op, const u64 *const *keys, const u32 *const *t
     UKM_TRY(ws_alloc_t(c, ((size_t)S + 1) * RP, &P));
     UKM_TRY(ws_alloc_t(c, 8, &ctl));
     UKM_HIP(hipMemsetAsync(ctl, 0, 8 * sizeof(u64), c->stream));
+    UKM_HIP(hipMemsetAsync(ctl + 4, 0xFF, 2 * sizeof(u64), c->stream));  // ctl[4]: KW_MAX for the lanes without a record
     u64 *samples = nullptr;
     if (R > 1) {
         UKM_TRY(ws_alloc_t(c, ns, &samples));
