@@ -44,26 +44,39 @@ constexpr u32 DMASK = RADIX - 1;
 constexpr int MAX_PASSES = 8;
 
 // ---- histogram of all digits -------------------------------------------------------------------
+struct __attribute__((packed, aligned(8))) U2a8 {  // 16 bytes at 8-byte alignment
+    u64 x, y;
+};
 __global__ __launch_bounds__(NT) void radix_hist_kernel(const u64 *k, u64 n, int passes, u64 *ghist) {
     __shared__ u32 s_h[MAX_PASSES * RADIX];
     const int tid = (int)threadIdx.x;
     for (int i = tid; i < MAX_PASSES * RADIX; i += NT) s_h[i] = 0;
     __syncthreads();
-    constexpr int U = 4;  // independent loads in flight per thread (one load per iteration was latency bound: 1.6 TB/s)
-    const u64 per_block = ((n + gridDim.x - 1) / gridDim.x + (u64)(NT * U) - 1) / (u64)(NT * U) * (u64)(NT * U);
+    constexpr int U = 4;  // independent 16-byte loads in flight per thread (one 8-byte load per iteration was latency
+                          // bound: 1.6 TB/s; four: 3.6 TB/s; four pairs: 4.3 TB/s.  Four copies of every bin, chosen by the lane, were slower: 0.206 against 0.185 ms)
+    constexpr u64 STEP = (u64)NT * U * 2;
+    const u64 per_block = ((n + gridDim.x - 1) / gridDim.x + STEP - 1) / STEP * STEP;
     const u64 beg = (u64)blockIdx.x * per_block;
     const u64 end = (beg + per_block < n) ? beg + per_block : n;
-    for (u64 i0 = beg; i0 < end; i0 += (u64)NT * U) {
-        u64 key[U];
-        bool valid[U];
+    for (u64 i0 = beg; i0 < end; i0 += STEP) {
+        u64 key[2 * U];
+        bool valid[2 * U];
 #pragma unroll
         for (int u = 0; u < U; u++) {
-            const u64 i = i0 + (u64)u * NT + tid;
-            valid[u] = i < end;
-            key[u] = k[valid[u] ? i : end - 1];  // unconditional load (a branch around it would serialise the loads)
+            const u64 i = i0 + ((u64)u * NT + tid) * 2;
+            valid[2 * u] = i < end;
+            valid[2 * u + 1] = i + 1 < end;
+            if (i + 1 < end) {
+                const U2a8 q = *reinterpret_cast<const U2a8 *>(k + i);  // (the caller's array may start on an odd 8-byte slot)
+                key[2 * u] = q.x;
+                key[2 * u + 1] = q.y;
+            } else {
+                key[2 * u] = k[valid[2 * u] ? i : end - 1];
+                key[2 * u + 1] = key[2 * u];
+            }
         }
 #pragma unroll
-        for (int u = 0; u < U; u++) {
+        for (int u = 0; u < 2 * U; u++) {
             const u64 vm = __ballot(valid[u]);
             for (int p = 0; p < passes; p++) {
                 const u32 d = (u32)(key[u] >> (RB * p)) & DMASK;
