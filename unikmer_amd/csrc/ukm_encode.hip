@@ -62,6 +62,9 @@ constexpr u32 base2bit(u32 c) {
 #define SEED_G 0x20323ed082572324ULL
 #define SEED_T 0x295549f54be24456ULL
 
+// a ^ b ^ c in one instruction (gfx950's three-input v_bitop3_b32, truth table 0x96)
+__device__ __forceinline__ u32 xor3(u32 a, u32 b, u32 c) { return __builtin_amdgcn_bitop3_b32(a, b, c, 0x96); }
+
 // branch-free rotates: for s = 0 both shifts are by 0 and x | x = x
 __device__ __forceinline__ u64 rol64(u64 x, u32 s) { return (x << (s & 63)) | (x >> ((0u - s) & 63)); }
 __device__ __forceinline__ u64 ror64(u64 x, u32 s) { return (x >> (s & 63)) | (x << ((0u - s) & 63)); }
@@ -554,6 +557,7 @@ __global__ __launch_bounds__(ST_NT) void nthash_strip_kernel(StripArgs p) {
     const bool active = s0 < p.total_bases;
     const u32 mh_hi = (u32)(p.max_hash >> 32);
     const bool canon = p.canonical != 0;
+    const u32 rmask = canon ? 0u : 0xFFFFFFFFu;  // forward hashes only: the reverse strand never passes the coarse test
     u32 flo = 0, fhi = 0, rlo = 0, rhi = 0;  // fwd / rev hash of the k bases ending at the current position
     u32 myseq = 0;
     const int nsteps = L + k - 1;
@@ -585,15 +589,22 @@ __global__ __launch_bounds__(ST_NT) void nthash_strip_kernel(StripArgs p) {
                 const uint4 ein = s_tin[(i4 >> (8 * q)) & 0xFFu];
                 const uint4 eout = s_tout[(o4 >> (8 * q)) & 0xFFu];
                 // fwd = rol(fwd, 1) ^ seed[in] ^ rol(seed[out], k)
-                const u32 nflo = __builtin_amdgcn_alignbit(flo, fhi, 31) ^ ein.x ^ eout.x;
-                const u32 nfhi = __builtin_amdgcn_alignbit(fhi, flo, 31) ^ ein.y ^ eout.y;
+                const u32 nflo = xor3(__builtin_amdgcn_alignbit(flo, fhi, 31), ein.x, eout.x);
+                const u32 nfhi = xor3(__builtin_amdgcn_alignbit(fhi, flo, 31), ein.y, eout.y);
                 // rev = ror(rev, 1) ^ rol(cseed[in], k - 1) ^ ror(cseed[out], 1)
-                const u32 nrlo = __builtin_amdgcn_alignbit(rhi, rlo, 1) ^ ein.z ^ eout.z;
-                const u32 nrhi = __builtin_amdgcn_alignbit(rlo, rhi, 1) ^ ein.w ^ eout.w;
+                const u32 nrlo = xor3(__builtin_amdgcn_alignbit(rhi, rlo, 1), ein.z, eout.z);
+                const u32 nrhi = xor3(__builtin_amdgcn_alignbit(rlo, rhi, 1), ein.w, eout.w);
                 flo = nflo; fhi = nfhi; rlo = nrlo; rhi = nrhi;
-                // coarse test on the high words; everything else only for the rare hit
-                const bool hit = (fhi <= mh_hi) || (canon && rhi <= mh_hi);
-                if (hit && i >= k - 1 && i < nsteps) {
+                // Coarse test on the high words with ONE vector compare; everything else — also the uniform range
+                // check of the step index — only inside the rare hit.  (Written as `hit && i >= k - 1 && i < nsteps`
+                // the compiler evaluated the scalar range checks and a short-circuit branch for the second strand on
+                // EVERY step: 27 scalar instructions per step against 19 vector ones, and a CU issues one scalar
+                // instruction per cycle: the kernel was bound by its scalar unit.)
+                const u32 hmin = fhi < (rhi | rmask) ? fhi : (rhi | rmask);
+                if (__builtin_expect(hmin <= mh_hi, 0)) {
+                    int ii = i;
+                    asm volatile("" : "+s"(ii));  // keeps the range check inside the branch
+                    if (ii >= k - 1 && ii < nsteps) {
                     const u64 f = ((u64)fhi << 32) | flo, rv = ((u64)rhi << 32) | rlo;
                     const u64 h = (canon && rv < f) ? rv : f;
                     const u32 w = (u32)(i - (k - 1));  // window index inside the strip
@@ -604,6 +615,7 @@ __global__ __launch_bounds__(ST_NT) void nthash_strip_kernel(StripArgs p) {
                             s_ci[e] = ((u32)tid << 24) | ((myseq & 0x1FFFu) << 11) | w;
                         }
                         myseq++;
+                    }
                     }
                 }
             }
@@ -888,10 +900,10 @@ __global__ __launch_bounds__(SW_NT) __attribute__((amdgpu_waves_per_eu(HASH ? 3 
                 if constexpr (HASH) {
                     const uint4 ein = s_tin[(i4 >> (8 * q)) & 0xFFu];
                     const uint4 eout = s_tout[(o4 >> (8 * q)) & 0xFFu];
-                    const u32 nflo = __builtin_amdgcn_alignbit(flo, fhi, 31) ^ ein.x ^ eout.x;
-                    const u32 nfhi = __builtin_amdgcn_alignbit(fhi, flo, 31) ^ ein.y ^ eout.y;
-                    const u32 nrlo = __builtin_amdgcn_alignbit(rhi, rlo, 1) ^ ein.z ^ eout.z;
-                    const u32 nrhi = __builtin_amdgcn_alignbit(rlo, rhi, 1) ^ ein.w ^ eout.w;
+                    const u32 nflo = xor3(__builtin_amdgcn_alignbit(flo, fhi, 31), ein.x, eout.x);
+                    const u32 nfhi = xor3(__builtin_amdgcn_alignbit(fhi, flo, 31), ein.y, eout.y);
+                    const u32 nrlo = xor3(__builtin_amdgcn_alignbit(rhi, rlo, 1), ein.z, eout.z);
+                    const u32 nrhi = xor3(__builtin_amdgcn_alignbit(rlo, rhi, 1), ein.w, eout.w);
                     flo = nflo; fhi = nfhi; rlo = nrlo; rhi = nrhi;
                     const u64 f = ((u64)fhi << 32) | flo, rv = ((u64)rhi << 32) | rlo;
                     v = (canon && rv < f) ? rv : f;
