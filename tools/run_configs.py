@@ -201,7 +201,7 @@ def main():
             torch.cuda.synchronize(); t0 = time.perf_counter()
             h = ctx.nthash(bases, reads, 51, canonical=True, max_hash=mh, out=out)
             torch.cuda.synchronize(); t1 = time.perf_counter()
-            ctx.sort_u64(h, 64)
+            ctx.sort_u64(h, int(mh).bit_length())  # kept hashes are <= maxHash: 55 significant bits at scale 1000
             u = ctx.unique(h, out=uq)
             torch.cuda.synchronize(); t2 = time.perf_counter()
             t["nthash+filter"], t["sort+unique"] = (t1 - t0) * 1e3, (t2 - t1) * 1e3
