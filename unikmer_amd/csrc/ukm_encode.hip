@@ -1095,7 +1095,10 @@ int run_windows(ukm_ctx *c, bool hash, const u8 *bases, const u64 *rec_off, u64 
 //   arg(g)   == g+w-1      <=>  h[g+w-1] <  m
 // and otherwise arg(g-1) == arg(g), so  emit(g) = g==0 || h[g-1] <= m || h[g+w-1] < m  -- every
 // group is decided independently of the others (no serial scan over the record).
-constexpr int MT = 1024;        // window indices per tile
+#ifndef MIN_MT
+#define MIN_MT 2048  /* 1024 / 2048 / 4096: 1.24 / 1.01 / 1.19 ms per 1e8 windows incl. the ntHash pass (w = 15) */
+#endif
+constexpr int MT = MIN_MT;      // window indices per tile
 constexpr int MPT = MT / NT;    // per thread, striped
 constexpr int MW_MAX = 1024;    // largest supported w (LDS halo)
 
@@ -1116,9 +1119,19 @@ struct MinArgs {
     const u64 *tile_rec;
 };
 
+// The leftmost minimum of h[g .. g+w-2] for every group comes from a sparse table built in place in LDS:
+// level t holds the (leftmost) minimum of the 2^t hashes starting at every index; log2(w-1) doubling steps
+// (operands to registers | barrier | store | barrier), then two overlapping table entries per group.  The first
+// version walked the w - 2 hashes per group: O(w) LDS reads per window (w = 15: 1.0 ms per 1e8 windows, w = 200:
+// 3.0 ms) and a binary search in the global record table per window.
+constexpr int M_EPT = (MT + MW_MAX + 1 + NT - 1) / NT;  // table entries per thread
+constexpr int M_REC = 256;                              // records of a tile kept in LDS
+
 template <bool TICKET>
 __global__ __launch_bounds__(NT) void minimizer_kernel(MinArgs p) {
-    __shared__ u64 s_h[MT + MW_MAX + 1];  // s_h[i] = h[J0 - 1 + i]
+    __shared__ u64 s_h[MT + MW_MAX + 1];            // s_h[i] = h[J0 - 1 + i]; becomes the sparse table's top level
+    __shared__ unsigned short s_ix[MT + MW_MAX + 1];  // arg-min (index into s_h) of every table entry
+    __shared__ u64 s_off[M_REC + 2];
     __shared__ u32 s_cnt[MPT * NWV + 1];
     __shared__ u64 s_r[2];
     __shared__ u64 s_misc[2];
@@ -1131,9 +1144,11 @@ __global__ __launch_bounds__(NT) void minimizer_kernel(MinArgs p) {
     }
     const u64 J0 = tile * (u64)MT;
     const int w = p.w;
-    for (int i = tid; i < MT + w; i += NT) {
+    const int E = MT + w + 1;  // entries in use
+    for (int i = tid; i < E; i += NT) {
         const u64 g = J0 + (u64)i;
         s_h[i] = (g >= 1 && g - 1 < p.total) ? p.h[g - 1] : ~0ull;
+        s_ix[i] = (unsigned short)i;
     }
     if (tid == 0) {
         s_r[0] = p.tile_rec[tile];
@@ -1142,31 +1157,103 @@ __global__ __launch_bounds__(NT) void minimizer_kernel(MinArgs p) {
     __syncthreads();
     const u64 r_lo = s_r[0];
     const u64 r_hi = (s_r[1] + 1 < p.n_rec + 1) ? s_r[1] + 1 : p.n_rec + 1;
+    // the tile's slice of the record table: off[r_lo .. r_hi]
+    // (the search looks at entries r_lo .. r_hi - 1; entry r_hi is read as the end of the last record when it exists)
+    const bool rec_in_lds = r_hi - r_lo <= (u64)M_REC;
+    if (rec_in_lds) {
+        const u64 top_e = r_hi < p.n_rec ? r_hi : p.n_rec;
+        for (u64 q = (u64)tid; r_lo + q <= top_e; q += NT) s_off[q] = p.off[r_lo + q];
+    }
+    // per group: its record, validity, the two hashes outside the inner window (the table overwrites s_h)
+    u64 prevh[MPT], lasth[MPT], gpos[MPT];
+    u32 valid = 0;
+#pragma unroll
+    for (int jj = 0; jj < MPT; jj++) {
+        const int i = tid + jj * NT;
+        prevh[jj] = s_h[i];
+        lasth[jj] = s_h[i + w];
+        gpos[jj] = 0;
+    }
+    __syncthreads();  // s_off complete; s_h read
+#pragma unroll
+    for (int jj = 0; jj < MPT; jj++) {
+        const int i = tid + jj * NT;
+        const u64 j = J0 + (u64)i;
+        if (j >= p.total) continue;
+        u64 rs, nwin;
+        if (rec_in_lds) {
+            u32 lo = 0, hi = (u32)(r_hi - r_lo);  // first entry > j among off[r_lo .. r_hi)
+            while (lo < hi) {
+                const u32 mid = (lo + hi) >> 1;
+                if (s_off[mid] <= j) lo = mid + 1; else hi = mid;
+            }
+            if (lo == 0 || r_lo + lo > p.n_rec) continue;
+            rs = s_off[lo - 1];
+            nwin = s_off[lo] - rs;
+        } else {
+            const u64 ub = upper_bound_u64(p.off, r_lo, r_hi, j);
+            if (ub == 0 || ub > p.n_rec) continue;
+            rs = p.off[ub - 1];
+            nwin = p.off[ub] - rs;
+        }
+        const u64 g = j - rs;
+        if (g + (u64)w > nwin) continue;
+        valid |= 1u << jj;
+        gpos[jj] = g;
+    }
+    // ---- sparse table over s_h[1 ..]: after level t, entry i = leftmost minimum of s_h[i .. i + 2^t) ----
+    const int W1 = w - 1;  // inner window h[g .. g+w-2]
+    int top = 0;
+    while ((2 << top) <= W1) top++;  // 2^top <= W1 < 2^(top+1)   (W1 >= 1 here; w == 1 skips the table)
+    if (W1 >= 1) {
+        for (int t = 0; t < top; t++) {
+            const int d = 1 << t;
+            u64 nv[M_EPT];
+            unsigned short ni[M_EPT];
+#pragma unroll
+            for (int e = 0; e < M_EPT; e++) {
+                const int i = tid + e * NT;
+                nv[e] = ~0ull; ni[e] = 0;
+                if (i < E) {
+                    const u64 a0 = s_h[i];
+                    const unsigned short i0 = s_ix[i];
+                    const bool has = i + d < E;
+                    const u64 a1 = has ? s_h[i + d] : ~0ull;
+                    const unsigned short i1 = has ? s_ix[i + d] : i0;
+                    const bool right = a1 < a0;  // ties: the left one (leftmost minimum)
+                    nv[e] = right ? a1 : a0;
+                    ni[e] = right ? i1 : i0;
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int e = 0; e < M_EPT; e++) {
+                const int i = tid + e * NT;
+                if (i < E) { s_h[i] = nv[e]; s_ix[i] = ni[e]; }
+            }
+            __syncthreads();
+        }
+    }
     u64 val[MPT], apos[MPT];
     u32 keep = 0;
 #pragma unroll
     for (int jj = 0; jj < MPT; jj++) {
         const int i = tid + jj * NT;
-        const u64 j = J0 + (u64)i;
         val[jj] = 0; apos[jj] = 0;
-        if (j >= p.total) continue;
-        const u64 ub = upper_bound_u64(p.off, r_lo, r_hi, j);
-        if (ub == 0 || ub > p.n_rec) continue;
-        const u64 rs = p.off[ub - 1], nwin = p.off[ub] - rs, g = j - rs;
-        if (g + (u64)w > nwin) continue;
-        const u64 last = s_h[i + w];  // h[j + w - 1]
+        if (!((valid >> jj) & 1u)) continue;
+        const u64 g = gpos[jj], last = lasth[jj];
         bool e;
         u64 v, a;
         if (w == 1) {
             e = true; v = last; a = g;
         } else {
-            u64 m = s_h[i + 1];
-            int am = 0;
-            for (int q = 1; q < w - 1; q++) {
-                const u64 x = s_h[i + 1 + q];
-                if (x < m) { m = x; am = q; }
-            }
-            e = (g == 0) || (s_h[i] <= m) || (last < m);
+            // inner window = s_h[i + 1 .. i + W1]: two table entries of length 2^top that cover it
+            const int a0 = i + 1, a1 = i + 1 + W1 - (1 << top);
+            const u64 m0 = s_h[a0], m1 = s_h[a1];
+            const bool right = m1 < m0;
+            const u64 m = right ? m1 : m0;
+            const int am = (int)(right ? s_ix[a1] : s_ix[a0]) - a0;
+            e = (g == 0) || (prevh[jj] <= m) || (last < m);
             v = last < m ? last : m;
             a = last < m ? g + (u64)w - 1 : g + (u64)am;
         }
