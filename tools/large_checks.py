@@ -65,3 +65,42 @@ for lo in range(0, n - 1, step):                          # sortedness in slices
     ok = ok and bool((K[lo + 1:hi] >= K[lo:hi - 1]).all())
 assert ok and xor_all(K) == x0, "sort of > 2^32 keys failed"
 print("sort n=%d ok (%.1f ms, %.2e keys/s)" % (n, ctx.last_call_ms(), n / ctx.last_call_ms() * 1e3))
+# 4. every window of more than 2^32 bases: the rolling strip kernel against the prefix-word kernel (two algorithms),
+#    compared slice by slice; the Scaled sketch of the same bases through both ntHash kernels
+del K
+torch.cuda.empty_cache()
+nb = (1 << 32) + 300_000_007
+chunk = 1 << 28
+bases = torch.empty(nb, dtype=torch.uint8, device=dev)
+lut = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=dev)
+for lo in range(0, nb, chunk):
+    hi = min(nb, lo + chunk)
+    i = torch.arange(lo, hi, dtype=torch.int64, device=dev)
+    w = bench.splitmix64_torch((i >> 5) ^ bench._i64(bench.SEED + 11))
+    bases[lo:hi] = lut[(w >> (2 * (i & 31))) & 3]
+    del i, w
+cuts = sorted(set([0, nb, 1_000_000_007, 1_000_000_030, (1 << 32) - 5, (1 << 32) + 17, 3_333_333_333]))
+off = torch.tensor(cuts, dtype=torch.int64, device=dev)
+outs = []
+for flag in ("1", "0"):
+    os.environ["UKM_WIN_STRIP"] = flag
+    o = torch.empty(nb, dtype=torch.int64, device=dev)
+    r = ctx.encode_kmers(bases, off, 31, canonical=True, out=o)
+    outs.append(r)
+assert outs[0].numel() == outs[1].numel() > (1 << 32)
+same = True
+for lo in range(0, outs[0].numel(), 1 << 30):
+    same = same and bool((outs[0][lo:lo + (1 << 30)] == outs[1][lo:lo + (1 << 30)]).all())
+assert same, "strip window kernel != general kernel beyond 2^32 bases"
+print("encode of %d bases ok: %d windows, strip kernel == general kernel" % (nb, outs[0].numel()))
+del outs, o, r
+os.environ.pop("UKM_WIN_STRIP", None)
+torch.cuda.empty_cache()
+mh = ctx.max_hash(1000)
+sk = []
+for flag in ("1", "0"):
+    os.environ["UKM_NTHASH_STRIP"] = flag
+    sk.append(ctx.nthash(bases, off, 51, canonical=True, max_hash=mh).clone())
+os.environ.pop("UKM_NTHASH_STRIP", None)
+assert sk[0].numel() == sk[1].numel() > 8_000_000 and bool((sk[0] == sk[1]).all())
+print("Scaled sketch of %d bases ok: %d hashes, strip kernel == general kernel" % (nb, sk[0].numel()))
