@@ -351,7 +351,9 @@ __global__ __launch_bounds__(NT_) SORT_WAVES_ATTR void onesweep_kernel(PassArgs<
             }
             t -= used;
             if (!done && used < SORT_LB_W) {  // hit an unpublished tile: back off, then re-read from it
-                if (++spins > LB_SPIN_LIMIT) { timed_out = true; break; }
+                // (ticketed tile ids: every predecessor is running, the wait always ends — no watchdog, the host
+                //  does not look at the flag in that mode)
+                if (!TICKET && ++spins > LB_SPIN_LIMIT) { timed_out = true; break; }
                 __builtin_amdgcn_s_sleep(4);
             }
         }
