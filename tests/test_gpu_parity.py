@@ -393,9 +393,8 @@ def test_windows_strip_kernel_long_records(ctx, O, L, monkeypatch, force):
     """The rolling strip kernel for every window of long records (count.go's per-record k-mer loop over a
     chromosome): codes and ntHash, every k phase, canonical / forward, ragged records incl. empty and
     shorter-than-k ones, record ends inside a row block and inside a strip's warm-up, degenerate and lower-case
-    bases, several tiles and strip lengths.  force=1 also runs it on record mixes the library would hand to the
-    general kernel; None = the library's own choice (9e6 bases of long records: the strip kernel for k <= 32, the
-    general kernel for larger k, which switches at 1.7e7 bases)."""
+    bases, several tiles and strip lengths.  force=1 runs it whatever the size; None = the library's own choice (9e6
+    bases: the strip kernel for k <= 32, the general kernel for larger k, which switches at 1.7e7 bases)."""
     if force is None:
         monkeypatch.delenv("UKM_WIN_STRIP", raising=False)
     else:
@@ -410,7 +409,7 @@ def test_windows_strip_kernel_long_records(ctx, O, L, monkeypatch, force):
     long_cuts = np.array([0, 1_000_003, 1_000_003, 1_000_020, 2_500_001, 4_499_990, n], dtype=np.uint64)
     ragged = np.array([0, 0, 3, 40, 41, 333, 5000, 5000, 65_535, 65_536, 65_543, 65_600, 262_144, 262_145, 700_000,
                        1_199_950, 3_000_000, n - 7, n], dtype=np.uint64)
-    cases = [long_cuts] + ([ragged] if force else [])
+    cases = [long_cuts, ragged]
     for Ls in (None, "64", "128"):
         if Ls is None:
             monkeypatch.delenv("UKM_WIN_STRIP_L", raising=False)

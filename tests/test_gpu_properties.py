@@ -98,8 +98,9 @@ def test_sort_is_a_sorted_permutation(env):
     assert torch.equal(ctx.unique(U, mode=lib.UNIQUE), U)         # idempotent
 
 
-def test_encode_and_hash_window_counts(env):
+def test_encode_and_hash_window_counts(env, monkeypatch):
     torch, bench, lib, ctx, A, B = env
+    monkeypatch.delenv("UKM_WIN_STRIP", raising=False)
     nb = 40_000_000
     i = torch.arange(nb, dtype=torch.int64, device=A.device)
     w = bench.splitmix64_torch((i >> 5) ^ bench._i64(bench.SEED))
@@ -121,6 +122,14 @@ def test_encode_and_hash_window_counts(env):
     assert bool((((first[:-1] << 2) & mask) >> 2 == (first[1:] >> 2)).all())
     h = ctx.nthash(bases, reads, k, canonical=True)
     assert h.numel() == expect
+    # 150-bp reads: the library's choice (the rolling strip kernel since round 2) against the general kernel
+    h51 = ctx.nthash(bases, reads, 51, canonical=False)
+    monkeypatch.setenv("UKM_WIN_STRIP", "0")
+    assert torch.equal(ctx.encode_kmers(bases, reads, k, canonical=True), canon)
+    assert torch.equal(ctx.nthash(bases, reads, k, canonical=True), h)
+    assert torch.equal(ctx.nthash(bases, reads, 51, canonical=False), h51)
+    monkeypatch.delenv("UKM_WIN_STRIP", raising=False)
+    del h51
     mh = ctx.max_hash(100)
     hs = ctx.nthash(bases, reads, k, canonical=True, max_hash=mh)
     # the fused Scaled filter keeps exactly the hashes <= maxHash, in window order

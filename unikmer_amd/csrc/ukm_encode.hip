@@ -773,7 +773,7 @@ int run_strip_filter(ukm_ctx *c, const u8 *bases, const u64 *rec_off, u64 n_rec,
 // Not for circular records; more than SW_REC records under one tile -> flag, the caller runs window_kernel.
 constexpr int SW_NT = 256;
 constexpr int SW_NWV = SW_NT / 64;
-constexpr int SW_REC = 126;   // records one tile may touch
+constexpr int SW_REC = 254;   // records one tile may touch
 constexpr int SW_B = 16;      // values per row = one 128-byte line
 constexpr int SW_ROW = 17;    // u64 per LDS row: 16 values + 1 pad (bank spread)
 #ifndef SW_ABL
@@ -800,7 +800,7 @@ __global__ __launch_bounds__(SW_NT) __attribute__((amdgpu_waves_per_eu(HASH ? 3 
     __shared__ __attribute__((aligned(16))) uint4 s_tout[HASH ? 256 : 1];
     __shared__ u8 s_lut[HASH ? 1 : 256];
     __shared__ u64 s_ro[SW_REC + 2];
-    __shared__ u64 s_gap[SW_REC + 2];
+    __shared__ u32 s_gap[SW_REC + 2];  // gap of a record minus the gap of the tile's first record (< tile positions + k per record)
     __shared__ u64 s_row[SW_NWV][64 * SW_ROW];
     __shared__ u64 s_desc[SW_NWV][64];
     const int tid = (int)threadIdx.x, lane = lane_id(), wave = tid >> 6;
@@ -825,15 +825,16 @@ __global__ __launch_bounds__(SW_NT) __attribute__((amdgpu_waves_per_eu(HASH ? 3 
         if (tid == 0) atomicOr((unsigned long long *)&p.result[1], 4ull);
         return;
     }
+    const u64 gap_first = p.rec_off[r0] - p.out_off[r0];  // (uniform: scalar loads)
     for (u64 j = (u64)tid; j <= nr; j += SW_NT) {
         const u64 ro = p.rec_off[r0 + j];
         s_ro[j] = ro;
-        s_gap[j] = ro - p.out_off[r0 + j];
+        s_gap[j] = (u32)((ro - p.out_off[r0 + j]) - gap_first);
     }
     __syncthreads();
     // output index of the window that ends at e (inside record r) = e + 1 - k - gap[r]; shift the strips so that it
     // is a multiple of 16 at every row start of the tile's first record
-    const u32 sh = (u32)(P0 + 1 - (u64)k - s_gap[0]) & (u32)(SW_B - 1);
+    const u32 sh = (u32)(P0 + 1 - (u64)k - gap_first) & (u32)(SW_B - 1);
     const long long s0 = (long long)P0 - (long long)sh + (long long)tid * L;  // first END position of this lane's rows
     const u64 e_lo = s0 < (long long)P0 ? P0 : (u64)s0;                       // the lane emits END positions [e_lo, e_hi)
     const u64 e_hi = tid == SW_NT - 1 ? P0 + TS : (u64)(s0 + L);
@@ -848,7 +849,7 @@ __global__ __launch_bounds__(SW_NT) __attribute__((amdgpu_waves_per_eu(HASH ? 3 
             if (s_ro[mid] <= e_lo) lo = mid + 1; else hi = mid;
         }
         if (lo == 0 || lo > (u32)nr) dead = true;
-        else { j = lo - 1; rec_start = s_ro[j]; rec_end = s_ro[j + 1]; gap = s_gap[j]; }
+        else { j = lo - 1; rec_start = s_ro[j]; rec_end = s_ro[j + 1]; gap = gap_first + (u64)s_gap[j]; }
         if (dead) { rec_start = ~0ull; rec_end = 0; }
     }
     const bool canon = p.canonical != 0;
@@ -866,7 +867,7 @@ __global__ __launch_bounds__(SW_NT) __attribute__((amdgpu_waves_per_eu(HASH ? 3 
 #define SW_NEXT_RECORD()                                                                  \
     do {                                                                                  \
         if (j + 1 >= (u32)nr) { dead = true; rec_start = ~0ull; rec_end = 0; }            \
-        else { j++; rec_start = rec_end; rec_end = s_ro[j + 1]; gap = s_gap[j]; }         \
+        else { j++; rec_start = rec_end; rec_end = s_ro[j + 1]; gap = gap_first + (u64)s_gap[j]; } \
     } while (0)
     for (int c0 = 0; c0 < nsteps; c0 += 64) {
         u32 iw[17];
@@ -976,7 +977,13 @@ int run_strip_windows(ukm_ctx *c, bool hash, const u8 *bases, const u64 *rec_off
     // 1.6e7 bases: codes 0.042 ms against 0.060 ms for the general kernel); short records spend their time in the
     // value-by-value path of rows that touch a record boundary
     const u64 min_bases = (k <= 32) ? (1ull << 23) : (1ull << 24);
-    if (force != 1 && (total_bases < min_bases || n_rec * 32768ull > total_bases)) return UKM_OK;
+    // Records: the kernel also wins on short ones — 1e8 bases of 150-bp reads: codes 0.29 ms against 0.43 ms for the
+    // general kernel, ntHash k = 51 0.32 against 0.51 ms (every wave then has rows in the value-by-value path, still
+    // fewer instructions per window than the general kernel's 125) — as long as a tile's records fit its table (254
+    // per 256 x L positions, else the call falls back after one wasted launch): average length >= 80 bases for
+    // L = 64, >= 140 for L = 128.
+    const u64 min_avg = (k <= 32) ? 80 : 140;
+    if (force != 1 && (total_bases < min_bases || n_rec * min_avg > total_bases)) return UKM_OK;
     // several rounds of workgroups per CU matter more than the k - 1 warm-up steps per strip (measured at 1e8
     // bases, codes: L = 64 / 128 / 256 / 512 -> 0.178 / 0.185 / 0.21 / 0.22 ms; ntHash k = 51: 0.242 / 0.230 / 0.244)
     // (1e9 bases: codes 1.71 / 1.84 / 1.94 ms, ntHash k = 51 2.23 / 1.89 / 1.96 ms: short strips keep a wave's 64 output
