@@ -146,10 +146,15 @@ __device__ __forceinline__ u64 lb_resolve(u64 *status, u64 tile, u64 agg, int la
     u32 spins = 0;
     bool dead = false;
     LbHop hop;
+#ifdef LB_OPTIMISTIC
+    bool skip_poll = true;  // first hop: read the window straight away (one round trip when the predecessor is there)
+#else
+    const bool skip_poll = false;
+#endif
     for (;;) {
         // wait for the nearest not-yet-counted predecessor with a single-word poll
         int ok = 1;
-        if (lane == 0) {
+        if (lane == 0 && !skip_poll) {
             while ((lb_load(&status[base * LB_STRIDE]) >> 62) == 0) {
                 // the watchdog is for tile ids taken from blockIdx; with ticketed ids (timed_out == nullptr)
                 // every predecessor is running and the wait always ends
@@ -163,6 +168,9 @@ __device__ __forceinline__ u64 lb_resolve(u64 *status, u64 tile, u64 agg, int la
         if (r == 1) break;
         if (r == 0) base -= 64 * LB_W;
         else base -= 64 * (-r - 1);
+#ifdef LB_OPTIMISTIC
+        skip_poll = (r == 0);  // a complete window: try the next one directly; a hole: poll first
+#endif
     }
     if (dead && timed_out) *timed_out = true;
     // publish even after a timeout so that successors drain quickly

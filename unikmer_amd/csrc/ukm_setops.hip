@@ -354,28 +354,33 @@ __device__ __forceinline__ bool tile_is_fast(const SetopArgs &p, const TileGeom 
            g.b0 + (u64)g.nb_t + 5 <= p.nb;
 }
 
+// The same tile, global memory -> LDS without a register round trip (gfx950 LDS-DMA, `global_load_lds_dwordx4`): the
+// LDS image is lane-linear (wave-uniform base + 16 bytes per lane), which is exactly the staging layout above; the
+// source address is per lane.  Saves the 40 staging VGPRs and the ds_write_b128 pass of the tile.
 template <int NTH, int VT>
-__device__ __forceinline__ void tile_load_fast(const SetopArgs &p, const TileGeom &g, int tid,
-                                               u64 (&rk)[2 * TilePairs<NTH, VT>::NP]) {
+__device__ __forceinline__ void tile_dma_fast(const SetopArgs &p, const TileGeom &g, int tid, u64 *s_keys) {
     constexpr int NP = TilePairs<NTH, VT>::NP;
     constexpr int SLOTS = NTH * VT + 8;
+    typedef __attribute__((address_space(3))) void lds_void;
+    typedef __attribute__((address_space(1))) const void glb_void;
     const u64 *pa = p.a + g.a0 - 1 - g.sa0;  // slot s of region A is pa[s]
     const u64 *pb = p.b + g.b0 - 1 - g.sb0;  // slot s of region B is pb[s]
-    const u64 *safe = p.result;
+    const int wbase = __builtin_amdgcn_readfirstlane(tid & ~63);
 #pragma unroll
     for (int j = 0; j < NP; j++) {
         const int s0 = 2 * (tid + j * NTH);
         const u64 *src = (s0 < g.split ? pa : pb) + s0;
-        if (2 * (NTH - 1 + j * NTH) + 1 >= SLOTS) src = (s0 < SLOTS) ? src : safe;  // last round only (compile time)
-        const ulonglong2 q = *reinterpret_cast<const ulonglong2 *>(src);
-        rk[2 * j] = q.x;
-        rk[2 * j + 1] = q.y;
+        u64 *dst = s_keys + 2 * (wbase + j * NTH);  // wave-uniform; lane l lands 16 l bytes behind it
+        if (2 * (NTH - 1 + j * NTH) + 1 >= SLOTS) {  // last round only (compile time): lanes beyond the tile stay off
+            if (s0 < SLOTS) __builtin_amdgcn_global_load_lds((glb_void *)src, (lds_void *)dst, 16, 0, 0);
+        } else {
+            __builtin_amdgcn_global_load_lds((glb_void *)src, (lds_void *)dst, 16, 0, 0);
+        }
     }
 }
 
 template <int NTH, int VT>
-__device__ __forceinline__ u32 tile_check_order_fast(const TileGeom &g, int tid,
-                                                     const u64 (&rk)[2 * TilePairs<NTH, VT>::NP], const u64 *s_keys) {
+__device__ __forceinline__ u32 tile_check_order_lds(const TileGeom &g, int tid, const u64 *s_keys) {
     constexpr int NP = TilePairs<NTH, VT>::NP;
     constexpr int SLOTS = NTH * VT + 8;
     bool unsorted = false, dup = false;
@@ -384,7 +389,9 @@ __device__ __forceinline__ u32 tile_check_order_fast(const TileGeom &g, int tid,
         const int s0 = 2 * (tid + j * NTH);
         bool c0 = (s0 != 0) & (s0 != g.split), c1 = true;  // slot s0 - 1 belongs to the same region
         if (2 * (NTH - 1 + j * NTH) + 1 >= SLOTS) { c1 = s0 < SLOTS; c0 &= c1; }
-        const u64 pk = s_keys[s0 > 0 ? s0 - 1 : 0], k0 = rk[2 * j], k1 = rk[2 * j + 1];
+        const int sr = c1 ? s0 : 0;
+        const ulonglong2 q = *reinterpret_cast<const ulonglong2 *>(s_keys + sr);
+        const u64 pk = s_keys[sr > 0 ? sr - 1 : 0], k0 = q.x, k1 = q.y;
         unsorted |= (c0 & (pk > k0)) | (c1 & (k0 > k1));
         dup |= (c0 & (pk == k0)) | (c1 & (k0 == k1));
     }
@@ -572,13 +579,12 @@ __device__ __forceinline__ void tile_flush(const SetopArgs &p, int tid, u64 base
 //   a predecessor fails to publish within LB_SPIN_LIMIT polls the kernel raises FLAG_TIMEOUT
 //   and the host re-runs with TICKET = true, where tile ids come from an atomic counter and
 //   forward progress holds for any dispatch order.
+// Plain keys: two 512-thread workgroups per CU (LDS) = 4 waves per SIMD, so the register budget is 128; the
+// allocator is told so (it budgets 256 for a 512-thread workgroup by itself and came out at 129 with the two load
+// paths).  Instantiations with taxids / ranks keep the default budget.
 template <int OP, bool TAX, bool RANK, bool TICKET, int NTH, int VT>
-#ifndef SETOP_WAVES_PER_EU
-#define SETOP_WAVES_ATTR
-#else
-#define SETOP_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(SETOP_WAVES_PER_EU, SETOP_WAVES_PER_EU)))
-#endif
-__global__ __launch_bounds__(NTH) SETOP_WAVES_ATTR void setop_tile_kernel(SetopArgs p) {
+__global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu((TAX || RANK) ? 2 : 4, (TAX || RANK) ? 8 : 4)))
+void setop_tile_kernel(SetopArgs p) {
     constexpr int TILE = NTH * VT;
     constexpr int SLOTS = TILE + 8;
     constexpr int NP = TilePairs<NTH, VT>::NP;
@@ -602,21 +608,24 @@ __global__ __launch_bounds__(NTH) SETOP_WAVES_ATTR void setop_tile_kernel(SetopA
     setop_resolve_sizes(p, (u64)TILE);
     if (tile >= p.ntiles) return;  // chained call: the launch covers the upper bound of |A|
     const TileGeom g = tile_geom<NTH, VT>(p, tile);
-    u32 bad;
-    {
+    u32 bad = 0;
+    bool fast = false;  // workgroup-uniform
+#ifndef SETOP_NO_FAST
+    if (!TAX && !RANK) fast = tile_is_fast<NTH, VT>(p, g);
+#endif
+    if (fast) {
+        // interior tile of plain keys: LDS-DMA staging; its order check runs after the aggregate is published (below)
+        tile_dma_fast<NTH, VT>(p, g, tid, s_keys);
+        __syncthreads();  // hipcc puts the vmcnt(0) for the LDS-DMA in front of the barrier
+        PH(1);
+    } else {
         u64 rk[2 * NP];
         u32 rt[2 * NP], rr[2 * NP];
-        bool fast = false;
-#ifndef SETOP_NO_FAST
-        if (!TAX && !RANK) fast = tile_is_fast<NTH, VT>(p, g);  // workgroup-uniform
-#endif
-        if (fast) tile_load_fast<NTH, VT>(p, g, tid, rk);
-        else tile_load<TAX, RANK, NTH, VT>(p, g, tid, rk, rt, rr);
+        tile_load<TAX, RANK, NTH, VT>(p, g, tid, rk, rt, rr);
         tile_to_lds<TAX, RANK, NTH, VT>(tid, rk, rt, rr, s_keys, s_tax, s_rank);
         __syncthreads();
         PH(1);
-        if (fast) bad = tile_check_order_fast<NTH, VT>(g, tid, rk, s_keys);
-        else bad = tile_check_order<RANK, NTH, VT>(g, tid, rk, rr, s_keys, s_rank);
+        bad = tile_check_order<RANK, NTH, VT>(g, tid, rk, rr, s_keys, s_rank);
     }
     u64 ok[VT];
     u32 ot[VT];
@@ -630,9 +639,32 @@ __global__ __launch_bounds__(NTH) SETOP_WAVES_ATTR void setop_tile_kernel(SetopA
 #endif
     PH(2);
     u32 tile_total;
-    const u32 excl = block_excl_scan_u32<NTH>((u32)__popc(mask), s_scan, &tile_total);
-    // (the scan's barriers also guarantee every thread finished reading the tile from LDS)
-    if (OP != UKM_OP_MERGE_INTERNAL && tid == 0) lb_publish(p.status, tile, (u64)tile_total);
+    // The block scan, opened up: the tile's aggregate is known (and published) behind its FIRST barrier; the order
+    // check of an interior tile's inputs -- which nothing downstream needs -- runs between the two barriers, i.e.
+    // AFTER the publication instead of in front of the merge.  Successors see the aggregate ~1 k cycles earlier
+    // relative to this tile's own look-back, which is what their look-back waits for (round 3: union 5.0 -> 4.8 ms,
+    // inter 4.15 -> 4.0 ms at 2 x 1e9).  Unsorted input only makes the merge emit garbage that the flag voids.
+    u32 excl;
+    {
+        constexpr int NW = NTH / 64;
+        const u32 v = (u32)__popc(mask);
+        const int lane = lane_id(), wave = tid >> 6;
+        const u32 incl = wave_incl_scan_u32(v);
+        if (lane == 63) s_scan[wave] = incl;
+        __syncthreads();
+        u32 wbase = 0, tot = 0;
+#pragma unroll
+        for (int w = 0; w < NW; w++) {
+            const u32 t = s_scan[w];
+            if (w < wave) wbase += t;
+            tot += t;
+        }
+        tile_total = tot;
+        excl = wbase + incl - v;
+        if (OP != UKM_OP_MERGE_INTERNAL && tid == 0) lb_publish(p.status, tile, (u64)tile_total);
+        if (fast) bad |= tile_check_order_lds<NTH, VT>(g, tid, s_keys);
+        __syncthreads();  // every thread has finished reading the tile from LDS; s_scan may be reused
+    }
 #ifndef SETOP_ABL_NOCOMPACT
     tile_compact<TAX, VT>(excl, mask, ok, ot, s_keys, s_tax);
 #endif
