@@ -214,6 +214,20 @@ int ukm_comm_info(ukm_ctx *ctx, int *nranks, int *rank);
 int ukm_prefix_splitters(int key_bits, int nranks, uint64_t *splitters);
 int ukm_shard_exchange(ukm_ctx *ctx, const uint64_t *keys, const uint32_t *taxids, const uint64_t *send_counts,
                        uint64_t *out_keys, uint32_t *out_taxids, uint64_t out_cap, uint64_t *recv_counts, uint64_t *n_out);
+/*      Capacity is decided COLLECTIVELY: the slice sizes travel together with every rank's out_cap, and either all
+ *      ranks exchange or all ranks return UKM_ERR_CAPACITY (n_out = what this rank would have received), so a short
+ *      buffer on one rank can never leave its peers blocked in RCCL.  ukm_shard_plan is that decision as a pure host
+ *      function (all = [source rank][nranks slice sizes | out_cap of the source rank], the gathered matrix).
+ *      Hosts that move many files use the two-step form: ukm_shard_counts (send_counts[nfiles][nranks] ->
+ *      recv_counts[nfiles][nranks], ONE all-gather and host round trip for all files; size the receive buffers
+ *      from it), then ukm_shard_exchange_known per file, which has no gather and no host round trip in front of the
+ *      transfers (own slice: device-to-device copy; peers: one ncclSend / ncclRecv group on the context's stream; like
+ *      every entry point the call returns when its stream work is done). */
+int ukm_shard_plan(int nranks, int rank, const uint64_t *all, uint64_t *recv_counts, uint64_t *n_out);
+int ukm_shard_counts(ukm_ctx *ctx, const uint64_t *send_counts, int nfiles, uint64_t *recv_counts);
+int ukm_shard_exchange_known(ukm_ctx *ctx, const uint64_t *keys, const uint32_t *taxids, const uint64_t *send_counts,
+                             const uint64_t *recv_counts, uint64_t *out_keys, uint32_t *out_taxids, uint64_t out_cap,
+                             uint64_t *n_out);
 
 #ifdef __cplusplus
 }

@@ -4,6 +4,7 @@ import ctypes as C
 import os
 import re
 
+import numpy as np
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -32,6 +33,44 @@ def test_pure_host_entry_points(lib):
     assert L.ukm_max_hash(15) == 1229782938247303424
     assert L.ukm_common_threshold(10, 0.75, 0) == 7            # common.go:93-105 (truncation)
     assert L.ukm_common_threshold(10, 1.0, 3) == 3
+
+
+def test_shard_plan_capacity_is_decided_collectively(lib):
+    """ukm_shard_plan (the capacity decision inside ukm_shard_exchange): every rank evaluates the same predicate over
+    ALL ranks, so a rank whose buffer is too small makes EVERY rank return UKM_ERR_CAPACITY before anything is
+    posted -- a local failure on one rank would leave its peers blocked in their grouped Send/Recv (round-2 advice).
+    Skewed counts: rank 1 holds nothing but owns the dense prefix range."""
+    W = 2
+    big = 1_000_000
+    # [source][dest 0, dest 1 | capacity of source]: rank 0 sends 10 to itself and 1e6 to rank 1; rank 1 sends nothing
+    ok = np.array([[10, big, 10], [0, 0, big]], dtype=np.uint64)
+    for me, want in ((0, [10, 0]), (1, [big, 0])):
+        rc, n = lib.Context.shard_plan(W, me, ok)
+        assert rc.tolist() == want and n == sum(want)
+    # rank 1 sized its buffer n_local x W = 0 -> max(1, 0) = 1: BOTH ranks must fail, and rank 1 learns what it needs
+    short = ok.copy()
+    short[1, W] = 1
+    for me in (0, 1):
+        with pytest.raises(lib.CapacityError) as e:
+            lib.Context.shard_plan(W, me, short)
+        assert "rank 1" in str(e.value)
+    L = lib.load()
+    rcv = np.zeros(W, dtype=np.uint64)
+    n = C.c_uint64()
+    assert L.ukm_shard_plan(W, 1, short.ctypes.data, rcv.ctypes.data, C.byref(n)) == lib.ERR_CAPACITY
+    assert n.value == big and rcv.tolist() == [big, 0]
+    assert L.ukm_shard_plan(0, 0, short.ctypes.data, rcv.ctypes.data, C.byref(n)) == lib.ERR_INVALID
+    # 8 ranks, uniform: everybody receives W x 5
+    W = 8
+    g = np.full((W, W + 1), 5, dtype=np.uint64)
+    g[:, W] = 40
+    for me in range(W):
+        rc, n = lib.Context.shard_plan(W, me, g)
+        assert n == 40 and rc.tolist() == [5] * W
+    g[3, W] = 39
+    for me in range(W):
+        with pytest.raises(lib.CapacityError):
+            lib.Context.shard_plan(W, me, g)
 
 
 def test_no_gpu_fails_loudly(lib):

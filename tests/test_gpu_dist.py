@@ -125,10 +125,7 @@ def test_sharded_ops_two_ranks_real_context():
     assert np.array_equal(cat("distinct"), np.unique(allx))
 
 
-def test_bench_two_ranks_incl_exchange():
-    """bench.py's N > 1 path end to end (launched exactly as the driver launches it), two ranks sharing the one
-    GPU over gloo: the pre-partitioned `value`, the bare all-to-all-v and `value_incl_exchange` (file-sharded
-    start -> dist.sharded_setop) are all produced and agree on the result sizes."""
+def _run_bench_two_ranks(extra):
     import json
     import subprocess
     import sys
@@ -136,15 +133,39 @@ def test_bench_two_ranks_incl_exchange():
     env = dict(os.environ, UKM_BENCH_ONE_GPU="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
-           "--set-size", "1e6", "--cpu-sample", "0"]
+           "--set-size", "1e6", "--cpu-sample", "0"] + extra
     r = subprocess.run(cmd, capture_output=True, text=True, env=env, cwd=root, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
-    res = json.loads(line)
+    return json.loads(line)
+
+
+def test_bench_two_ranks_incl_exchange():
+    """bench.py's N > 1 path end to end (launched exactly as the driver launches it), two ranks sharing the one
+    GPU over gloo.  `value` is the END-TO-END figure (file-sharded start -> each input exchanged once ->
+    dist.redistribute -> union + inter), `value_prepartitioned` the same job without the exchange; both legs and the
+    bare all-to-all-v are produced and agree on the result sizes (bench.py asserts that)."""
+    res = _run_bench_two_ranks([])
     assert res["n_gpus"] == 2 and res["value"] > 0 and res["scaling"] == "weak"
     assert "error" not in res.get("exchange", {}), res.get("exchange")
-    assert res["value_incl_exchange"] > 0 and res["incl_exchange"]["steps"] >= 1
+    assert res["value"] == res["value_incl_exchange"] == res["incl_exchange"]["value"]
+    assert res["value_is"].startswith("end to end")
+    assert res["value_prepartitioned"] > 0 and res["ms_per_step"] == res["incl_exchange"]["ms_per_step"]
+    assert res["incl_exchange"]["steps"] == 2 and res["config"]["per_gpu_set_size"] == 1_000_000
+    assert res["config"]["global_set_size"] == 2_000_000
     assert res["roofline"]["frac"] > 0 and res["cpu_baseline"] is None
+    assert res["roofline"]["traffic"] is None or res["roofline"]["traffic_from_profile"]["note"].startswith("profile-derived")
+
+
+def test_bench_two_ranks_strong_scaling_and_no_exchange():
+    """--scaling strong: --set-size is the GLOBAL set size (the metric's wording), each rank holds 1/N of it;
+    --no-exchange: the line says that `value` is the pre-partitioned figure."""
+    res = _run_bench_two_ranks(["--scaling", "strong"])
+    assert res["scaling"] == "strong" and res["config"]["per_gpu_set_size"] == 500_000
+    assert res["config"]["global_set_size"] == 1_000_000 and res["value"] == res["value_incl_exchange"]
+    res = _run_bench_two_ranks(["--no-exchange"])
+    assert "value_incl_exchange" not in res and res["value"] == res["value_prepartitioned"]
+    assert res["value_is"].startswith("PRE-PARTITIONED")
 
 
 def test_c_abi_rccl_exchange_one_rank():
@@ -173,6 +194,28 @@ def test_c_abi_rccl_exchange_one_rank():
     assert dout.is_cuda and np.array_equal(dout.cpu().numpy().view(np.uint64), keys)
     out, _, rc = ctx.shard_exchange(np.empty(0, np.uint64), [0])
     assert len(out) == 0 and rc.tolist() == [0]
+    # the two-step form: sizes of several files in one gather, then exchanges that neither gather nor synchronise
+    rcs = ctx.shard_counts([[len(keys)], [7], [0]])
+    assert rcs.tolist() == [[len(keys)], [7], [0]]
+    out, out_t, rc = ctx.shard_exchange(keys, [len(keys)], tax, recv_counts=rcs[0])
+    assert np.array_equal(out, keys) and np.array_equal(out_t, tax)
+    # the one-call form (gather of sizes + capacities, collective decision): too small a buffer is an error on all ranks
+    L = lib.load()
+    import ctypes as C
+    small = np.empty(10, dtype=np.uint64)
+    rcv = np.zeros(1, dtype=np.uint64)
+    sc = np.array([len(keys)], dtype=np.uint64)
+    m = C.c_uint64()
+    assert L.ukm_shard_exchange(ctx.h, keys.ctypes.data, None, sc.ctypes.data, small.ctypes.data, None, 10, rcv.ctypes.data,
+                                C.byref(m)) == lib.ERR_CAPACITY
+    assert m.value == len(keys)
+    full = np.empty(len(keys), dtype=np.uint64)
+    assert L.ukm_shard_exchange(ctx.h, keys.ctypes.data, None, sc.ctypes.data, full.ctypes.data, None, len(full),
+                                rcv.ctypes.data, C.byref(m)) == 0
+    assert m.value == len(keys) and np.array_equal(full, keys)
+    # known counts with a short buffer: the rank still takes part (drains into workspace) and reports the error after
+    assert L.ukm_shard_exchange_known(ctx.h, keys.ctypes.data, None, sc.ctypes.data, sc.ctypes.data, small.ctypes.data, None,
+                                      10, C.byref(m)) == lib.ERR_CAPACITY
     # the library's splitters are dist.py's
     for bits, world in ((62, 8), (42, 3), (64, 4), (2, 5)):
         assert ctx.prefix_splitters(bits, world).tolist() == ud.prefix_splitters(bits, world)[:-1]

@@ -1,0 +1,206 @@
+"""BASELINE.json's configurations at their FULL sizes on one MI355X (round-2 review: the full-size runs were only
+checked for sortedness).  The CPU oracle cannot process 1e9..1e10 records in test time, so each test combines
+
+  * size-independent identities over the WHOLE output (inclusion-exclusion, XOR checksum of checksums, strict order,
+    rank consistency between the union and the intersection),
+  * bit-exact comparison of 1e6-record WINDOWS cut from both ends and the middle of the outputs with the oracle run on
+    the matching slices of the inputs, and
+  * equality with an independent device computation of the same result (torch boolean algebra on the generator's
+    membership bits; a chain of 2-way kernels against the k-way kernel; the prefix-XOR window kernel against the rolling
+    strip kernel).
+"""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+pytestmark = pytest.mark.gpu
+
+W = 1_000_000  # records per oracle-checked window
+
+
+@pytest.fixture(scope="module")
+def env():
+    import torch
+    import bench
+    from unikmer_amd import lib
+    from oracle import oracle
+    dev = torch.device("cuda", 0)
+    ctx = lib.Context(0, stream=torch.cuda.current_stream(dev).cuda_stream)
+    return torch, bench, lib, ctx, oracle, dev
+
+
+def _xor(torch, t):
+    x = t
+    while x.numel() > 1:
+        if x.numel() & 1:
+            x = torch.cat([x, torch.zeros(1, dtype=x.dtype, device=x.device)])
+        h = x.numel() // 2
+        x = x[:h] ^ x[h:]
+    return int(x.item()) if x.numel() else 0
+
+
+def _strict(t):
+    return bool((t[1:] > t[:-1]).all())
+
+
+def _np(t):
+    return t.cpu().numpy().view(np.uint64)
+
+
+def _lower(torch, S, v):
+    """number of elements of the sorted int64 tensor S (codes < 2^63) below the python int v"""
+    return int(torch.searchsorted(S, torch.tensor([v], dtype=torch.int64, device=S.device)).item())
+
+
+def test_metric_config_2x1e9_full_size(env):
+    """BASELINE metric: union + inter (+ diff) of two sorted k=31 sets of 1e9 codes, bench.py's generator."""
+    torch, bench, lib, ctx, O, dev = env
+    n = 1_000_000_000
+    A, B = bench.gen_sets_device((4 * n + 2) // 3, 32, 0, bench.SEED, dev)
+    na, nb = A.numel(), B.numel()
+    out_u = torch.empty(na + nb, dtype=torch.int64, device=dev)
+    out_i = torch.empty(min(na, nb), dtype=torch.int64, device=dev)
+    U = ctx.setop2(lib.OP_UNION, A, B, out=out_u)
+    I = ctx.setop2(lib.OP_INTER, A, B, out=out_i)
+    nu, ni = U.numel(), I.numel()
+    assert nu + ni == na + nb                                   # inclusion-exclusion
+    assert _strict(U) and _strict(I)
+    xa, xb, xu, xi = (_xor(torch, t) for t in (A, B, U, I))
+    assert xu == xa ^ xb ^ xi                                   # checksum of checksums
+    # windows at both ends and in the middle: the oracle on the matching input slices, and the window's RANK in the
+    # output from the inputs (|{u in U: u < v}| = |{a < v}| + |{b < v}| - |{i in I: i < v}|)
+    for start in (0, nu // 2 - W // 2, nu - W):
+        win = U[start:start + W]
+        lo, hi = int(win[0].item()), int(win[-1].item())
+        a0, a1 = _lower(torch, A, lo), _lower(torch, A, hi + 1)
+        b0, b1 = _lower(torch, B, lo), _lower(torch, B, hi + 1)
+        assert np.array_equal(_np(win), O.union([_np(A[a0:a1]), _np(B[b0:b1])])), start
+        assert start == a0 + b0 - _lower(torch, I, lo), start
+    for start in (0, ni // 2 - W // 2, ni - W):
+        win = I[start:start + W]
+        lo, hi = int(win[0].item()), int(win[-1].item())
+        a0, a1 = _lower(torch, A, lo), _lower(torch, A, hi + 1)
+        b0, b1 = _lower(torch, B, lo), _lower(torch, B, hi + 1)
+        assert np.array_equal(_np(win), O.inter([_np(A[a0:a1]), _np(B[b0:b1])])), start
+        # every element of I below the window is an element of A and of B below it, and U accounts for the rest
+        assert start == a0 + b0 - _lower(torch, U, lo), start
+    # diff reuses the union buffer
+    del U
+    D = ctx.setop2(lib.OP_DIFF, A, B, out=out_u)
+    nd = D.numel()
+    assert nd == na - ni and _strict(D)
+    assert _xor(torch, D) == xa ^ xi
+    for start in (0, nd // 2 - W // 2, nd - W):
+        win = D[start:start + W]
+        lo, hi = int(win[0].item()), int(win[-1].item())
+        a0, a1 = _lower(torch, A, lo), _lower(torch, A, hi + 1)
+        b0, b1 = _lower(torch, B, lo), _lower(torch, B, hi + 1)
+        assert np.array_equal(_np(win), O.diff([_np(A[a0:a1]), _np(B[b0:b1])])), start
+        assert start == a0 - _lower(torch, I, lo), start
+
+
+def test_config3_union_of_100_files_x_1e8_full_size(env):
+    """BASELINE config 3 on one GPU: 100 sorted files of ~1e8 codes drawn (p = 0.5) from one universe of 2e8.
+    The k-way streaming union must equal (a) the universe elements that are in at least one file, computed with torch
+    from the generator's membership bits, and (b) a chain of 99 two-way unions through the tile kernel."""
+    torch, bench, lib, ctx, O, dev = env
+    nfiles, per = 100, 100_000_000
+    nu = 2 * per
+    j = torch.arange(nu, dtype=torch.int64, device=dev)
+    Uv = torch.cumsum(1 + (bench.splitmix64_torch(j ^ bench._i64(bench.SEED)) & ((1 << 32) - 1)), 0)
+    files = []
+    anym = torch.zeros(nu, dtype=torch.bool, device=dev)
+    for f in range(nfiles):
+        m = (bench.splitmix64_torch(j ^ bench._i64(bench.SEED + 1000 * (f + 1))) & 1) == 1
+        files.append(Uv[m])
+        anym |= m
+    del j, m
+    total = sum(x.numel() for x in files)
+    assert 0.99e10 < total < 1.01e10
+    expect = Uv[anym]
+    del anym
+    out = torch.empty(nu + 8, dtype=torch.int64, device=dev)
+    got = ctx.union(files, out=out)
+    assert got.numel() == expect.numel() and _strict(got)
+    assert bool((got == expect).all())
+    x = _xor(torch, got)
+    del expect
+    # oracle on windows: the oracle's hash-map union of the 100 matching slices
+    for start in (0, got.numel() // 2 - W // 2, got.numel() - W):
+        win = got[start:start + W]
+        lo, hi = int(win[0].item()), int(win[-1].item())
+        sl = []
+        for f in files:
+            s0, s1 = _lower(torch, f, lo), _lower(torch, f, hi + 1)
+            sl.append(_np(f[s0:s1]))
+        assert np.array_equal(_np(win), O.union(sl)), start
+    # the same stream from the 2-way tile kernel, chained (ping-pong buffers)
+    buf = [torch.empty(nu + 8, dtype=torch.int64, device=dev) for _ in range(2)]
+    acc = files[0]
+    for t, f in enumerate(files[1:]):
+        acc = ctx.setop2(lib.OP_UNION, acc, f, out=buf[t & 1])
+    assert acc.numel() == got.numel() and _xor(torch, acc) == x and bool((acc == got).all())
+
+
+def test_config5_sketch_1e10_bases_full_size(env, monkeypatch):
+    """BASELINE config 5: ntHash Scaled-MinHash sketch, k = 51, scale 1000, 1e10 bases of 150-bp reads.
+    The rolling strip kernel against the prefix-XOR kernel over all 6.7e9 windows (two algorithms), the oracle on the
+    reads at both ends, the expected keep rate, and the sort + unique of the sketch."""
+    torch, bench, lib, ctx, O, dev = env
+    nb = 10_000_000_000
+    nb -= nb % 150
+    chunk = 1 << 30
+    lut = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=dev)
+    bases = torch.empty(nb, dtype=torch.uint8, device=dev)
+    for lo in range(0, nb, chunk):
+        hi = min(lo + chunk, nb)
+        i = torch.arange(lo, hi, dtype=torch.int64, device=dev)
+        w = bench.splitmix64_torch((i >> 5) ^ bench._i64(bench.SEED))
+        bases[lo:hi] = lut[(w >> (2 * (i & 31))) & 3]
+        del i, w
+    bases[5_000_000_025:5_000_000_125] = ord("N")                   # a stretch of N inside the middle reads
+    reads = torch.arange(0, nb + 1, 150, dtype=torch.int64, device=dev)
+    k = 51
+    windows = (nb // 150) * (150 - k + 1)
+    mh = ctx.max_hash(1000)
+    cap = nb // 400
+    out_a = torch.empty(cap, dtype=torch.int64, device=dev)
+    out_b = torch.empty(cap, dtype=torch.int64, device=dev)
+    torch.cuda.synchronize()
+    monkeypatch.setenv("UKM_NTHASH_STRIP", "1")
+    a = ctx.nthash(bases, reads, k, canonical=True, max_hash=mh, out=out_a)
+    monkeypatch.setenv("UKM_NTHASH_STRIP", "0")
+    b = ctx.nthash(bases, reads, k, canonical=True, max_hash=mh, out=out_b)
+    monkeypatch.delenv("UKM_NTHASH_STRIP", raising=False)
+    assert a.numel() == b.numel() and bool((a == b).all())
+    # canonical = min of two (nearly) independent uniform hashes: P(keep) = 1 - (1 - 1/scale)^2
+    p = 1.0 - (1.0 - 1.0 / 1000) ** 2
+    assert abs(a.numel() - windows * p) < 6 * (windows * p) ** 0.5 + 1e-5 * windows
+    assert bool((a >= 0).all()) and int(a.max().item()) <= mh        # maxHash < 2^63
+    # oracle on the first and the last 40000 reads (window order: a prefix / suffix of the sketch)
+    R = 40_000
+    head = O.count_windows(bases[:R * 150].cpu().numpy(), np.arange(0, R * 150 + 1, 150, dtype=np.uint64), k,
+                           hashed=True, canonical=True, max_hash=mh)
+    tail = O.count_windows(bases[nb - R * 150:].cpu().numpy(), np.arange(0, R * 150 + 1, 150, dtype=np.uint64), k,
+                           hashed=True, canonical=True, max_hash=mh)
+    assert len(head) > 5000 and np.array_equal(_np(a[:len(head)]), head)
+    assert len(tail) > 5000 and np.array_equal(_np(a[a.numel() - len(tail):]), tail)
+    # ... and on 40000 reads around the N stretch in the middle, located in the sketch by its first hash
+    m0 = (5_000_000_025 // 150 - R // 2) * 150
+    mid = O.count_windows(bases[m0:m0 + R * 150].cpu().numpy(), np.arange(0, R * 150 + 1, 150, dtype=np.uint64), k,
+                          hashed=True, canonical=True, max_hash=mh)
+    pos = torch.nonzero(a == int(mid[0])).flatten()                  # kept hashes are <= maxHash < 2^63
+    assert pos.numel() >= 1
+    assert any(np.array_equal(_np(a[int(q):int(q) + len(mid)]), mid) for q in pos.tolist())
+    # the sketch as a set: sort + unique (the count path's tail)
+    xs = _xor(torch, a)
+    n_kept = a.numel()
+    ctx.sort_u64(a, int(mh).bit_length())
+    assert bool((a[1:] >= a[:-1]).all()) and _xor(torch, a) == xs
+    u = ctx.unique(a, out=out_b)
+    assert _strict(u) and 0.99 * n_kept < u.numel() <= n_kept

@@ -7,6 +7,8 @@
 // host never touches it).  unikmer_amd/dist.py is the same protocol over torch.distributed.
 #include <dlfcn.h>
 
+#include <mutex>
+#include <string>
 #include <vector>
 
 #include "ukm_internal.h"
@@ -30,31 +32,47 @@ struct Rccl {
     const char *(*GetErrorString)(int) = nullptr;
 };
 
+// dlopen error text of the first failed attempt (dlerror() itself may be NULL after an intervening dlclose)
+std::string g_rccl_err = "not tried";
+
 Rccl *rccl() {
     static Rccl r;
-    static bool tried = false;
-    if (tried) return r.h ? &r : nullptr;
-    tried = true;
-    const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
-    for (const char *n : names) {
-        r.h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
-        if (r.h) break;
-    }
-    if (!r.h) return nullptr;
-#define UKM_SYM(field, name)                                         \
-    *(void **)(&r.field) = dlsym(r.h, name);                         \
-    if (!r.field) { dlclose(r.h); r.h = nullptr; return nullptr; }
-    UKM_SYM(GetUniqueId, "ncclGetUniqueId")
-    UKM_SYM(CommInitRank, "ncclCommInitRank")
-    UKM_SYM(CommDestroy, "ncclCommDestroy")
-    UKM_SYM(AllGather, "ncclAllGather")
-    UKM_SYM(Send, "ncclSend")
-    UKM_SYM(Recv, "ncclRecv")
-    UKM_SYM(GroupStart, "ncclGroupStart")
-    UKM_SYM(GroupEnd, "ncclGroupEnd")
-    UKM_SYM(GetErrorString, "ncclGetErrorString")
+    static std::once_flag once;
+    std::call_once(once, [] {
+        const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        for (const char *n : names) {
+            r.h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+            if (r.h) break;
+            const char *e = dlerror();
+            g_rccl_err = e ? e : "dlopen failed";
+        }
+        if (!r.h) return;
+        bool ok = true;
+#define UKM_SYM(field, name)                                                        \
+        if (ok) {                                                                       \
+            *(void **)(&r.field) = dlsym(r.h, name);                                    \
+            if (!r.field) {                                                             \
+                const char *e = dlerror();                                              \
+                g_rccl_err = std::string(name) + ": " + (e ? e : "symbol not found");   \
+                ok = false;                                                             \
+            }                                                                           \
+        }
+        UKM_SYM(GetUniqueId, "ncclGetUniqueId")
+        UKM_SYM(CommInitRank, "ncclCommInitRank")
+        UKM_SYM(CommDestroy, "ncclCommDestroy")
+        UKM_SYM(AllGather, "ncclAllGather")
+        UKM_SYM(Send, "ncclSend")
+        UKM_SYM(Recv, "ncclRecv")
+        UKM_SYM(GroupStart, "ncclGroupStart")
+        UKM_SYM(GroupEnd, "ncclGroupEnd")
+        UKM_SYM(GetErrorString, "ncclGetErrorString")
 #undef UKM_SYM
-    return &r;
+        if (!ok) {
+            dlclose(r.h);
+            r.h = nullptr;
+        }
+    });
+    return r.h ? &r : nullptr;
 }
 
 #define UKM_NCCL(expr)                                                                              \
@@ -71,7 +89,7 @@ Rccl *rccl() {
 extern "C" int ukm_comm_get_unique_id(void *id) {
     if (!id) UKM_FAIL(UKM_ERR_INVALID, "ukm_comm_get_unique_id: id is NULL");
     Rccl *R = rccl();
-    if (!R) UKM_FAIL(UKM_ERR_HIP, "ukm_comm_get_unique_id: librccl.so could not be loaded (%s)", dlerror());
+    if (!R) UKM_FAIL(UKM_ERR_HIP, "ukm_comm_get_unique_id: librccl.so could not be loaded (%s)", g_rccl_err.c_str());
     UKM_NCCL(R->GetUniqueId((UkmNcclId *)id));
     return UKM_OK;
 }
@@ -80,7 +98,7 @@ extern "C" int ukm_comm_init(ukm_ctx *c, int nranks, int rank, const void *id) {
     if (!c || !id || nranks < 1 || rank < 0 || rank >= nranks) UKM_FAIL(UKM_ERR_INVALID, "ukm_comm_init: bad argument");
     if (c->comm) UKM_FAIL(UKM_ERR_INVALID, "ukm_comm_init: the context already has a communicator");
     Rccl *R = rccl();
-    if (!R) UKM_FAIL(UKM_ERR_HIP, "ukm_comm_init: librccl.so could not be loaded (%s)", dlerror());
+    if (!R) UKM_FAIL(UKM_ERR_HIP, "ukm_comm_init: librccl.so could not be loaded (%s)", g_rccl_err.c_str());
     UKM_HIP(hipSetDevice(c->device));
     UkmNcclId uid;
     memcpy(&uid, id, sizeof(uid));
@@ -123,13 +141,160 @@ extern "C" int ukm_prefix_splitters(int key_bits, int nranks, uint64_t *splitter
     return UKM_OK;
 }
 
+// The capacity decision of an exchange, as a pure function of what every rank knows after the all-gather: `all` is
+// the W x (W + 1) matrix [source rank][destination rank | capacity of the source rank's output buffer].  Every rank
+// evaluates the SAME predicate over ALL ranks, so either all of them post their sends and receives or none does: a
+// rank that returned UKM_ERR_CAPACITY on its own while its peers were already blocked in RCCL would hang the job
+// (round-2 review).  recv_counts / n_out describe rank `me`.
+extern "C" int ukm_shard_plan(int nranks, int me, const uint64_t *all, uint64_t *recv_counts, uint64_t *n_out) {
+    if (nranks < 1 || me < 0 || me >= nranks || !all || !recv_counts || !n_out) UKM_FAIL(UKM_ERR_INVALID, "ukm_shard_plan: bad argument");
+    const int W = nranks;
+    int short_rank = -1;
+    u64 short_need = 0, short_cap = 0;
+    for (int d = 0; d < W; d++) {
+        u64 total = 0;
+        for (int g = 0; g < W; g++) total += all[(size_t)g * (W + 1) + d];
+        const u64 cap = all[(size_t)d * (W + 1) + W];
+        if (d == me) {
+            for (int g = 0; g < W; g++) recv_counts[g] = all[(size_t)g * (W + 1) + me];  // what rank g sends to me
+            *n_out = total;
+        }
+        if (total > cap && short_rank < 0) {
+            short_rank = d;
+            short_need = total;
+            short_cap = cap;
+        }
+    }
+    if (short_rank >= 0)
+        UKM_FAIL(UKM_ERR_CAPACITY, "ukm_shard_exchange: %llu records arrive at rank %d, its capacity is %llu (no rank exchanges)",
+                 (unsigned long long)short_need, short_rank, (unsigned long long)short_cap);
+    return UKM_OK;
+}
+
+namespace {
+
+// all-gather of `per_rank` u64 values per rank; the host copy arrives in `all` ([rank][per_rank]); ONE stream sync
+int gather_u64(ukm_ctx *c, Rccl *R, const u64 *mine, size_t per_rank, std::vector<u64> &all) {
+    const int W = c->comm_size;
+    u64 *d_cnt = nullptr, *d_all = nullptr;
+    UKM_TRY(ws_alloc_t(c, per_rank, &d_cnt));
+    UKM_TRY(ws_alloc_t(c, per_rank * W, &d_all));
+    UKM_HIP(hipMemcpyAsync(d_cnt, mine, per_rank * sizeof(u64), hipMemcpyHostToDevice, c->stream));
+    UKM_NCCL(R->AllGather(d_cnt, d_all, per_rank, UKM_NCCL_UINT64, (UkmNcclComm)c->comm, c->stream));
+    all.resize(per_rank * W);
+    UKM_HIP(hipMemcpyAsync(all.data(), d_all, all.size() * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
+    UKM_HIP(hipStreamSynchronize(c->stream));
+    return UKM_OK;
+}
+
+// the data movement of one stream: the rank's own slice is a device-to-device copy, every other slice one
+// ncclSend + ncclRecv inside ONE group (every peer's transfers are posted before any of them blocks: full mesh over
+// xGMI).  Nothing in here waits on the host: the transfers are stream-ordered.
+int post_exchange(ukm_ctx *c, Rccl *R, const u64 *k, const u32 *t, const u64 *send_counts, const u64 *recv_counts, u64 *ok,
+                  u32 *ot) {
+    const int W = c->comm_size, me = c->comm_rank;
+    UkmNcclComm comm = (UkmNcclComm)c->comm;
+    u64 so = 0, ro = 0, my_so = 0, my_ro = 0;
+    for (int g = 0; g < me; g++) { my_so += send_counts[g]; my_ro += recv_counts[g]; }
+    if (send_counts[me] != recv_counts[me]) UKM_FAIL(UKM_ERR_INVALID, "ukm_shard_exchange: own slice sizes disagree");
+    if (send_counts[me]) {
+        UKM_HIP(hipMemcpyAsync(ok + my_ro, k + my_so, (size_t)send_counts[me] * sizeof(u64), hipMemcpyDeviceToDevice, c->stream));
+        if (t) UKM_HIP(hipMemcpyAsync(ot + my_ro, t + my_so, (size_t)send_counts[me] * sizeof(u32), hipMemcpyDeviceToDevice, c->stream));
+    }
+    if (W == 1) return UKM_OK;
+    UKM_NCCL(R->GroupStart());
+    int first_err = 0;
+    for (int g = 0; g < W && !first_err; g++) {
+        if (g != me) {
+            if (send_counts[g]) first_err = R->Send(k + so, (size_t)send_counts[g], UKM_NCCL_UINT64, g, comm, c->stream);
+            if (!first_err && recv_counts[g]) first_err = R->Recv(ok + ro, (size_t)recv_counts[g], UKM_NCCL_UINT64, g, comm, c->stream);
+            if (!first_err && t && send_counts[g]) first_err = R->Send(t + so, (size_t)send_counts[g], UKM_NCCL_UINT32, g, comm, c->stream);
+            if (!first_err && t && recv_counts[g]) first_err = R->Recv(ot + ro, (size_t)recv_counts[g], UKM_NCCL_UINT32, g, comm, c->stream);
+        }
+        so += send_counts[g];
+        ro += recv_counts[g];
+    }
+    const int end_err = R->GroupEnd();  // always closed, also after a failed post
+    if (first_err || end_err)
+        UKM_FAIL(UKM_ERR_HIP, "ukm_shard_exchange: RCCL send/recv failed: %s", R->GetErrorString(first_err ? first_err : end_err));
+    return UKM_OK;
+}
+
+}  // namespace
+
+// Slice sizes of `nfiles` streams at once: send_counts[nfiles][nranks] (host) -> recv_counts[nfiles][nranks] (host),
+// recv_counts[f][g] = records of file f that rank g sends to this rank.  ONE all-gather and ONE host synchronisation
+// for all files; the data then moves with ukm_shard_exchange_known, which needs no gather of its own.
+extern "C" int ukm_shard_counts(ukm_ctx *c, const uint64_t *send_counts, int nfiles, uint64_t *recv_counts) {
+    if (!c || !send_counts || !recv_counts || nfiles < 1) UKM_FAIL(UKM_ERR_INVALID, "ukm_shard_counts: bad argument");
+    if (!c->comm) UKM_FAIL(UKM_ERR_INVALID, "ukm_shard_counts: ukm_comm_init has not been called on this context");
+    Rccl *R = rccl();
+    if (!R) UKM_FAIL(UKM_ERR_HIP, "ukm_shard_counts: librccl.so could not be loaded (%s)", g_rccl_err.c_str());
+    const int W = c->comm_size, me = c->comm_rank;
+    CallScope s;
+    UKM_TRY(ukm_begin(c, &s));
+    int rc = [&]() -> int {
+        std::vector<u64> all;
+        UKM_TRY(gather_u64(c, R, send_counts, (size_t)nfiles * W, all));
+        for (int f = 0; f < nfiles; f++)
+            for (int g = 0; g < W; g++) recv_counts[(size_t)f * W + g] = all[((size_t)g * nfiles + f) * W + me];
+        return UKM_OK;
+    }();
+    return ukm_finish(&s, rc);
+}
+
+// The exchange with slice sizes that are already known on both sides (ukm_shard_counts): no all-gather and no host
+// round trip in front of the transfers (the call still ends with the stream synchronisation of every entry point).
+// A rank whose buffer is
+// too small still takes part (its slices land in workspace memory and are dropped) and reports UKM_ERR_CAPACITY
+// afterwards, so that its peers never wait for a rank that left.
+extern "C" int ukm_shard_exchange_known(ukm_ctx *c, const uint64_t *keys, const uint32_t *taxids, const uint64_t *send_counts,
+                                        const uint64_t *recv_counts, uint64_t *out_keys, uint32_t *out_taxids,
+                                        uint64_t out_cap, uint64_t *n_out) {
+    if (!c || !send_counts || !recv_counts || !n_out) UKM_FAIL(UKM_ERR_INVALID, "ukm_shard_exchange_known: NULL argument");
+    if (!c->comm) UKM_FAIL(UKM_ERR_INVALID, "ukm_shard_exchange_known: ukm_comm_init has not been called on this context");
+    Rccl *R = rccl();
+    if (!R) UKM_FAIL(UKM_ERR_HIP, "ukm_shard_exchange_known: librccl.so could not be loaded (%s)", g_rccl_err.c_str());
+    const int W = c->comm_size;
+    u64 n = 0, total = 0;
+    for (int g = 0; g < W; g++) { n += send_counts[g]; total += recv_counts[g]; }
+    if ((!keys && n) || (taxids && !out_taxids)) UKM_FAIL(UKM_ERR_INVALID, "ukm_shard_exchange_known: bad argument");
+    *n_out = total;
+    CallScope s;
+    UKM_TRY(ukm_begin(c, &s));
+    int rc = [&]() -> int {
+        const u64 *k = nullptr;
+        const u32 *t = nullptr;
+        u64 *ok = nullptr;
+        u32 *ot = nullptr;
+        UKM_TRY(ukm_in_t(c, keys, n, &k));
+        if (taxids) UKM_TRY(ukm_in_t(c, taxids, n, &t));
+        const bool fits = total <= out_cap;
+        if (fits) {
+            UKM_TRY(ukm_out_t(c, out_keys, out_cap, &ok));
+            if (taxids) UKM_TRY(ukm_out_t(c, out_taxids, out_cap, &ot));
+        } else {  // drain
+            UKM_TRY(ws_alloc_t(c, (size_t)total + 1, &ok));
+            if (taxids) UKM_TRY(ws_alloc_t(c, (size_t)total + 1, &ot));
+        }
+        UKM_TRY(post_exchange(c, R, k, t, send_counts, recv_counts, ok, ot));
+        if (!fits)
+            UKM_FAIL(UKM_ERR_CAPACITY, "ukm_shard_exchange_known: %llu records arrived, capacity is %llu", (unsigned long long)total,
+                     (unsigned long long)out_cap);
+        ukm_out_resize(c, out_keys, total * sizeof(u64));
+        if (taxids) ukm_out_resize(c, out_taxids, total * sizeof(u32));
+        return UKM_OK;
+    }();
+    return ukm_finish(&s, rc);
+}
+
 extern "C" int ukm_shard_exchange(ukm_ctx *c, const uint64_t *keys, const uint32_t *taxids, const uint64_t *send_counts,
                                   uint64_t *out_keys, uint32_t *out_taxids, uint64_t out_cap, uint64_t *recv_counts,
                                   uint64_t *n_out) {
     if (!c || !send_counts || !recv_counts || !n_out) UKM_FAIL(UKM_ERR_INVALID, "ukm_shard_exchange: NULL argument");
     if (!c->comm) UKM_FAIL(UKM_ERR_INVALID, "ukm_shard_exchange: ukm_comm_init has not been called on this context");
     Rccl *R = rccl();
-    if (!R) UKM_FAIL(UKM_ERR_HIP, "ukm_shard_exchange: librccl.so could not be loaded");
+    if (!R) UKM_FAIL(UKM_ERR_HIP, "ukm_shard_exchange: librccl.so could not be loaded (%s)", g_rccl_err.c_str());
     const int W = c->comm_size, me = c->comm_rank;
     u64 n = 0;
     for (int g = 0; g < W; g++) n += send_counts[g];
@@ -137,25 +302,14 @@ extern "C" int ukm_shard_exchange(ukm_ctx *c, const uint64_t *keys, const uint32
     CallScope s;
     UKM_TRY(ukm_begin(c, &s));
     int rc = [&]() -> int {
-        UkmNcclComm comm = (UkmNcclComm)c->comm;
-        // 1. everybody learns everybody's slice sizes: all-gather of the W send counts
-        u64 *d_cnt = nullptr, *d_all = nullptr;
-        UKM_TRY(ws_alloc_t(c, (size_t)W, &d_cnt));
-        UKM_TRY(ws_alloc_t(c, (size_t)W * W, &d_all));
-        UKM_HIP(hipMemcpyAsync(d_cnt, send_counts, (size_t)W * sizeof(u64), hipMemcpyHostToDevice, c->stream));
-        UKM_NCCL(R->AllGather(d_cnt, d_all, (size_t)W, UKM_NCCL_UINT64, comm, c->stream));
-        std::vector<u64> all((size_t)W * W);
-        UKM_HIP(hipMemcpyAsync(all.data(), d_all, all.size() * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
-        UKM_HIP(hipStreamSynchronize(c->stream));
-        u64 total = 0;
-        for (int g = 0; g < W; g++) {
-            recv_counts[g] = all[(size_t)g * W + me];  // what rank g sends to me
-            total += recv_counts[g];
-        }
-        *n_out = total;
-        if (total > out_cap)
-            UKM_FAIL(UKM_ERR_CAPACITY, "ukm_shard_exchange: %llu records arrive, capacity is %llu", (unsigned long long)total,
-                     (unsigned long long)out_cap);
+        // 1. everybody learns everybody's slice sizes AND buffer capacities: all-gather of W + 1 words per rank, then
+        //    the collective decision of ukm_shard_plan (all ranks exchange, or all ranks return UKM_ERR_CAPACITY)
+        std::vector<u64> mine((size_t)W + 1), all;
+        for (int g = 0; g < W; g++) mine[g] = send_counts[g];
+        mine[W] = out_cap;
+        UKM_TRY(gather_u64(c, R, mine.data(), (size_t)W + 1, all));
+        UKM_TRY(ukm_shard_plan(W, me, all.data(), recv_counts, n_out));
+        const u64 total = *n_out;
         // 2. the slices themselves: device pointers go to RCCL as they are, host arrays are staged
         const u64 *k = nullptr;
         const u32 *t = nullptr;
@@ -165,21 +319,7 @@ extern "C" int ukm_shard_exchange(ukm_ctx *c, const uint64_t *keys, const uint32
         if (taxids) UKM_TRY(ukm_in_t(c, taxids, n, &t));
         UKM_TRY(ukm_out_t(c, out_keys, out_cap, &ok));
         if (taxids) UKM_TRY(ukm_out_t(c, out_taxids, out_cap, &ot));
-        // one group: every peer's send and receive is posted before any of them blocks (full mesh over xGMI)
-        UKM_NCCL(R->GroupStart());
-        int first_err = 0;
-        u64 so = 0, ro = 0;
-        for (int g = 0; g < W && !first_err; g++) {
-            if (send_counts[g]) first_err = R->Send(k + so, (size_t)send_counts[g], UKM_NCCL_UINT64, g, comm, c->stream);
-            if (!first_err && recv_counts[g]) first_err = R->Recv(ok + ro, (size_t)recv_counts[g], UKM_NCCL_UINT64, g, comm, c->stream);
-            if (!first_err && taxids && send_counts[g]) first_err = R->Send(t + so, (size_t)send_counts[g], UKM_NCCL_UINT32, g, comm, c->stream);
-            if (!first_err && taxids && recv_counts[g]) first_err = R->Recv(ot + ro, (size_t)recv_counts[g], UKM_NCCL_UINT32, g, comm, c->stream);
-            so += send_counts[g];
-            ro += recv_counts[g];
-        }
-        const int end_err = R->GroupEnd();  // always closed, also after a failed post
-        if (first_err || end_err)
-            UKM_FAIL(UKM_ERR_HIP, "ukm_shard_exchange: RCCL send/recv failed: %s", R->GetErrorString(first_err ? first_err : end_err));
+        UKM_TRY(post_exchange(c, R, k, t, send_counts, recv_counts, ok, ot));
         ukm_out_resize(c, out_keys, total * sizeof(u64));
         if (taxids) ukm_out_resize(c, out_taxids, total * sizeof(u32));
         return UKM_OK;

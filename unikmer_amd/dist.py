@@ -81,46 +81,30 @@ def split_by_counts(t, counts):
     return out
 
 
-def sharded_setop(ctx, op, files_keys, key_bits, files_taxids=None, group=None, **kw):
-    """`union` / `inter` / `diff` / `common` over files that are FILE-sharded across ranks
-    (every rank holds whole sorted files spanning the full code range).
-
-    1. cut every local file at the prefix splitters (GPU lower_bound),
-    2. one all-to-all-v per file ships slice g to rank g,
-    3. each rank rebuilds its range of every file (slices are disjoint across source files,
-       so the received pieces of one logical file position are concatenated by rank order),
-    4. the single-GPU n-way op runs on the rank's range.
-    Returns this rank's part of the result; concatenating the parts in rank order gives the
-    globally sorted output, bit-identical to the 1-GPU result (including `inter`'s empty-later-file rule, which
-    is decided on the global file sizes, not on a rank's slice).
-
-    files_keys: list of 1-D int64 device tensors; every rank must pass the SAME number of
-    files (file i of every rank are the per-rank chunks of logical input i).  `ctx` must run on
-    torch's current stream (lib.Context(device, stream=torch.cuda.current_stream().cuda_stream)):
-    the exchange of file i+1 is issued asynchronously and overlaps the merge of file i.
-    """
+def _exchange_files(ctx, files_keys, key_bits, files_taxids=None, group=None):
+    """Generator over the logical files: cuts every local file at the prefix splitters, ships ALL slice sizes in ONE
+    small all-to-all, then yields (pieces, taxid_pieces | None) of file 0, 1, ... -- the sorted slices that arrived for
+    this rank's range, one per source rank -- while the all-to-all-v of the NEXT file is already in flight.
+    Also returns, through the `info` dict it yields first, the global size of every logical file."""
     world = dist.get_world_size(group)
     spl = prefix_splitters(key_bits, world)[:-1]
     nfiles = len(files_keys)
     dev = files_keys[0].device if nfiles else None
-    # slice sizes of every file for every destination; ONE small all-to-all carries all of them
-    counts_all = []
-    for k in files_keys:
-        counts_all.append(cuts_to_counts(ctx.partition_points(k, spl), k.numel()))
+    counts_all = [cuts_to_counts(ctx.partition_points(k, spl), k.numel()) for k in files_keys]
     recv_counts_all = [[0] * world for _ in range(nfiles)]
+    global_sizes = [0] * nfiles
     if nfiles:
         send = torch.tensor(counts_all, dtype=torch.int64, device=dev).t().contiguous()   # [world, nfiles]
         recv = torch.empty_like(send)
         _all_to_all(recv, send, group=group)
         rc = recv.cpu().tolist()                                                            # [source rank][file]
         recv_counts_all = [[int(rc[src][i]) for src in range(world)] for i in range(nfiles)]
-    # GLOBAL size of every logical file (`inter` needs it: see below); same small-message pattern
-    global_sizes = [0] * nfiles
-    if nfiles:
+        # GLOBAL size of every logical file (`inter` needs it); same small-message pattern
         gs = torch.tensor([k.numel() for k in files_keys], dtype=torch.int64,
                           device=dev if dist.get_backend(group) != "gloo" else "cpu")
         dist.all_reduce(gs, op=dist.ReduceOp.SUM, group=group)
         global_sizes = [int(x) for x in gs.cpu()]
+    yield {"global_sizes": global_sizes}
 
     def issue(i):
         """start the all-to-all-v of file i (asynchronous: it overlaps the merge of file i - 1)"""
@@ -135,25 +119,77 @@ def sharded_setop(ctx, op, files_keys, key_bits, files_taxids=None, group=None, 
             works.append(_all_to_all(out_t, t, rcv, list(counts_all[i]), group, async_op=True))
         return works, out, out_t
 
-    local = []
-    local_t = [] if files_taxids is not None else None
     pending = issue(0) if nfiles else None
     for i in range(nfiles):
         nxt = issue(i + 1) if i + 1 < nfiles else None      # file i+1 travels while file i is merged
         works, rk, rt = pending
         for w in works:
             w.wait()   # nccl: makes torch's current stream (= the ctx stream) wait, the host does not block
-        # pieces from different source ranks overlap in value -> merge them into one sorted set
         pieces = split_by_counts(rk, recv_counts_all[i])
         tpieces = split_by_counts(rt, recv_counts_all[i]) if rt is not None else None
+        yield pieces, tpieces
+        pending = nxt
+
+
+def redistribute(ctx, files_keys, key_bits, files_taxids=None, group=None, with_sizes=False):
+    """Prefix redistribution of FILE-sharded sorted sets: every logical file is exchanged ONCE and rebuilt on its
+    range owner (k-way merge of the slices that arrived, which overlap in value).  Returns the list of local sorted
+    sets (and the list of their taxids, or None): the inputs of any number of single-GPU operations on this rank's
+    range -- `union` AND `inter` of the same two sets need one exchange of each, not one per operation."""
+    it = _exchange_files(ctx, files_keys, key_bits, files_taxids, group)
+    info = next(it)
+    local, local_t = [], ([] if files_taxids is not None else None)
+    for pieces, tpieces in it:
+        live = [j for j, x in enumerate(pieces) if x.numel()]
+        if len(live) == 1 and tpieces is None:
+            local.append(pieces[live[0]])                  # one source only: already this rank's sorted range
+            continue
         merged = ctx.union(pieces, tpieces)
         if tpieces is not None:
             local.append(merged[0])
             local_t.append(merged[1])
         else:
             local.append(merged)
-        pending = nxt
-    fn = {"union": ctx.union, "inter": ctx.inter, "diff": ctx.diff, "common": ctx.common}[op]
+    return (local, local_t, info["global_sizes"]) if with_sizes else (local, local_t)
+
+
+def sharded_setop(ctx, op, files_keys, key_bits, files_taxids=None, group=None, **kw):
+    """`union` / `inter` / `diff` / `common` over files that are FILE-sharded across ranks
+    (every rank holds whole sorted files spanning the full code range).
+
+    1. cut every local file at the prefix splitters (GPU lower_bound),
+    2. one all-to-all-v per file ships slice g to rank g,
+    3. `union`: all received pieces feed one k-way union.  `inter` / `diff` / `common` fold over FILES, so each rank
+       first rebuilds its range of every logical file (k-way merge of the pieces that arrived for it: `redistribute`),
+    4. then the single-GPU n-way op runs on the rank's range.
+    Returns this rank's part of the result; concatenating the parts in rank order gives the
+    globally sorted output, bit-identical to the 1-GPU result (including `inter`'s empty-later-file rule, which
+    is decided on the global file sizes, not on a rank's slice).
+
+    files_keys: list of 1-D int64 device tensors; every rank must pass the SAME number of
+    files (file i of every rank are the per-rank chunks of logical input i).  `ctx` must run on
+    torch's current stream (lib.Context(device, stream=torch.cuda.current_stream().cuda_stream)):
+    the exchange of file i+1 is issued asynchronously and overlaps the merge of file i.
+    """
+    nfiles = len(files_keys)
+    if op == "union":
+        # a union does not care which logical file a record came from: every received piece (nfiles x world sorted
+        # slices of this rank's range) goes straight into ONE k-way union -- no per-file merge pass over HBM first
+        it = _exchange_files(ctx, files_keys, key_bits, files_taxids, group)
+        next(it)
+        allp, allt = [], ([] if files_taxids is not None else None)
+        for pieces, tpieces in it:
+            for j, x in enumerate(pieces):
+                if x.numel():
+                    allp.append(x)
+                    if tpieces is not None:
+                        allt.append(tpieces[j])
+        if not allp:
+            empty = files_keys[0][:0]
+            return (empty, files_taxids[0][:0]) if files_taxids is not None else empty
+        return ctx.union(allp, allt)
+    local, local_t, global_sizes = redistribute(ctx, files_keys, key_bits, files_taxids, group, with_sizes=True)
+    fn = {"inter": ctx.inter, "diff": ctx.diff, "common": ctx.common}[op]
     if op == "common":
         return fn(local, kw["threshold"], local_t)
     if op == "inter" and nfiles > 1:

@@ -29,7 +29,7 @@ SYMBOLS = [
     "ukm_unique", "ukm_merge_k", "ukm_setop2", "ukm_union", "ukm_inter", "ukm_diff",
     "ukm_common", "ukm_common_threshold", "ukm_partition_points",
     "ukm_comm_get_unique_id", "ukm_comm_init", "ukm_comm_destroy", "ukm_comm_info", "ukm_prefix_splitters",
-    "ukm_shard_exchange",
+    "ukm_shard_exchange", "ukm_shard_plan", "ukm_shard_counts", "ukm_shard_exchange_known",
 ]
 
 
@@ -131,6 +131,9 @@ def load():
     L.ukm_comm_info.argtypes = [vp, C.POINTER(i32), C.POINTER(i32)]
     L.ukm_prefix_splitters.argtypes = [i32, i32, vp]
     L.ukm_shard_exchange.argtypes = [vp, vp, vp, vp, vp, vp, u64, vp, pu64]
+    L.ukm_shard_plan.argtypes = [i32, i32, vp, vp, pu64]
+    L.ukm_shard_counts.argtypes = [vp, vp, i32, vp]
+    L.ukm_shard_exchange_known.argtypes = [vp, vp, vp, vp, vp, vp, vp, u64, pu64]
     _lib = L
     return L
 
@@ -443,22 +446,43 @@ class Context:
         _check(self.L.ukm_prefix_splitters(key_bits, nranks, sp.ctypes.data))
         return sp
 
-    def shard_exchange(self, keys, send_counts, taxids=None):
-        """all-to-all-v of the contiguous slices of one sorted stream; returns (keys, taxids | None, recv_counts)"""
+    @staticmethod
+    def shard_plan(nranks, rank, gathered):
+        """the collective capacity decision of ukm_shard_exchange as a pure host function: gathered =
+        [source rank][nranks slice sizes | out_cap of that rank].  Returns (recv_counts, n_out); raises CapacityError
+        on EVERY rank when ANY rank's buffer is too small."""
+        g = np.ascontiguousarray(gathered, dtype=np.uint64).reshape(nranks, nranks + 1)
+        rc = np.zeros(nranks, dtype=np.uint64)
+        m = C.c_uint64()
+        _check(load().ukm_shard_plan(nranks, rank, g.ctypes.data, rc.ctypes.data, C.byref(m)))
+        return rc, m.value
+
+    def shard_counts(self, send_counts):
+        """send_counts [nfiles][nranks] -> recv_counts [nfiles][nranks] (one all-gather + one host sync for all files)"""
+        sc = np.ascontiguousarray(send_counts, dtype=np.uint64)
+        if sc.ndim == 1:
+            sc = sc[None, :]
+        rc = np.zeros_like(sc)
+        _check(self.L.ukm_shard_counts(self.h, sc.ctypes.data, sc.shape[0], rc.ctypes.data))
+        return rc
+
+    def shard_exchange(self, keys, send_counts, taxids=None, recv_counts=None):
+        """all-to-all-v of the contiguous slices of one sorted stream; returns (keys, taxids | None, recv_counts).
+        The receive sizes are learned first (ukm_shard_counts) and the output is sized from them: n_local x nranks is
+        NOT a bound on what a rank receives (a rank with few local records may own a dense prefix range).  Callers
+        that already hold the counts of many files (shard_counts) pass recv_counts and skip the per-file gather."""
         pk, n, k1 = _ptr(keys, np.uint64)
         pt, _, k2 = _ptr(taxids, np.uint32)
         sc = np.ascontiguousarray(send_counts, dtype=np.uint64)
         assert int(sc.sum()) == n
-        rc = np.zeros(len(sc), dtype=np.uint64)
-        # capacity: the counts are not known before the call; size for the worst case of this job (callers that know
-        # better pass device tensors of their own through the C ABI directly)
-        cap = max(1, int(n) * len(sc))
+        rc = np.ascontiguousarray(recv_counts, dtype=np.uint64) if recv_counts is not None else self.shard_counts(sc)[0]
+        cap = max(1, int(rc.sum()))
         out = _empty_like_kind(keys, cap, np.uint64)
         out_t = _empty_like_kind(keys, cap, np.uint32) if taxids is not None else None
         po, _, _ = _ptr(out, np.uint64)
         pot, _, _ = _ptr(out_t, np.uint32)
         m = C.c_uint64()
-        _check(self.L.ukm_shard_exchange(self.h, pk, pt, sc.ctypes.data, po, pot, cap, rc.ctypes.data, C.byref(m)))
+        _check(self.L.ukm_shard_exchange_known(self.h, pk, pt, sc.ctypes.data, rc.ctypes.data, po, pot, cap, C.byref(m)))
         return out[: m.value], (out_t[: m.value] if out_t is not None else None), rc
 
     def partition_points(self, keys, splitters):
