@@ -170,6 +170,39 @@ def test_lca_merged_and_forest(ctx, O):
     c.close()
 
 
+def test_lca_deep_and_ragged_trees(O, L):
+    """The root-path table (round 3: 16 bytes per node per 4 levels, LCA = last equal entry of two root paths) against
+    the oracle's ancestor walk on shapes that cross chunk boundaries: a chain of 203 nodes, a caterpillar, a forest of
+    three trees, ids with gaps, merged ids."""
+    c = L.Context(0)
+    child, parent = [], []
+    # tree 1: chain 100 -> 101 -> ... -> 302 (depth 202), with a leaf hanging off every 7th node (ids 1000 + i)
+    child.append(100); parent.append(100)
+    for i in range(101, 303):
+        child.append(i); parent.append(i - 1)
+    for i in range(100, 303, 7):
+        child.append(1000 + i); parent.append(i)
+    # tree 2: complete ternary tree of depth 5 rooted at 5000
+    base, nodes = 5000, sum(3 ** d for d in range(6))
+    for t in range(1, nodes + 1):
+        child.append(base + t - 1); parent.append(base + (0 if t == 1 else (t - 2) // 3 + 1) - (0 if t == 1 else 1))
+    # tree 3: a root that appears only as a parent
+    child += [9001, 9002]; parent += [9000, 9001]
+    child, parent = np.array(child, dtype=np.uint32), np.array(parent, dtype=np.uint32)
+    mo, mn = np.array([50, 51, 52], dtype=np.uint32), np.array([302, 5003, 77777], dtype=np.uint32)
+    c.taxonomy_load(child, parent, mo, mn)
+    tax = O.Taxonomy(child, parent, mo, mn)
+    rng = np.random.default_rng(5)
+    pool = np.concatenate([child, [0, 50, 51, 52, 9000, 400, 99999]]).astype(np.uint32)
+    a, b = rng.choice(pool, 30000), rng.choice(pool, 30000)
+    # many pairs inside the chain (deep common prefixes: several chunks of the table)
+    a[:8000] = rng.integers(100, 303, 8000)
+    b[:8000] = np.where(rng.random(8000) < 0.5, rng.integers(100, 303, 8000), 1000 + 100 + 7 * rng.integers(0, 29, 8000))
+    exp = np.array([tax.lca(x, y) for x, y in zip(a, b)], dtype=np.uint32)
+    assert np.array_equal(c.lca(a.astype(np.uint32), b.astype(np.uint32)), exp)
+    c.close()
+
+
 # ---------------------------------------------------------------------------------- n-way
 def _files(nfiles, n_universe, p, seed=11):
     j = np.arange(n_universe, dtype=np.uint64)

@@ -47,6 +47,10 @@ struct TaxDev {
     const u8 *depth;    // dense [size]; root depth 0
     const u32 *merged;  // dense [size] or nullptr; 0 = not merged
     u32 size;
+    // root-path table (round 3): anc[c * size + t] = the ancestors of t at depths 4c .. 4c+3 (t itself at its own
+    // depth, 0 beyond it; all 0 for an absent taxid).  nullptr when the tree is too deep for it: lca_dev then climbs.
+    const uint4 *anc;
+    u32 nchunks;
 };
 
 // ---- workspace arena: chunked bump allocator on the ctx's device ------------------------------
@@ -88,6 +92,8 @@ struct ukm_ctx {
     u32 *tax_parent = nullptr;
     u8 *tax_depth = nullptr;
     u32 *tax_merged = nullptr;
+    uint4 *tax_anc = nullptr;  // root-path table, see TaxDev
+    u32 tax_nchunks = 0;
     u32 tax_size = 0;
     u32 tax_max = 0;
 
@@ -168,6 +174,8 @@ static inline TaxDev ukm_taxdev(const ukm_ctx *c) {
     t.parent = c->tax_parent;
     t.depth = c->tax_depth;
     t.merged = c->tax_merged;
+    t.anc = c->tax_anc;
+    t.nchunks = c->tax_nchunks;
     t.size = c->tax_size;
     return t;
 }

@@ -579,11 +579,13 @@ __device__ __forceinline__ void tile_flush(const SetopArgs &p, int tid, u64 base
 //   a predecessor fails to publish within LB_SPIN_LIMIT polls the kernel raises FLAG_TIMEOUT
 //   and the host re-runs with TICKET = true, where tile ids come from an atomic counter and
 //   forward progress holds for any dispatch order.
-// Plain keys: two 512-thread workgroups per CU (LDS) = 4 waves per SIMD, so the register budget is 128; the
-// allocator is told so (it budgets 256 for a 512-thread workgroup by itself and came out at 129 with the two load
-// paths).  Instantiations with taxids / ranks keep the default budget.
+// Up to 80 KB of LDS per workgroup (plain keys; taxids OR ranks riding along): two 512-thread workgroups per CU = 4
+// waves per SIMD, so the register budget is 128 and the allocator is told so (by itself it budgets 256 for a
+// 512-thread workgroup: the plain kernel came out at 129 with its two load paths, the union with taxids at 131 once
+// the LCA grew -- one workgroup per CU, union with taxids 1.45 -> 1.92 ms).  Taxids AND ranks (106 KB of LDS, one
+// workgroup per CU anyway) keep the default budget.
 template <int OP, bool TAX, bool RANK, bool TICKET, int NTH, int VT>
-__global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu((TAX || RANK) ? 2 : 4, (TAX || RANK) ? 8 : 4)))
+__global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu((TAX && RANK) ? 2 : 4, (TAX && RANK) ? 8 : 4)))
 void setop_tile_kernel(SetopArgs p) {
     constexpr int TILE = NTH * VT;
     constexpr int SLOTS = TILE + 8;

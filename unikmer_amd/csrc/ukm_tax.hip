@@ -3,10 +3,12 @@
 // sites union.go:199, inter.go:235,238, diff.go:362,407, common.go:265, sort.go:491,515,
 // util-sort.go:128,151,325,374).
 //
-// Layout in HBM: dense parent[taxid] (u32), depth[taxid] (u8) and, when merged.dmp is given,
-// merged[taxid] (u32).  NCBI has ~2.6 M nodes with ids < 4 M -> ~36 MB, resident in the
-// 256 MiB Infinity Cache.  LCA = resolve merged ids, equalise depths, climb in lock step.
+// Layout in HBM: dense parent[taxid] (u32), depth[taxid] (u8), merged[taxid] (u32, when merged.dmp is given) and the
+// root-path table anc[chunk][taxid] (uint4: the ancestors at depths 4 chunk .. 4 chunk + 3) built from them on the
+// device.  LCA = resolve merged ids, then the last equal entry of the two root paths (ukm_device.h: two independent
+// 16-byte reads for pairs that diverge within four levels of the root; rounds 1-2 climbed parent[] in lock step).
 // Contract (taxdump parity is unpinned): see include/unikmer_hip.h.
+#include <cstdlib>
 #include <vector>
 
 #include "ukm_device.h"
@@ -16,6 +18,17 @@ namespace {
 __global__ void lca_bulk_kernel(TaxDev T, const u32 *a, const u32 *b, u64 n, u32 *out) {
     u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = lca_dev(T, a[i], b[i]);
+}
+
+// root paths: thread t climbs from t to its root once and writes the node it passes at depth l into slot l of t's row
+__global__ void build_anc_kernel(const u32 *parent, const u8 *depth, u32 size, u32 *anc) {
+    const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= size || parent[t] == 0) return;
+    u32 x = t;
+    for (int l = depth[t]; l >= 0; l--) {
+        anc[((size_t)(l >> 2) * size + t) * 4 + (l & 3)] = x;
+        x = parent[x];
+    }
 }
 
 // copy a (host or device) array to a host vector
@@ -97,6 +110,21 @@ extern "C" int ukm_taxonomy_load(ukm_ctx *c, const uint32_t *child, const uint32
     }
     c->tax_size = (u32)size;
     c->tax_max = mx_node;
+    // root-path table for lca_dev: 16 bytes per node per 4 levels (NCBI: ~3.4 M dense ids x ~45 levels = 0.65 GB of the
+    // 288 GB; the first chunk -- all that random pairs touch -- is 54 MB; the deepest tree the loader accepts, 250
+    // levels, would take 1 KB per id)
+    if (c->tax_anc) { (void)hipFree(c->tax_anc); c->tax_anc = nullptr; c->tax_nchunks = 0; }
+    int maxd = 0;
+    for (u64 t = 0; t < size; t++) maxd = std::max(maxd, (int)D[t]);
+    const u32 nchunks = (u32)(maxd + 1 + 3) / 4;
+    const u64 bytes = (u64)nchunks * size * sizeof(uint4);
+    UKM_HIP(hipMalloc((void **)&c->tax_anc, bytes));
+    UKM_HIP(hipMemsetAsync(c->tax_anc, 0, bytes, c->stream));
+    hipLaunchKernelGGL(build_anc_kernel, dim3((unsigned)((size + 255) / 256)), dim3(256), 0, c->stream, c->tax_parent,
+                       c->tax_depth, (u32)size, (u32 *)c->tax_anc);
+    UKM_HIP(hipGetLastError());
+    UKM_HIP(hipStreamSynchronize(c->stream));
+    c->tax_nchunks = nchunks;
     return UKM_OK;
 }
 
