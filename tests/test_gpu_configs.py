@@ -210,10 +210,11 @@ def test_config4_chain_with_duplicates_falls_back(env):
 
 # ------------------------------------------------------------------------------------------- k-way kernel edges
 @pytest.mark.parametrize("nstreams", [3, 4, 5, 8, 9, 17, 64, 65])
-def test_kway_stream_counts_and_extreme_codes(env, nstreams):
+def test_kway_stream_counts_and_extreme_codes(env, nstreams, monkeypatch):
     """fan-in 4 (<= 4 streams) and 8, one / two / three levels, nodes with a single child, and the codes 0 and
     2^64-1 (the in-LDS merges use 2^64-1 as their sentinel: a real one takes the bounds-checked loop)"""
     O, L, ctx, tax, T = env
+    monkeypatch.setenv("UKM_KWAY", "1")   # 3-4 tiny streams would take the pairwise tree by default (round 3)
     rng = np.random.default_rng(nstreams)
     streams = []
     for i in range(nstreams):

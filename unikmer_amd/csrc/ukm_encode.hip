@@ -717,7 +717,7 @@ int run_strip_filter(ukm_ctx *c, const u8 *bases, const u64 *rec_off, u64 n_rec,
     // (the count is Poisson: 0.6 x capacity leaves more than ten standard deviations of head room)
     while (L > 64 && (double)ST_NT * L * frac > ST_CAP * 0.6) L >>= 1;
     if (force != 1 && ((double)ST_NT * L * frac > ST_CAP * 0.6 || L < 256)) return UKM_OK;  // small --scale: general kernel
-    if (const char *le = getenv("UKM_STRIP_L")) L = std::max(64, atoi(le) / 64 * 64);  // developer knob
+    if (const char *le = getenv("UKM_STRIP_L")) L = std::min(1024, std::max(64, atoi(le) / 64 * 64));  // developer knob; s_ci packs the window index into 11 bits
     const u64 tile_pos = (u64)ST_NT * (u64)L;
     const u64 ntiles = (total_bases + tile_pos - 1) / tile_pos;
     if (ntiles > 0x7FFFFFFFull) return UKM_OK;

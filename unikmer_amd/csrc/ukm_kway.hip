@@ -804,6 +804,18 @@ int ukm_dev_kway(ukm_ctx *c, int op, const u64 *const *keys, const u32 *const *t
         }
         UKM_HIP(hipGetLastError());
         mark(lv == 0 ? "level0" : (lv == 1 ? "level1" : "level2+"));
+        if (lv == 0 && levels > 1 && N >= (1u << 22)) {
+            // order and degenerate runs are checked while level 0 loads the leaves: a flagged input goes to the
+            // caller's general route NOW instead of after the remaining levels and the compaction have moved all N
+            // records again (one 20-us read-back against a level of >= 4e6 records)
+            u64 fl = 0;
+            UKM_TRY(ukm_read_u64(c, ctl + 1, &fl));
+            if (fl & (KW_FLAG_UNSORTED | KW_FLAG_DEGENERATE)) {
+                if (dbg) for (auto &m : marks) (void)hipEventDestroy(m.second);
+                *fallback = true;
+                return UKM_OK;
+            }
+        }
         in_k = ok;
         in_t = ot;
         in_cnt = cnt;

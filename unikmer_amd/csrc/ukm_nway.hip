@@ -12,6 +12,7 @@
 //                                  sort, unique/repeated scan (a heap has no place on a GPU)
 // All of it is host-side orchestration; every byte of data stays on the device.
 #include <algorithm>
+#include <cstdlib>
 #include <vector>
 
 #include "ukm_device.h"
@@ -220,6 +221,15 @@ int try_kway(ukm_ctx *ctx, int op, const std::vector<Stream> &ss, bool tax, u64 
              bool *done) {
     *done = false;
     if (ss.size() < 3 || !ukm_kway_enabled()) return UKM_OK;
+    {
+        // a handful of tiny streams: the pairwise tree (a few 60-us calls) beats the k-way set-up (sample, sort,
+        // cuts, several small launches and read-backs).  UKM_KWAY=1 forces the k-way path (tests).
+        u64 total = 0;
+        for (auto &x : ss) total += x.n;
+        const char *fe = getenv("UKM_KWAY");
+        const bool forced = fe != nullptr && fe[0] == '1';
+        if (!forced && ss.size() <= 4 && total < (1u << 16)) return UKM_OK;
+    }
     std::vector<const u64 *> kp(ss.size());
     std::vector<const u32 *> tp(ss.size());
     std::vector<u64> ln(ss.size());

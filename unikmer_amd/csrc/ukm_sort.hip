@@ -19,9 +19,9 @@
 
 namespace {
 
-// onesweep tile shapes (threads x keys per thread), measured on MI355X at 1e8 keys (profiles/r01_notes.md):
-// keys only 512x14 (4.15 ms; 512x12 4.3, 512x15 5.3, 256x24 4.6, 768x10 4.9, 1024x7 5.1),
-// key + taxid 1024x11 (5.1 ms; 768x14 5.1, 512x20 5.4, 512x12 6.4)
+// onesweep tile shapes (threads x keys per thread), measured on MI355X at 1e8 keys (profiles/r01_notes.md, r02_notes.md):
+// keys only 1024x14 with the fused next-digit histogram (3.67 ms; round 1 without it: 512x14 4.15, 512x12 4.3,
+// 512x15 5.3, 256x24 4.6, 768x10 4.9, 1024x7 5.1), key + taxid 1024x11 (5.1 ms; 768x14 5.1, 512x20 5.4, 512x12 6.4)
 #ifndef SORT_NT_KEYS
 #define SORT_NT_KEYS 1024
 #endif
@@ -47,7 +47,7 @@ constexpr int MAX_PASSES = 8;
 struct __attribute__((packed, aligned(8))) U2a8 {  // 16 bytes at 8-byte alignment
     u64 x, y;
 };
-__global__ __launch_bounds__(NT) void radix_hist_kernel(const u64 *k, u64 n, int passes, u64 *ghist) {
+__global__ __launch_bounds__(NT) void radix_hist_kernel(const u64 *k, u64 n, int passes, u64 *ghist, u64 *or_all) {
     __shared__ u32 s_h[MAX_PASSES * RADIX];
     const int tid = (int)threadIdx.x;
     for (int i = tid; i < MAX_PASSES * RADIX; i += NT) s_h[i] = 0;
@@ -58,6 +58,7 @@ __global__ __launch_bounds__(NT) void radix_hist_kernel(const u64 *k, u64 n, int
     const u64 per_block = ((n + gridDim.x - 1) / gridDim.x + STEP - 1) / STEP * STEP;
     const u64 beg = (u64)blockIdx.x * per_block;
     const u64 end = (beg + per_block < n) ? beg + per_block : n;
+    u64 orv = 0;  // OR of every key this thread sees: tells the host which high digits are all zero
     for (u64 i0 = beg; i0 < end; i0 += STEP) {
         u64 key[2 * U];
         bool valid[2 * U];
@@ -78,6 +79,7 @@ __global__ __launch_bounds__(NT) void radix_hist_kernel(const u64 *k, u64 n, int
 #pragma unroll
         for (int u = 0; u < 2 * U; u++) {
             const u64 vm = __ballot(valid[u]);
+            if (valid[u]) orv |= key[u];
             for (int p = 0; p < passes; p++) {
                 const u32 d = (u32)(key[u] >> (RB * p)) & DMASK;
                 const u32 d0 = __builtin_amdgcn_readfirstlane(d);
@@ -93,6 +95,11 @@ __global__ __launch_bounds__(NT) void radix_hist_kernel(const u64 *k, u64 n, int
     for (int i = tid; i < passes * RADIX; i += NT) {
         u32 v = s_h[i];
         if (v) atomicAdd((unsigned long long *)&ghist[i], (unsigned long long)v);
+    }
+    if (or_all) {
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) orv |= __shfl_xor(orv, d, 64);
+        if (lane_id() == 0 && orv) atomicOr((unsigned long long *)or_all, (unsigned long long)orv);
     }
 }
 
@@ -486,28 +493,40 @@ int ukm_dev_sort(ukm_ctx *c, u64 *keys, u32 *vals, u64 n, int key_bits) {
 #endif
     if (n >= SORT_FUSED_MIN) {
         // Large inputs: only the FIRST digit's histogram is built by a pass over the keys; every scatter pass counts
-        // the next digit on the fly and a 256-thread kernel turns the counts into bases between two passes.  No
-        // host round trip at all (the histograms never leave the device), at the price of not seeing digits that
-        // happen to be constant beyond what key_bits says.
+        // the next digit on the fly and a 256-thread kernel turns the counts into bases between two passes.  The
+        // histograms never leave the device and the passes take their tile ids from a ticket counter (SORT_TICKET,
+        // no watchdog flag to read back), so a sort with a known key width has no host round trip at all; constant
+        // digits inside the key width are not detected here.
         u64 *fh = nullptr, *gb = nullptr, *tk = nullptr;
         u32 *tv = nullptr;
-        UKM_TRY(ws_alloc_t(c, (size_t)MAX_PASSES * RADIX, &fh));
+        UKM_TRY(ws_alloc_t(c, (size_t)MAX_PASSES * RADIX + 1, &fh));
         UKM_TRY(ws_alloc_t(c, (size_t)MAX_PASSES * RADIX, &gb));
-        UKM_HIP(hipMemsetAsync(fh, 0, MAX_PASSES * RADIX * sizeof(u64), c->stream));
+        UKM_HIP(hipMemsetAsync(fh, 0, (MAX_PASSES * RADIX + 1) * sizeof(u64), c->stream));
         unsigned hb = (unsigned)std::min<u64>((n + 4095) / 4096, (u64)c->num_cu * 8);
-        hipLaunchKernelGGL(radix_hist_kernel, dim3(hb), dim3(NT), 0, c->stream, keys, n, 1, fh);
+        // A caller that could not narrow key_bits (64) gets ONE 8-byte read-back: the OR of all keys, gathered by the
+        // pre-pass for free, drops the passes over high digits that are zero everywhere (hashes restricted by a
+        // Scaled threshold, k <= 28 codes handed over as plain uint64: 5-7 passes instead of 8).
+        u64 *or_all = key_bits == 64 ? fh + (size_t)MAX_PASSES * RADIX : nullptr;
+        hipLaunchKernelGGL(radix_hist_kernel, dim3(hb), dim3(NT), 0, c->stream, keys, n, 1, fh, or_all);
         UKM_HIP(hipGetLastError());
+        int passes_f = passes;
+        if (or_all) {
+            u64 orv = 0;
+            UKM_TRY(ukm_read_u64(c, or_all, &orv));
+            const int bits = orv ? 64 - __builtin_clzll(orv) : 1;
+            passes_f = (bits + RB - 1) / RB;
+        }
         int sh[MAX_PASSES];
-        for (int p = 0; p < passes; p++) sh[p] = RB * p;
+        for (int p = 0; p < passes_f; p++) sh[p] = RB * p;
         UKM_TRY(ws_alloc_t(c, n, &tk));
         if (vals) UKM_TRY(ws_alloc_t(c, n, &tv));
         bool in_tmp = false;
         if (vals) {
-            if (n < (1ull << 30)) UKM_TRY((run_passes<u32, true, SORT_NT_PAIRS, SORT_VT_PAIRS>(c, keys, vals, tk, tv, n, passes, sh, gb, &in_tmp, fh)));
-            else UKM_TRY((run_passes<u64, true, SORT_NT_PAIRS, SORT_VT_PAIRS>(c, keys, vals, tk, tv, n, passes, sh, gb, &in_tmp, fh)));
+            if (n < (1ull << 30)) UKM_TRY((run_passes<u32, true, SORT_NT_PAIRS, SORT_VT_PAIRS>(c, keys, vals, tk, tv, n, passes_f, sh, gb, &in_tmp, fh)));
+            else UKM_TRY((run_passes<u64, true, SORT_NT_PAIRS, SORT_VT_PAIRS>(c, keys, vals, tk, tv, n, passes_f, sh, gb, &in_tmp, fh)));
         } else {
-            if (n < (1ull << 30)) UKM_TRY((run_passes<u32, false, SORT_NT_KEYS, SORT_VT_KEYS>(c, keys, vals, tk, tv, n, passes, sh, gb, &in_tmp, fh)));
-            else UKM_TRY((run_passes<u64, false, SORT_NT_KEYS, SORT_VT_KEYS>(c, keys, vals, tk, tv, n, passes, sh, gb, &in_tmp, fh)));
+            if (n < (1ull << 30)) UKM_TRY((run_passes<u32, false, SORT_NT_KEYS, SORT_VT_KEYS>(c, keys, vals, tk, tv, n, passes_f, sh, gb, &in_tmp, fh)));
+            else UKM_TRY((run_passes<u64, false, SORT_NT_KEYS, SORT_VT_KEYS>(c, keys, vals, tk, tv, n, passes_f, sh, gb, &in_tmp, fh)));
         }
         if (in_tmp) {
             UKM_HIP(hipMemcpyAsync(keys, tk, n * sizeof(u64), hipMemcpyDeviceToDevice, c->stream));
@@ -520,7 +539,7 @@ int ukm_dev_sort(ukm_ctx *c, u64 *keys, u32 *vals, u64 n, int key_bits) {
     UKM_TRY(ws_alloc_t(c, MAX_PASSES * RADIX, &ghist));
     UKM_HIP(hipMemsetAsync(ghist, 0, MAX_PASSES * RADIX * sizeof(u64), c->stream));
     unsigned hblocks = (unsigned)std::min<u64>((n + 4095) / 4096, (u64)c->num_cu * 8);
-    hipLaunchKernelGGL(radix_hist_kernel, dim3(hblocks), dim3(NT), 0, c->stream, keys, n, passes, ghist);
+    hipLaunchKernelGGL(radix_hist_kernel, dim3(hblocks), dim3(NT), 0, c->stream, keys, n, passes, ghist, (u64 *)nullptr);
     UKM_HIP(hipGetLastError());
     std::vector<u64> h((size_t)passes * RADIX);
     UKM_HIP(hipMemcpyAsync(h.data(), ghist, h.size() * sizeof(u64), hipMemcpyDeviceToHost, c->stream));

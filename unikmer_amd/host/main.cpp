@@ -34,6 +34,7 @@
 #include <regex>
 #include <set>
 #include <sstream>
+#include <stdexcept>
 #include <string>
 #include <thread>
 #include <vector>
@@ -50,13 +51,18 @@ static const char *VERSION = "0.21.0-hip";
 static const string EXT = ".unik";
 
 // ---- errors / logging (util-cli.go:39-44 checkError -> log + os.Exit(-1)) -------------------------
+// A worker thread (the FASTA/Q parser of `count`) must not call exit(): atexit handlers and static destructors --
+// the HIP runtime's among them -- would run while the main thread is inside HIP calls.  There die() throws; the
+// thread's catch hands the message to the main thread, which reports it after join() (round-2 advice).
+static thread_local bool t_worker_thread = false;
 [[noreturn]] static void die(const char *fmt, ...) {
+    char buf[2048];
     va_list ap;
     va_start(ap, fmt);
-    fprintf(stderr, "[ERRO] ");
-    vfprintf(stderr, fmt, ap);
-    fprintf(stderr, "\n");
+    vsnprintf(buf, sizeof(buf), fmt, ap);
     va_end(ap);
+    if (t_worker_thread) throw std::runtime_error(buf);
+    fprintf(stderr, "[ERRO] %s\n", buf);
     exit(255);
 }
 static bool g_verbose = false;
@@ -575,6 +581,7 @@ static u64 count_on_device(Gpu &g, int device, const vector<string> &files, cons
     ChunkPipe pipe;
     for (int i = 0; i < 3; i++) { ch[i].c = gp.c; ch[i].reserve(CH + (1 << 20)); pipe.free_.push_back(i); }
     std::thread parser([&]() {
+        t_worker_thread = true;  // die() throws here instead of exiting under the main thread's HIP calls
         try {
             ChunkSink sink(pipe, ch, CH, skip_name);
             for (auto &f : files) { info("reading sequence file: %s", f.c_str()); parse_fastx(f, sink); }
