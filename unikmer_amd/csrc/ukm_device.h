@@ -8,6 +8,14 @@
 
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
 
+// A u64 that an EARLIER kernel (or a host copy) wrote and this kernel only reads, fetched inside a loop that also
+// stores: through a plain pointer the compiler cannot prove the word unchanged and uses a vector load, whose vmcnt(0)
+// also waits for every prefetch the wave has in flight.  Read through the CONSTANT address space it becomes a scalar
+// load (s_load_dwordx2/x4, lgkmcnt) that the compiler schedules early and waits for at the first use.  `p` must be
+// wave-uniform and the word must not be written by the running kernel.
+typedef const u64 __attribute__((address_space(4))) ukm_const_u64;
+__device__ __forceinline__ u64 sload_u64(const u64 *p) { return *(ukm_const_u64 *)(uintptr_t)p; }
+
 // ---- wave64 scans ---------------------------------------------------------------------------
 // Inclusive scan across the 64 lanes with DPP row shifts / row broadcasts (gfx9 DPP controls:
 // row_shr:n = 0x110+n, row_bcast:15 = 0x142, row_bcast:31 = 0x143): six VALU adds, no LDS
@@ -190,12 +198,25 @@ __device__ __forceinline__ u64 lb_lookback(u64 *status, u64 tile, u64 agg) {
 // needed only when the first agrees completely (relatives inside one clade: cache-friendly by construction).
 // Random taxid pairs diverge next to the root: one round of two loads instead of the chain of ~2 x depth dependent
 // random reads of the parent / depth climb of rounds 1-2 (union of 2 x 1e8 records with random taxids 5.4 -> 3.1 ms).
-__device__ __forceinline__ u32 lca_dev(const TaxDev &T, u32 a, u32 b) {
+// The LCA in two halves, so that a thread with several pairs can have the first-chunk reads of all of them in flight
+// before it looks at any (ukm_fold.hip: up to four pairs per thread per file).
+struct LcaReq {
+    u32 a, b;
+    uint4 pa, pb;
+};
+__device__ __forceinline__ void lca_begin(const TaxDev &T, u32 a, u32 b, LcaReq &q) {
+    const uint4 zero = make_uint4(0, 0, 0, 0);
+    q.a = a;
+    q.b = b;
+    const bool trivial = a == 0 || b == 0 || a == b;
+    q.pa = (!trivial && a < T.size) ? T.anc[a] : zero;
+    q.pb = (!trivial && b < T.size) ? T.anc[b] : zero;
+}
+__device__ __forceinline__ u32 lca_finish(const TaxDev &T, const LcaReq &q) {
+    u32 a = q.a, b = q.b;
     if (a == 0 || b == 0) return 0;
     if (a == b) return a;
-    const uint4 zero = make_uint4(0, 0, 0, 0);
-    uint4 pa = a < T.size ? T.anc[a] : zero;
-    uint4 pb = b < T.size ? T.anc[b] : zero;
+    uint4 pa = q.pa, pb = q.pb;
     if (pa.x == 0) {  // absent: merged into another taxid?
         const u32 m = (a < T.size && T.merged) ? T.merged[a] : 0u;
         a = (m && m < T.size) ? m : 0u;
@@ -224,4 +245,9 @@ __device__ __forceinline__ u32 lca_dev(const TaxDev &T, u32 a, u32 b) {
         if (pa.x != pb.x || pa.x == 0) return last;
         last = pa.x;
     }
+}
+__device__ __forceinline__ u32 lca_dev(const TaxDev &T, u32 a, u32 b) {
+    LcaReq q;
+    lca_begin(T, a, b, q);
+    return lca_finish(T, q);
 }

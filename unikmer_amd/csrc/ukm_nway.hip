@@ -16,6 +16,7 @@
 #include <vector>
 
 #include "ukm_device.h"
+#include "ukm_fold.h"
 #include "ukm_kway.h"
 
 namespace {
@@ -359,6 +360,33 @@ int fold_chained(ukm_ctx *ctx, int op, const std::vector<Stream> &ss, u32 flags,
     return UKM_OK;
 }
 
+// `inter` / `diff` over many files as ONE range-partitioned launch (ukm_fold.hip) instead of one link per file.
+// ss[0] is the running result's start; empty later files have already been handled by the caller's rule (inter:
+// the list ends in front of the first one; diff: they are dropped).  *done = false: not eligible, or the kernel saw
+// a duplicate code (the exact multiset route of the chained / synchronous fold answers then).
+constexpr u64 FOLD_MAX_FIRST = 1ull << 24;  // larger first files: the 2-way tile kernel streams them faster per link
+int try_range_fold(ukm_ctx *ctx, int op, const std::vector<Stream> &ss, u32 flags, bool tax, u64 *fk, u32 *ft, u64 fcap,
+                   u64 *n_out, bool *done) {
+    *done = false;
+    if (!ukm_fold_enabled() || ss.size() < (size_t)CHAIN_MIN_STREAMS || ss[0].n == 0 || ss[0].n > FOLD_MAX_FIRST) return UKM_OK;
+    std::vector<const u64 *> kp(ss.size());
+    std::vector<const u32 *> tp(ss.size());
+    std::vector<u64> ln(ss.size());
+    for (size_t i = 0; i < ss.size(); i++) {
+        kp[i] = ss[i].k;
+        tp[i] = ss[i].t;
+        ln[i] = ss[i].n;
+    }
+    WsMark mark = ws_mark(ctx);
+    bool fallback = false;
+    const int rc = ukm_dev_range_fold(ctx, op, kp.data(), tax ? tp.data() : nullptr, ln.data(), (int)ss.size(), tax, flags, fk, ft,
+                                      fcap, n_out, &fallback);
+    ws_release(ctx, mark);
+    UKM_TRY(rc);
+    *done = !fallback;
+    return UKM_OK;
+}
+
 }  // namespace
 
 extern "C" int ukm_union(ukm_ctx *ctx, const uint64_t *const *keys, const uint32_t *const *taxids,
@@ -402,6 +430,14 @@ extern "C" int ukm_inter(ukm_ctx *ctx, const uint64_t *const *keys, const uint32
                 UKM_TRY(ws_alloc_t(ctx, acc.n + 1, &bk[i]));
                 if (tax) UKM_TRY(ws_alloc_t(ctx, acc.n + 1, &bt[i]));
             }
+        }
+        if (nstreams >= CHAIN_MIN_STREAMS && acc.n) {
+            // inter.go:211-217: an empty later file ends the fold and the running result is kept
+            std::vector<Stream> live(ss.begin(), ss.begin() + 1);
+            for (int i = 1; i < nstreams && ss[(size_t)i].n; i++) live.push_back(ss[(size_t)i]);
+            bool done = false;
+            UKM_TRY(try_range_fold(ctx, UKM_OP_INTER, live, flags, tax, o.k, o.t, out_cap, n_out, &done));
+            if (done) return UKM_OK;
         }
         if (nstreams >= CHAIN_MIN_STREAMS && acc.n) {
             ChainResult cr;
@@ -466,6 +502,14 @@ extern "C" int ukm_diff(ukm_ctx *ctx, const uint64_t *const *keys, const uint32_
                 UKM_TRY(ukm_dev_sort(ctx, k, t, q.n, 64));
                 q.k = k;
                 q.t = t;
+            }
+            {
+                std::vector<Stream> live;
+                for (auto &q : ss2)
+                    if (q.n) live.push_back(q);  // diff.go: empty files subtract nothing
+                bool done = false;
+                UKM_TRY(try_range_fold(ctx, UKM_OP_DIFF, live, flags, tax, o.k, o.t, out_cap, n_out, &done));
+                if (done) return UKM_OK;
             }
             ChainResult cr;
             UKM_TRY(fold_chained(ctx, UKM_OP_DIFF, ss2, flags, tax, false, bk, bt, &cr));
