@@ -62,7 +62,14 @@ def main():
             if k.startswith("setop_tile_kernel<%d," % op):
                 return v.get(cn)
         return None
-    tr = {"n": int(lines[0]["config"]["per_gpu_set_size"]), "tag": tag,
+    import subprocess
+    try:
+        head = subprocess.check_output(["git", "-C", ROOT, "rev-parse", "--short=12", "HEAD"], text=True).strip()
+    except Exception:
+        head = None
+    tr = {"n": int(lines[0]["config"]["per_gpu_set_size"]), "tag": tag, "head": head,
+          "method": "rocprofv3 --kernel-trace --pmc FETCH_SIZE and --pmc WRITE_SIZE, one pass each, over `python bench.py --steps 5 "
+                    "--warmup 2 --cpu-sample 0` (tools/collect_profiles.sh)",
           "note": "FETCH_SIZE x2 (gfx950 wide-stream correction), WRITE_SIZE as reported; KiB -> bytes; "
                   "separate --pmc passes; mean per launch over the run's dispatches"}
     for op, nm in ((0, "union"), (1, "inter")):
