@@ -225,6 +225,74 @@ def test_count_device_pipeline_chunked(cli, tmp_path, monkeypatch):
 
 
 @pytest.mark.gpu
+def test_count_taxid_and_minimizer_stream_through_chunks(cli, tmp_path, monkeypatch):
+    """`count -T -r` (a taxid per record, parsed from the header: count.go:334-344) and `count -W` go through the same
+    chunked device pipeline as the plain path since round 3: 1 MB chunks, records shorter than k (skipped BEFORE their
+    header is parsed: the header without a taxid must not fail), a record longer than a chunk, `-B` name filter.
+    Expected: the oracle's windows with each record's taxid, sorted, LCA-folded per code; the oracle's minimizers."""
+    from conftest import synth_tree
+    from oracle import oracle as O
+    d = str(tmp_path)
+    child, parent = synth_tree(depth=4, arity=4)
+    os.makedirs(d + "/tax")
+    with open(d + "/tax/nodes.dmp", "w") as fh:
+        for c, p in zip(child, parent):
+            fh.write("%d\t|\t%d\t|\tno rank\t|\n" % (c, p))
+    tax = O.Taxonomy(child, parent)
+    T = len(child)
+    rng = np.random.default_rng(9)
+    k = 21
+    lens = [1_300_000, 20, 5000, 0, 21, 400_000] + [150] * 3000 + [900_000]
+    # a small alphabet window makes codes repeat across records, so the LCA fold has work
+    pool = "".join(np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, 200_000)].tobytes().decode())
+    seqs, taxid = [], []
+    for n in lens:
+        st = int(rng.integers(0, max(1, len(pool) - 1)))
+        q = (pool[st:] + pool * (n // len(pool) + 1))[:n]
+        seqs.append(q)
+        taxid.append(int(rng.integers(1, T + 1)))
+    with open(d + "/t.fa", "w") as fh:
+        for i, q in enumerate(seqs):
+            short = len(q) < k
+            fh.write((">r%d notaxid\n" % i) if short else (">r%d taxid|%d| skipme%d\n" % (i, taxid[i], i % 7)))
+            for j in range(0, len(q), 80):
+                fh.write(q[j:j + 80] + "\n")
+    monkeypatch.setenv("UNIKMER_CHUNK_MB", "1")
+    keep = [i for i in range(len(seqs)) if i % 7 != 3 or len(seqs[i]) < k]      # -B drops "skipme3"
+    bases = np.frombuffer("".join(seqs[i] for i in keep).encode(), dtype=np.uint8)
+    off = np.zeros(len(keep) + 1, dtype=np.uint64)
+    off[1:] = np.cumsum([len(seqs[i]) for i in keep])
+    p = cli("count", "-k", k, "-K", "-s", "-T", "-r", r"taxid\|(\d+)", "-B", "skipme3", "--data-dir", d + "/tax", "--verbose",
+            d + "/t.fa", "-o", d + "/ct")
+    assert b"device pipeline:" in p.stderr and b" 1 chunk(s)" not in p.stderr
+    gk = np.array([int(x) for x in cli("view", "-N", d + "/ct.unik").stdout.split()], dtype=np.uint64)
+    gt = np.array([int(x) for x in cli("view", "-T", d + "/ct.unik").stdout.split()], dtype=np.uint32)
+    codes = O.count_windows(bases, off, k, canonical=True)
+    wt = np.concatenate([np.full(max(0, len(seqs[i]) - k + 1), taxid[i], dtype=np.uint32) for i in keep]) if keep else np.empty(0, np.uint32)
+    assert len(codes) == len(wt)
+    sk, st_ = O.sort_pairs(codes, wt)
+    ek, et = O.unique(sk, st_, tax=tax)
+    assert np.array_equal(gk, ek) and np.array_equal(gt, et)
+    # a header without a taxid on a record that HAS windows is an error (count.go:338-341)
+    with open(d + "/bad.fa", "w") as fh:
+        fh.write(">x notaxid\n" + seqs[2] + "\n")
+    bad = cli("count", "-k", k, "-K", "-s", "-T", "-r", r"taxid\|(\d+)", "--data-dir", d + "/tax", d + "/bad.fa", "-o", d + "/b", ok=False)
+    assert bad.returncode != 0 and b"failed to parse taxid" in bad.stderr
+    # -W: the minimizer sketch record by record through the chunks (linear order), then as a sorted set
+    cli("count", "-k", k, "-W", 11, "-H", "-K", "-l", d + "/t.fa", "-o", d + "/mw")
+    got = np.array([int(x) for x in cli("view", "-N", d + "/mw.unik").stdout.split()], dtype=np.uint64)
+    all_b = np.frombuffer("".join(seqs).encode(), dtype=np.uint8)
+    all_off = np.zeros(len(seqs) + 1, dtype=np.uint64)
+    all_off[1:] = np.cumsum(lens)
+    exp = np.concatenate([O.minimizer(all_b[int(all_off[i]):int(all_off[i + 1])], k, 11)[0] for i in range(len(seqs))
+                          if lens[i] >= k + 11 - 1])   # shorter records have no group of w windows: ErrShortSeq, skipped
+    assert np.array_equal(got, exp)
+    cli("count", "-k", k, "-W", 11, "-H", "-K", "-s", d + "/t.fa", "-o", d + "/ms")
+    got = np.array([int(x) for x in cli("view", "-N", d + "/ms.unik").stdout.split()], dtype=np.uint64)
+    assert np.array_equal(got, np.unique(exp))
+
+
+@pytest.mark.gpu
 def test_taxonomy_lca_through_cli(cli, tmp_path):
     """union / inter / sort -u / diff -t with per-record taxids and a synthetic nodes.dmp +
     merged.dmp (util.go:119-171); expected values from the oracle."""

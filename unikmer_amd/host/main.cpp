@@ -503,6 +503,7 @@ struct HostChunk {
     uint8_t *bases = nullptr;
     u64 cap = 0, nb = 0;
     vector<u64> off{0};
+    vector<u32> wtax;  // -T: the taxid of every window of the chunk, in window order (count.go:334-344)
     void reserve(u64 want) {  // grows the page-locked buffer (a record longer than a chunk)
         if (want <= cap) return;
         u64 ncap = std::max<u64>(want, cap + cap / 2);
@@ -513,7 +514,7 @@ struct HostChunk {
         bases = (uint8_t *)p;
         cap = ncap;
     }
-    void reset() { nb = 0; off.assign(1, 0); }
+    void reset() { nb = 0; off.assign(1, 0); wtax.clear(); }
 };
 // parser thread -> device thread hand-off: three chunks go round (one being filled, one travelling, one in the kernels)
 struct ChunkPipe {
@@ -534,8 +535,21 @@ struct ChunkSink : FastxSink {
     u64 chunk_bytes;
     int cur;
     const std::regex *skip_name;
-    ChunkSink(ChunkPipe &p, HostChunk *c, u64 cb, const std::regex *skip) : pipe(p), ch(c), chunk_bytes(cb), skip_name(skip) { cur = pipe.get_free(); ch[cur].reset(); }
-    bool begin_record(const string &name) override { return !(skip_name && std::regex_search(name, *skip_name)); }  // -B (count.go:300-312)
+    // -T: the taxid is parsed from the header when the record ENDS, and only if the record is long enough to have a
+    // window (count.go:323-344: ErrShortSeq is hit before the header is looked at); every window gets its record's taxid
+    const std::regex *tax_re;
+    int k;
+    bool circular;
+    string cur_name;
+    u64 rec_start = 0;
+    ChunkSink(ChunkPipe &p, HostChunk *c, u64 cb, const std::regex *skip, const std::regex *tre = nullptr, int kk = 0, bool circ = false)
+        : pipe(p), ch(c), chunk_bytes(cb), skip_name(skip), tax_re(tre), k(kk), circular(circ) { cur = pipe.get_free(); ch[cur].reset(); }
+    bool begin_record(const string &name) override {
+        if (skip_name && std::regex_search(name, *skip_name)) return false;  // -B (count.go:300-312)
+        if (tax_re) cur_name = name;
+        rec_start = ch[cur].nb;
+        return true;
+    }
     void add_seq(const char *p, size_t n) override {
         HostChunk &h = ch[cur];
         h.reserve(h.nb + n);
@@ -545,6 +559,15 @@ struct ChunkSink : FastxSink {
     void end_record() override {
         HostChunk &h = ch[cur];
         h.off.push_back(h.nb);
+        if (tax_re) {
+            const u64 len = h.nb - rec_start;
+            if (len >= (u64)k) {
+                std::smatch m;
+                if (!std::regex_search(cur_name, m, *tax_re) || m.size() < 2) die("failed to parse taxid in header: %s", cur_name.c_str());
+                const u32 t = (u32)strtoul(m[1].str().c_str(), nullptr, 10);
+                h.wtax.insert(h.wtax.end(), circular ? len : len - (u64)k + 1, t);
+            }
+        }
         if (h.nb >= chunk_bytes) flush();
     }
     void flush() {
@@ -572,7 +595,8 @@ struct DevArray {
 };
 
 static u64 count_on_device(Gpu &g, int device, const vector<string> &files, const std::regex *skip_name, int k, bool canonical, bool circular,
-                           bool hashed, u64 max_hash, bool linear, int uniq_mode, int key_bits, vector<u64> &codes) {
+                           bool hashed, u64 max_hash, bool linear, int uniq_mode, int key_bits, vector<u64> &codes,
+                           int minimizer_w = 0, const std::regex *tax_re = nullptr, vector<u32> *taxids_out = nullptr) {
     const char *ce = getenv("UNIKMER_CHUNK_MB");
     const u64 CH = (u64)(ce ? std::max(1, atoi(ce)) : 32) << 20;
     const double t0 = now_ms();
@@ -583,7 +607,7 @@ static u64 count_on_device(Gpu &g, int device, const vector<string> &files, cons
     std::thread parser([&]() {
         t_worker_thread = true;  // die() throws here instead of exiting under the main thread's HIP calls
         try {
-            ChunkSink sink(pipe, ch, CH, skip_name);
+            ChunkSink sink(pipe, ch, CH, skip_name, tax_re, k, circular);
             for (auto &f : files) { info("reading sequence file: %s", f.c_str()); parse_fastx(f, sink); }
             sink.flush();
         } catch (const std::exception &e) {
@@ -593,9 +617,13 @@ static u64 count_on_device(Gpu &g, int device, const vector<string> &files, cons
         pipe.finish();
     });
     // device side: chunk i+1 travels (transfer stream) while chunk i is encoded / hashed
-    struct Slot { void *bases = nullptr; u64 bcap = 0; void *off = nullptr; u64 ocap = 0; int host = -1; u64 nrec = 0; };
+    struct Slot { void *bases = nullptr; u64 bcap = 0; void *off = nullptr; u64 ocap = 0; void *tax = nullptr; u64 tcap = 0; int host = -1; u64 nrec = 0; };
     Slot sl[2];
     DevArray dcodes(g.c);
+    // -T: the windows' taxids travel with their chunk and are appended to a second growing device array (u32, kept in
+    // a u64-granular DevArray: capacity counts pairs of taxids)
+    DevArray dtax(g.c);
+    const bool with_tax = tax_re != nullptr;
     u64 n = 0, total_bases = 0, nchunks = 0;
     auto upload = [&](Slot &d, int hi) {
         HostChunk &h = ch[hi];
@@ -604,6 +632,11 @@ static u64 count_on_device(Gpu &g, int device, const vector<string> &files, cons
         if (ob > d.ocap) { if (d.off) ukm_dev_free(g.c, d.off); d.ocap = ob + ob / 8; ck(ukm_dev_alloc(g.c, d.ocap, &d.off)); }
         ck(ukm_copy_async(g.c, d.bases, h.bases, h.nb));
         ck(ukm_copy_async(g.c, d.off, h.off.data(), ob));   // (pageable source: staged by the runtime)
+        if (with_tax && !h.wtax.empty()) {
+            const u64 tb = h.wtax.size() * 4;
+            if (tb > d.tcap) { if (d.tax) ukm_dev_free(g.c, d.tax); d.tcap = tb + tb / 8; ck(ukm_dev_alloc(g.c, d.tcap, &d.tax)); }
+            ck(ukm_copy_async(g.c, d.tax, h.wtax.data(), tb));
+        }
         d.host = hi;
         d.nrec = h.off.size() - 1;
         total_bases += h.nb;
@@ -613,8 +646,14 @@ static u64 count_on_device(Gpu &g, int device, const vector<string> &files, cons
         HostChunk &h = ch[d.host];
         dcodes.ensure(n, n + h.nb);  // windows <= bases
         u64 m = 0;
-        if (hashed) ck(ukm_nthash(g.c, (const uint8_t *)d.bases, (const u64 *)d.off, d.nrec, k, canonical, circular, max_hash, dcodes.p + n, dcodes.cap - n, &m));
+        if (minimizer_w > 0) ck(ukm_minimizer(g.c, (const uint8_t *)d.bases, (const u64 *)d.off, d.nrec, k, minimizer_w, circular, max_hash, dcodes.p + n, nullptr, dcodes.cap - n, &m));
+        else if (hashed) ck(ukm_nthash(g.c, (const uint8_t *)d.bases, (const u64 *)d.off, d.nrec, k, canonical, circular, max_hash, dcodes.p + n, dcodes.cap - n, &m));
         else ck(ukm_encode_kmers(g.c, (const uint8_t *)d.bases, (const u64 *)d.off, d.nrec, k, canonical, circular, dcodes.p + n, dcodes.cap - n, &m));
+        if (with_tax) {
+            if (m != h.wtax.size()) die("count -T: %llu windows but %zu taxids in a chunk", (unsigned long long)m, h.wtax.size());
+            dtax.ensure((n + 1) / 2, (n + m + 1) / 2 + 1);
+            if (m) ck(ukm_copy(g.c, (u32 *)dtax.p + n, d.tax, m * 4));  // device to device, ordered behind the upload by the fence above
+        }
         n += m;
         pipe.put_free(d.host);  // its upload is complete (the kernels waited for it): the parser may refill it
         d.host = -1;
@@ -632,7 +671,7 @@ static u64 count_on_device(Gpu &g, int device, const vector<string> &files, cons
     }
     parser.join();
     ck(ukm_copy_sync(g.c));
-    for (auto &d : sl) { if (d.bases) ukm_dev_free(g.c, d.bases); if (d.off) ukm_dev_free(g.c, d.off); }
+    for (auto &d : sl) { if (d.bases) ukm_dev_free(g.c, d.bases); if (d.off) ukm_dev_free(g.c, d.off); if (d.tax) ukm_dev_free(g.c, d.tax); }
     for (auto &h : ch) if (h.bases) ukm_host_free(gp.c, h.bases);
     if (!pipe.error.empty()) die("%s", pipe.error.c_str());
     const double t1 = now_ms();
@@ -640,13 +679,20 @@ static u64 count_on_device(Gpu &g, int device, const vector<string> &files, cons
     u64 nout = n;
     if (!linear && n) {
         float ms_sort = 0, ms_uniq = 0;
-        ck(ukm_sort_u64(g.c, dcodes.p, n, key_bits));
+        if (with_tax) ck(ukm_sort_pairs(g.c, dcodes.p, (u32 *)dtax.p, n, key_bits));
+        else ck(ukm_sort_u64(g.c, dcodes.p, n, key_bits));
         ukm_last_call_ms(g.c, &ms_sort);
         const double t1b = now_ms();
         DevMem dout(g.c, n * 8);
+        DevMem dtout(g.c, with_tax ? n * 4 : 8);
         const double t1c = now_ms();
-        ck(ukm_unique(g.c, dcodes.p, nullptr, n, uniq_mode, (u64 *)dout.p, nullptr, n, &nout));
+        ck(ukm_unique(g.c, dcodes.p, with_tax ? (u32 *)dtax.p : nullptr, n, uniq_mode, (u64 *)dout.p, with_tax ? (u32 *)dtout.p : nullptr, n, &nout));
         ukm_last_call_ms(g.c, &ms_uniq);
+        if (with_tax && taxids_out) {
+            taxids_out->resize(nout ? nout : 1);
+            ck(ukm_copy(g.c, taxids_out->data(), dtout.p, nout * 4));
+            taxids_out->resize(nout);
+        }
         const double t2 = now_ms();
         info("  sort: %.2f ms wall (%.2f ms on the device), output allocation %.2f ms, unique: %.2f ms wall (%.2f ms on the device)",
              t1b - t1, ms_sort, t1c - t1b, t2 - t1c, ms_uniq);
@@ -657,6 +703,11 @@ static u64 count_on_device(Gpu &g, int device, const vector<string> &files, cons
     } else {
         codes.resize(n ? n : 1);
         if (n) ck(ukm_copy(g.c, codes.data(), dcodes.p, n * 8));
+        if (with_tax && taxids_out) {
+            taxids_out->resize(n ? n : 1);
+            if (n) ck(ukm_copy(g.c, taxids_out->data(), dtax.p, n * 4));
+            taxids_out->resize(n);
+        }
         info("device pipeline: %llu bases in %llu chunk(s); parse+upload+encode %.2f ms (overlapped), download of %llu codes %.2f ms",
              (unsigned long long)total_bases, (unsigned long long)nchunks, t1 - t0, (unsigned long long)n, now_ms() - t1);
     }
@@ -704,96 +755,32 @@ static int cmd_count(int argc, char **argv) {
     if (linear && (repeated || unique || sortk)) die("flag -l/--linear is not compatible with -s, -u and -d");
     const string out_file = out_name(a.str("out-prefix", "-"));
 
-    const bool device_pipeline = !parse_taxid && !minimizer;
-    SeqBatch sb;
-    if (!device_pipeline)
-        for (auto &f : files) { info("reading sequence file: %s", f.c_str()); read_fastx(f, sb, parse_taxid || a.has("seq-name-filter")); }
-    const u64 n_rec = sb.off.size() - 1;
-    // -B name filter / -T taxid per record (count.go:300-344)
-    vector<u32> rec_taxid;
-    if (!device_pipeline && (a.has("seq-name-filter") || parse_taxid)) {
-        std::regex re_tax;
-        if (parse_taxid) re_tax = std::regex(a.str("parse-taxid-regexp"));
-        std::regex re_name;
-        if (a.has("seq-name-filter")) re_name = std::regex(a.str("seq-name-filter"), std::regex::icase);
-        SeqBatch kept;
-        for (u64 r = 0; r < n_rec; r++) {
-            if (a.has("seq-name-filter") && std::regex_search(sb.names[r], re_name)) continue;
-            if (sb.off[r + 1] - sb.off[r] < (u64)k) continue;  // ErrShortSeq -> skipped before its header is parsed (count.go:323-344)
-            if (parse_taxid) {
-                std::smatch m;
-                if (!std::regex_search(sb.names[r], m, re_tax) || m.size() < 2) die("failed to parse taxid in header: %s", sb.names[r].c_str());
-                rec_taxid.push_back((u32)strtoul(m[1].str().c_str(), nullptr, 10));
-            }
-            kept.bases.insert(kept.bases.end(), sb.bases.begin() + (long)sb.off[r], sb.bases.begin() + (long)sb.off[r + 1]);
-            kept.off.push_back(kept.bases.size());
-        }
-        sb.bases.swap(kept.bases);
-        sb.off.swap(kept.off);
-    }
-    const u64 nrec = sb.off.size() - 1;
-
+    // every mode goes through the device pipeline (round 3: also -T and -W): the parser thread fills page-locked
+    // chunks -- with -T it also parses each record's taxid and expands it to the record's windows --, the device thread
+    // uploads chunk i + 1 while chunk i is encoded / hashed / sketched, and sort + dedup run on the device
+    if (parse_taxid && (scaled || minimizer)) die("-T/--parse-taxid together with -D/--scale or -W/--minimizer-w is not supported in this build");
     Gpu g(o.gpu);
     u32 max_taxid = o.max_taxid;
     if (parse_taxid) max_taxid = load_taxonomy(g, o);
     const u64 max_hash = scaled ? ukm_max_hash((u64)scale) : 0;
-    // every window of every record, in order
-    u64 cap = 0;
-    for (u64 r = 0; r < nrec; r++) { u64 len = sb.off[r + 1] - sb.off[r]; if (len >= (u64)k) cap += circular ? len : len - k + 1; }
     // Scaled sketch: every kept hash is <= maxHash, so the radix sort needs only its significant bits
     // (scale 1000: 55 bits = 7 passes instead of 8)
     int key_bits = hashed ? 64 : 2 * k;
     if (hashed && max_hash != 0) { key_bits = 1; while (key_bits < 64 && (max_hash >> key_bits) != 0) key_bits++; }
-    const int uniq_mode = unique ? UKM_SINGLETON : (repeated ? UKM_REPEATED : UKM_UNIQUE);
+    const int uniq_mode = unique ? UKM_SINGLETON : (repeated ? UKM_REPEATED : UKM_UNIQUE);  // count.go:424-436
     vector<u64> codes;
-    u64 n = 0;
-    if (device_pipeline) {
-        std::regex re_skip;
-        if (a.has("seq-name-filter")) re_skip = std::regex(a.str("seq-name-filter"), std::regex::icase);
-        n = count_on_device(g, o.gpu, files, a.has("seq-name-filter") ? &re_skip : nullptr, k, canonical, circular, hashed, max_hash, linear,
-                            uniq_mode, key_bits, codes);
-    } else {
-        codes.assign(cap ? cap : 1, 0);
-        if (nrec) {
-            if (minimizer) ck(ukm_minimizer(g.c, sb.bases.data(), sb.off.data(), nrec, k, (int)minimizer_w, circular, max_hash, codes.data(), nullptr, cap, &n));
-            else if (hashed) ck(ukm_nthash(g.c, sb.bases.data(), sb.off.data(), nrec, k, canonical, circular, max_hash, codes.data(), cap, &n));
-            else ck(ukm_encode_kmers(g.c, sb.bases.data(), sb.off.data(), nrec, k, canonical, circular, codes.data(), cap, &n));
-        }
-        codes.resize(n);
-    }
     vector<u32> taxids;
-    if (parse_taxid) {  // per-window taxid = its record's taxid (only without the Scaled filter, whose survivors lose their record)
-        if (scaled || minimizer) die("-T/--parse-taxid together with -D/--scale or -W/--minimizer-w is not supported in this build");
-        taxids.reserve(n);
-        for (u64 r = 0; r < nrec; r++) {
-            u64 len = sb.off[r + 1] - sb.off[r];
-            if (len < (u64)k) continue;
-            u64 w = circular ? len : len - k + 1;
-            taxids.insert(taxids.end(), w, rec_taxid[r]);
-        }
-    }
+    std::regex re_skip, re_tax;
+    if (a.has("seq-name-filter")) re_skip = std::regex(a.str("seq-name-filter"), std::regex::icase);
+    if (parse_taxid) re_tax = std::regex(a.str("parse-taxid-regexp"));
+    const u64 n = count_on_device(g, o.gpu, files, a.has("seq-name-filter") ? &re_skip : nullptr, k, canonical, circular, hashed, max_hash, linear,
+                                  uniq_mode, key_bits, codes, minimizer ? (int)minimizer_w : 0, parse_taxid ? &re_tax : nullptr, &taxids);
     u32 mode = 0;
     if (canonical) mode |= unik::UnikCanonical;
     if (parse_taxid) mode |= unik::UnikIncludeTaxID;
     if (hashed) mode |= unik::UnikHashed;
     unik::Header sh;
     if (scaled) { sh.flag |= unik::UnikScaled; sh.scale = (u32)scale; sh.max_hash = max_hash; }
-    if (!linear && !device_pipeline) {
-        // dedup: distinct set, or codes seen exactly once (-u), or at least twice (-d)  (count.go:424-436)
-        const int m = uniq_mode;
-        vector<u64> out(n ? n : 1);
-        vector<u32> tout(parse_taxid ? (n ? n : 1) : 0);
-        u64 nu = 0;
-        if (n) {
-            if (parse_taxid) ck(ukm_sort_pairs(g.c, codes.data(), taxids.data(), n, key_bits));
-            else ck(ukm_sort_u64(g.c, codes.data(), n, key_bits));
-            ck(ukm_unique(g.c, codes.data(), parse_taxid ? taxids.data() : nullptr, n, m, out.data(),
-                          parse_taxid ? tout.data() : nullptr, n, &nu));
-        }
-        codes.swap(out);
-        taxids.swap(tout);
-        n = nu;
-    }
     if (!linear) {
         // without -s the reference writes Go-map order; any order is valid there, we keep the
         // sorted order but only set the Sorted flag (and its encoding) when -s is given
