@@ -923,15 +923,46 @@ __global__ __launch_bounds__(SW_NT) __attribute__((amdgpu_waves_per_eu(HASH ? 3 
                 // ---- one row: END positions e0 .. e0 + 15 ----
                 const long long e0s = s0 + (long long)(c0 - 64 + 4 * (g - 3));
                 const u64 e0 = (u64)e0s;
+                if (k >= 17) {
+                    // A window needs k - 1 >= 16 bases in front of its END inside its record, so a row of 16 END
+                    // positions holds valid windows of AT MOST ONE record, and they form one run [qlo, qhi) of the
+                    // row: rows cut by a record end, a record start or the strip's own limits go through the same
+                    // cooperative 16-byte stores as whole rows, with the run packed into the descriptor (round 3; on
+                    // 150-bp reads every wave used to spend every row step in a divergent value-by-value loop).
+                    u64 dsc = ~0ull;
+                    if (!dead && e0s + (SW_B - 1) >= (long long)e_lo && e0s < (long long)e_hi) {
+                        const u64 ef = e0s < (long long)e_lo ? e_lo : e0;  // first END of the row this lane may emit
+                        while (!dead && ef >= rec_end) SW_NEXT_RECORD();
+                        if (!dead) {
+                            u64 lo_e = rec_start + (u64)k - 1;
+                            lo_e = lo_e < ef ? ef : lo_e;
+                            u64 hi_e = e0 + SW_B;
+                            hi_e = hi_e < rec_end ? hi_e : rec_end;
+                            hi_e = hi_e < e_hi ? hi_e : e_hi;
+                            if (lo_e < hi_e) {
+                                const u32 qlo = (u32)(lo_e - e0), qhi = (u32)(hi_e - e0);
+                                const u64 d = (e0 + 1 - (u64)k - gap) & ((1ull << 55) - 1);  // output index of slot 0 (mod 2^55)
+                                dsc = d | ((u64)qlo << 55) | ((u64)qhi << 59);
+                                if (!HASH) {
+                                    // illegal base inside an emitted window: history bits 16 - qhi .. 14 - qlo + k
+                                    const u32 cntb = (u32)k + qhi - qlo - 1;
+                                    const u64 hm = (cntb >= 64 ? ~0ull : ((1ull << cntb) - 1)) << (SW_B - qhi);
+                                    if ((hist & hm) != 0) illegal = true;
+                                }
+                            }
+                        }
+                    }
+                    s_desc[wave][lane] = dsc;
+                } else {
                 bool ok = false;
                 if (!dead && e0s >= (long long)e_lo) {
                     while (!dead && e0 >= rec_end) SW_NEXT_RECORD();
                     ok = !dead && e0 + (SW_B - 1) < rec_end && e0 + (SW_B - 1) < e_hi && e0 + 1 >= rec_start + (u64)k;
                 }
-                s_desc[wave][lane] = ok ? (e0 + 1 - (u64)k - gap) : ~0ull;
+                s_desc[wave][lane] = ok ? (((e0 + 1 - (u64)k - gap) & ((1ull << 55) - 1)) | ((u64)SW_B << 59)) : ~0ull;
                 if (!HASH && ok && (hist & ((1ull << (k + SW_B - 1)) - 1)) != 0) illegal = true;
                 if (!ok && !dead && e0s + (SW_B - 1) >= (long long)e_lo && e0s < (long long)e_hi) {
-                    // the row touches a record or strip boundary: the owner writes what is valid, value by value
+                    // k <= 16: a row can hold windows of several records: the owner writes what is valid, value by value
                     for (int q = 0; q < SW_B; q++) {
                         const long long es = e0s + q;
                         if (es < (long long)e_lo || es >= (long long)e_hi) continue;
@@ -943,17 +974,31 @@ __global__ __launch_bounds__(SW_NT) __attribute__((amdgpu_waves_per_eu(HASH ? 3 
                         }
                     }
                 }
+                }
                 __builtin_amdgcn_wave_barrier();
 #pragma unroll
                 for (int m = 0; m < 8; m++) {
                     const int strip = m * 8 + (lane >> 3), pr = lane & 7;
-                    const u64 d = s_desc[wave][strip];
-                    if (d != ~0ull && (SW_ABL != 1 || d == 12345ull)) {
+                    const u64 dd = s_desc[wave][strip];
+                    if (dd != ~0ull && (SW_ABL != 1 || dd == 12345ull)) {
+                        // descriptor: output index of slot 0 (55 bits) | first valid slot (4 bits) | end of the run (5 bits)
+                        const u32 qlo = (u32)(dd >> 55) & 15u, qhi = (u32)(dd >> 59);
+                        const u32 q0 = 2u * (u32)pr, q1 = q0 + 1;
+                        const bool w0 = q0 >= qlo && q0 < qhi, w1 = q1 >= qlo && q1 < qhi;
                         const u64 *src = &s_row[wave][strip * SW_ROW + 2 * pr];
                         const u64 v0 = src[0], v1 = src[1];
-                        U4a4 st;
-                        st.x = (u32)v0; st.y = (u32)(v0 >> 32); st.z = (u32)v1; st.w = (u32)(v1 >> 32);
-                        *reinterpret_cast<U4a4 *>(p.out + d + 2 * pr) = st;
+                        // (each slot's index is reduced on its own: slot 0 of a row that starts in front of its
+                        //  record's first window has a "negative" index, and -1 + 1 must come out as 0)
+                        const u64 i0 = (dd + q0) & ((1ull << 55) - 1), i1 = (dd + q1) & ((1ull << 55) - 1);
+                        if (w0 && w1) {
+                            U4a4 st;
+                            st.x = (u32)v0; st.y = (u32)(v0 >> 32); st.z = (u32)v1; st.w = (u32)(v1 >> 32);
+                            *reinterpret_cast<U4a4 *>(p.out + i0) = st;
+                        } else if (w0) {
+                            p.out[i0] = v0;
+                        } else if (w1) {
+                            p.out[i1] = v1;
+                        }
                     }
                 }
                 __builtin_amdgcn_wave_barrier();
