@@ -16,6 +16,17 @@ __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
 typedef const u64 __attribute__((address_space(4))) ukm_const_u64;
 __device__ __forceinline__ u64 sload_u64(const u64 *p) { return *(ukm_const_u64 *)(uintptr_t)p; }
 
+// A pointer that was fetched from a table in memory (streams of an n-way operation) is a GENERIC pointer to the
+// compiler, and loads through it are FLAT loads: they count in vmcnt AND lgkmcnt, so every LDS wait behind them
+// (s_waitcnt lgkmcnt(0)) also waits for the global data -- a prefetch that is supposed to fly during LDS work does not.
+// All such pointers are device memory here: say so.
+template <typename T>
+using ukm_gptr = const T __attribute__((address_space(1))) *;
+template <typename T>
+__device__ __forceinline__ ukm_gptr<T> as_global(const T *p) {
+    return (ukm_gptr<T>)(uintptr_t)p;
+}
+
 // ---- wave64 scans ---------------------------------------------------------------------------
 // Inclusive scan across the 64 lanes with DPP row shifts / row broadcasts (gfx9 DPP controls:
 // row_shr:n = 0x110+n, row_bcast:15 = 0x142, row_bcast:31 = 0x143): six VALU adds, no LDS

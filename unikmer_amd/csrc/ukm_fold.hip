@@ -123,6 +123,12 @@ __device__ __forceinline__ void fd_search(const u64 *s_k, u32 m, const u64 (&key
     }
 }
 
+#ifdef FD_PROFILE
+#define FPH(i) do { if (tid == 0) { const u64 _t = clock64(); fph[i] += _t - flast; flast = _t; } } while (0)
+#else
+#define FPH(i) do {} while (0)
+#endif
+
 template <int OP, bool TAX>
 __global__ __launch_bounds__(FD_NT) __attribute__((amdgpu_waves_per_eu(TAX ? FD_WAVES_TAX : FD_WAVES_PLAIN, TAX ? FD_WAVES_TAX : FD_WAVES_PLAIN)))
 void fd_fold_kernel(FoldArgs a) {
@@ -135,17 +141,29 @@ void fd_fold_kernel(FoldArgs a) {
     const bool mix = (a.flags & UKM_F_MIX_TAXID) != 0;
     const bool cmp = (a.flags & UKM_F_CMP_TAXID) != 0;
     u32 bad = 0;
-    // tables written before this launch: scalar loads, scheduled by the compiler (sload_u64)
-    auto file_meta = [&](u32 j) -> FdFile {
+    // Tables written before this launch: SCALAR loads through the constant address space (sload_u64), issued one file
+    // ahead.  (Vector loads from the uniform address + readfirstlane were tried to get the words out of lgkmcnt's way:
+    // no gain in the phase counters, and wrong metadata once slices needed several chunks -- not understood, dropped.)
+    struct FdRaw { u64 lo, hi, k, t; };
+    auto meta_issue = [&](u32 j) -> FdRaw {
         const u32 jj = j < S ? j : S - 1;  // (one past the end: a harmless reload of the last entry)
+        FdRaw w;
+        const u64 *c = a.cuts + ((size_t)r * S + jj) * 2, *m = a.meta + 2 * (size_t)jj;
+        w.lo = sload_u64(c);
+        w.hi = sload_u64(c + 1);
+        w.k = sload_u64(m);
+        w.t = sload_u64(m + 1);
+        return w;
+    };
+    auto meta_take = [&](const FdRaw &w) -> FdFile {
         FdFile f;
-        const u64 *c = a.cuts + ((size_t)r * S + jj) * 2;
-        f.lo = sload_u64(c);
-        f.hi = sload_u64(c + 1);
-        f.k = (const u64 *)(uintptr_t)sload_u64(a.meta + 2 * (size_t)jj);
-        f.t = (const u32 *)(uintptr_t)sload_u64(a.meta + 2 * (size_t)jj + 1);
+        f.lo = w.lo;
+        f.hi = w.hi;
+        f.k = (const u64 *)(uintptr_t)w.k;
+        f.t = (const u32 *)(uintptr_t)w.t;
         return f;
     };
+    auto file_meta = [&](u32 j) -> FdFile { return meta_take(meta_issue(j)); };
 
     // ---- survivors: this range's records of the first file, FD_SPT consecutive ones per thread ----------------------
     u64 sk[FD_SPT];
@@ -157,15 +175,15 @@ void fd_fold_kernel(FoldArgs a) {
         const u64 first = f0.lo + (u64)tid * FD_SPT;
         u64 prev = 0;
         bool has_prev = false;
-        if (first > 0 && first < n0) { prev = f0.k[first - 1]; has_prev = true; }
+        if (first > 0 && first < n0) { prev = as_global(f0.k)[first - 1]; has_prev = true; }
 #pragma unroll
         for (int i = 0; i < FD_SPT; i++) {
             const u64 g = first + i;
             sk[i] = 0;
             st[i] = 0;
             if (g < n0) {
-                sk[i] = f0.k[g];
-                if (TAX && f0.t) st[i] = f0.t[g];
+                sk[i] = as_global(f0.k)[g];
+                if (TAX && f0.t) st[i] = as_global(f0.t)[g];
                 alive |= 1u << i;
                 if (has_prev) {
                     if (prev > sk[i]) bad |= FD_FLAG_UNSORTED;
@@ -184,15 +202,16 @@ void fd_fold_kernel(FoldArgs a) {
     u64 pk[FD_LPT];
     u32 pt[FD_LPT];
     u32 nj = 1;              // file of the pending chunk
-    FdFile cur = file_meta(1), nxt = file_meta(2);
+    FdFile cur = file_meta(1);
+    FdRaw nxt = meta_issue(2);  // consumed one file later
     u64 npos = cur.lo;       // first record of the pending chunk
     bool kill_all = false;   // inter: a file without a single record in this range empties it
     auto skip_empty = [&]() {
         while (nj < S && cur.lo >= cur.hi) {
             if (OP == UKM_OP_INTER) kill_all = true;
             nj++;
-            cur = nxt;
-            nxt = file_meta(nj + 1);
+            cur = meta_take(nxt);
+            nxt = meta_issue(nj + 1);
         }
         npos = cur.lo;
     };
@@ -203,8 +222,8 @@ void fd_fold_kernel(FoldArgs a) {
             const u32 slot = (u32)tid + (u32)q * FD_NT;
             const bool ok = slot <= m && (slot > 0 || npos > 0);
             const u64 g = ok ? npos + slot - 1 : 0;
-            pk[q] = cur.k[g];  // (record 0 is always mapped: the slice is not empty)
-            if (TAX) pt[q] = cur.t ? cur.t[g] : 0u;
+            pk[q] = as_global(cur.k)[g];  // (record 0 is always mapped: the slice is not empty); GLOBAL loads, see as_global
+            if (TAX) pt[q] = cur.t ? as_global(cur.t)[g] : 0u;
         }
     };
     skip_empty();
@@ -220,6 +239,10 @@ void fd_fold_kernel(FoldArgs a) {
     u32 files_done = 0;  // files finished since the counter was last looked at (parity selects the counter word)
     bool file_ended = false;
     if (tid < 2) s_alive[tid] = 0;
+#ifdef FD_PROFILE
+    u64 fph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    u64 flast = clock64();
+#endif
 
     while (nj < S) {
         // (A) commit the pending chunk
@@ -228,6 +251,7 @@ void fd_fold_kernel(FoldArgs a) {
         const bool has_halo = cpos > 0;
         const bool last_of_file = cpos + m >= cur.hi;
         __syncthreads();  // the searches of the previous chunk are done
+        FPH(0);
         if (file_ended) {
             // re-pack?  (the count was accumulated behind the previous file's rule; one LDS word, read by all)
             const u32 word = (files_done - 1) & 1u;
@@ -262,23 +286,27 @@ void fd_fold_kernel(FoldArgs a) {
             if (tid == 0) s_alive[word ^ 1u] = 0;  // the OTHER word: nobody reads it now, the file in progress adds to it
             file_ended = false;
         }
+        FPH(1);
 #pragma unroll
         for (int q = 0; q < FD_LPT; q++) {
             const u32 slot = (u32)tid + (u32)q * FD_NT;
             s_k[slot] = pk[q];
             if (TAX) s_t[slot] = pt[q];
         }
+        FPH(2);
         // (B) the next chunk starts travelling before this one is searched
         if (last_of_file) {
             nj++;
-            cur = nxt;
-            nxt = file_meta(nj + 1);
+            cur = meta_take(nxt);
+            nxt = meta_issue(nj + 1);
             skip_empty();
         } else {
             npos += m;
         }
         if (nj < S) issue();
+        FPH(3);
         __syncthreads();
+        FPH(4);
         // (C) strict order of what was staged (the halo ties the chunk to the record in front of it)
 #ifndef FD_ABL_NOCHECK  /* ablation builds only (tools/build_variant_any.sh fold ...) */
 #pragma unroll
@@ -291,6 +319,7 @@ void fd_fold_kernel(FoldArgs a) {
             }
         }
 #endif
+        FPH(5);
 #ifndef FD_ABL_NOSEARCH
         // (D) every survivor looks itself up in records [1, m] -- all of a thread's searches in LOCK STEP (a fixed
         //     descent over power-of-two strides, no data-dependent branch): the FD_SPT chains of dependent LDS reads
@@ -319,14 +348,15 @@ void fd_fold_kernel(FoldArgs a) {
             }
         }
 #endif
+        FPH(6);
         // (E) behind a file's last chunk: the reference's rule for this file.  The LCAs of four survivors are in
         //     flight together (lca_begin / lca_finish): a thread's pairs are independent random reads.
         if (last_of_file) {
 #pragma unroll
             for (int g0 = 0; g0 < FD_SPT; g0 += FD_LCAB) {
                 if ((u32)g0 >= spt_now) break;  // workgroup-uniform
-                LcaReq rq[FD_LCAB];
                 bool need[FD_LCAB];
+                bool any_need = false;
 #pragma unroll
                 for (int u = 0; u < FD_LCAB; u++) {
                     const int i = g0 + u;
@@ -335,9 +365,16 @@ void fd_fold_kernel(FoldArgs a) {
                     const u32 ta = st[i], tb = ft[i];
                     if (OP == UKM_OP_INTER) need[u] = TAX && hit && !(mix && (ta == 0 || tb == 0));
                     else need[u] = TAX && cmp && hit && ta != tb;
-                    if (TAX) {
-                        if (OP == UKM_OP_INTER) lca_begin(a.T, need[u] ? ta : 0u, tb, rq[u]);
-                        else lca_begin(a.T, need[u] ? tb : 0u, ta, rq[u]);
+                    any_need |= need[u];
+                }
+                LcaReq rq[FD_LCAB];
+                const bool lca_round = TAX && __ballot(any_need) != 0;  // wave-uniform: no lane needs one -> no LCA code at all
+                if (lca_round) {
+#pragma unroll
+                    for (int u = 0; u < FD_LCAB; u++) {
+                        const int i = g0 + u;
+                        if (OP == UKM_OP_INTER) lca_begin(a.T, need[u] ? st[i] : 0u, ft[i], rq[u]);
+                        else lca_begin(a.T, need[u] ? ft[i] : 0u, st[i], rq[u]);
                     }
                 }
 #pragma unroll
@@ -351,13 +388,12 @@ void fd_fold_kernel(FoldArgs a) {
                         if (!hit) {
                             alive &= ~bit;
                         } else if (TAX) {
-                            if (need[u]) st[i] = lca_finish(a.T, rq[u]);
-                            else if (mix) st[i] = (ta == 0) ? tb : ta;  // (tb == 0 here when ta != 0)
-                            else st[i] = lca_finish(a.T, rq[u]);
+                            if (need[u]) st[i] = lca_round ? lca_finish(a.T, rq[u]) : 0u;  // (need implies lca_round)
+                            else st[i] = (ta == 0) ? tb : ta;  // mix-taxid with a missing side (tb == 0 when ta != 0)
                         }
                     } else if (hit) {
                         bool keep = false;
-                        if (TAX && cmp) keep = (ta == tb) || (need[u] && lca_finish(a.T, rq[u]) == ta);  // diff.go:404-409
+                        if (TAX && cmp) keep = (ta == tb) || (need[u] && lca_round && lca_finish(a.T, rq[u]) == ta);  // diff.go:404-409
                         if (!keep) alive &= ~bit;
                     }
                 }
@@ -373,7 +409,16 @@ void fd_fold_kernel(FoldArgs a) {
             files_done++;
             file_ended = true;
         }
+        FPH(7);
     }
+#ifdef FD_PROFILE
+    if (tid == 0 && (r == 0 || r == a.R / 2)) {
+        printf("[fold r=%u] cycles per step: topbar=%llu repack=%llu commit=%llu meta+issue=%llu bar=%llu check=%llu search=%llu rule=%llu (steps %u)\n", r,
+               (unsigned long long)(fph[0] / (S - 1)), (unsigned long long)(fph[1] / (S - 1)), (unsigned long long)(fph[2] / (S - 1)),
+               (unsigned long long)(fph[3] / (S - 1)), (unsigned long long)(fph[4] / (S - 1)), (unsigned long long)(fph[5] / (S - 1)),
+               (unsigned long long)(fph[6] / (S - 1)), (unsigned long long)(fph[7] / (S - 1)), S - 1);
+    }
+#endif
     if (OP == UKM_OP_INTER && kill_all) alive = 0;
 
     // ---- survivors of the range, compacted in order ----------------------------------------------------------------
@@ -506,6 +551,9 @@ int ukm_dev_range_fold(ukm_ctx *c, int op, const u64 *const *keys, const u32 *co
     UKM_HIP(hipGetLastError());
     u64 h[2] = {0, 0};
     UKM_TRY(ukm_read_u64(c, a.ctl, h, 2));
+    if (getenv("UKM_FOLD_DEBUG"))
+        fprintf(stderr, "[fold] op=%d S=%d R=%u range_len=%llu slots=%llu tax=%d flags=%llu out=%llu\n", op, S, R,
+                (unsigned long long)range_len, (unsigned long long)slots, (int)tax, (unsigned long long)h[1], (unsigned long long)h[0]);
     if (h[1] & FD_FLAG_UNSORTED) UKM_FAIL(UKM_ERR_UNSORTED, "ukm_setop2: an input stream is not sorted");
     if (h[1] & FD_FLAG_DUP) {
         *fallback = true;

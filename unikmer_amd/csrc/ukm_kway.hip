@@ -297,11 +297,11 @@ __global__ __launch_bounds__(NT, KW_WAVES) void kway_kernel(KwArgs p) {
             KwMap<K, NT, VT>::at(t, i, slot, e);
             const bool valid = (u64)e < s_rem[slot];
             const u64 *src = s_ptr[slot];
-            kk[i] = *(valid ? src + e : safe);
+            kk[i] = *as_global(valid ? src + e : safe);  // GLOBAL, not FLAT loads (ukm_device.h: as_global)
             if (TAX) {
                 const u32 *ts = s_tptr[slot];
                 const bool tv = valid && ts != nullptr;
-                tt[i] = *(tv ? ts + e : reinterpret_cast<const u32 *>(safe));
+                tt[i] = *as_global(tv ? ts + e : reinterpret_cast<const u32 *>(safe));
                 tt[i] = tv ? tt[i] : 0u;
             }
         }
