@@ -108,10 +108,28 @@ struct FdFile {  // what a workgroup needs to know about its slice of one file (
 // in LOCK STEP: a fixed descent over power-of-two strides without a data-dependent branch, so the N chains of dependent
 // LDS reads overlap and the whole search costs one chain's latency.  (N is a template argument on purpose: with
 // `if (i < spt_now)` around each slot the bodies became separate basic blocks and ran one after the other.)
+#ifndef FD_SEARCH_ARITY
+#define FD_SEARCH_ARITY 2  /* 4: measured slower (15.1 against 10.6 ms on config 4-core: three probes per round cost more VALU than the halved rounds save, and the taxid build spills at 256 VGPRs) */
+#endif
 template <int N, int SPT>
 __device__ __forceinline__ void fd_search(const u64 *s_k, u32 m, const u64 (&key)[SPT], u32 (&cnt)[SPT]) {
 #pragma unroll
     for (int i = 0; i < N; i++) cnt[i] = 0;
+#if FD_SEARCH_ARITY == 4
+    // 4-ary descent: three independent probes per round, six rounds for a chunk of up to 4095 records instead of twelve
+    // binary ones -- the kernel runs at 2 waves per SIMD, where a round is a bare LDS latency + its dependent VALU chain
+    u32 stride = 1;
+    while (4ull * stride <= m) stride <<= 2;  // largest power of four <= m (m >= 1: the slice is not empty)
+    for (; stride; stride >>= 2) {
+#pragma unroll
+        for (int i = 0; i < N; i++) {
+            const u32 t1 = cnt[i] + stride, t2 = t1 + stride, t3 = t2 + stride;
+            const u64 k1 = s_k[t1 <= m ? t1 : m], k2 = s_k[t2 <= m ? t2 : m], k3 = s_k[t3 <= m ? t3 : m];
+            const u32 c = (u32)(t1 <= m && k1 < key[i]) + (u32)(t2 <= m && k2 < key[i]) + (u32)(t3 <= m && k3 < key[i]);
+            cnt[i] += c * stride;  // (sorted chunk: the three answers are monotone)
+        }
+    }
+#else
     for (u32 stride = m ? (1u << (31 - __builtin_clz(m))) : 0u; stride; stride >>= 1) {
 #pragma unroll
         for (int i = 0; i < N; i++) {
@@ -121,6 +139,7 @@ __device__ __forceinline__ void fd_search(const u64 *s_k, u32 m, const u64 (&key
             cnt[i] = (t <= m && below) ? t : cnt[i];
         }
     }
+#endif
 }
 
 #ifdef FD_PROFILE
