@@ -1,5 +1,6 @@
 #!/bin/bash
-# developer tool (GPU box): set-op kernel variants at 2 x 1e9 keys.  args: "ENV=.. [ENV=..] [lib=TAG]" per variant
+# developer tool (GPU box): set-op kernel timings at 2 x 1e9 keys, one line per variant.  Each argument is one variant:
+# "ENV=.. [ENV=..] [lib=TAG]" (environment knobs and / or an experimental library built by tools/build_variant_any.sh)
 cd $GRAFT_REPO_ROOT
 for v in "$@"; do
   echo "== $v"
