@@ -626,6 +626,32 @@ def test_device_tensors_roundtrip(ctx, O, L):
     assert ctx.last_kernel_ms() > 0
 
 
+def test_setop2_device_views_every_alignment(ctx, O, L):
+    """Interior tiles are staged by LDS-DMA in 16-byte units (round 3), so the kernel lays its tile out by the PARITY of
+    every input's 8-byte address; the outputs go out in 16-byte stores where their address allows.  Device views that
+    start on every combination of odd / even 8-byte slots (inputs and output), at a size with hundreds of interior
+    tiles, must give the oracle's result."""
+    import torch
+    A, B = synth_sets(4_000_000, 22)
+    u, i, d = O.union([A, B]), O.inter([A, B]), O.diff([A, B])
+    dev = torch.device("cuda", 0)
+    pad = 3
+    bufa = torch.zeros(len(A) + pad, dtype=torch.int64, device=dev)
+    bufb = torch.zeros(len(B) + pad, dtype=torch.int64, device=dev)
+    bufo = torch.zeros(len(A) + len(B) + pad, dtype=torch.int64, device=dev)
+    for oa in (0, 1):
+        for ob in (0, 1, 2):
+            for oo in (0, 1):
+                ta, tb = bufa[oa:oa + len(A)], bufb[ob:ob + len(B)]
+                ta.copy_(torch.from_numpy(A.view(np.int64)))
+                tb.copy_(torch.from_numpy(B.view(np.int64)))
+                torch.cuda.synchronize()
+                for op, exp in ((L.OP_UNION, u), (L.OP_INTER, i), (L.OP_DIFF, d)):
+                    got = ctx.setop2(op, ta, tb, out=bufo[oo:])
+                    assert got.data_ptr() == bufo.data_ptr() + 8 * oo
+                    assert np.array_equal(got.cpu().numpy().view(np.uint64), exp), (oa, ob, oo, op)
+
+
 def test_partition_points(ctx):
     A, _ = synth_sets(100_000, 22)
     sp = np.array([0, A[10], A[10] + np.uint64(1), A[-1], 2**63], dtype=np.uint64)
