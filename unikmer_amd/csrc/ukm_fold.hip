@@ -21,6 +21,7 @@
 // rounds 1-2 (multiset semantics need the rank path).  Algorithmic bytes: 8 (+4) per input record read + the
 // survivors written twice (temporary + gather).
 #include <algorithm>
+#include <atomic>
 #include <cstdlib>
 #include <vector>
 
@@ -500,9 +501,9 @@ int ukm_dev_range_fold(ukm_ctx *c, int op, const u64 *const *keys, const u32 *co
     if (tax && !tout) UKM_FAIL(UKM_ERR_INVALID, "range fold: taxids given but out_taxids is NULL");
     // Range length: the whole fold is ONE round of resident workgroups when the first file allows it (a step costs a
     // latency, not a bandwidth: ~1000 dependent steps per workgroup, so a second round of workgroups doubles the time).
-    static int slots_cache[4] = {0, 0, 0, 0};
+    static std::atomic<int> slots_cache[4];  // (zero-initialised; racing first calls compute the same value)
     const int vi = (op == UKM_OP_INTER ? 0 : 2) + (tax ? 1 : 0);
-    if (!slots_cache[vi]) {
+    if (!slots_cache[vi].load(std::memory_order_relaxed)) {
         int per_cu = 0;
         hipError_t e;
         if (vi == 0) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fd_fold_kernel<UKM_OP_INTER, false>, FD_NT, 0);
@@ -510,9 +511,9 @@ int ukm_dev_range_fold(ukm_ctx *c, int op, const u64 *const *keys, const u32 *co
         else if (vi == 2) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fd_fold_kernel<UKM_OP_DIFF, false>, FD_NT, 0);
         else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fd_fold_kernel<UKM_OP_DIFF, true>, FD_NT, 0);
         if (e != hipSuccess || per_cu <= 0) per_cu = 2;
-        slots_cache[vi] = per_cu * c->num_cu;
+        slots_cache[vi].store(per_cu * c->num_cu, std::memory_order_relaxed);
     }
-    const u64 slots = (u64)slots_cache[vi];
+    const u64 slots = (u64)slots_cache[vi].load(std::memory_order_relaxed);
     u64 range_len = (lens[0] + slots - 1) / slots;
     range_len = std::max<u64>(range_len, FD_RANGE_MIN);
     range_len = std::min<u64>((range_len + FD_SPT - 1) / FD_SPT * FD_SPT, FD_RANGE_MAX);
