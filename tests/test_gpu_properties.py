@@ -247,3 +247,44 @@ def test_window_strip_kernel_equals_general_kernel_large(env, monkeypatch):
                 assert bool((c == a).all())
                 del c
             del a, b
+
+
+def test_range_fold_equals_chained_fold_large(env, monkeypatch):
+    """inter / diff / diff -t over 9 files of ~1.4e7 codes with taxids: the range-partitioned fold kernel (one launch;
+    5000+ ranges = several rounds of workgroups, slices of several chunks where a file is denser than the first one)
+    against the chained 2-way tile kernels of rounds 1-2 (UKM_NO_FOLD=1) -- two independent device paths, same stream."""
+    torch, bench, lib, ctx, A, B = env
+    from conftest import synth_tree
+    child, parent = synth_tree(6, 8)
+    ctx.taxonomy_load(child, parent)
+    T = len(child)
+    dev = A.device
+    nu = 20_000_000
+    j = torch.arange(nu, dtype=torch.int64, device=dev)
+    U = torch.cumsum(1 + (bench.splitmix64_torch(j ^ bench._i64(bench.SEED + 9)) & ((1 << 30) - 1)), 0)
+    core = (bench.splitmix64_torch(j ^ bench._i64(bench.SEED + 77)) & 7) < 3
+    files, taxs = [], []
+    for f in range(9):
+        h = bench.splitmix64_torch(j ^ bench._i64(bench.SEED + 1000 * (f + 1)))
+        p = 0.55 if f == 0 else (0.95 if f == 4 else 0.7)          # file 4 is much denser than the first: multi-chunk slices
+        m = (((h >> 11) & ((1 << 20) - 1)) < int(p * (1 << 20))) | core
+        k = U[m]
+        files.append(k)
+        taxs.append((1 + (bench.splitmix64_torch(k ^ bench._i64(bench.SEED + 2 + f)) & ((1 << 40) - 1)) % T).to(torch.int32))
+    del j, h, m, core
+    torch.cuda.synchronize()
+    res = {}
+    for mode in ("fold", "chain"):
+        if mode == "chain":
+            monkeypatch.setenv("UKM_NO_FOLD", "1")
+        else:
+            monkeypatch.delenv("UKM_NO_FOLD", raising=False)
+        ik, it = ctx.inter(files, taxs)
+        dk, dt = ctx.diff(files, taxs)
+        ck, ct = ctx.diff(files, taxs, compare_taxid=True)
+        pk = ctx.inter(files)
+        res[mode] = [x.clone() for x in (ik, it, dk, dt, ck, ct, pk)]
+    monkeypatch.delenv("UKM_NO_FOLD", raising=False)
+    assert res["fold"][0].numel() > 1_000_000 and res["fold"][2].numel() > 10 and res["fold"][4].numel() > res["fold"][2].numel()
+    for a, b in zip(res["fold"], res["chain"]):
+        assert a.numel() == b.numel() and bool((a == b).all())
