@@ -192,6 +192,26 @@ def test_config4_chain_multi_tile_links(env):
     _check_all(O, L, ctx, tax, files, taxs, expect_nonempty_inter=True)
 
 
+def test_fold_shapes_tiny_first_file_and_dense_later_files(env):
+    """shapes at the edge of the range fold's eligibility: a first file of a few records against much larger files (the
+    fold would stream whole files through one workgroup: the chained per-file kernels answer), and later files several
+    times denser than the first (slices of several chunks inside the fold)"""
+    O, L, ctx, tax, T = env
+    rng = np.random.default_rng(77)
+    U = np.cumsum(rng.integers(1, 1 << 20, 600_000).astype(np.uint64))
+    big = [U[rng.random(len(U)) < 0.8] for _ in range(6)]
+    tiny = np.sort(rng.choice(U, 40, replace=False))
+    sparse = U[rng.random(len(U)) < 0.1]
+    for first in (tiny, sparse):
+        files = [first] + big
+        taxs = [_taxids(f, T, i) for i, f in enumerate(files)]
+        for fn, ofn in ((ctx.inter, O.inter), (ctx.diff, O.diff)):
+            gk, gt = fn(files, taxs)
+            ok, ot = ofn(files, taxs, tax)
+            assert np.array_equal(gk, ok) and np.array_equal(gt, ot)
+            assert np.array_equal(fn(files), ofn(files))
+
+
 def test_config4_chain_with_duplicates_falls_back(env):
     """a multiset file inside a long chain: the chained fold reports it and the synchronous fold (rank path,
     'equality advances both cursors') takes over"""

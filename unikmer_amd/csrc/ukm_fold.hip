@@ -520,6 +520,20 @@ int ukm_dev_range_fold(ukm_ctx *c, int op, const u64 *const *keys, const u32 *co
     const u64 R64 = (lens[0] + range_len - 1) / range_len;
     if (R64 > 0x7FFFFFFFull) UKM_FAIL(UKM_ERR_INVALID, "range fold: first stream too large");
     const u32 R = (u32)R64;
+    {
+        // A workgroup walks ITS slice of every file chunk by chunk, ~7 us per chunk.  That is the right trade when the
+        // slices are about as long as the range (files comparable to the first one).  A tiny first file against huge
+        // later ones would make a handful of workgroups stream whole files through one CU each (10 records against
+        // 1000 files of 1e6: one workgroup, 4e5 chunks, seconds) -- the per-file 2-way kernels use the whole chip for
+        // that shape.  Not eligible: the caller's chained fold answers.
+        u64 rest = 0;
+        for (int j = 1; j < S; j++) rest += lens[j];
+        const u64 avg_slice = rest / (u64)(S - 1) / R64;
+        if (avg_slice > 4ull * FD_CH) {
+            *fallback = true;
+            return UKM_OK;
+        }
+    }
 
     // device tables: [meta S x 2][lens S]
     const size_t ntab = (size_t)3 * S;

@@ -362,8 +362,9 @@ int fold_chained(ukm_ctx *ctx, int op, const std::vector<Stream> &ss, u32 flags,
 
 // `inter` / `diff` over many files as ONE range-partitioned launch (ukm_fold.hip) instead of one link per file.
 // ss[0] is the running result's start; empty later files have already been handled by the caller's rule (inter:
-// the list ends in front of the first one; diff: they are dropped).  *done = false: not eligible, or the kernel saw
-// a duplicate code (the exact multiset route of the chained / synchronous fold answers then).
+// the list ends in front of the first one; diff: they are dropped).  *done = false: not eligible (too few files, a
+// first file that is too large or far smaller than the others), or the kernel saw a duplicate code (the exact
+// multiset route of the chained / synchronous fold answers then).
 constexpr u64 FOLD_MAX_FIRST = 1ull << 24;  // larger first files: the 2-way tile kernel streams them faster per link
 int try_range_fold(ukm_ctx *ctx, int op, const std::vector<Stream> &ss, u32 flags, bool tax, u64 *fk, u32 *ft, u64 fcap,
                    u64 *n_out, bool *done) {

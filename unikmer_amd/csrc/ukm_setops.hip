@@ -584,8 +584,11 @@ __device__ __forceinline__ void tile_flush(const SetopArgs &p, int tid, u64 base
 // 512-thread workgroup: the plain kernel came out at 129 with its two load paths, the union with taxids at 131 once
 // the LCA grew -- one workgroup per CU, union with taxids 1.45 -> 1.92 ms).  Taxids AND ranks (106 KB of LDS, one
 // workgroup per CU anyway) keep the default budget.
+#ifndef SETOP_WAVES
+#define SETOP_WAVES 4  /* experiments only: 6 = three workgroups per CU (needs SETOP_VT <= 12) */
+#endif
 template <int OP, bool TAX, bool RANK, bool TICKET, int NTH, int VT>
-__global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu((TAX && RANK) ? 2 : 4, (TAX && RANK) ? 8 : 4)))
+__global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu((TAX && RANK) ? 2 : SETOP_WAVES, (TAX && RANK) ? 8 : SETOP_WAVES)))
 void setop_tile_kernel(SetopArgs p) {
     constexpr int TILE = NTH * VT;
     constexpr int SLOTS = TILE + 8;
