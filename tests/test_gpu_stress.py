@@ -276,3 +276,44 @@ def test_random_nway_with_taxids(env, seed):
             gk, gt = ctx.inter(files, mixed, mix_taxid=True)
             ek, et = O.inter(files, mixed, tax, mix_taxid=True)
             assert np.array_equal(gk, ek) and np.array_equal(gt, et), (seed, it, "inter -m", drop)
+
+
+@pytest.mark.parametrize("seed", _seeds(3))
+def test_strip_windows_on_ragged_reads(env, seed, monkeypatch):
+    """Reads through the strip kernel: every lane shifts its strip for the record it starts in, so with records of
+    80-260 bases every lane has its own shift, shifts reach back into the previous record, most strips cross a
+    record boundary and rows are cut at both ends — codes and ntHash against the oracle for k on both sides of 16 /
+    32, both strip lengths, with reads shorter than k and empty ones in between."""
+    O, L, ctx, tax, T = env
+    rng = np.random.default_rng(9100 + seed)
+    monkeypatch.setenv("UKM_WIN_STRIP", "1")
+    n_target = 1_500_000
+    lens = rng.integers(80, 261, n_target // 170)
+    lens[rng.integers(0, len(lens), len(lens) // 40)] = rng.integers(0, 34, len(lens) // 40)   # shorter than k, empty
+    if seed % 2:
+        lens[:] = 150   # fixed-length reads: every record's gap step is k - 1
+    cuts = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    n = int(cuts[-1])
+    bases = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, n)]
+    for Ls in ("64", "128"):
+        monkeypatch.setenv("UKM_WIN_STRIP_L", Ls)
+        for k in (9, 16, 17, 30, 31, 32):
+            canon = bool(rng.integers(0, 2))
+            assert np.array_equal(ctx.encode_kmers(bases, cuts, k, canonical=canon),
+                                  O.count_windows(bases, cuts, k, canonical=canon)), (seed, "codes", k, canon, Ls)
+        for kh in (15, 33, 50, 51, 64):
+            canon = bool(rng.integers(0, 2))
+            assert np.array_equal(ctx.nthash(bases, cuts, kh, canonical=canon),
+                                  O.count_windows(bases, cuts, kh, hashed=True, canonical=canon)), (seed, "nthash", kh, canon, Ls)
+    # an illegal base in a read that is emitted / in one that is shorter than k
+    monkeypatch.delenv("UKM_WIN_STRIP_L", raising=False)
+    long_r = int(np.argmax(lens >= 80))
+    bad = bases.copy()
+    bad[int(cuts[long_r]) + 40] = ord("*")
+    with pytest.raises(L.IllegalBaseError):
+        ctx.encode_kmers(bad, cuts, 31)
+    short = np.flatnonzero((lens > 0) & (lens < 31))
+    if len(short):
+        bad = bases.copy()
+        bad[int(cuts[short[0]])] = ord("*")
+        assert np.array_equal(ctx.encode_kmers(bad, cuts, 31), O.count_windows(bad, cuts, 31))

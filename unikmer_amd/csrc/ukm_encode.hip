@@ -764,9 +764,10 @@ int run_strip_filter(ukm_ctx *c, const u8 *bases, const u64 *rec_off, u64 n_rec,
 // step i of the unrolled loop always fills slot i & 15 of the lane's LDS row whatever k is.  Every 16 steps
 // the wave turns its 64 rows x 16 values around: eight lanes write one row's 128 bytes with 16-byte stores.
 // Neighbouring lanes work 8L bytes apart, so what matters is that every row is one whole, ALIGNED cache line
-// of the output (measured: rows that straddle lines cost 2.3 x): the tile's strips start `sh` (< 16)
-// positions early so that the first record's output index of a row start is a multiple of 16; the first lane
-// skips what belongs to the previous tile, the last wave runs 16 steps longer to reach the tile's end.
+// of the output (measured: rows that straddle lines cost 2.3 x; on 150-bp reads, k = 31: rows on 128 / 64 / 32 /
+// 16 / 8-byte boundaries 0.206 / 0.230 / 0.30 / 0.33 / 0.35 ms per 1e8 windows): every lane starts its strip `sh`
+// (< 16) positions early so that the output index of its row starts is a multiple of 16 in the record it starts
+// in; the tile's first lane skips what belongs to the previous tile, every wave runs 16 steps longer.
 // All record logic (is the window inside one record, where does it go) happens once per row, not per window:
 // a row that lies inside one record gets its output index published; a row that touches a record or strip
 // boundary (rare for long records) is written by its owner lane value by value.
@@ -832,21 +833,47 @@ __global__ __launch_bounds__(SW_NT) __attribute__((amdgpu_waves_per_eu(HASH ? 3 
         s_gap[j] = (u32)((ro - p.out_off[r0 + j]) - gap_first);
     }
     __syncthreads();
-    // output index of the window that ends at e (inside record r) = e + 1 - k - gap[r]; shift the strips so that it
-    // is a multiple of 16 at every row start of the tile's first record
-    const u32 sh = (u32)(P0 + 1 - (u64)k - gap_first) & (u32)(SW_B - 1);
-    const long long s0 = (long long)P0 - (long long)sh + (long long)tid * L;  // first END position of this lane's rows
-    const u64 e_lo = s0 < (long long)P0 ? P0 : (u64)s0;                       // the lane emits END positions [e_lo, e_hi)
-    const u64 e_hi = tid == SW_NT - 1 ? P0 + TS : (u64)(s0 + L);
-    const bool active = e_lo < p.total_bases;
+    // output index of the window that ends at e (inside record r) = e + 1 - k - gap[r].  Every lane starts its strip
+    // `sh` (< 16) positions in front of its nominal start b = P0 + tid * L so that this index is a multiple of 16 at
+    // each of its row starts, FOR THE RECORD THAT HOLDS b: the lane's rows are then whole output lines until it walks
+    // into the next record (reads: 8 % of the rows of 64-position strips; one shift per tile, the first version, left
+    // every record but the tile's first one at the alignment its gap happens to have).  The boundaries between lanes
+    // move with the shifts (s_bnd); the tile's own boundaries stay where they are.
+    const u64 b_nom = P0 + (u64)tid * (u64)L;
+    u32 sh = 0, jb = 0;
+    bool active = b_nom < p.total_bases;
+    if (active) {
+        active = false;
+        u32 lo = 0, hi = (u32)nr + 1;  // first index with s_ro > b_nom (records of length 0 are skipped)
+        while (lo < hi) {
+            const u32 mid = (lo + hi) >> 1;
+            if (s_ro[mid] <= b_nom) lo = mid + 1; else hi = mid;
+        }
+        if (lo >= 1 && lo <= (u32)nr) {
+            active = true;
+            jb = lo - 1;
+            sh = (u32)(b_nom + 1 - (u64)k - (gap_first + (u64)s_gap[jb])) & (u32)(SW_B - 1);
+        }
+    }
+    u32 *s_bnd = reinterpret_cast<u32 *>(&s_desc[0][0]);  // first END position of every lane, relative to the tile
+    s_bnd[tid] = tid == 0 ? 0u : (u32)tid * (u32)L - sh;  // (tid >= 1: L >= 64 > sh)
+    __syncthreads();
+    const long long s0 = (long long)b_nom - (long long)sh;                  // first END position of this lane's rows
+    const u64 e_lo = P0 + (u64)s_bnd[tid];                                  // the lane emits END positions [e_lo, e_hi)
+    const u64 e_hi = P0 + (tid == SW_NT - 1 ? TS : (u64)s_bnd[tid + 1]);
+    __syncthreads();  // (s_bnd lives in the descriptor words)
     u32 j = 0;
     u64 rec_start = ~0ull, rec_end = 0, gap = 0;
     bool dead = !active;
     if (active) {
-        u32 lo = 0, hi = (u32)nr + 1;  // first index with s_ro > e_lo (records of length 0 are skipped)
-        while (lo < hi) {
-            const u32 mid = (lo + hi) >> 1;
-            if (s_ro[mid] <= e_lo) lo = mid + 1; else hi = mid;
+        u32 lo = jb + 1;
+        if (e_lo < s_ro[jb]) {  // the shift reached into the previous record
+            lo = 0;
+            u32 hi = jb + 1;
+            while (lo < hi) {
+                const u32 mid = (lo + hi) >> 1;
+                if (s_ro[mid] <= e_lo) lo = mid + 1; else hi = mid;
+            }
         }
         if (lo == 0 || lo > (u32)nr) dead = true;
         else { j = lo - 1; rec_start = s_ro[j]; rec_end = s_ro[j + 1]; gap = gap_first + (u64)s_gap[j]; }
@@ -855,7 +882,10 @@ __global__ __launch_bounds__(SW_NT) __attribute__((amdgpu_waves_per_eu(HASH ? 3 
     const bool canon = p.canonical != 0;
     const int WU = k <= 32 ? 32 : 64;     // warm-up steps in front of the strip (>= k)
     const int i_start = 64 - WU;          // step i reads the base at s0 - 64 + i
-    const int nsteps = 64 + L + (wave == SW_NWV - 1 ? SW_B : 0);
+    // a strip is up to 15 positions longer than L (its own shift, its neighbour's none): the wave runs one more row
+    // only if one of its lanes needs it (long records: every lane has the same shift, only the tile's last wave does)
+    const bool longer = active && e_hi > (u64)s0 + (u64)L;
+    const int nsteps = 64 + L + (__ballot(longer) != 0ull ? SW_B : 0);
     u64 fwd = 0, rc = 0, hist = 0;
     u32 flo = 0, fhi = 0, rlo = 0, rhi = 0;
     const u64 kmask = k >= 32 ? ~0ull : ((1ull << (2 * k)) - 1);
@@ -1019,14 +1049,13 @@ int run_strip_windows(ukm_ctx *c, bool hash, const u8 *bases, const u64 *rec_off
     if (force == 0) return UKM_OK;
     if (((uintptr_t)bases & 3) != 0 || (!hash && k > 32)) return UKM_OK;
     // small inputs have too few strips to fill the chip (measured cross-over: 8e6 bases for L = 64, 1.6e7 for L = 128;
-    // 1.6e7 bases: codes 0.042 ms against 0.060 ms for the general kernel); short records spend their time in the
-    // value-by-value path of rows that touch a record boundary
+    // 1.6e7 bases: codes 0.042 ms against 0.060 ms for the general kernel)
     const u64 min_bases = (k <= 32) ? (1ull << 23) : (1ull << 24);
-    // Records: the kernel also wins on short ones — 1e8 bases of 150-bp reads: codes 0.29 ms against 0.43 ms for the
-    // general kernel, ntHash k = 51 0.32 against 0.51 ms (every wave then has rows in the value-by-value path, still
-    // fewer instructions per window than the general kernel's 125) — as long as a tile's records fit its table (254
-    // per 256 x L positions, else the call falls back after one wasted launch): average length >= 80 bases for
-    // L = 64, >= 140 for L = 128.
+    // Records: the kernel also wins on short ones — 1e8 bases of 150-bp reads: codes 0.20 ms against 0.43 ms for the
+    // general kernel, ntHash k = 51 0.25 against 0.51 ms (0.29 / 0.32 ms with value-by-value boundary rows, 0.264 /
+    // 0.285 ms with one strip shift per tile, round 3) — as long as a tile's records fit its table (254 per 256 x L
+    // positions, else the call falls back after one wasted launch): average length >= 80 bases for L = 64, >= 140
+    // for L = 128.
     const u64 min_avg = (k <= 32) ? 80 : 140;
     if (force != 1 && (total_bases < min_bases || n_rec * min_avg > total_bases)) return UKM_OK;
     // several rounds of workgroups per CU matter more than the k - 1 warm-up steps per strip (measured at 1e8
