@@ -779,3 +779,34 @@ def test_c_example_client_runs(tmp_path):
     a = canon_set("ACGTTGCAAGGCTTAACCGGTTACGATCGATCGGCTAGCTAGGATCCGATCGTTAGC")
     b = canon_set("TTGCAAGGCTTAACCGGTTACGTTTTTTTTGATCGGCTAGCTAGGATCC")
     assert r.stdout.strip() == "k=11 |A|=%d |B|=%d |A u B|=%d |A n B|=%d" % (len(a), len(b), len(a | b), len(a & b))
+
+
+def test_setop2_partition_on_skewed_inputs(ctx, O, L):
+    """The merge-path partition brackets every split around an interpolated position (evenly spread keys); inputs
+    that are anything but evenly spread must only lose the two probes: disjoint value ranges in both orders, a dense
+    cluster of one set inside the other's range, one value repeated (multisets), sets of very different size, and a
+    geometric spread — several hundred tiles each, i.e. both partition levels, every operation against numpy."""
+    rng = np.random.default_rng(77)
+    n = 3_000_000
+
+    def uniq_sorted(x):
+        return np.unique(x.astype(np.uint64))
+
+    lowhalf = uniq_sorted(rng.integers(0, 1 << 40, n))
+    highhalf = uniq_sorted(rng.integers(1 << 41, 1 << 42, n))
+    wide = uniq_sorted(rng.integers(0, 1 << 62, n))
+    cluster = uniq_sorted((1 << 61) + rng.integers(0, 1 << 24, n))
+    geometric = uniq_sorted((rng.random(n) ** 8 * float(1 << 62)).astype(np.uint64))
+    tiny = uniq_sorted(rng.integers(0, 1 << 62, 1000))
+    cases = [(lowhalf, highhalf), (highhalf, lowhalf), (wide, cluster), (cluster, wide), (geometric, wide),
+             (wide, geometric), (tiny, wide), (wide, tiny), (geometric, geometric[::3].copy())]
+    for a, b in cases:
+        assert np.array_equal(ctx.setop2(L.OP_UNION, a, b), np.union1d(a, b))
+        assert np.array_equal(ctx.setop2(L.OP_INTER, a, b), np.intersect1d(a, b, assume_unique=True))
+        assert np.array_equal(ctx.setop2(L.OP_DIFF, a, b), np.setdiff1d(a, b, assume_unique=True))
+    # multisets: long runs of one value straddling many tiles (oracle semantics, util of union/inter/diff on multisets)
+    m1 = np.sort(np.concatenate([np.full(1_500_000, 7, np.uint64), wide[:1_000_000]]))
+    m2 = np.sort(np.concatenate([np.full(900_000, 7, np.uint64), cluster[:1_200_000], np.full(300_000, 1 << 61, np.uint64)]))
+    assert np.array_equal(ctx.setop2(L.OP_UNION, m1, m2), O.union([m1, m2]))
+    assert np.array_equal(ctx.setop2(L.OP_INTER, m1, m2), O.inter([m1, m2]))
+    assert np.array_equal(ctx.setop2(L.OP_DIFF, m1, m2), O.diff([m1, m2]))

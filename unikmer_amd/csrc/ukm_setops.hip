@@ -90,6 +90,12 @@ __device__ __forceinline__ bool key_eq(u64 ka, u32 ra, u64 kb, u32 rb) {
 #ifndef SETOP_PART_COARSE
 #define SETOP_PART_COARSE 64
 #endif
+#ifndef SETOP_PART_INTERP1
+#define SETOP_PART_INTERP1 (1 << 17)  // the same for the coarse level (whole-input diagonal): +-1 MB of keys
+#endif
+#ifndef SETOP_PART_INTERP
+#define SETOP_PART_INTERP 512  // half-width of the bracket around the interpolated split (0: plain binary search)
+#endif
 constexpr int PART_COARSE = SETOP_PART_COARSE;
 template <bool RANK, int LEVEL>
 __global__ void setop_partition_kernel(SetopArgs p, int tile_items) {
@@ -115,6 +121,25 @@ __global__ void setop_partition_kernel(SetopArgs p, int tile_items) {
         const u64 l0 = p.mp[c0], h0 = p.mp[c1];
         lo = lo > l0 ? lo : l0;
         hi = hi < h0 ? hi : h0;
+#if SETOP_PART_INTERP
+        // The path between two coarse neighbours is close to a straight line when the keys are spread evenly (k-mer
+        // codes, hashes): two probes SETOP_PART_INTERP positions either side of the interpolated split usually bracket
+        // it, and the search that follows stays inside a few KB (the probes of a plain binary search over the window
+        // each touch another page).  Whatever the probes say narrows [lo, hi] correctly, so skewed inputs only lose
+        // the two probes.
+        if (lo < hi) {
+            const u64 W = SETOP_PART_INTERP;
+            u64 est = l0 + (h0 - l0) * (t - c0) / (c1 - c0);
+            est = est < lo ? lo : (est > hi ? hi : est);
+            const u64 L = est > lo + W ? est - W : lo;
+            const u64 R = est + W < hi ? est + W : hi;
+            bool pl = true, pr = false;
+            if (L > lo) { const u64 j = diag - L; pl = key_le<RANK>(p.a[L - 1], RANK ? p.ra[L - 1] : 0, p.b[j], RANK ? p.rb[j] : 0); }
+            if (R < hi) { const u64 j = diag - 1 - R; pr = key_le<RANK>(p.a[R], RANK ? p.ra[R] : 0, p.b[j], RANK ? p.rb[j] : 0); }
+            if (L > lo) { if (pl) lo = L; else hi = L - 1; }
+            if (R < hi) { if (!pr) hi = R; else lo = R + 1; }  // (R < hi fails when the left probe already cut below R)
+        }
+#endif
     }
     while (lo < hi) {
         u64 mid = (lo + hi) >> 1;
@@ -154,6 +179,22 @@ __global__ void setop_partition_coop_kernel(SetopArgs p, int tile_items) {
     if (diag > N) diag = N;
     u64 lo = diag > p.nb ? diag - p.nb : 0;
     u64 hi = diag < p.na ? diag : p.na;
+#if SETOP_PART_INTERP1
+    if (lo < hi) {
+        // evenly spread keys: the split of diagonal d lies near d * |A| / (|A| + |B|); two (wave-uniform) probes either
+        // side of it cut two or three of the five 64-ary rounds.  Skewed inputs only lose the probes.
+        const u64 W = SETOP_PART_INTERP1;
+        u64 est = (u64)((double)diag * ((double)p.na / (double)N));
+        est = est < lo ? lo : (est > hi ? hi : est);
+        const u64 L = est > lo + W ? est - W : lo;
+        const u64 R = est + W < hi ? est + W : hi;
+        bool pl = true, pr = false;
+        if (L > lo) { const u64 j = diag - L; pl = key_le<RANK>(p.a[L - 1], RANK ? p.ra[L - 1] : 0, p.b[j], RANK ? p.rb[j] : 0); }
+        if (R < hi) { const u64 j = diag - 1 - R; pr = key_le<RANK>(p.a[R], RANK ? p.ra[R] : 0, p.b[j], RANK ? p.rb[j] : 0); }
+        if (L > lo) { if (pl) lo = L; else hi = L - 1; }
+        if (R < hi) { if (!pr) hi = R; else lo = R + 1; }
+    }
+#endif
     while (lo < hi) {  // wave-uniform
         const u64 span = hi - lo;
         // candidates: strictly increasing positions in [lo, hi); fewer than 64 when the span is short
