@@ -284,3 +284,48 @@ def test_kway_long_runs_and_multisets(env):
     same = [base] * 9
     assert np.array_equal(ctx.union(same), np.unique(base))
     assert np.array_equal(ctx.common(same, 9), np.unique(base))
+
+
+# ------------------------------------------------------------------- union by LDS hash probes (ukm_punion.hip)
+def test_probe_union_matches_oracle(env, monkeypatch):
+    """`union` of many plain sets that overlap heavily: the first eight files become the base set, every later record
+    is one hash probe in the LDS table of its range, misses are sorted and merged in (ukm_punion.hip; the reference
+    probes a hash map per k-mer, union.go:186-208).  UKM_PUNION=1 takes the path whatever the size, =2 also without
+    the hit-rate guard.  Shapes: config 3's draws over one universe (few misses), a base set of less than one range
+    and of many, more later files than one launch holds, later files that share nothing with the base set (every
+    record a miss), 64-bit hashes including all-ones codes, duplicates inside files; an unsorted later file and a
+    first-eight file that is unsorted make the path back out and the general route answer."""
+    O, L, ctx, tax, T = env
+    rng = np.random.default_rng(41)
+    monkeypatch.setenv("UKM_PUNION", "1")
+    for n_univ, nfiles, p in ((60_000, 40, 0.5), (3_000, 30, 0.5), (200_000, 26, 0.35), (20_000, 600, 0.3)):
+        U = _universe(n_univ)
+        files = [U[_member(len(U), f, p, 77)] for f in range(nfiles)]
+        assert np.array_equal(ctx.union(files), O.union(files)), (n_univ, nfiles, p)
+    # later files with private codes (misses), duplicates inside files, all-ones hashes
+    U = _universe(50_000, gap_bits=40)
+    files = [U[_member(len(U), f, 0.6, 5)] for f in range(30)]
+    extra = np.sort(rng.integers(0, 1 << 63, 3000, dtype=np.uint64) * np.uint64(2) + np.uint64(1))
+    files[12] = np.sort(np.concatenate([files[12], extra[:2000]]))
+    files[20] = np.sort(np.concatenate([files[20], extra[1000:], np.full(3, np.uint64(2**64 - 1))]))
+    files[25] = np.sort(np.concatenate([files[25], files[25][:700]]))          # a multiset
+    files[2] = np.sort(np.concatenate([files[2], np.full(2, np.uint64(2**64 - 1))]))   # all ones inside the base set
+    assert np.array_equal(ctx.union(files), O.union(files))
+    # nothing in common with the base set: the guard backs out (mode 1) / every record is a miss (mode 2)
+    disjoint = [np.sort(rng.choice(1 << 40, 4000, replace=False).astype(np.uint64) + np.uint64(f << 44)) for f in range(20)]
+    assert np.array_equal(ctx.union(disjoint), O.union(disjoint))
+    monkeypatch.setenv("UKM_PUNION", "2")
+    assert np.array_equal(ctx.union(disjoint), O.union(disjoint))
+    assert np.array_equal(ctx.union(files), O.union(files))
+    # unsorted inputs: in the later files and among the first eight
+    dirty = list(files)
+    dirty[15] = rng.permutation(dirty[15])
+    assert np.array_equal(ctx.union(dirty), O.union(dirty))
+    dirty = list(files)
+    dirty[3] = rng.permutation(dirty[3])
+    assert np.array_equal(ctx.union(dirty), O.union(dirty))
+    # with taxids the path does not apply (LCA fold): same answer as before
+    taxs = [_taxids(f, T, i) for i, f in enumerate(files)]
+    gk, gt = ctx.union(files, taxs)
+    ok, ot = O.union(files, taxs, tax)
+    assert np.array_equal(gk, ok) and np.array_equal(gt, ot)

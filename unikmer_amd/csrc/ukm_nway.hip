@@ -18,6 +18,7 @@
 #include "ukm_device.h"
 #include "ukm_fold.h"
 #include "ukm_kway.h"
+#include "ukm_punion.h"
 
 namespace {
 
@@ -249,6 +250,37 @@ int try_kway(ukm_ctx *ctx, int op, const std::vector<Stream> &ss, bool tax, u64 
     return UKM_OK;
 }
 
+// `union` of many plain sets by LDS hash probes against the union of the first eight (ukm_punion.hip): the shape of an
+// n-file union over related genomes, where after a few files nearly every record is already in the result.  Taken
+// for >= PUNION_MIN_STREAMS streams without taxids and >= 2^27 records behind the first eight; the path itself
+// backs out (*done = false, nothing written) when a sample of the later files is not found in the base set, when a
+// stream is unsorted or when its miss list overflows, and the k-way merge below answers.
+constexpr int PUNION_MIN_STREAMS = 24;
+int try_probe_union(ukm_ctx *ctx, const std::vector<Stream> &ss, bool tax, u64 *fk, u64 fcap, u64 *n_out, bool *done) {
+    *done = false;
+    const int mode = ukm_punion_mode();
+    if (tax || mode == 0 || !ukm_kway_enabled()) return UKM_OK;
+    if (mode < 1) {
+        if ((int)ss.size() < PUNION_MIN_STREAMS) return UKM_OK;
+        u64 later = 0;
+        for (size_t i = 8; i < ss.size(); i++) later += ss[i].n;
+        if (later < (1ull << 27)) return UKM_OK;
+    }
+    std::vector<const u64 *> kp(ss.size());
+    std::vector<u64> ln(ss.size());
+    for (size_t i = 0; i < ss.size(); i++) {
+        kp[i] = ss[i].k;
+        ln[i] = ss[i].n;
+    }
+    WsMark mark = ws_mark(ctx);
+    bool fallback = false;
+    const int rc = ukm_dev_probe_union(ctx, kp.data(), ln.data(), (int)ss.size(), fk, fcap, n_out, &fallback);
+    ws_release(ctx, mark);
+    UKM_TRY(rc);
+    *done = !fallback;
+    return UKM_OK;
+}
+
 // All records of the (non-empty) streams as ONE sequence ordered by code, equal codes in stream
 // order (= a stable sort of the concatenation).  Sorted streams (chunk files, .unik sets) go through
 // the keep-everything merge tree; anything else is concatenated and radix sorted.
@@ -408,6 +440,8 @@ extern "C" int ukm_union(ukm_ctx *ctx, const uint64_t *const *keys, const uint32
             return copy_result(ctx, ss[0], tax, o.k, o.t, out_cap, n_out);
         }
         bool done = false;
+        UKM_TRY(try_probe_union(ctx, ss, tax, o.k, out_cap, n_out, &done));
+        if (done) return UKM_OK;
         UKM_TRY(try_kway(ctx, UKM_KWAY_UNION, ss, tax, o.k, o.t, out_cap, n_out, &done));
         if (done) return UKM_OK;
         return tree_reduce(ctx, ss, UKM_OP_UNION, flags, tax, o.k, o.t, out_cap, n_out, true);

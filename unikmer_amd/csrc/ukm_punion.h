@@ -1,0 +1,11 @@
+// ukm_punion.h — internal: `union` of many heavily overlapping sorted sets by LDS hash probes (ukm_punion.hip)
+#pragma once
+#include "ukm_internal.h"
+
+// developer / test knob UKM_PUNION: 0 = never, 1 = whenever the shape allows it (size thresholds ignored),
+// 2 = as 1 and without the hit-rate guard.  Unset: the library's own choice.
+int ukm_punion_mode();
+// *fallback = true: not applicable to these inputs (low overlap, unsorted stream, miss buffer overflow): the
+// caller's k-way merge answers; nothing was written that matters.
+int ukm_dev_probe_union(ukm_ctx *c, const u64 *const *keys, const u64 *lens, int S, u64 *out, u64 out_cap, u64 *n_out,
+                        bool *fallback);

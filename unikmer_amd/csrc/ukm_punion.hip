@@ -1,0 +1,418 @@
+// ukm_punion.hip — `union` of MANY sorted sets that overlap heavily, the shape of an n-file `unikmer union` over
+// related genomes (BASELINE config 3: 100 files drawn from one universe).  The reference answers every k-mer of every
+// file with one probe of a hash map (union.go:186-208, 225-246); the k-way streaming merge of ukm_kway.hip pays three
+// in-LDS merge rounds per input record instead (VALU bound: 119 lane-instructions per record, 34 ms of the 46.7 ms of
+// config 3 for level 0 alone) although after the first few files nearly every record is already in the result.
+//
+// Here the reference's algorithm is laid out for the chip:
+//   1. BASE  = k-way union of the first PU_K0 files (ukm_kway.hip): a sorted, duplicate-free set.
+//   2. A sample of later records is looked up in BASE (global binary search): when fewer than PU_MIN_HIT of them are
+//      found the inputs do not have this shape and the caller's k-way merge answers.
+//   3. The VALUE SPACE is cut into ranges of PU_RANGE consecutive BASE entries.  One workgroup per range builds a
+//      bucketised table of its entries in LDS (2048 buckets of four, 64 KB) and streams through its slice of EVERY later
+//      file (lower-bound cuts of the range limits, one thread per (range, file)): per record one multiplicative hash
+//      and one 32-byte bucket read; the order of every file is checked on the way (neighbouring records are compared once).
+//      Records that are not in the table — not in BASE — are appended to a miss list (one atomic per 64 slots).
+//   4. Result = 2-way union of BASE and sort + unique of the miss list (ukm_sort.hip, ukm_scan.hip, ukm_setops.hip).
+// Whatever the data, BASE ∪ later records = BASE ∪ misses, because a hit is an exact 64-bit match; a bad hash or an
+// unlucky range only costs probes.  An unsorted file or a full miss list raise a flag and the caller falls back.  Plain sets only (no TaxId fold): LCA updates of table entries would
+// need per-entry atomics.
+// Algorithmic bytes: 8 B per input record read once (+ the base and miss passes); nothing is written per hit.
+#include <stdlib.h>
+
+#include <algorithm>
+#include <chrono>
+#include <vector>
+
+#include "ukm_device.h"
+#include "ukm_kway.h"
+#include "ukm_punion.h"
+
+namespace {
+
+constexpr int PU_K0 = 8;          // files merged into the base set
+constexpr int PU_NT = 512;        // threads of a probe workgroup
+constexpr int PU_RANGE = 2048;    // base entries per range
+constexpr int PU_BUCKET_BITS = 11;  // 2048 buckets x 4 slots x 8 B = 64 KB of LDS: two workgroups per CU
+constexpr int PU_BUCKETS = 1 << PU_BUCKET_BITS;
+constexpr int PU_SLOTS = 4 * PU_BUCKETS;
+constexpr int PU_MAXS = 4096;     // later files per launch
+constexpr u32 PU_CHUNK = 32;      // slots of the miss list a wave reserves at a time
+constexpr u64 PU_EMPTY = ~0ull;
+constexpr double PU_MIN_HIT = 0.90;
+enum { PU_FLAG_UNSORTED = 1, PU_FLAG_OVERFLOW = 2 };
+
+struct PuArgs {
+    const u64 *const *files;  // [S1] later files (device table of device pointers)
+    const u64 *lens;          // [S1]
+    u32 S1;
+    const u64 *base;          // sorted, duplicate-free
+    u64 n0;
+    u32 R;                    // ranges = ceil(n0 / PU_RANGE)
+    u64 *cuts;                // [R + 1][S1]
+    u64 *miss;
+    u64 miss_cap;
+    u64 *ctl;                 // [0] misses, [1] flags, [2] sample hits, [3] samples
+};
+
+__device__ __forceinline__ u32 pu_hash(u64 x) {
+    const u32 lo = (u32)x, hi = (u32)(x >> 32);
+    return ((lo ^ (hi * 0x85EBCA6Bu)) * 0x9E3779B1u) >> (32 - PU_BUCKET_BITS);
+}
+
+__device__ __forceinline__ u64 pu_splitmix(u64 x) {
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+
+// cuts[r][j] = lower bound of the first base entry of range r in later file j (r = 0: 0, r = R: the file's length).
+// Threads of one file are neighbours: their first probes coincide, their last ones share lines.
+__global__ void pu_cuts_kernel(PuArgs a) {
+    const u64 gid = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    const u64 per = (u64)a.R + 1;
+    if (gid >= per * a.S1) return;
+    const u32 j = (u32)(gid / per), r = (u32)(gid % per);
+    const u64 len = a.lens[j];
+    u64 res;
+    if (r == 0) {
+        res = 0;
+    } else if (r == a.R) {
+        res = len;
+    } else {
+        const u64 v = a.base[(u64)r * PU_RANGE];
+        const auto f = as_global(a.files[j]);
+        u64 lo = 0, hi = len;
+        while (lo < hi) {
+            const u64 mid = (lo + hi) >> 1;
+            if (f[mid] < v) lo = mid + 1; else hi = mid;
+        }
+        res = lo;
+    }
+    a.cuts[(u64)r * a.S1 + j] = res;
+}
+
+// hit rate of a sample of later records in the base set
+__global__ void pu_sample_kernel(PuArgs a, u32 nsamp, u32 nfiles_s) {
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    bool tested = false, hit = false;
+    if (i < nsamp) {
+        const u32 j = (u32)(((u64)(i % nfiles_s) * a.S1) / nfiles_s);
+        const u64 len = a.lens[j];
+        if (len) {
+            const u64 key = as_global(a.files[j])[pu_splitmix(i) % len];
+            u64 lo = 0, hi = a.n0;
+            while (lo < hi) {
+                const u64 mid = (lo + hi) >> 1;
+                if (a.base[mid] < key) lo = mid + 1; else hi = mid;
+            }
+            tested = true;
+            hit = lo < a.n0 && a.base[lo] == key;
+        }
+    }
+    const u64 mh = __ballot(hit), mt = __ballot(tested);
+    if (lane_id() == 0 && mt) {
+        atomicAdd((unsigned long long *)&a.ctl[2], (unsigned long long)__popcll(mh));
+        atomicAdd((unsigned long long *)&a.ctl[3], (unsigned long long)__popcll(mt));
+    }
+}
+
+typedef u64 pu_u64x2 __attribute__((ext_vector_type(2)));
+typedef pu_u64x2 __attribute__((aligned(8))) pu_pair;  // 16 bytes at 8-byte alignment
+
+__global__ __launch_bounds__(PU_NT) void pu_probe_kernel(PuArgs a) {
+    __shared__ __attribute__((aligned(32))) u64 s_tab[PU_SLOTS];
+    __shared__ u32 s_next;
+    const int tid = (int)threadIdx.x, lane = lane_id();
+    const u32 r = blockIdx.x, S1 = a.S1;
+    for (int i = tid; i < PU_SLOTS; i += PU_NT) s_tab[i] = PU_EMPTY;
+    if (tid == 0) s_next = 0;
+    __syncthreads();
+    // the table of this range's base entries (distinct; an all-ones code can not be told from an empty slot and is
+    // left out: records with that code are "misses" and meet their base entry again in the final union)
+    {
+        const u64 b0 = (u64)r * PU_RANGE;
+        const u32 nb = (u32)((a.n0 - b0 < (u64)PU_RANGE) ? (a.n0 - b0) : (u64)PU_RANGE);
+        constexpr int PER = PU_RANGE / PU_NT;
+        u64 ent[PER];
+#pragma unroll
+        for (int i = 0; i < PER; i++) {  // (all loads in flight before the first insert)
+            const u32 idx = (u32)tid + (u32)i * PU_NT;
+            ent[i] = a.base[b0 + (idx < nb ? idx : 0)];
+            if (idx >= nb) ent[i] = PU_EMPTY;
+        }
+#pragma unroll
+        for (int i = 0; i < PER; i++) {
+            const u64 e = ent[i];
+            if (e == PU_EMPTY) continue;
+            // first free slot of the first bucket of its probe sequence that is not full (slots fill in order, nothing
+            // is ever removed: "slot 3 taken" = "bucket full" for every later reader)
+            u32 h = pu_hash(e);
+            for (bool placed = false; !placed; h = (h + 1) & (PU_BUCKETS - 1)) {
+#pragma unroll
+                for (int k = 0; k < 4 && !placed; k++) {
+                    const u64 old = atomicCAS((unsigned long long *)&s_tab[4 * h + k], (unsigned long long)PU_EMPTY, (unsigned long long)e);
+                    placed = old == PU_EMPTY || old == e;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    // one bucket = 32 bytes = two ds_read_b128: with one entry per bucket on average 0.4 % of the buckets are full, so a
+    // wave's lookup runs 1.2 rounds (slot-by-slot linear probing ran as many rounds as the unluckiest of 64 lanes needed:
+    // ~160 instructions per record)
+    auto member = [&](u64 x) -> bool {
+        u32 h = pu_hash(x);
+        for (;;) {
+            const ulonglong2 *b = reinterpret_cast<const ulonglong2 *>(&s_tab[4 * h]);
+            const ulonglong2 p = b[0], q = b[1];
+            if (p.x == x || p.y == x || q.x == x || q.y == x) return x != PU_EMPTY;
+            if (q.y == PU_EMPTY) return false;
+            h = (h + 1) & (PU_BUCKETS - 1);
+        }
+    };
+    // Misses go to the global list in CHUNKS of PU_CHUNK slots that a wave reserves with one atomic (one counter for the
+    // whole grid: an atomic per wave step that saw a miss — 3e7 of them on config 3 — serialised the kernel at 380 ms).
+    // Slots a wave does not use are filled with a copy of one of its misses (duplicates vanish in sort + unique).
+    const u64 lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+    u64 chunk_at = 0, fill = 0;  // wave-uniform
+    u32 chunk_cap = 0, chunk_used = 0;
+    auto close_chunk = [&]() {
+        if ((u32)lane < chunk_cap - chunk_used) a.miss[chunk_at + chunk_used + (u32)lane] = fill;
+        chunk_cap = chunk_used = 0;
+    };
+    auto append = [&](bool m, u64 x) {
+        const u64 mask = __ballot(m);
+        if (mask == 0ull) return;
+        const u32 n = (u32)__popcll(mask);
+        const int lead = __ffsll((long long)mask) - 1;
+        if (n > chunk_cap - chunk_used) {
+            close_chunk();
+            const u32 want = n > PU_CHUNK ? 64u : PU_CHUNK;
+            u64 at = 0;
+            if (lane == lead) at = atomicAdd((unsigned long long *)&a.ctl[0], (unsigned long long)want);
+            at = __shfl(at, lead, 64);
+            if (at + want > a.miss_cap) {
+                if (lane == lead) atomicOr((unsigned long long *)&a.ctl[1], (unsigned long long)PU_FLAG_OVERFLOW);
+                return;  // (the host discards everything)
+            }
+            chunk_at = at;
+            chunk_cap = want;
+        }
+        fill = __shfl(x, lead, 64);
+        if (m) a.miss[chunk_at + chunk_used + (u32)__popcll(mask & lt)] = x;
+        chunk_used += n;
+    };
+    // A WAVE takes one file's slice at a time (next free one from an LDS counter): everything about the slice is
+    // wave-uniform, the lanes stream it 128 records per step, up to four steps of loads in flight; the cut points of
+    // the NEXT slice are fetched (scalar loads) while this one is streamed.
+    bool bad = false;
+    auto step = [&](auto UU, const ukm_gptr<u64> f, u64 p0, u64 end, u64 len) {
+        constexpr int U = decltype(UU)::value;
+        // Branch-free loads (a load inside a conditional made the compiler wait for each one in turn: 8 round trips
+        // per step): the pair is read from an address clamped into the file, what it means is sorted out afterwards.
+        pu_pair pr[U];
+        u64 nx[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const u64 pos = p0 + (u64)u * 128 + 2u * (u32)lane;
+            const u64 q = pos < len - 2 ? pos : len - 2;
+            const u64 q2 = pos + 2 < len ? pos + 2 : len - 1;
+            pr[u] = *(const pu_pair __attribute__((address_space(1))) *)(f + q);
+            nx[u] = f[q2];
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const u64 pos = p0 + (u64)u * 128 + 2u * (u32)lane;
+            const u32 nv = pos + 1 < end ? 2u : (pos < end ? 1u : 0u);
+            const bool shifted = pos > len - 2;  // pos = len - 1 (or beyond: nv = 0): the record is the pair's second
+            const u64 x0 = shifted ? pr[u].y : pr[u].x;
+            const u64 x1 = nv == 2 ? pr[u].y : x0;
+            // the record behind the last valid one (order check, also across slices); all ones behind the file
+            const u64 x2 = nv == 2 ? (pos + 2 < len ? nx[u] : PU_EMPTY) : ((!shifted && pos + 1 < len) ? pr[u].y : PU_EMPTY);
+            const bool v0 = nv >= 1, v1 = nv == 2;
+            if (v0) bad |= x0 > x1 || x1 > x2;
+            const bool m0 = v0 && !member(x0);
+            const bool m1 = v1 && !member(x1);
+            append(m0, x0);
+            append(m1, x1);
+        }
+    };
+    auto take = [&]() -> u32 {
+        u32 j = 0;
+        if (lane == 0) j = atomicAdd(&s_next, 1u);
+        return (u32)__builtin_amdgcn_readfirstlane((int)j);
+    };
+    struct Meta { u64 beg, end, len, f; };
+    auto fetch = [&](u32 j) -> Meta {
+        Meta m = {0, 0, 0, 0};
+        if (j < S1) {
+            m.beg = sload_u64(&a.cuts[(u64)r * S1 + j]);
+            m.end = sload_u64(&a.cuts[(u64)(r + 1) * S1 + j]);
+            m.len = sload_u64(&a.lens[j]);
+            m.f = sload_u64((const u64 *)&a.files[j]);
+        }
+        return m;
+    };
+    u32 j = take();
+    Meta cur = fetch(j);
+    while (j < S1) {
+        const u32 jn = take();
+        const Meta nxt = fetch(jn);
+        const auto f = as_global((const u64 *)(uintptr_t)cur.f);
+        const u64 len = cur.len, end = cur.end < cur.beg ? cur.beg : cur.end;
+        if (len < 2) {  // (a one-record file: no 16-byte load fits)
+            if (end > cur.beg) {
+                const u64 x = f[0];
+                append(lane == 0 && !member(x), x);
+            }
+        } else {
+            u64 p0 = cur.beg;
+            while (p0 < end) {
+                const u64 rem = end - p0;
+                if (rem > 256) { step(std::integral_constant<int, 4>{}, f, p0, end, len); p0 += 512; }
+                else if (rem > 128) { step(std::integral_constant<int, 2>{}, f, p0, end, len); p0 += 256; }
+                else { step(std::integral_constant<int, 1>{}, f, p0, end, len); p0 += 128; }
+            }
+        }
+        j = jn;
+        cur = nxt;
+    }
+    close_chunk();
+    if (bad) atomicOr((unsigned long long *)&a.ctl[1], (unsigned long long)PU_FLAG_UNSORTED);
+}
+
+double ms_since(std::chrono::steady_clock::time_point t0) {
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+}
+
+}  // namespace
+
+int ukm_punion_mode() {
+    const char *e = getenv("UKM_PUNION");
+    if (!e || !*e) return -1;
+    return atoi(e);
+}
+
+int ukm_dev_probe_union(ukm_ctx *c, const u64 *const *keys, const u64 *lens, int S, u64 *out, u64 out_cap, u64 *n_out,
+                        bool *fallback) {
+    *fallback = true;
+    *n_out = 0;
+    if (S < PU_K0 + 1) return UKM_OK;
+    const int mode = ukm_punion_mode();
+    const bool dbg = getenv("UKM_PUNION_DEBUG") != nullptr;
+    auto t0 = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {
+        if (!dbg) return;
+        (void)hipStreamSynchronize(c->stream);
+        fprintf(stderr, "[punion] %-10s %8.3f ms\n", what, ms_since(t0));
+        t0 = std::chrono::steady_clock::now();
+    };
+    // 1. the base set
+    u64 cap0 = 0, later = 0;
+    for (int j = 0; j < PU_K0; j++) cap0 += lens[j];
+    for (int j = PU_K0; j < S; j++) later += lens[j];
+    u64 *base = nullptr;
+    UKM_TRY(ws_alloc_t(c, cap0 + 1, &base));
+    u64 n0 = 0;
+    bool fb = false;
+    UKM_TRY(ukm_dev_kway(c, UKM_KWAY_UNION, keys, nullptr, lens, PU_K0, false, base, nullptr, cap0, &n0, &fb));
+    if (fb || n0 == 0) return UKM_OK;
+    const u64 R64 = (n0 + PU_RANGE - 1) / PU_RANGE;
+    if (R64 > 0x7FFFFFFEull) return UKM_OK;
+    lap("base");
+
+    // device tables of the later files: [pointers S1][lens S1]
+    const int S1all = S - PU_K0;
+    std::vector<u64> tab((size_t)2 * S1all);
+    for (int j = 0; j < S1all; j++) {
+        tab[(size_t)j] = (u64)(uintptr_t)keys[PU_K0 + j];
+        tab[(size_t)S1all + j] = lens[PU_K0 + j];
+    }
+    u64 *d_tab = nullptr, *ctl = nullptr;
+    UKM_TRY(ws_alloc_t(c, tab.size(), &d_tab));
+    UKM_TRY(ws_alloc_t(c, 8, &ctl));
+    UKM_HIP(hipMemcpyAsync(d_tab, tab.data(), tab.size() * sizeof(u64), hipMemcpyHostToDevice, c->stream));
+    UKM_HIP(hipMemsetAsync(ctl, 0, 8 * sizeof(u64), c->stream));
+    UKM_HIP(hipStreamSynchronize(c->stream));  // `tab` is a pageable host buffer of this frame
+
+    PuArgs a;
+    memset(&a, 0, sizeof(a));
+    a.base = base;
+    a.n0 = n0;
+    a.R = (u32)R64;
+    a.ctl = ctl;
+
+    // 2. do the later files look like the base set?
+    double miss_rate = 0.0;
+    {
+        a.files = (const u64 *const *)d_tab;
+        a.lens = d_tab + S1all;
+        a.S1 = (u32)S1all;
+        const u32 nsamp = 1u << 16, nf = (u32)std::min(S1all, 16);
+        hipLaunchKernelGGL(pu_sample_kernel, dim3(nsamp / 256), dim3(256), 0, c->stream, a, nsamp, nf);
+        UKM_HIP(hipGetLastError());
+        u64 h[4] = {0, 0, 0, 0};
+        UKM_TRY(ukm_read_u64(c, ctl, h, 4));
+        if (h[3] == 0) return UKM_OK;
+        miss_rate = 1.0 - (double)h[2] / (double)h[3];
+        if (dbg) fprintf(stderr, "[punion] sample: %llu of %llu later records in the base set (n0 = %llu)\n",
+                         (unsigned long long)h[2], (unsigned long long)h[3], (unsigned long long)n0);
+        if (mode != 2 && 1.0 - miss_rate < PU_MIN_HIT) return UKM_OK;
+    }
+    lap("sample");
+
+    // 3. probe pass
+    // (+ one partly used chunk of 64 per wave of the grid)
+    u64 miss_cap = (u64)((double)later * std::min(1.0, 2.0 * miss_rate + 0.01)) + (1u << 20);
+    miss_cap = std::min(miss_cap, later) + 64ull * (PU_NT / 64) * R64 * (u64)((S1all + PU_MAXS - 1) / PU_MAXS) + later / 32;
+    UKM_TRY(ws_alloc_t(c, miss_cap + 1, &a.miss));
+    a.miss_cap = miss_cap;
+    for (int s0 = 0; s0 < S1all; s0 += PU_MAXS) {
+        const int s1 = std::min(PU_MAXS, S1all - s0);
+        // (the pointer and length rows of a batch are not adjacent in d_tab: lens sits S1all entries behind)
+        a.files = (const u64 *const *)(d_tab + s0);
+        a.lens = d_tab + S1all + s0;
+        a.S1 = (u32)s1;
+        WsMark mark = ws_mark(c);
+        UKM_TRY(ws_alloc_t(c, ((size_t)a.R + 1) * s1, &a.cuts));
+        const u64 ncuts = ((u64)a.R + 1) * (u64)s1;
+        hipLaunchKernelGGL(pu_cuts_kernel, dim3((unsigned)((ncuts + 255) / 256)), dim3(256), 0, c->stream, a);
+        lap("cuts");
+        (void)hipEventRecord(c->ev_k0, c->stream);
+        hipLaunchKernelGGL(pu_probe_kernel, dim3(a.R), dim3(PU_NT), 0, c->stream, a);
+        (void)hipEventRecord(c->ev_k1, c->stream);
+        c->evk_valid = true;
+        UKM_HIP(hipGetLastError());
+        lap("probe");
+        ws_release(c, mark);  // (the stream orders the next batch's cuts behind this probe)
+    }
+    u64 h[2] = {0, 0};
+    UKM_TRY(ukm_read_u64(c, ctl, h, 2));
+    if (dbg) fprintf(stderr, "[punion] S=%d n0=%llu R=%u later=%llu misses=%llu (cap %llu) flags=%llu\n", S, (unsigned long long)n0,
+                     a.R, (unsigned long long)later, (unsigned long long)h[0], (unsigned long long)miss_cap, (unsigned long long)h[1]);
+    if (h[1] != 0) return UKM_OK;  // unsorted input / overflow: the general route reports or handles it
+
+    // 4. base ∪ misses
+    const u64 nm = h[0];
+    if (nm == 0) {
+        *n_out = n0;
+        if (n0 > out_cap)
+            UKM_FAIL(UKM_ERR_CAPACITY, "output needs %llu records, capacity is %llu", (unsigned long long)n0, (unsigned long long)out_cap);
+        UKM_HIP(hipMemcpyAsync(out, base, n0 * sizeof(u64), hipMemcpyDeviceToDevice, c->stream));
+        *fallback = false;
+        return UKM_OK;
+    }
+    UKM_TRY(ukm_dev_sort(c, a.miss, nullptr, nm, 64));
+    u64 *mu = nullptr;
+    UKM_TRY(ws_alloc_t(c, nm + 1, &mu));
+    u64 nmu = 0;
+    UKM_TRY(ukm_dev_unique(c, a.miss, nullptr, nm, UKM_UNIQUE, mu, nullptr, nm, &nmu));
+    lap("miss sort");
+    // (capacity: the 2-way kernel reports the size it needs)
+    UKM_TRY(ukm_dev_setop2(c, UKM_OP_UNION, base, nullptr, n0, mu, nullptr, nmu, 0, out, nullptr, out_cap, n_out));
+    lap("final");
+    *fallback = false;
+    return UKM_OK;
+}
