@@ -317,6 +317,14 @@ def test_probe_union_matches_oracle(env, monkeypatch):
     monkeypatch.setenv("UKM_PUNION", "2")
     assert np.array_equal(ctx.union(disjoint), O.union(disjoint))
     assert np.array_equal(ctx.union(files), O.union(files))
+    # thousands of new codes per range (the base set has three ranges): the LDS list of a range overflows into the
+    # global chunks, and past 2048 claimed codes the rest is listed without being inserted (duplicates in the list)
+    Us = _universe(5_000, gap_bits=30)
+    small = [Us[_member(len(Us), f, 0.7, 9)] for f in range(8)]
+    fresh = np.unique(rng.integers(0, int(Us[-1]), 20_000).astype(np.uint64))
+    crowded = small + [np.sort(np.concatenate([Us[_member(len(Us), 8 + f, 0.7, 9)], fresh[_member(len(fresh), f, 0.6, 13)]]))
+                       for f in range(22)]
+    assert np.array_equal(ctx.union(crowded), O.union(crowded))
     # unsorted inputs: in the later files and among the first eight
     dirty = list(files)
     dirty[15] = rng.permutation(dirty[15])

@@ -37,6 +37,7 @@ constexpr int PU_BUCKET_BITS = 11;  // 2048 buckets x 4 slots x 8 B = 64 KB of L
 constexpr int PU_BUCKETS = 1 << PU_BUCKET_BITS;
 constexpr int PU_SLOTS = 4 * PU_BUCKETS;
 constexpr int PU_MAXS = 4096;     // later files per launch
+constexpr int PU_LMISS = 512;     // new codes a range keeps in LDS before they go out in one piece
 constexpr u32 PU_CHUNK = 32;      // slots of the miss list a wave reserves at a time
 constexpr u64 PU_EMPTY = ~0ull;
 constexpr double PU_MIN_HIT = 0.90;
@@ -123,11 +124,13 @@ typedef pu_u64x2 __attribute__((aligned(8))) pu_pair;  // 16 bytes at 8-byte ali
 
 __global__ __launch_bounds__(PU_NT) void pu_probe_kernel(PuArgs a) {
     __shared__ __attribute__((aligned(32))) u64 s_tab[PU_SLOTS];
-    __shared__ u32 s_next;
+    __shared__ u64 s_miss[PU_LMISS];
+    __shared__ u32 s_next, s_nmiss, s_nins;
+    __shared__ u64 s_flush_at;
     const int tid = (int)threadIdx.x, lane = lane_id();
     const u32 r = blockIdx.x, S1 = a.S1;
     for (int i = tid; i < PU_SLOTS; i += PU_NT) s_tab[i] = PU_EMPTY;
-    if (tid == 0) s_next = 0;
+    if (tid == 0) { s_next = 0; s_nmiss = 0; s_nins = 0; }
     __syncthreads();
     // the table of this range's base entries (distinct; an all-ones code can not be told from an empty slot and is
     // left out: records with that code are "misses" and meet their base entry again in the final union)
@@ -162,8 +165,7 @@ __global__ __launch_bounds__(PU_NT) void pu_probe_kernel(PuArgs a) {
     // one bucket = 32 bytes = two ds_read_b128: with one entry per bucket on average 0.4 % of the buckets are full, so a
     // wave's lookup runs 1.2 rounds (slot-by-slot linear probing ran as many rounds as the unluckiest of 64 lanes needed:
     // ~160 instructions per record)
-    auto member = [&](u64 x) -> bool {
-        u32 h = pu_hash(x);
+    auto member_from = [&](u64 x, u32 h) -> bool {
         for (;;) {
             const ulonglong2 *b = reinterpret_cast<const ulonglong2 *>(&s_tab[4 * h]);
             const ulonglong2 p = b[0], q = b[1];
@@ -172,9 +174,41 @@ __global__ __launch_bounds__(PU_NT) void pu_probe_kernel(PuArgs a) {
             h = (h + 1) & (PU_BUCKETS - 1);
         }
     };
-    // Misses go to the global list in CHUNKS of PU_CHUNK slots that a wave reserves with one atomic (one counter for the
-    // whole grid: an atomic per wave step that saw a miss — 3e7 of them on config 3 — serialised the kernel at 380 ms).
-    // Slots a wave does not use are filled with a copy of one of its misses (duplicates vanish in sort + unique).
+    auto member = [&](u64 x) -> bool { return member_from(x, pu_hash(x)); };
+    // two lookups with their four LDS reads in flight together; a full bucket (0.4 %) continues the slow way
+    auto member2 = [&](u64 xa, u64 xb, bool &ha, bool &hb) {
+        const u32 h0 = pu_hash(xa), h1 = pu_hash(xb);
+        const ulonglong2 *b0 = reinterpret_cast<const ulonglong2 *>(&s_tab[4 * h0]);
+        const ulonglong2 *b1 = reinterpret_cast<const ulonglong2 *>(&s_tab[4 * h1]);
+        const ulonglong2 p0 = b0[0], q0 = b0[1], p1 = b1[0], q1 = b1[1];
+        ha = (p0.x == xa) | (p0.y == xa) | (q0.x == xa) | (q0.y == xa);
+        hb = (p1.x == xb) | (p1.y == xb) | (q1.x == xb) | (q1.y == xb);
+        const bool more0 = !ha && q0.y != PU_EMPTY, more1 = !hb && q1.y != PU_EMPTY;
+        ha = ha && xa != PU_EMPTY;
+        hb = hb && xb != PU_EMPTY;
+        if (more0) ha = member_from(xa, (h0 + 1) & (PU_BUCKETS - 1));
+        if (more1) hb = member_from(xb, (h1 + 1) & (PU_BUCKETS - 1));
+    };
+    // A record that is not in the table is a NEW code of this range: the first lane to put it into the table (same
+    // insertion as above) owns it, every later occurrence — the same code comes with every other file — is a hit.
+    // On config 3 that leaves 8e5 list entries instead of 3.6e7.  (All-ones codes and, once the table has doubled,
+    // further new codes are listed without being inserted: duplicates in the list are harmless.)
+    auto claim = [&](u64 x) -> bool {
+        if (x == PU_EMPTY || s_nins >= (u32)PU_RANGE) return true;
+        u32 h = pu_hash(x);
+        for (;; h = (h + 1) & (PU_BUCKETS - 1)) {
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const u64 old = atomicCAS((unsigned long long *)&s_tab[4 * h + k], (unsigned long long)PU_EMPTY, (unsigned long long)x);
+                if (old == PU_EMPTY) { atomicAdd(&s_nins, 1u); return true; }
+                if (old == x) return false;
+            }
+        }
+    };
+    // New codes collect in an LDS list that leaves with ONE atomic on the global counter at the end.  What does not fit
+    // goes to the global list directly, in CHUNKS of PU_CHUNK slots that a wave reserves with one atomic (an atomic per
+    // wave step that saw a miss — 3e7 of them before the codes were claimed — serialised the kernel at 380 ms); slots
+    // of a chunk that stay unused are filled with a copy of one of the wave's codes (duplicates vanish in sort + unique).
     const u64 lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
     u64 chunk_at = 0, fill = 0;  // wave-uniform
     u32 chunk_cap = 0, chunk_used = 0;
@@ -182,7 +216,7 @@ __global__ __launch_bounds__(PU_NT) void pu_probe_kernel(PuArgs a) {
         if ((u32)lane < chunk_cap - chunk_used) a.miss[chunk_at + chunk_used + (u32)lane] = fill;
         chunk_cap = chunk_used = 0;
     };
-    auto append = [&](bool m, u64 x) {
+    auto append_global = [&](bool m, u64 x) {
         const u64 mask = __ballot(m);
         if (mask == 0ull) return;
         const u32 n = (u32)__popcll(mask);
@@ -204,6 +238,19 @@ __global__ __launch_bounds__(PU_NT) void pu_probe_kernel(PuArgs a) {
         if (m) a.miss[chunk_at + chunk_used + (u32)__popcll(mask & lt)] = x;
         chunk_used += n;
     };
+    auto append = [&](bool missing, u64 x) {
+        if (__ballot(missing) == 0ull) return;
+        const bool m = missing && claim(x);
+        const u64 mask = __ballot(m);
+        if (mask == 0ull) return;
+        const int lead = __ffsll((long long)mask) - 1;
+        u32 at = 0;
+        if (lane == lead) at = atomicAdd(&s_nmiss, (u32)__popcll(mask));
+        at = (u32)__shfl((int)at, lead, 64) + (u32)__popcll(mask & lt);
+        const bool in_lds = m && at < (u32)PU_LMISS;
+        if (in_lds) s_miss[at] = x;
+        append_global(m && !in_lds, x);
+    };
     // A WAVE takes one file's slice at a time (next free one from an LDS counter): everything about the slice is
     // wave-uniform, the lanes stream it 128 records per step, up to four steps of loads in flight; the cut points of
     // the NEXT slice are fetched (scalar loads) while this one is streamed.
@@ -224,6 +271,28 @@ __global__ __launch_bounds__(PU_NT) void pu_probe_kernel(PuArgs a) {
         }
 #pragma unroll
         for (int u = 0; u < U; u++) {
+            // (pins every load in front of the processing: the compiler otherwise sinks the `nx` load of the first step
+            //  into the branch that uses it and waits for it there — a second round trip per step)
+            u64 t0 = pr[u].x, t1 = pr[u].y;
+            asm volatile("" : "+v"(t0), "+v"(t1), "+v"(nx[u]));
+            pr[u].x = t0;
+            pr[u].y = t1;
+        }
+        if (p0 + (u64)U * 128 <= end && p0 + (u64)U * 128 + 2 <= len) {
+            // every lane has two records and a record behind them (wave-uniform test): no validity logic
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const u64 x0 = pr[u].x, x1 = pr[u].y;
+                bad |= x0 > x1 || x1 > nx[u];
+                bool h0, h1;
+                member2(x0, x1, h0, h1);
+                append(!h0, x0);
+                append(!h1, x1);
+            }
+            return;
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
             const u64 pos = p0 + (u64)u * 128 + 2u * (u32)lane;
             const u32 nv = pos + 1 < end ? 2u : (pos < end ? 1u : 0u);
             const bool shifted = pos > len - 2;  // pos = len - 1 (or beyond: nv = 0): the record is the pair's second
@@ -233,10 +302,10 @@ __global__ __launch_bounds__(PU_NT) void pu_probe_kernel(PuArgs a) {
             const u64 x2 = nv == 2 ? (pos + 2 < len ? nx[u] : PU_EMPTY) : ((!shifted && pos + 1 < len) ? pr[u].y : PU_EMPTY);
             const bool v0 = nv >= 1, v1 = nv == 2;
             if (v0) bad |= x0 > x1 || x1 > x2;
-            const bool m0 = v0 && !member(x0);
-            const bool m1 = v1 && !member(x1);
-            append(m0, x0);
-            append(m1, x1);
+            bool h0, h1;
+            member2(x0, x1, h0, h1);
+            append(v0 && !h0, x0);
+            append(v1 && !h1, x1);
         }
     };
     auto take = [&]() -> u32 {
@@ -281,6 +350,18 @@ __global__ __launch_bounds__(PU_NT) void pu_probe_kernel(PuArgs a) {
     }
     close_chunk();
     if (bad) atomicOr((unsigned long long *)&a.ctl[1], (unsigned long long)PU_FLAG_UNSORTED);
+    __syncthreads();
+    const u32 nl = s_nmiss < (u32)PU_LMISS ? s_nmiss : (u32)PU_LMISS;
+    if (nl == 0) return;
+    if (tid == 0) {
+        const u64 at = atomicAdd((unsigned long long *)&a.ctl[0], (unsigned long long)nl);
+        if (at + nl > a.miss_cap) atomicOr((unsigned long long *)&a.ctl[1], (unsigned long long)PU_FLAG_OVERFLOW);
+        s_flush_at = at;
+    }
+    __syncthreads();
+    const u64 at = s_flush_at;
+    if (at + nl <= a.miss_cap)
+        for (u32 i = (u32)tid; i < nl; i += PU_NT) a.miss[at + i] = s_miss[i];
 }
 
 double ms_since(std::chrono::steady_clock::time_point t0) {
