@@ -104,10 +104,11 @@ def test_metric_config_2x1e9_full_size(env):
         assert start == a0 - _lower(torch, I, lo), start
 
 
-def test_config3_union_of_100_files_x_1e8_full_size(env):
+def test_config3_union_of_100_files_x_1e8_full_size(env, monkeypatch):
     """BASELINE config 3 on one GPU: 100 sorted files of ~1e8 codes drawn (p = 0.5) from one universe of 2e8.
-    The k-way streaming union must equal (a) the universe elements that are in at least one file, computed with torch
-    from the generator's membership bits, and (b) a chain of 99 two-way unions through the tile kernel."""
+    The union — the library's own choice (the hash-probe pass of ukm_punion.hip) AND the k-way streaming merge alone
+    (UKM_PUNION=0) — must equal (a) the universe elements that are in at least one file, computed with torch from the
+    generator's membership bits, and (b) a chain of 99 two-way unions through the tile kernel."""
     torch, bench, lib, ctx, O, dev = env
     nfiles, per = 100, 100_000_000
     nu = 2 * per
@@ -125,6 +126,12 @@ def test_config3_union_of_100_files_x_1e8_full_size(env):
     expect = Uv[anym]
     del anym
     out = torch.empty(nu + 8, dtype=torch.int64, device=dev)
+    monkeypatch.setenv("UKM_PUNION", "0")
+    got = ctx.union(files, out=out)
+    assert got.numel() == expect.numel() and _strict(got)
+    assert bool((got == expect).all())
+    monkeypatch.delenv("UKM_PUNION")
+    out[:8].zero_()
     got = ctx.union(files, out=out)
     assert got.numel() == expect.numel() and _strict(got)
     assert bool((got == expect).all())

@@ -107,11 +107,19 @@ def main():
         ctx.union(files, out=out)  # untimed: the first call grows the workspace and first-touches ~20 GB of it (1.5-3 s)
         ms, u = wall(lambda: ctx.union(files, out=out), reps=args.reps)
         assert u.numel() <= nu and bool((u[1:] > u[:-1]).all())
+        n_probe, x_probe = u.numel(), int(bench._xor_fold(u)) if hasattr(bench, "_xor_fold") else 0
+        os.environ["UKM_PUNION"] = "0"   # the k-way streaming merge alone (what answers when the sets do not overlap)
+        ctx.union(files, out=out)
+        ms_kway, uk = wall(lambda: ctx.union(files, out=out), reps=args.reps)
+        del os.environ["UKM_PUNION"]
+        assert uk.numel() == n_probe and (not hasattr(bench, "_xor_fold") or int(bench._xor_fold(uk)) == x_probe)
         res["config3_union_%d_files_x_%.0e" % (nfiles, per)] = {"ms": ms, "input_kmers": total, "kmers_per_s": total / ms * 1e3,
                                                                   "out": u.numel(), "gpus": 1,
                                                                   "algorithmic_GB": (8 * total + 8 * u.numel()) / 1e9,
-                                                                  "note": "k-way streaming merge (ukm_kway.hip): 3 levels of 8-way merges over shared value "
-                                                                          "ranges, all on one GPU (round 1: 7-level pairwise tree, 78.7 ms)"}
+                                                                  "ms_kway_merge_only": ms_kway,
+                                                                  "note": "union by LDS hash probes against the union of the first eight files (ukm_punion.hip); "
+                                                                          "ms_kway_merge_only = the k-way streaming merge (ukm_kway.hip, UKM_PUNION=0), same "
+                                                                          "result (size and XOR checksum compared); round 1: 7-level pairwise tree, 78.7 ms"}
         del files, U, out
 
     if "4" in want:
