@@ -325,6 +325,17 @@ def test_probe_union_matches_oracle(env, monkeypatch):
     crowded = small + [np.sort(np.concatenate([Us[_member(len(Us), 8 + f, 0.7, 9)], fresh[_member(len(fresh), f, 0.6, 13)]]))
                        for f in range(22)]
     assert np.array_equal(ctx.union(crowded), O.union(crowded))
+    # a dense private cluster behind the base set's last code: one range would have to stream it all, the load guard
+    # backs out (mode 1) / the one workgroup does it (mode 2)
+    Ub = _universe(1_000_000, gap_bits=20)
+    big = [Ub[_member(len(Ub), f, 0.5, 21)] for f in range(8)]
+    tail = Ub[-1] + np.uint64(1) + np.arange(400_000, dtype=np.uint64) * np.uint64(3)
+    big += [np.concatenate([Ub[_member(len(Ub), 8 + f, 0.5, 21)], tail[_member(len(tail), f, 0.8, 23)]]) for f in range(12)]
+    expect = np.unique(np.concatenate(big))
+    monkeypatch.setenv("UKM_PUNION", "1")
+    assert np.array_equal(ctx.union(big), expect)
+    monkeypatch.setenv("UKM_PUNION", "2")
+    assert np.array_equal(ctx.union(big), expect)
     # unsorted inputs: in the later files and among the first eight
     dirty = list(files)
     dirty[15] = rng.permutation(dirty[15])

@@ -69,7 +69,8 @@ __device__ __forceinline__ u64 pu_splitmix(u64 x) {
 }
 
 // cuts[r][j] = lower bound of the first base entry of range r in later file j (r = 0: 0, r = R: the file's length).
-// Threads of one file are neighbours: their first probes coincide, their last ones share lines.
+// Threads of one file are neighbours: their first probes coincide, their last ones share lines (bracketing every cut
+// around its interpolated position first made the kernel slower, 1.8 -> 2.9 ms: those probes are all distinct and cold).
 __global__ void pu_cuts_kernel(PuArgs a) {
     const u64 gid = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     const u64 per = (u64)a.R + 1;
@@ -92,6 +93,18 @@ __global__ void pu_cuts_kernel(PuArgs a) {
         res = lo;
     }
     a.cuts[(u64)r * a.S1 + j] = res;
+}
+
+// heaviest range: records of all later files inside one range (ctl[4] = max over the ranges)
+__global__ void pu_load_kernel(PuArgs a) {
+    const u32 r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= a.R) return;
+    u64 sum = 0;
+    for (u32 j = 0; j < a.S1; j++) {
+        const u64 b = a.cuts[(u64)r * a.S1 + j], e = a.cuts[(u64)(r + 1) * a.S1 + j];
+        sum += e > b ? e - b : 0;
+    }
+    atomicMax((unsigned long long *)&a.ctl[4], (unsigned long long)sum);
 }
 
 // hit rate of a sample of later records in the base set
@@ -461,6 +474,24 @@ int ukm_dev_probe_union(ukm_ctx *c, const u64 *const *keys, const u64 *lens, int
         const u64 ncuts = ((u64)a.R + 1) * (u64)s1;
         hipLaunchKernelGGL(pu_cuts_kernel, dim3((unsigned)((ncuts + 255) / 256)), dim3(256), 0, c->stream, a);
         lap("cuts");
+        {
+            // One workgroup streams everything that falls into its range: later files whose records crowd into a few
+            // ranges (codes beyond the base set's last entry, a dense cluster the base set does not have) would leave
+            // the pass to a handful of CUs.  More than 64 x the average load in one range: not this path.
+            hipLaunchKernelGGL(pu_load_kernel, dim3((a.R + 255) / 256), dim3(256), 0, c->stream, a);
+            UKM_HIP(hipGetLastError());
+            u64 heaviest = 0;
+            UKM_TRY(ukm_read_u64(c, ctl + 4, &heaviest));
+            u64 batch_records = 0;
+            for (int j = 0; j < s1; j++) batch_records += lens[PU_K0 + s0 + j];
+            const u64 avg = batch_records / a.R + 1;
+            if (dbg) fprintf(stderr, "[punion] heaviest range %llu records, average %llu\n", (unsigned long long)heaviest, (unsigned long long)avg);
+            if (mode != 2 && heaviest > 64 * avg + 65536) {
+                ws_release(c, mark);
+                return UKM_OK;  // (*fallback is still true; a batch that already ran only produced list entries)
+            }
+            UKM_HIP(hipMemsetAsync(ctl + 4, 0, sizeof(u64), c->stream));
+        }
         (void)hipEventRecord(c->ev_k0, c->stream);
         hipLaunchKernelGGL(pu_probe_kernel, dim3(a.R), dim3(PU_NT), 0, c->stream, a);
         (void)hipEventRecord(c->ev_k1, c->stream);
