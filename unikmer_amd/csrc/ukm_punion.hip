@@ -30,7 +30,10 @@
 
 namespace {
 
-constexpr int PU_K0 = 8;          // files merged into the base set
+#ifndef PU_K0_N
+#define PU_K0_N 8
+#endif
+constexpr int PU_K0 = PU_K0_N;    // files merged into the base set
 constexpr int PU_NT = 512;        // threads of a probe workgroup
 constexpr int PU_RANGE = 2048;    // base entries per range
 constexpr int PU_BUCKET_BITS = 11;  // 2048 buckets x 4 slots x 8 B = 64 KB of LDS: two workgroups per CU
