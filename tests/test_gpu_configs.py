@@ -348,3 +348,71 @@ def test_probe_union_matches_oracle(env, monkeypatch):
     gk, gt = ctx.union(files, taxs)
     ok, ot = O.union(files, taxs, tax)
     assert np.array_equal(gk, ok) and np.array_equal(gt, ot)
+
+
+# ---------------------------------------------------------- inter / diff by LDS hash probes (ukm_pfold.hip)
+def test_probe_fold_shapes(env, monkeypatch):
+    """`inter` (plain, LCA of taxids) and `diff` (plain) over many files through the hash-probe fold: same answers as the
+    oracle's sequential folds (inter.go:205-286, diff.go:379-454) AND as the range fold of ukm_fold.hip (UKM_NO_PFOLD=1),
+    for later files with and without taxids, one-record files, an all-ones code in the first file or in a later one
+    (the table's empty marker: exact route), first files of one range and of many, an unsorted stream (error)."""
+    O, L, ctx, tax, T = env
+    rng = np.random.default_rng(91)
+
+    monkeypatch.setenv("UKM_PFOLD_TAX", "1")   # inter with taxids through the probe fold as well (off by default: slower)
+
+    def both(files, taxs):
+        res = []
+        for no_pf in (None, "1"):
+            if no_pf is None:
+                monkeypatch.delenv("UKM_NO_PFOLD", raising=False)
+            else:
+                monkeypatch.setenv("UKM_NO_PFOLD", no_pf)
+            res.append((ctx.inter(files, taxs), ctx.inter(files), ctx.diff(files, taxs), ctx.diff(files)))
+        monkeypatch.delenv("UKM_NO_PFOLD", raising=False)
+        (ik, it), i0, (dk, dt), d0 = res[0]
+        (ik2, it2), i02, (dk2, dt2), d02 = res[1]
+        assert np.array_equal(ik, ik2) and np.array_equal(it, it2) and np.array_equal(i0, i02)
+        assert np.array_equal(dk, dk2) and np.array_equal(dt, dt2) and np.array_equal(d0, d02)
+        ok, ot = O.inter(files, taxs, tax)
+        assert np.array_equal(ik, ok) and np.array_equal(it, ot) and np.array_equal(i0, O.inter(files))
+        ok, ot = O.diff(files, taxs, tax)
+        assert np.array_equal(dk, ok) and np.array_equal(dt, ot) and np.array_equal(d0, O.diff(files))
+
+    for n_univ, nfiles, p, core in ((3_000, 40, 0.9, 0.2), (700_000, 12, 0.9, 0.3), (200, 9, 0.7, 0.3), (60_000, 130, 0.95, 0.1)):
+        files, taxs = _chain_files(nfiles, n_univ, p, core, 61, T)
+        both(files, taxs)
+    files, taxs = _chain_files(30, 20_000, 0.9, 0.25, 67, T)
+    # a later file of ONE record that is in the core / that is not; later files whose taxids are all zero
+    core_code = O.inter(files)[:1]
+    f2, t2 = list(files), list(taxs)
+    f2[7], t2[7] = core_code.copy(), _taxids(core_code, T, 7)
+    both(f2, t2)
+    f2[9], t2[9] = np.array([3], np.uint64), np.array([5], np.uint32)
+    both(f2, t2)
+    f2, t2 = list(files), list(taxs)
+    t2[4] = np.zeros(len(f2[4]), np.uint32)
+    t2[11] = np.zeros(len(f2[11]), np.uint32)
+    both(f2, t2)
+    # all-ones codes: in the first file (and everywhere: it survives inter), in later files only
+    ones = np.array([2**64 - 1], np.uint64)
+    f2 = [np.concatenate([f, ones]) for f in files]
+    t2 = [np.concatenate([t, np.array([7], np.uint32)]) for t in taxs]
+    both(f2, t2)
+    f2 = [files[0]] + [np.concatenate([f, ones]) for f in files[1:]]
+    t2 = [taxs[0]] + [np.concatenate([t, np.array([7], np.uint32)]) for t in taxs[1:]]
+    both(f2, t2)
+    # a duplicate inside a later file / inside the first: the exact multiset route
+    f2, t2 = list(files), list(taxs)
+    f2[13] = np.sort(np.concatenate([f2[13], f2[13][:5]]))
+    t2[13] = _taxids(f2[13], T, 13)
+    both(f2, t2)
+    f2, t2 = list(files), list(taxs)
+    f2[0] = np.sort(np.concatenate([f2[0], f2[0][-3:]]))
+    t2[0] = _taxids(f2[0], T, 0)
+    both(f2, t2)
+    # an unsorted later stream is an error for inter (the reference's 2-pointer walk would silently miss codes)
+    f2 = list(files)
+    f2[5] = rng.permutation(f2[5])
+    with pytest.raises(L.UkmError):
+        ctx.inter(f2)

@@ -19,6 +19,7 @@
 #include "ukm_fold.h"
 #include "ukm_kway.h"
 #include "ukm_punion.h"
+#include "ukm_pfold.h"
 
 namespace {
 
@@ -409,6 +410,19 @@ int try_range_fold(ukm_ctx *ctx, int op, const std::vector<Stream> &ss, u32 flag
         kp[i] = ss[i].k;
         tp[i] = ss[i].t;
         ln[i] = ss[i].n;
+    }
+    if (ukm_pfold_enabled()) {
+        // the order-independent rules (inter without --mix-taxid, diff without -t) by hash probes (ukm_pfold.hip)
+        WsMark pm = ws_mark(ctx);
+        bool fb = true;
+        const int prc = ukm_dev_probe_fold(ctx, op, kp.data(), tax ? tp.data() : nullptr, ln.data(), (int)ss.size(), tax, flags, fk, ft,
+                                           fcap, n_out, &fb);
+        ws_release(ctx, pm);
+        UKM_TRY(prc);
+        if (!fb) {
+            *done = true;
+            return UKM_OK;
+        }
     }
     WsMark mark = ws_mark(ctx);
     bool fallback = false;

@@ -1,0 +1,412 @@
+// ukm_pfold.hip — `inter` / `diff` over MANY sorted sets by LDS hash probes (round 3, after ukm_punion.hip).
+// Replaces the per-file loops inter.go:205-286 / diff.go:379-454 like ukm_fold.hip does, for the rules that do not depend
+// on the ORDER of the files:
+//     inter        a code of file 0 survives when every later file has it; TaxId = LCA over all files (inter.go:229-239
+//                  without --mix-taxid: LCA is associative and commutative, 0 / unknown absorbing — ukm_device.h lca_dev)
+//     diff         a code of file 0 survives when no later file has it; it keeps its own TaxId (diff.go:404-409 without -t)
+// (`inter --mix-taxid` and `diff -t` go to the range fold of ukm_fold.hip, whose survivors see the files in order; so
+//  does, by default, `inter` with taxids: see ukm_dev_probe_fold.)
+//
+// ukm_fold.hip keeps the survivors in registers and looks each of them up in every file's slice (a lock-step binary
+// search per survivor per file: bound by dependent-instruction latency, 1.6-1.9 TB/s).  Here the roles are swapped, as in
+// ukm_punion.hip: file 0 is cut into ranges of L <= 1536 records; one workgroup per range puts its records into a
+// bucketised LDS table (1024 buckets x 4 slots, slot -> record index beside it) and its waves STREAM the slices of the
+// later files, one slice per wave at a time: per record one hash and one 32-byte bucket read; a hit bumps the record's
+// counter (inter: alive = S - 1 hits; diff: any hit kills) and, for inter with taxids, folds the TaxId in with a CAS
+// loop (skipped for records that are already known to be dead: fewer hits than files finished).  Every file is
+// checked for strictly increasing order on the way; a duplicate code anywhere (or an all-ones code in file 0, which
+// is the table's empty marker) sends the call to the exact routes behind it.
+// Algorithmic bytes: 8 per record of the later files (+ 4 for inter with taxids), read once.
+#include <stdlib.h>
+
+#include <algorithm>
+#include <atomic>
+#include <vector>
+
+#include "ukm_device.h"
+#include "ukm_pfold.h"
+
+namespace {
+
+constexpr int PF_NT = 512;
+constexpr int PF_BUCKET_BITS = 10;
+constexpr int PF_BUCKETS = 1 << PF_BUCKET_BITS;
+constexpr int PF_SLOTS = 4 * PF_BUCKETS;
+constexpr int PF_PER = 3;                // records of file 0 per thread
+constexpr int PF_MAXL = PF_NT * PF_PER;  // 1536
+constexpr int PF_MINL = 256;
+constexpr u64 PF_EMPTY = ~0ull;
+enum { PF_FLAG_DUP = 1, PF_FLAG_UNSORTED = 2 };
+
+struct PfArgs {
+    const u64 *tab;  // [keys S][taxids S][lens S] (device copies of the caller's tables)
+    u32 S, R, L;
+    u64 *cuts;       // [R + 1][S - 1]: lower bound of file0[r * L] in file j (j = 1 .. S - 1)
+    u64 *tmp_k;      // [R][L]
+    u32 *tmp_t;
+    u64 *cnt;        // [R]
+    u64 *ctl;        // [0] total (written by the scan), [1] flags
+    TaxDev T;
+};
+
+__device__ __forceinline__ u32 pf_hash(u64 x) {
+    const u32 lo = (u32)x, hi = (u32)(x >> 32);
+    return ((lo ^ (hi * 0x85EBCA6Bu)) * 0x9E3779B1u) >> (32 - PF_BUCKET_BITS);
+}
+
+__global__ void pf_cuts_kernel(PfArgs a) {
+    const u64 gid = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    const u64 per = (u64)a.R + 1;
+    const u32 S1 = a.S - 1;
+    if (gid >= per * S1) return;
+    const u32 j = (u32)(gid / per) + 1, r = (u32)(gid % per);
+    const u64 len = a.tab[2 * (u64)a.S + j];
+    u64 res;
+    if (r == 0) {
+        res = 0;
+    } else if (r == a.R) {
+        res = len;
+    } else {
+        const auto f0 = as_global((const u64 *)(uintptr_t)a.tab[0]);
+        const auto f = as_global((const u64 *)(uintptr_t)a.tab[j]);
+        const u64 v = f0[(u64)r * a.L];
+        u64 lo = 0, hi = len;
+        while (lo < hi) {
+            const u64 mid = (lo + hi) >> 1;
+            if (f[mid] < v) lo = mid + 1; else hi = mid;
+        }
+        res = lo;
+    }
+    a.cuts[(u64)r * S1 + (j - 1)] = res;
+}
+
+typedef u64 pf_u64x2 __attribute__((ext_vector_type(2)));
+typedef pf_u64x2 __attribute__((aligned(8))) pf_pair;
+typedef u32 pf_u32x2 __attribute__((ext_vector_type(2)));
+typedef pf_u32x2 __attribute__((aligned(4))) pf_tpair;
+
+template <int OP, bool TAX>
+__global__ __launch_bounds__(PF_NT) void pf_probe_kernel(PfArgs a) {
+    __shared__ __attribute__((aligned(32))) u64 s_tab[PF_SLOTS];
+    __shared__ unsigned short s_idx[PF_SLOTS];
+    __shared__ u32 s_cnt[PF_MAXL];
+    __shared__ u32 s_tax[TAX ? PF_MAXL : 1];
+    __shared__ u32 s_scan[PF_NT / 64 + 1];
+    __shared__ u32 s_next, s_done;
+    constexpr bool FOLD_TAX = TAX && OP == UKM_OP_INTER;
+    const int tid = (int)threadIdx.x, lane = lane_id();
+    const u32 r = blockIdx.x, S = a.S, S1 = S - 1, L = a.L;
+    const auto f0 = as_global((const u64 *)(uintptr_t)sload_u64(&a.tab[0]));
+    const auto t0 = as_global((const u32 *)(uintptr_t)sload_u64(&a.tab[S]));
+    const u64 len0 = sload_u64(&a.tab[2 * (u64)S]);
+    const u64 e0 = (u64)r * L;
+    const u32 ne = (u32)((len0 - e0 < (u64)L) ? (len0 - e0) : (u64)L);
+    for (int i = tid; i < PF_SLOTS; i += PF_NT) s_tab[i] = PF_EMPTY;
+    if (tid == 0) { s_next = 0; s_done = 0; }
+    u32 flags = 0;
+    u64 ent[PF_PER];
+#pragma unroll
+    for (int k = 0; k < PF_PER; k++) {
+        const u32 i = (u32)tid + (u32)k * PF_NT;
+        ent[k] = PF_EMPTY;
+        if (i < ne) {
+            const u64 e = f0[e0 + i];
+            ent[k] = e;
+            s_cnt[i] = 0;
+            if (TAX) s_tax[i] = t0 ? t0[e0 + i] : 0u;
+            if (e0 + i + 1 < len0) {  // file 0 strictly increasing (also across the range's end)
+                const u64 nx = f0[e0 + i + 1];
+                if (e == nx) flags |= PF_FLAG_DUP;
+                if (e > nx) flags |= PF_FLAG_UNSORTED;
+            }
+            if (e == PF_EMPTY) flags |= PF_FLAG_DUP;  // (the empty marker: the exact route takes the call)
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < PF_PER; k++) {
+        const u32 i = (u32)tid + (u32)k * PF_NT;
+        const u64 e = ent[k];
+        if (i >= ne || e == PF_EMPTY) continue;
+        // first free slot of the first bucket of its probe sequence that is not full (slots fill in order, nothing is
+        // ever removed: "slot 3 taken" = "bucket full")
+        u32 h = pf_hash(e);
+        for (bool placed = false; !placed; h = (h + 1) & (PF_BUCKETS - 1)) {
+#pragma unroll
+            for (int q = 0; q < 4 && !placed; q++) {
+                const u64 old = atomicCAS((unsigned long long *)&s_tab[4 * h + q], (unsigned long long)PF_EMPTY, (unsigned long long)e);
+                if (old == PF_EMPTY) { s_idx[4 * h + q] = (unsigned short)i; placed = true; }
+                else if (old == e) { flags |= PF_FLAG_DUP; placed = true; }
+            }
+        }
+    }
+    __syncthreads();
+
+    // record index of x in this range's table, or -1
+    auto find = [&](u64 x) -> int {
+        u32 h = pf_hash(x);
+        for (;;) {
+            const ulonglong2 *b = reinterpret_cast<const ulonglong2 *>(&s_tab[4 * h]);
+            const ulonglong2 p = b[0], q = b[1];
+            const bool m0 = p.x == x, m1 = p.y == x, m2 = q.x == x, m3 = q.y == x;
+            if (m0 | m1 | m2 | m3) {
+                if (x == PF_EMPTY) return -1;
+                const int k = m0 ? 0 : (m1 ? 1 : (m2 ? 2 : 3));
+                return (int)s_idx[4 * h + k];
+            }
+            if (q.y == PF_EMPTY) return -1;
+            h = (h + 1) & (PF_BUCKETS - 1);
+        }
+    };
+    auto hit = [&](int idx, u32 tb) {
+        if (OP == UKM_OP_DIFF) {
+            s_cnt[idx] = 1;  // (every writer stores the same value)
+        } else {
+            // files finished BEFORE this hit is counted (acquire: the count below is not moved in front of the read):
+            // a record that is in every file has one hit from each of them in its counter by now
+            const u32 finished = FOLD_TAX ? __hip_atomic_load(&s_done, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) : 0u;
+            const u32 now = atomicAdd(&s_cnt[idx], 1u) + 1;
+            if (FOLD_TAX && now > finished) {  // (not more hits than finished files: one of them did not have it — dead)
+                u32 old = s_tax[idx];
+                for (;;) {
+                    const u32 nw = lca_dev(a.T, old, tb);
+                    if (nw == old) break;
+                    const u32 prev = atomicCAS(&s_tax[idx], old, nw);
+                    if (prev == old) break;
+                    old = prev;
+                }
+            }
+        }
+    };
+    auto step = [&](auto UU, const ukm_gptr<u64> f, const ukm_gptr<u32> t, u64 p0, u64 end, u64 len) {
+        constexpr int U = decltype(UU)::value;
+        pf_pair pr[U];
+        pf_tpair tq[U];
+        u64 nx[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {  // branch-free loads from addresses clamped into the file (see ukm_punion.hip)
+            const u64 pos = p0 + (u64)u * 128 + 2u * (u32)lane;
+            const u64 q = pos < len - 2 ? pos : len - 2;
+            const u64 q2 = pos + 2 < len ? pos + 2 : len - 1;
+            pr[u] = *(const pf_pair __attribute__((address_space(1))) *)(f + q);
+            nx[u] = f[q2];
+            tq[u] = pf_tpair{0, 0};
+            if (FOLD_TAX && t) tq[u] = *(const pf_tpair __attribute__((address_space(1))) *)(t + q);  // (wave-uniform test)
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            u64 v0 = pr[u].x, v1 = pr[u].y;
+            asm volatile("" : "+v"(v0), "+v"(v1), "+v"(nx[u]));  // (pins the loads in front of the processing)
+            pr[u].x = v0;
+            pr[u].y = v1;
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const u64 pos = p0 + (u64)u * 128 + 2u * (u32)lane;
+            const u32 nv = pos + 1 < end ? 2u : (pos < end ? 1u : 0u);
+            const bool shifted = pos > len - 2;  // pos = len - 1: the record is the pair's second
+            const u64 x0 = shifted ? pr[u].y : pr[u].x;
+            const u64 x1 = pr[u].y;
+            const u32 tb0 = shifted ? tq[u].y : tq[u].x, tb1 = tq[u].y;
+            // strictly increasing, every neighbouring pair of the file once (also across slices)
+            if (nv == 2) {
+                if (x0 == x1) flags |= PF_FLAG_DUP;
+                if (x0 > x1) flags |= PF_FLAG_UNSORTED;
+                if (pos + 2 < len) {
+                    if (x1 == nx[u]) flags |= PF_FLAG_DUP;
+                    if (x1 > nx[u]) flags |= PF_FLAG_UNSORTED;
+                }
+            } else if (nv == 1 && !shifted && pos + 1 < len) {
+                if (x0 == x1) flags |= PF_FLAG_DUP;
+                if (x0 > x1) flags |= PF_FLAG_UNSORTED;
+            }
+            if (nv >= 1) {
+                const int i0 = find(x0);
+                if (i0 >= 0) hit(i0, tb0);
+            }
+            if (nv == 2) {
+                const int i1 = find(x1);
+                if (i1 >= 0) hit(i1, tb1);
+            }
+        }
+    };
+    auto take = [&]() -> u32 {
+        u32 j = 0;
+        if (lane == 0) j = atomicAdd(&s_next, 1u);
+        return (u32)__builtin_amdgcn_readfirstlane((int)j);
+    };
+    struct Meta { u64 beg, end, len, f, t; };
+    auto fetch = [&](u32 j) -> Meta {  // j = 0 .. S1 - 1 stands for file j + 1
+        Meta m = {0, 0, 0, 0, 0};
+        if (j < S1) {
+            m.beg = sload_u64(&a.cuts[(u64)r * S1 + j]);
+            m.end = sload_u64(&a.cuts[(u64)(r + 1) * S1 + j]);
+            m.f = sload_u64(&a.tab[j + 1]);
+            m.t = sload_u64(&a.tab[(u64)S + j + 1]);
+            m.len = sload_u64(&a.tab[2 * (u64)S + j + 1]);
+        }
+        return m;
+    };
+    u32 j = take();
+    Meta cur = fetch(j);
+    while (j < S1) {
+        const u32 jn = take();
+        const Meta nxt = fetch(jn);
+        const auto f = as_global((const u64 *)(uintptr_t)cur.f);
+        const auto t = as_global((const u32 *)(uintptr_t)cur.t);
+        const u64 len = cur.len, end = cur.end < cur.beg ? cur.beg : cur.end;
+        if (len < 2) {  // (a one-record file: no 16-byte load fits)
+            if (end > cur.beg && lane == 0) {
+                const int i0 = find(f[0]);
+                if (i0 >= 0) hit(i0, (FOLD_TAX && t) ? t[0] : 0u);
+            }
+        } else {
+            u64 p0 = cur.beg;
+            while (p0 < end) {
+                const u64 rem = end - p0;
+                if (rem > 256) { step(std::integral_constant<int, 4>{}, f, t, p0, end, len); p0 += 512; }
+                else if (rem > 128) { step(std::integral_constant<int, 2>{}, f, t, p0, end, len); p0 += 256; }
+                else { step(std::integral_constant<int, 1>{}, f, t, p0, end, len); p0 += 128; }
+            }
+        }
+        if (OP == UKM_OP_INTER && lane == 0) atomicAdd(&s_done, 1u);  // (its hits are all in: LDS operations of a wave stay in order)
+        j = jn;
+        cur = nxt;
+    }
+    if (flags) atomicOr((unsigned long long *)&a.ctl[1], (unsigned long long)flags);
+    __syncthreads();
+    // survivors in file-0 order: three ordered compactions of 512 records each
+    u32 base = 0;
+#pragma unroll
+    for (int k = 0; k < PF_PER; k++) {
+        const u32 i = (u32)tid + (u32)k * PF_NT;
+        bool alive = false;
+        if (i < ne) alive = OP == UKM_OP_INTER ? s_cnt[i] == S1 : s_cnt[i] == 0;
+        u32 total = 0;
+        const u32 excl = block_excl_scan_u32<PF_NT>(alive ? 1u : 0u, s_scan, &total);
+        if (alive) {
+            const u64 o = (u64)r * L + base + excl;
+            a.tmp_k[o] = ent[k];
+            if (TAX) a.tmp_t[o] = s_tax[i];
+        }
+        base += total;
+    }
+    if (tid == 0) a.cnt[r] = base;
+}
+
+// ranges -> contiguous output: workgroup r copies its cnt[r] survivors to out[excl[r] ...)
+__global__ void pf_gather_kernel(const u64 *tmp_k, const u32 *tmp_t, const u64 *cnt, const u64 *excl, u64 *out, u32 *tout,
+                                 u64 out_cap, u32 L) {
+    const u32 r = blockIdx.x;
+    const u64 n = cnt[r], base = excl[r];
+    for (u64 i = threadIdx.x; i < n; i += blockDim.x) {
+        const u64 pos = base + i;
+        if (pos < out_cap) {
+            out[pos] = tmp_k[(size_t)r * L + i];
+            if (tout) tout[pos] = tmp_t ? tmp_t[(size_t)r * L + i] : 0u;
+        }
+    }
+}
+
+}  // namespace
+
+bool ukm_pfold_enabled() {
+    const char *e = getenv("UKM_NO_PFOLD");
+    return !(e && e[0] == '1');
+}
+
+int ukm_dev_probe_fold(ukm_ctx *c, int op, const u64 *const *keys, const u32 *const *taxids, const u64 *lens, int S, bool tax,
+                       u32 flags, u64 *out, u32 *tout, u64 out_cap, u64 *n_out, bool *fallback) {
+    *fallback = true;
+    *n_out = 0;
+    if (op != UKM_OP_INTER && op != UKM_OP_DIFF) return UKM_OK;
+    if ((op == UKM_OP_INTER && (flags & UKM_F_MIX_TAXID)) || (op == UKM_OP_DIFF && (flags & UKM_F_CMP_TAXID))) return UKM_OK;
+    {
+        // inter WITH taxids: one LCA per hit of a record that is still alive, done where the hit is found (a CAS loop
+        // around two dependent table reads, nothing else of the lane in flight).  Measured on config 4-core (3e8 such
+        // LCAs): 12.5 ms against the range fold's 10.1 (five LCAs in flight per thread there); on config 4 itself, whose
+        // survivors die within 130 files, 5.5 against 5.7.  Taken only on request (UKM_PFOLD_TAX=1: tests).
+        const char *e = getenv("UKM_PFOLD_TAX");
+        if (op == UKM_OP_INTER && tax && !(e && e[0] == '1')) return UKM_OK;
+    }
+    if (S < 2 || lens[0] == 0) return UKM_OK;
+    for (int j = 0; j < S; j++)
+        if (lens[j] == 0) return UKM_OK;  // (the caller drops / truncates at empty files; anything else: not here)
+    if (tax && op == UKM_OP_INTER && c->tax_parent == nullptr)
+        UKM_FAIL(UKM_ERR_NO_TAXONOMY, "ukm_setop2: records carry taxids but no taxonomy is loaded");
+    if (tax && !tout) UKM_FAIL(UKM_ERR_INVALID, "probe fold: taxids given but out_taxids is NULL");
+    // one round of resident workgroups when the first file allows it
+    static std::atomic<int> slots_cache;
+    if (!slots_cache.load(std::memory_order_relaxed)) {
+        int per_cu = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pf_probe_kernel<UKM_OP_INTER, true>, PF_NT, 0) != hipSuccess || per_cu <= 0)
+            per_cu = 2;
+        slots_cache.store(per_cu * c->num_cu, std::memory_order_relaxed);
+    }
+    const u64 slots = (u64)slots_cache.load(std::memory_order_relaxed);
+    u64 L = (lens[0] + slots - 1) / slots;
+    L = std::min<u64>(std::max<u64>(L, PF_MINL), PF_MAXL);
+    const u64 R64 = (lens[0] + L - 1) / L;
+    if (R64 > 0x7FFFFFFEull) return UKM_OK;
+    {
+        // (the shape guard of ukm_fold.hip: a tiny first file against huge later ones leaves whole files to a few CUs)
+        u64 rest = 0;
+        for (int j = 1; j < S; j++) rest += lens[j];
+        if (rest / (u64)(S - 1) / R64 > 16ull * PF_MAXL) return UKM_OK;
+    }
+    const size_t ntab = (size_t)3 * S;
+    std::vector<u64> tab(ntab);
+    for (int j = 0; j < S; j++) {
+        tab[(size_t)j] = (u64)(uintptr_t)keys[j];
+        tab[(size_t)S + j] = (u64)(uintptr_t)((tax && taxids) ? taxids[j] : nullptr);
+        tab[(size_t)2 * S + j] = lens[j];
+    }
+    u64 *d_tab = nullptr;
+    UKM_TRY(ws_alloc_t(c, ntab, &d_tab));
+    UKM_HIP(hipMemcpyAsync(d_tab, tab.data(), ntab * sizeof(u64), hipMemcpyHostToDevice, c->stream));
+    UKM_HIP(hipStreamSynchronize(c->stream));  // `tab` is a pageable host buffer of this frame
+
+    PfArgs a;
+    memset(&a, 0, sizeof(a));
+    a.tab = d_tab;
+    a.S = (u32)S;
+    a.R = (u32)R64;
+    a.L = (u32)L;
+    a.T = ukm_taxdev(c);
+    u64 *excl = nullptr;
+    UKM_TRY(ws_alloc_t(c, ((size_t)a.R + 1) * (S - 1), &a.cuts));
+    UKM_TRY(ws_alloc_t(c, (size_t)a.R * L, &a.tmp_k));
+    if (tax) UKM_TRY(ws_alloc_t(c, (size_t)a.R * L, &a.tmp_t));
+    UKM_TRY(ws_alloc_t(c, (size_t)a.R, &a.cnt));
+    UKM_TRY(ws_alloc_t(c, (size_t)a.R + 1, &excl));
+    UKM_TRY(ws_alloc_t(c, 8, &a.ctl));
+    UKM_HIP(hipMemsetAsync(a.ctl, 0, 8 * sizeof(u64), c->stream));
+    const u64 ncuts = ((u64)a.R + 1) * (u64)(S - 1);
+    hipLaunchKernelGGL(pf_cuts_kernel, dim3((unsigned)((ncuts + 255) / 256)), dim3(256), 0, c->stream, a);
+    (void)hipEventRecord(c->ev_k0, c->stream);
+    if (op == UKM_OP_INTER) {
+        if (tax) hipLaunchKernelGGL((pf_probe_kernel<UKM_OP_INTER, true>), dim3(a.R), dim3(PF_NT), 0, c->stream, a);
+        else hipLaunchKernelGGL((pf_probe_kernel<UKM_OP_INTER, false>), dim3(a.R), dim3(PF_NT), 0, c->stream, a);
+    } else {
+        if (tax) hipLaunchKernelGGL((pf_probe_kernel<UKM_OP_DIFF, true>), dim3(a.R), dim3(PF_NT), 0, c->stream, a);
+        else hipLaunchKernelGGL((pf_probe_kernel<UKM_OP_DIFF, false>), dim3(a.R), dim3(PF_NT), 0, c->stream, a);
+    }
+    (void)hipEventRecord(c->ev_k1, c->stream);
+    c->evk_valid = true;
+    UKM_HIP(hipGetLastError());
+    UKM_TRY(ukm_dev_exclusive_scan_u64(c, a.cnt, excl, a.R, a.ctl));  // ctl[0] = total
+    hipLaunchKernelGGL(pf_gather_kernel, dim3(a.R), dim3(256), 0, c->stream, a.tmp_k, tax ? a.tmp_t : nullptr, a.cnt, excl, out,
+                       tax ? tout : nullptr, out_cap, a.L);
+    UKM_HIP(hipGetLastError());
+    u64 h[2] = {0, 0};
+    UKM_TRY(ukm_read_u64(c, a.ctl, h, 2));
+    if (getenv("UKM_FOLD_DEBUG"))
+        fprintf(stderr, "[pfold] op=%d S=%d R=%u L=%u slots=%llu tax=%d flags=%llu out=%llu\n", op, S, a.R, a.L, (unsigned long long)slots,
+                (int)tax, (unsigned long long)h[1], (unsigned long long)h[0]);
+    if (h[1] != 0) return UKM_OK;  // duplicate / unsorted / empty marker: the routes behind this one handle and report it
+    *n_out = h[0];
+    if (h[0] > out_cap)
+        UKM_FAIL(UKM_ERR_CAPACITY, "output needs %llu records, capacity is %llu", (unsigned long long)h[0], (unsigned long long)out_cap);
+    *fallback = false;
+    return UKM_OK;
+}
