@@ -368,12 +368,16 @@ def test_probe_fold_shapes(env, monkeypatch):
                 monkeypatch.delenv("UKM_NO_PFOLD", raising=False)
             else:
                 monkeypatch.setenv("UKM_NO_PFOLD", no_pf)
-            res.append((ctx.inter(files, taxs), ctx.inter(files), ctx.diff(files, taxs), ctx.diff(files)))
+            res.append((ctx.inter(files, taxs), ctx.inter(files), ctx.diff(files, taxs), ctx.diff(files),
+                        ctx.diff(files, taxs, compare_taxid=True)))
         monkeypatch.delenv("UKM_NO_PFOLD", raising=False)
-        (ik, it), i0, (dk, dt), d0 = res[0]
-        (ik2, it2), i02, (dk2, dt2), d02 = res[1]
+        (ik, it), i0, (dk, dt), d0, (ck, ct) = res[0]
+        (ik2, it2), i02, (dk2, dt2), d02, (ck2, ct2) = res[1]
         assert np.array_equal(ik, ik2) and np.array_equal(it, it2) and np.array_equal(i0, i02)
         assert np.array_equal(dk, dk2) and np.array_equal(dt, dt2) and np.array_equal(d0, d02)
+        assert np.array_equal(ck, ck2) and np.array_equal(ct, ct2)
+        ok, ot = O.diff(files, taxs, tax, compare_taxid=True)
+        assert np.array_equal(ck, ok) and np.array_equal(ct, ot)
         ok, ot = O.inter(files, taxs, tax)
         assert np.array_equal(ik, ok) and np.array_equal(it, ot) and np.array_equal(i0, O.inter(files))
         ok, ot = O.diff(files, taxs, tax)
@@ -393,6 +397,13 @@ def test_probe_fold_shapes(env, monkeypatch):
     f2, t2 = list(files), list(taxs)
     t2[4] = np.zeros(len(f2[4]), np.uint32)
     t2[11] = np.zeros(len(f2[11]), np.uint32)
+    both(f2, t2)
+    # diff -t keeps a code whose taxid in the later file equals the first file's or lies below it: later files that
+    # copy the first file's taxids for the codes they share (kept), and files with the PARENT-side taxid (removed)
+    f2, t2 = list(files), list(taxs)
+    first = dict(zip(files[0].tolist(), taxs[0].tolist()))
+    for j in (3, 8, 21):
+        t2[j] = np.array([first.get(int(c), int(t)) for c, t in zip(f2[j], t2[j])], np.uint32)
     both(f2, t2)
     # all-ones codes: in the first file (and everywhere: it survives inter), in later files only
     ones = np.array([2**64 - 1], np.uint64)

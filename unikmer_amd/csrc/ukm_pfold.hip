@@ -3,9 +3,10 @@
 // on the ORDER of the files:
 //     inter        a code of file 0 survives when every later file has it; TaxId = LCA over all files (inter.go:229-239
 //                  without --mix-taxid: LCA is associative and commutative, 0 / unknown absorbing — ukm_device.h lca_dev)
-//     diff         a code of file 0 survives when no later file has it; it keeps its own TaxId (diff.go:404-409 without -t)
-// (`inter --mix-taxid` and `diff -t` go to the range fold of ukm_fold.hip, whose survivors see the files in order; so
-//  does, by default, `inter` with taxids: see ukm_dev_probe_fold.)
+//     diff         a code of file 0 survives when no later file has it; it keeps its own TaxId (diff.go:404-409)
+//     diff -t      ... when no later file has it with a taxid that differs from its own and does not lie below it
+// (`inter --mix-taxid` goes to the range fold of ukm_fold.hip, whose survivors see the files in order; so does, by
+//  default, `inter` with taxids: see ukm_dev_probe_fold.)
 //
 // ukm_fold.hip keeps the survivors in registers and looks each of them up in every file's slice (a lock-step binary
 // search per survivor per file: bound by dependent-instruction latency, 1.6-1.9 TB/s).  Here the roles are swapped, as in
@@ -85,7 +86,7 @@ typedef pf_u64x2 __attribute__((aligned(8))) pf_pair;
 typedef u32 pf_u32x2 __attribute__((ext_vector_type(2)));
 typedef pf_u32x2 __attribute__((aligned(4))) pf_tpair;
 
-template <int OP, bool TAX>
+template <int OP, bool TAX, bool CMP = false>
 __global__ __launch_bounds__(PF_NT) void pf_probe_kernel(PfArgs a) {
     __shared__ __attribute__((aligned(32))) u64 s_tab[PF_SLOTS];
     __shared__ unsigned short s_idx[PF_SLOTS];
@@ -93,7 +94,7 @@ __global__ __launch_bounds__(PF_NT) void pf_probe_kernel(PfArgs a) {
     __shared__ u32 s_tax[TAX ? PF_MAXL : 1];
     __shared__ u32 s_scan[PF_NT / 64 + 1];
     __shared__ u32 s_next, s_done;
-    constexpr bool FOLD_TAX = TAX && OP == UKM_OP_INTER;
+    constexpr bool FOLD_TAX = TAX && (OP == UKM_OP_INTER || CMP);  // the later files' taxids are read
     const int tid = (int)threadIdx.x, lane = lane_id();
     const u32 r = blockIdx.x, S = a.S, S1 = S - 1, L = a.L;
     const auto f0 = as_global((const u64 *)(uintptr_t)sload_u64(&a.tab[0]));
@@ -160,7 +161,18 @@ __global__ __launch_bounds__(PF_NT) void pf_probe_kernel(PfArgs a) {
     };
     auto hit = [&](int idx, u32 tb) {
         if (OP == UKM_OP_DIFF) {
-            s_cnt[idx] = 1;  // (every writer stores the same value)
+            if (CMP) {
+                // diff -t (diff.go:404-409): the hit removes the code unless the file's taxid equals the survivor's own or
+                // lies below it.  The survivor's taxid never changes, so the files may come in any order; a code that is
+                // already gone needs no LCA (with taxids that rarely nest that is nearly every hit after the first).
+                if (s_cnt[idx] == 0) {
+                    const u32 ta = s_tax[idx];
+                    const bool keep = ta == tb || lca_dev(a.T, tb, ta) == ta;
+                    if (!keep) s_cnt[idx] = 1;
+                }
+            } else {
+                s_cnt[idx] = 1;  // (every writer stores the same value)
+            }
         } else {
             // files finished BEFORE this hit is counted (acquire: the count below is not moved in front of the read):
             // a record that is in every file has one hit from each of them in its counter by now
@@ -320,7 +332,8 @@ int ukm_dev_probe_fold(ukm_ctx *c, int op, const u64 *const *keys, const u32 *co
     *fallback = true;
     *n_out = 0;
     if (op != UKM_OP_INTER && op != UKM_OP_DIFF) return UKM_OK;
-    if ((op == UKM_OP_INTER && (flags & UKM_F_MIX_TAXID)) || (op == UKM_OP_DIFF && (flags & UKM_F_CMP_TAXID))) return UKM_OK;
+    if (op == UKM_OP_INTER && (flags & UKM_F_MIX_TAXID)) return UKM_OK;
+    const bool cmp = op == UKM_OP_DIFF && tax && (flags & UKM_F_CMP_TAXID);
     {
         // inter WITH taxids: one LCA per hit of a record that is still alive, done where the hit is found (a CAS loop
         // around two dependent table reads, nothing else of the lane in flight).  Measured on config 4-core (3e8 such
@@ -332,7 +345,7 @@ int ukm_dev_probe_fold(ukm_ctx *c, int op, const u64 *const *keys, const u32 *co
     if (S < 2 || lens[0] == 0) return UKM_OK;
     for (int j = 0; j < S; j++)
         if (lens[j] == 0) return UKM_OK;  // (the caller drops / truncates at empty files; anything else: not here)
-    if (tax && op == UKM_OP_INTER && c->tax_parent == nullptr)
+    if (tax && (op == UKM_OP_INTER || cmp) && c->tax_parent == nullptr)
         UKM_FAIL(UKM_ERR_NO_TAXONOMY, "ukm_setop2: records carry taxids but no taxonomy is loaded");
     if (tax && !tout) UKM_FAIL(UKM_ERR_INVALID, "probe fold: taxids given but out_taxids is NULL");
     // one round of resident workgroups when the first file allows it
@@ -388,7 +401,8 @@ int ukm_dev_probe_fold(ukm_ctx *c, int op, const u64 *const *keys, const u32 *co
         if (tax) hipLaunchKernelGGL((pf_probe_kernel<UKM_OP_INTER, true>), dim3(a.R), dim3(PF_NT), 0, c->stream, a);
         else hipLaunchKernelGGL((pf_probe_kernel<UKM_OP_INTER, false>), dim3(a.R), dim3(PF_NT), 0, c->stream, a);
     } else {
-        if (tax) hipLaunchKernelGGL((pf_probe_kernel<UKM_OP_DIFF, true>), dim3(a.R), dim3(PF_NT), 0, c->stream, a);
+        if (cmp) hipLaunchKernelGGL((pf_probe_kernel<UKM_OP_DIFF, true, true>), dim3(a.R), dim3(PF_NT), 0, c->stream, a);
+        else if (tax) hipLaunchKernelGGL((pf_probe_kernel<UKM_OP_DIFF, true>), dim3(a.R), dim3(PF_NT), 0, c->stream, a);
         else hipLaunchKernelGGL((pf_probe_kernel<UKM_OP_DIFF, false>), dim3(a.R), dim3(PF_NT), 0, c->stream, a);
     }
     (void)hipEventRecord(c->ev_k1, c->stream);
