@@ -86,8 +86,9 @@ typedef pf_u64x2 __attribute__((aligned(8))) pf_pair;
 typedef u32 pf_u32x2 __attribute__((ext_vector_type(2)));
 typedef pf_u32x2 __attribute__((aligned(4))) pf_tpair;
 
+// (three 512-thread workgroups per CU = 6 waves per SIMD: 85 registers; the inter + taxids variant came out at 89)
 template <int OP, bool TAX, bool CMP = false>
-__global__ __launch_bounds__(PF_NT) void pf_probe_kernel(PfArgs a) {
+__global__ __launch_bounds__(PF_NT) __attribute__((amdgpu_waves_per_eu(6, 6))) void pf_probe_kernel(PfArgs a) {
     __shared__ __attribute__((aligned(32))) u64 s_tab[PF_SLOTS];
     __shared__ unsigned short s_idx[PF_SLOTS];
     __shared__ u32 s_cnt[PF_MAXL];
@@ -195,6 +196,8 @@ __global__ __launch_bounds__(PF_NT) void pf_probe_kernel(PfArgs a) {
         pf_pair pr[U];
         pf_tpair tq[U];
         u64 nx[U];
+        int li[OP == UKM_OP_INTER && TAX ? 2 * U : 1];
+        u32 lt[OP == UKM_OP_INTER && TAX ? 2 * U : 1];
 #pragma unroll
         for (int u = 0; u < U; u++) {  // branch-free loads from addresses clamped into the file (see ukm_punion.hip)
             const u64 pos = p0 + (u64)u * 128 + 2u * (u32)lane;
@@ -232,13 +235,52 @@ __global__ __launch_bounds__(PF_NT) void pf_probe_kernel(PfArgs a) {
                 if (x0 == x1) flags |= PF_FLAG_DUP;
                 if (x0 > x1) flags |= PF_FLAG_UNSORTED;
             }
-            if (nv >= 1) {
-                const int i0 = find(x0);
-                if (i0 >= 0) hit(i0, tb0);
+            if constexpr (OP == UKM_OP_INTER && TAX) {
+                // inter with taxids: count the hits now, fold the taxids below with the table reads of all of the
+                // step's LCAs in flight together
+                li[2 * u] = nv >= 1 ? find(x0) : -1;
+                li[2 * u + 1] = nv == 2 ? find(x1) : -1;
+                lt[2 * u] = tb0;
+                lt[2 * u + 1] = tb1;
+            } else {
+                if (nv >= 1) {
+                    const int i0 = find(x0);
+                    if (i0 >= 0) hit(i0, tb0);
+                }
+                if (nv == 2) {
+                    const int i1 = find(x1);
+                    if (i1 >= 0) hit(i1, tb1);
+                }
             }
-            if (nv == 2) {
-                const int i1 = find(x1);
-                if (i1 >= 0) hit(i1, tb1);
+        }
+        if constexpr (OP == UKM_OP_INTER && TAX) {
+            LcaReq rq[2 * U];
+            u32 old[2 * U];
+#pragma unroll
+            for (int q = 0; q < 2 * U; q++) {
+                bool need = false;
+                if (li[q] >= 0) {
+                    // files finished BEFORE this hit is counted (acquire: the count is not moved in front of the read): a
+                    // record that is in every file has one hit from each of them in its counter by now, so a counter
+                    // that is not above that number belongs to a record some finished file did not have — dead
+                    const u32 finished = __hip_atomic_load(&s_done, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    need = atomicAdd(&s_cnt[li[q]], 1u) + 1 > finished;
+                }
+                if (!need) li[q] = -1;
+                old[q] = need ? s_tax[li[q]] : 0u;
+                lca_begin(a.T, old[q], lt[q], rq[q]);  // (a = 0: no table read)
+            }
+#pragma unroll
+            for (int q = 0; q < 2 * U; q++) {
+                if (li[q] < 0) continue;
+                u32 o = old[q];
+                u32 nw = lca_finish(a.T, rq[q]);
+                while (nw != o) {  // (LCA is associative and commutative: concurrent folds of other files commute)
+                    const u32 prev = atomicCAS(&s_tax[li[q]], o, nw);
+                    if (prev == o) break;
+                    o = prev;
+                    nw = lca_dev(a.T, o, lt[q]);
+                }
             }
         }
     };
@@ -276,7 +318,7 @@ __global__ __launch_bounds__(PF_NT) void pf_probe_kernel(PfArgs a) {
             u64 p0 = cur.beg;
             while (p0 < end) {
                 const u64 rem = end - p0;
-                if (rem > 256) { step(std::integral_constant<int, 4>{}, f, t, p0, end, len); p0 += 512; }
+                if (rem > 256 && !(OP == UKM_OP_INTER && TAX)) { step(std::integral_constant<int, 4>{}, f, t, p0, end, len); p0 += 512; }
                 else if (rem > 128) { step(std::integral_constant<int, 2>{}, f, t, p0, end, len); p0 += 256; }
                 else { step(std::integral_constant<int, 1>{}, f, t, p0, end, len); p0 += 128; }
             }
@@ -335,10 +377,9 @@ int ukm_dev_probe_fold(ukm_ctx *c, int op, const u64 *const *keys, const u32 *co
     if (op == UKM_OP_INTER && (flags & UKM_F_MIX_TAXID)) return UKM_OK;
     const bool cmp = op == UKM_OP_DIFF && tax && (flags & UKM_F_CMP_TAXID);
     {
-        // inter WITH taxids: one LCA per hit of a record that is still alive, done where the hit is found (a CAS loop
-        // around two dependent table reads, nothing else of the lane in flight).  Measured on config 4-core (3e8 such
-        // LCAs): 12.5 ms against the range fold's 10.1 (five LCAs in flight per thread there); on config 4 itself, whose
-        // survivors die within 130 files, 5.5 against 5.7.  Taken only on request (UKM_PFOLD_TAX=1: tests).
+        // inter WITH taxids: correct here (the LCAs of a step with their table reads in flight together, folded in by CAS)
+        // but not faster than the range fold, whose survivors sit in registers: config 4 6.3 against 6.0 ms, config 4-core
+        // 10.7 against 10.2 (one LCA at a time: 12.5).  Taken only on request (UKM_PFOLD_TAX=1: tests).
         const char *e = getenv("UKM_PFOLD_TAX");
         if (op == UKM_OP_INTER && tax && !(e && e[0] == '1')) return UKM_OK;
     }
