@@ -317,3 +317,52 @@ def test_strip_windows_on_ragged_reads(env, seed, monkeypatch):
         bad = bases.copy()
         bad[int(cuts[short[0]])] = ord("*")
         assert np.array_equal(ctx.encode_kmers(bad, cuts, 31), O.count_windows(bad, cuts, 31))
+
+
+@pytest.mark.parametrize("seed", _seeds(3))
+def test_random_probe_paths(env, seed, monkeypatch):
+    """The hash-probe routes forced on (UKM_PUNION=2: union without its size and hit-rate guards; the probe fold takes
+    inter / diff / diff -t from four streams on, UKM_PFOLD_TAX=1 also inter with taxids) over random shapes: 9-40
+    streams of 0 - 30k codes with every degree of overlap, value spaces from a few hundred codes (dense duplicates across
+    streams) to 62 bits, taxids on all / some / no streams, against the oracle's sequential folds."""
+    O, L, ctx, tax, T = env
+    rng = np.random.default_rng(9300 + seed)
+    monkeypatch.setenv("UKM_PUNION", "2")
+    monkeypatch.setenv("UKM_PFOLD_TAX", "1")
+    for it in range(8):
+        nf = int(rng.integers(9, 41))
+        space = int(rng.choice([300, 5_000, 200_000, 1 << 40, 1 << 62]))
+        base = np.unique(rng.integers(0, space, int(rng.choice([50, 3_000, 30_000])), dtype=np.uint64))
+        files = []
+        for f in range(nf):
+            kind = rng.integers(0, 4)
+            if kind == 0:       # a random subset of a common pool
+                x = base[rng.random(len(base)) < rng.random()]
+            elif kind == 1:     # private codes
+                x = np.unique(rng.integers(0, space, int(rng.integers(0, 4_000)), dtype=np.uint64))
+            elif kind == 2:     # the pool plus private codes
+                x = np.unique(np.concatenate([base[rng.random(len(base)) < 0.8],
+                                              rng.integers(0, space, int(rng.integers(0, 500)), dtype=np.uint64)]))
+            else:               # almost the whole pool
+                x = base[rng.random(len(base)) < 0.97]
+            files.append(x)
+        taxs = [(1 + rng.integers(0, T, len(f))).astype(np.uint32) for f in files]
+        assert np.array_equal(ctx.union(files), O.union(files)), (seed, it, "union", nf, space)
+        live = [f for f in files if len(f)]
+        ltax = [t for f, t in zip(files, taxs) if len(f)]
+        if len(live) >= 4:
+            assert np.array_equal(ctx.inter(live), O.inter(live)), (seed, it, "inter")
+            gk, gt = ctx.inter(live, ltax)
+            ok, ot = O.inter(live, ltax, tax)
+            assert np.array_equal(gk, ok) and np.array_equal(gt, ot), (seed, it, "inter+tax")
+        if len(files[0]):
+            assert np.array_equal(ctx.diff(files), O.diff(files)), (seed, it, "diff")
+            for cmp_t in (False, True):
+                gk, gt = ctx.diff(files, taxs, compare_taxid=cmp_t)
+                ok, ot = O.diff(files, taxs, tax, compare_taxid=cmp_t)
+                assert np.array_equal(gk, ok) and np.array_equal(gt, ot), (seed, it, "diff+tax", cmp_t)
+            some = [t if i % 3 else None for i, t in enumerate(taxs)]   # streams without taxids among streams with
+            some[0] = taxs[0]
+            gk, gt = ctx.diff(files, some, compare_taxid=True)
+            ok, ot = O.diff(files, some, tax, compare_taxid=True)
+            assert np.array_equal(gk, ok) and np.array_equal(gt, ot), (seed, it, "diff+some tax")
