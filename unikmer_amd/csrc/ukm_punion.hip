@@ -34,7 +34,13 @@ namespace {
 #define PU_K0_N 8
 #endif
 constexpr int PU_K0 = PU_K0_N;    // files merged into the base set
-constexpr int PU_NT = 512;        // threads of a probe workgroup
+#ifndef PU_NT_N
+#define PU_NT_N 512
+#endif
+#ifndef PU_WAVES
+#define PU_WAVES 4
+#endif
+constexpr int PU_NT = PU_NT_N;    // threads of a probe workgroup
 constexpr int PU_RANGE = 2048;    // base entries per range
 constexpr int PU_BUCKET_BITS = 11;  // 2048 buckets x 4 slots x 8 B = 64 KB of LDS: two workgroups per CU
 constexpr int PU_BUCKETS = 1 << PU_BUCKET_BITS;
@@ -138,7 +144,7 @@ __global__ void pu_sample_kernel(PuArgs a, u32 nsamp, u32 nfiles_s) {
 typedef u64 pu_u64x2 __attribute__((ext_vector_type(2)));
 typedef pu_u64x2 __attribute__((aligned(8))) pu_pair;  // 16 bytes at 8-byte alignment
 
-__global__ __launch_bounds__(PU_NT) void pu_probe_kernel(PuArgs a) {
+__global__ __launch_bounds__(PU_NT) __attribute__((amdgpu_waves_per_eu(PU_WAVES, PU_WAVES))) void pu_probe_kernel(PuArgs a) {
     __shared__ __attribute__((aligned(32))) u64 s_tab[PU_SLOTS];
     __shared__ u64 s_miss[PU_LMISS];
     __shared__ u32 s_next, s_nmiss, s_nins;
@@ -153,7 +159,7 @@ __global__ __launch_bounds__(PU_NT) void pu_probe_kernel(PuArgs a) {
     {
         const u64 b0 = (u64)r * PU_RANGE;
         const u32 nb = (u32)((a.n0 - b0 < (u64)PU_RANGE) ? (a.n0 - b0) : (u64)PU_RANGE);
-        constexpr int PER = PU_RANGE / PU_NT;
+        constexpr int PER = (PU_RANGE + PU_NT - 1) / PU_NT;
         u64 ent[PER];
 #pragma unroll
         for (int i = 0; i < PER; i++) {  // (all loads in flight before the first insert)
