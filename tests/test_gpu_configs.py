@@ -427,3 +427,53 @@ def test_probe_fold_shapes(env, monkeypatch):
     f2[5] = rng.permutation(f2[5])
     with pytest.raises(L.UkmError):
         ctx.inter(f2)
+
+
+def test_probe_fold_inter_taxids_forest_merged_unknown(monkeypatch):
+    """inter with taxids through the probe fold folds pre-order numbers (minimum / maximum per record) and does one
+    table LCA per survivor; the reference folds LCA(LCA(t0, t1), t2) ... file by file.  Same answers on the awkward
+    ids: a forest of three trees (LCA across trees = 0), merged ids (resolved, except when every taxid of a record is the
+    same old id), taxid 0 and unknown ids (0, unless every taxid of the record is that same id), deep chains."""
+    from oracle import oracle as O
+    from unikmer_amd import lib as L
+    c = L.Context(0)
+    child, parent = [], []
+    child.append(100); parent.append(100)
+    for i in range(101, 160):
+        child.append(i); parent.append(i - 1)                  # a chain of 60
+    for i in range(100, 160, 5):
+        child.append(1000 + i); parent.append(i)               # leaves off the chain
+    for t in range(1, 122):                                     # a complete ternary tree of depth 4 at 5000
+        child.append(4999 + t); parent.append(4999 + (1 if t == 1 else (t - 2) // 3 + 1))
+    child += [9001, 9002]; parent += [9000, 9001]              # a root that only appears as a parent
+    child, parent = np.array(child, np.uint32), np.array(parent, np.uint32)
+    mo, mn = np.array([50, 51, 52], np.uint32), np.array([159, 5003, 77777], np.uint32)
+    c.taxonomy_load(child, parent, mo, mn)
+    tax = O.Taxonomy(child, parent, mo, mn)
+    rng = np.random.default_rng(17)
+    pool = np.concatenate([child, [0, 50, 51, 52, 9000, 400, 99999]]).astype(np.uint32)
+    U = _universe(6_000)
+    nfiles = 12
+    files = [U[_member(len(U), f, 0.93, 31)] for f in range(nfiles)]
+    taxs = []
+    # per code a "theme": all files the same id (incl. 0 / merged / unknown), ids of one clade, or anything
+    theme = rng.integers(0, 4, len(U))
+    fixed = rng.choice(pool, len(U))
+    pos = {int(code): i for i, code in enumerate(U)}
+    for f in range(nfiles):
+        idx = np.array([pos[int(x)] for x in files[f]])
+        t = rng.choice(pool, len(idx))
+        same = theme[idx] == 0
+        t[same] = fixed[idx][same]
+        chain = theme[idx] == 1
+        t[chain] = rng.integers(100, 160, int(chain.sum()))
+        tern = theme[idx] == 2
+        t[tern] = rng.integers(5000, 5121, int(tern.sum()))
+        taxs.append(t.astype(np.uint32))
+    for env_tax in ("1", "0"):   # the probe fold / the range fold
+        monkeypatch.setenv("UKM_PFOLD_TAX", env_tax)
+        gk, gt = c.inter(files, taxs)
+        ok, ot = O.inter(files, taxs, tax)
+        assert len(ok) > 1000
+        assert np.array_equal(gk, ok) and np.array_equal(gt, ot), env_tax
+    c.close()

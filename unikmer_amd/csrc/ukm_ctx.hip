@@ -81,6 +81,8 @@ extern "C" int ukm_ctx_destroy(ukm_ctx *c) {
     if (c->tax_depth) (void)hipFree(c->tax_depth);
     if (c->tax_merged) (void)hipFree(c->tax_merged);
     if (c->tax_anc) (void)hipFree(c->tax_anc);
+    if (c->tax_euler) (void)hipFree(c->tax_euler);
+    if (c->tax_node_at) (void)hipFree(c->tax_node_at);
     if (c->h_scratch) (void)hipHostFree(c->h_scratch);
     if (c->ev_start) (void)hipEventDestroy(c->ev_start);
     if (c->ev_stop) (void)hipEventDestroy(c->ev_stop);

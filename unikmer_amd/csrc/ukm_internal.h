@@ -51,6 +51,11 @@ struct TaxDev {
     // depth, 0 beyond it; all 0 for an absent taxid).  nullptr when the tree is too deep for it: lca_dev then climbs.
     const uint4 *anc;
     u32 nchunks;
+    // pre-order numbers (round 3, ukm_pfold.hip): euler[t] = 1 + the position of t (merged ids: of their target) in a
+    // depth-first walk of the forest, 0 for taxid 0 / absent / unknown ids; node_at[e] = the taxid with number e.
+    // The LCA of a SET of nodes is the LCA of its members with the smallest and the largest number.
+    const u32 *euler;
+    const u32 *node_at;
 };
 
 // ---- workspace arena: chunked bump allocator on the ctx's device ------------------------------
@@ -93,6 +98,7 @@ struct ukm_ctx {
     u8 *tax_depth = nullptr;
     u32 *tax_merged = nullptr;
     uint4 *tax_anc = nullptr;  // root-path table, see TaxDev
+    u32 *tax_euler = nullptr, *tax_node_at = nullptr;  // pre-order numbers, see TaxDev
     u32 tax_nchunks = 0;
     u32 tax_size = 0;
     u32 tax_max = 0;
@@ -175,6 +181,8 @@ static inline TaxDev ukm_taxdev(const ukm_ctx *c) {
     t.depth = c->tax_depth;
     t.merged = c->tax_merged;
     t.anc = c->tax_anc;
+    t.euler = c->tax_euler;
+    t.node_at = c->tax_node_at;
     t.nchunks = c->tax_nchunks;
     t.size = c->tax_size;
     return t;

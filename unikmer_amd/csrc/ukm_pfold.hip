@@ -33,8 +33,10 @@ constexpr int PF_NT = 512;
 constexpr int PF_BUCKET_BITS = 10;
 constexpr int PF_BUCKETS = 1 << PF_BUCKET_BITS;
 constexpr int PF_SLOTS = 4 * PF_BUCKETS;
-constexpr int PF_PER = 3;                // records of file 0 per thread
-constexpr int PF_MAXL = PF_NT * PF_PER;  // 1536
+constexpr int PF_PER = 3;                // records of file 0 per thread (range length <= 1536; three workgroups per CU)
+constexpr int PF_PER_TAXFOLD = 4;        // inter with taxids: 2048 (more per-record state: two workgroups per CU)
+constexpr int PF_MAXL = PF_NT * PF_PER;
+constexpr u32 PF_CNT_MASK = 0x3FFFFFFFu, PF_NEQ = 0x40000000u, PF_BAD = 0x80000000u;  // inter + taxids: flags in the counter word
 constexpr int PF_MINL = 256;
 constexpr u64 PF_EMPTY = ~0ull;
 enum { PF_FLAG_DUP = 1, PF_FLAG_UNSORTED = 2 };
@@ -86,13 +88,17 @@ typedef pf_u64x2 __attribute__((aligned(8))) pf_pair;
 typedef u32 pf_u32x2 __attribute__((ext_vector_type(2)));
 typedef pf_u32x2 __attribute__((aligned(4))) pf_tpair;
 
-// (three 512-thread workgroups per CU = 6 waves per SIMD: 85 registers; the inter + taxids variant came out at 89)
+// (three 512-thread workgroups per CU = 6 waves per SIMD: 85 registers; inter with taxids: 72 KB of LDS, two per CU)
 template <int OP, bool TAX, bool CMP = false>
-__global__ __launch_bounds__(PF_NT) __attribute__((amdgpu_waves_per_eu(6, 6))) void pf_probe_kernel(PfArgs a) {
+__global__ __launch_bounds__(PF_NT) __attribute__((amdgpu_waves_per_eu((OP == UKM_OP_INTER && TAX) ? 4 : 6, (OP == UKM_OP_INTER && TAX) ? 4 : 6)))
+void pf_probe_kernel(PfArgs a) {
     __shared__ __attribute__((aligned(32))) u64 s_tab[PF_SLOTS];
     __shared__ unsigned short s_idx[PF_SLOTS];
-    __shared__ u32 s_cnt[PF_MAXL];
-    __shared__ u32 s_tax[TAX ? PF_MAXL : 1];
+    constexpr bool EULER = OP == UKM_OP_INTER && TAX;  // inter with taxids: LCA of all files' taxids from pre-order numbers
+    constexpr int PER = EULER ? PF_PER_TAXFOLD : PF_PER, MAXL = PF_NT * PER;
+    __shared__ u32 s_cnt[MAXL];
+    __shared__ u32 s_tax[TAX ? MAXL : 1];
+    __shared__ u32 s_min[EULER ? MAXL : 1], s_max[EULER ? MAXL : 1];
     __shared__ u32 s_scan[PF_NT / 64 + 1];
     __shared__ u32 s_next, s_done;
     constexpr bool FOLD_TAX = TAX && (OP == UKM_OP_INTER || CMP);  // the later files' taxids are read
@@ -106,16 +112,25 @@ __global__ __launch_bounds__(PF_NT) __attribute__((amdgpu_waves_per_eu(6, 6))) v
     for (int i = tid; i < PF_SLOTS; i += PF_NT) s_tab[i] = PF_EMPTY;
     if (tid == 0) { s_next = 0; s_done = 0; }
     u32 flags = 0;
-    u64 ent[PF_PER];
+    u64 ent[PER];
 #pragma unroll
-    for (int k = 0; k < PF_PER; k++) {
+    for (int k = 0; k < PER; k++) {
         const u32 i = (u32)tid + (u32)k * PF_NT;
         ent[k] = PF_EMPTY;
         if (i < ne) {
             const u64 e = f0[e0 + i];
             ent[k] = e;
             s_cnt[i] = 0;
-            if (TAX) s_tax[i] = t0 ? t0[e0 + i] : 0u;
+            if (TAX) {
+                const u32 tf = t0 ? t0[e0 + i] : 0u;
+                s_tax[i] = tf;
+                if (EULER) {
+                    const u32 ef = tf < a.T.size ? a.T.euler[tf] : 0u;
+                    s_min[i] = ef ? ef : 0xFFFFFFFFu;
+                    s_max[i] = ef;
+                    if (!ef) s_cnt[i] = PF_BAD;
+                }
+            }
             if (e0 + i + 1 < len0) {  // file 0 strictly increasing (also across the range's end)
                 const u64 nx = f0[e0 + i + 1];
                 if (e == nx) flags |= PF_FLAG_DUP;
@@ -126,7 +141,7 @@ __global__ __launch_bounds__(PF_NT) __attribute__((amdgpu_waves_per_eu(6, 6))) v
     }
     __syncthreads();
 #pragma unroll
-    for (int k = 0; k < PF_PER; k++) {
+    for (int k = 0; k < PER; k++) {
         const u32 i = (u32)tid + (u32)k * PF_NT;
         const u64 e = ent[k];
         if (i >= ne || e == PF_EMPTY) continue;
@@ -175,20 +190,7 @@ __global__ __launch_bounds__(PF_NT) __attribute__((amdgpu_waves_per_eu(6, 6))) v
                 s_cnt[idx] = 1;  // (every writer stores the same value)
             }
         } else {
-            // files finished BEFORE this hit is counted (acquire: the count below is not moved in front of the read):
-            // a record that is in every file has one hit from each of them in its counter by now
-            const u32 finished = FOLD_TAX ? __hip_atomic_load(&s_done, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) : 0u;
-            const u32 now = atomicAdd(&s_cnt[idx], 1u) + 1;
-            if (FOLD_TAX && now > finished) {  // (not more hits than finished files: one of them did not have it — dead)
-                u32 old = s_tax[idx];
-                for (;;) {
-                    const u32 nw = lca_dev(a.T, old, tb);
-                    if (nw == old) break;
-                    const u32 prev = atomicCAS(&s_tax[idx], old, nw);
-                    if (prev == old) break;
-                    old = prev;
-                }
-            }
+            atomicAdd(&s_cnt[idx], 1u);  // (inter with taxids does not come here: see the step)
         }
     };
     auto step = [&](auto UU, const ukm_gptr<u64> f, const ukm_gptr<u32> t, u64 p0, u64 end, u64 len) {
@@ -254,8 +256,12 @@ __global__ __launch_bounds__(PF_NT) __attribute__((amdgpu_waves_per_eu(6, 6))) v
             }
         }
         if constexpr (OP == UKM_OP_INTER && TAX) {
-            LcaReq rq[2 * U];
-            u32 old[2 * U];
+            // The LCA of a SET of taxids is the LCA of its members with the smallest and the largest pre-order number
+            // (TaxDev::euler): a hit only has to fold its taxid's number into the record's minimum and maximum — two
+            // commutative LDS atomics, files in any order — and ONE table LCA per survivor follows at the end.  Taxid 0 /
+            // unknown ids (number 0) make the result 0 (lca_dev: absorbing) unless every taxid of the record is the
+            // same (lca_dev: a == b -> a), which the NEQ flag keeps track of.
+            u32 en[2 * U];
 #pragma unroll
             for (int q = 0; q < 2 * U; q++) {
                 bool need = false;
@@ -264,22 +270,18 @@ __global__ __launch_bounds__(PF_NT) __attribute__((amdgpu_waves_per_eu(6, 6))) v
                     // record that is in every file has one hit from each of them in its counter by now, so a counter
                     // that is not above that number belongs to a record some finished file did not have — dead
                     const u32 finished = __hip_atomic_load(&s_done, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    need = atomicAdd(&s_cnt[li[q]], 1u) + 1 > finished;
+                    need = ((atomicAdd(&s_cnt[li[q]], 1u) + 1) & PF_CNT_MASK) > finished && lt[q] != s_tax[li[q]];
                 }
                 if (!need) li[q] = -1;
-                old[q] = need ? s_tax[li[q]] : 0u;
-                lca_begin(a.T, old[q], lt[q], rq[q]);  // (a = 0: no table read)
+                en[q] = a.T.euler[(need && lt[q] < a.T.size) ? lt[q] : 0u];  // (all of the step's table reads in flight; euler[0] = 0)
             }
 #pragma unroll
             for (int q = 0; q < 2 * U; q++) {
                 if (li[q] < 0) continue;
-                u32 o = old[q];
-                u32 nw = lca_finish(a.T, rq[q]);
-                while (nw != o) {  // (LCA is associative and commutative: concurrent folds of other files commute)
-                    const u32 prev = atomicCAS(&s_tax[li[q]], o, nw);
-                    if (prev == o) break;
-                    o = prev;
-                    nw = lca_dev(a.T, o, lt[q]);
+                atomicOr(&s_cnt[li[q]], en[q] ? PF_NEQ : (PF_NEQ | PF_BAD));
+                if (en[q]) {
+                    atomicMin(&s_min[li[q]], en[q]);
+                    atomicMax(&s_max[li[q]], en[q]);
                 }
             }
         }
@@ -318,7 +320,7 @@ __global__ __launch_bounds__(PF_NT) __attribute__((amdgpu_waves_per_eu(6, 6))) v
             u64 p0 = cur.beg;
             while (p0 < end) {
                 const u64 rem = end - p0;
-                if (rem > 256 && !(OP == UKM_OP_INTER && TAX)) { step(std::integral_constant<int, 4>{}, f, t, p0, end, len); p0 += 512; }
+                if (rem > 256) { step(std::integral_constant<int, 4>{}, f, t, p0, end, len); p0 += 512; }
                 else if (rem > 128) { step(std::integral_constant<int, 2>{}, f, t, p0, end, len); p0 += 256; }
                 else { step(std::integral_constant<int, 1>{}, f, t, p0, end, len); p0 += 128; }
             }
@@ -329,19 +331,27 @@ __global__ __launch_bounds__(PF_NT) __attribute__((amdgpu_waves_per_eu(6, 6))) v
     }
     if (flags) atomicOr((unsigned long long *)&a.ctl[1], (unsigned long long)flags);
     __syncthreads();
-    // survivors in file-0 order: three ordered compactions of 512 records each
+    // survivors in file-0 order: ordered compactions of 512 records each
     u32 base = 0;
 #pragma unroll
-    for (int k = 0; k < PF_PER; k++) {
+    for (int k = 0; k < PER; k++) {
         const u32 i = (u32)tid + (u32)k * PF_NT;
         bool alive = false;
-        if (i < ne) alive = OP == UKM_OP_INTER ? s_cnt[i] == S1 : s_cnt[i] == 0;
+        u32 w = 0;
+        if (i < ne) {
+            w = s_cnt[i];
+            alive = OP == UKM_OP_INTER ? (EULER ? (w & PF_CNT_MASK) : w) == S1 : w == 0;
+        }
         u32 total = 0;
         const u32 excl = block_excl_scan_u32<PF_NT>(alive ? 1u : 0u, s_scan, &total);
         if (alive) {
             const u64 o = (u64)r * L + base + excl;
             a.tmp_k[o] = ent[k];
-            if (TAX) a.tmp_t[o] = s_tax[i];
+            if (TAX) {
+                u32 tx = s_tax[i];
+                if (EULER && (w & PF_NEQ)) tx = (w & PF_BAD) ? 0u : lca_dev(a.T, a.T.node_at[s_min[i]], a.T.node_at[s_max[i]]);
+                a.tmp_t[o] = tx;
+            }
         }
         base += total;
     }
@@ -377,11 +387,8 @@ int ukm_dev_probe_fold(ukm_ctx *c, int op, const u64 *const *keys, const u32 *co
     if (op == UKM_OP_INTER && (flags & UKM_F_MIX_TAXID)) return UKM_OK;
     const bool cmp = op == UKM_OP_DIFF && tax && (flags & UKM_F_CMP_TAXID);
     {
-        // inter WITH taxids: correct here (the LCAs of a step with their table reads in flight together, folded in by CAS)
-        // but not faster than the range fold, whose survivors sit in registers: config 4 6.3 against 6.0 ms, config 4-core
-        // 10.7 against 10.2 (one LCA at a time: 12.5).  Taken only on request (UKM_PFOLD_TAX=1: tests).
-        const char *e = getenv("UKM_PFOLD_TAX");
-        if (op == UKM_OP_INTER && tax && !(e && e[0] == '1')) return UKM_OK;
+        const char *e = getenv("UKM_PFOLD_TAX");  // developer knob: 0 = inter with taxids through the range fold of ukm_fold.hip
+        if (op == UKM_OP_INTER && tax && e && e[0] == '0') return UKM_OK;
     }
     if (S < 2 || lens[0] == 0) return UKM_OK;
     for (int j = 0; j < S; j++)
@@ -390,16 +397,19 @@ int ukm_dev_probe_fold(ukm_ctx *c, int op, const u64 *const *keys, const u32 *co
         UKM_FAIL(UKM_ERR_NO_TAXONOMY, "ukm_setop2: records carry taxids but no taxonomy is loaded");
     if (tax && !tout) UKM_FAIL(UKM_ERR_INVALID, "probe fold: taxids given but out_taxids is NULL");
     // one round of resident workgroups when the first file allows it
-    static std::atomic<int> slots_cache;
-    if (!slots_cache.load(std::memory_order_relaxed)) {
+    const bool euler = op == UKM_OP_INTER && tax;
+    static std::atomic<int> slots_cache[2];
+    if (!slots_cache[euler].load(std::memory_order_relaxed)) {
         int per_cu = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pf_probe_kernel<UKM_OP_INTER, true>, PF_NT, 0) != hipSuccess || per_cu <= 0)
-            per_cu = 2;
-        slots_cache.store(per_cu * c->num_cu, std::memory_order_relaxed);
+        const hipError_t e = euler ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pf_probe_kernel<UKM_OP_INTER, true>, PF_NT, 0)
+                                   : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pf_probe_kernel<UKM_OP_DIFF, true, true>, PF_NT, 0);
+        if (e != hipSuccess || per_cu <= 0) per_cu = 2;
+        slots_cache[euler].store(per_cu * c->num_cu, std::memory_order_relaxed);
     }
-    const u64 slots = (u64)slots_cache.load(std::memory_order_relaxed);
+    const u64 slots = (u64)slots_cache[euler].load(std::memory_order_relaxed);
+    const u64 maxl = (u64)PF_NT * (euler ? PF_PER_TAXFOLD : PF_PER);
     u64 L = (lens[0] + slots - 1) / slots;
-    L = std::min<u64>(std::max<u64>(L, PF_MINL), PF_MAXL);
+    L = std::min<u64>(std::max<u64>(L, PF_MINL), maxl);
     const u64 R64 = (lens[0] + L - 1) / L;
     if (R64 > 0x7FFFFFFEull) return UKM_OK;
     {

@@ -125,6 +125,50 @@ extern "C" int ukm_taxonomy_load(ukm_ctx *c, const uint32_t *child, const uint32
     UKM_HIP(hipGetLastError());
     UKM_HIP(hipStreamSynchronize(c->stream));
     c->tax_nchunks = nchunks;
+    // Pre-order numbers of the forest (children in increasing taxid order; any order works): the LCA of a set of nodes is
+    // the LCA of the members with the smallest and the largest number, which lets a fold over MANY files keep a minimum
+    // and a maximum per record (two commutative LDS atomics per hit) and do ONE table LCA at the end (ukm_pfold.hip).
+    {
+        std::vector<u32> first(size + 1, 0), kids;  // CSR of the children lists
+        for (u64 t = 1; t < size; t++)
+            if (P[t] != 0 && P[t] != t) first[P[t] + 1]++;
+        for (u64 t = 0; t < size; t++) first[t + 1] += first[t];
+        kids.resize(first[size]);
+        {
+            std::vector<u32> fill(first.begin(), first.end() - 1);
+            for (u64 t = 1; t < size; t++)
+                if (P[t] != 0 && P[t] != t) kids[fill[P[t]]++] = (u32)t;
+        }
+        std::vector<u32> E(size, 0), N(1, 0);  // N[0] unused: numbers start at 1
+        std::vector<std::pair<u32, u32>> st;   // (node, next child slot)
+        for (u64 r = 1; r < size; r++) {
+            if (P[r] != r) continue;
+            st.clear();
+            st.emplace_back((u32)r, first[r]);
+            E[r] = (u32)N.size();
+            N.push_back((u32)r);
+            while (!st.empty()) {
+                auto &top = st.back();
+                if (top.second < first[top.first + 1]) {
+                    const u32 k = kids[top.second++];
+                    E[k] = (u32)N.size();
+                    N.push_back(k);
+                    st.emplace_back(k, first[k]);
+                } else {
+                    st.pop_back();
+                }
+            }
+        }
+        if (m)
+            for (u64 t = 1; t < size; t++)
+                if (P[t] == 0 && M[t] != 0 && M[t] < size && P[M[t]] != 0) E[t] = E[M[t]];  // (lca_dev resolves exactly these)
+        if (c->tax_euler) { (void)hipFree(c->tax_euler); c->tax_euler = nullptr; }
+        if (c->tax_node_at) { (void)hipFree(c->tax_node_at); c->tax_node_at = nullptr; }
+        UKM_HIP(hipMalloc((void **)&c->tax_euler, size * sizeof(u32)));
+        UKM_HIP(hipMalloc((void **)&c->tax_node_at, N.size() * sizeof(u32)));
+        UKM_HIP(hipMemcpy(c->tax_euler, E.data(), size * sizeof(u32), hipMemcpyHostToDevice));
+        UKM_HIP(hipMemcpy(c->tax_node_at, N.data(), N.size() * sizeof(u32), hipMemcpyHostToDevice));
+    }
     return UKM_OK;
 }
 
