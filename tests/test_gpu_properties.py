@@ -288,3 +288,52 @@ def test_range_fold_equals_chained_fold_large(env, monkeypatch):
     assert res["fold"][0].numel() > 1_000_000 and res["fold"][2].numel() > 10 and res["fold"][4].numel() > res["fold"][2].numel()
     for a, b in zip(res["fold"], res["chain"]):
         assert a.numel() == b.numel() and bool((a == b).all())
+
+
+def test_sort_top16_then_lds_buckets(env, monkeypatch):
+    """Keys-only sorts of >= 2^24 keys take two scatter passes over the top 16 bits and then sort every bucket inside LDS
+    (ukm_sort.hip).  Against torch.sort and against the all-passes route (UKM_SORT_LOCAL=0): evenly spread 62-bit and
+    64-bit keys (all buckets small), keys with a few heavy buckets (sorted by the general route afterwards), keys
+    crowded into a handful of buckets (the whole call falls back), narrow keys handed over as 64-bit (the OR word narrows
+    them), duplicates, all-ones keys, every key the same."""
+    torch, bench, lib, ctx, A, B = env
+    dev = A.device
+    n = 20_000_000
+    g = torch.Generator(device=dev)
+    g.manual_seed(11)
+
+    def rnd(bits, count=n):
+        hi = torch.randint(0, 1 << 31, (count,), device=dev, generator=g, dtype=torch.int64)
+        lo = torch.randint(0, 1 << 31, (count,), device=dev, generator=g, dtype=torch.int64)
+        x = (hi << 33) ^ (lo << 2) ^ torch.randint(0, 4, (count,), device=dev, generator=g, dtype=torch.int64)
+        return x if bits == 64 else x & ((1 << bits) - 1)
+
+    def usort(x):   # unsigned order of the int64 bit patterns
+        s = torch.sort(x ^ (-1 << 63)).values
+        return s ^ (-1 << 63)
+
+    cases = []
+    cases.append((rnd(62), 62))
+    cases.append((rnd(64), 64))
+    x = rnd(62)
+    x[: 3_000_000] = (x[: 3_000_000] & ((1 << 46) - 1)) | (5 << 46)          # one heavy bucket (3e6 keys)
+    x[3_000_000: 3_400_000] = (x[3_000_000: 3_400_000] & ((1 << 46) - 1)) | (77 << 46)
+    cases.append((x, 62))
+    cases.append((rnd(62) & ((1 << 50) - 1) | (3 << 50), 62))                 # 16 buckets only: the general route
+    cases.append((rnd(40), 64))                                               # narrow keys declared 64-bit
+    y = rnd(62)
+    y[::7] = y[1::7][: y[::7].numel()]                                        # duplicates
+    y[:5] = -1                                                                # all ones (as 64-bit patterns)
+    cases.append((y, 64))
+    cases.append((torch.full((n,), 123456789, dtype=torch.int64, device=dev), 62))
+    for x, bits in cases:
+        exp = usort(x)
+        for knob in (None, "0"):
+            if knob is None:
+                monkeypatch.delenv("UKM_SORT_LOCAL", raising=False)
+            else:
+                monkeypatch.setenv("UKM_SORT_LOCAL", knob)
+            w = x.clone()
+            ctx.sort_u64(w, bits)
+            assert torch.equal(w, exp), (bits, knob)
+    monkeypatch.delenv("UKM_SORT_LOCAL", raising=False)

@@ -47,7 +47,7 @@ constexpr int MAX_PASSES = 8;
 struct __attribute__((packed, aligned(8))) U2a8 {  // 16 bytes at 8-byte alignment
     u64 x, y;
 };
-__global__ __launch_bounds__(NT) void radix_hist_kernel(const u64 *k, u64 n, int passes, u64 *ghist, u64 *or_all) {
+__global__ __launch_bounds__(NT) void radix_hist_kernel(const u64 *k, u64 n, int passes, u64 *ghist, u64 *or_all, int shift0 = 0) {
     __shared__ u32 s_h[MAX_PASSES * RADIX];
     const int tid = (int)threadIdx.x;
     for (int i = tid; i < MAX_PASSES * RADIX; i += NT) s_h[i] = 0;
@@ -81,7 +81,7 @@ __global__ __launch_bounds__(NT) void radix_hist_kernel(const u64 *k, u64 n, int
             const u64 vm = __ballot(valid[u]);
             if (valid[u]) orv |= key[u];
             for (int p = 0; p < passes; p++) {
-                const u32 d = (u32)(key[u] >> (RB * p)) & DMASK;
+                const u32 d = (u32)(key[u] >> (shift0 + RB * p)) & DMASK;
                 const u32 d0 = __builtin_amdgcn_readfirstlane(d);
                 if (vm == ~0ull && __all(d == d0)) {
                     if (lane_id() == 0) atomicAdd(&s_h[p * RADIX + d0], 64u);
@@ -438,6 +438,194 @@ int run_passes(ukm_ctx *c, u64 *keys, u32 *vals, u64 *tk, u32 *tv, u64 n, int np
     return UKM_OK;
 }
 
+// ---- two passes over the TOP 16 bits, then every bucket sorted inside LDS -------------------------------------------
+// A scatter pass costs ~0.43 ms per 1e8 keys whatever it moves (latency bound, above), and a 62-bit key takes eight of
+// them.  Sorted by its top 16 bits alone (two passes: LSD over the two highest digits) the array falls into 65,536
+// buckets of n / 65,536 keys on evenly spread keys (k-mer codes, hashes): 1.5 k keys = 12 KB at n = 1e8, which one
+// 256-thread workgroup sorts by the remaining low bits entirely in LDS (the same ballot ranking as the global pass,
+// ping-pong between two LDS buffers) and writes back in place.  Keys cross HBM three times instead of eight.
+// The instantiation (512 / 1024 / 2048 keys) follows the average bucket; buckets that do not fit go through a list to the
+// 4096-key instantiation, buckets beyond that are sorted by the general route afterwards; too many of either, narrow
+// keys, or n beyond ~1.7e8 and the whole call takes the general route (the two passes only permuted the keys).
+constexpr int LS_NT = 256, LS_NW = LS_NT / 64;  // keys per thread 2 / 4 / 8 / 16: buckets of up to 512 ... 4096 keys
+constexpr int LS_TOP_BITS = 16;
+constexpr int LS_LIST = 8192;  // oversized buckets a kernel may hand on
+constexpr int LS_MAX_BIG = 48; // buckets beyond 4096 keys, sorted by the general route (read back through the 64-word scratch)
+
+struct LocalSortArgs {
+    u64 *keys;
+    u64 n;
+    const u64 *start;  // [65537]
+    int low_bits;      // bits below the top 16
+    const u64 *in;     // bucket ids to sort (nullptr: bucket = blockIdx.x)
+    u64 *out;          // [0] count, [1 ...] ids of the buckets that do not fit this instantiation
+    u32 out_cap;
+};
+
+// start[b] = first index whose top-16-bit value is >= b (b = 0 .. 65536)
+__global__ void ls_bounds_kernel(const u64 *keys, u64 n, int low_bits, u64 *start) {
+    const u32 b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b > (1u << LS_TOP_BITS)) return;
+    u64 lo = 0, hi = n;
+    if (b == (1u << LS_TOP_BITS)) {
+        lo = n;
+    } else {
+        while (lo < hi) {
+            const u64 mid = (lo + hi) >> 1;
+            if ((keys[mid] >> low_bits) < (u64)b) lo = mid + 1; else hi = mid;
+        }
+    }
+    start[b] = lo;
+}
+
+template <int LS_KPT>
+__global__ __launch_bounds__(LS_NT) void ls_sort_kernel(LocalSortArgs a) {
+    constexpr int LS_CAP = LS_NT * LS_KPT;
+    __shared__ u64 s_buf[2][LS_CAP];
+    __shared__ unsigned short s_wh[LS_NW][RADIX];
+    __shared__ u32 s_dex[RADIX];
+    __shared__ u32 s_scan[LS_NW + 1];
+    static_assert(LS_NT == RADIX, "thread d owns digit d");
+    const int tid = (int)threadIdx.x, lane = lane_id(), wave = tid >> 6;
+    const u32 b = a.in ? (u32)a.in[1 + blockIdx.x] : blockIdx.x;
+    const u64 beg = a.start[b], end = a.start[b + 1];
+    const u64 m64 = end - beg;
+    if (m64 <= 1) return;
+    if (m64 > (u64)LS_CAP) {
+        if (tid == 0) {
+            const u64 at = atomicAdd((unsigned long long *)&a.out[0], 1ull);
+            if (at < (u64)a.out_cap) a.out[1 + at] = b;
+        }
+        return;
+    }
+    const u32 m = (u32)m64;
+    u64 key[LS_KPT];
+    const u32 wbase = (u32)wave * 64 * LS_KPT + (u32)lane;
+#pragma unroll
+    for (int j = 0; j < LS_KPT; j++) {
+        const u32 i = wbase + j * 64;
+        key[j] = i < m ? a.keys[beg + i] : ~0ull;  // padding: the highest digit in every pass, last in tile order
+    }
+    const u32 lt_lo = lane < 32 ? ((1u << lane) - 1u) : ~0u;
+    const u32 lt_hi = lane < 32 ? 0u : ((1u << (lane - 32)) - 1u);
+    const int npass = (a.low_bits + RB - 1) / RB;
+    int cur = 0;
+    for (int p = 0; p < npass; p++) {
+        const int shift = RB * p;
+        for (int i = tid; i < LS_NW * RADIX / 2; i += LS_NT) reinterpret_cast<u32 *>(&s_wh[0][0])[i] = 0;
+        __syncthreads();
+        u32 rk[LS_KPT];
+#pragma unroll
+        for (int j = 0; j < LS_KPT; j++) {
+            const u32 d = (u32)(key[j] >> shift) & DMASK;
+            u32 plo, phi;
+            match_any8(d, plo, phi);
+            const u32 pre = s_wh[wave][d];
+            rk[j] = pre + (u32)__popc(plo & lt_lo) + (u32)__popc(phi & lt_hi);
+            s_wh[wave][d] = (unsigned short)(pre + (u32)__popc(plo) + (u32)__popc(phi));
+        }
+        __syncthreads();
+        u32 cnt = 0;
+#pragma unroll
+        for (int w = 0; w < LS_NW; w++) {  // thread d: exclusive scan of digit d over the waves
+            const u32 cw = s_wh[w][tid];
+            s_wh[w][tid] = (unsigned short)cnt;
+            cnt += cw;
+        }
+        u32 total = 0;
+        const u32 dex = block_excl_scan_u32<LS_NT>(cnt, s_scan, &total);
+        s_dex[tid] = dex;
+        __syncthreads();
+        u64 *dst = s_buf[cur];
+#pragma unroll
+        for (int j = 0; j < LS_KPT; j++) {
+            const u32 d = (u32)(key[j] >> shift) & DMASK;
+            dst[s_dex[d] + s_wh[wave][d] + rk[j]] = key[j];
+        }
+        __syncthreads();
+        if (p + 1 < npass) {
+#pragma unroll
+            for (int j = 0; j < LS_KPT; j++) key[j] = dst[wbase + j * 64];
+        }
+        cur ^= 1;  // (the next pass writes the other buffer: this one is still being read)
+    }
+    const u64 *res = s_buf[cur ^ 1];
+    for (u32 i = (u32)tid; i < m; i += LS_NT) a.keys[beg + i] = res[i];
+}
+
+bool sort_local_enabled() {
+    const char *e = getenv("UKM_SORT_LOCAL");  // developer knob: 0 = all passes through HBM
+    return !(e && e[0] == '0');
+}
+
+// keys only, 2^24 <= n < 2^32.  *done = false: not this route (narrow keys, too many oversized buckets): the caller runs the
+// general passes over the keys as they are now (a permutation of the input).
+int sort_top16_local(ukm_ctx *c, u64 *keys, u64 n, int key_bits, bool *done) {
+    *done = false;
+    u64 *fh = nullptr, *gb = nullptr, *tk = nullptr, *start = nullptr, *big = nullptr;
+    UKM_TRY(ws_alloc_t(c, (size_t)MAX_PASSES * RADIX + 1, &fh));
+    UKM_TRY(ws_alloc_t(c, (size_t)MAX_PASSES * RADIX, &gb));
+    UKM_TRY(ws_alloc_t(c, (size_t)(1u << LS_TOP_BITS) + 2, &start));
+    UKM_TRY(ws_alloc_t(c, (size_t)LS_MAX_BIG + 2, &big));
+    const unsigned hb = (unsigned)std::min<u64>((n + 4095) / 4096, (u64)c->num_cu * 8);
+    int kb = key_bits;
+    for (int attempt = 0; attempt < 2; attempt++) {
+        UKM_HIP(hipMemsetAsync(fh, 0, (MAX_PASSES * RADIX + 1) * sizeof(u64), c->stream));
+        u64 *or_all = (key_bits == 64 && attempt == 0) ? fh + (size_t)MAX_PASSES * RADIX : nullptr;
+        hipLaunchKernelGGL(radix_hist_kernel, dim3(hb), dim3(NT), 0, c->stream, keys, n, 1, fh, or_all, kb - LS_TOP_BITS);
+        UKM_HIP(hipGetLastError());
+        if (!or_all) break;
+        u64 orv = 0;
+        UKM_TRY(ukm_read_u64(c, or_all, &orv));  // (a caller that could not narrow key_bits: one read-back, as in the general route)
+        const int bits = orv ? 64 - __builtin_clzll(orv) : 1;
+        if (bits > 56) break;  // the histogram above is the right one
+        kb = bits;
+        if (kb < 32) return UKM_OK;
+    }
+    if (kb < 32 || (n >> LS_TOP_BITS) * 3 > 2 * 4096) return UKM_OK;  // (narrow keys; buckets beyond the largest instantiation)
+    const int low_bits = kb - LS_TOP_BITS;
+    int sh[2] = {kb - 16, kb - 8};
+    UKM_TRY(ws_alloc_t(c, n, &tk));
+    bool in_tmp = false;
+    if (n < (1ull << 30)) UKM_TRY((run_passes<u32, false, SORT_NT_KEYS, SORT_VT_KEYS>(c, keys, nullptr, tk, nullptr, n, 2, sh, gb, &in_tmp, fh)));
+    else UKM_TRY((run_passes<u64, false, SORT_NT_KEYS, SORT_VT_KEYS>(c, keys, nullptr, tk, nullptr, n, 2, sh, gb, &in_tmp, fh)));
+    if (in_tmp) UKM_HIP(hipMemcpyAsync(keys, tk, n * sizeof(u64), hipMemcpyDeviceToDevice, c->stream));  // (two passes: not the case)
+    hipLaunchKernelGGL(ls_bounds_kernel, dim3(((1u << LS_TOP_BITS) + 1 + 255) / 256), dim3(256), 0, c->stream, keys, n, low_bits, start);
+    // first instantiation: the smallest one that holds 1.5 x the average bucket; what does not fit goes to the 4096-key
+    // instantiation through a list, what does not fit there to the general route
+    u64 *mid = nullptr;
+    UKM_TRY(ws_alloc_t(c, (size_t)LS_LIST + 2, &mid));
+    UKM_HIP(hipMemsetAsync(mid, 0, sizeof(u64), c->stream));
+    UKM_HIP(hipMemsetAsync(big, 0, sizeof(u64), c->stream));
+    LocalSortArgs a;
+    a.keys = keys; a.n = n; a.start = start; a.low_bits = low_bits;
+    a.in = nullptr; a.out = mid; a.out_cap = LS_LIST;
+    const u64 avg = n >> LS_TOP_BITS;
+    const dim3 grid(1u << LS_TOP_BITS), block(LS_NT);
+    if (avg * 3 <= 2 * 512) hipLaunchKernelGGL(ls_sort_kernel<2>, grid, block, 0, c->stream, a);
+    else if (avg * 3 <= 2 * 1024) hipLaunchKernelGGL(ls_sort_kernel<4>, grid, block, 0, c->stream, a);
+    else hipLaunchKernelGGL(ls_sort_kernel<8>, grid, block, 0, c->stream, a);
+    UKM_HIP(hipGetLastError());
+    u64 nmid = 0;
+    UKM_TRY(ukm_read_u64(c, mid, &nmid));
+    if (nmid > (u64)LS_LIST) return UKM_OK;  // (the small buckets are sorted, the others are not: the general passes redo it all)
+    if (nmid) {
+        a.in = mid; a.out = big; a.out_cap = LS_MAX_BIG;
+        hipLaunchKernelGGL(ls_sort_kernel<16>, dim3((unsigned)nmid), block, 0, c->stream, a);
+        UKM_HIP(hipGetLastError());
+        u64 hbig[LS_MAX_BIG + 1];
+        UKM_TRY(ukm_read_u64(c, big, hbig, LS_MAX_BIG + 1));
+        if (hbig[0] > (u64)LS_MAX_BIG) return UKM_OK;
+        for (u64 i = 0; i < hbig[0]; i++) {
+            u64 se[2];
+            UKM_TRY(ukm_read_u64(c, start + hbig[1 + i], se, 2));
+            UKM_TRY(ukm_dev_sort(c, keys + se[0], nullptr, se[1] - se[0], low_bits));
+        }
+    }
+    *done = true;
+    return UKM_OK;
+}
+
 }  // namespace
 
 // keys (and vals, may be NULL) are device pointers; sorted in place (stable for pairs)
@@ -491,6 +679,15 @@ int ukm_dev_sort(ukm_ctx *c, u64 *keys, u32 *vals, u64 n, int key_bits) {
 #ifndef SORT_FUSED_MIN
 #define SORT_FUSED_MIN (1ull << 24)
 #endif
+    if (!vals && n >= SORT_FUSED_MIN && RB == 8 && key_bits >= 32 && sort_local_enabled()) {
+        // keys only: two passes over the top 16 bits, then every bucket in LDS (above)
+        WsMark mark = ws_mark(c);
+        bool done = false;
+        const int rc = sort_top16_local(c, keys, n, key_bits, &done);
+        ws_release(c, mark);
+        UKM_TRY(rc);
+        if (done) return UKM_OK;
+    }
     if (n >= SORT_FUSED_MIN) {
         // Large inputs: only the FIRST digit's histogram is built by a pass over the keys; every scatter pass counts
         // the next digit on the fly and a 256-thread kernel turns the counts into bases between two passes.  The
