@@ -336,4 +336,11 @@ def test_sort_top16_then_lds_buckets(env, monkeypatch):
             w = x.clone()
             ctx.sort_u64(w, bits)
             assert torch.equal(w, exp), (bits, knob)
+        # taxids riding along: the order of equal keys is the input order (stable)
+        order = torch.sort(x ^ (-1 << 63), stable=True).indices
+        w = x.clone()
+        v = torch.arange(n, dtype=torch.int32, device=dev)
+        ctx.sort_pairs(w, v, bits)
+        assert torch.equal(w, exp) and torch.equal(v.long(), order), (bits, "pairs")
+        del order, w, v
     monkeypatch.delenv("UKM_SORT_LOCAL", raising=False)

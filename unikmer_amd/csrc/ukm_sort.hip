@@ -14,6 +14,7 @@
 //     the tile through LDS so that global stores are contiguous per digit, and scatters.
 //   Algorithmic bytes: 8n (histogram) + P * (8n read + 8n write) [+ P * 8n for taxids].
 #include <algorithm>
+#include <cmath>
 
 #include "ukm_device.h"
 
@@ -454,6 +455,7 @@ constexpr int LS_MAX_BIG = 48; // buckets beyond 4096 keys, sorted by the genera
 
 struct LocalSortArgs {
     u64 *keys;
+    u32 *vals;         // taxids riding along (PAIRS) or nullptr
     u64 n;
     const u64 *start;  // [65537]
     int low_bits;      // bits below the top 16
@@ -478,10 +480,11 @@ __global__ void ls_bounds_kernel(const u64 *keys, u64 n, int low_bits, u64 *star
     start[b] = lo;
 }
 
-template <int LS_KPT>
+template <int LS_KPT, bool PAIRS = false>
 __global__ __launch_bounds__(LS_NT) void ls_sort_kernel(LocalSortArgs a) {
     constexpr int LS_CAP = LS_NT * LS_KPT;
     __shared__ u64 s_buf[2][LS_CAP];
+    __shared__ u32 s_vbuf[PAIRS ? 2 : 1][PAIRS ? LS_CAP : 1];
     __shared__ unsigned short s_wh[LS_NW][RADIX];
     __shared__ u32 s_dex[RADIX];
     __shared__ u32 s_scan[LS_NW + 1];
@@ -500,11 +503,13 @@ __global__ __launch_bounds__(LS_NT) void ls_sort_kernel(LocalSortArgs a) {
     }
     const u32 m = (u32)m64;
     u64 key[LS_KPT];
+    u32 val[PAIRS ? LS_KPT : 1];
     const u32 wbase = (u32)wave * 64 * LS_KPT + (u32)lane;
 #pragma unroll
     for (int j = 0; j < LS_KPT; j++) {
         const u32 i = wbase + j * 64;
         key[j] = i < m ? a.keys[beg + i] : ~0ull;  // padding: the highest digit in every pass, last in tile order
+        if (PAIRS) val[j] = i < m ? a.vals[beg + i] : 0u;
     }
     const u32 lt_lo = lane < 32 ? ((1u << lane) - 1u) : ~0u;
     const u32 lt_hi = lane < 32 ? 0u : ((1u << (lane - 32)) - 1u);
@@ -537,20 +542,30 @@ __global__ __launch_bounds__(LS_NT) void ls_sort_kernel(LocalSortArgs a) {
         s_dex[tid] = dex;
         __syncthreads();
         u64 *dst = s_buf[cur];
+        u32 *vdst = s_vbuf[PAIRS ? cur : 0];
 #pragma unroll
         for (int j = 0; j < LS_KPT; j++) {
             const u32 d = (u32)(key[j] >> shift) & DMASK;
-            dst[s_dex[d] + s_wh[wave][d] + rk[j]] = key[j];
+            const u32 pos = s_dex[d] + s_wh[wave][d] + rk[j];
+            dst[pos] = key[j];
+            if (PAIRS) vdst[pos] = val[j];
         }
         __syncthreads();
         if (p + 1 < npass) {
 #pragma unroll
-            for (int j = 0; j < LS_KPT; j++) key[j] = dst[wbase + j * 64];
+            for (int j = 0; j < LS_KPT; j++) {
+                key[j] = dst[wbase + j * 64];
+                if (PAIRS) val[j] = vdst[wbase + j * 64];
+            }
         }
         cur ^= 1;  // (the next pass writes the other buffer: this one is still being read)
     }
     const u64 *res = s_buf[cur ^ 1];
-    for (u32 i = (u32)tid; i < m; i += LS_NT) a.keys[beg + i] = res[i];
+    const u32 *vres = s_vbuf[PAIRS ? (cur ^ 1) : 0];
+    for (u32 i = (u32)tid; i < m; i += LS_NT) {
+        a.keys[beg + i] = res[i];
+        if (PAIRS) a.vals[beg + i] = vres[i];
+    }
 }
 
 bool sort_local_enabled() {
@@ -558,9 +573,9 @@ bool sort_local_enabled() {
     return !(e && e[0] == '0');
 }
 
-// keys only, 2^24 <= n < 2^32.  *done = false: not this route (narrow keys, too many oversized buckets): the caller runs the
+// 2^24 <= n < 2^32.  *done = false: not this route (narrow keys, too many oversized buckets): the caller runs the
 // general passes over the keys as they are now (a permutation of the input).
-int sort_top16_local(ukm_ctx *c, u64 *keys, u64 n, int key_bits, bool *done) {
+int sort_top16_local(ukm_ctx *c, u64 *keys, u32 *vals, u64 n, int key_bits, bool *done) {
     *done = false;
     u64 *fh = nullptr, *gb = nullptr, *tk = nullptr, *start = nullptr, *big = nullptr;
     UKM_TRY(ws_alloc_t(c, (size_t)MAX_PASSES * RADIX + 1, &fh));
@@ -582,14 +597,24 @@ int sort_top16_local(ukm_ctx *c, u64 *keys, u64 n, int key_bits, bool *done) {
         kb = bits;
         if (kb < 32) return UKM_OK;
     }
-    if (kb < 32 || (n >> LS_TOP_BITS) * 3 > 2 * 4096) return UKM_OK;  // (narrow keys; buckets beyond the largest instantiation)
+    if (kb < 32 || (n >> LS_TOP_BITS) > 2700) return UKM_OK;  // (narrow keys; buckets beyond the 3072-key instantiation)
     const int low_bits = kb - LS_TOP_BITS;
     int sh[2] = {kb - 16, kb - 8};
+    u32 *tv = nullptr;
     UKM_TRY(ws_alloc_t(c, n, &tk));
+    if (vals) UKM_TRY(ws_alloc_t(c, n, &tv));
     bool in_tmp = false;
-    if (n < (1ull << 30)) UKM_TRY((run_passes<u32, false, SORT_NT_KEYS, SORT_VT_KEYS>(c, keys, nullptr, tk, nullptr, n, 2, sh, gb, &in_tmp, fh)));
-    else UKM_TRY((run_passes<u64, false, SORT_NT_KEYS, SORT_VT_KEYS>(c, keys, nullptr, tk, nullptr, n, 2, sh, gb, &in_tmp, fh)));
-    if (in_tmp) UKM_HIP(hipMemcpyAsync(keys, tk, n * sizeof(u64), hipMemcpyDeviceToDevice, c->stream));  // (two passes: not the case)
+    if (vals) {
+        if (n < (1ull << 30)) UKM_TRY((run_passes<u32, true, SORT_NT_PAIRS, SORT_VT_PAIRS>(c, keys, vals, tk, tv, n, 2, sh, gb, &in_tmp, fh)));
+        else UKM_TRY((run_passes<u64, true, SORT_NT_PAIRS, SORT_VT_PAIRS>(c, keys, vals, tk, tv, n, 2, sh, gb, &in_tmp, fh)));
+    } else {
+        if (n < (1ull << 30)) UKM_TRY((run_passes<u32, false, SORT_NT_KEYS, SORT_VT_KEYS>(c, keys, nullptr, tk, nullptr, n, 2, sh, gb, &in_tmp, fh)));
+        else UKM_TRY((run_passes<u64, false, SORT_NT_KEYS, SORT_VT_KEYS>(c, keys, nullptr, tk, nullptr, n, 2, sh, gb, &in_tmp, fh)));
+    }
+    if (in_tmp) {  // (two passes: not the case)
+        UKM_HIP(hipMemcpyAsync(keys, tk, n * sizeof(u64), hipMemcpyDeviceToDevice, c->stream));
+        if (vals) UKM_HIP(hipMemcpyAsync(vals, tv, n * sizeof(u32), hipMemcpyDeviceToDevice, c->stream));
+    }
     hipLaunchKernelGGL(ls_bounds_kernel, dim3(((1u << LS_TOP_BITS) + 1 + 255) / 256), dim3(256), 0, c->stream, keys, n, low_bits, start);
     // first instantiation: the smallest one that holds 1.5 x the average bucket; what does not fit goes to the 4096-key
     // instantiation through a list, what does not fit there to the general route
@@ -598,20 +623,37 @@ int sort_top16_local(ukm_ctx *c, u64 *keys, u64 n, int key_bits, bool *done) {
     UKM_HIP(hipMemsetAsync(mid, 0, sizeof(u64), c->stream));
     UKM_HIP(hipMemsetAsync(big, 0, sizeof(u64), c->stream));
     LocalSortArgs a;
-    a.keys = keys; a.n = n; a.start = start; a.low_bits = low_bits;
+    a.keys = keys; a.vals = vals; a.n = n; a.start = start; a.low_bits = low_bits;
     a.in = nullptr; a.out = mid; a.out_cap = LS_LIST;
+    // keys per thread: the average bucket + 8 standard deviations of an even spread (a bucket is padded to the
+    // instantiation's size: at n = 1e8, 1526 per bucket, 7 x 256 = 1792 slots instead of 2048 are 12 % less work)
     const u64 avg = n >> LS_TOP_BITS;
+    const u64 need = avg + 8 * (u64)std::sqrt((double)avg) + 16;
+    const int kpt = (int)std::min<u64>(std::max<u64>((need + LS_NT - 1) / LS_NT, 2), 12);
     const dim3 grid(1u << LS_TOP_BITS), block(LS_NT);
-    if (avg * 3 <= 2 * 512) hipLaunchKernelGGL(ls_sort_kernel<2>, grid, block, 0, c->stream, a);
-    else if (avg * 3 <= 2 * 1024) hipLaunchKernelGGL(ls_sort_kernel<4>, grid, block, 0, c->stream, a);
-    else hipLaunchKernelGGL(ls_sort_kernel<8>, grid, block, 0, c->stream, a);
+#define LS_LAUNCH(K, G)                                                                                       \
+    do {                                                                                                      \
+        if (vals) hipLaunchKernelGGL((ls_sort_kernel<K, true>), G, block, 0, c->stream, a);                   \
+        else hipLaunchKernelGGL((ls_sort_kernel<K, false>), G, block, 0, c->stream, a);                       \
+    } while (0)
+    switch (kpt) {
+    case 2: LS_LAUNCH(2, grid); break;
+    case 3: LS_LAUNCH(3, grid); break;
+    case 4: LS_LAUNCH(4, grid); break;
+    case 5: LS_LAUNCH(5, grid); break;
+    case 6: LS_LAUNCH(6, grid); break;
+    case 7: LS_LAUNCH(7, grid); break;
+    case 8: LS_LAUNCH(8, grid); break;
+    case 9: case 10: LS_LAUNCH(10, grid); break;
+    default: LS_LAUNCH(12, grid); break;
+    }
     UKM_HIP(hipGetLastError());
     u64 nmid = 0;
     UKM_TRY(ukm_read_u64(c, mid, &nmid));
     if (nmid > (u64)LS_LIST) return UKM_OK;  // (the small buckets are sorted, the others are not: the general passes redo it all)
     if (nmid) {
         a.in = mid; a.out = big; a.out_cap = LS_MAX_BIG;
-        hipLaunchKernelGGL(ls_sort_kernel<16>, dim3((unsigned)nmid), block, 0, c->stream, a);
+        LS_LAUNCH(16, dim3((unsigned)nmid));
         UKM_HIP(hipGetLastError());
         u64 hbig[LS_MAX_BIG + 1];
         UKM_TRY(ukm_read_u64(c, big, hbig, LS_MAX_BIG + 1));
@@ -619,9 +661,10 @@ int sort_top16_local(ukm_ctx *c, u64 *keys, u64 n, int key_bits, bool *done) {
         for (u64 i = 0; i < hbig[0]; i++) {
             u64 se[2];
             UKM_TRY(ukm_read_u64(c, start + hbig[1 + i], se, 2));
-            UKM_TRY(ukm_dev_sort(c, keys + se[0], nullptr, se[1] - se[0], low_bits));
+            UKM_TRY(ukm_dev_sort(c, keys + se[0], vals ? vals + se[0] : nullptr, se[1] - se[0], low_bits));
         }
     }
+#undef LS_LAUNCH
     *done = true;
     return UKM_OK;
 }
@@ -679,11 +722,11 @@ int ukm_dev_sort(ukm_ctx *c, u64 *keys, u32 *vals, u64 n, int key_bits) {
 #ifndef SORT_FUSED_MIN
 #define SORT_FUSED_MIN (1ull << 24)
 #endif
-    if (!vals && n >= SORT_FUSED_MIN && RB == 8 && key_bits >= 32 && sort_local_enabled()) {
-        // keys only: two passes over the top 16 bits, then every bucket in LDS (above)
+    if (n >= SORT_FUSED_MIN && RB == 8 && key_bits >= 32 && sort_local_enabled()) {
+        // two passes over the top 16 bits, then every bucket in LDS (above); stable, so taxids may ride along
         WsMark mark = ws_mark(c);
         bool done = false;
-        const int rc = sort_top16_local(c, keys, n, key_bits, &done);
+        const int rc = sort_top16_local(c, keys, vals, n, key_bits, &done);
         ws_release(c, mark);
         UKM_TRY(rc);
         if (done) return UKM_OK;
