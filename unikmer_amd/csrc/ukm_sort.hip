@@ -445,13 +445,14 @@ int run_passes(ukm_ctx *c, u64 *keys, u32 *vals, u64 *tk, u32 *tv, u64 n, int np
 // buckets of n / 65,536 keys on evenly spread keys (k-mer codes, hashes): 1.5 k keys = 12 KB at n = 1e8, which one
 // 256-thread workgroup sorts by the remaining low bits entirely in LDS (the same ballot ranking as the global pass,
 // ping-pong between two LDS buffers) and writes back in place.  Keys cross HBM three times instead of eight.
-// The instantiation (512 / 1024 / 2048 keys) follows the average bucket; buckets that do not fit go through a list to the
-// 4096-key instantiation, buckets beyond that are sorted by the general route afterwards; too many of either, narrow
-// keys, or n beyond ~1.7e8 and the whole call takes the general route (the two passes only permuted the keys).
+// Six instantiations (512 ... 4096 keys) serve the buckets by size class; buckets beyond 4096 keys are sorted by the
+// general route afterwards; too many of those, narrow keys, or n beyond ~1.3e8 and the whole call takes the general
+// route (the two passes only permuted the keys).
 constexpr int LS_NT = 256, LS_NW = LS_NT / 64;  // keys per thread 2 / 4 / 8 / 16: buckets of up to 512 ... 4096 keys
 constexpr int LS_TOP_BITS = 16;
-constexpr int LS_LIST = 8192;  // oversized buckets a kernel may hand on
-constexpr int LS_MAX_BIG = 48; // buckets beyond 4096 keys, sorted by the general route (read back through the 64-word scratch)
+constexpr int LS_MAX_BIG = 48; // buckets beyond 4096 keys, sorted by the general route (the list is read back through the 64-word scratch)
+constexpr int LS_NCLASS = 6;
+constexpr int LS_CLASS_KPT[LS_NCLASS] = {2, 4, 6, 8, 12, 16};  // keys per thread of the size classes: up to 512 ... 4096 keys
 
 struct LocalSortArgs {
     u64 *keys;
@@ -459,9 +460,7 @@ struct LocalSortArgs {
     u64 n;
     const u64 *start;  // [65537]
     int low_bits;      // bits below the top 16
-    const u64 *in;     // bucket ids to sort (nullptr: bucket = blockIdx.x)
-    u64 *out;          // [0] count, [1 ...] ids of the buckets that do not fit this instantiation
-    u32 out_cap;
+    u32 size_lo;       // this launch sorts the buckets with size_lo < size <= its capacity
 };
 
 // start[b] = first index whose top-16-bit value is >= b (b = 0 .. 65536)
@@ -480,6 +479,30 @@ __global__ void ls_bounds_kernel(const u64 *keys, u64 n, int low_bits, u64 *star
     start[b] = lo;
 }
 
+// size class of every bucket: cls[k] = buckets of class k (k = LS_NCLASS: beyond every class), cls[LS_NCLASS + 1 ...] = their ids
+__global__ void ls_classify_kernel(const u64 *start, u64 *cls) {
+    const u32 b = blockIdx.x * blockDim.x + threadIdx.x;  // (the grid covers the buckets exactly)
+    const u64 m = start[b + 1] - start[b];
+    int k = -1;
+    if (m > 1) {
+        k = 0;
+        while (k < LS_NCLASS && m > (u64)LS_NT * LS_CLASS_KPT[k]) k++;
+    }
+    // one atomic per wave and class (65,536 atomics on two or three addresses took 0.55 ms)
+#pragma unroll
+    for (int q = 0; q <= LS_NCLASS; q++) {
+        const u64 mask = __ballot(k == q);
+        if (mask == 0ull) continue;
+        const int lead = __ffsll((long long)mask) - 1;
+        u64 at = 0;
+        if (lane_id() == lead) at = atomicAdd((unsigned long long *)&cls[q], (unsigned long long)__popcll(mask));
+        if (q == LS_NCLASS) {
+            at = __shfl(at, lead, 64) + (u64)__popcll(mask & ((1ull << lane_id()) - 1ull));
+            if (k == q && at < (u64)LS_MAX_BIG) cls[LS_NCLASS + 1 + at] = b;
+        }
+    }
+}
+
 template <int LS_KPT, bool PAIRS = false>
 __global__ __launch_bounds__(LS_NT) void ls_sort_kernel(LocalSortArgs a) {
     constexpr int LS_CAP = LS_NT * LS_KPT;
@@ -490,17 +513,10 @@ __global__ __launch_bounds__(LS_NT) void ls_sort_kernel(LocalSortArgs a) {
     __shared__ u32 s_scan[LS_NW + 1];
     static_assert(LS_NT == RADIX, "thread d owns digit d");
     const int tid = (int)threadIdx.x, lane = lane_id(), wave = tid >> 6;
-    const u32 b = a.in ? (u32)a.in[1 + blockIdx.x] : blockIdx.x;
+    const u32 b = blockIdx.x;
     const u64 beg = a.start[b], end = a.start[b + 1];
     const u64 m64 = end - beg;
-    if (m64 <= 1) return;
-    if (m64 > (u64)LS_CAP) {
-        if (tid == 0) {
-            const u64 at = atomicAdd((unsigned long long *)&a.out[0], 1ull);
-            if (at < (u64)a.out_cap) a.out[1 + at] = b;
-        }
-        return;
-    }
+    if (m64 <= 1 || m64 <= (u64)a.size_lo || m64 > (u64)LS_CAP) return;  // (another size class's bucket, or the general route's)
     const u32 m = (u32)m64;
     u64 key[LS_KPT];
     u32 val[PAIRS ? LS_KPT : 1];
@@ -577,11 +593,10 @@ bool sort_local_enabled() {
 // general passes over the keys as they are now (a permutation of the input).
 int sort_top16_local(ukm_ctx *c, u64 *keys, u32 *vals, u64 n, int key_bits, bool *done) {
     *done = false;
-    u64 *fh = nullptr, *gb = nullptr, *tk = nullptr, *start = nullptr, *big = nullptr;
+    u64 *fh = nullptr, *gb = nullptr, *tk = nullptr, *start = nullptr;
     UKM_TRY(ws_alloc_t(c, (size_t)MAX_PASSES * RADIX + 1, &fh));
     UKM_TRY(ws_alloc_t(c, (size_t)MAX_PASSES * RADIX, &gb));
     UKM_TRY(ws_alloc_t(c, (size_t)(1u << LS_TOP_BITS) + 2, &start));
-    UKM_TRY(ws_alloc_t(c, (size_t)LS_MAX_BIG + 2, &big));
     const unsigned hb = (unsigned)std::min<u64>((n + 4095) / 4096, (u64)c->num_cu * 8);
     int kb = key_bits;
     for (int attempt = 0; attempt < 2; attempt++) {
@@ -597,7 +612,7 @@ int sort_top16_local(ukm_ctx *c, u64 *keys, u32 *vals, u64 n, int key_bits, bool
         kb = bits;
         if (kb < 32) return UKM_OK;
     }
-    if (kb < 32 || (n >> LS_TOP_BITS) > 2700) return UKM_OK;  // (narrow keys; buckets beyond the 3072-key instantiation)
+    if (kb < 32 || (n >> LS_TOP_BITS) > 2048) return UKM_OK;  // (narrow keys; average bucket beyond half the largest class)
     const int low_bits = kb - LS_TOP_BITS;
     int sh[2] = {kb - 16, kb - 8};
     u32 *tv = nullptr;
@@ -616,53 +631,43 @@ int sort_top16_local(ukm_ctx *c, u64 *keys, u32 *vals, u64 n, int key_bits, bool
         if (vals) UKM_HIP(hipMemcpyAsync(vals, tv, n * sizeof(u32), hipMemcpyDeviceToDevice, c->stream));
     }
     hipLaunchKernelGGL(ls_bounds_kernel, dim3(((1u << LS_TOP_BITS) + 1 + 255) / 256), dim3(256), 0, c->stream, keys, n, low_bits, start);
-    // first instantiation: the smallest one that holds 1.5 x the average bucket; what does not fit goes to the 4096-key
-    // instantiation through a list, what does not fit there to the general route
-    u64 *mid = nullptr;
-    UKM_TRY(ws_alloc_t(c, (size_t)LS_LIST + 2, &mid));
-    UKM_HIP(hipMemsetAsync(mid, 0, sizeof(u64), c->stream));
-    UKM_HIP(hipMemsetAsync(big, 0, sizeof(u64), c->stream));
+    // Buckets differ in size (canonical k-mers: twice the average at the low end of the code space, none at the top), so
+    // every bucket goes to the instantiation of ITS size class: a tiny kernel counts the classes, the classes that occur
+    // are launched over all buckets (a workgroup whose bucket belongs to another class leaves at once), and the few
+    // buckets beyond 4096 keys are sorted by the general route.
+    u64 *cls = nullptr;
+    UKM_TRY(ws_alloc_t(c, (size_t)LS_NCLASS + 2 + LS_MAX_BIG, &cls));
+    UKM_HIP(hipMemsetAsync(cls, 0, (LS_NCLASS + 2 + LS_MAX_BIG) * sizeof(u64), c->stream));
+    hipLaunchKernelGGL(ls_classify_kernel, dim3((1u << LS_TOP_BITS) / 256), dim3(256), 0, c->stream, start, cls);
+    UKM_HIP(hipGetLastError());
+    u64 hc[LS_NCLASS + 1 + LS_MAX_BIG];
+    UKM_TRY(ukm_read_u64(c, cls, hc, LS_NCLASS + 1 + LS_MAX_BIG));
+    if (hc[LS_NCLASS] > (u64)LS_MAX_BIG) return UKM_OK;  // (keys crowded into few buckets: the general passes sort the permuted keys)
     LocalSortArgs a;
     a.keys = keys; a.vals = vals; a.n = n; a.start = start; a.low_bits = low_bits;
-    a.in = nullptr; a.out = mid; a.out_cap = LS_LIST;
-    // keys per thread: the average bucket + 8 standard deviations of an even spread (a bucket is padded to the
-    // instantiation's size: at n = 1e8, 1526 per bucket, 7 x 256 = 1792 slots instead of 2048 are 12 % less work)
-    const u64 avg = n >> LS_TOP_BITS;
-    const u64 need = avg + 8 * (u64)std::sqrt((double)avg) + 16;
-    const int kpt = (int)std::min<u64>(std::max<u64>((need + LS_NT - 1) / LS_NT, 2), 12);
     const dim3 grid(1u << LS_TOP_BITS), block(LS_NT);
-#define LS_LAUNCH(K, G)                                                                                       \
+#define LS_LAUNCH(K)                                                                                          \
     do {                                                                                                      \
-        if (vals) hipLaunchKernelGGL((ls_sort_kernel<K, true>), G, block, 0, c->stream, a);                   \
-        else hipLaunchKernelGGL((ls_sort_kernel<K, false>), G, block, 0, c->stream, a);                       \
+        if (vals) hipLaunchKernelGGL((ls_sort_kernel<K, true>), grid, block, 0, c->stream, a);                \
+        else hipLaunchKernelGGL((ls_sort_kernel<K, false>), grid, block, 0, c->stream, a);                    \
     } while (0)
-    switch (kpt) {
-    case 2: LS_LAUNCH(2, grid); break;
-    case 3: LS_LAUNCH(3, grid); break;
-    case 4: LS_LAUNCH(4, grid); break;
-    case 5: LS_LAUNCH(5, grid); break;
-    case 6: LS_LAUNCH(6, grid); break;
-    case 7: LS_LAUNCH(7, grid); break;
-    case 8: LS_LAUNCH(8, grid); break;
-    case 9: case 10: LS_LAUNCH(10, grid); break;
-    default: LS_LAUNCH(12, grid); break;
+    for (int k = 0; k < LS_NCLASS; k++) {
+        if (hc[k] == 0) continue;
+        a.size_lo = k ? (u32)LS_NT * LS_CLASS_KPT[k - 1] : 0u;
+        switch (LS_CLASS_KPT[k]) {
+        case 2: LS_LAUNCH(2); break;
+        case 4: LS_LAUNCH(4); break;
+        case 6: LS_LAUNCH(6); break;
+        case 8: LS_LAUNCH(8); break;
+        case 12: LS_LAUNCH(12); break;
+        default: LS_LAUNCH(16); break;
+        }
     }
     UKM_HIP(hipGetLastError());
-    u64 nmid = 0;
-    UKM_TRY(ukm_read_u64(c, mid, &nmid));
-    if (nmid > (u64)LS_LIST) return UKM_OK;  // (the small buckets are sorted, the others are not: the general passes redo it all)
-    if (nmid) {
-        a.in = mid; a.out = big; a.out_cap = LS_MAX_BIG;
-        LS_LAUNCH(16, dim3((unsigned)nmid));
-        UKM_HIP(hipGetLastError());
-        u64 hbig[LS_MAX_BIG + 1];
-        UKM_TRY(ukm_read_u64(c, big, hbig, LS_MAX_BIG + 1));
-        if (hbig[0] > (u64)LS_MAX_BIG) return UKM_OK;
-        for (u64 i = 0; i < hbig[0]; i++) {
-            u64 se[2];
-            UKM_TRY(ukm_read_u64(c, start + hbig[1 + i], se, 2));
-            UKM_TRY(ukm_dev_sort(c, keys + se[0], vals ? vals + se[0] : nullptr, se[1] - se[0], low_bits));
-        }
+    for (u64 i = 0; i < hc[LS_NCLASS]; i++) {
+        u64 se[2];
+        UKM_TRY(ukm_read_u64(c, start + hc[LS_NCLASS + 1 + i], se, 2));
+        UKM_TRY(ukm_dev_sort(c, keys + se[0], vals ? vals + se[0] : nullptr, se[1] - se[0], low_bits));
     }
 #undef LS_LAUNCH
     *done = true;
