@@ -445,14 +445,14 @@ int run_passes(ukm_ctx *c, u64 *keys, u32 *vals, u64 *tk, u32 *tv, u64 n, int np
 // buckets of n / 65,536 keys on evenly spread keys (k-mer codes, hashes): 1.5 k keys = 12 KB at n = 1e8, which one
 // 256-thread workgroup sorts by the remaining low bits entirely in LDS (the same ballot ranking as the global pass,
 // ping-pong between two LDS buffers) and writes back in place.  Keys cross HBM three times instead of eight.
-// Six instantiations (512 ... 4096 keys) serve the buckets by size class; buckets beyond 4096 keys are sorted by the
+// Twelve instantiations (256 ... 4096 keys) serve the buckets by size class; buckets beyond 4096 keys are sorted by the
 // general route afterwards; too many of those, narrow keys, or n beyond ~1.3e8 and the whole call takes the general
 // route (the two passes only permuted the keys).
 constexpr int LS_NT = 256, LS_NW = LS_NT / 64;  // keys per thread 2 / 4 / 8 / 16: buckets of up to 512 ... 4096 keys
 constexpr int LS_TOP_BITS = 16;
 constexpr int LS_MAX_BIG = 48; // buckets beyond 4096 keys, sorted by the general route (the list is read back through the 64-word scratch)
-constexpr int LS_NCLASS = 6;
-constexpr int LS_CLASS_KPT[LS_NCLASS] = {2, 4, 6, 8, 12, 16};  // keys per thread of the size classes: up to 512 ... 4096 keys
+constexpr int LS_NCLASS = 12;
+constexpr int LS_CLASS_KPT[LS_NCLASS] = {1, 2, 3, 4, 5, 6, 7, 8, 10, 12, 14, 16};  // keys per thread of the size classes: 256 ... 4096 keys
 
 struct LocalSortArgs {
     u64 *keys;
@@ -460,7 +460,7 @@ struct LocalSortArgs {
     u64 n;
     const u64 *start;  // [65537]
     int low_bits;      // bits below the top 16
-    u32 size_lo;       // this launch sorts the buckets with size_lo < size <= its capacity
+    const u32 *ids;    // the buckets of this launch's size class
 };
 
 // start[b] = first index whose top-16-bit value is >= b (b = 0 .. 65536)
@@ -479,8 +479,9 @@ __global__ void ls_bounds_kernel(const u64 *keys, u64 n, int low_bits, u64 *star
     start[b] = lo;
 }
 
-// size class of every bucket: cls[k] = buckets of class k (k = LS_NCLASS: beyond every class), cls[LS_NCLASS + 1 ...] = their ids
-__global__ void ls_classify_kernel(const u64 *start, u64 *cls) {
+// size class of every bucket: cls[k] = number of buckets of class k (k = LS_NCLASS: beyond every class, their ids in
+// cls[LS_NCLASS + 1 ...]); ids[k][...] = the buckets of class k
+__global__ void ls_classify_kernel(const u64 *start, u64 *cls, u32 *ids) {
     const u32 b = blockIdx.x * blockDim.x + threadIdx.x;  // (the grid covers the buckets exactly)
     const u64 m = start[b + 1] - start[b];
     int k = -1;
@@ -489,16 +490,17 @@ __global__ void ls_classify_kernel(const u64 *start, u64 *cls) {
         while (k < LS_NCLASS && m > (u64)LS_NT * LS_CLASS_KPT[k]) k++;
     }
     // one atomic per wave and class (65,536 atomics on two or three addresses took 0.55 ms)
-#pragma unroll
+    const u64 lt = (1ull << lane_id()) - 1ull;
     for (int q = 0; q <= LS_NCLASS; q++) {
         const u64 mask = __ballot(k == q);
         if (mask == 0ull) continue;
         const int lead = __ffsll((long long)mask) - 1;
         u64 at = 0;
         if (lane_id() == lead) at = atomicAdd((unsigned long long *)&cls[q], (unsigned long long)__popcll(mask));
-        if (q == LS_NCLASS) {
-            at = __shfl(at, lead, 64) + (u64)__popcll(mask & ((1ull << lane_id()) - 1ull));
-            if (k == q && at < (u64)LS_MAX_BIG) cls[LS_NCLASS + 1 + at] = b;
+        at = __shfl(at, lead, 64) + (u64)__popcll(mask & lt);
+        if (k == q) {
+            if (q < LS_NCLASS) ids[(size_t)q << LS_TOP_BITS | at] = b;
+            else if (at < (u64)LS_MAX_BIG) cls[LS_NCLASS + 1 + at] = b;
         }
     }
 }
@@ -513,10 +515,9 @@ __global__ __launch_bounds__(LS_NT) void ls_sort_kernel(LocalSortArgs a) {
     __shared__ u32 s_scan[LS_NW + 1];
     static_assert(LS_NT == RADIX, "thread d owns digit d");
     const int tid = (int)threadIdx.x, lane = lane_id(), wave = tid >> 6;
-    const u32 b = blockIdx.x;
+    const u32 b = a.ids[blockIdx.x];
     const u64 beg = a.start[b], end = a.start[b + 1];
     const u64 m64 = end - beg;
-    if (m64 <= 1 || m64 <= (u64)a.size_lo || m64 > (u64)LS_CAP) return;  // (another size class's bucket, or the general route's)
     const u32 m = (u32)m64;
     u64 key[LS_KPT];
     u32 val[PAIRS ? LS_KPT : 1];
@@ -632,20 +633,22 @@ int sort_top16_local(ukm_ctx *c, u64 *keys, u32 *vals, u64 n, int key_bits, bool
     }
     hipLaunchKernelGGL(ls_bounds_kernel, dim3(((1u << LS_TOP_BITS) + 1 + 255) / 256), dim3(256), 0, c->stream, keys, n, low_bits, start);
     // Buckets differ in size (canonical k-mers: twice the average at the low end of the code space, none at the top), so
-    // every bucket goes to the instantiation of ITS size class: a tiny kernel counts the classes, the classes that occur
-    // are launched over all buckets (a workgroup whose bucket belongs to another class leaves at once), and the few
-    // buckets beyond 4096 keys are sorted by the general route.
+    // every bucket goes to the instantiation of ITS size class: a tiny kernel lists the buckets of every class, one launch
+    // per class that occurs, and the few buckets beyond 4096 keys are sorted by the general route.
     u64 *cls = nullptr;
+    u32 *ids = nullptr;
+    static_assert(LS_NCLASS + 1 + LS_MAX_BIG <= 64, "one read-back through the scratch");
     UKM_TRY(ws_alloc_t(c, (size_t)LS_NCLASS + 2 + LS_MAX_BIG, &cls));
+    UKM_TRY(ws_alloc_t(c, (size_t)LS_NCLASS << LS_TOP_BITS, &ids));
     UKM_HIP(hipMemsetAsync(cls, 0, (LS_NCLASS + 2 + LS_MAX_BIG) * sizeof(u64), c->stream));
-    hipLaunchKernelGGL(ls_classify_kernel, dim3((1u << LS_TOP_BITS) / 256), dim3(256), 0, c->stream, start, cls);
+    hipLaunchKernelGGL(ls_classify_kernel, dim3((1u << LS_TOP_BITS) / 256), dim3(256), 0, c->stream, start, cls, ids);
     UKM_HIP(hipGetLastError());
     u64 hc[LS_NCLASS + 1 + LS_MAX_BIG];
     UKM_TRY(ukm_read_u64(c, cls, hc, LS_NCLASS + 1 + LS_MAX_BIG));
     if (hc[LS_NCLASS] > (u64)LS_MAX_BIG) return UKM_OK;  // (keys crowded into few buckets: the general passes sort the permuted keys)
     LocalSortArgs a;
     a.keys = keys; a.vals = vals; a.n = n; a.start = start; a.low_bits = low_bits;
-    const dim3 grid(1u << LS_TOP_BITS), block(LS_NT);
+    const dim3 block(LS_NT);
 #define LS_LAUNCH(K)                                                                                          \
     do {                                                                                                      \
         if (vals) hipLaunchKernelGGL((ls_sort_kernel<K, true>), grid, block, 0, c->stream, a);                \
@@ -653,13 +656,20 @@ int sort_top16_local(ukm_ctx *c, u64 *keys, u32 *vals, u64 n, int key_bits, bool
     } while (0)
     for (int k = 0; k < LS_NCLASS; k++) {
         if (hc[k] == 0) continue;
-        a.size_lo = k ? (u32)LS_NT * LS_CLASS_KPT[k - 1] : 0u;
+        a.ids = ids + ((size_t)k << LS_TOP_BITS);
+        const dim3 grid((unsigned)hc[k]);
         switch (LS_CLASS_KPT[k]) {
+        case 1: LS_LAUNCH(1); break;
         case 2: LS_LAUNCH(2); break;
+        case 3: LS_LAUNCH(3); break;
         case 4: LS_LAUNCH(4); break;
+        case 5: LS_LAUNCH(5); break;
         case 6: LS_LAUNCH(6); break;
+        case 7: LS_LAUNCH(7); break;
         case 8: LS_LAUNCH(8); break;
+        case 10: LS_LAUNCH(10); break;
         case 12: LS_LAUNCH(12); break;
+        case 14: LS_LAUNCH(14); break;
         default: LS_LAUNCH(16); break;
         }
     }
