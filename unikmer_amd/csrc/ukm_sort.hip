@@ -737,7 +737,10 @@ int ukm_dev_sort(ukm_ctx *c, u64 *keys, u32 *vals, u64 n, int key_bits) {
 #ifndef SORT_FUSED_MIN
 #define SORT_FUSED_MIN (1ull << 24)
 #endif
-    if (n >= SORT_FUSED_MIN && RB == 8 && key_bits >= 32 && sort_local_enabled()) {
+#ifndef SORT_LOCAL_MIN
+#define SORT_LOCAL_MIN (1ull << 23)  // (measured: 1.2e7 keys 0.62 -> 0.50 ms, 6.7e6 equal, 1.5e6 slower)
+#endif
+    if (n >= SORT_LOCAL_MIN && RB == 8 && key_bits >= 32 && sort_local_enabled()) {
         // two passes over the top 16 bits, then every bucket in LDS (above); stable, so taxids may ride along
         WsMark mark = ws_mark(c);
         bool done = false;
