@@ -110,6 +110,8 @@ struct ukm_ctx {
 
     // set once the blockIdx-ordered set-op kernel hit its watchdog on this device
     bool setop_force_ticket = false;
+    // set once a sort found its keys crowded into few top-16-bit buckets (ukm_sort.hip): later sorts look at a sample first
+    bool sort_skew_seen = false;
 };
 
 // Arena API.  Pointers stay valid until the enclosing top-level call returns.

@@ -479,6 +479,31 @@ __global__ void ls_bounds_kernel(const u64 *keys, u64 n, int low_bits, u64 *star
     start[b] = lo;
 }
 
+// A sample of 2^20 keys counted by top-16-bit bucket, then the buckets whose share of the sample says "beyond 4096 keys":
+// run before the two passes on a context that has already met crowded keys (a wasted attempt costs two passes)
+__global__ void ls_sample_kernel(const u64 *keys, u64 n, int low_bits, u32 *cnt, u32 nsamp) {
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nsamp) return;
+    const u64 pos = (u64)(((unsigned __int128)i * n) / nsamp);
+    const u64 bb = keys[pos] >> low_bits;
+    const u32 b = bb < (1u << LS_TOP_BITS) ? (u32)bb : (1u << LS_TOP_BITS) - 1;
+    // one atomic per distinct bucket of the wave (crowded keys: 2^20 atomics on a few dozen addresses took ~1 ms)
+    bool todo = true;
+    while (todo) {
+        const u32 b0 = (u32)__builtin_amdgcn_readfirstlane((int)b);
+        const u64 same = __ballot(b == b0);
+        if (b == b0) {
+            if ((int)lane_id() == __ffsll((long long)same) - 1) atomicAdd(&cnt[b0], (u32)__popcll(same));
+            todo = false;
+        }
+    }
+}
+__global__ void ls_sample_count_kernel(const u32 *cnt, u32 thr, u64 *out) {
+    const u32 b = blockIdx.x * blockDim.x + threadIdx.x;
+    const u64 m = __ballot(cnt[b] > thr);
+    if (lane_id() == 0 && m) atomicAdd((unsigned long long *)out, (unsigned long long)__popcll(m));
+}
+
 // size class of every bucket: cls[k] = number of buckets of class k (k = LS_NCLASS: beyond every class, their ids in
 // cls[LS_NCLASS + 1 ...]); ids[k][...] = the buckets of class k
 __global__ void ls_classify_kernel(const u64 *start, u64 *cls, u32 *ids) {
@@ -598,6 +623,32 @@ int sort_top16_local(ukm_ctx *c, u64 *keys, u32 *vals, u64 n, int key_bits, bool
     UKM_TRY(ws_alloc_t(c, (size_t)MAX_PASSES * RADIX + 1, &fh));
     UKM_TRY(ws_alloc_t(c, (size_t)MAX_PASSES * RADIX, &gb));
     UKM_TRY(ws_alloc_t(c, (size_t)(1u << LS_TOP_BITS) + 2, &start));
+    // (a context that has met crowded keys looks at a sample before anything else is spent on this route)
+    bool heavy_seen = false;
+    auto guard = [&](int low_bits) -> int {
+        const u32 nsamp = 1u << 20;
+        u32 *scnt = nullptr;
+        u64 *sout = nullptr;
+        UKM_TRY(ws_alloc_t(c, (size_t)1 << LS_TOP_BITS, &scnt));
+        UKM_TRY(ws_alloc_t(c, 1, &sout));
+        UKM_HIP(hipMemsetAsync(scnt, 0, sizeof(u32) << LS_TOP_BITS, c->stream));
+        UKM_HIP(hipMemsetAsync(sout, 0, sizeof(u64), c->stream));
+        hipLaunchKernelGGL(ls_sample_kernel, dim3(nsamp / 256), dim3(256), 0, c->stream, keys, n, low_bits, scnt, nsamp);
+        // a bucket of 4096 keys holds 4096 * nsamp / n samples on average; 25 % above that to let borderline buckets pass
+        const u32 thr = (u32)((double)(LS_NT * LS_CLASS_KPT[LS_NCLASS - 1]) * 1.25 * (double)nsamp / (double)n) + 4;
+        hipLaunchKernelGGL(ls_sample_count_kernel, dim3((1u << LS_TOP_BITS) / 256), dim3(256), 0, c->stream, scnt, thr, sout);
+        UKM_HIP(hipGetLastError());
+        u64 heavy = 0;
+        UKM_TRY(ukm_read_u64(c, sout, &heavy));
+        if (getenv("UKM_SORT_DEBUG")) fprintf(stderr, "[sort] sample: %llu buckets look heavier than %u samples\n", (unsigned long long)heavy, thr);
+        heavy_seen = heavy > (u64)LS_MAX_BIG;
+        return UKM_OK;
+    };
+    if (c->sort_skew_seen && key_bits < 64) {
+        if (key_bits < 32) return UKM_OK;
+        UKM_TRY(guard(key_bits - LS_TOP_BITS));
+        if (heavy_seen) return UKM_OK;
+    }
     const unsigned hb = (unsigned)std::min<u64>((n + 4095) / 4096, (u64)c->num_cu * 8);
     int kb = key_bits;
     for (int attempt = 0; attempt < 2; attempt++) {
@@ -615,6 +666,8 @@ int sort_top16_local(ukm_ctx *c, u64 *keys, u32 *vals, u64 n, int key_bits, bool
     }
     if (kb < 32 || (n >> LS_TOP_BITS) > 2048) return UKM_OK;  // (narrow keys; average bucket beyond half the largest class)
     const int low_bits = kb - LS_TOP_BITS;
+    if (c->sort_skew_seen && key_bits == 64) UKM_TRY(guard(low_bits));
+    if (heavy_seen) return UKM_OK;
     int sh[2] = {kb - 16, kb - 8};
     u32 *tv = nullptr;
     UKM_TRY(ws_alloc_t(c, n, &tk));
@@ -645,7 +698,11 @@ int sort_top16_local(ukm_ctx *c, u64 *keys, u32 *vals, u64 n, int key_bits, bool
     UKM_HIP(hipGetLastError());
     u64 hc[LS_NCLASS + 1 + LS_MAX_BIG];
     UKM_TRY(ukm_read_u64(c, cls, hc, LS_NCLASS + 1 + LS_MAX_BIG));
-    if (hc[LS_NCLASS] > (u64)LS_MAX_BIG) return UKM_OK;  // (keys crowded into few buckets: the general passes sort the permuted keys)
+    if (hc[LS_NCLASS] > (u64)LS_MAX_BIG) {  // keys crowded into few buckets: the general passes sort the permuted keys
+        c->sort_skew_seen = true;        // (and the next sort on this context looks at a sample before it tries)
+        if (getenv("UKM_SORT_DEBUG")) fprintf(stderr, "[sort] %llu buckets beyond every class: general route\n", (unsigned long long)hc[LS_NCLASS]);
+        return UKM_OK;
+    }
     LocalSortArgs a;
     a.keys = keys; a.vals = vals; a.n = n; a.start = start; a.low_bits = low_bits;
     const dim3 block(LS_NT);
