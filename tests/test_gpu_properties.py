@@ -344,3 +344,35 @@ def test_sort_top16_then_lds_buckets(env, monkeypatch):
         assert torch.equal(w, exp) and torch.equal(v.long(), order), (bits, "pairs")
         del order, w, v
     monkeypatch.delenv("UKM_SORT_LOCAL", raising=False)
+
+
+def test_sort_three_top_passes_then_lds_buckets(env):
+    """Beyond 1.34e8 keys the bucket route sorts by the top 24 bits (three scatter passes, the result sits in the scratch
+    copy) and the bucket kernels write the caller's array from there: 1.6e8 random 62-bit keys and 64-bit keys with
+    duplicates against torch.sort, keys only and with taxids (stable)."""
+    torch, bench, lib, ctx, A, B = env
+    dev = A.device
+    n = 160_000_000
+    g = torch.Generator(device=dev)
+    g.manual_seed(23)
+    for bits in (62, 64):
+        hi = torch.randint(0, 1 << 31, (n,), device=dev, generator=g, dtype=torch.int64)
+        lo = torch.randint(0, 1 << 31, (n,), device=dev, generator=g, dtype=torch.int64)
+        x = (hi << 33) ^ (lo << 1)
+        del hi, lo
+        if bits == 62:
+            x &= (1 << 62) - 1
+        else:
+            x[::5] = x[1::5][: x[::5].numel()]   # duplicates
+            x[:3] = -1
+        srt = torch.sort(x ^ (-1 << 63), stable=True)
+        exp, order = srt.values ^ (-1 << 63), srt.indices
+        del srt
+        w = x.clone()
+        ctx.sort_u64(w, bits)
+        assert torch.equal(w, exp), bits
+        v = torch.arange(n, dtype=torch.int32, device=dev)
+        w.copy_(x)
+        ctx.sort_pairs(w, v, bits)
+        assert torch.equal(w, exp) and torch.equal(v.long(), order), (bits, "pairs")
+        del w, v, exp, order, x

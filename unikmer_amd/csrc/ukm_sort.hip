@@ -449,26 +449,28 @@ int run_passes(ukm_ctx *c, u64 *keys, u32 *vals, u64 *tk, u32 *tv, u64 n, int np
 // general route afterwards; too many of those, narrow keys, or n beyond ~1.3e8 and the whole call takes the general
 // route (the two passes only permuted the keys).
 constexpr int LS_NT = 256, LS_NW = LS_NT / 64;  // keys per thread 2 / 4 / 8 / 16: buckets of up to 512 ... 4096 keys
-constexpr int LS_TOP_BITS = 16;
+constexpr int LS_TOP_MIN = 12, LS_TOP_MAX = 22;  // bucket = the top `topb` bits: 2^topb buckets of ~1400 keys
 constexpr int LS_MAX_BIG = 48; // buckets beyond 4096 keys, sorted by the general route (the list is read back through the 64-word scratch)
 constexpr int LS_NCLASS = 12;
 constexpr int LS_CLASS_KPT[LS_NCLASS] = {1, 2, 3, 4, 5, 6, 7, 8, 10, 12, 14, 16};  // keys per thread of the size classes: 256 ... 4096 keys
 
 struct LocalSortArgs {
-    u64 *keys;
-    u32 *vals;         // taxids riding along (PAIRS) or nullptr
+    const u64 *src;    // sorted by its top bits (the caller's array after two top passes, the scratch copy after three)
+    const u32 *vsrc;   // taxids riding along (PAIRS) or nullptr
+    u64 *keys;         // the caller's array: every bucket is written to its own segment
+    u32 *vals;
     u64 n;
-    const u64 *start;  // [65537]
-    int low_bits;      // bits below the top 16
+    const u64 *start;  // [2^topb + 1]
+    int low_bits;      // bits below the bucket bits
     const u32 *ids;    // the buckets of this launch's size class
 };
 
-// start[b] = first index whose top-16-bit value is >= b (b = 0 .. 65536)
-__global__ void ls_bounds_kernel(const u64 *keys, u64 n, int low_bits, u64 *start) {
+// start[b] = first index whose bucket value (key >> low_bits) is >= b (b = 0 .. 2^topb)
+__global__ void ls_bounds_kernel(const u64 *keys, u64 n, int low_bits, int topb, u64 *start) {
     const u32 b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b > (1u << LS_TOP_BITS)) return;
+    if (b > (1u << topb)) return;
     u64 lo = 0, hi = n;
-    if (b == (1u << LS_TOP_BITS)) {
+    if (b == (1u << topb)) {
         lo = n;
     } else {
         while (lo < hi) {
@@ -479,14 +481,14 @@ __global__ void ls_bounds_kernel(const u64 *keys, u64 n, int low_bits, u64 *star
     start[b] = lo;
 }
 
-// A sample of 2^20 keys counted by top-16-bit bucket, then the buckets whose share of the sample says "beyond 4096 keys":
+// A sample of 2^20 keys counted by bucket, then the buckets whose share of the sample says "beyond 4096 keys":
 // run before the two passes on a context that has already met crowded keys (a wasted attempt costs two passes)
-__global__ void ls_sample_kernel(const u64 *keys, u64 n, int low_bits, u32 *cnt, u32 nsamp) {
+__global__ void ls_sample_kernel(const u64 *keys, u64 n, int low_bits, int topb, u32 *cnt, u32 nsamp) {
     const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nsamp) return;
     const u64 pos = (u64)(((unsigned __int128)i * n) / nsamp);
     const u64 bb = keys[pos] >> low_bits;
-    const u32 b = bb < (1u << LS_TOP_BITS) ? (u32)bb : (1u << LS_TOP_BITS) - 1;
+    const u32 b = bb < (1u << topb) ? (u32)bb : (1u << topb) - 1;
     // one atomic per distinct bucket of the wave (crowded keys: 2^20 atomics on a few dozen addresses took ~1 ms)
     bool todo = true;
     while (todo) {
@@ -506,11 +508,11 @@ __global__ void ls_sample_count_kernel(const u32 *cnt, u32 thr, u64 *out) {
 
 // size class of every bucket: cls[k] = number of buckets of class k (k = LS_NCLASS: beyond every class, their ids in
 // cls[LS_NCLASS + 1 ...]); ids[k][...] = the buckets of class k
-__global__ void ls_classify_kernel(const u64 *start, u64 *cls, u32 *ids) {
+__global__ void ls_classify_kernel(const u64 *start, u64 *cls, u32 *ids, int topb) {
     const u32 b = blockIdx.x * blockDim.x + threadIdx.x;  // (the grid covers the buckets exactly)
     const u64 m = start[b + 1] - start[b];
     int k = -1;
-    if (m > 1) {
+    if (m > 0) {  // (a bucket of one key still has to reach the caller's array when the sorted-by-top-bits copy is the scratch)
         k = 0;
         while (k < LS_NCLASS && m > (u64)LS_NT * LS_CLASS_KPT[k]) k++;
     }
@@ -524,7 +526,7 @@ __global__ void ls_classify_kernel(const u64 *start, u64 *cls, u32 *ids) {
         if (lane_id() == lead) at = atomicAdd((unsigned long long *)&cls[q], (unsigned long long)__popcll(mask));
         at = __shfl(at, lead, 64) + (u64)__popcll(mask & lt);
         if (k == q) {
-            if (q < LS_NCLASS) ids[(size_t)q << LS_TOP_BITS | at] = b;
+            if (q < LS_NCLASS) ids[(size_t)q << topb | at] = b;
             else if (at < (u64)LS_MAX_BIG) cls[LS_NCLASS + 1 + at] = b;
         }
     }
@@ -550,8 +552,8 @@ __global__ __launch_bounds__(LS_NT) void ls_sort_kernel(LocalSortArgs a) {
 #pragma unroll
     for (int j = 0; j < LS_KPT; j++) {
         const u32 i = wbase + j * 64;
-        key[j] = i < m ? a.keys[beg + i] : ~0ull;  // padding: the highest digit in every pass, last in tile order
-        if (PAIRS) val[j] = i < m ? a.vals[beg + i] : 0u;
+        key[j] = i < m ? a.src[beg + i] : ~0ull;  // padding: the highest digit in every pass, last in tile order
+        if (PAIRS) val[j] = i < m ? a.vsrc[beg + i] : 0u;
     }
     const u32 lt_lo = lane < 32 ? ((1u << lane) - 1u) : ~0u;
     const u32 lt_hi = lane < 32 ? 0u : ((1u << (lane - 32)) - 1u);
@@ -615,28 +617,41 @@ bool sort_local_enabled() {
     return !(e && e[0] == '0');
 }
 
-// 2^24 <= n < 2^32.  *done = false: not this route (narrow keys, too many oversized buckets): the caller runs the
+// 2^23 <= n < 2^32.  *done = false: not this route (narrow keys, too many oversized buckets): the caller runs the
 // general passes over the keys as they are now (a permutation of the input).
+// The buckets are the top `topb` bits with 2^topb ~ n / 1400: up to 1.3e8 keys the array is sorted by its top 16 bits (two
+// scatter passes), beyond that by its top 24 (three passes, the result sits in the scratch copy and the bucket kernels
+// write the caller's array from there).
 int sort_top16_local(ukm_ctx *c, u64 *keys, u32 *vals, u64 n, int key_bits, bool *done) {
     *done = false;
+    int topb;
+    if ((n >> 16) <= 2048) {  // two passes as long as 65,536 buckets hold the keys (a third pass costs more than larger buckets)
+        topb = LS_TOP_MIN;
+        while (topb < 16 && (n >> topb) > 1400) topb++;
+    } else {
+        topb = 17;
+        while (topb < LS_TOP_MAX && (n >> topb) > 1400) topb++;
+    }
+    const int npass = topb <= 16 ? 2 : 3;
+    const u32 nbuckets = 1u << topb;
     u64 *fh = nullptr, *gb = nullptr, *tk = nullptr, *start = nullptr;
     UKM_TRY(ws_alloc_t(c, (size_t)MAX_PASSES * RADIX + 1, &fh));
     UKM_TRY(ws_alloc_t(c, (size_t)MAX_PASSES * RADIX, &gb));
-    UKM_TRY(ws_alloc_t(c, (size_t)(1u << LS_TOP_BITS) + 2, &start));
+    UKM_TRY(ws_alloc_t(c, (size_t)nbuckets + 2, &start));
     // (a context that has met crowded keys looks at a sample before anything else is spent on this route)
     bool heavy_seen = false;
     auto guard = [&](int low_bits) -> int {
         const u32 nsamp = 1u << 20;
         u32 *scnt = nullptr;
         u64 *sout = nullptr;
-        UKM_TRY(ws_alloc_t(c, (size_t)1 << LS_TOP_BITS, &scnt));
+        UKM_TRY(ws_alloc_t(c, (size_t)nbuckets, &scnt));
         UKM_TRY(ws_alloc_t(c, 1, &sout));
-        UKM_HIP(hipMemsetAsync(scnt, 0, sizeof(u32) << LS_TOP_BITS, c->stream));
+        UKM_HIP(hipMemsetAsync(scnt, 0, sizeof(u32) * (size_t)nbuckets, c->stream));
         UKM_HIP(hipMemsetAsync(sout, 0, sizeof(u64), c->stream));
-        hipLaunchKernelGGL(ls_sample_kernel, dim3(nsamp / 256), dim3(256), 0, c->stream, keys, n, low_bits, scnt, nsamp);
+        hipLaunchKernelGGL(ls_sample_kernel, dim3(nsamp / 256), dim3(256), 0, c->stream, keys, n, low_bits, topb, scnt, nsamp);
         // a bucket of 4096 keys holds 4096 * nsamp / n samples on average; 25 % above that to let borderline buckets pass
         const u32 thr = (u32)((double)(LS_NT * LS_CLASS_KPT[LS_NCLASS - 1]) * 1.25 * (double)nsamp / (double)n) + 4;
-        hipLaunchKernelGGL(ls_sample_count_kernel, dim3((1u << LS_TOP_BITS) / 256), dim3(256), 0, c->stream, scnt, thr, sout);
+        hipLaunchKernelGGL(ls_sample_count_kernel, dim3(nbuckets / 256), dim3(256), 0, c->stream, scnt, thr, sout);
         UKM_HIP(hipGetLastError());
         u64 heavy = 0;
         UKM_TRY(ukm_read_u64(c, sout, &heavy));
@@ -644,9 +659,10 @@ int sort_top16_local(ukm_ctx *c, u64 *keys, u32 *vals, u64 n, int key_bits, bool
         heavy_seen = heavy > (u64)LS_MAX_BIG;
         return UKM_OK;
     };
+    const int min_bits = 8 * npass + 16;  // (at least two digits for the buckets' own passes)
     if (c->sort_skew_seen && key_bits < 64) {
-        if (key_bits < 32) return UKM_OK;
-        UKM_TRY(guard(key_bits - LS_TOP_BITS));
+        if (key_bits < min_bits) return UKM_OK;
+        UKM_TRY(guard(key_bits - topb));
         if (heavy_seen) return UKM_OK;
     }
     const unsigned hb = (unsigned)std::min<u64>((n + 4095) / 4096, (u64)c->num_cu * 8);
@@ -654,7 +670,7 @@ int sort_top16_local(ukm_ctx *c, u64 *keys, u32 *vals, u64 n, int key_bits, bool
     for (int attempt = 0; attempt < 2; attempt++) {
         UKM_HIP(hipMemsetAsync(fh, 0, (MAX_PASSES * RADIX + 1) * sizeof(u64), c->stream));
         u64 *or_all = (key_bits == 64 && attempt == 0) ? fh + (size_t)MAX_PASSES * RADIX : nullptr;
-        hipLaunchKernelGGL(radix_hist_kernel, dim3(hb), dim3(NT), 0, c->stream, keys, n, 1, fh, or_all, kb - LS_TOP_BITS);
+        hipLaunchKernelGGL(radix_hist_kernel, dim3(hb), dim3(NT), 0, c->stream, keys, n, 1, fh, or_all, kb - 8 * npass);
         UKM_HIP(hipGetLastError());
         if (!or_all) break;
         u64 orv = 0;
@@ -662,29 +678,35 @@ int sort_top16_local(ukm_ctx *c, u64 *keys, u32 *vals, u64 n, int key_bits, bool
         const int bits = orv ? 64 - __builtin_clzll(orv) : 1;
         if (bits > 56) break;  // the histogram above is the right one
         kb = bits;
-        if (kb < 32) return UKM_OK;
+        if (kb < min_bits) return UKM_OK;
     }
-    if (kb < 32 || (n >> LS_TOP_BITS) > 2048) return UKM_OK;  // (narrow keys; average bucket beyond half the largest class)
-    const int low_bits = kb - LS_TOP_BITS;
+    if (kb < min_bits) return UKM_OK;  // (narrow keys)
+    const int low_bits = kb - topb;
     if (c->sort_skew_seen && key_bits == 64) UKM_TRY(guard(low_bits));
     if (heavy_seen) return UKM_OK;
-    int sh[2] = {kb - 16, kb - 8};
+    int sh[3];
+    for (int i = 0; i < npass; i++) sh[i] = kb - 8 * (npass - i);
     u32 *tv = nullptr;
     UKM_TRY(ws_alloc_t(c, n, &tk));
     if (vals) UKM_TRY(ws_alloc_t(c, n, &tv));
     bool in_tmp = false;
     if (vals) {
-        if (n < (1ull << 30)) UKM_TRY((run_passes<u32, true, SORT_NT_PAIRS, SORT_VT_PAIRS>(c, keys, vals, tk, tv, n, 2, sh, gb, &in_tmp, fh)));
-        else UKM_TRY((run_passes<u64, true, SORT_NT_PAIRS, SORT_VT_PAIRS>(c, keys, vals, tk, tv, n, 2, sh, gb, &in_tmp, fh)));
+        if (n < (1ull << 30)) UKM_TRY((run_passes<u32, true, SORT_NT_PAIRS, SORT_VT_PAIRS>(c, keys, vals, tk, tv, n, npass, sh, gb, &in_tmp, fh)));
+        else UKM_TRY((run_passes<u64, true, SORT_NT_PAIRS, SORT_VT_PAIRS>(c, keys, vals, tk, tv, n, npass, sh, gb, &in_tmp, fh)));
     } else {
-        if (n < (1ull << 30)) UKM_TRY((run_passes<u32, false, SORT_NT_KEYS, SORT_VT_KEYS>(c, keys, nullptr, tk, nullptr, n, 2, sh, gb, &in_tmp, fh)));
-        else UKM_TRY((run_passes<u64, false, SORT_NT_KEYS, SORT_VT_KEYS>(c, keys, nullptr, tk, nullptr, n, 2, sh, gb, &in_tmp, fh)));
+        if (n < (1ull << 30)) UKM_TRY((run_passes<u32, false, SORT_NT_KEYS, SORT_VT_KEYS>(c, keys, nullptr, tk, nullptr, n, npass, sh, gb, &in_tmp, fh)));
+        else UKM_TRY((run_passes<u64, false, SORT_NT_KEYS, SORT_VT_KEYS>(c, keys, nullptr, tk, nullptr, n, npass, sh, gb, &in_tmp, fh)));
     }
-    if (in_tmp) {  // (two passes: not the case)
-        UKM_HIP(hipMemcpyAsync(keys, tk, n * sizeof(u64), hipMemcpyDeviceToDevice, c->stream));
-        if (vals) UKM_HIP(hipMemcpyAsync(vals, tv, n * sizeof(u32), hipMemcpyDeviceToDevice, c->stream));
-    }
-    hipLaunchKernelGGL(ls_bounds_kernel, dim3(((1u << LS_TOP_BITS) + 1 + 255) / 256), dim3(256), 0, c->stream, keys, n, low_bits, start);
+    const u64 *src = in_tmp ? tk : keys;   // (three passes end in the scratch copy)
+    const u32 *vsrc = in_tmp ? tv : vals;
+    auto give_up = [&]() -> int {          // the general passes work on the caller's array
+        if (in_tmp) {
+            UKM_HIP(hipMemcpyAsync(keys, tk, n * sizeof(u64), hipMemcpyDeviceToDevice, c->stream));
+            if (vals) UKM_HIP(hipMemcpyAsync(vals, tv, n * sizeof(u32), hipMemcpyDeviceToDevice, c->stream));
+        }
+        return UKM_OK;
+    };
+    hipLaunchKernelGGL(ls_bounds_kernel, dim3((nbuckets + 1 + 255) / 256), dim3(256), 0, c->stream, src, n, low_bits, topb, start);
     // Buckets differ in size (canonical k-mers: twice the average at the low end of the code space, none at the top), so
     // every bucket goes to the instantiation of ITS size class: a tiny kernel lists the buckets of every class, one launch
     // per class that occurs, and the few buckets beyond 4096 keys are sorted by the general route.
@@ -692,19 +714,19 @@ int sort_top16_local(ukm_ctx *c, u64 *keys, u32 *vals, u64 n, int key_bits, bool
     u32 *ids = nullptr;
     static_assert(LS_NCLASS + 1 + LS_MAX_BIG <= 64, "one read-back through the scratch");
     UKM_TRY(ws_alloc_t(c, (size_t)LS_NCLASS + 2 + LS_MAX_BIG, &cls));
-    UKM_TRY(ws_alloc_t(c, (size_t)LS_NCLASS << LS_TOP_BITS, &ids));
+    UKM_TRY(ws_alloc_t(c, (size_t)LS_NCLASS << topb, &ids));
     UKM_HIP(hipMemsetAsync(cls, 0, (LS_NCLASS + 2 + LS_MAX_BIG) * sizeof(u64), c->stream));
-    hipLaunchKernelGGL(ls_classify_kernel, dim3((1u << LS_TOP_BITS) / 256), dim3(256), 0, c->stream, start, cls, ids);
+    hipLaunchKernelGGL(ls_classify_kernel, dim3(nbuckets / 256), dim3(256), 0, c->stream, start, cls, ids, topb);
     UKM_HIP(hipGetLastError());
     u64 hc[LS_NCLASS + 1 + LS_MAX_BIG];
     UKM_TRY(ukm_read_u64(c, cls, hc, LS_NCLASS + 1 + LS_MAX_BIG));
     if (hc[LS_NCLASS] > (u64)LS_MAX_BIG) {  // keys crowded into few buckets: the general passes sort the permuted keys
         c->sort_skew_seen = true;        // (and the next sort on this context looks at a sample before it tries)
         if (getenv("UKM_SORT_DEBUG")) fprintf(stderr, "[sort] %llu buckets beyond every class: general route\n", (unsigned long long)hc[LS_NCLASS]);
-        return UKM_OK;
+        return give_up();
     }
     LocalSortArgs a;
-    a.keys = keys; a.vals = vals; a.n = n; a.start = start; a.low_bits = low_bits;
+    a.src = src; a.vsrc = vsrc; a.keys = keys; a.vals = vals; a.n = n; a.start = start; a.low_bits = low_bits;
     const dim3 block(LS_NT);
 #define LS_LAUNCH(K)                                                                                          \
     do {                                                                                                      \
@@ -713,7 +735,7 @@ int sort_top16_local(ukm_ctx *c, u64 *keys, u32 *vals, u64 n, int key_bits, bool
     } while (0)
     for (int k = 0; k < LS_NCLASS; k++) {
         if (hc[k] == 0) continue;
-        a.ids = ids + ((size_t)k << LS_TOP_BITS);
+        a.ids = ids + ((size_t)k << topb);
         const dim3 grid((unsigned)hc[k]);
         switch (LS_CLASS_KPT[k]) {
         case 1: LS_LAUNCH(1); break;
@@ -734,6 +756,10 @@ int sort_top16_local(ukm_ctx *c, u64 *keys, u32 *vals, u64 n, int key_bits, bool
     for (u64 i = 0; i < hc[LS_NCLASS]; i++) {
         u64 se[2];
         UKM_TRY(ukm_read_u64(c, start + hc[LS_NCLASS + 1 + i], se, 2));
+        if (in_tmp) {
+            UKM_HIP(hipMemcpyAsync(keys + se[0], tk + se[0], (se[1] - se[0]) * sizeof(u64), hipMemcpyDeviceToDevice, c->stream));
+            if (vals) UKM_HIP(hipMemcpyAsync(vals + se[0], tv + se[0], (se[1] - se[0]) * sizeof(u32), hipMemcpyDeviceToDevice, c->stream));
+        }
         UKM_TRY(ukm_dev_sort(c, keys + se[0], vals ? vals + se[0] : nullptr, se[1] - se[0], low_bits));
     }
 #undef LS_LAUNCH
