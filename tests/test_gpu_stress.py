@@ -366,3 +366,59 @@ def test_random_probe_paths(env, seed, monkeypatch):
             gk, gt = ctx.diff(files, some, compare_taxid=True)
             ok, ot = O.diff(files, some, tax, compare_taxid=True)
             assert np.array_equal(gk, ok) and np.array_equal(gt, ot), (seed, it, "diff+some tax")
+
+
+@pytest.mark.parametrize("seed", _seeds(3))
+def test_random_sorts_through_the_bucket_route(env, seed):
+    """Sorts of 9e6 - 2.5e7 keys (the LDS bucket route of ukm_sort.hip) on seeded key distributions: even, power-law
+    clusters (heavy buckets, sometimes the fallback), smooth skew like canonical k-mers (min of two draws), few distinct
+    values, random key widths; keys only against torch.sort, with taxids against a stable torch.sort."""
+    import torch
+    O, L, _, tax, T = env
+    dev = torch.device("cuda:0")
+    # (device tensors made by torch: the context works on torch's stream, so that the sort is ordered behind them)
+    ctx = L.Context(0, stream=torch.cuda.current_stream(dev).cuda_stream)
+    g = torch.Generator(device=dev)
+    g.manual_seed(9400 + seed)
+    rng = np.random.default_rng(9400 + seed)
+
+    def rnd(n, bits):
+        hi = torch.randint(0, 1 << 31, (n,), device=dev, generator=g, dtype=torch.int64)
+        lo = torch.randint(0, 1 << 31, (n,), device=dev, generator=g, dtype=torch.int64)
+        x = (hi << 33) ^ (lo << 2) ^ torch.randint(0, 4, (n,), device=dev, generator=g, dtype=torch.int64)
+        return x if bits == 64 else x & ((1 << bits) - 1)
+
+    for it in range(4):
+        n = int(rng.integers(9_000_000, 25_000_000))
+        bits = int(rng.choice([40, 52, 62, 64]))
+        kind = int(rng.integers(0, 4))
+        x = rnd(n, bits)
+        if kind == 1:      # power-law clusters: a random share of the keys gets its top bits from a small set
+            share = float(rng.choice([0.02, 0.2, 0.6]))
+            m = torch.rand(n, device=dev, generator=g) < share
+            tops = torch.randint(0, 1 << 12, (int(rng.choice([3, 40, 2000])),), device=dev, generator=g, dtype=torch.int64)
+            pick = tops[torch.randint(0, tops.numel(), (n,), device=dev, generator=g)]
+            low = bits - 16 if bits < 64 else 48
+            x = torch.where(m, (x & ((1 << low) - 1)) | (pick << low), x)
+            if bits < 64:
+                x &= (1 << bits) - 1
+        elif kind == 2:    # canonical-like: the smaller of two draws (unsigned order)
+            y = rnd(n, bits)
+            f = -1 << 63
+            x = torch.where((x ^ f) < (y ^ f), x, y)
+        elif kind == 3:    # few distinct values
+            vals = rnd(int(rng.choice([1, 17, 5000])), bits)
+            x = vals[torch.randint(0, vals.numel(), (n,), device=dev, generator=g)]
+        f = -1 << 63
+        srt = torch.sort(x ^ f, stable=True)
+        exp, order = srt.values ^ f, srt.indices
+        w = x.clone()
+        ctx.sort_u64(w, bits)
+        assert torch.equal(w, exp), (seed, it, n, bits, kind, "keys")
+        v = torch.arange(n, dtype=torch.int32, device=dev)
+        w.copy_(x)
+        ctx.sort_pairs(w, v, bits)
+        assert torch.equal(w, exp) and torch.equal(v.long(), order), (seed, it, n, bits, kind, "pairs")
+        del x, w, v, exp, order, srt
+    torch.cuda.synchronize()
+    ctx.close()
