@@ -14,6 +14,8 @@
 //     the tile through LDS so that global stores are contiguous per digit, and scatters.
 //   Algorithmic bytes: 8n (histogram) + P * (8n read + 8n write) [+ P * 8n for taxids].
 #include <algorithm>
+#include <utility>
+#include <vector>
 #include <cmath>
 
 #include "ukm_device.h"
@@ -450,7 +452,7 @@ int run_passes(ukm_ctx *c, u64 *keys, u32 *vals, u64 *tk, u32 *tv, u64 n, int np
 // route (the two passes only permuted the keys).
 constexpr int LS_NT = 256, LS_NW = LS_NT / 64;  // keys per thread 2 / 4 / 8 / 16: buckets of up to 512 ... 4096 keys
 constexpr int LS_TOP_MIN = 12, LS_TOP_MAX = 22;  // bucket = the top `topb` bits: 2^topb buckets of ~1400 keys
-constexpr int LS_MAX_BIG = 48; // buckets beyond 4096 keys, sorted by the general route (the list is read back through the 64-word scratch)
+constexpr int LS_MAX_BIG = 32; // buckets beyond 4096 keys, sorted together by the general route (the list is read back through the 64-word scratch)
 constexpr int LS_NCLASS = 12;
 constexpr int LS_CLASS_KPT[LS_NCLASS] = {1, 2, 3, 4, 5, 6, 7, 8, 10, 12, 14, 16};  // keys per thread of the size classes: 256 ... 4096 keys
 
@@ -500,10 +502,18 @@ __global__ void ls_sample_kernel(const u64 *keys, u64 n, int low_bits, int topb,
         }
     }
 }
-__global__ void ls_sample_count_kernel(const u32 *cnt, u32 thr, u64 *out) {
+__global__ void ls_sample_count_kernel(const u32 *cnt, u32 thr, u64 *out) {  // out[0] heavy buckets, out[1] samples in them
     const u32 b = blockIdx.x * blockDim.x + threadIdx.x;
-    const u64 m = __ballot(cnt[b] > thr);
-    if (lane_id() == 0 && m) atomicAdd((unsigned long long *)out, (unsigned long long)__popcll(m));
+    const u32 cb = cnt[b];
+    const u64 m = __ballot(cb > thr);
+    if (m == 0ull) return;
+    u64 in_heavy = cb > thr ? cb : 0;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) in_heavy += __shfl_xor(in_heavy, d, 64);
+    if (lane_id() == 0) {
+        atomicAdd((unsigned long long *)&out[0], (unsigned long long)__popcll(m));
+        atomicAdd((unsigned long long *)&out[1], (unsigned long long)in_heavy);
+    }
 }
 
 // size class of every bucket: cls[k] = number of buckets of class k (k = LS_NCLASS: beyond every class, their ids in
@@ -529,6 +539,23 @@ __global__ void ls_classify_kernel(const u64 *start, u64 *cls, u32 *ids, int top
             if (q < LS_NCLASS) ids[(size_t)q << topb | at] = b;
             else if (at < (u64)LS_MAX_BIG) cls[LS_NCLASS + 1 + at] = b;
         }
+    }
+    // keys in oversized buckets (cls[LS_NCLASS + 1 + LS_MAX_BIG]): one atomic per wave
+    u64 big = k == LS_NCLASS ? m : 0;
+    if (__ballot(big != 0) != 0ull) {
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) big += __shfl_xor(big, d, 64);
+        if (lane_id() == 0) atomicAdd((unsigned long long *)&cls[LS_NCLASS + 1 + LS_MAX_BIG], (unsigned long long)big);
+    }
+}
+
+// (begin, end) of the listed oversized buckets, for one read-back
+__global__ void ls_big_ranges_kernel(const u64 *start, const u64 *cls, u64 *out) {
+    const u32 i = threadIdx.x;
+    if (i < (u32)LS_MAX_BIG && (u64)i < cls[LS_NCLASS]) {
+        const u64 b = cls[LS_NCLASS + 1 + i];
+        out[2 * i] = start[b];
+        out[2 * i + 1] = start[b + 1];
     }
 }
 
@@ -645,18 +672,20 @@ int sort_top16_local(ukm_ctx *c, u64 *keys, u32 *vals, u64 n, int key_bits, bool
         u32 *scnt = nullptr;
         u64 *sout = nullptr;
         UKM_TRY(ws_alloc_t(c, (size_t)nbuckets, &scnt));
-        UKM_TRY(ws_alloc_t(c, 1, &sout));
+        UKM_TRY(ws_alloc_t(c, 2, &sout));
         UKM_HIP(hipMemsetAsync(scnt, 0, sizeof(u32) * (size_t)nbuckets, c->stream));
-        UKM_HIP(hipMemsetAsync(sout, 0, sizeof(u64), c->stream));
+        UKM_HIP(hipMemsetAsync(sout, 0, 2 * sizeof(u64), c->stream));
         hipLaunchKernelGGL(ls_sample_kernel, dim3(nsamp / 256), dim3(256), 0, c->stream, keys, n, low_bits, topb, scnt, nsamp);
         // a bucket of 4096 keys holds 4096 * nsamp / n samples on average; 25 % above that to let borderline buckets pass
         const u32 thr = (u32)((double)(LS_NT * LS_CLASS_KPT[LS_NCLASS - 1]) * 1.25 * (double)nsamp / (double)n) + 4;
         hipLaunchKernelGGL(ls_sample_count_kernel, dim3(nbuckets / 256), dim3(256), 0, c->stream, scnt, thr, sout);
         UKM_HIP(hipGetLastError());
-        u64 heavy = 0;
-        UKM_TRY(ukm_read_u64(c, sout, &heavy));
-        if (getenv("UKM_SORT_DEBUG")) fprintf(stderr, "[sort] sample: %llu buckets look heavier than %u samples\n", (unsigned long long)heavy, thr);
-        heavy_seen = heavy > (u64)LS_MAX_BIG;
+        u64 heavy[2] = {0, 0};
+        UKM_TRY(ukm_read_u64(c, sout, heavy, 2));
+        if (getenv("UKM_SORT_DEBUG"))
+            fprintf(stderr, "[sort] sample: %llu buckets look heavier than %u samples, %llu of %u samples in them\n", (unsigned long long)heavy[0], thr,
+                    (unsigned long long)heavy[1], nsamp);
+        heavy_seen = heavy[0] > (u64)LS_MAX_BIG || heavy[1] > (u64)nsamp / 4;
         return UKM_OK;
     };
     const int min_bits = 8 * npass + 16;  // (at least two digits for the buckets' own passes)
@@ -712,15 +741,18 @@ int sort_top16_local(ukm_ctx *c, u64 *keys, u32 *vals, u64 n, int key_bits, bool
     // per class that occurs, and the few buckets beyond 4096 keys are sorted by the general route.
     u64 *cls = nullptr;
     u32 *ids = nullptr;
-    static_assert(LS_NCLASS + 1 + LS_MAX_BIG <= 64, "one read-back through the scratch");
-    UKM_TRY(ws_alloc_t(c, (size_t)LS_NCLASS + 2 + LS_MAX_BIG, &cls));
+    static_assert(LS_NCLASS + 2 + LS_MAX_BIG <= 64 && 2 * LS_MAX_BIG <= 64, "read-backs through the scratch");
+    UKM_TRY(ws_alloc_t(c, (size_t)LS_NCLASS + 3 + LS_MAX_BIG, &cls));
     UKM_TRY(ws_alloc_t(c, (size_t)LS_NCLASS << topb, &ids));
-    UKM_HIP(hipMemsetAsync(cls, 0, (LS_NCLASS + 2 + LS_MAX_BIG) * sizeof(u64), c->stream));
+    UKM_HIP(hipMemsetAsync(cls, 0, (LS_NCLASS + 3 + LS_MAX_BIG) * sizeof(u64), c->stream));
     hipLaunchKernelGGL(ls_classify_kernel, dim3(nbuckets / 256), dim3(256), 0, c->stream, start, cls, ids, topb);
     UKM_HIP(hipGetLastError());
-    u64 hc[LS_NCLASS + 1 + LS_MAX_BIG];
-    UKM_TRY(ukm_read_u64(c, cls, hc, LS_NCLASS + 1 + LS_MAX_BIG));
-    if (hc[LS_NCLASS] > (u64)LS_MAX_BIG) {  // keys crowded into few buckets: the general passes sort the permuted keys
+    u64 hc[LS_NCLASS + 2 + LS_MAX_BIG];
+    UKM_TRY(ukm_read_u64(c, cls, hc, LS_NCLASS + 2 + LS_MAX_BIG));
+    const u64 big_keys = hc[LS_NCLASS + 1 + LS_MAX_BIG];
+    // oversized buckets are gathered and sorted by ONE call of the general route: worth it for a few of them holding a
+    // minor share of the keys, else the general passes sort everything (keys crowded into few buckets)
+    if (hc[LS_NCLASS] > (u64)LS_MAX_BIG || big_keys > n / 4) {
         c->sort_skew_seen = true;        // (and the next sort on this context looks at a sample before it tries)
         if (getenv("UKM_SORT_DEBUG")) fprintf(stderr, "[sort] %llu buckets beyond every class: general route\n", (unsigned long long)hc[LS_NCLASS]);
         return give_up();
@@ -753,14 +785,37 @@ int sort_top16_local(ukm_ctx *c, u64 *keys, u32 *vals, u64 n, int key_bits, bool
         }
     }
     UKM_HIP(hipGetLastError());
-    for (u64 i = 0; i < hc[LS_NCLASS]; i++) {
-        u64 se[2];
-        UKM_TRY(ukm_read_u64(c, start + hc[LS_NCLASS + 1 + i], se, 2));
-        if (in_tmp) {
-            UKM_HIP(hipMemcpyAsync(keys + se[0], tk + se[0], (se[1] - se[0]) * sizeof(u64), hipMemcpyDeviceToDevice, c->stream));
-            if (vals) UKM_HIP(hipMemcpyAsync(vals + se[0], tv + se[0], (se[1] - se[0]) * sizeof(u32), hipMemcpyDeviceToDevice, c->stream));
+    if (hc[LS_NCLASS]) {
+        // the oversized buckets, in bucket order, side by side in a scratch array: sorted by the whole key they stay side by
+        // side (their top bits differ), each one sorted; one general sort instead of one per bucket (48 small sorts took 8 ms)
+        const int nb = (int)hc[LS_NCLASS];
+        u64 *rng = nullptr, *bk = nullptr;
+        u32 *bv = nullptr;
+        UKM_TRY(ws_alloc_t(c, (size_t)2 * LS_MAX_BIG, &rng));
+        UKM_TRY(ws_alloc_t(c, big_keys, &bk));
+        if (vals) UKM_TRY(ws_alloc_t(c, big_keys, &bv));
+        hipLaunchKernelGGL(ls_big_ranges_kernel, dim3(1), dim3(64), 0, c->stream, start, cls, rng);
+        UKM_HIP(hipGetLastError());
+        u64 se[2 * LS_MAX_BIG];
+        UKM_TRY(ukm_read_u64(c, rng, se, 2 * nb));
+        std::vector<std::pair<u64, u64>> seg(nb);
+        for (int i = 0; i < nb; i++) seg[i] = {se[2 * i], se[2 * i + 1]};
+        std::sort(seg.begin(), seg.end());  // (the list is in the order the waves appended it)
+        u64 off = 0;
+        for (auto &sg : seg) {
+            const u64 m = sg.second - sg.first;
+            UKM_HIP(hipMemcpyAsync(bk + off, src + sg.first, m * sizeof(u64), hipMemcpyDeviceToDevice, c->stream));
+            if (vals) UKM_HIP(hipMemcpyAsync(bv + off, vsrc + sg.first, m * sizeof(u32), hipMemcpyDeviceToDevice, c->stream));
+            off += m;
         }
-        UKM_TRY(ukm_dev_sort(c, keys + se[0], vals ? vals + se[0] : nullptr, se[1] - se[0], low_bits));
+        UKM_TRY(ukm_dev_sort(c, bk, bv, big_keys, kb));
+        off = 0;
+        for (auto &sg : seg) {
+            const u64 m = sg.second - sg.first;
+            UKM_HIP(hipMemcpyAsync(keys + sg.first, bk + off, m * sizeof(u64), hipMemcpyDeviceToDevice, c->stream));
+            if (vals) UKM_HIP(hipMemcpyAsync(vals + sg.first, bv + off, m * sizeof(u32), hipMemcpyDeviceToDevice, c->stream));
+            off += m;
+        }
     }
 #undef LS_LAUNCH
     *done = true;
