@@ -359,7 +359,7 @@ def test_probe_fold_shapes(env, monkeypatch):
     O, L, ctx, tax, T = env
     rng = np.random.default_rng(91)
 
-    monkeypatch.setenv("UKM_PFOLD_TAX", "1")   # inter with taxids through the probe fold as well (off by default: slower)
+    monkeypatch.setenv("UKM_PFOLD_TAX", "1")   # (the default: inter with taxids through the probe fold as well)
 
     def both(files, taxs):
         res = []
@@ -476,4 +476,132 @@ def test_probe_fold_inter_taxids_forest_merged_unknown(monkeypatch):
         ok, ot = O.inter(files, taxs, tax)
         assert len(ok) > 1000
         assert np.array_equal(gk, ok) and np.array_equal(gt, ot), env_tax
+    c.close()
+
+
+def test_common_of_all_files_through_the_probe_fold(env, monkeypatch):
+    """`common` with the default threshold (every file, common.go:93-105 with -p 1) over duplicate-free sorted files is
+    answered by the hash-probe fold; same answers as the oracle's counting map (common.go:220-344) and as the counting
+    merge (UKM_COMMON_PROBE=0).  A duplicate in a later file (counts twice there: a code missing elsewhere can still reach
+    the threshold), duplicates in the first file (collapse), an empty file, an unsorted file, streams without taxids and
+    the all-ones code must come out the same way through the fallback."""
+    O, L, ctx, tax, T = env
+
+    def both(files, taxs, thr=None):
+        thr = len(files) if thr is None else thr
+        res = []
+        for knob in (None, "0"):
+            if knob is None:
+                monkeypatch.delenv("UKM_COMMON_PROBE", raising=False)
+            else:
+                monkeypatch.setenv("UKM_COMMON_PROBE", knob)
+            res.append((ctx.common(files, thr, taxs), ctx.common(files, thr)))
+        monkeypatch.delenv("UKM_COMMON_PROBE", raising=False)
+        (gk, gt), g0 = res[0]
+        (gk2, gt2), g02 = res[1]
+        ok, ot = O.common(files, thr, taxs, tax)
+        assert np.array_equal(gk, ok) and np.array_equal(gt, ot), (len(gk), len(ok))
+        assert np.array_equal(gk2, ok) and np.array_equal(gt2, ot)
+        assert np.array_equal(g0, O.common(files, thr)) and np.array_equal(g02, g0)
+        return ok
+
+    for n_univ, nfiles, p, core in ((3_000, 40, 0.9, 0.2), (700_000, 12, 0.9, 0.3), (200, 9, 0.7, 0.3), (60_000, 130, 0.95, 0.1),
+                                    (5_000, 4, 0.5, 0.0)):
+        files, taxs = _chain_files(nfiles, n_univ, p, core, 71, T)
+        ok = both(files, taxs)
+        if core > 0:
+            assert len(ok) > 0
+        both(files, taxs, len(files) - 1)      # (another threshold: the counting merge)
+    files, taxs = _chain_files(24, 20_000, 0.9, 0.25, 73, T)
+    core = O.common(files, len(files))
+    # a later file holds a code twice that one other file lacks: the count still reaches the number of files
+    lacking = np.setdiff1d(np.intersect1d(files[0], files[5]), files[9])
+    lacking = lacking[np.isin(lacking, O.common([f for j, f in enumerate(files) if j != 9], len(files) - 1))][:3]
+    assert len(lacking) > 0
+    f2, t2 = list(files), list(taxs)
+    order = np.argsort(np.concatenate([f2[5], lacking]), kind="stable")
+    f2[5] = np.concatenate([files[5], lacking])[order]
+    t2[5] = np.concatenate([taxs[5], _taxids(lacking, T, 99)])[order]
+    ok = both(f2, t2)
+    assert np.isin(lacking, ok).all() and len(ok) == len(core) + len(lacking)
+    # duplicates in the FIRST file collapse to one count (the last taxid stays)
+    f2, t2 = list(files), list(taxs)
+    f2[0] = np.repeat(files[0], 2)
+    t2[0] = np.stack([taxs[0], _taxids(files[0], T, 98)], 1).reshape(-1)
+    both(f2, t2)
+    # an empty file: nothing reaches the count; an unsorted file: the map does not care
+    f2, t2 = list(files), list(taxs)
+    f2[3], t2[3] = np.zeros(0, np.uint64), np.zeros(0, np.uint32)
+    assert len(both(f2, t2)) == 0
+    f2, t2 = list(files), list(taxs)
+    perm = np.random.default_rng(5).permutation(len(f2[6]))
+    f2[6], t2[6] = f2[6][perm], t2[6][perm]
+    assert np.array_equal(both(f2, t2), core)
+    # the all-ones code everywhere / in later files only
+    ones = np.array([2**64 - 1], np.uint64)
+    f2 = [np.concatenate([f, ones]) for f in files]
+    t2 = [np.concatenate([t, np.array([7], np.uint32)]) for t in taxs]
+    assert len(both(f2, t2)) == len(core) + 1
+    both([files[0]] + f2[1:], [taxs[0]] + t2[1:])
+    # some streams without taxids (taken as 0: the LCA rule's absorbing value)
+    t2 = list(taxs)
+    t2[2] = None
+    gk, gt = ctx.common(files, len(files), t2)
+    t3 = list(taxs)
+    t3[2] = np.zeros(len(files[2]), np.uint32)
+    ok, ot = O.common(files, len(files), t3, tax)
+    assert np.array_equal(gk, ok) and np.array_equal(gt, ot)
+
+
+def test_long_runs_fold_taxids_by_the_wave():
+    """Runs of one code longer than eight records (merged chunk files, `common` over many files) have their taxids folded
+    by the whole wave through pre-order numbers instead of by the head's lane; the reference folds LCA(LCA(t0, t1), t2) ...
+    (sort.go:491, common.go:265).  Same answers as the oracle for run lengths around every boundary (1, 8, 9, 10, 63..66,
+    72, 73, 200, runs across tile boundaries, one run of 9000) and the awkward ids: a forest, merged ids, 0, unknown ids,
+    every record the same old / unknown id."""
+    from oracle import oracle as O
+    from unikmer_amd import lib as L
+    c = L.Context(0)
+    child, parent = [], []
+    child.append(100); parent.append(100)
+    for i in range(101, 160):
+        child.append(i); parent.append(i - 1)
+    for i in range(100, 160, 5):
+        child.append(1000 + i); parent.append(i)
+    for t in range(1, 122):
+        child.append(4999 + t); parent.append(4999 + (1 if t == 1 else (t - 2) // 3 + 1))
+    child += [9001, 9002]; parent += [9000, 9001]
+    child, parent = np.array(child, np.uint32), np.array(parent, np.uint32)
+    mo, mn = np.array([50, 51, 52], np.uint32), np.array([159, 5003, 77777], np.uint32)
+    c.taxonomy_load(child, parent, mo, mn)
+    tax = O.Taxonomy(child, parent, mo, mn)
+    rng = np.random.default_rng(23)
+    pool = np.concatenate([child, [0, 50, 51, 52, 9000, 400, 99999]]).astype(np.uint32)
+    lens = np.concatenate([rng.choice([1, 2, 8, 9, 10, 11, 63, 64, 65, 66, 72, 73, 74, 137, 200, 1000], 1500), [9000, 1, 5000]])
+    codes = np.cumsum(rng.integers(1, 1 << 30, len(lens)).astype(np.uint64))
+    keys = np.repeat(codes, lens)
+    theme = np.repeat(rng.integers(0, 5, len(lens)), lens)
+    fixed = np.repeat(rng.choice(pool, len(lens)), lens)
+    t = rng.choice(pool, len(keys))
+    t[theme == 0] = fixed[theme == 0]                                               # every record the same id
+    t[theme == 1] = rng.integers(100, 160, int((theme == 1).sum()))                 # one chain
+    t[theme == 2] = rng.integers(5000, 5121, int((theme == 2).sum()))               # one tree
+    late = (theme == 3) & (rng.random(len(keys)) < 0.98)                            # the same id but for a few records
+    t[late] = fixed[late]
+    t = t.astype(np.uint32)
+    for mode in (L.UNIQUE, L.REPEATED, L.SINGLETON, L.REPEATED_CHUNK):
+        gk, gt = c.unique(keys, t, mode)
+        ok, ot = O.unique(keys, t, mode, tax)
+        assert np.array_equal(gk, ok) and np.array_equal(gt, ot), mode
+    # the same sequence as a `common` over files: record i of a run goes to file i (every file strictly increasing)
+    rank = np.arange(len(keys)) - np.repeat(np.cumsum(lens) - lens, lens)
+    nfiles = 64
+    short = rank < nfiles  # (longer runs: their first 64 records)
+    files = [keys[short & (rank == f)] for f in range(nfiles)]
+    taxs = [t[short & (rank == f)] for f in range(nfiles)]
+    for thr in (1, 2, 9, 10, 11, 63, 64):
+        gk, gt = c.common(files, thr, taxs)
+        ok, ot = O.common(files, thr, taxs, tax)
+        assert len(ok) > 0 and np.array_equal(gk, ok) and np.array_equal(gt, ot), thr
+        assert np.array_equal(c.common(files, thr), O.common(files, thr))
     c.close()

@@ -173,7 +173,20 @@ def main():
         ms_d, rd = wall(lambda: ctx.diff(files2, taxs2, out=ok, out_taxids=ot), reps=max(1, args.reps - 1))
         n_diff = rd[0].numel()
         ms_dt, rdt = wall(lambda: ctx.diff(files2, taxs2, compare_taxid=True, out=ok, out_taxids=ot), reps=max(1, args.reps - 1))
+        # `common` of the same files with the default threshold (every file): the probe fold again; the counting merge
+        # (k-way keep-all merge + threshold scan) timed beside it
+        okc = torch.empty(total2 + 8, dtype=torch.int64, device=dev)
+        otc = torch.empty(total2 + 8, dtype=torch.int32, device=dev)
+        ms_c, rc = wall(lambda: ctx.common(files2, nfiles, taxs2, out=okc, out_taxids=otc), reps=max(1, args.reps - 1))
+        assert rc[0].numel() == n_inter
+        sums = (int(rc[0].sum()), int(rc[1].long().sum()))
+        os.environ["UKM_COMMON_PROBE"] = "0"
+        ms_cm, rcm = wall(lambda: ctx.common(files2, nfiles, taxs2, out=okc, out_taxids=otc), reps=1)
+        del os.environ["UKM_COMMON_PROBE"]
+        assert rcm[0].numel() == n_inter and sums == (int(rcm[0].sum()), int(rcm[1].long().sum()))
+        del okc, otc
         res["config4_core_inter_diff_%d_files_taxids" % nfiles] = {
+            "common_all_files_ms": ms_c, "common_all_files_counting_merge_ms": ms_cm,
             "inter_ms": ms_i, "inter_out": n_inter, "diff_ms": ms_d, "diff_out": n_diff,
             "diff_compare_taxid_ms": ms_dt, "diff_compare_taxid_out": rdt[0].numel(), "input_kmers": total2,
             "inter_kmers_per_s": total2 / ms_i * 1e3, "diff_kmers_per_s": total2 / ms_d * 1e3,

@@ -693,7 +693,17 @@ int ukm_dev_kway(ukm_ctx *c, int op, const u64 *const *keys, const u32 *const *t
     u64 R64 = (N / (u64)S) / 2048;
     R64 = std::min<u64>(R64, 4096);
     R64 = std::min<u64>(R64, ((u64)1 << 22) / ((u64)S + 1));
+    // A keep-everything merge moves all N records at EVERY level and the top level has one workgroup per range: with
+    // many short files the rule above leaves it 488 workgroups for 1e9 records (1000 files x 1e6: levels of 7, 7, 24
+    // and 54 ms; with 4096 ranges 8, 6, 7 and 12 ms).  A union's upper levels are small (the duplicates are gone) and
+    // its level 0 prefers the longer shares (24 against 34 ms on the same files).
+    if (!uni) R64 = std::max<u64>(R64, std::min<u64>(4096, N / 16384));
+    R64 = std::min<u64>(R64, ((u64)1 << 22) / ((u64)S + 1));
     if (R64 < 1) R64 = 1;
+    {
+        const char *e = getenv("UKM_KWAY_R");  // developer knob
+        if (e && atoll(e) > 0) R64 = std::min<u64>((u64)atoll(e), ((u64)1 << 22) / ((u64)S + 1));
+    }
     u64 D = 1, ns = 0;
     std::vector<u64> sample_base((size_t)S + 1, 0);
     if (R64 > 1) {

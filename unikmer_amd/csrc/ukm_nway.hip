@@ -610,6 +610,11 @@ extern "C" uint32_t ukm_common_threshold(uint32_t nfiles, double proportion, uin
     return (uint32_t)(uint16_t)number;
 }
 
+static bool common_probe_enabled() {
+    const char *e = getenv("UKM_COMMON_PROBE");  // developer knob: 0 = `common` always by the counting merge
+    return !(e && e[0] == '0');
+}
+
 extern "C" int ukm_common(ukm_ctx *ctx, const uint64_t *const *keys, const uint32_t *const *taxids,
                           const uint64_t *lens, int nstreams, uint32_t threshold, uint32_t flags,
                           uint64_t *out_keys, uint32_t *out_taxids, uint64_t out_cap, uint64_t *n_out) {
@@ -621,6 +626,33 @@ extern "C" int ukm_common(ukm_ctx *ctx, const uint64_t *const *keys, const uint3
         if (nstreams == 0) return UKM_OK;
         std::vector<Stream> ss;
         UKM_TRY(stage_streams(ctx, keys, taxids, lens, nstreams, tax, ss));
+        // threshold = number of files (the default `-p 1`) over duplicate-free sorted files: a code reaches the count
+        // only by being in every file, and its taxid is the same left fold of LCAs as `inter`'s (common.go:262-266 /
+        // inter.go:252-262) -> the hash-probe fold of ukm_pfold.hip answers in one pass over the files.  It checks the
+        // strict order of every file on the way; a duplicate, an unsorted or an empty file, an all-ones code in the
+        // first file or an unsuitable shape leave the call to the counting merge below.
+        if (threshold == (u32)nstreams && nstreams >= CHAIN_MIN_STREAMS && ukm_pfold_enabled() && common_probe_enabled()) {
+            bool eligible = ss[0].n <= FOLD_MAX_FIRST;
+            for (auto &q : ss) eligible = eligible && q.n > 0 && (!tax || q.t != nullptr);
+            if (eligible) {
+                std::vector<const u64 *> kp(ss.size());
+                std::vector<const u32 *> tp(ss.size());
+                std::vector<u64> ln(ss.size());
+                for (size_t i = 0; i < ss.size(); i++) {
+                    kp[i] = ss[i].k;
+                    tp[i] = ss[i].t;
+                    ln[i] = ss[i].n;
+                }
+                WsMark pm = ws_mark(ctx);
+                bool fb = true;
+                const int prc = ukm_dev_probe_fold(ctx, UKM_OP_INTER, kp.data(), tax ? tp.data() : nullptr, ln.data(), nstreams, tax, 0,
+                                                   o.k, o.t, out_cap, n_out, &fb);
+                ws_release(ctx, pm);
+                UKM_TRY(prc);
+                if (!fb) return UKM_OK;
+                *n_out = 0;
+            }
+        }
         // first file: every code counts once (common.go:232,244) -> collapse duplicates, last wins
         if (ss[0].n) {
             bool sorted = true, strict = true;

@@ -57,6 +57,8 @@ struct UniqArgs {
 // TICKET: tile ids from an atomic counter (always live) instead of blockIdx (no single-address atomic in front
 // of every tile, but look-back liveness then relies on in-order dispatch: watchdog -> flag 4 -> the host re-runs
 // the ticketed instantiation, see ukm_setops.hip).
+constexpr int UNIQ_OWN = 8;  // records of a run its head's lane folds itself before the wave takes over
+
 template <bool TAX, bool CHUNK, int VTU, bool TICKET>
 __global__ __launch_bounds__(UNT) void unique_tile_kernel(UniqArgs p) {
     constexpr int TILE_U = UNT * VTU;
@@ -115,23 +117,68 @@ __global__ __launch_bounds__(UNT) void unique_tile_kernel(UniqArgs p) {
         else if (mode == UKM_REPEATED_CHUNK) { e1 = head; e2 = head && repeated; }
         else if (mode == UKM_UNIQUE_LAST) e1 = tail;
         u32 t = 0;
-        if (mode == UKM_COMMON) {
-            if (head) {  // run length against the threshold (common.go:331-335), LCA over the run
-                u64 len = 1;
-                for (u64 q = gi + 1; q < p.n && p.k[q] == k && (TAX || len < p.threshold); q++) len++;
-                e1 = len >= p.threshold;
-                if (TAX && e1) {
-                    t = p.t[gi];
-                    for (u64 q = gi + 1; q < gi + len; q++) t = lca_dev(p.tax, t, p.t[q]);  // common.go:265
-                }
-            }
-        } else if (TAX) {
+        if (mode == UKM_COMMON && head) {
+            // run length against the threshold (common.go:331-335): in a sorted sequence the run has `threshold` records
+            // iff the record threshold - 1 places on carries the same code — one probe, whatever the run length
+            const u64 need = p.threshold > 1 ? (u64)p.threshold - 1 : 0;
+            e1 = need == 0 || (gi + need < p.n && p.k[gi + need] == k);
+        }
+        if (TAX) {
+            // LCA over the run of an emitted record (common.go:265, sort.go:491).  The lane folds up to UNIQ_OWN records
+            // itself; what a longer run has behind them (a merge of n files: runs of up to n records) is folded by the
+            // whole wave, 64 records per step, through the pre-order numbers (ukm_internal.h: TaxDev::euler): the
+            // sequential fold of lca_dev over a set is its first member when all are equal, 0 when they differ and one is
+            // unknown, else the LCA of the members with the smallest and the largest number.
+            bool more = false;
+            u64 qn = 0;
             if (mode == UKM_UNIQUE_LAST) {
                 if (e1) t = p.t[gi];
             } else if (e1) {
                 t = p.t[gi];
-                if (repeated)
-                    for (u64 q = gi + 1; q < p.n && p.k[q] == k; q++) t = lca_dev(p.tax, p.t[q], t);  // sort.go:491
+                if (mode == UKM_COMMON || repeated) {
+                    const int own_max = p.tax.euler ? UNIQ_OWN : 0x7FFFFFFF;
+                    u64 q = gi + 1;
+                    int own = 0;
+                    for (; own < own_max && q < p.n && p.k[q] == k; q++, own++) t = lca_dev(p.tax, p.t[q], t);
+                    more = own == own_max && q < p.n && p.k[q] == k;
+                    qn = q;
+                }
+            }
+            for (u64 m = __ballot(more); m != 0ull; m &= m - 1ull) {
+                const int lead = __ffsll((long long)m) - 1;
+                const u64 k0 = ((u64)(u32)__shfl((int)(k >> 32), lead, 64) << 32) | (u32)__shfl((int)(u32)k, lead, 64);
+                u64 q0 = ((u64)(u32)__shfl((int)(qn >> 32), lead, 64) << 32) | (u32)__shfl((int)(u32)qn, lead, 64);
+                const u32 t0 = (u32)__shfl((int)t, lead, 64);
+                const u32 e0 = t0 < p.tax.size ? p.tax.euler[t0] : 0u;
+                u32 mn = 0xFFFFFFFFu, mx = 0u, fl = 0u;  // fl: 1 = a taxid differs from t0, 2 = one of those is unknown
+                for (;;) {
+                    const u64 pos = q0 + (u64)lane;
+                    const u64 pc = pos < p.n ? pos : p.n - 1;
+                    const u64 kk = p.k[pc];
+                    const u32 tt = p.t[pc];
+                    const bool match = pos < p.n && kk == k0;
+                    if (match && tt != t0) {
+                        const u32 e = tt < p.tax.size ? p.tax.euler[tt] : 0u;
+                        fl |= e ? 1u : 3u;
+                        if (e) {
+                            mn = e < mn ? e : mn;
+                            mx = e > mx ? e : mx;
+                        }
+                    }
+                    if (__ballot(match) != ~0ull) break;
+                    q0 += 64;
+                }
+#pragma unroll
+                for (int d = 32; d >= 1; d >>= 1) {
+                    const u32 omn = (u32)__shfl_xor((int)mn, d, 64), omx = (u32)__shfl_xor((int)mx, d, 64);
+                    mn = omn < mn ? omn : mn;
+                    mx = omx > mx ? omx : mx;
+                    fl |= (u32)__shfl_xor((int)fl, d, 64);
+                }
+                if (lane == lead && (fl & 1u)) {
+                    if ((fl & 2u) || !e0) t = 0;
+                    else t = lca_dev(p.tax, p.tax.node_at[e0 < mn ? e0 : mn], p.tax.node_at[e0 > mx ? e0 : mx]);
+                }
             }
         }
         if (TAX) tx[s] = t;
