@@ -58,6 +58,7 @@ struct UniqArgs {
 // of every tile, but look-back liveness then relies on in-order dispatch: watchdog -> flag 4 -> the host re-runs
 // the ticketed instantiation, see ukm_setops.hip).
 constexpr int UNIQ_OWN = 8;  // records of a run its head's lane folds itself before the wave takes over
+constexpr int UNIQ_FEW = 4;  // ... one head at a time, when at most this many lanes of the wave ask for it
 
 template <bool TAX, bool CHUNK, int VTU, bool TICKET>
 __global__ __launch_bounds__(UNT) void unique_tile_kernel(UniqArgs p) {
@@ -142,6 +143,16 @@ __global__ __launch_bounds__(UNT) void unique_tile_kernel(UniqArgs p) {
                     for (; own < own_max && q < p.n && p.k[q] == k; q++, own++) t = lca_dev(p.tax, p.t[q], t);
                     more = own == own_max && q < p.n && p.k[q] == k;
                     qn = q;
+                }
+            }
+            if (__popcll(__ballot(more)) > UNIQ_FEW) {
+                // many heads of this wave want more: runs of a few dozen records one after the other (chunk files of the
+                // same genomes).  The wave-wide fold takes them one at a time; their lanes walking on side by side is
+                // cheaper up to a wave's width of records.
+                if (more) {
+                    int own = UNIQ_OWN;
+                    for (; own < 64 && qn < p.n && p.k[qn] == k; qn++, own++) t = lca_dev(p.tax, p.t[qn], t);
+                    more = own == 64 && qn < p.n && p.k[qn] == k;
                 }
             }
             for (u64 m = __ballot(more); m != 0ull; m &= m - 1ull) {
