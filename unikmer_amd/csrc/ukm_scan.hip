@@ -137,12 +137,32 @@ __global__ __launch_bounds__(UNT) void unique_tile_kernel(UniqArgs p) {
             } else if (e1) {
                 t = p.t[gi];
                 if (mode == UKM_COMMON || repeated) {
-                    const int own_max = p.tax.euler ? UNIQ_OWN : 0x7FFFFFFF;
-                    u64 q = gi + 1;
-                    int own = 0;
-                    for (; own < own_max && q < p.n && p.k[q] == k; q++, own++) t = lca_dev(p.tax, p.t[q], t);
-                    more = own == own_max && q < p.n && p.k[q] == k;
-                    qn = q;
+                    if (p.tax.euler) {
+                        // the codes behind the head come from the staged tile (global memory behind its end), their
+                        // taxids are fetched together: one round trip + one per LCA instead of three per record
+                        int own = 0;
+                        bool open = true;
+#pragma unroll
+                        for (int i = 0; i <= UNIQ_OWN; i++) {
+                            const u64 q = gi + 1 + (u64)i;
+                            u64 kq = ~k;
+                            if (j + 1 + i < cnt_t) kq = s_keys[j + 2 + i];
+                            else if (q < p.n) kq = p.k[q];
+                            open = open && kq == k;
+                            if (i < UNIQ_OWN) own += open ? 1 : 0;
+                            else more = open;
+                        }
+                        u32 tq[UNIQ_OWN];
+#pragma unroll
+                        for (int i = 0; i < UNIQ_OWN; i++) tq[i] = p.t[gi + (u64)(i < own ? 1 + i : 0)];
+#pragma unroll
+                        for (int i = 0; i < UNIQ_OWN; i++)
+                            if (i < own) t = lca_dev(p.tax, tq[i], t);
+                        qn = gi + 1 + (u64)own;
+                    } else {
+                        u64 q = gi + 1;
+                        for (; q < p.n && p.k[q] == k; q++) t = lca_dev(p.tax, p.t[q], t);
+                    }
                 }
             }
             if (__popcll(__ballot(more)) > UNIQ_FEW) {
