@@ -29,6 +29,10 @@ constexpr int NT = 256;   // exclusive-scan kernel
 #endif
 constexpr int UNT = UNIQ_NT;  // unique kernel: threads per workgroup
 constexpr int UVT = UNIQ_VT;  // records per thread (half of it for the chunk protocol)
+#ifndef UNIQ_VT_TAX
+#define UNIQ_VT_TAX 12
+#endif
+constexpr int UVT_TAX = UNIQ_VT_TAX;  // with taxids: 12 B per staged record, 80 KB of LDS -> two workgroups per CU instead of one
 
 struct UniqArgs {
     const u64 *k;
@@ -423,7 +427,8 @@ int ukm_dev_unique_ex(ukm_ctx *c, const u64 *keys, const u32 *taxids, u64 n, int
     p.k = keys; p.t = taxids; p.n = n;
     p.out = out; p.tout = tout; p.out_cap = out_cap;
     const bool chunk = mode == UKM_REPEATED_CHUNK;
-    const u64 tile_items = (u64)UNT * (chunk ? UVT / 2 : UVT);
+    const int vt = tax ? UVT_TAX : UVT;
+    const u64 tile_items = (u64)UNT * (chunk ? vt / 2 : vt);
     p.ntiles = (n + tile_items - 1) / tile_items;
     p.tax = ukm_taxdev(c);
     p.mode = mode;
@@ -444,18 +449,18 @@ int ukm_dev_unique_ex(ukm_ctx *c, const u64 *keys, const u32 *taxids, u64 n, int
         if (attempt == 1) UKM_HIP(hipMemsetAsync(ctl, 0, nctl * sizeof(u64), c->stream));
         if (attempt == 0) {
             if (chunk) {
-                if (tax) hipLaunchKernelGGL((unique_tile_kernel<true, true, UVT / 2, false>), grid, block, 0, c->stream, p);
+                if (tax) hipLaunchKernelGGL((unique_tile_kernel<true, true, UVT_TAX / 2, false>), grid, block, 0, c->stream, p);
                 else hipLaunchKernelGGL((unique_tile_kernel<false, true, UVT / 2, false>), grid, block, 0, c->stream, p);
             } else {
-                if (tax) hipLaunchKernelGGL((unique_tile_kernel<true, false, UVT, false>), grid, block, 0, c->stream, p);
+                if (tax) hipLaunchKernelGGL((unique_tile_kernel<true, false, UVT_TAX, false>), grid, block, 0, c->stream, p);
                 else hipLaunchKernelGGL((unique_tile_kernel<false, false, UVT, false>), grid, block, 0, c->stream, p);
             }
         } else {
             if (chunk) {
-                if (tax) hipLaunchKernelGGL((unique_tile_kernel<true, true, UVT / 2, true>), grid, block, 0, c->stream, p);
+                if (tax) hipLaunchKernelGGL((unique_tile_kernel<true, true, UVT_TAX / 2, true>), grid, block, 0, c->stream, p);
                 else hipLaunchKernelGGL((unique_tile_kernel<false, true, UVT / 2, true>), grid, block, 0, c->stream, p);
             } else {
-                if (tax) hipLaunchKernelGGL((unique_tile_kernel<true, false, UVT, true>), grid, block, 0, c->stream, p);
+                if (tax) hipLaunchKernelGGL((unique_tile_kernel<true, false, UVT_TAX, true>), grid, block, 0, c->stream, p);
                 else hipLaunchKernelGGL((unique_tile_kernel<false, false, UVT, true>), grid, block, 0, c->stream, p);
             }
         }
