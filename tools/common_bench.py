@@ -12,11 +12,12 @@ tax = len(sys.argv) > 3 and sys.argv[3] == "tax"
 sys.path.insert(0, os.path.join(os.getcwd(), "tests"))
 from conftest import synth_tree
 child, parent = synth_tree(7, 8); ctx.taxonomy_load(child, parent); T = len(child)
-nu = int(per / 0.9)
+P = float(os.environ.get("CB_P", "0.9"))   # share of the universe a file holds (overlap between files)
+nu = int(per / P)
 j = torch.arange(nu, dtype=torch.int64, device=dev)
 gaps = 1 + (bench.splitmix64_torch(j ^ bench._i64(bench.SEED)) & ((1 << 32) - 1))
 U = torch.cumsum(gaps, 0)
-thr = int(0.9 * (1 << 20))
+thr = int(P * (1 << 20))
 files, taxs = [], []
 for f in range(nfiles):
     h = bench.splitmix64_torch(j ^ bench._i64(bench.SEED + 1000 * (f + 1)))

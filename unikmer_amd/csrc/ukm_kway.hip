@@ -693,11 +693,17 @@ int ukm_dev_kway(ukm_ctx *c, int op, const u64 *const *keys, const u32 *const *t
     u64 R64 = (N / (u64)S) / 2048;
     R64 = std::min<u64>(R64, 4096);
     R64 = std::min<u64>(R64, ((u64)1 << 22) / ((u64)S + 1));
-    // A keep-everything merge moves all N records at EVERY level and the top level has one workgroup per range: with
-    // many short files the rule above leaves it 488 workgroups for 1e9 records (1000 files x 1e6: levels of 7, 7, 24
-    // and 54 ms; with 4096 ranges 8, 6, 7 and 12 ms).  A union's upper levels are small (the duplicates are gone) and
-    // its level 0 prefers the longer shares (24 against 34 ms on the same files).
-    if (!uni) R64 = std::max<u64>(R64, std::min<u64>(4096, N / 16384));
+    // The top level has one workgroup per range, and a level moves whatever is left of the N records: with many short
+    // files the rule above leaves the upper levels too few workgroups (1000 files x 1e6: 488 ranges; a keep-everything
+    // merge with taxids ran levels of 7, 7, 24 and 54 ms, with 4096 ranges 8, 6, 7 and 12 ms; a union of files that
+    // hardly overlap 61 ms against 24, with taxids 149 against 52).  Only a union WITH taxids of files that overlap
+    // heavily prefers the longer shares of the old rule (its upper levels are small, its level 0 slows from 24 to 34 ms
+    // at 4096 ranges): whether files overlap is not known here, so it takes 2048 (33 / 63 ms in the two cases).
+    {
+        u64 want = std::min<u64>((uni && tax) ? 2048 : 4096, N / 16384);
+        if (uni) want = std::min<u64>(want, (N / (u64)S) / 64);  // (a union's level 0 wants a child's share >= 64 records)
+        R64 = std::max<u64>(R64, want);
+    }
     R64 = std::min<u64>(R64, ((u64)1 << 22) / ((u64)S + 1));
     if (R64 < 1) R64 = 1;
     {
