@@ -631,6 +631,11 @@ int ukm_kway_fanin() {  // 0 = automatic
     return k;
 }
 
+static bool kw_top2_enabled() {
+    static const bool on = !(getenv("UKM_KWAY_TOP2") && getenv("UKM_KWAY_TOP2")[0] == '0');  // developer knob
+    return on;
+}
+
 bool ukm_kway_enabled() {
     static int on = -1;
     if (on < 0) {
@@ -787,6 +792,26 @@ int ukm_dev_kway(ukm_ctx *c, int op, const u64 *const *keys, const u32 *const *t
         } else {
             ok = tk[lv & 1];
             ot = tt[lv & 1];
+        }
+        if (final_lv && !uni && nprev == 2 && lv > 0 && N >= (1u << 20) && kw_top2_enabled()) {
+            // A keep-everything merge leaves every node's output as ONE sorted array (slot = rank among the node's
+            // leaves), so a top level of two children is a plain 2-way merge: the merge-path tile kernel of
+            // ukm_setops.hip (every record kept, the first child's copies of a code first = stream order) runs it at
+            // ≈ 4.5 TB/s where one streaming workgroup per range manages 2 (1000 files x 1e6 with taxids: 12 -> 6 ms).
+            u64 fl = 0;
+            UKM_TRY(ukm_read_u64(c, ctl + 1, &fl));
+            if (fl & (KW_FLAG_UNSORTED | KW_FLAG_DEGENERATE)) {
+                if (dbg) for (auto &m : marks) (void)hipEventDestroy(m.second);
+                *fallback = true;
+                return UKM_OK;
+            }
+            u64 nA = 0;
+            for (u64 j = 0; j < span && j < (u64)S; j++) nA += lens[(size_t)j];
+            u64 nm = 0;
+            UKM_TRY(ukm_dev_setop2(c, UKM_OP_MERGE_INTERNAL, in_k, tax ? in_t : nullptr, nA, in_k + nA, tax ? in_t + nA : nullptr,
+                                   N - nA, 0, out, tax ? tout : nullptr, out_cap, &nm));
+            mark("top-2way");
+            break;
         }
         u64 *cnt = nullptr;
         UKM_TRY(ws_alloc_t(c, (size_t)nodes * R, &cnt));
