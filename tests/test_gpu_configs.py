@@ -605,3 +605,33 @@ def test_long_runs_fold_taxids_by_the_wave():
         assert len(ok) > 0 and np.array_equal(gk, ok) and np.array_equal(gt, ot), thr
         assert np.array_equal(c.common(files, thr), O.common(files, thr))
     c.close()
+
+
+def test_merge_top_level_of_two_children_through_the_tile_kernel(env, monkeypatch):
+    """A keep-everything merge of >= 2^20 records whose last level has two children (9..16 and 65..128 streams at fan-in 8)
+    runs that level as a 2-way merge through the set-op tile kernel: the result is still the stable sort of the
+    concatenation (util-sort.go:196-225: equal codes in stream order), with duplicates inside the streams, for plain keys
+    and with taxids, and the same as with the k-way kernel at the top (UKM_KWAY_TOP2=0)."""
+    O, L, ctx, tax, T = env
+    rng = np.random.default_rng(41)
+    for nstreams, per in ((12, 110_000), (100, 14_000), (9, 150_000)):
+        streams = [np.sort(rng.integers(0, 1 << 22, per + 977 * i).astype(np.uint64)) for i in range(nstreams)]   # many ties
+        taxs = [_taxids(s + np.uint64(i), T, i) for i, s in enumerate(streams)]
+        cat, tcat = np.concatenate(streams), np.concatenate(taxs)
+        assert len(cat) >= 1 << 20
+        o = np.argsort(cat, kind="stable")
+        for knob in (None, "0"):
+            if knob is None:
+                monkeypatch.delenv("UKM_KWAY_TOP2", raising=False)
+            else:
+                monkeypatch.setenv("UKM_KWAY_TOP2", knob)
+            gk, gt = ctx.merge_k(streams, taxs, mode=L.PLAIN)
+            assert np.array_equal(gk, cat[o]) and np.array_equal(gt, tcat[o]), (nstreams, knob)
+            assert np.array_equal(ctx.merge_k(streams, mode=L.PLAIN), cat[o])
+            gk, gt = ctx.merge_k(streams, taxs, mode=L.REPEATED)
+            ok, ot = O.merge_k(streams, taxs, mode=O.REPEATED, tax=tax)
+            assert np.array_equal(gk, ok) and np.array_equal(gt, ot), (nstreams, knob)
+        monkeypatch.delenv("UKM_KWAY_TOP2", raising=False)
+    # an unsorted stream: the call still answers (concatenate + sort route)
+    streams[3] = streams[3][::-1].copy()
+    assert np.array_equal(ctx.merge_k(streams, mode=L.PLAIN), np.sort(np.concatenate(streams)))
