@@ -61,7 +61,10 @@ struct UniqArgs {
 // TICKET: tile ids from an atomic counter (always live) instead of blockIdx (no single-address atomic in front
 // of every tile, but look-back liveness then relies on in-order dispatch: watchdog -> flag 4 -> the host re-runs
 // the ticketed instantiation, see ukm_setops.hip).
-constexpr int UNIQ_OWN = 8;  // records of a run its head's lane folds itself before the wave takes over
+#ifndef UNIQ_OWN_N
+#define UNIQ_OWN_N 8
+#endif
+constexpr int UNIQ_OWN = UNIQ_OWN_N;  // records of a run its head's lane folds itself before the wave takes over
 constexpr int UNIQ_FEW = 4;  // ... one head at a time, when at most this many lanes of the wave ask for it
 
 template <bool TAX, bool CHUNK, int VTU, bool TICKET>
