@@ -7,8 +7,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 SO = os.path.join(HERE, "libunikmer_hip.so")
 SOURCES = ["ukm_ctx.hip", "ukm_setops.hip", "ukm_scan.hip", "ukm_sort.hip", "ukm_encode.hip",
-           "ukm_tax.hip", "ukm_nway.hip", "ukm_kway.hip", "ukm_comm.hip", "ukm_fold.hip", "ukm_punion.hip", "ukm_pfold.hip"]
-HEADERS = ["ukm_internal.h", "ukm_device.h", "ukm_kway.h", "ukm_fold.h", "ukm_punion.h", "ukm_pfold.h", os.path.join("..", "..", "include", "unikmer_hip.h")]
+           "ukm_tax.hip", "ukm_nway.hip", "ukm_kway.hip", "ukm_comm.hip", "ukm_fold.hip", "ukm_punion.hip", "ukm_pfold.hip", "ukm_srmerge.hip"]
+HEADERS = ["ukm_internal.h", "ukm_device.h", "ukm_kway.h", "ukm_fold.h", "ukm_punion.h", "ukm_pfold.h", "ukm_srmerge.h", os.path.join("..", "..", "include", "unikmer_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 
 

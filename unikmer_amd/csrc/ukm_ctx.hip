@@ -338,6 +338,8 @@ extern "C" int ukm_last_call_ms(ukm_ctx *c, float *ms) {
     return UKM_OK;
 }
 
+extern "C" int ukm_last_route(ukm_ctx *c) { return c ? c->last_route : 0; }
+
 extern "C" int ukm_last_kernel_ms(ukm_ctx *c, float *ms) {
     if (!c || !ms) UKM_FAIL(UKM_ERR_INVALID, "ukm_last_kernel_ms: NULL argument");
     if (!c->evk_valid) return ukm_last_call_ms(c, ms);

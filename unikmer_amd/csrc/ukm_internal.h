@@ -81,6 +81,7 @@ struct ukm_ctx {
     void *comm = nullptr;
     int comm_size = 0, comm_rank = 0;
     int depth = 0;  // nesting depth of API calls (n-way ops call 2-way ops)
+    int last_route = 0;  // ukm_last_route(): which n-way route answered last
 
     std::vector<WsBlock> blocks;
     size_t ws_high = 0;  // high-water mark of one top-level call, for consolidation

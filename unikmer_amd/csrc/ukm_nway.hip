@@ -20,6 +20,7 @@
 #include "ukm_kway.h"
 #include "ukm_punion.h"
 #include "ukm_pfold.h"
+#include "ukm_srmerge.h"
 
 namespace {
 
@@ -143,6 +144,7 @@ int run_entry(ukm_ctx *ctx, uint64_t *out_keys, uint32_t *out_taxids, uint64_t o
         if (tax && !out_taxids) UKM_FAIL(UKM_ERR_INVALID, "records carry taxids but out_taxids is NULL");
         if (tax) UKM_TRY(ukm_out_t(ctx, out_taxids, out_cap, &o.t));
         *n_out = 0;
+        ctx->last_route = 0;
         int r = body(o);
         u64 n = (r == UKM_OK) ? *n_out : 0;
         ukm_out_resize(ctx, out_keys, n * sizeof(u64));
@@ -163,6 +165,7 @@ int tree_reduce(ukm_ctx *ctx, std::vector<Stream> ss, int op, u32 flags, bool ta
                 bool lazy_normalise = false) {
     u64 total = 0;
     for (auto &s : ss) total += s.n;
+    ctx->last_route = ss.size() > 2 ? 1 : 0;
     std::vector<char> orig(ss.size(), lazy_normalise ? 1 : 0);
     u64 *bk[2] = {nullptr, nullptr};
     u32 *bt[2] = {nullptr, nullptr};
@@ -242,12 +245,28 @@ int try_kway(ukm_ctx *ctx, int op, const std::vector<Stream> &ss, bool tax, u64 
         ln[i] = ss[i].n;
     }
     WsMark mark = ws_mark(ctx);
-    bool fallback = false;
+    bool fallback = true;
+    {
+        // many short streams: one pass over HBM, every value range ordered inside LDS (ukm_srmerge.hip); it declines
+        // (*fallback) for few streams, small inputs, unsorted streams and one code with thousands of copies
+        const int src = ukm_dev_srmerge(ctx, op, kp.data(), tax ? tp.data() : nullptr, ln.data(), (int)ss.size(), tax, fk, ft, fcap,
+                                        n_out, &fallback);
+        if (src != UKM_OK || !fallback) {
+            ws_release(ctx, mark);
+            UKM_TRY(src);
+            ctx->last_route = 4;
+            *done = true;
+            return UKM_OK;
+        }
+        ws_release(ctx, mark);
+    }
+    fallback = false;
     const int rc = ukm_dev_kway(ctx, op, kp.data(), tax ? tp.data() : nullptr, ln.data(), (int)ss.size(), tax, fk, ft, fcap,
                                 n_out, &fallback);
     ws_release(ctx, mark);
     UKM_TRY(rc);
     *done = !fallback;
+    if (*done) ctx->last_route = 2;
     return UKM_OK;
 }
 
@@ -279,13 +298,17 @@ int try_probe_union(ukm_ctx *ctx, const std::vector<Stream> &ss, bool tax, u64 *
     ws_release(ctx, mark);
     UKM_TRY(rc);
     *done = !fallback;
+    if (*done) ctx->last_route = 3;
     return UKM_OK;
 }
 
 // All records of the (non-empty) streams as ONE sequence ordered by code, equal codes in stream
 // order (= a stable sort of the concatenation).  Sorted streams (chunk files, .unik sets) go through
 // the keep-everything merge tree; anything else is concatenated and radix sorted.
-int merged_sequence(ukm_ctx *ctx, const std::vector<Stream> &all, bool tax, u64 **k, u32 **t, u64 *total) {
+// (dk, dt): optional destination with room for every record (a PLAIN merge writes the caller's buffer directly instead
+// of a workspace copy that is copied once more: 12 GB less traffic for 1e9 records with taxids)
+int merged_sequence(ukm_ctx *ctx, const std::vector<Stream> &all, bool tax, u64 **k, u32 **t, u64 *total, u64 *dk = nullptr,
+                    u32 *dt = nullptr) {
     std::vector<Stream> ss;
     u64 n = 0;
     for (auto &s : all)
@@ -301,8 +324,13 @@ int merged_sequence(ukm_ctx *ctx, const std::vector<Stream> &all, bool tax, u64 
     if (ss.size() > 1) {
         // optimistic: the merges check the order of what they read; an unsorted stream makes the tree fail
         // with UKM_ERR_UNSORTED and the whole input takes the concatenate + sort route instead
-        UKM_TRY(ws_alloc_t(ctx, n + 1, k));
-        if (tax) UKM_TRY(ws_alloc_t(ctx, n + 1, t));
+        if (dk && (!tax || dt)) {
+            *k = dk;
+            *t = tax ? dt : nullptr;
+        } else {
+            UKM_TRY(ws_alloc_t(ctx, n + 1, k));
+            if (tax) UKM_TRY(ws_alloc_t(ctx, n + 1, t));
+        }
         u64 nm = 0;
         bool done = false;
         UKM_TRY(try_kway(ctx, UKM_KWAY_MERGE, ss, tax, *k, *t, n, &nm, &done));
@@ -704,9 +732,15 @@ extern "C" int ukm_merge_k(ukm_ctx *ctx, const uint64_t *const *keys, const uint
         if (mode == UKM_REPEATED && !final_round) m = UKM_REPEATED_CHUNK;
         u64 *k = nullptr;
         u32 *t = nullptr;
-        u64 total = 0;
-        UKM_TRY(merged_sequence(ctx, all, tax, &k, &t, &total));
+        u64 total = 0, need = 0;
+        for (auto &s : all) need += s.n;
+        const bool direct = m == UKM_PLAIN && need <= out_cap;  // every record kept: merge straight into the caller's buffer
+        UKM_TRY(merged_sequence(ctx, all, tax, &k, &t, &total, direct ? o.k : nullptr, direct ? o.t : nullptr));
         if (total == 0) return UKM_OK;
+        if (direct && k == o.k) {
+            *n_out = total;
+            return UKM_OK;
+        }
         return ukm_dev_unique(ctx, k, t, total, m, o.k, o.t, out_cap, n_out);
     });
 }

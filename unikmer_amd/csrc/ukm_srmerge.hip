@@ -1,0 +1,980 @@
+// ukm_srmerge.hip — merge / union of MANY sorted streams (hundreds to a thousand files) in ONE pass over HBM: the
+// MI355X replacement for container/heap's pop/push per k-mer in mergeChunksFile (util-sort.go:196-225, 227-606) and for
+// the per-k-mer map probes of an n-file `union` (union.go:186-208) when the files are many and short.
+//
+// Why: the streaming k-way kernel of ukm_kway.hip merges 8 streams per level, so 1000 files take four levels and every
+// record crosses HBM four times (1000 x 1e6 records with taxids: 33 ms for 24 GB of algorithmic traffic).  Its fan-in is
+// bound by LDS (a chunk of every child must be resident), not by anything in the data.  With ~1000 streams a value range
+// of a few thousand records holds only a handful of records of each stream, so here the roles are swapped:
+//
+//   * the CODE SPACE is cut into R = N / ~3900 value ranges by splitters from a regular sample of all streams; a range's
+//     records (~4 per stream for 1000 streams) fit ONE LDS tile;
+//   * `sr_cuts_kernel` finds every stream's slice of every range while it streams each input once, coalesced: a tile of
+//     2048 consecutive records of one stream sits in LDS and every splitter that falls into the tile's value span is
+//     looked up there (an S x R table of u32 cut points; 1 GB for 1000 files x 1e6 records).  The strict / non-strict
+//     order of every stream is checked on the way, so the merge pass does no checking at all;
+//   * `sr_merge_kernel`, one workgroup per range: every thread owns two streams (cut points, base pointers and cursors in
+//     registers; the output position of the range is the sum of its cut points over the streams — no look-back, no scan),
+//     copies their slices into the LDS tile in STREAM ORDER, then orders its VT consecutive tile positions by a stable
+//     rank count (branch-free), and
+//     log2(threads) rounds of pairwise merge-path merges inside LDS (A before B on ties) finish a stable merge sort of
+//     the tile: equal codes stay in stream order, which is the order a stable k-way merge gives.  MERGE writes the tile
+//     to its final place; UNION folds every run (TaxId: the left fold of LCAs over a run is its first member when all
+//     are equal, 0 when they differ and one has no pre-order number, else the LCA of the members with the smallest and
+//     the largest pre-order number: two LDS atomics per record of a run, one table LCA per run) and writes the heads to
+//     the range's slot, gathered afterwards by one copy kernel.
+//   A range whose slices do not fit the tile (sampling is approximate; one code may be in every file) is worked off in
+//   several passes by value: a code v with half a tile to a tile of records below it is found by interpolation between
+//   the range's ends (bisection if that does not converge; every probe is one lower bound per stream inside its slice
+//   and a block sum), and the pass takes the records below v; a single code with more copies than the tile holds sends
+//   the call back to the multi-level merge.
+//   Algorithmic bytes: 8 (+4) per input record read + the same per output record written; on top the cut pass reads
+//   the keys once more (8 B per record) and the tables cost 8 B per (stream, range).
+// Integer, HBM / LDS bound; no MFMA.
+#include <stdlib.h>
+
+#include <algorithm>
+#include <vector>
+
+#include "ukm_device.h"
+#include "ukm_srmerge.h"
+
+namespace {
+
+constexpr u64 SR_MAX = ~0ull;
+enum { SR_FLAG_UNSORTED = 2, SR_FLAG_DEGENERATE = 8 };
+enum { SR_NEQ = 1, SR_BAD = 2 };
+
+constexpr int SR_MAX_STREAMS = 1024;  // two streams per thread, their cursors in registers
+constexpr int SR_SAMPLES_PER_RANGE = 128;
+
+// ---- sample: every D-th record of every stream ---------------------------------------------------------------------
+__global__ void sr_sample_kernel(const u64 *const *leaf_keys, const u64 *sample_base, u32 S, u64 D, u64 ns, u64 *samples) {
+    const u64 g = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= ns) return;
+    u32 lo = 0, hi = S;  // last j with sample_base[j] <= g
+    while (hi - lo > 1) {
+        const u32 mid = (lo + hi) >> 1;
+        if (sample_base[mid] <= g) lo = mid; else hi = mid;
+    }
+    const u64 i = g - sample_base[lo];
+    // every stream samples at its own phase: files that are subsets of one collection walk through the code space in
+    // step, and samples taken at the same indices of every file would arrive in clusters
+    const u64 phase = ((u64)lo * 0x9E3779B97F4A7C15ull >> 33) % D;
+    samples[g] = leaf_keys[lo][(i + 1) * D - 1 - phase];
+}
+
+// splitter r (1 <= r < R) = the sample of rank r * ns / R; spl[0] is unused
+__global__ void sr_splitters_kernel(const u64 *samples, u64 ns, u32 R, u64 *spl) {
+    const u64 r = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= R) return;
+    spl[r] = r == 0 ? 0 : samples[r * ns / R];  // (the host keeps R * ns below 2^62)
+}
+
+// ---- cut points -----------------------------------------------------------------------------------------------------
+// One workgroup per SEGMENT of CT_SEG consecutive tiles of one stream.  Per tile: 2048 records -> LDS (coalesced), order
+// check against the predecessor, then every splitter v with key[beg - 1] < v <= key[end - 1] is looked up in the tile:
+// lower_bound(stream, v) = beg + lower_bound(tile, v).  Splitters are taken NT at a time from where the previous tile
+// stopped (they are sorted), so only a segment's first tile searches the splitter array.
+constexpr int CT_NT = 256;
+constexpr int CT_VT = 8;
+constexpr int CT = CT_NT * CT_VT;
+constexpr int CT_SEG = 16;
+
+struct CutArgs {
+    const u64 *const *leaf_keys;
+    const u64 *leaf_len;
+    const u64 *seg_base;  // [S + 1]: segments in front of stream j
+    const u64 *spl;       // [R]
+    u32 *cuts;            // [S][R + 1]
+    u64 *result;          // [1] |= flags
+    u32 S, R;
+};
+
+__global__ __launch_bounds__(CT_NT) void sr_cuts_kernel(CutArgs p) {
+    __shared__ u64 s_k[CT + 2];
+    __shared__ u32 s_cnt[CT_NT / 64];
+    __shared__ u32 s_r;
+    const int tid = (int)threadIdx.x, lane = lane_id(), wave = tid >> 6;
+    // stream of this segment (uniform: scalar loads)
+    u32 lo = 0, hi = p.S;
+    const u64 g = blockIdx.x;
+    while (hi - lo > 1) {
+        const u32 mid = (lo + hi) >> 1;
+        if (sload_u64(p.seg_base + mid) <= g) lo = mid; else hi = mid;
+    }
+    const u32 j = lo;
+    const u64 seg = g - sload_u64(p.seg_base + j);
+    const u64 n = sload_u64(p.leaf_len + j);
+    const u64 *k = p.leaf_keys[j];
+    const u32 R = p.R;
+    u32 *crow = p.cuts + (size_t)j * ((size_t)R + 1);
+    const u64 ntiles = (n + CT - 1) / CT;
+    const u64 t0 = seg * CT_SEG, t1 = (t0 + CT_SEG < ntiles) ? t0 + CT_SEG : ntiles;
+    if (tid == 0) {
+        if (seg == 0) crow[0] = 0;
+        if (t1 == ntiles) crow[R] = (u32)n;
+        // first splitter of this segment: the first r >= 1 with spl[r] > key[beg - 1]
+        u32 ra = 1;
+        if (t0 > 0 && R > 1) {
+            const u64 pk = k[t0 * CT - 1];
+            u32 a = 1, b = R;  // first r in [1, R) with spl[r] > pk, else R
+            while (a < b) {
+                const u32 mid = (a + b) >> 1;
+                if (p.spl[mid] > pk) b = mid; else a = mid + 1;
+            }
+            ra = a;
+        }
+        s_r = ra;
+    }
+    __syncthreads();
+    u32 rc = s_r;  // next splitter to place (the same in every thread)
+    u32 bad = 0;
+    for (u64 t = t0; t < t1; t++) {
+        const u64 beg = t * CT;
+        const int cnt = (int)((n - beg < (u64)CT) ? (n - beg) : (u64)CT);
+        __syncthreads();  // the previous tile's searches are done
+#pragma unroll
+        for (int s = 0; s < CT_VT; s++) {
+            const int x = tid + s * CT_NT;
+            if (x < cnt) s_k[x + 1] = k[beg + x];
+        }
+        if (tid == 0) s_k[0] = beg > 0 ? k[beg - 1] : 0;
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < CT_VT; s++) {
+            const int x = tid + s * CT_NT;
+            if (x < cnt && (x > 0 || beg > 0) && s_k[x] > s_k[x + 1]) bad = SR_FLAG_UNSORTED;
+        }
+        const bool last = t + 1 == ntiles;
+        const u64 lastkey = s_k[cnt];
+        for (;;) {
+            const u32 r = rc + (u32)tid;
+            bool mine = false;
+            if (r < R) {
+                const u64 v = p.spl[r];
+                mine = last || v <= lastkey;
+                if (mine) {
+                    int a = 0, b = cnt;  // first x with tile[x] >= v
+                    while (a < b) {
+                        const int mid = (a + b) >> 1;
+                        if (s_k[mid + 1] < v) a = mid + 1; else b = mid;
+                    }
+                    crow[r] = (u32)(beg + (u64)a);
+                }
+            }
+            const u64 m = __ballot(mine);
+            if (lane == 0) s_cnt[wave] = (u32)__popcll(m);
+            __syncthreads();
+            u32 tot = 0;
+#pragma unroll
+            for (int w = 0; w < CT_NT / 64; w++) tot += s_cnt[w];
+            __syncthreads();
+            rc += tot;
+            if (tot < (u32)CT_NT) break;
+        }
+    }
+    if (__ballot(bad != 0) && lane == 0) atomicOr((unsigned long long *)&p.result[1], (unsigned long long)SR_FLAG_UNSORTED);
+}
+
+// ---- the merge ---------------------------------------------------------------------------------------------------------
+struct SrArgs {
+    const u64 *const *leaf_keys;  // [S]
+    const u32 *const *leaf_tax;   // [S] (entries may be null) or nullptr
+    const u32 *cuts;              // [S][R + 1]
+    const u64 *spl;               // [R]: range r holds the codes in [spl[r], spl[r + 1]) (r = 0: from 0; r = R - 1: to the end)
+    u64 *out_keys;                // MERGE: the caller's buffer; UNION: slots of N records
+    u32 *out_tax;
+    u64 *out_cnt;                 // [R] (UNION)
+    u64 *out_off;                 // [R] (UNION): where the range's slot begins
+    u64 *result;                  // [1] |= flags
+    u32 S, R, per_xcd;
+    TaxDev tax;
+};
+
+// One round of the in-LDS merge sort: thread `lt` of a pair merges VT consecutive positions of merge(A, B) (A first on
+// ties) into registers.  Both runs are followed by an SR_MAX sentinel; positions >= la + lb receive garbage nobody
+// reads.  With TaxIds the thread records the LDS slot every output came from and fetches the nine taxids afterwards
+// (independent reads), instead of one more dependent read and two more selects per step.
+// The kernel is bound by VALU issue (PMC: 354 lane-instructions per record, 61 % of the chip's issue rate), so the step is
+// the 12-instruction one of ukm_kway.hip: ONE compare feeds the minimum, the cursor and the head update, only the B cursor
+// is tracked (in bytes).  (Measured and dropped: two heads per side in registers so that a step's LDS read is not needed
+// before the step after next -- 17 instructions per step and no faster: LDS latency is not what the rounds wait for.)
+template <int VT>
+__device__ __forceinline__ int sr_merge_path(const u64 *in, int abase, int la, int bbase, int lb, int diag) {
+    // byte offsets: two adds per probe instead of shifts and index arithmetic
+    const char *inb = reinterpret_cast<const char *>(in);
+    const char *a8 = inb + abase * 8, *b8 = inb + (bbase + diag - 1) * 8;
+    int lo8 = (diag > lb ? diag - lb : 0) * 8;
+    int hi8 = (diag < la ? diag : la) * 8;
+    while (lo8 < hi8) {
+        const int mid8 = ((lo8 + hi8) >> 1) & ~7;
+        const bool le = *reinterpret_cast<const u64 *>(a8 + mid8) <= *reinterpret_cast<const u64 *>(b8 - mid8);
+        lo8 = le ? mid8 + 8 : lo8;
+        hi8 = le ? hi8 : mid8;
+    }
+    return lo8 >> 3;
+}
+
+template <bool TAX, int VT>
+__device__ __forceinline__ void sr_merge_fast(const u64 *in, const u32 *tin, int abase, int la, int bbase, int lb, int lt,
+                                              u64 (&ro)[VT], u32 (&rt)[VT]) {
+    const int L = la + lb;
+    int diag = lt * VT;
+    diag = diag < L ? diag : L;
+    const int lo8 = sr_merge_path<VT>(in, abase, la, bbase, lb, diag) * 8;
+    const char *inb = reinterpret_cast<const char *>(in);
+    const int sum8 = (abase + bbase + diag) * 8;  // A cursor + B cursor, in bytes, grows by one record per step
+    int pb8 = (bbase + diag) * 8 - lo8;
+    u64 ak = *reinterpret_cast<const u64 *>(inb + abase * 8 + lo8), bk = *reinterpret_cast<const u64 *>(inb + pb8);
+    int src8[VT];
+#pragma unroll
+    for (int s = 0; s < VT; s++) {
+        const bool take_b = bk < ak;
+        ro[s] = take_b ? bk : ak;
+        asm volatile("" : "+v"(ro[s]));
+        if (TAX) src8[s] = take_b ? pb8 : sum8 + 8 * s - pb8;
+        pb8 += take_b ? 8 : 0;
+        const int idx8 = take_b ? pb8 : sum8 + 8 * (s + 1) - pb8;
+        const u64 nk = *reinterpret_cast<const u64 *>(inb + idx8);
+        ak = take_b ? ak : nk;
+        bk = take_b ? nk : bk;
+    }
+    if (TAX) {
+        const char *tb = reinterpret_cast<const char *>(tin);
+#pragma unroll
+        for (int s = 0; s < VT; s++) rt[s] = *reinterpret_cast<const u32 *>(tb + (src8[s] >> 1));
+    }
+}
+
+// the same with exhaustion tested by index: for a tile that holds a real 2^64-1 code (the sentinel's value)
+template <bool TAX, int VT>
+__device__ __forceinline__ void sr_merge_checked(const u64 *in, const u32 *tin, int abase, int la, int bbase, int lb, int lt,
+                                                 u64 (&ro)[VT], u32 (&rt)[VT]) {
+    const int L = la + lb;
+    int diag = lt * VT;
+    diag = diag < L ? diag : L;
+    const int lo = sr_merge_path<VT>(in, abase, la, bbase, lb, diag);
+    int pa = abase + lo, pb = bbase + diag - lo;
+    const int ea = abase + la, eb = bbase + lb;
+    u64 ak = in[pa], bk = in[pb];
+#pragma unroll
+    for (int s = 0; s < VT; s++) {
+        const bool take_a = (pa < ea) && (pb >= eb || ak <= bk);
+        ro[s] = take_a ? ak : bk;
+        if (TAX) rt[s] = tin[take_a ? pa : pb];
+        pa += take_a ? 1 : 0;
+        pb += take_a ? 0 : 1;
+        const u64 nk = in[take_a ? pa : pb];
+        ak = take_a ? nk : ak;
+        bk = take_a ? bk : nk;
+    }
+}
+
+template <int NT>
+__device__ __forceinline__ u32 sr_block_sum_u32(u32 v, u32 *smem) {
+    u32 tot;
+    (void)block_excl_scan_u32<NT>(v, smem, &tot);
+    return tot;
+}
+
+template <int NT>
+__device__ __forceinline__ u64 sr_block_min_u64(u64 v, u64 *smem) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        const u64 o = __shfl_xor(v, d, 64);
+        v = o < v ? o : v;
+    }
+    if (lane_id() == 0) smem[threadIdx.x >> 6] = v;
+    __syncthreads();
+    u64 m = smem[0];
+#pragma unroll
+    for (int w = 1; w < NT / 64; w++) m = smem[w] < m ? smem[w] : m;
+    __syncthreads();
+    return m;
+}
+
+template <int NT>
+__device__ __forceinline__ u64 sr_block_sum_u64(u64 v, u64 *smem) {
+    v = wave_reduce_sum_u64(v);
+    if (lane_id() == 0) smem[threadIdx.x >> 6] = v;
+    __syncthreads();
+    u64 m = 0;
+#pragma unroll
+    for (int w = 0; w < NT / 64; w++) m += smem[w];
+    __syncthreads();
+    return m;
+}
+
+#ifndef SR_WAVES_TAX
+#define SR_WAVES_TAX 4
+#endif
+#ifndef SR_WAVES_PLAIN
+#define SR_WAVES_PLAIN 4
+#endif
+
+#ifdef SR_PHASES  // developer build: thread 0 of every workgroup adds the cycles of each phase to result[8 + k]
+#define SR_PH(k)                                                                                  \
+    do {                                                                                          \
+        if (threadIdx.x == 0) {                                                                   \
+            const long long _c = clock64();                                                       \
+            atomicAdd((unsigned long long *)&p.result[8 + (k)], (unsigned long long)(_c - ph_t)); \
+            ph_t = _c;                                                                            \
+        }                                                                                         \
+    } while (0)
+#else
+#define SR_PH(k) do { } while (0)
+#endif
+
+// first record >= v (UPPER = false) / > v (UPPER = true) of k[a, b)
+template <bool UPPER>
+__device__ __forceinline__ u32 sr_bound(const u64 *k, u32 a, u32 b, u64 v) {
+    while (a < b) {
+        const u32 mid = a + ((b - a) >> 1);
+        const u64 x = *as_global(k + mid);
+        const bool below = UPPER ? x <= v : x < v;
+        a = below ? mid + 1 : a;
+        b = below ? b : mid;
+    }
+    return a;
+}
+
+typedef u64 sr_u64x2 __attribute__((ext_vector_type(2), aligned(8)));
+typedef u32 sr_u32x4 __attribute__((ext_vector_type(4), aligned(4)));
+
+constexpr int SR_SPT = 2;  // streams per thread (their cursors and pointers live in registers): S <= NT * SR_SPT
+
+template <bool TAX, bool UNION, int NT, int VT, int LOGNT>
+__global__ __launch_bounds__(NT, (TAX ? SR_WAVES_TAX : SR_WAVES_PLAIN)) void sr_merge_kernel(SrArgs p) {
+#ifdef SR_PHASES
+    long long ph_t = clock64();
+#endif
+    constexpr int CAP = NT * VT;
+    constexpr int BUF = CAP + NT + VT + 8;
+    static_assert((1 << LOGNT) == NT, "NT");
+    __shared__ __attribute__((aligned(16))) u64 s_key[BUF];
+    __shared__ __attribute__((aligned(16))) u32 s_tax[TAX ? BUF : 4];
+    __shared__ u32 s_scan[NT / 64 + 1];
+    __shared__ u64 s_red[NT / 64];
+
+    const int tid = (int)threadIdx.x;
+    const u32 r = (blockIdx.x & 7u) * p.per_xcd + (blockIdx.x >> 3);  // an XCD works through CONSECUTIVE ranges: the
+    if (r >= p.R) return;                                              // slices of neighbouring ranges share lines in its L2
+    const u32 S = p.S;
+    const size_t RP = (size_t)p.R + 1;
+    // ---- this thread's streams: slice of the range, base pointers ----------------------------------------------------------
+    u32 lo[SR_SPT], hi[SR_SPT];
+    const u64 *kp[SR_SPT];
+    const u32 *tp[SR_SPT];
+#pragma unroll
+    for (int q = 0; q < SR_SPT; q++) {
+        const u32 j = (u32)tid * SR_SPT + (u32)q;
+        lo[q] = hi[q] = 0;
+        kp[q] = nullptr;
+        tp[q] = nullptr;
+        if (j < S) {
+            const u32 c0 = p.cuts[(size_t)j * RP + r], c1 = p.cuts[(size_t)j * RP + r + 1];
+            lo[q] = c0;
+            hi[q] = c1 > c0 ? c1 : c0;
+            kp[q] = p.leaf_keys[j];
+            if (TAX && p.leaf_tax) tp[q] = p.leaf_tax[j];
+        }
+    }
+    // records below the range = where its output begins
+    u64 out_pos;
+    {
+        u64 below = 0;
+#pragma unroll
+        for (int q = 0; q < SR_SPT; q++) below += lo[q];
+        out_pos = sr_block_sum_u64<NT>(below, s_red);
+    }
+    const u64 out_pos0 = out_pos;
+    u64 va = r > 0 ? sload_u64(p.spl + r) : 0;  // no record of what is left lies below va
+
+    for (;;) {
+        // ---- what is left of the range; a pass by value if it does not fit the tile -------------------------------------
+        u32 e[SR_SPT];
+        u32 loc = 0;
+#pragma unroll
+        for (int q = 0; q < SR_SPT; q++) {
+            e[q] = hi[q];
+            loc += hi[q] - lo[q];
+        }
+        u32 n;
+        u32 excl = block_excl_scan_u32<NT>(loc, s_scan, &n);
+        if (n == 0) break;
+#ifdef SR_PHASES
+        if (tid == 0 && out_pos == out_pos0) {
+            atomicMax((unsigned long long *)&p.result[16], (unsigned long long)n);
+            if (n > (u32)CAP) atomicAdd((unsigned long long *)&p.result[17], 1ull);
+            if (n > (u32)CAP * 2) atomicAdd((unsigned long long *)&p.result[18], 1ull);
+        }
+#endif
+        bool more = false;
+        if (n > (u32)CAP) {
+            more = true;
+#ifdef SR_PHASES
+            if (tid == 0) atomicAdd((unsigned long long *)&p.result[14], 1ull);
+#endif
+            // A value v with CAP / 2 <= #records below v <= CAP: interpolation between the bracket's ends (codes are
+            // spread evenly inside a range, or the range would not be this small), bisection when that does not
+            // converge.  Bracket: ca = #records below a (0 at the start), cb = #records below b (> CAP).
+            u64 a = va, b = (r + 1 < p.R) ? sload_u64(p.spl + r + 1) : SR_MAX;
+            u32 ca = 0, cb = n;
+            u32 ea[SR_SPT], eb[SR_SPT];  // per stream: first record >= a, first record >= b
+#pragma unroll
+            for (int q = 0; q < SR_SPT; q++) {
+                ea[q] = lo[q];
+                eb[q] = hi[q];
+            }
+            if (b == SR_MAX || b <= a) {  // the last range (open end) or nothing known: the largest code that is left
+                u64 mx = 0;
+#pragma unroll
+                for (int q = 0; q < SR_SPT; q++)
+                    if (hi[q] > lo[q]) {
+                        const u64 x = *as_global(kp[q] + (hi[q] - 1));
+                        mx = x > mx ? x : mx;
+                    }
+                mx = ~sr_block_min_u64<NT>(~mx, s_red);
+                b = mx;  // #records below mx <= n; if that fits, the pass takes them and the copies of mx follow
+                u32 cl = 0;
+#pragma unroll
+                for (int q = 0; q < SR_SPT; q++) {
+                    eb[q] = hi[q] > lo[q] ? sr_bound<false>(kp[q], lo[q], hi[q], b) : lo[q];
+                    cl += eb[q] - lo[q];
+                }
+                cb = sr_block_sum_u32<NT>(cl, s_scan);
+            }
+            int it = 0;
+            while (cb > (u32)CAP) {
+                if (b - a <= 1) break;  // every record below b equals a
+                u64 v;
+                const u64 span = b - a;
+                if (it < 4) {
+                    const double f = ((double)(CAP - CAP / 8) - (double)ca) / ((double)cb - (double)ca);
+                    v = a + (u64)((double)span * (f < 0.0 ? 0.0 : f));
+                } else {
+                    v = a + (span >> 1);
+                }
+                v = v <= a ? a + 1 : (v >= b ? b - 1 : v);
+                it++;
+                u32 ev[SR_SPT];
+                u32 cl = 0;
+#pragma unroll
+                for (int q = 0; q < SR_SPT; q++) {
+                    ev[q] = eb[q] > ea[q] ? sr_bound<false>(kp[q], ea[q], eb[q], v) : ea[q];
+                    cl += ev[q] - lo[q];
+                }
+                const u32 c = sr_block_sum_u32<NT>(cl, s_scan);
+                if (c > (u32)CAP) {
+                    b = v;
+                    cb = c;
+#pragma unroll
+                    for (int q = 0; q < SR_SPT; q++) eb[q] = ev[q];
+                } else {
+                    a = v;
+                    ca = c;
+#pragma unroll
+                    for (int q = 0; q < SR_SPT; q++) ea[q] = ev[q];
+                    if (c >= (u32)CAP / 2) break;
+                }
+            }
+            if (cb <= (u32)CAP) {  // (the open-ended case: everything below the largest code fits)
+                a = b;
+                ca = cb;
+#pragma unroll
+                for (int q = 0; q < SR_SPT; q++) ea[q] = eb[q];
+            }
+            if (ca == 0) {
+                // no record below a + 1 ... and more than a tile below b: the smallest code that is left has many copies.
+                // All of them, from all streams, if they fit; else the multi-level merge answers (it streams such runs)
+                u64 mn = SR_MAX;
+#pragma unroll
+                for (int q = 0; q < SR_SPT; q++)
+                    if (hi[q] > lo[q]) {
+                        const u64 x = *as_global(kp[q] + lo[q]);
+                        mn = x < mn ? x : mn;
+                    }
+                mn = sr_block_min_u64<NT>(mn, s_red);
+                u32 cl = 0;
+#pragma unroll
+                for (int q = 0; q < SR_SPT; q++) {
+                    ea[q] = hi[q] > lo[q] ? sr_bound<true>(kp[q], lo[q], hi[q], mn) : lo[q];
+                    cl += ea[q] - lo[q];
+                }
+                ca = sr_block_sum_u32<NT>(cl, s_scan);
+                if (ca > (u32)CAP) {
+                    if (tid == 0) atomicOr((unsigned long long *)&p.result[1], (unsigned long long)SR_FLAG_DEGENERATE);
+                    return;
+                }
+                a = mn;  // (the next pass starts above mn: nothing below it is left)
+            }
+            va = a;
+            loc = 0;
+#pragma unroll
+            for (int q = 0; q < SR_SPT; q++) {
+                e[q] = ea[q];
+                loc += e[q] - lo[q];
+            }
+            excl = block_excl_scan_u32<NT>(loc, s_scan, &n);
+        }
+        SR_PH(0);
+
+        // ---- gather: a lane copies its streams' slices (a few records each) to the tile, in stream order ------------------
+        bool danger = false;
+        {
+            u32 base = excl;
+#pragma unroll
+            for (int q = 0; q < SR_SPT; q++) {
+                const u32 len = e[q] - lo[q];
+                const u64 *src = kp[q] + lo[q];
+                // a slice is a few consecutive records: 16-byte loads (two codes / four taxids each; the addresses are
+                // only 8- / 4-byte aligned), four codes in flight -- one cache-line look-up per load instead of one per
+                // record is what the gather is bound by
+                u32 x = 0;
+                for (; x + 4 <= len; x += 4) {
+                    const sr_u64x2 v0 = *reinterpret_cast<ukm_gptr<sr_u64x2>>((uintptr_t)(src + x));
+                    const sr_u64x2 v1 = *reinterpret_cast<ukm_gptr<sr_u64x2>>((uintptr_t)(src + x + 2));
+                    s_key[base + x] = v0.x; s_key[base + x + 1] = v0.y; s_key[base + x + 2] = v1.x; s_key[base + x + 3] = v1.y;
+                    danger = danger || v1.y == SR_MAX;
+                }
+                if (x + 2 <= len) {
+                    const sr_u64x2 v0 = *reinterpret_cast<ukm_gptr<sr_u64x2>>((uintptr_t)(src + x));
+                    s_key[base + x] = v0.x; s_key[base + x + 1] = v0.y;
+                    danger = danger || v0.y == SR_MAX;
+                    x += 2;
+                }
+                if (x < len) {
+                    const u64 k = *as_global(src + x);
+                    s_key[base + x] = k;
+                    danger = danger || k == SR_MAX;
+                }
+                if (TAX) {
+                    if (tp[q]) {
+                        const u32 *ts = tp[q] + lo[q];
+                        u32 y = 0;
+                        for (; y + 4 <= len; y += 4) {
+                            const sr_u32x4 v = *reinterpret_cast<ukm_gptr<sr_u32x4>>((uintptr_t)(ts + y));
+                            s_tax[base + y] = v.x; s_tax[base + y + 1] = v.y; s_tax[base + y + 2] = v.z; s_tax[base + y + 3] = v.w;
+                        }
+                        for (; y < len; y++) s_tax[base + y] = *as_global(ts + y);
+                    } else {
+                        for (u32 y = 0; y < len; y++) s_tax[base + y] = 0u;
+                    }
+                }
+                base += len;
+            }
+        }
+        __syncthreads();
+        SR_PH(1);
+        // ---- a thread's VT consecutive tile positions in stable order: rank = #smaller + #equal in front ------------------
+        {
+            u64 kk[VT];
+            u32 tt[VT];
+            int tr = tid;
+            asm volatile("" : "+v"(tr));  // index math of a phase is recomputed, not kept live across the pass loop
+            const int p0 = tr * VT;
+#pragma unroll
+            for (int i = 0; i < VT; i++) {
+                const bool valid = p0 + i < (int)n;
+                kk[i] = valid ? s_key[p0 + i] : SR_MAX;
+                if (TAX) tt[i] = valid ? s_tax[p0 + i] : 0u;
+            }
+            u32 rk[VT];
+#pragma unroll
+            for (int i = 0; i < VT; i++) rk[i] = 0;
+#pragma unroll
+            for (int i = 0; i < VT; i++)
+#pragma unroll
+                for (int q = i + 1; q < VT; q++) {
+                    const bool c = kk[q] < kk[i];
+                    rk[i] += c ? 1u : 0u;
+                    rk[q] += c ? 0u : 1u;
+                }
+            __syncthreads();  // every thread has read its positions: the tile is rewritten as runs of VT with sentinels
+            const int base = tr * (VT + 1);
+#pragma unroll
+            for (int i = 0; i < VT; i++) {
+                s_key[base + (int)rk[i]] = kk[i];
+                if (TAX) s_tax[base + (int)rk[i]] = tt[i];
+            }
+            s_key[base + VT] = SR_MAX;
+        }
+        danger = __syncthreads_or(danger ? 1 : 0) != 0;
+        SR_PH(2);
+
+        // ---- merge rounds: runs of VT << (k - 1) records, run i at i * (run length + 1), a sentinel behind it ----------
+#ifndef SR_ABL_ROUNDS
+#define SR_ABL_ROUNDS LOGNT  /* experiment only: fewer merge rounds (wrong results) */
+#endif
+#pragma unroll
+        for (int k = 1; k <= SR_ABL_ROUNDS; k++) {
+            const int L = VT << (k - 1);
+            if ((int)n > L) {  // (uniform) otherwise everything already is one run
+                int te = tid;
+                asm volatile("" : "+v"(te));
+                const int pair = te >> k, lt = te & ((1 << k) - 1);
+                const int abase = 2 * pair * (L + 1), bbase = abase + L + 1;
+                int la = (int)n - 2 * pair * L, lb = (int)n - (2 * pair + 1) * L;
+                la = la < 0 ? 0 : (la > L ? L : la);
+                lb = lb < 0 ? 0 : (lb > L ? L : lb);
+                u64 ro[VT];
+                u32 rt[VT];
+                if (danger) sr_merge_checked<TAX, VT>(s_key, s_tax, abase, la, bbase, lb, lt, ro, rt);
+                else sr_merge_fast<TAX, VT>(s_key, s_tax, abase, la, bbase, lb, lt, ro, rt);
+                __syncthreads();  // every thread has read its inputs: the runs are rewritten in place
+                const int obase = pair * (2 * L + 1), o0 = obase + lt * VT, Lo = la + lb;
+#pragma unroll
+                for (int q = 0; q < VT; q++) {
+                    s_key[o0 + q] = ro[q];
+                    if (TAX) s_tax[o0 + q] = rt[q];
+                }
+                if ((Lo >= lt * VT && Lo < lt * VT + VT) || (lt == (1 << k) - 1 && Lo == (VT << k))) s_key[obase + Lo] = SR_MAX;
+                __syncthreads();
+            }
+        }
+
+        SR_PH(3);
+        // ---- emit: the merged tile is s_key / s_tax [0, n) ---------------------------------------------------------------
+        int count = (int)n;
+        if (UNION) {
+            int tf = tid;
+            asm volatile("" : "+v"(tf));
+            const int i0 = tf * VT;
+            u64 hk[VT];
+            u32 ht[VT];
+            u32 headm = 0, multim = 0, neqm = 0;
+            {
+                u64 prevk = (i0 > 0 && i0 <= (int)n) ? s_key[i0 - 1] : 0;
+                u32 prevt = (TAX && i0 > 0 && i0 <= (int)n) ? s_tax[i0 - 1] : 0;
+                u64 kcur = s_key[i0];
+#pragma unroll
+                for (int s = 0; s < VT; s++) {
+                    const int i = i0 + s;
+                    const u64 knext = s_key[i + 1];  // (inside the buffer; garbage behind the tile is never used)
+                    const bool in = i < (int)n;
+                    const bool head = in && (i == 0 || kcur != prevk);
+                    hk[s] = kcur;
+                    headm |= head ? (1u << s) : 0u;
+                    if (TAX) {
+                        const u32 t = s_tax[i];
+                        ht[s] = t;
+                        const bool follows = in && !head;
+                        const bool multi = follows || (in && i + 1 < (int)n && knext == kcur);
+                        multim |= multi ? (1u << s) : 0u;
+                        neqm |= (follows && t != prevt) ? (1u << s) : 0u;
+                        prevt = t;
+                    }
+                    prevk = kcur;
+                    kcur = knext;
+                }
+            }
+            u32 tot;
+            const u32 hexcl = block_excl_scan_u32<NT>((u32)__popc(headm), s_scan, &tot);
+            // (the scan's barriers lie between every thread's last read of the tile and the writes below)
+            if (TAX) {
+                u64 *s_acc = s_key;   // per output slot: [31:0] smallest, [63:32] largest pre-order number of the run
+                u32 *s_flag = s_tax;  // per output slot: SR_NEQ | SR_BAD
+                for (u32 w = (u32)tid; w < tot; w += NT) {
+                    s_acc[w] = 0x00000000FFFFFFFFull;
+                    s_flag[w] = 0;
+                }
+                __syncthreads();
+                if (multim) {
+#pragma unroll
+                    for (int s = 0; s < VT; s++) {
+                        if (multim & (1u << s)) {
+                            const u32 w = hexcl + (u32)__popc(headm & ((2u << s) - 1u)) - 1u;
+                            const u32 t = ht[s];
+                            const u32 eu = t < p.tax.size ? p.tax.euler[t] : 0u;
+                            u32 fl = (neqm & (1u << s)) ? (u32)SR_NEQ : 0u;
+                            if (eu == 0) fl |= (u32)SR_BAD;
+                            else {
+                                atomicMin(reinterpret_cast<u32 *>(&s_acc[w]), eu);
+                                atomicMax(reinterpret_cast<u32 *>(&s_acc[w]) + 1, eu);
+                            }
+                            if (fl) atomicOr(&s_flag[w], fl);
+                        }
+                    }
+                }
+                __syncthreads();
+#pragma unroll
+                for (int s = 0; s < VT; s++) {
+                    if ((headm & multim) & (1u << s)) {
+                        const u32 w = hexcl + (u32)__popc(headm & ((2u << s) - 1u)) - 1u;
+                        const u32 fl = s_flag[w];
+                        if (fl & SR_NEQ) {
+                            if (fl & SR_BAD) ht[s] = 0;
+                            else {
+                                const u64 acc = s_acc[w];
+                                ht[s] = lca_dev(p.tax, p.tax.node_at[(u32)acc], p.tax.node_at[(u32)(acc >> 32)]);
+                            }
+                        }
+                    }
+                }
+                __syncthreads();
+            }
+            u32 w = hexcl;
+#pragma unroll
+            for (int s = 0; s < VT; s++) {
+                if (headm & (1u << s)) {
+                    s_key[w] = hk[s];
+                    if (TAX) s_tax[w] = ht[s];
+                    w++;
+                }
+            }
+            __syncthreads();
+            count = (int)tot;
+        }
+        {
+            u64 *o = p.out_keys + out_pos;
+            for (int i = tid; i < count; i += NT) o[i] = s_key[i];
+            if (TAX) {
+                u32 *to = p.out_tax + out_pos;
+                for (int i = tid; i < count; i += NT) to[i] = s_tax[i];
+            }
+            out_pos += (u64)count;
+        }
+        SR_PH(4);
+#ifdef SR_PHASES
+        if (tid == 0) atomicAdd((unsigned long long *)&p.result[13], 1ull);
+#endif
+        if (!more) break;
+        __syncthreads();  // the tile is rewritten by the next pass
+#pragma unroll
+        for (int q = 0; q < SR_SPT; q++) lo[q] = e[q];
+    }
+    if (UNION && tid == 0) {
+        p.out_cnt[r] = out_pos - out_pos0;
+        p.out_off[r] = out_pos0;
+    }
+}
+
+// gather the ranges' slots of a union into the caller's buffer: range r goes to dst + excl[r]
+__global__ void sr_gather_kernel(const u64 *src, const u32 *tsrc, const u64 *slot, const u64 *cnt, const u64 *excl, u64 *dst,
+                                 u32 *tdst, u64 cap) {
+    const u32 r = blockIdx.x;
+    const u64 off = slot[r], n = cnt[r], d0 = excl[r];
+    if (d0 + n > cap) return;  // the host reports UKM_ERR_CAPACITY
+    for (u64 i = threadIdx.x; i < n; i += blockDim.x) dst[d0 + i] = src[off + i];
+    if (tsrc)
+        for (u64 i = threadIdx.x; i < n; i += blockDim.x) tdst[d0 + i] = tsrc[off + i];
+}
+
+template <bool TAX, bool UNION, int NT, int VT, int LOGNT>
+int sr_launch(const SrArgs &a, hipStream_t st) {
+    hipLaunchKernelGGL((sr_merge_kernel<TAX, UNION, NT, VT, LOGNT>), dim3(a.per_xcd * 8), dim3(NT), 0, st, a);
+    return UKM_OK;
+}
+
+#ifndef SR_NT
+#define SR_NT 512
+#endif
+#ifndef SR_VT
+#define SR_VT 9
+#endif
+constexpr int SR_LOGNT = SR_NT == 512 ? 9 : (SR_NT == 256 ? 8 : 10);
+constexpr int SR_CAP = SR_NT * SR_VT;
+
+}  // namespace
+
+int ukm_srmerge_mode() {  // read per call: the tests switch it
+    const char *e = getenv("UKM_SRMERGE");
+    return e ? atoi(e) : -1;
+}
+
+int ukm_dev_srmerge(ukm_ctx *c, int op, const u64 *const *keys, const u32 *const *taxids, const u64 *lens, int S, bool tax,
+                    u64 *out, u32 *tout, u64 out_cap, u64 *n_out, bool *fallback) {
+    *fallback = true;
+    *n_out = 0;
+    const bool uni = op == UKM_KWAY_UNION;
+    const int mode = ukm_srmerge_mode();
+    if (mode == 0 || S < 2 || S > SR_MAX_STREAMS) return UKM_OK;
+    u64 N = 0;
+    for (int j = 0; j < S; j++) {
+        if (lens[j] == 0 || lens[j] >= (1ull << 32)) return UKM_OK;  // (callers drop empty streams)
+        N += lens[j];
+    }
+    if (mode < 1) {
+        // the library's own choice: the multi-level merge needs three or more levels for these streams, and there is
+        // enough to do for the set-up (sample sort, cut table) to pay
+        if (S <= 64 || N < (1ull << 24)) return UKM_OK;
+    }
+    if (tax && !tout) UKM_FAIL(UKM_ERR_INVALID, "merge: taxids given but out_taxids is NULL");
+    if (tax && uni && c->tax_parent == nullptr)
+        UKM_FAIL(UKM_ERR_NO_TAXONOMY, "union: records carry taxids but no taxonomy is loaded");
+    if (tax && uni && (c->tax_euler == nullptr || c->tax_node_at == nullptr)) return UKM_OK;
+    if (!uni && N > out_cap) {
+        *n_out = N;
+        UKM_FAIL(UKM_ERR_CAPACITY, "merge: output needs %llu records, capacity is %llu", (unsigned long long)N,
+                 (unsigned long long)out_cap);
+    }
+    // ---- ranges: ~85 % of a tile on average, splitters from 128 samples per range -------------------------------------
+    const int fill_pct = getenv("UKM_SRMERGE_FILL") ? std::max(10, std::min(400, atoi(getenv("UKM_SRMERGE_FILL")))) : 85;  // developer knob
+    const u64 target = std::max<u64>(1, (u64)SR_CAP * (u64)fill_pct / 100);
+    u64 R64 = (N + target - 1) / target;
+    u64 D = 1, ns = 0;
+    std::vector<u64> sample_base((size_t)S + 1, 0);
+    if (R64 > 1) {
+        const u64 spr = getenv("UKM_SRMERGE_SPR") ? std::max(8, atoi(getenv("UKM_SRMERGE_SPR"))) : SR_SAMPLES_PER_RANGE;  // developer knob
+        D = std::max<u64>(1, N / (R64 * spr));
+        for (int j = 0; j < S; j++) sample_base[(size_t)j + 1] = sample_base[(size_t)j] + lens[j] / D;
+        ns = sample_base[(size_t)S];
+        if (ns < R64) R64 = std::max<u64>(1, ns);
+    }
+    // cut tables of more than 4 GB each (or a splitter index that overflows): the multi-level merge answers
+    if (R64 >= (1ull << 28) || (u64)S * (R64 + 1) > (1ull << 30) || ns >= (1ull << 34)) return UKM_OK;
+    const u32 R = (u32)R64;
+    const u32 RP = R + 1;
+
+    static const bool dbg = getenv("UKM_SRMERGE_DEBUG") != nullptr;
+    std::vector<std::pair<const char *, hipEvent_t>> marks;
+    auto mark = [&](const char *name) {
+        if (!dbg) return;
+        hipEvent_t e;
+        if (hipEventCreate(&e) == hipSuccess) {
+            (void)hipEventRecord(e, c->stream);
+            marks.emplace_back(name, e);
+        }
+    };
+    auto drop_marks = [&]() {
+        for (auto &m : marks) (void)hipEventDestroy(m.second);
+        marks.clear();
+    };
+    mark("start");
+
+    // ---- device tables: [keys S][tax S][len S][sample_base S + 1][seg_base S + 1] ------------------------------------
+    const size_t ntab = (size_t)5 * S + 2;
+    std::vector<u64> tab(ntab);
+    u64 nseg = 0;
+    for (int j = 0; j < S; j++) {
+        tab[(size_t)j] = (u64)(uintptr_t)keys[j];
+        tab[(size_t)S + j] = (u64)(uintptr_t)((tax && taxids) ? taxids[j] : nullptr);
+        tab[(size_t)2 * S + j] = lens[j];
+        tab[(size_t)4 * S + 1 + j] = nseg;
+        nseg += (lens[j] + (u64)CT * CT_SEG - 1) / ((u64)CT * CT_SEG);
+    }
+    tab[(size_t)5 * S + 1] = nseg;
+    for (int j = 0; j <= S; j++) tab[(size_t)3 * S + j] = sample_base[(size_t)j];
+    if (nseg > 0x7FFFFFFFull) return UKM_OK;
+    u64 *d_tab = nullptr;
+    UKM_TRY(ws_alloc_t(c, ntab, &d_tab));
+    UKM_HIP(hipMemcpyAsync(d_tab, tab.data(), ntab * sizeof(u64), hipMemcpyHostToDevice, c->stream));
+    UKM_HIP(hipStreamSynchronize(c->stream));  // `tab` is a pageable host buffer of this frame
+    const u64 *const *d_keys = reinterpret_cast<const u64 *const *>(d_tab);
+    const u32 *const *d_tax = reinterpret_cast<const u32 *const *>(d_tab + S);
+    const u64 *d_len = d_tab + 2 * (size_t)S;
+    const u64 *d_sbase = d_tab + 3 * (size_t)S;
+    const u64 *d_segbase = d_tab + 4 * (size_t)S + 1;
+
+    u64 *ctl = nullptr, *spl = nullptr;
+    u32 *cuts = nullptr;
+    UKM_TRY(ws_alloc_t(c, 32, &ctl));
+    UKM_HIP(hipMemsetAsync(ctl, 0, 32 * sizeof(u64), c->stream));
+    UKM_TRY(ws_alloc_t(c, (size_t)R + 1, &spl));
+    UKM_TRY(ws_alloc_t(c, (size_t)S * RP, &cuts));
+    if (R > 1) {
+        u64 *samples = nullptr;
+        UKM_TRY(ws_alloc_t(c, ns, &samples));
+        hipLaunchKernelGGL(sr_sample_kernel, dim3((unsigned)((ns + 255) / 256)), dim3(256), 0, c->stream, d_keys, d_sbase, (u32)S, D,
+                           ns, samples);
+        UKM_TRY(ukm_dev_sort(c, samples, nullptr, ns, 64));
+        hipLaunchKernelGGL(sr_splitters_kernel, dim3((R + 255) / 256), dim3(256), 0, c->stream, samples, ns, R, spl);
+    }
+    mark("sample+sort");
+    {
+        CutArgs a;
+        a.leaf_keys = d_keys;
+        a.leaf_len = d_len;
+        a.seg_base = d_segbase;
+        a.spl = spl;
+        a.cuts = cuts;
+        a.result = ctl;
+        a.S = (u32)S;
+        a.R = R;
+        hipLaunchKernelGGL(sr_cuts_kernel, dim3((unsigned)nseg), dim3(CT_NT), 0, c->stream, a);
+        UKM_HIP(hipGetLastError());
+    }
+    mark("cuts");
+    {
+        u64 fl = 0;
+        UKM_TRY(ukm_read_u64(c, ctl + 1, &fl));
+        if (fl & SR_FLAG_UNSORTED) {
+            drop_marks();
+            return UKM_OK;  // *fallback: the caller's general route sorts / reports it
+        }
+    }
+    // ---- the merge pass -----------------------------------------------------------------------------------------------
+    u64 *slots_k = nullptr, *cnt = nullptr, *slot_off = nullptr;
+    u32 *slots_t = nullptr;
+    if (uni) {
+        UKM_TRY(ws_alloc_t(c, N + 1, &slots_k));
+        if (tax) UKM_TRY(ws_alloc_t(c, N + 1, &slots_t));
+        UKM_TRY(ws_alloc_t(c, (size_t)R + 1, &cnt));
+        UKM_TRY(ws_alloc_t(c, (size_t)R + 1, &slot_off));
+    }
+    SrArgs a;
+    memset(&a, 0, sizeof(a));
+    a.leaf_keys = d_keys;
+    a.leaf_tax = tax ? d_tax : nullptr;
+    a.cuts = cuts;
+    a.spl = spl;
+    a.out_keys = uni ? slots_k : out;
+    a.out_tax = tax ? (uni ? slots_t : tout) : nullptr;
+    a.out_cnt = cnt;
+    a.out_off = slot_off;
+    a.result = ctl;
+    a.S = (u32)S;
+    a.R = R;
+    a.per_xcd = (R + 7) / 8;
+    a.tax = ukm_taxdev(c);
+    (void)hipEventRecord(c->ev_k0, c->stream);
+    if (tax) {
+        if (uni) sr_launch<true, true, SR_NT, SR_VT, SR_LOGNT>(a, c->stream);
+        else sr_launch<true, false, SR_NT, SR_VT, SR_LOGNT>(a, c->stream);
+    } else {
+        if (uni) sr_launch<false, true, SR_NT, SR_VT, SR_LOGNT>(a, c->stream);
+        else sr_launch<false, false, SR_NT, SR_VT, SR_LOGNT>(a, c->stream);
+    }
+    (void)hipEventRecord(c->ev_k1, c->stream);
+    c->evk_valid = true;
+    UKM_HIP(hipGetLastError());
+    mark("merge");
+    if (uni) {
+        u64 *excl = nullptr;
+        UKM_TRY(ws_alloc_t(c, (size_t)R + 1, &excl));
+        UKM_TRY(ukm_dev_exclusive_scan_u64(c, cnt, excl, R, ctl));  // ctl[0] = total
+        hipLaunchKernelGGL(sr_gather_kernel, dim3(R), dim3(256), 0, c->stream, slots_k, tax ? slots_t : nullptr, slot_off, cnt, excl, out,
+                           tout, out_cap);
+        UKM_HIP(hipGetLastError());
+        mark("gather");
+    }
+    u64 h[2] = {0, 0};
+    UKM_TRY(ukm_read_u64(c, ctl, h, 2));
+    if (dbg) {
+        fprintf(stderr, "[srmerge] S=%d N=%llu R=%u ns=%llu D=%llu flags=%llu out=%llu :", S, (unsigned long long)N, R,
+                (unsigned long long)ns, (unsigned long long)D, (unsigned long long)h[1], (unsigned long long)(uni ? h[0] : N));
+        for (size_t i = 1; i < marks.size(); i++) {
+            float ms = 0;
+            (void)hipEventElapsedTime(&ms, marks[i - 1].second, marks[i].second);
+            fprintf(stderr, " %s=%.3fms", marks[i].first, ms);
+        }
+        fprintf(stderr, "\n");
+#ifdef SR_PHASES
+        u64 ph[16];
+        UKM_TRY(ukm_read_u64(c, ctl + 8, ph, 16));
+        fprintf(stderr, "[srmerge] k-cycles per range: prologue %.1f gather %.1f rank %.1f rounds %.1f emit %.1f\n", ph[0] / 1e3 / R,
+                ph[1] / 1e3 / R, ph[2] / 1e3 / R, ph[3] / 1e3 / R, ph[4] / 1e3 / R);
+        fprintf(stderr, "[srmerge] passes %llu, of them by the quota rule %llu; ranges over one tile %llu, over two %llu, largest %llu\n",
+                (unsigned long long)ph[5], (unsigned long long)ph[6], (unsigned long long)ph[9], (unsigned long long)ph[10], (unsigned long long)ph[8]);
+#endif
+    }
+    drop_marks();
+    if (h[1] & (SR_FLAG_UNSORTED | SR_FLAG_DEGENERATE)) return UKM_OK;  // *fallback stays set
+    *fallback = false;
+    *n_out = uni ? h[0] : N;
+    if (*n_out > out_cap)
+        UKM_FAIL(UKM_ERR_CAPACITY, "union: output needs %llu records, capacity is %llu", (unsigned long long)*n_out,
+                 (unsigned long long)out_cap);
+    return UKM_OK;
+}

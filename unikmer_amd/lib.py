@@ -24,7 +24,7 @@ F_MIX_TAXID, F_CMP_TAXID = 2, 4
 SYMBOLS = [
     "ukm_last_error", "ukm_version", "ukm_device_count", "ukm_ctx_create", "ukm_ctx_destroy",
     "ukm_ctx_set_stream", "ukm_ctx_sync", "ukm_ctx_reserve", "ukm_dev_alloc", "ukm_dev_free",
-    "ukm_copy", "ukm_host_alloc", "ukm_host_free", "ukm_copy_async", "ukm_copy_fence", "ukm_copy_sync", "ukm_last_kernel_ms", "ukm_last_call_ms", "ukm_taxonomy_load", "ukm_taxonomy_max_taxid", "ukm_lca",
+    "ukm_copy", "ukm_host_alloc", "ukm_host_free", "ukm_copy_async", "ukm_copy_fence", "ukm_copy_sync", "ukm_last_kernel_ms", "ukm_last_call_ms", "ukm_last_route", "ukm_taxonomy_load", "ukm_taxonomy_max_taxid", "ukm_lca",
     "ukm_encode_kmers", "ukm_nthash", "ukm_minimizer", "ukm_max_hash", "ukm_sort_u64", "ukm_sort_pairs",
     "ukm_unique", "ukm_merge_k", "ukm_setop2", "ukm_union", "ukm_inter", "ukm_diff",
     "ukm_common", "ukm_common_threshold", "ukm_partition_points",
@@ -105,6 +105,7 @@ def load():
     L.ukm_copy_sync.argtypes = [vp]
     L.ukm_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
     L.ukm_last_call_ms.argtypes = [vp, C.POINTER(C.c_float)]
+    L.ukm_last_route.argtypes = [vp]
     L.ukm_taxonomy_load.argtypes = [vp, vp, vp, u64, vp, vp, u64]
     L.ukm_taxonomy_max_taxid.argtypes = [vp, C.POINTER(u32)]
     L.ukm_lca.argtypes = [vp, vp, vp, u64, vp]
@@ -218,6 +219,10 @@ class Context:
         ms = C.c_float()
         _check(self.L.ukm_last_kernel_ms(self.h, C.byref(ms)))
         return ms.value
+
+    def last_route(self):
+        """which internal route answered the last n-way call (include/unikmer_hip.h: ukm_last_route)"""
+        return int(self.L.ukm_last_route(self.h))
 
     def last_call_ms(self):
         ms = C.c_float()
