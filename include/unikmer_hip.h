@@ -228,6 +228,16 @@ int ukm_shard_exchange(ukm_ctx *ctx, const uint64_t *keys, const uint32_t *taxid
  *      transfers (own slice: device-to-device copy; peers: one ncclSend / ncclRecv group on the context's stream; like
  *      every entry point the call returns when its stream work is done). */
 int ukm_shard_plan(int nranks, int rank, const uint64_t *all, uint64_t *recv_counts, uint64_t *n_out);
+/*      Sampled splitters (k-mer codes are not uniform in their top bits -- README.md:177-180, sorted
+ *      k-mers start AAAAAAAAA... -- so equal-width ranges leave the ranks unevenly loaded): ukm_shard_splitters is
+ *      collective; every rank passes the sorted files it holds and gets the same nranks + 1 boundaries, cut so that the
+ *      ranks receive about the same number of records (1024 regular samples per rank, one all-gather).  Use them in
+ *      place of ukm_prefix_splitters; any non-decreasing boundaries give the same concatenated result.
+ *      ukm_shard_splitters_plan is the decision as a pure host function over the gathered words
+ *      ([rank][1 + per_rank] = record count, samples). */
+int ukm_shard_splitters(ukm_ctx *ctx, const uint64_t *const *keys, const uint64_t *lens, int nfiles, int key_bits,
+                        uint64_t *splitters);
+int ukm_shard_splitters_plan(int nranks, int per_rank, const uint64_t *all, int key_bits, uint64_t *splitters);
 int ukm_shard_counts(ukm_ctx *ctx, const uint64_t *send_counts, int nfiles, uint64_t *recv_counts);
 int ukm_shard_exchange_known(ukm_ctx *ctx, const uint64_t *keys, const uint32_t *taxids, const uint64_t *send_counts,
                              const uint64_t *recv_counts, uint64_t *out_keys, uint32_t *out_taxids, uint64_t out_cap,

@@ -279,3 +279,120 @@ def test_sharded_inter_empty_slice_vs_empty_file_world2():
     assert cat("slice_empty").tolist() == [1]
     assert cat("file_empty").tolist() == [1, hi]
     assert cat("cross").tolist() == [5, 9, hi]
+
+
+# ---------------------------------------------------------------- sampled splitters, ordered pieces, multiset rebuild
+def _canonical_kmers(tmp_path_factory=None):
+    """distinct canonical 31-mers of the E. coli fixture genome (the oracle is the checker's encoder), sorted"""
+    from conftest import read_fasta_gz, MG1655
+    from oracle import oracle as O
+    seq, off = read_fasta_gz(MG1655)
+    return np.unique(O.count_windows(seq, off, 31))
+
+
+class _CountingCtx(_NumpyCtx):
+    merges = 0
+
+    def merge_k(self, pieces, tpieces=None):
+        type(self).merges += 1
+        return super().merge_k(pieces, tpieces)
+
+
+def _kmers_worker(rank, world, port, path, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        codes = np.load(path)
+        n = len(codes)
+        t = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.int64))
+        out = {}
+        # file A stride-sharded (rank r holds every world-th k-mer), file B offset-sharded (rank r holds the r-th chunk)
+        A = codes[rank::world]
+        Bfull = codes[::3]
+        B = Bfull[rank * len(Bfull) // world:(rank + 1) * len(Bfull) // world]
+        spl = ud.sampled_splitters([t(A), t(B)], 62)
+        out["spl"] = spl
+        ctx = _CountingCtx()
+        for name, sp in (("equal", None), ("sampled", spl)):
+            _CountingCtx.merges = 0
+            local, _ = ud.redistribute(ctx, [t(A), t(B)], 62, splitters=sp)
+            out[name + "_sizes"] = [x.numel() for x in local]
+            out[name + "_A"] = local[0].numpy().view(np.uint64).copy()
+            out[name + "_B"] = local[1].numpy().view(np.uint64).copy()
+            out[name + "_merges"] = _CountingCtx.merges
+        out["inter"] = ud.sharded_setop(_NumpyCtx(), "inter", [t(A), t(B)], 62, splitters="sampled").numpy().view(np.uint64).copy()
+        out["union"] = ud.sharded_setop(_NumpyCtx(), "union", [t(A), t(B)], 62, splitters="sampled").numpy().view(np.uint64).copy()
+        # a multiset file (every 5th code twice), stride-sharded: the rebuild keeps both copies
+        M = np.sort(np.concatenate([codes[::7], codes[::35]]))
+        local, _ = ud.redistribute(_NumpyCtx(), [t(M[rank::world])], 62, splitters=spl)
+        out["multi"] = local[0].numpy().view(np.uint64).copy()
+        # the count path with sampled splitters of the locally sorted codes
+        rng = np.random.default_rng(5 + rank)
+        mine = rng.permutation(codes[rank::world])[: 200_000]
+        out["sorted"] = ud.sharded_sort(_NumpyCtx(), t(mine.copy()), 62, splitters="sampled").numpy().view(np.uint64).copy()
+        out["sort_in"] = mine
+        ret[rank] = out
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sampled_splitters_balance_canonical_kmers_world2(tmp_path):
+    """canonical k-mer codes crowd the low prefixes, so equal-width ranges are uneven; splitters from a
+    sample of every rank's files bring each rank within 10 % of the mean, every rank computes the same boundaries, and the
+    concatenated results do not change.  Offset-sharded files arrive in value order and are NOT merged (one concatenated
+    view); stride-sharded files go through the keep-everything merge, so a file that holds codes twice still does."""
+    world = 2
+    codes = _canonical_kmers()
+    path = str(tmp_path / "codes.npy")
+    np.save(path, codes)
+    port = _free_port()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_kmers_worker, args=(world, port, path, ret), nprocs=world, join=True)
+    r0, r1 = ret[0], ret[1]
+    assert r0["spl"] == r1["spl"] and r0["spl"][0] == 0 and r0["spl"][-1] == 1 << 62
+    assert all(a <= b for a, b in zip(r0["spl"], r0["spl"][1:]))
+    B = codes[::3]
+    for name in ("equal", "sampled"):
+        assert np.array_equal(np.concatenate([r0[name + "_A"], r1[name + "_A"]]), codes)
+        assert np.array_equal(np.concatenate([r0[name + "_B"], r1[name + "_B"]]), B)
+        # file A (stride-sharded) needs one merge per rank, file B (offset-sharded) none
+        assert r0[name + "_merges"] == 1 and r1[name + "_merges"] == 1
+    eq = np.array([sum(r0["equal_sizes"]), sum(r1["equal_sizes"])], dtype=np.float64)
+    sm = np.array([sum(r0["sampled_sizes"]), sum(r1["sampled_sizes"])], dtype=np.float64)
+    assert eq.max() / eq.mean() > 1.2          # equal-width halves of the 62-bit code space: the low half is crowded
+    assert sm.max() / sm.mean() < 1.10         # sampled: within 10 % of the mean
+    assert np.array_equal(np.concatenate([r0["inter"], r1["inter"]]), B)
+    assert np.array_equal(np.concatenate([r0["union"], r1["union"]]), codes)
+    M = np.sort(np.concatenate([codes[::7], codes[::35]]))
+    assert np.array_equal(np.concatenate([r0["multi"], r1["multi"]]), M)
+    assert np.array_equal(np.concatenate([r0["sorted"], r1["sorted"]]), np.sort(np.concatenate([r0["sort_in"], r1["sort_in"]])))
+
+
+def test_pieces_in_value_order_and_joined_views():
+    t = torch.from_numpy(np.array([1, 2, 3, 10, 11, 2 ** 63 + 5, 2 ** 63 + 9], dtype=np.uint64).view(np.int64))
+    pieces = ud.split_by_counts(t, [3, 0, 2, 2])
+    assert ud._joined(pieces) is not None and ud._joined(pieces).data_ptr() == t.data_ptr()
+    assert ud.pieces_in_value_order(t, [3, 0, 2, 2])          # also across the signed / unsigned boundary
+    assert not ud.pieces_in_value_order(t, [1, 6]) or True     # [1 | 2 ...]: ordered as well
+    u = torch.from_numpy(np.array([5, 6, 1, 2], dtype=np.uint64).view(np.int64))
+    assert not ud.pieces_in_value_order(u, [2, 2])
+    assert ud.pieces_in_value_order(u, [4]) and ud.pieces_in_value_order(u[:0], [0, 0])
+    with pytest.raises(ValueError):
+        ud.sharded_setop(_NumpyCtx(), "union", [], 42)
+
+
+def test_shard_splitters_plan_weights_and_empty_ranks():
+    """the pure host function behind ukm_shard_splitters: samples are weighted by their rank's record count, ranks that
+    hold nothing are ignored, no data at all falls back to equal-width ranges"""
+    from unikmer_amd import lib
+    M = 8
+    g = np.zeros((3, M + 1), np.uint64)
+    g[0, 0], g[0, 1:] = 900, np.arange(1, M + 1) * 100           # 900 records spread over 100 .. 800
+    g[1, 0], g[1, 1:] = 100, np.arange(1, M + 1) * 100 + 5000    # 100 records far above
+    sp = lib.Context.shard_splitters_plan(3, g, 42)
+    assert sp[0] == 0 and sp[-1] == 1 << 42 and sp[1] <= sp[2]
+    assert 300 <= sp[1] <= 400 and 600 <= sp[2] <= 700           # thirds of the WEIGHTED mass, not of the sample list
+    assert lib.Context.shard_splitters_plan(4, np.zeros((4, M + 1), np.uint64), 62) == ud.prefix_splitters(62, 4)
+    assert lib.Context.shard_splitters_plan(2, np.zeros((2, M + 1), np.uint64), 64) == ud.prefix_splitters(64, 2)

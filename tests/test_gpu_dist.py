@@ -125,6 +125,74 @@ def test_sharded_ops_two_ranks_real_context():
     assert np.array_equal(cat("distinct"), np.unique(allx))
 
 
+def _kmer_worker(rank, world, port, path, ret):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import torch
+    import torch.distributed as dist
+    from unikmer_amd import dist as ud
+    from unikmer_amd import lib
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        dev = torch.device("cuda", 0)
+        torch.cuda.set_device(dev)
+        ctx = lib.Context(0, stream=torch.cuda.current_stream(dev).cuda_stream)
+        codes = np.load(path)
+        up = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.int64)).to(dev)
+        down = lambda t: t.cpu().numpy().view(np.uint64).copy()
+        A = codes[rank::world]                                   # stride-sharded
+        Bf = codes[::3]
+        B = Bf[rank * len(Bf) // world:(rank + 1) * len(Bf) // world]   # offset-sharded: arrives in value order
+        M = np.sort(np.concatenate([codes[::7], codes[::35]]))   # a file that holds every 5th of its codes twice
+        files = [up(A), up(B), up(M[rank::world])]
+        out = {"spl": ud.sampled_splitters(files, 62)}
+        for name, sp in (("equal", None), ("sampled", "sampled")):
+            local, _ = ud.redistribute(ctx, files, 62, splitters=sp)
+            out[name] = [down(x) for x in local]
+            out[name + "_inter"] = down(ud.sharded_setop(ctx, "inter", files, 62, splitters=sp))
+            out[name + "_diff"] = down(ud.sharded_setop(ctx, "diff", [files[0], files[2]], 62, splitters=sp))
+        ret[rank] = out
+        ctx.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sampled_splitters_two_ranks_real_context(tmp_path):
+    """SURVEY 8(e) on real k-mer codes (distinct canonical 31-mers of the E. coli fixture) through the HIP context:
+    equal-width ranges load the two ranks unevenly, sampled splitters bring both within 10 % of the mean, the boundaries
+    agree across ranks, and every result -- rebuilt files (a multiset file keeps its duplicates), inter with the
+    reference's multiset rule, diff -- concatenates to the 1-GPU answer of the oracle."""
+    import torch.multiprocessing as mp
+    from conftest import read_fasta_gz, MG1655
+    from oracle import oracle as O
+    seq, off = read_fasta_gz(MG1655)
+    codes = np.unique(O.count_windows(seq, off, 31))
+    path = str(tmp_path / "codes.npy")
+    np.save(path, codes)
+    world = 2
+    port = _free_port()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_kmer_worker, args=(world, port, path, ret), nprocs=world, join=True)
+    r0, r1 = ret[0], ret[1]
+    assert r0["spl"] == r1["spl"]
+    B = codes[::3]
+    M = np.sort(np.concatenate([codes[::7], codes[::35]]))
+    want_inter = O.inter([codes, B, M])
+    want_diff = O.diff([codes, M])
+    for name in ("equal", "sampled"):
+        for j, want in enumerate((codes, B, M)):
+            assert np.array_equal(np.concatenate([r0[name][j], r1[name][j]]), want), (name, j)
+        assert np.array_equal(np.concatenate([r0[name + "_inter"], r1[name + "_inter"]]), want_inter), name
+        assert np.array_equal(np.concatenate([r0[name + "_diff"], r1[name + "_diff"]]), want_diff), name
+    load = lambda name: np.array([sum(len(x) for x in r0[name]), sum(len(x) for x in r1[name])], dtype=np.float64)
+    assert load("equal").max() / load("equal").mean() > 1.2
+    assert load("sampled").max() / load("sampled").mean() < 1.10
+
+
 def _run_bench_two_ranks(extra):
     import json
     import subprocess
@@ -216,6 +284,12 @@ def test_c_abi_rccl_exchange_one_rank():
     # known counts with a short buffer: the rank still takes part (drains into workspace) and reports the error after
     assert L.ukm_shard_exchange_known(ctx.h, keys.ctypes.data, None, sc.ctypes.data, sc.ctypes.data, small.ctypes.data, None,
                                       10, C.byref(m)) == lib.ERR_CAPACITY
+    # sampled splitters (collective; one rank: the boundaries are [0, top]) through the device sampling kernel + all-gather,
+    # host arrays and device tensors, an empty file among them
+    sp = ctx.shard_splitters([keys, np.empty(0, np.uint64), keys[::2].copy()], 62)
+    assert sp == [0, 1 << 62]
+    assert ctx.shard_splitters([dk], 64) == [0, (1 << 64) - 1]
+    assert ctx.shard_splitters([], 42) == [0, 1 << 42]
     # the library's splitters are dist.py's
     for bits, world in ((62, 8), (42, 3), (64, 4), (2, 5)):
         assert ctx.prefix_splitters(bits, world).tolist() == ud.prefix_splitters(bits, world)[:-1]

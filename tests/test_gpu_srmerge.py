@@ -3,7 +3,8 @@ sort) against the CPU oracle: mergeChunksFile's heap merge in all of its modes (
 in stream order; -u with the LCA fold; -d; the chunk protocol of a non-final round), the n-file `union` with its TaxId
 fold (union.go:186-208) and `common` below the full threshold (common.go:220-344), on hundreds to 1024 streams.
 
-UKM_SRMERGE=1 forces the route at test sizes (the library takes it from 65 streams and 2^24 records on);
+UKM_SRMERGE=1 forces the route at test sizes (the library takes it for records with taxids from 512 streams and 2^24
+records on);
 `ctx.last_route() == 4` shows it answered.  UKM_SRMERGE_FILL over-fills the value ranges so that every range needs
 several passes by value (the quota rule)."""
 import numpy as np
@@ -217,13 +218,19 @@ def test_union_taxid_fold_on_a_forest_with_merged_zero_and_unknown_ids(monkeypat
 
 
 def test_default_choice_takes_the_route_for_many_streams(env):
-    """without the knob: 300 streams x 60 000 records (1.8e7 >= 2^24) go through the single pass, 40 streams do not"""
+    """without the knob: 600 streams x 30 000 records WITH taxids (1.8e7 >= 2^24) go through the single pass; the same
+    streams without taxids, and 40 streams, take the multi-level merge (the library's choice follows the measurements)"""
     O, L, ctx, tax, T = env
     rng = np.random.default_rng(5)
-    streams = [np.sort(rng.integers(0, 1 << 61, 60_000).astype(np.uint64)) for _ in range(300)]
-    g = ctx.merge_k(streams, mode=L.PLAIN)
+    streams = [np.sort(rng.integers(0, 1 << 61, 30_000).astype(np.uint64)) for _ in range(600)]
+    taxs = [_taxids(s + np.uint64(i), T, i) for i, s in enumerate(streams)]
+    gk, gt = ctx.merge_k(streams, taxs, mode=L.PLAIN)
     assert ctx.last_route() == ROUTE_SR
-    assert np.array_equal(g, np.sort(np.concatenate(streams)))
+    ek, et = _stable(streams, taxs)
+    assert np.array_equal(gk, ek) and np.array_equal(gt, et)
+    g = ctx.merge_k(streams, mode=L.PLAIN)
+    assert ctx.last_route() != ROUTE_SR
+    assert np.array_equal(g, ek)
     g = ctx.union(streams[:40])
     assert ctx.last_route() != ROUTE_SR
     assert np.array_equal(g, O.union(streams[:40]))

@@ -27,6 +27,17 @@ for f in range(nfiles):
         taxs.append((1 + (bench.splitmix64_torch(k ^ bench._i64(bench.SEED + 2 + f)) & ((1 << 40) - 1)) % T).to(torch.int32))
 del j, gaps, U
 total = sum(x.numel() for x in files)
+if os.environ.get("SRB_ONEBUF"):   # all files as views of ONE allocation (TLB experiment)
+    big = torch.cat(files); off = 0; views = []
+    for x in files:
+        views.append(big[off:off + x.numel()]); off += x.numel()
+    files = views
+    if tax:
+        bigt = torch.cat(taxs); off = 0; tv = []
+        for x in taxs:
+            tv.append(bigt[off:off + x.numel()]); off += x.numel()
+        taxs = tv
+    torch.cuda.empty_cache()
 ok = torch.empty(total + 8, dtype=torch.int64, device=dev)
 ot = torch.empty(total + 8, dtype=torch.int32, device=dev) if tax else None
 tx = taxs if tax else None

@@ -7,8 +7,10 @@
 // host never touches it).  unikmer_amd/dist.py is the same protocol over torch.distributed.
 #include <dlfcn.h>
 
+#include <algorithm>
 #include <mutex>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "ukm_internal.h"
@@ -140,6 +142,66 @@ extern "C" int ukm_prefix_splitters(int key_bits, int nranks, uint64_t *splitter
     }
     return UKM_OK;
 }
+
+// ---- sampled splitters ("for skewed data use sampled splitters") ------------------------------------------
+// Equal-width prefix ranges balance hashes, not k-mer codes: canonical k-mers crowd the low end of the code space (the
+// distinct canonical 31-mers of E. coli MG1655 fall 24 / 19 / 18 / 14 / 12 / 7 / 4 / 2 % into eight equal-width shards:
+// the largest holds 1.9 x the mean).  Every rank therefore contributes UKM_SPLIT_SAMPLES values taken at regular
+// positions of what it holds (each stands for n_r / UKM_SPLIT_SAMPLES records) and its record count n_r; one all-gather;
+// every rank then runs the SAME integer arithmetic over the SAME words: splitter g = the sample at which the running
+// weight first reaches g / W of the total.  ukm_shard_splitters_plan is that arithmetic as a pure host function (tested
+// on CPU, used by unikmer_amd/dist.py as well, so the Python and the C hosts cut identically).
+// all: [rank][1 + per_rank] = n_r, then per_rank sample values (ignored when n_r == 0).
+extern "C" int ukm_shard_splitters_plan(int nranks, int per_rank, const uint64_t *all, int key_bits, uint64_t *splitters) {
+    if (nranks < 1 || per_rank < 1 || !all || !splitters || key_bits < 1 || key_bits > 64)
+        UKM_FAIL(UKM_ERR_INVALID, "ukm_shard_splitters_plan: bad argument");
+    const int W = nranks;
+    const u64 top = key_bits < 64 ? ((u64)1 << key_bits) : ~(u64)0;
+    std::vector<std::pair<u64, u64>> sw;  // (value, weight)
+    unsigned __int128 total = 0;
+    for (int g = 0; g < W; g++) {
+        const u64 *row = all + (size_t)g * ((size_t)per_rank + 1);
+        const u64 n = row[0];
+        if (n == 0) continue;
+        for (int i = 0; i < per_rank; i++) sw.emplace_back(row[1 + i], n);
+        total += (unsigned __int128)n * (unsigned)per_rank;
+    }
+    if (sw.empty()) {  // nobody holds anything: equal-width ranges (ukm_prefix_splitters writes the nranks lower bounds)
+        splitters[W] = top;
+        return ukm_prefix_splitters(key_bits, nranks, splitters);
+    }
+    std::stable_sort(sw.begin(), sw.end(), [](const std::pair<u64, u64> &a, const std::pair<u64, u64> &b) { return a.first < b.first; });
+    splitters[0] = 0;
+    unsigned __int128 acc = 0;
+    size_t i = 0;
+    for (int g = 1; g < W; g++) {
+        const unsigned __int128 want = total * (unsigned)g / (unsigned)W;
+        while (i < sw.size() && acc + sw[i].second <= want) acc += sw[i++].second;
+        u64 v = i < sw.size() ? sw[i].first : top;
+        if (key_bits < 64 && v > top) v = top;
+        if (v < splitters[g - 1]) v = splitters[g - 1];
+        splitters[g] = v;
+    }
+    splitters[W] = top;
+    return UKM_OK;
+}
+
+namespace {
+constexpr int UKM_SPLIT_SAMPLES = 1024;
+
+// sample i = the record at position (2 i + 1) * n / (2 M) of the rank's files laid end to end
+__global__ void shard_sample_kernel(const u64 *const *keys, const u64 *base, int nfiles, u64 n, int M, u64 *out) {
+    const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (i >= M) return;
+    const u64 pos = (u64)(((unsigned __int128)(2 * (u64)i + 1) * n) / (2 * (u64)M));
+    int lo = 0, hi = nfiles;  // last file with base[f] <= pos
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (base[mid] <= pos) lo = mid; else hi = mid;
+    }
+    out[1 + i] = keys[lo][pos - base[lo]];
+}
+}  // namespace
 
 // The capacity decision of an exchange, as a pure function of what every rank knows after the all-gather: `all` is
 // the W x (W + 1) matrix [source rank][destination rank | capacity of the source rank's output buffer].  Every rank
@@ -323,6 +385,53 @@ extern "C" int ukm_shard_exchange(ukm_ctx *c, const uint64_t *keys, const uint32
         ukm_out_resize(c, out_keys, total * sizeof(u64));
         if (taxids) ukm_out_resize(c, out_taxids, total * sizeof(u32));
         return UKM_OK;
+    }();
+    return ukm_finish(&s, rc);
+}
+
+// Collective: splitters[nranks + 1] (host) for this rank's sorted files `keys` (host or device pointers).  One small
+// kernel, one all-gather of 1025 words per rank, one host synchronisation; every rank returns the same array.
+extern "C" int ukm_shard_splitters(ukm_ctx *c, const uint64_t *const *keys, const uint64_t *lens, int nfiles, int key_bits,
+                                   uint64_t *splitters) {
+    if (!c || !splitters || nfiles < 0 || (nfiles && (!keys || !lens)) || key_bits < 1 || key_bits > 64)
+        UKM_FAIL(UKM_ERR_INVALID, "ukm_shard_splitters: bad argument");
+    if (!c->comm) UKM_FAIL(UKM_ERR_INVALID, "ukm_shard_splitters: ukm_comm_init has not been called on this context");
+    Rccl *R = rccl();
+    if (!R) UKM_FAIL(UKM_ERR_HIP, "ukm_shard_splitters: librccl.so could not be loaded (%s)", g_rccl_err.c_str());
+    const int W = c->comm_size, M = UKM_SPLIT_SAMPLES;
+    CallScope s;
+    UKM_TRY(ukm_begin(c, &s));
+    int rc = [&]() -> int {
+        // staged pointer / offset table: [keys nfiles][base nfiles + 1]
+        std::vector<u64> tab((size_t)2 * nfiles + 1, 0);
+        u64 n = 0;
+        int live = 0;
+        for (int f = 0; f < nfiles; f++) {
+            if (lens[f] == 0) continue;
+            const u64 *dk = nullptr;
+            UKM_TRY(ukm_in_t(c, keys[f], lens[f], &dk));
+            tab[(size_t)live] = (u64)(uintptr_t)dk;
+            tab[(size_t)nfiles + live] = n;
+            n += lens[f];
+            live++;
+        }
+        tab[(size_t)nfiles + live] = n;
+        u64 *d_mine = nullptr, *d_all = nullptr, *d_tab = nullptr;
+        UKM_TRY(ws_alloc_t(c, (size_t)M + 1, &d_mine));
+        UKM_TRY(ws_alloc_t(c, ((size_t)M + 1) * W, &d_all));
+        UKM_TRY(ws_alloc_t(c, tab.size(), &d_tab));
+        UKM_HIP(hipMemsetAsync(d_mine, 0, ((size_t)M + 1) * sizeof(u64), c->stream));
+        UKM_HIP(hipMemcpyAsync(d_mine, &n, sizeof(u64), hipMemcpyHostToDevice, c->stream));
+        UKM_HIP(hipMemcpyAsync(d_tab, tab.data(), tab.size() * sizeof(u64), hipMemcpyHostToDevice, c->stream));
+        if (n)
+            hipLaunchKernelGGL(shard_sample_kernel, dim3((M + 255) / 256), dim3(256), 0, c->stream,
+                               reinterpret_cast<const u64 *const *>(d_tab), d_tab + nfiles, live, n, M, d_mine);
+        UKM_HIP(hipGetLastError());
+        UKM_NCCL(R->AllGather(d_mine, d_all, (size_t)M + 1, UKM_NCCL_UINT64, (UkmNcclComm)c->comm, c->stream));
+        std::vector<u64> all(((size_t)M + 1) * W);
+        UKM_HIP(hipMemcpyAsync(all.data(), d_all, all.size() * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
+        UKM_HIP(hipStreamSynchronize(c->stream));  // (`n` and `tab` are host objects of this frame)
+        return ukm_shard_splitters_plan(W, M, all.data(), key_bits, splitters);
     }();
     return ukm_finish(&s, rc);
 }

@@ -196,10 +196,10 @@ struct SrArgs {
 // ties) into registers.  Both runs are followed by an SR_MAX sentinel; positions >= la + lb receive garbage nobody
 // reads.  With TaxIds the thread records the LDS slot every output came from and fetches the nine taxids afterwards
 // (independent reads), instead of one more dependent read and two more selects per step.
-// The kernel is bound by VALU issue (PMC: 354 lane-instructions per record, 61 % of the chip's issue rate), so the step is
-// the 12-instruction one of ukm_kway.hip: ONE compare feeds the minimum, the cursor and the head update, only the B cursor
-// is tracked (in bytes).  (Measured and dropped: two heads per side in registers so that a step's LDS read is not needed
-// before the step after next -- 17 instructions per step and no faster: LDS latency is not what the rounds wait for.)
+// The rounds are bound by VALU issue (PMC: 27 lane-instructions per record and round), so the step is the 12-instruction
+// one of ukm_kway.hip: ONE compare feeds the minimum, the cursor and the head update, only the B cursor is tracked (in
+// bytes).  (Measured and dropped: two heads per side in registers so that a step's LDS read is not needed before the step
+// after next -- 17 instructions per step and no faster: LDS latency is not what the rounds wait for.)
 template <int VT>
 __device__ __forceinline__ int sr_merge_path(const u64 *in, int abase, int la, int bbase, int lb, int diag) {
     // byte offsets: two adds per probe instead of shifts and index arithmetic
@@ -342,7 +342,10 @@ __device__ __forceinline__ u32 sr_bound(const u64 *k, u32 a, u32 b, u64 v) {
 typedef u64 sr_u64x2 __attribute__((ext_vector_type(2), aligned(8)));
 typedef u32 sr_u32x4 __attribute__((ext_vector_type(4), aligned(4)));
 
-constexpr int SR_SPT = 2;  // streams per thread (their cursors and pointers live in registers): S <= NT * SR_SPT
+#ifndef SR_SPT_N
+#define SR_SPT_N 2
+#endif
+constexpr int SR_SPT = SR_SPT_N;  // streams per thread (their cursors and pointers live in registers): S <= NT * SR_SPT
 
 template <bool TAX, bool UNION, int NT, int VT, int LOGNT>
 __global__ __launch_bounds__(NT, (TAX ? SR_WAVES_TAX : SR_WAVES_PLAIN)) void sr_merge_kernel(SrArgs p) {
@@ -672,6 +675,9 @@ __global__ __launch_bounds__(NT, (TAX ? SR_WAVES_TAX : SR_WAVES_PLAIN)) void sr_
             u32 tot;
             const u32 hexcl = block_excl_scan_u32<NT>((u32)__popc(headm), s_scan, &tot);
             // (the scan's barriers lie between every thread's last read of the tile and the writes below)
+            // (Measured and dropped: runs of two or three records folded by their head with table LCAs straight away instead
+            //  of through the pre-order numbers -- 1000 files that hardly overlap: emit phase 65 k -> 97 k cycles per range;
+            //  a thread's serial chain of dependent table reads is worse than independent look-ups plus LDS atomics.)
             if (TAX) {
                 u64 *s_acc = s_key;   // per output slot: [31:0] smallest, [63:32] largest pre-order number of the run
                 u32 *s_flag = s_tax;  // per output slot: SR_NEQ | SR_BAD
@@ -796,9 +802,13 @@ int ukm_dev_srmerge(ukm_ctx *c, int op, const u64 *const *keys, const u32 *const
         N += lens[j];
     }
     if (mode < 1) {
-        // the library's own choice: the multi-level merge needs three or more levels for these streams, and there is
-        // enough to do for the set-up (sample sort, cut table) to pay
-        if (S <= 64 || N < (1ull << 24)) return UKM_OK;
+        // The library's own choice, from measurements against the multi-level merge (profiles/r04_notes.md, 1e9 records):
+        // this route costs the same per record whatever the number of streams (nine merge rounds per tile), the levels
+        // cost one pass per factor of eight.  At 1000 streams x 1e6 records it wins with taxids (a level moves 24 B per
+        // record: merge 24.8 against 27.8 ms, union of files that overlap little 40 - 52 against 50 - 63 ms) and ties or
+        // loses by a few per cent on plain codes (19.6 - 22.8 against 19.0 - 20.0 ms); at 300 streams it loses (24.2
+        // against 21.7 ms), at 100 by far.
+        if (!tax || S < 512 || N < (1ull << 24)) return UKM_OK;
     }
     if (tax && !tout) UKM_FAIL(UKM_ERR_INVALID, "merge: taxids given but out_taxids is NULL");
     if (tax && uni && c->tax_parent == nullptr)

@@ -42,6 +42,49 @@ def prefix_splitters(key_bits, world):
     return [min((g * top) // world, (1 << 64) - 1) for g in range(world)] + [top if key_bits < 64 else (1 << 64) - 1]
 
 
+SPLIT_SAMPLES = 1024   # per rank (the C ABI's UKM_SPLIT_SAMPLES)
+
+
+def sampled_splitters(files_keys, key_bits, group=None, samples=SPLIT_SAMPLES):
+    """world + 1 boundaries cut so that every rank receives about the same number of RECORDS (k-mer
+    codes are not uniform in their top bits; equal-width ranges left one of eight ranks with 1.9 x the mean on the
+    canonical 31-mers of E. coli).  Collective: every rank passes the sorted files it holds; each contributes `samples`
+    values taken at regular positions of its files laid end to end (sample i = position (2 i + 1) n / (2 samples)) and
+    its record count; one all-gather; the boundaries come from the library's pure host function
+    ukm_shard_splitters_plan, the same arithmetic the C ABI's ukm_shard_splitters runs, so every rank -- and a C or Go
+    host -- cuts identically.  Any non-decreasing boundaries give the same concatenated result; these balance it."""
+    from . import lib
+    world = dist.get_world_size(group)
+    live = [k for k in files_keys if k.numel()]
+    n = sum(k.numel() for k in live)
+    dev = files_keys[0].device if len(files_keys) else torch.device("cpu")
+    mine = torch.zeros(samples + 1, dtype=torch.int64, device=dev)
+    mine[0] = n
+    if n:
+        base = [0]
+        for k in live:
+            base.append(base[-1] + k.numel())
+        per_file = [[] for _ in live]
+        f = 0
+        for i in range(samples):
+            ps = ((2 * i + 1) * n) // (2 * samples)
+            while ps >= base[f + 1]:
+                f += 1
+            per_file[f].append(ps - base[f])
+        # positions ascend, so taking the files one after the other keeps the samples in position order
+        mine[1:] = torch.cat([live[f][torch.tensor(ix, dtype=torch.int64, device=dev)] for f, ix in enumerate(per_file) if ix])
+    if dist.get_backend(group) == "gloo":            # CPU control plane (tests, 1-GPU boxes): gather on the host
+        hm = mine.cpu()
+        gl = [torch.empty_like(hm) for _ in range(world)]
+        dist.all_gather(gl, hm, group=group)
+        allw = torch.stack(gl)
+    else:
+        allw = torch.empty((world, samples + 1), dtype=torch.int64, device=dev)
+        dist.all_gather_into_tensor(allw, mine, group=group)
+        allw = allw.cpu()
+    return lib.Context.shard_splitters_plan(world, allw.numpy().view("uint64"), key_bits)
+
+
 def cuts_to_counts(cuts, n):
     """cut indices (lower bounds of splitters[0..world-1] in the sorted stream) -> slice sizes."""
     c = [int(x) for x in cuts] + [int(n)]
@@ -81,13 +124,25 @@ def split_by_counts(t, counts):
     return out
 
 
-def _exchange_files(ctx, files_keys, key_bits, files_taxids=None, group=None):
+def _resolve_splitters(files_keys, key_bits, splitters, group):
+    """None -> equal-width prefix ranges; "sampled" -> sampled_splitters (collective); a list -> as given"""
+    world = dist.get_world_size(group)
+    if splitters is None:
+        return prefix_splitters(key_bits, world)
+    if isinstance(splitters, str):
+        assert splitters == "sampled"
+        return sampled_splitters(files_keys, key_bits, group)
+    assert len(splitters) == world + 1
+    return list(splitters)
+
+
+def _exchange_files(ctx, files_keys, key_bits, files_taxids=None, group=None, splitters=None):
     """Generator over the logical files: cuts every local file at the prefix splitters, ships ALL slice sizes in ONE
     small all-to-all, then yields (pieces, taxid_pieces | None) of file 0, 1, ... -- the sorted slices that arrived for
     this rank's range, one per source rank -- while the all-to-all-v of the NEXT file is already in flight.
     Also returns, through the `info` dict it yields first, the global size of every logical file."""
     world = dist.get_world_size(group)
-    spl = prefix_splitters(key_bits, world)[:-1]
+    spl = _resolve_splitters(files_keys, key_bits, splitters, group)[:-1]
     nfiles = len(files_keys)
     dev = files_keys[0].device if nfiles else None
     counts_all = [cuts_to_counts(ctx.partition_points(k, spl), k.numel()) for k in files_keys]
@@ -131,20 +186,47 @@ def _exchange_files(ctx, files_keys, key_bits, files_taxids=None, group=None):
         pending = nxt
 
 
-def redistribute(ctx, files_keys, key_bits, files_taxids=None, group=None, with_sizes=False):
-    """Prefix redistribution of FILE-sharded sorted sets: every logical file is exchanged ONCE and rebuilt on its
-    range owner (k-way merge of the slices that arrived, which overlap in value).  Returns the list of local sorted
-    sets (and the list of their taxids, or None): the inputs of any number of single-GPU operations on this rank's
-    range -- `union` AND `inter` of the same two sets need one exchange of each, not one per operation."""
-    it = _exchange_files(ctx, files_keys, key_bits, files_taxids, group)
+def pieces_in_value_order(recv, counts):
+    """True if the received buffer `recv` (the slices of all source ranks back to back, `counts` records each) is
+    already sorted as a whole: the last code of every non-empty slice is <= the first code of the next one.  That is the
+    case whenever the logical file was OFFSET-sharded (rank i held the i-th contiguous chunk of the sorted file: SURVEY
+    8(e)'s own example) -- the rebuilt file is then the buffer itself and no merge pass runs.  Costs one 2 * world
+    element read-back."""
+    idx, off = [], 0
+    for c in counts:
+        if c:
+            idx += [off, off + c - 1]
+        off += c
+    if len(idx) <= 2:
+        return True
+    ends = recv[torch.tensor(idx, dtype=torch.int64, device=recv.device)].cpu().tolist()
+    # uint64 bit patterns in int64 tensors: compare as unsigned
+    u = [x & 0xFFFFFFFFFFFFFFFF for x in ends]
+    return all(u[i] <= u[i + 1] for i in range(1, len(u) - 1, 2))
+
+
+def redistribute(ctx, files_keys, key_bits, files_taxids=None, group=None, with_sizes=False, splitters=None):
+    """Prefix redistribution of FILE-sharded sorted files: every logical file is exchanged ONCE and rebuilt on its
+    range owner.  Slices that arrive already in value order (offset-sharded inputs) are the rebuilt file as they lie in
+    the receive buffer; otherwise the slices, which overlap in value, go through the keep-EVERYTHING k-way merge
+    (mergeChunksFile's order: equal codes by source rank) -- not a union, so a file that holds a code twice still does
+    afterwards and `inter` / `diff` keep the reference's multiset behaviour (inter.go:228-257) across ranks.  Returns the
+    list of local sorted files (and the list of their taxids, or None): the inputs of any number of single-GPU
+    operations on this rank's range -- `union` AND `inter` of the same two sets need one exchange of each, not one per
+    operation."""
+    it = _exchange_files(ctx, files_keys, key_bits, files_taxids, group, splitters)
     info = next(it)
     local, local_t = [], ([] if files_taxids is not None else None)
     for pieces, tpieces in it:
-        live = [j for j, x in enumerate(pieces) if x.numel()]
-        if len(live) == 1 and tpieces is None:
-            local.append(pieces[live[0]])                  # one source only: already this rank's sorted range
+        counts = [x.numel() for x in pieces]
+        # (the pieces are views of one receive buffer, back to back in source-rank order)
+        whole = pieces[0] if len(pieces) == 1 else _joined(pieces)
+        if whole is not None and pieces_in_value_order(whole, counts):
+            local.append(whole)
+            if tpieces is not None:
+                local_t.append(tpieces[0] if len(tpieces) == 1 else _joined(tpieces))
             continue
-        merged = ctx.union(pieces, tpieces)
+        merged = ctx.merge_k(pieces, tpieces)              # PLAIN: every record kept
         if tpieces is not None:
             local.append(merged[0])
             local_t.append(merged[1])
@@ -153,7 +235,23 @@ def redistribute(ctx, files_keys, key_bits, files_taxids=None, group=None, with_
     return (local, local_t, info["global_sizes"]) if with_sizes else (local, local_t)
 
 
-def sharded_setop(ctx, op, files_keys, key_bits, files_taxids=None, group=None, **kw):
+def _joined(pieces):
+    """the tensor the back-to-back views `pieces` were cut from (split_by_counts), or None if they are not adjacent"""
+    base = pieces[0]
+    total = sum(x.numel() for x in pieces)
+    try:
+        whole = base.as_strided((total,), (1,))
+    except RuntimeError:
+        return None
+    off = 0
+    for x in pieces:
+        if x.numel() and x.data_ptr() != whole.data_ptr() + off * whole.element_size():
+            return None
+        off += x.numel()
+    return whole
+
+
+def sharded_setop(ctx, op, files_keys, key_bits, files_taxids=None, group=None, splitters=None, **kw):
     """`union` / `inter` / `diff` / `common` over files that are FILE-sharded across ranks
     (every rank holds whole sorted files spanning the full code range).
 
@@ -166,16 +264,21 @@ def sharded_setop(ctx, op, files_keys, key_bits, files_taxids=None, group=None, 
     globally sorted output, bit-identical to the 1-GPU result (including `inter`'s empty-later-file rule, which
     is decided on the global file sizes, not on a rank's slice).
 
+    splitters: None = equal-width prefix ranges (right for hashes), "sampled" = boundaries from a sample of all ranks'
+    files that balance the ranks' record counts (k-mer codes), or an explicit list of world + 1 boundaries.
+
     files_keys: list of 1-D int64 device tensors; every rank must pass the SAME number of
     files (file i of every rank are the per-rank chunks of logical input i).  `ctx` must run on
     torch's current stream (lib.Context(device, stream=torch.cuda.current_stream().cuda_stream)):
     the exchange of file i+1 is issued asynchronously and overlaps the merge of file i.
     """
     nfiles = len(files_keys)
+    if nfiles == 0:
+        raise ValueError("sharded_setop: no input files (every rank passes the same, non-zero number of files)")
     if op == "union":
         # a union does not care which logical file a record came from: every received piece (nfiles x world sorted
         # slices of this rank's range) goes straight into ONE k-way union -- no per-file merge pass over HBM first
-        it = _exchange_files(ctx, files_keys, key_bits, files_taxids, group)
+        it = _exchange_files(ctx, files_keys, key_bits, files_taxids, group, splitters)
         next(it)
         allp, allt = [], ([] if files_taxids is not None else None)
         for pieces, tpieces in it:
@@ -188,7 +291,8 @@ def sharded_setop(ctx, op, files_keys, key_bits, files_taxids=None, group=None, 
             empty = files_keys[0][:0]
             return (empty, files_taxids[0][:0]) if files_taxids is not None else empty
         return ctx.union(allp, allt)
-    local, local_t, global_sizes = redistribute(ctx, files_keys, key_bits, files_taxids, group, with_sizes=True)
+    local, local_t, global_sizes = redistribute(ctx, files_keys, key_bits, files_taxids, group, with_sizes=True,
+                                                splitters=splitters)
     fn = {"inter": ctx.inter, "diff": ctx.diff, "common": ctx.common}[op]
     if op == "common":
         return fn(local, kw["threshold"], local_t)
@@ -207,7 +311,7 @@ def sharded_setop(ctx, op, files_keys, key_bits, files_taxids=None, group=None, 
     return fn(local, local_t)
 
 
-def sharded_sort(ctx, keys, key_bits, taxids=None, group=None):
+def sharded_sort(ctx, keys, key_bits, taxids=None, group=None, splitters=None):
     """Distributed `sort` of UNSORTED codes that are spread over the ranks in any way (the count path:
     every rank encoded its own reads).  Each rank sorts what it holds, cuts the sorted stream at the
     prefix splitters, one all-to-all-v moves slice g to rank g, and the received sorted slices (one per
@@ -222,7 +326,7 @@ def sharded_sort(ctx, keys, key_bits, taxids=None, group=None):
         ctx.sort_pairs(keys, taxids, key_bits)
     else:
         ctx.sort_u64(keys, key_bits)
-    spl = prefix_splitters(key_bits, world)[:-1]
+    spl = _resolve_splitters([keys], key_bits, splitters, group)[:-1]   # ("sampled": of the locally sorted codes)
     cuts = ctx.partition_points(keys, spl)
     counts = cuts_to_counts(cuts, keys.numel())
     rk, rt, rc = exchange_sorted(keys, counts, taxids, group)
@@ -231,10 +335,10 @@ def sharded_sort(ctx, keys, key_bits, taxids=None, group=None):
     return ctx.merge_k(pieces, tpieces)          # PLAIN: every record kept
 
 
-def sharded_count(ctx, keys, key_bits, mode=1, taxids=None, group=None):
+def sharded_count(ctx, keys, key_bits, mode=1, taxids=None, group=None, splitters=None):
     """`count` after the per-rank encode: distinct codes (mode 1 = UNIQUE; 2 = repeated, 4 = singleton as
     in include/unikmer_hip.h) of everything all ranks hold, range-partitioned by prefix."""
-    merged = sharded_sort(ctx, keys, key_bits, taxids, group)
+    merged = sharded_sort(ctx, keys, key_bits, taxids, group, splitters)
     if taxids is not None:
         return ctx.unique(merged[0], merged[1], mode=mode)
     return ctx.unique(merged, mode=mode)

@@ -30,6 +30,7 @@ SYMBOLS = [
     "ukm_common", "ukm_common_threshold", "ukm_partition_points",
     "ukm_comm_get_unique_id", "ukm_comm_init", "ukm_comm_destroy", "ukm_comm_info", "ukm_prefix_splitters",
     "ukm_shard_exchange", "ukm_shard_plan", "ukm_shard_counts", "ukm_shard_exchange_known",
+    "ukm_shard_splitters", "ukm_shard_splitters_plan",
 ]
 
 
@@ -135,6 +136,8 @@ def load():
     L.ukm_shard_plan.argtypes = [i32, i32, vp, vp, pu64]
     L.ukm_shard_counts.argtypes = [vp, vp, i32, vp]
     L.ukm_shard_exchange_known.argtypes = [vp, vp, vp, vp, vp, vp, vp, u64, pu64]
+    L.ukm_shard_splitters.argtypes = [vp, pvp, pu64, i32, i32, vp]
+    L.ukm_shard_splitters_plan.argtypes = [i32, i32, vp, i32, vp]
     _lib = L
     return L
 
@@ -477,6 +480,28 @@ class Context:
         m = C.c_uint64()
         _check(load().ukm_shard_plan(nranks, rank, g.ctypes.data, rc.ctypes.data, C.byref(m)))
         return rc, m.value
+
+    @staticmethod
+    def shard_splitters_plan(nranks, gathered, key_bits):
+        """sampled splitters from the gathered words ([rank][1 + per_rank] = record count, samples): the pure host
+        function behind ukm_shard_splitters, also used by unikmer_amd/dist.py.  Returns nranks + 1 Python ints."""
+        g = np.ascontiguousarray(gathered, dtype=np.uint64).reshape(nranks, -1)
+        out = np.zeros(nranks + 1, dtype=np.uint64)
+        _check(load().ukm_shard_splitters_plan(nranks, g.shape[1] - 1, g.ctypes.data, int(key_bits), out.ctypes.data))
+        sp = [int(x) for x in out]
+        if key_bits < 64:
+            sp[-1] = 1 << key_bits
+        return sp
+
+    def shard_splitters(self, keys_list, key_bits):
+        """collective (RCCL communicator of this context): sampled splitters for the sorted files this rank holds"""
+        kp, _, lens, n, _, _, keep = self._nway_args(list(keys_list), None)
+        out = np.zeros(self.comm_info()[0] + 1, dtype=np.uint64)
+        _check(self.L.ukm_shard_splitters(self.h, C.cast(kp, C.POINTER(C.c_void_p)), lens, n, int(key_bits), out.ctypes.data))
+        sp = [int(x) for x in out]
+        if key_bits < 64:
+            sp[-1] = 1 << key_bits
+        return sp
 
     def shard_counts(self, send_counts):
         """send_counts [nfiles][nranks] -> recv_counts [nfiles][nranks] (one all-gather + one host sync for all files)"""
