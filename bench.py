@@ -16,7 +16,9 @@ N > 1: the code space is sharded by high-bits prefix.  `value` is the job END TO
 FILE-sharded state (a stride sample of both global sets), cuts both at the prefix splitters, exchanges each set ONCE
 (RCCL all-to-all-v over xGMI, unikmer_amd/dist.py), k-way merges what arrived and runs union + inter on its range --
 that figure is bounded by xGMI, not HBM.  `value_prepartitioned` is the same job on inputs that
-already sit on their range owners (no data-path collective); `exchange` is one bare all-to-all-v.  --scaling weak (default):
+already sit on their range owners (no data-path collective); `value_offset_sharded_start` the end-to-end job from an
+OFFSET-sharded start (rank r holds the r-th contiguous chunk of each sorted set: the slices arrive in value order and are
+not merged); `exchange` is one bare all-to-all-v.  --scaling weak (default):
 --set-size k-mers per set PER GPU; --scaling strong: in total (the metric's wording).
 """
 import argparse
@@ -397,6 +399,47 @@ def main():
                     "ms_per_step": t1 * 1e3 / args.steps,
                     "note": "file-sharded start -> cut at the prefix splitters -> one all-to-all-v per input set -> k-way merge "
                             "of the received slices -> union + inter on the rank's range (each input is exchanged once per step)"}
+            # The same job from an OFFSET-sharded start (rank r holds the r-th contiguous chunk of each globally sorted
+            # set: what a rank has after reading its share of one sorted file, SURVEY 8(e)'s example).  The slices that
+            # arrive are already in value order, so dist.redistribute hands back the receive buffer and no merge pass
+            # runs; with uniform synthetic codes nearly everything already sits on its range owner, so this leg shows the
+            # floor of the end-to-end step (cuts + a near-empty all-to-all-v + union + inter).
+            try:
+                def offset_shard(X):
+                    sizes = [0] * world
+                    sizes[rank] = X.numel()
+                    tot = sum_over_ranks(sizes)                     # every rank's range size
+                    first, N = sum(tot[:rank]), sum(tot)
+                    counts = []
+                    for r in range(world):                          # records of mine inside chunk r = [r N / W, (r + 1) N / W)
+                        lo_r, hi_r = r * N // world, (r + 1) * N // world
+                        counts.append(max(0, min(hi_r, first + X.numel()) - max(lo_r, first)))
+                    full, _, _ = ud.exchange_sorted(X, counts)
+                    return full
+                Ao, Bo = offset_shard(A), offset_shard(B)
+
+                def step_off():
+                    (Al, Bl), _ = ud.redistribute(ctx, [Ao, Bo], 62)
+                    u = ctx.setop2(lib.OP_UNION, Al, Bl, out=out_u)
+                    i = ctx.setop2(lib.OP_INTER, Al, Bl, out=out_i)
+                    return Al, Bl, u, i
+                Al, Bl, ou, oi = step_off()
+                assert torch.equal(Al, A) and torch.equal(Bl, B), "offset-sharded redistribution did not rebuild the rank's range"
+                assert ou.numel() == nu and oi.numel() == ni
+                del Al, Bl
+                barrier()
+                t2 = time.perf_counter()
+                for _ in range(args.steps):
+                    step_off()
+                barrier()
+                t2 = max_over_ranks(time.perf_counter() - t2)
+                incl["offset_sharded_start"] = {
+                    "value": 2.0 * g_in * args.steps / t2, "unit": "k-mers/s", "ms_per_step": t2 * 1e3 / args.steps,
+                    "note": "rank r starts with the r-th contiguous chunk of each sorted set: the received slices are in "
+                            "value order and are used as they lie in the receive buffer (no merge pass)"}
+                del Ao, Bo
+            except Exception as e:
+                incl["offset_sharded_start"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
             # the bare all-to-all-v of one set, for the link rate
             counts = ud.cuts_to_counts(ctx.partition_points(Af, spl), Af.numel())
             barrier()
@@ -429,6 +472,8 @@ def main():
                 res["value_is"] = "end to end, including the prefix redistribution (all-to-all-v) of both inputs in every step"
                 res["value_incl_exchange"] = incl["value"]
                 res["incl_exchange"] = incl
+                if "value" in incl.get("offset_sharded_start", {}):
+                    res["value_offset_sharded_start"] = incl["offset_sharded_start"]["value"]
             else:
                 res["value_is"] = ("PRE-PARTITIONED (no redistribution in the timed region): " +
                                    ("--no-exchange was given" if args.no_exchange else "the end-to-end leg failed, see `exchange`"))

@@ -108,7 +108,11 @@ int ukm_last_route(ukm_ctx *ctx);
  *      (util.go:119-171; 14 taxondb.LCA call sites).
  *      child/parent = the first two columns of nodes.dmp; merged_* = merged.dmp (may be NULL).
  *      Contract (taxdump parity is unpinned): LCA(0,x)=LCA(x,0)=0; LCA(x,x)=x;
- *      merged ids are remapped; ids absent from nodes.dmp -> 0. */
+ *      merged ids are remapped; ids absent from nodes.dmp -> 0.
+ *      The device tables are dense in the taxid (>= 25 bytes per id up to the largest one, 16 more per id for every four
+ *      levels of depth): NCBI's dump takes ~0.7 GB; a dump with sparse huge ids is refused (UKM_ERR_NOMEM, message says
+ *      how much it would need) when that exceeds the device's free memory.  A load either replaces the context's taxonomy
+ *      completely or, on any error, leaves the previous one in place. */
 int ukm_taxonomy_load(ukm_ctx *ctx, const uint32_t *child, const uint32_t *parent, uint64_t n,
                       const uint32_t *merged_old, const uint32_t *merged_new, uint64_t m);
 int ukm_taxonomy_max_taxid(ukm_ctx *ctx, uint32_t *max_taxid); /* taxdump.MaxTaxid, util.go:169 */

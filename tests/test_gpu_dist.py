@@ -219,6 +219,10 @@ def test_bench_two_ranks_incl_exchange():
     assert res["value"] == res["value_incl_exchange"] == res["incl_exchange"]["value"]
     assert res["value_is"].startswith("end to end")
     assert res["value_prepartitioned"] > 0 and res["ms_per_step"] == res["incl_exchange"]["ms_per_step"]
+    # the same job from an offset-sharded start (slices arrive in value order: no merge pass), beside the stride one
+    off = res["incl_exchange"]["offset_sharded_start"]
+    assert "error" not in off, off
+    assert off["value"] > 0 and res["value_offset_sharded_start"] == off["value"]
     assert res["incl_exchange"]["steps"] == 2 and res["config"]["per_gpu_set_size"] == 1_000_000
     assert res["config"]["global_set_size"] == 2_000_000
     assert res["roofline"]["frac"] > 0 and res["cpu_baseline"] is None

@@ -170,6 +170,40 @@ def test_lca_merged_and_forest(ctx, O):
     c.close()
 
 
+def test_failed_taxonomy_load_leaves_the_previous_one(O, L):
+    """A load either replaces the taxonomy completely or not at all (round-3 advice): a dump whose dense tables do not fit
+    the device's free memory (a sparse huge taxid), a cyclic dump and taxid 0 are refused with an error, and the context
+    still answers from the taxonomy it had -- LCA and a union with taxids."""
+    c = L.Context(0)
+    child = np.array([1, 2, 3, 4, 5], dtype=np.uint32)
+    parent = np.array([1, 1, 1, 2, 2], dtype=np.uint32)
+    c.taxonomy_load(child, parent)
+    tax = O.Taxonomy(child, parent)
+    check = lambda: (c.lca(np.array([4, 4, 3], np.uint32), np.array([5, 3, 0], np.uint32)).tolist() == [2, 1, 0]
+                     and c.max_taxid() == 5)
+    assert check()
+    # largest taxid 2^32 - 2: at least 25 B x 4.3e9 ids = 107 GB of dense tables; make sure that is more than what is free
+    import torch
+    free, _ = torch.cuda.mem_get_info()
+    hog = torch.empty(max(0, free - (60 << 30)), dtype=torch.uint8, device="cuda") if free > (60 << 30) else None
+    with pytest.raises(L.UkmError) as e:
+        c.taxonomy_load(np.array([1, 4294967294], np.uint32), np.array([1, 1], np.uint32))
+    assert "renumber" in str(e.value)
+    del hog
+    torch.cuda.empty_cache()
+    assert check()
+    with pytest.raises(L.UkmError):
+        c.taxonomy_load(np.array([7, 8], np.uint32), np.array([8, 7], np.uint32))      # a cycle
+    with pytest.raises(L.UkmError):
+        c.taxonomy_load(np.array([0, 2], np.uint32), np.array([1, 1], np.uint32))      # taxid 0 is reserved
+    assert check()
+    A = np.array([10, 20, 30], np.uint64)
+    gk, gt = c.union([A, A[1:]], [np.array([4, 4, 3], np.uint32), np.array([5, 3], np.uint32)])
+    ok, ot = O.union([A, A[1:]], [np.array([4, 4, 3], np.uint32), np.array([5, 3], np.uint32)], tax)
+    assert np.array_equal(gk, ok) and np.array_equal(gt, ot)
+    c.close()
+
+
 def test_lca_deep_and_ragged_trees(O, L):
     """The root-path table (round 3: 16 bytes per node per 4 levels, LCA = last equal entry of two root paths) against
     the oracle's ancestor walk on shapes that cross chunk boundaries: a chain of 203 nodes, a caterpillar, a forest of

@@ -48,7 +48,8 @@ struct TaxDev {
     const u32 *merged;  // dense [size] or nullptr; 0 = not merged
     u32 size;
     // root-path table (round 3): anc[c * size + t] = the ancestors of t at depths 4c .. 4c+3 (t itself at its own
-    // depth, 0 beyond it; all 0 for an absent taxid).  nullptr when the tree is too deep for it: lca_dev then climbs.
+    // depth, 0 beyond it; all 0 for an absent taxid).  Always present when a taxonomy is loaded: ukm_taxonomy_load builds
+    // every table or none (it refuses dumps whose dense tables do not fit the device).
     const uint4 *anc;
     u32 nchunks;
     // pre-order numbers (round 3, ukm_pfold.hip): euler[t] = 1 + the position of t (merged ids: of their target) in a

@@ -325,7 +325,10 @@ void pf_probe_kernel(PfArgs a) {
                 else { step(std::integral_constant<int, 1>{}, f, t, p0, end, len); p0 += 128; }
             }
         }
-        if (OP == UKM_OP_INTER && lane == 0) atomicAdd(&s_done, 1u);  // (its hits are all in: LDS operations of a wave stay in order)
+        // RELEASE: the wave's hit atomics on s_cnt are ordered before the count of finished files that the `need` shortcut
+        // reads with ACQUIRE (the hardware keeps a wave's LDS operations in order; the release keeps the compiler from
+        // moving the increment in front of them)
+        if (OP == UKM_OP_INTER && lane == 0) (void)__hip_atomic_fetch_add(&s_done, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
         j = jn;
         cur = nxt;
     }

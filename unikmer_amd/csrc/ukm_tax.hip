@@ -65,6 +65,17 @@ extern "C" int ukm_taxonomy_load(ukm_ctx *c, const uint32_t *child, const uint32
     }
     for (u64 i = 0; i < m; i++) mx = std::max(mx, std::max(mo[i], mn[i]));
     const u64 size = (u64)mx + 1;
+    {
+        // the tables are dense in the taxid (at least 25 bytes per id on the device, about as much on the host while they
+        // are built): refuse sparse huge ids here, before any of it is allocated
+        size_t free_b = 0, total_b = 0;
+        UKM_HIP(hipMemGetInfo(&free_b, &total_b));
+        if (size * 25 > (u64)free_b / 10 * 9)
+            UKM_FAIL(UKM_ERR_NOMEM,
+                     "ukm_taxonomy_load: dense tables for the largest taxid %u need at least %.2f GB, the device has %.2f GB free; "
+                     "renumber sparse taxids densely",
+                     mx, size * 25 / 1e9, free_b / 1e9);
+    }
     std::vector<u32> P(size, 0), M;
     std::vector<u8> D(size, 0);
     for (u64 i = 0; i < n; i++) P[ch[i]] = pa[i];
@@ -96,38 +107,10 @@ extern "C" int ukm_taxonomy_load(ukm_ctx *c, const uint32_t *child, const uint32
         M.assign(size, 0);
         for (u64 i = 0; i < m; i++) M[mo[i]] = mn[i];
     }
-    UKM_HIP(hipStreamSynchronize(c->stream));
-    if (c->tax_parent) { (void)hipFree(c->tax_parent); c->tax_parent = nullptr; }
-    if (c->tax_depth) { (void)hipFree(c->tax_depth); c->tax_depth = nullptr; }
-    if (c->tax_merged) { (void)hipFree(c->tax_merged); c->tax_merged = nullptr; }
-    UKM_HIP(hipMalloc((void **)&c->tax_parent, size * sizeof(u32)));
-    UKM_HIP(hipMalloc((void **)&c->tax_depth, size * sizeof(u8)));
-    UKM_HIP(hipMemcpy(c->tax_parent, P.data(), size * sizeof(u32), hipMemcpyHostToDevice));
-    UKM_HIP(hipMemcpy(c->tax_depth, D.data(), size * sizeof(u8), hipMemcpyHostToDevice));
-    if (m) {
-        UKM_HIP(hipMalloc((void **)&c->tax_merged, size * sizeof(u32)));
-        UKM_HIP(hipMemcpy(c->tax_merged, M.data(), size * sizeof(u32), hipMemcpyHostToDevice));
-    }
-    c->tax_size = (u32)size;
-    c->tax_max = mx_node;
-    // root-path table for lca_dev: 16 bytes per node per 4 levels (NCBI: ~3.4 M dense ids x ~45 levels = 0.65 GB of the
-    // 288 GB; the first chunk -- all that random pairs touch -- is 54 MB; the deepest tree the loader accepts, 250
-    // levels, would take 1 KB per id)
-    if (c->tax_anc) { (void)hipFree(c->tax_anc); c->tax_anc = nullptr; c->tax_nchunks = 0; }
-    int maxd = 0;
-    for (u64 t = 0; t < size; t++) maxd = std::max(maxd, (int)D[t]);
-    const u32 nchunks = (u32)(maxd + 1 + 3) / 4;
-    const u64 bytes = (u64)nchunks * size * sizeof(uint4);
-    UKM_HIP(hipMalloc((void **)&c->tax_anc, bytes));
-    UKM_HIP(hipMemsetAsync(c->tax_anc, 0, bytes, c->stream));
-    hipLaunchKernelGGL(build_anc_kernel, dim3((unsigned)((size + 255) / 256)), dim3(256), 0, c->stream, c->tax_parent,
-                       c->tax_depth, (u32)size, (u32 *)c->tax_anc);
-    UKM_HIP(hipGetLastError());
-    UKM_HIP(hipStreamSynchronize(c->stream));
-    c->tax_nchunks = nchunks;
     // Pre-order numbers of the forest (children in increasing taxid order; any order works): the LCA of a set of nodes is
     // the LCA of the members with the smallest and the largest number, which lets a fold over MANY files keep a minimum
     // and a maximum per record (two commutative LDS atomics per hit) and do ONE table LCA at the end (ukm_pfold.hip).
+    std::vector<u32> E(size, 0), N(1, 0);  // N[0] unused: numbers start at 1
     {
         std::vector<u32> first(size + 1, 0), kids;  // CSR of the children lists
         for (u64 t = 1; t < size; t++)
@@ -139,7 +122,6 @@ extern "C" int ukm_taxonomy_load(ukm_ctx *c, const uint32_t *child, const uint32
             for (u64 t = 1; t < size; t++)
                 if (P[t] != 0 && P[t] != t) kids[fill[P[t]]++] = (u32)t;
         }
-        std::vector<u32> E(size, 0), N(1, 0);  // N[0] unused: numbers start at 1
         std::vector<std::pair<u32, u32>> st;   // (node, next child slot)
         for (u64 r = 1; r < size; r++) {
             if (P[r] != r) continue;
@@ -162,13 +144,81 @@ extern "C" int ukm_taxonomy_load(ukm_ctx *c, const uint32_t *child, const uint32
         if (m)
             for (u64 t = 1; t < size; t++)
                 if (P[t] == 0 && M[t] != 0 && M[t] < size && P[M[t]] != 0) E[t] = E[M[t]];  // (lca_dev resolves exactly these)
-        if (c->tax_euler) { (void)hipFree(c->tax_euler); c->tax_euler = nullptr; }
-        if (c->tax_node_at) { (void)hipFree(c->tax_node_at); c->tax_node_at = nullptr; }
-        UKM_HIP(hipMalloc((void **)&c->tax_euler, size * sizeof(u32)));
-        UKM_HIP(hipMalloc((void **)&c->tax_node_at, N.size() * sizeof(u32)));
-        UKM_HIP(hipMemcpy(c->tax_euler, E.data(), size * sizeof(u32), hipMemcpyHostToDevice));
-        UKM_HIP(hipMemcpy(c->tax_node_at, N.data(), N.size() * sizeof(u32), hipMemcpyHostToDevice));
     }
+    // ---- device tables: ALL of them are built beside the context's current ones and swapped in only when every
+    // allocation, copy and kernel has succeeded; a failed load leaves the context exactly as it was (a half-replaced
+    // taxonomy would pass the `tax_parent != nullptr` guards and send the kernels through a null root-path table).
+    // Root-path table for lca_dev: 16 bytes per id per 4 levels (NCBI: ~3.4 M dense ids x ~45 levels = 0.65 GB of the
+    // 288 GB; the first chunk -- all that random pairs touch -- is 54 MB).  The tables are DENSE in the taxid: a dump with
+    // sparse huge ids (hash-like ids up to 2^31) multiplies that by the largest id, so the load is refused with a clear
+    // message when the tables would not fit the device's free memory instead of failing half-way through.
+    int maxd = 0;
+    for (u64 t = 0; t < size; t++) maxd = std::max(maxd, (int)D[t]);
+    const u32 nchunks = (u32)(maxd + 1 + 3) / 4;
+    const u64 anc_bytes = (u64)nchunks * size * sizeof(uint4);
+    const u64 need = size * (sizeof(u32) + sizeof(u8) + (m ? sizeof(u32) : 0) + sizeof(u32)) + N.size() * sizeof(u32) + anc_bytes;
+    {
+        size_t free_b = 0, total_b = 0;
+        UKM_HIP(hipMemGetInfo(&free_b, &total_b));
+        if (need > (u64)free_b / 10 * 9)
+            UKM_FAIL(UKM_ERR_NOMEM,
+                     "ukm_taxonomy_load: the dense tables need %.2f GB (largest taxid %u, depth %d: 16 B per id per 4 levels), the "
+                     "device has %.2f GB free; renumber sparse taxids densely",
+                     need / 1e9, mx, maxd, free_b / 1e9);
+    }
+    UKM_HIP(hipStreamSynchronize(c->stream));
+    u32 *n_parent = nullptr, *n_merged = nullptr, *n_euler = nullptr, *n_node_at = nullptr;
+    u8 *n_depth = nullptr;
+    uint4 *n_anc = nullptr;
+    auto drop_new = [&]() {
+        if (n_parent) (void)hipFree(n_parent);
+        if (n_depth) (void)hipFree(n_depth);
+        if (n_merged) (void)hipFree(n_merged);
+        if (n_euler) (void)hipFree(n_euler);
+        if (n_node_at) (void)hipFree(n_node_at);
+        if (n_anc) (void)hipFree(n_anc);
+    };
+    int rc = [&]() -> int {
+        UKM_HIP(hipMalloc((void **)&n_parent, size * sizeof(u32)));
+        UKM_HIP(hipMalloc((void **)&n_depth, size * sizeof(u8)));
+        UKM_HIP(hipMemcpy(n_parent, P.data(), size * sizeof(u32), hipMemcpyHostToDevice));
+        UKM_HIP(hipMemcpy(n_depth, D.data(), size * sizeof(u8), hipMemcpyHostToDevice));
+        if (m) {
+            UKM_HIP(hipMalloc((void **)&n_merged, size * sizeof(u32)));
+            UKM_HIP(hipMemcpy(n_merged, M.data(), size * sizeof(u32), hipMemcpyHostToDevice));
+        }
+        UKM_HIP(hipMalloc((void **)&n_euler, size * sizeof(u32)));
+        UKM_HIP(hipMalloc((void **)&n_node_at, N.size() * sizeof(u32)));
+        UKM_HIP(hipMemcpy(n_euler, E.data(), size * sizeof(u32), hipMemcpyHostToDevice));
+        UKM_HIP(hipMemcpy(n_node_at, N.data(), N.size() * sizeof(u32), hipMemcpyHostToDevice));
+        UKM_HIP(hipMalloc((void **)&n_anc, anc_bytes));
+        UKM_HIP(hipMemsetAsync(n_anc, 0, anc_bytes, c->stream));
+        hipLaunchKernelGGL(build_anc_kernel, dim3((unsigned)((size + 255) / 256)), dim3(256), 0, c->stream, n_parent, n_depth,
+                           (u32)size, (u32 *)n_anc);
+        UKM_HIP(hipGetLastError());
+        UKM_HIP(hipStreamSynchronize(c->stream));
+        return UKM_OK;
+    }();
+    if (rc != UKM_OK) {
+        drop_new();
+        return rc;
+    }
+    // the swap: nothing below can fail
+    if (c->tax_parent) (void)hipFree(c->tax_parent);
+    if (c->tax_depth) (void)hipFree(c->tax_depth);
+    if (c->tax_merged) (void)hipFree(c->tax_merged);
+    if (c->tax_anc) (void)hipFree(c->tax_anc);
+    if (c->tax_euler) (void)hipFree(c->tax_euler);
+    if (c->tax_node_at) (void)hipFree(c->tax_node_at);
+    c->tax_parent = n_parent;
+    c->tax_depth = n_depth;
+    c->tax_merged = n_merged;
+    c->tax_anc = n_anc;
+    c->tax_euler = n_euler;
+    c->tax_node_at = n_node_at;
+    c->tax_nchunks = nchunks;
+    c->tax_size = (u32)size;
+    c->tax_max = mx_node;
     return UKM_OK;
 }
 
