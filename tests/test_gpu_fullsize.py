@@ -211,3 +211,155 @@ def test_config5_sketch_1e10_bases_full_size(env, monkeypatch):
     assert bool((a[1:] >= a[:-1]).all()) and _xor(torch, a) == xs
     u = ctx.unique(a, out=out_b)
     assert _strict(u) and 0.99 * n_kept < u.numel() <= n_kept
+
+
+def _synth_bases(torch, bench, n, dev):
+    """base i = "ACGT"[splitmix64(seed ^ (i >> 5)) >> (2 (i & 31)) & 3]"""
+    i = torch.arange(n, dtype=torch.int64, device=dev)
+    w = bench.splitmix64_torch((i >> 5) ^ bench._i64(bench.SEED))
+    lut = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=dev)
+    return lut[(w >> (2 * (i & 31))) & 3]
+
+
+def test_config2_count_sort_100Mbp_full_size(env, monkeypatch, genomes):
+    """BASELINE config 2 end to end at its real size: 100 records x 1 Mbp -> 2-bit encode + canonical (strip kernel) ->
+    radix sort (two scatter passes over the top bits, then LDS buckets in their size classes: the route the canonical
+    k-mer distribution takes from 2^23 windows on) -> unique, element for element against the oracle's rolling encoder,
+    its sort and its scan (count.go:285-436,581; sort.go:463,541-550).  Then a real-genome-like input of 2.5e7 bases
+    (the three fixture genomes twice, the second copy with every 97th base changed): low-complexity k-mers crowd single
+    buckets of the top-bits route.  Both also with the route switched off (all passes through HBM)."""
+    torch, bench, lib, ctx, O, dev = env
+    nb = 100_000_000
+    bases = _synth_bases(torch, bench, nb, dev)
+    off = np.array([nb * r // 100 for r in range(101)], dtype=np.uint64)
+    hb = bases.cpu().numpy()
+    ow = O.count_windows(hb, off, 31)
+    assert len(ow) == nb - 100 * 30
+    osorted = O.sort_u64(ow)
+    ou = O.unique(osorted)
+    doff = torch.from_numpy(off.view(np.int64)).to(dev)
+    for knob in (None, "0"):
+        if knob is None:
+            monkeypatch.delenv("UKM_SORT_LOCAL", raising=False)
+        else:
+            monkeypatch.setenv("UKM_SORT_LOCAL", knob)
+        c = ctx.encode_kmers(bases, doff, 31, canonical=True)
+        assert np.array_equal(_np(c), ow), knob                 # window order, every code
+        ctx.sort_u64(c, 62)
+        assert np.array_equal(_np(c), osorted), knob
+        u = ctx.unique(c)
+        assert np.array_equal(_np(u), ou), knob
+        del c, u
+    monkeypatch.delenv("UKM_SORT_LOCAL", raising=False)
+    del bases, hb, ow, osorted, ou
+    # the fixture genomes, twice
+    from conftest import MG1655, IAI39, AMUC
+    seqs, offs, at = [], [0], 0
+    for rep in range(2):
+        for name in (MG1655, IAI39, AMUC):
+            s, o = genomes(name)
+            s = s.copy()
+            if rep:
+                s[::97] = np.frombuffer(b"CATG", dtype=np.uint8)[(s[::97] >> 1) & 3]   # a deterministic substitution
+            seqs.append(s)
+            for b in o[1:]:
+                offs.append(at + int(b))
+            at += len(s)
+    seq = np.concatenate(seqs)
+    goff = np.array(offs, dtype=np.uint64)
+    gw = O.count_windows(seq, goff, 31)
+    assert len(gw) >= 1 << 23                                    # the top-bits route is eligible
+    gs = O.sort_u64(gw)
+    gu = O.unique(gs)
+    dseq = torch.from_numpy(seq).to(dev)
+    dgoff = torch.from_numpy(goff.view(np.int64)).to(dev)
+    for knob in (None, "0"):
+        if knob is None:
+            monkeypatch.delenv("UKM_SORT_LOCAL", raising=False)
+        else:
+            monkeypatch.setenv("UKM_SORT_LOCAL", knob)
+        c = ctx.encode_kmers(dseq, dgoff, 31, canonical=True)
+        assert np.array_equal(_np(c), gw), knob
+        ctx.sort_u64(c, 62)
+        assert np.array_equal(_np(c), gs), knob
+        assert np.array_equal(_np(ctx.unique(c)), gu), knob
+    monkeypatch.delenv("UKM_SORT_LOCAL", raising=False)
+
+
+def _config4_files(torch, bench, dev, nfiles, per, T, core_share):
+    """independent p = 0.9 membership draws over one universe, taxid = 1 + splitmix64(seed3 ^ code)
+    mod T per record.  core_share > 0: that share of the universe is in EVERY file and the first file gets private codes,
+    so inter / diff / diff -t all fold over all files (without it 0.9^n empties the running result after ~130 files)."""
+    nu = int(per / 0.9)
+    j = torch.arange(nu, dtype=torch.int64, device=dev)
+    U = torch.cumsum(1 + (bench.splitmix64_torch(j ^ bench._i64(bench.SEED)) & ((1 << 32) - 1)), 0)
+    thr = int(0.9 * (1 << 20))
+    core = None
+    if core_share > 0:
+        core = ((bench.splitmix64_torch(j ^ bench._i64(bench.SEED + 77)) >> 11) & ((1 << 20) - 1)) < int(core_share * (1 << 20))
+    files, taxs = [], []
+    for f in range(nfiles):
+        h = bench.splitmix64_torch(j ^ bench._i64(bench.SEED + 1000 * (f + 1)))
+        m = ((h >> 11) & ((1 << 20) - 1)) < thr
+        if core is not None:
+            m = m | core
+        k = U[m]
+        if core is not None and f == 0:
+            k = torch.cat([k, U[-1] + 1 + torch.arange(per // 10, dtype=torch.int64, device=dev) * 3])
+        files.append(k)
+        taxs.append((1 + (bench.splitmix64_torch(k ^ bench._i64(bench.SEED + 2 + f)) & ((1 << 40) - 1)) % T).to(torch.int32))
+    return files, taxs
+
+
+@pytest.mark.parametrize("core_share", [0.3, 0.0])
+def test_config4_inter_diff_common_1000_files_x_1e6_full_size(env, monkeypatch, core_share):
+    """BASELINE config 4 at its real size -- 1000 files x 1e6 k-mers with per-record taxids on the 8-ary depth-7 tree --
+    bit-exact against the oracle's file-by-file loops (inter.go:205-286, diff.go:379-454 incl. -t, common.go:220-344):
+    the shape in which every file matters (a 30 % core in every file, private codes in the first) and SURVEY 8(d)'s
+    plain p = 0.9 draws (inter and diff run empty after ~130 files: the early exits).  At this size the one-launch folds
+    choose range lengths, residency and multi-chunk slices that the small tests never see.  Default routes and
+    UKM_NO_PFOLD=1 (the range fold / chained fold behind the hash-probe fold)."""
+    torch, bench, lib, ctx, O, dev = env
+    from conftest import synth_tree
+    child, parent = synth_tree(7, 8)
+    ctx.taxonomy_load(child, parent)
+    tax = O.Taxonomy(child, parent)
+    nfiles, per = 1000, 1_000_000
+    files, taxs = _config4_files(torch, bench, dev, nfiles, per, len(child), core_share)
+    assert 0.85e9 < sum(x.numel() for x in files) < 1.3e9
+    hf = [_np(x) for x in files]
+    ht = [t.cpu().numpy().view(np.uint32) for t in taxs]
+    want = {"inter": O.inter(hf, ht, tax), "diff": O.diff(hf, ht, tax), "diff_t": O.diff(hf, ht, tax, compare_taxid=True)}
+    if core_share > 0:
+        assert len(want["inter"][0]) > 200_000 and len(want["diff"][0]) >= per // 10    # results that survive every file
+        want["common"] = O.common(hf, nfiles, ht, tax)
+    else:
+        assert len(want["inter"][0]) == 0 and len(want["diff"][0]) == 0 and len(want["diff_t"][0]) > 0
+    del hf, ht
+    cap = files[0].numel() + 8
+    ok = torch.empty(cap, dtype=torch.int64, device=dev)
+    ot = torch.empty(cap, dtype=torch.int32, device=dev)
+
+    def same(got, name, tag):
+        gk, gt = got
+        wk, wt = want[name]
+        assert gk.numel() == len(wk), (name, tag, gk.numel(), len(wk))
+        assert np.array_equal(_np(gk), wk) and np.array_equal(gt.cpu().numpy().view(np.uint32), wt), (name, tag)
+    for no_pf in (None, "1"):
+        if no_pf is None:
+            monkeypatch.delenv("UKM_NO_PFOLD", raising=False)
+        else:
+            monkeypatch.setenv("UKM_NO_PFOLD", no_pf)
+        same(ctx.inter(files, taxs, out=ok, out_taxids=ot), "inter", no_pf)
+        same(ctx.diff(files, taxs, out=ok, out_taxids=ot), "diff", no_pf)
+        same(ctx.diff(files, taxs, compare_taxid=True, out=ok, out_taxids=ot), "diff_t", no_pf)
+    monkeypatch.delenv("UKM_NO_PFOLD", raising=False)
+    if core_share > 0:
+        # `common` of all files: the probe fold, and the counting merge behind it (keep-everything merge + run scan)
+        same(ctx.common(files, nfiles, taxs, out=ok, out_taxids=ot), "common", "probe")
+        total = sum(x.numel() for x in files)
+        okc = torch.empty(total + 8, dtype=torch.int64, device=dev)
+        otc = torch.empty(total + 8, dtype=torch.int32, device=dev)
+        monkeypatch.setenv("UKM_COMMON_PROBE", "0")
+        same(ctx.common(files, nfiles, taxs, out=okc, out_taxids=otc), "common", "counting merge")
+        monkeypatch.delenv("UKM_COMMON_PROBE")
