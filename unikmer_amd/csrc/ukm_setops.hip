@@ -221,6 +221,100 @@ __global__ void setop_partition_coop_kernel(SetopArgs p, int tile_items) {
     if (lane == 0) p.mp[t] = lo;
 }
 
+// Both levels AND the clearing of the status lines in ONE launch (round 4): a workgroup owns one coarse segment of
+// PART_COARSE boundaries.  Waves 0 and 1 place the segment's two coarse ends with the 64-ary search (every coarse end is
+// found twice, by its two neighbouring segments: ~10 of them per CU, pure latency), the other boundaries are then searched
+// between the two by one thread each, and the segment's status lines (and, by segment 0, the control words) are zeroed on
+// the way.  Replaces hipMemsetAsync + the level-1 kernel + the level-2 kernel in front of every tile kernel of a plain
+// call: three launches and two dependent kernel tails less (2 x 1e9 codes: 0.19 -> see profiles/r04_notes.md).
+template <bool RANK>
+__global__ __launch_bounds__(256) void setop_partition_fused_kernel(SetopArgs p, int tile_items, u32 nclear) {
+    __shared__ u64 s_end[2];
+    const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const u64 c0 = (u64)blockIdx.x * PART_COARSE;
+    const u64 c1 = (c0 + PART_COARSE < p.ntiles) ? c0 + PART_COARSE : p.ntiles;
+    const u64 N = p.na + p.nb;
+    // status lines of this segment's tiles; the control words in front of them
+    if (tid < PART_COARSE && c0 + (u64)tid < p.ntiles) p.status[(c0 + (u64)tid) * LB_STRIDE] = 0;
+    if (blockIdx.x == 0 && tid < (int)nclear) p.result[tid] = 0;
+    if (wave < 2) {
+        const u64 t = wave == 0 ? c0 : c1;
+        u64 diag = t * (u64)tile_items;
+        if (diag > N) diag = N;
+        u64 lo = diag > p.nb ? diag - p.nb : 0;
+        u64 hi = diag < p.na ? diag : p.na;
+#if SETOP_PART_INTERP1
+        if (lo < hi) {
+            const u64 W = SETOP_PART_INTERP1;
+            u64 est = (u64)((double)diag * ((double)p.na / (double)N));
+            est = est < lo ? lo : (est > hi ? hi : est);
+            const u64 L = est > lo + W ? est - W : lo;
+            const u64 R = est + W < hi ? est + W : hi;
+            bool pl = true, pr = false;
+            if (L > lo) { const u64 j = diag - L; pl = key_le<RANK>(p.a[L - 1], RANK ? p.ra[L - 1] : 0, p.b[j], RANK ? p.rb[j] : 0); }
+            if (R < hi) { const u64 j = diag - 1 - R; pr = key_le<RANK>(p.a[R], RANK ? p.ra[R] : 0, p.b[j], RANK ? p.rb[j] : 0); }
+            if (L > lo) { if (pl) lo = L; else hi = L - 1; }
+            if (R < hi) { if (!pr) hi = R; else lo = R + 1; }
+        }
+#endif
+        while (lo < hi) {  // wave-uniform 64-ary search (see setop_partition_coop_kernel)
+            const u64 span = hi - lo;
+            const u64 cand = span <= 64 ? lo + (u64)lane
+                                        : lo + (span / 65) * (u64)(lane + 1) + ((span % 65) * (u64)(lane + 1)) / 65;
+            const bool active = cand < hi;
+            bool le = false;
+            if (active) {
+                const u64 j = diag - 1 - cand;
+                le = key_le<RANK>(p.a[cand], RANK ? p.ra[cand] : 0, p.b[j], RANK ? p.rb[j] : 0);
+            }
+            const u64 m_le = __ballot(le), m_act = __ballot(active);
+            const int n_true = __popcll(m_le), n_act = __popcll(m_act);
+            const u64 c_last_true = __shfl(cand, n_true > 0 ? n_true - 1 : 0, 64);
+            const u64 c_first_false = __shfl(cand, n_true < 64 ? n_true : 63, 64);
+            const u64 nlo = n_true > 0 ? c_last_true + 1 : lo;
+            const u64 nhi = n_true < n_act ? c_first_false : hi;
+            lo = nlo;
+            hi = nhi;
+        }
+        if (lane == 0) {
+            s_end[wave] = lo;
+            if (wave == 0) p.mp[c0] = lo;
+            else if (c1 == p.ntiles) p.mp[c1] = lo;  // the last boundary has no segment of its own
+        }
+    }
+    __syncthreads();
+    const u64 t = c0 + (u64)tid;
+    if (tid == 0 || tid >= PART_COARSE || t >= c1) return;
+    const u64 l0 = s_end[0], h0 = s_end[1];
+    u64 diag = t * (u64)tile_items;
+    if (diag > N) diag = N;
+    u64 lo = diag > p.nb ? diag - p.nb : 0;
+    u64 hi = diag < p.na ? diag : p.na;
+    lo = lo > l0 ? lo : l0;
+    hi = hi < h0 ? hi : h0;
+#if SETOP_PART_INTERP
+    if (lo < hi) {
+        const u64 W = SETOP_PART_INTERP;
+        u64 est = l0 + (h0 - l0) * (t - c0) / (c1 - c0);
+        est = est < lo ? lo : (est > hi ? hi : est);
+        const u64 L = est > lo + W ? est - W : lo;
+        const u64 R = est + W < hi ? est + W : hi;
+        bool pl = true, pr = false;
+        if (L > lo) { const u64 j = diag - L; pl = key_le<RANK>(p.a[L - 1], RANK ? p.ra[L - 1] : 0, p.b[j], RANK ? p.rb[j] : 0); }
+        if (R < hi) { const u64 j = diag - 1 - R; pr = key_le<RANK>(p.a[R], RANK ? p.ra[R] : 0, p.b[j], RANK ? p.rb[j] : 0); }
+        if (L > lo) { if (pl) lo = L; else hi = L - 1; }
+        if (R < hi) { if (!pr) hi = R; else lo = R + 1; }
+    }
+#endif
+    while (lo < hi) {
+        const u64 mid = (lo + hi) >> 1;
+        const u64 j = diag - 1 - mid;
+        const bool le = key_le<RANK>(p.a[mid], RANK ? p.ra[mid] : 0, p.b[j], RANK ? p.rb[j] : 0);
+        if (le) lo = mid + 1; else hi = mid;
+    }
+    p.mp[t] = lo;
+}
+
 // UKM_OP_MERGE_INTERNAL (ukm_internal.h): plain 2-way MERGE of two non-decreasing streams, every record
 // kept (A first on ties).  Output size is known (|A| + |B|), so the tile kernel needs no look-back for it.
 
@@ -844,8 +938,16 @@ int run_setop_pass(ukm_ctx *c, int op, const u64 *a, const u32 *ta, const u32 *r
     // re-runs with ticketed tile ids, which cannot stall whatever the dispatch order is.
     for (int attempt = c->setop_force_ticket ? 1 : 0; attempt < 2; attempt++) {
         const bool ticket = attempt == 1;
+        static const bool fused_on = !(getenv("UKM_SETOP_FUSED_PART") && getenv("UKM_SETOP_FUSED_PART")[0] == '0');  // developer knob
+        const bool first = attempt == (c->setop_force_ticket ? 1 : 0);
+        if (first && fused_on && p.ntiles >= 4 * PART_COARSE) {
+            // status lines, control words and both partition levels in one launch
+            const unsigned sblocks = (unsigned)((p.ntiles + PART_COARSE - 1) / PART_COARSE);
+            if (rank) hipLaunchKernelGGL((setop_partition_fused_kernel<true>), dim3(sblocks), dim3(256), 0, c->stream, p, (int)tile_items, 8u);
+            else hipLaunchKernelGGL((setop_partition_fused_kernel<false>), dim3(sblocks), dim3(256), 0, c->stream, p, (int)tile_items, 8u);
+        } else {
         UKM_HIP(hipMemsetAsync(ctl, 0, nzero * sizeof(u64), c->stream));
-        if (attempt == (c->setop_force_ticket ? 1 : 0)) {
+        if (first) {
             if (p.ntiles >= 4 * PART_COARSE) {
                 const unsigned cblocks = (unsigned)((p.ntiles / PART_COARSE + 2 + 3) / 4);  // one wave per coarse boundary
                 if (rank) {
@@ -860,6 +962,7 @@ int run_setop_pass(ukm_ctx *c, int op, const u64 *a, const u32 *ta, const u32 *r
                 if (rank) hipLaunchKernelGGL((setop_partition_coop_kernel<true, 0>), dim3(wblocks), dim3(256), 0, c->stream, p, (int)tile_items);
                 else hipLaunchKernelGGL((setop_partition_coop_kernel<false, 0>), dim3(wblocks), dim3(256), 0, c->stream, p, (int)tile_items);
             }
+        }
         }
         (void)hipEventRecord(c->ev_k0, c->stream);
         if (rank) {
