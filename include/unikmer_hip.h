@@ -62,6 +62,10 @@ extern "C" {
 /* flags */
 #define UKM_F_MIX_TAXID 2u   /* inter --mix-taxid, inter.go:229-236 */
 #define UKM_F_CMP_TAXID 4u   /* diff -t/--compare-taxid, diff.go:361-362,406-407 */
+#define UKM_F_DEVICE_STREAMS 256u /* n-way calls (union / inter / diff / common): every keys[i] / taxids[i] is a DEVICE pointer.
+                                   * Without it each pointer is classified with hipPointerGetAttributes (host arrays are
+                                   * staged), which for a fold over 1000 files is 2000 driver queries = most of the call's
+                                   * host time.  A host that keeps decoded .unik streams on the device sets it. */
 
 typedef struct ukm_ctx ukm_ctx;
 

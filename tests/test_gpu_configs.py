@@ -607,6 +607,35 @@ def test_long_runs_fold_taxids_by_the_wave():
     c.close()
 
 
+def test_stream_table_is_reusable_across_operations(env):
+    """Context.stream_table: the pointer / length tables of a file set built once and passed to several n-way calls (the
+    C ABI's own arguments; UKM_F_DEVICE_STREAMS is set for device tensors) -- same results as the Python lists"""
+    import torch
+    O, L, ctx, tax, T = env
+    U = _universe(20_000)
+    files = [U[_member(len(U), f, 0.8, 3)] for f in range(70)]
+    taxs = [_taxids(f, T, i) for i, f in enumerate(files)]
+    dfiles = [torch.from_numpy(f.view(np.int64)).cuda() for f in files]
+    dtaxs = [torch.from_numpy(t.view(np.int32)).cuda() for t in taxs]
+    tab = ctx.stream_table(dfiles, dtaxs)
+    dn = lambda r: (r[0].cpu().numpy().view(np.uint64), r[1].cpu().numpy().view(np.uint32))
+    for fn, ofn in ((ctx.inter, O.inter), (ctx.diff, O.diff), (ctx.union, O.union)):
+        gk, gt = dn(fn(tab))
+        ok, ot = ofn(files, taxs, tax)
+        assert np.array_equal(gk, ok) and np.array_equal(gt, ot), fn
+    gk, gt = dn(ctx.common(tab, 60))
+    ok, ot = O.common(files, 60, taxs, tax)
+    assert np.array_equal(gk, ok) and np.array_equal(gt, ot)
+    gk, gt = dn(ctx.merge_k(tab, mode=L.REPEATED))
+    ok, ot = O.merge_k(files, taxs, mode=O.REPEATED, tax=tax)
+    assert np.array_equal(gk, ok) and np.array_equal(gt, ot)
+    # host arrays through the same object (no device-streams flag: they are staged)
+    tabh = ctx.stream_table(files, taxs)
+    gk, gt = ctx.inter(tabh)
+    ok, ot = O.inter(files, taxs, tax)
+    assert np.array_equal(gk, ok) and np.array_equal(gt, ot)
+
+
 def test_merge_top_level_of_two_children_through_the_tile_kernel(env, monkeypatch):
     """A keep-everything merge of >= 2^20 records whose last level has two children (9..16 and 65..128 streams at fan-in 8)
     runs that level as a 2-way merge through the set-op tile kernel: the result is still the stable sort of the

@@ -53,6 +53,20 @@ def main():
             ts.append(time.perf_counter() - t0)
         return min(ts) * 1e3, out
 
+    HBM_PEAK = 8.0e12          # B/s (MI355X_MICROARCH.md)
+    VALU_PEAK = 256 * 4 * 16 * 2.4e9   # lane-instructions/s: 256 CUs x 4 SIMDs x 16 lanes at 2.4 GHz
+
+    def roof_hbm(nbytes, ms, what):
+        """the roofline object of a config: ALGORITHMIC bytes (SURVEY 8(d) formulas) over the wall time of the call(s)"""
+        a = nbytes / (ms * 1e-3)
+        return {"bound": "hbm", "algorithmic_bytes": float(nbytes), "ms": ms, "achieved": a / 1e9, "peak": HBM_PEAK / 1e9,
+                "unit": "GB/s", "frac": a / HBM_PEAK, "bytes_are": what}
+
+    def roof_valu(lane_instr, ms, what):
+        a = lane_instr / (ms * 1e-3)
+        return {"bound": "valu", "lane_instructions": float(lane_instr), "ms": ms, "achieved": a / 1e12, "peak": VALU_PEAK / 1e12,
+                "unit": "T lane-instr/s", "frac": a / VALU_PEAK, "instructions_are": what}
+
     def synth_bases(n):
         i = torch.arange(n, dtype=torch.int64, device=dev)
         w = bench.splitmix64_torch((i >> 5) ^ bench._i64(bench.SEED))
@@ -65,6 +79,7 @@ def main():
         out = torch.empty(A.numel() + B.numel(), dtype=torch.int64, device=dev)
         ms, u = wall(lambda: ctx.setop2(lib.OP_UNION, A, B, out=out), reps=10)
         res["config1_union_k21_2x1e6"] = {"ms": ms, "kmers_per_s": (A.numel() + B.numel()) / ms * 1e3, "out": u.numel(),
+                                          "roofline": roof_hbm(8 * (A.numel() + B.numel()) + 8 * u.numel(), ms, "8(|A|+|B|) read + 8|out| written"),
                                           "note": "launch/latency bound at this size (one partition + one tile kernel + 16-byte readback)"}
 
     if "2" in want:
@@ -86,8 +101,16 @@ def main():
             t["encode"], t["sort"], t["unique"] = (t1 - t0) * 1e3, (t2 - t1) * 1e3, (t3 - t2) * 1e3
             return u
         ms, u = wall(run)
+        w = nb - 100 * 30
         res["config2_count_sort_k31_100Mbp"] = {"ms": ms, "bases_per_s": nb / ms * 1e3, "distinct": u.numel(),
-                                                "phases_ms": dict(t), "windows": nb - 100 * 30}
+                                                "phases_ms": dict(t), "windows": w,
+                                                "roofline": roof_hbm((nb + 8 * w) + (8 * w + 16 * w * 8) + (8 * w + 8 * u.numel()), ms,
+                                                                     "SURVEY 8(d): encode 1 B/base + 8 B/window; LSB radix sort 8n + 16nP with "
+                                                                     "P = 8 passes; unique 8n + 8u"),
+                                                "roofline_moved": roof_hbm((nb + 8 * w) + (8 * w + 2 * 16 * w + 16 * w) + (8 * w + 8 * u.numel()), ms,
+                                                                           "what the route actually moves: the sort is one histogram read, TWO scatter "
+                                                                           "passes and one LDS bucket pass (5.6 GB per 1e8 keys instead of 13.6)"),
+                                                "roofline_sort_moved": roof_hbm(8 * w + 2 * 16 * w + 16 * w, t["sort"], "sort alone, bytes the route moves")}
         del bases, codes, uniq
 
     if "3" in want:
@@ -116,6 +139,8 @@ def main():
         res["config3_union_%d_files_x_%.0e" % (nfiles, per)] = {"ms": ms, "input_kmers": total, "kmers_per_s": total / ms * 1e3,
                                                                   "out": u.numel(), "gpus": 1,
                                                                   "algorithmic_GB": (8 * total + 8 * u.numel()) / 1e9,
+                                                                  "roofline": roof_hbm(8 * total + 8 * u.numel(), ms, "8 B per input record read + 8 B per output record written"),
+                                                                  "roofline_kway_merge_only": roof_hbm(8 * total + 8 * u.numel(), ms_kway, "the same bytes over the k-way merge's time"),
                                                                   "ms_kway_merge_only": ms_kway,
                                                                   "note": "union by LDS hash probes against the union of the first eight files (ukm_punion.hip); "
                                                                           "ms_kway_merge_only = the k-way streaming merge (ukm_kway.hip, UKM_PUNION=0), same "
@@ -168,11 +193,15 @@ def main():
         total2 = sum(x.numel() for x in files2)
         ok = torch.empty(files2[0].numel() + 8, dtype=torch.int64, device=dev)
         ot = torch.empty(files2[0].numel() + 8, dtype=torch.int32, device=dev)
-        ms_i, ri = wall(lambda: ctx.inter(files2, taxs2, out=ok, out_taxids=ot), reps=max(1, args.reps - 1))
+        # the pointer / length tables of the 1000 streams are built once (what a host that keeps its decoded files on the
+        # device holds anyway); passing the Python lists instead costs the binding ~0.4 - 0.8 ms per call
+        tab2 = ctx.stream_table(files2, taxs2)
+        ms_i, ri = wall(lambda: ctx.inter(tab2, out=ok, out_taxids=ot), reps=max(1, args.reps - 1))
         n_inter = ri[0].numel()
-        ms_d, rd = wall(lambda: ctx.diff(files2, taxs2, out=ok, out_taxids=ot), reps=max(1, args.reps - 1))
+        ms_d, rd = wall(lambda: ctx.diff(tab2, out=ok, out_taxids=ot), reps=max(1, args.reps - 1))
         n_diff = rd[0].numel()
-        ms_dt, rdt = wall(lambda: ctx.diff(files2, taxs2, compare_taxid=True, out=ok, out_taxids=ot), reps=max(1, args.reps - 1))
+        ms_dt, rdt = wall(lambda: ctx.diff(tab2, compare_taxid=True, out=ok, out_taxids=ot), reps=max(1, args.reps - 1))
+        ms_i_list, _ = wall(lambda: ctx.inter(files2, taxs2, out=ok, out_taxids=ot), reps=max(1, args.reps - 1))
         # `common` of the same files with the default threshold (every file): the probe fold again; the counting merge
         # (k-way keep-all merge + threshold scan) timed beside it
         okc = torch.empty(total2 + 8, dtype=torch.int64, device=dev)
@@ -184,12 +213,30 @@ def main():
         ms_cm, rcm = wall(lambda: ctx.common(files2, nfiles, taxs2, out=okc, out_taxids=otc), reps=1)
         del os.environ["UKM_COMMON_PROBE"]
         assert rcm[0].numel() == n_inter and sums == (int(rcm[0].sum()), int(rcm[1].long().sum()))
+        # the same 1000 files through the keep-everything merge (mergeChunksFile), `common` one below the full threshold
+        # (counting merge + run scan) and `union` with the taxid fold: the many-stream routes (ukm_srmerge.hip / ukm_kway.hip)
+        ms_m, rm = wall(lambda: ctx.merge_k(files2, taxs2, out=okc, out_taxids=otc), reps=max(1, args.reps - 1))
+        route_m = ctx.last_route()
+        ms_c1, rc1 = wall(lambda: ctx.common(files2, nfiles - 1, taxs2, out=okc, out_taxids=otc), reps=max(1, args.reps - 1))
+        ms_u, ru = wall(lambda: ctx.union(files2, taxs2, out=okc, out_taxids=otc), reps=max(1, args.reps - 1))
+        route_u = ctx.last_route()
+        many = {"merge_ms": ms_m, "merge_route": route_m, "common_threshold_minus_1_ms": ms_c1, "common_threshold_minus_1_out": rc1[0].numel(),
+                "union_ms": ms_u, "union_out": ru[0].numel(), "union_route": route_u, "input_kmers": total2,
+                "roofline_merge": roof_hbm(24 * total2, ms_m, "12 B per record read + 12 B per record written"),
+                "roofline_common_threshold_minus_1": roof_hbm(12 * total2 + 12 * rc1[0].numel(), ms_c1, "12 B per input record + 12 B per output record"),
+                "roofline_union": roof_hbm(12 * total2 + 12 * ru[0].numel(), ms_u, "12 B per input record + 12 B per output record"),
+                "note": "route 4 = single-pass range merge (ukm_srmerge.hip), 2 = multi-level k-way merge (ukm_kway.hip)"}
         del okc, otc
+        res["config4_core_files_merge_common_union"] = many
         res["config4_core_inter_diff_%d_files_taxids" % nfiles] = {
             "common_all_files_ms": ms_c, "common_all_files_counting_merge_ms": ms_cm,
-            "inter_ms": ms_i, "inter_out": n_inter, "diff_ms": ms_d, "diff_out": n_diff,
+            "inter_ms": ms_i, "inter_ms_python_lists": ms_i_list, "inter_out": n_inter, "diff_ms": ms_d, "diff_out": n_diff,
             "diff_compare_taxid_ms": ms_dt, "diff_compare_taxid_out": rdt[0].numel(), "input_kmers": total2,
             "inter_kmers_per_s": total2 / ms_i * 1e3, "diff_kmers_per_s": total2 / ms_d * 1e3,
+            "roofline_inter": roof_hbm(12 * total2 + 12 * n_inter, ms_i, "12 B (code + taxid) per input record read + 12 B per output record"),
+            "roofline_diff": roof_hbm(12 * total2 + 12 * n_diff, ms_d, "12 B per input record read + 12 B per output record"),
+            "roofline_diff_compare_taxid": roof_hbm(12 * total2 + 12 * rdt[0].numel(), ms_dt, "12 B per input record read + 12 B per output record"),
+            "roofline_common_all_files": roof_hbm(12 * total2 + 12 * n_inter, ms_c, "12 B per input record read + 12 B per output record"),
             "note": "no early exit: every one of the %d links runs (result sizes above are non-zero)" % (nfiles - 1)}
         del files2, taxs2
         del files, taxs, U
@@ -228,9 +275,16 @@ def main():
             t["nthash+filter"], t["sort+unique"] = (t1 - t0) * 1e3, (t2 - t1) * 1e3
             return h.numel(), u.numel()
         ms, (kept, distinct) = wall(run5, reps=max(1, args.reps - 1))
+        L5 = 512   # strip length the kernel picks at this size and scale: a strip of L windows rolls L + k - 1 bases
+        steps = nb * (L5 + 50) / L5
         res["config5_nthash_scaled1000_k51_reads150"] = {"ms": ms, "bases": nb, "bases_per_s": nb / ms * 1e3, "kept": kept,
                                                           "distinct": distinct, "phases_ms": dict(t),
-                                                          "GBps_read": nb / ms / 1e6}
+                                                          "GBps_read": nb / ms / 1e6,
+                                                          "roofline": roof_valu(steps * 15 * 1.0, t["nthash+filter"],
+                                                                                "the strip kernel is VALU bound by design: 15 vector instructions per "
+                                                                                "rolled base (13 VALU + 2 LDS issue slots; DESIGN 4.4), one lane per strip"),
+                                                          "roofline_hbm": roof_hbm(nb + 8 * kept, t["nthash+filter"], "1 B per base read + 8 B per kept hash (for reference: "
+                                                                                   "the kernel is not HBM bound)")}
     print(json.dumps(res, indent=1))
 
 

@@ -31,8 +31,9 @@ struct Stream {
 };
 
 // stage the caller's streams (host or device pointers) as device streams
+// device_streams (UKM_F_DEVICE_STREAMS): the caller vouches that every pointer is a device pointer, so none is classified
 int stage_streams(ukm_ctx *c, const uint64_t *const *keys, const uint32_t *const *taxids,
-                  const uint64_t *lens, int nstreams, bool want_tax, std::vector<Stream> &out) {
+                  const uint64_t *lens, int nstreams, bool want_tax, std::vector<Stream> &out, bool device_streams = false) {
     out.resize((size_t)nstreams);
     for (int i = 0; i < nstreams; i++) {
         Stream s;
@@ -40,8 +41,13 @@ int stage_streams(ukm_ctx *c, const uint64_t *const *keys, const uint32_t *const
         s.k = nullptr;
         s.t = nullptr;
         if (s.n && !keys[i]) UKM_FAIL(UKM_ERR_INVALID, "stream %d: keys is NULL", i);
-        UKM_TRY(ukm_in_t(c, keys[i], s.n, &s.k));
-        if (want_tax && taxids && taxids[i]) UKM_TRY(ukm_in_t(c, taxids[i], s.n, &s.t));
+        if (device_streams) {
+            s.k = keys[i];
+            if (want_tax && taxids && taxids[i]) s.t = taxids[i];
+        } else {
+            UKM_TRY(ukm_in_t(c, keys[i], s.n, &s.k));
+            if (want_tax && taxids && taxids[i]) UKM_TRY(ukm_in_t(c, taxids[i], s.n, &s.t));
+        }
         out[(size_t)i] = s;
     }
     return UKM_OK;
@@ -468,10 +474,12 @@ extern "C" int ukm_union(ukm_ctx *ctx, const uint64_t *const *keys, const uint32
                          const uint64_t *lens, int nstreams, uint32_t flags, uint64_t *out_keys,
                          uint32_t *out_taxids, uint64_t out_cap, uint64_t *n_out) {
     UKM_TRY(check_common_args(ctx, keys, lens, nstreams, out_keys, out_cap, n_out, "ukm_union"));
+    const bool device_streams = (flags & UKM_F_DEVICE_STREAMS) != 0;  // every stream pointer is a device pointer
+    flags &= ~(uint32_t)UKM_F_DEVICE_STREAMS;
     const bool tax = any_taxids(taxids, nstreams);
     return run_entry(ctx, out_keys, out_taxids, out_cap, n_out, tax, [&](OutBufs &o) -> int {
         std::vector<Stream> cur;
-        UKM_TRY(stage_streams(ctx, keys, taxids, lens, nstreams, tax, cur));
+        UKM_TRY(stage_streams(ctx, keys, taxids, lens, nstreams, tax, cur, device_streams));
         // drop empty streams; a single stream is made a sorted set here, several are checked by the merges
         std::vector<Stream> ss;
         for (auto &s : cur)
@@ -494,11 +502,13 @@ extern "C" int ukm_inter(ukm_ctx *ctx, const uint64_t *const *keys, const uint32
                          const uint64_t *lens, int nstreams, uint32_t flags, uint64_t *out_keys,
                          uint32_t *out_taxids, uint64_t out_cap, uint64_t *n_out) {
     UKM_TRY(check_common_args(ctx, keys, lens, nstreams, out_keys, out_cap, n_out, "ukm_inter"));
+    const bool device_streams = (flags & UKM_F_DEVICE_STREAMS) != 0;  // every stream pointer is a device pointer
+    flags &= ~(uint32_t)UKM_F_DEVICE_STREAMS;
     const bool tax = any_taxids(taxids, nstreams);
     return run_entry(ctx, out_keys, out_taxids, out_cap, n_out, tax, [&](OutBufs &o) -> int {
         if (nstreams == 0) return UKM_OK;
         std::vector<Stream> ss;
-        UKM_TRY(stage_streams(ctx, keys, taxids, lens, nstreams, tax, ss));
+        UKM_TRY(stage_streams(ctx, keys, taxids, lens, nstreams, tax, ss, device_streams));
         Stream acc = ss[0];  // inter.go:189-200: the running result starts as file 1
         u64 *bk[2] = {nullptr, nullptr};
         u32 *bt[2] = {nullptr, nullptr};
@@ -543,12 +553,14 @@ extern "C" int ukm_diff(ukm_ctx *ctx, const uint64_t *const *keys, const uint32_
                         const uint64_t *lens, int nstreams, const uint8_t *sorted_flags, uint32_t flags,
                         uint64_t *out_keys, uint32_t *out_taxids, uint64_t out_cap, uint64_t *n_out) {
     UKM_TRY(check_common_args(ctx, keys, lens, nstreams, out_keys, out_cap, n_out, "ukm_diff"));
+    const bool device_streams = (flags & UKM_F_DEVICE_STREAMS) != 0;  // every stream pointer is a device pointer
+    flags &= ~(uint32_t)UKM_F_DEVICE_STREAMS;
     const bool tax = any_taxids(taxids, nstreams);
     if ((flags & UKM_F_CMP_TAXID) && !tax) UKM_FAIL(UKM_ERR_INVALID, "ukm_diff: -t needs taxids");
     return run_entry(ctx, out_keys, out_taxids, out_cap, n_out, tax, [&](OutBufs &o) -> int {
         if (nstreams == 0) return UKM_OK;
         std::vector<Stream> ss;
-        UKM_TRY(stage_streams(ctx, keys, taxids, lens, nstreams, tax, ss));
+        UKM_TRY(stage_streams(ctx, keys, taxids, lens, nstreams, tax, ss, device_streams));
         Stream acc = ss[0];
         bool a_sorted = true, a_strict = true;
         UKM_TRY(ukm_dev_check_sorted(ctx, acc.k, acc.n, &a_sorted, &a_strict));
@@ -646,14 +658,15 @@ static bool common_probe_enabled() {
 extern "C" int ukm_common(ukm_ctx *ctx, const uint64_t *const *keys, const uint32_t *const *taxids,
                           const uint64_t *lens, int nstreams, uint32_t threshold, uint32_t flags,
                           uint64_t *out_keys, uint32_t *out_taxids, uint64_t out_cap, uint64_t *n_out) {
-    (void)flags;
     UKM_TRY(check_common_args(ctx, keys, lens, nstreams, out_keys, out_cap, n_out, "ukm_common"));
+    const bool device_streams = (flags & UKM_F_DEVICE_STREAMS) != 0;  // every stream pointer is a device pointer
+    flags &= ~(uint32_t)UKM_F_DEVICE_STREAMS;
     if (nstreams > 65535) UKM_FAIL(UKM_ERR_INVALID, "ukm_common: at most 65535 streams (common.go:75-77)");
     const bool tax = any_taxids(taxids, nstreams);
     return run_entry(ctx, out_keys, out_taxids, out_cap, n_out, tax, [&](OutBufs &o) -> int {
         if (nstreams == 0) return UKM_OK;
         std::vector<Stream> ss;
-        UKM_TRY(stage_streams(ctx, keys, taxids, lens, nstreams, tax, ss));
+        UKM_TRY(stage_streams(ctx, keys, taxids, lens, nstreams, tax, ss, device_streams));
         // threshold = number of files (the default `-p 1`) over duplicate-free sorted files: a code reaches the count
         // only by being in every file, and its taxid is the same left fold of LCAs as `inter`'s (common.go:262-266 /
         // inter.go:252-262) -> the hash-probe fold of ukm_pfold.hip answers in one pass over the files.  It checks the
