@@ -13,5 +13,5 @@ timeout 500 rocprofv3 --kernel-trace --output-format csv --pmc SQ_INSTS_SALU SQ_
 timeout 500 rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE -d $O/fetch -o p -- $CMD > $O/fetch.log 2>&1
 timeout 500 rocprofv3 --kernel-trace --output-format csv --pmc WRITE_SIZE -d $O/write -o p -- $CMD > $O/write.log 2>&1
 cd $R
-grep -h "$FILT" $(find $O/trace -name '*kernel_stats.csv') | cut -c1-220
+f0=$(find $O/trace -name "*kernel_stats.csv" | head -1); [ -n "$f0" ] && grep -h "$FILT" $f0 | cut -c1-220
 for d in sq1 sq2 fetch write; do f=$(find $O/$d -name '*counter_collection.csv' | head -1); [ -n "$f" ] && python tools/pmc_summary.py $(dirname $f) --filter=$FILT; done

@@ -148,6 +148,9 @@ def main():
         del files, U, out
 
     if "4" in want:
+        ctx.close()
+        torch.cuda.empty_cache()
+        ctx = lib.Context(0, stream=torch.cuda.current_stream(dev).cuda_stream)
         nfiles, per = args.files4, int(args.files4_size)
         child, parent = synth_tree(7, 8)
         ctx.taxonomy_load(child, parent)
@@ -238,10 +241,15 @@ def main():
             "roofline_diff_compare_taxid": roof_hbm(12 * total2 + 12 * rdt[0].numel(), ms_dt, "12 B per input record read + 12 B per output record"),
             "roofline_common_all_files": roof_hbm(12 * total2 + 12 * n_inter, ms_c, "12 B per input record read + 12 B per output record"),
             "note": "no early exit: every one of the %d links runs (result sizes above are non-zero)" % (nfiles - 1)}
-        del files2, taxs2
+        del files2, taxs2, tab2
         del files, taxs, U
 
     if "5" in want:
+        # (a fresh context: the workspace of config 3's k-way merge -- two buffers of 1e10 records -- stays with a context
+        #  until it is destroyed, and config 5 needs 30 GB of its own)
+        ctx.close()
+        torch.cuda.empty_cache()
+        ctx = lib.Context(0, stream=torch.cuda.current_stream(dev).cuda_stream)
         nb = int(args.bases5)
         nb -= nb % 150
         chunk = 1 << 31  # generate in pieces to bound torch temporaries
