@@ -422,3 +422,31 @@ def test_random_sorts_through_the_bucket_route(env, seed):
         del x, w, v, exp, order, srt
     torch.cuda.synchronize()
     ctx.close()
+
+
+def test_bucket_route_narrows_keys_declared_64_bits_wide():
+    """A caller that cannot narrow key_bits (hashes: 64) but whose keys happen to use 57 .. 63 bits: the bucket route
+    narrows to the bits in use (it used to keep 64 for > 56 bits: a sparsely populated top digit, two wasted scatter
+    passes, and the context marked as one that has met crowded keys).  Same result as torch.sort, keys and stable pairs,
+    and the context does NOT start sampling afterwards (a second, even, sort still takes the route: same result)."""
+    import torch
+    from unikmer_amd import lib as L
+    dev = torch.device("cuda:0")
+    ctx = L.Context(0, stream=torch.cuda.current_stream(dev).cuda_stream)
+    g = torch.Generator(device=dev)
+    g.manual_seed(77)
+    n = 10_000_000
+    for bits in (57, 60, 63):
+        hi = torch.randint(0, 1 << 31, (n,), device=dev, generator=g, dtype=torch.int64)
+        lo = torch.randint(0, 1 << 32, (n,), device=dev, generator=g, dtype=torch.int64)
+        x = ((hi << 32) ^ lo) & ((1 << bits) - 1)
+        exp = torch.sort(x, stable=True)          # (< 2^63: signed order = unsigned order)
+        w = x.clone()
+        ctx.sort_u64(w, 64)
+        assert torch.equal(w, exp.values), bits
+        v = torch.arange(n, dtype=torch.int32, device=dev)
+        w.copy_(x)
+        ctx.sort_pairs(w, v, 64)
+        assert torch.equal(w, exp.values) and torch.equal(v.long(), exp.indices), bits
+    torch.cuda.synchronize()
+    ctx.close()

@@ -705,7 +705,9 @@ int sort_top16_local(ukm_ctx *c, u64 *keys, u32 *vals, u64 n, int key_bits, bool
         u64 orv = 0;
         UKM_TRY(ukm_read_u64(c, or_all, &orv));  // (a caller that could not narrow key_bits: one read-back, as in the general route)
         const int bits = orv ? 64 - __builtin_clzll(orv) : 1;
-        if (bits > 56) break;  // the histogram above is the right one
+        if (bits == 64) break;  // the histogram above is the right one
+        // (57 .. 63 significant bits too: with kb left at 64 only 2^(bits - 48) of the top buckets would be populated, the
+        //  route would run its scatter passes, give up and mark the context as one that has met crowded keys)
         kb = bits;
         if (kb < min_bits) return UKM_OK;
     }

@@ -63,7 +63,10 @@ static thread_local bool t_worker_thread = false;
     va_end(ap);
     if (t_worker_thread) throw std::runtime_error(buf);
     fprintf(stderr, "[ERRO] %s\n", buf);
-    exit(255);
+    // _exit, not exit: a fatal error on the main thread may come while the parser thread of `count` is still filling
+    // page-locked chunks; exit() would run atexit handlers and static destructors (the HIP runtime's among them) under it
+    fflush(nullptr);
+    _exit(255);
 }
 static bool g_verbose = false;
 static void info(const char *fmt, ...) {
