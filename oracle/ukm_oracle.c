@@ -487,7 +487,7 @@ uint64_t ukmo_merge_k(const uint64_t *const *keys, const uint32_t *const *taxids
     int has_tax = taxids != NULL;
     for (int s = 0; s < nstreams; s++)
         if (lens[s] > 0) {
-            hentry e = {keys[s][0], has_tax ? taxids[s][0] : 0, s};
+            hentry e = {keys[s][0], (has_tax && taxids[s]) ? taxids[s][0] : 0, s};
             hpush(heap, &hn, e);
             cur[s] = 1;
         }
@@ -518,7 +518,7 @@ uint64_t ukmo_merge_k(const uint64_t *const *keys, const uint32_t *const *taxids
         }
         int s = e.idx;
         if (cur[s] < lens[s]) {
-            hentry ne = {keys[s][cur[s]], has_tax ? taxids[s][cur[s]] : 0, s};
+            hentry ne = {keys[s][cur[s]], (has_tax && taxids[s]) ? taxids[s][cur[s]] : 0, s};
             cur[s]++;
             hpush(heap, &hn, ne);
         }
@@ -594,6 +594,10 @@ static uint64_t map_get_or_insert(map64 *m, uint64_t key, int *found) {
     return i;
 }
 
+/* a stream without TaxId information (taxids[s] == NULL) among streams that carry it: its records read as taxid 0
+ * (the reader returns the file's global taxid, 0 when there is none: SURVEY.md Appendix A notation) */
+#define UKMO_TX(s, i) ((taxids && taxids[s]) ? taxids[s][i] : 0u)
+
 /* union.go:186-305 */
 uint64_t ukmo_union(const uint64_t *const *keys, const uint32_t *const *taxids,
                     const uint64_t *lens, int nstreams, uint32_t flags, const ukmo_tax *tax,
@@ -606,8 +610,8 @@ uint64_t ukmo_union(const uint64_t *const *keys, const uint32_t *const *taxids,
             int found;
             uint64_t slot = map_get_or_insert(&m, keys[s][i], &found);
             if (has_tax) { /* union.go:195-201 */
-                if (!found) m.vals[slot] = taxids[s][i];
-                else m.vals[slot] = ukmo_lca(tax, m.vals[slot], taxids[s][i]);
+                if (!found) m.vals[slot] = UKMO_TX(s, i);
+                else m.vals[slot] = ukmo_lca(tax, m.vals[slot], UKMO_TX(s, i));
             }
         }
     uint64_t n = 0;
@@ -753,11 +757,11 @@ uint64_t ukmo_common(const uint64_t *const *keys, const uint32_t *const *taxids,
             uint64_t slot = map_get_or_insert(&m, keys[s][i], &found);
             if (s == 0) { /* common.go:232,244: first file sets count = 1, taxid overwritten */
                 m.cnts[slot] = 1;
-                if (has_tax) m.vals[slot] = taxids[s][i];
+                if (has_tax) m.vals[slot] = UKMO_TX(s, i);
             } else {
                 if (has_tax) { /* common.go:262-266 */
-                    if (!found) m.vals[slot] = taxids[s][i];
-                    else m.vals[slot] = ukmo_lca(tax, m.vals[slot], taxids[s][i]);
+                    if (!found) m.vals[slot] = UKMO_TX(s, i);
+                    else m.vals[slot] = ukmo_lca(tax, m.vals[slot], UKMO_TX(s, i));
                 }
                 m.cnts[slot] = (uint16_t)(m.cnts[slot] + 1); /* uint16 counts (common.go:111) */
             }

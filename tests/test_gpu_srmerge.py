@@ -234,3 +234,24 @@ def test_default_choice_takes_the_route_for_many_streams(env):
     g = ctx.union(streams[:40])
     assert ctx.last_route() != ROUTE_SR
     assert np.array_equal(g, O.union(streams[:40]))
+
+
+def test_streams_without_taxids_among_streams_with_taxids(env, monkeypatch):
+    """files without TaxId information among files that carry it (a mixed `union` / `merge`: their records take part with
+    taxid 0, union.go:144,195-201), 600 streams through the single pass"""
+    O, L, ctx, tax, T = env
+    monkeypatch.setenv("UKM_SRMERGE", "1")
+    rng = np.random.default_rng(31)
+    U = _universe(60_000)
+    files = [U[_member(len(U), f, 0.05, 5)] for f in range(600)]
+    files = [f for f in files if len(f)]
+    taxs = [None if i % 7 == 3 else _taxids(f + np.uint64(i), T, i) for i, f in enumerate(files)]
+    gk, gt = ctx.union(files, taxs)
+    assert ctx.last_route() == ROUTE_SR
+    ok, ot = O.union(files, taxs, tax)
+    assert np.array_equal(gk, ok) and np.array_equal(gt, ot)
+    gk, gt = ctx.merge_k(files, taxs, mode=L.PLAIN)
+    assert ctx.last_route() == ROUTE_SR
+    zt = [np.zeros(len(f), np.uint32) if t is None else t for f, t in zip(files, taxs)]
+    ek, et = _stable(files, zt)
+    assert np.array_equal(gk, ek) and np.array_equal(gt, et)
