@@ -114,6 +114,8 @@ struct ukm_ctx {
     bool setop_force_ticket = false;
     // set once a sort found its keys crowded into few top-16-bit buckets (ukm_sort.hip): later sorts look at a sample first
     bool sort_skew_seen = false;
+    // set around the sort of the gathered oversized buckets: those keys are crowded by construction, the general passes take them
+    bool sort_general_only = false;
 };
 
 // Arena API.  Pointers stay valid until the enclosing top-level call returns.

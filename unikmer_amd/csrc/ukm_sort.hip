@@ -452,7 +452,7 @@ int run_passes(ukm_ctx *c, u64 *keys, u32 *vals, u64 *tk, u32 *tv, u64 n, int np
 // route (the two passes only permuted the keys).
 constexpr int LS_NT = 256, LS_NW = LS_NT / 64;  // keys per thread 2 / 4 / 8 / 16: buckets of up to 512 ... 4096 keys
 constexpr int LS_TOP_MIN = 12, LS_TOP_MAX = 22;  // bucket = the top `topb` bits: 2^topb buckets of ~1400 keys
-constexpr int LS_MAX_BIG = 32; // buckets beyond 4096 keys, sorted together by the general route (the list is read back through the 64-word scratch)
+constexpr int LS_MAX_BIG = 8192;  // buckets beyond 4096 keys, gathered side by side and sorted together by the general route
 constexpr int LS_NCLASS = 12;
 constexpr int LS_CLASS_KPT[LS_NCLASS] = {1, 2, 3, 4, 5, 6, 7, 8, 10, 12, 14, 16};  // keys per thread of the size classes: 256 ... 4096 keys
 
@@ -518,7 +518,7 @@ __global__ void ls_sample_count_kernel(const u32 *cnt, u32 thr, u64 *out) {  // 
 
 // size class of every bucket: cls[k] = number of buckets of class k (k = LS_NCLASS: beyond every class, their ids in
 // cls[LS_NCLASS + 1 ...]); ids[k][...] = the buckets of class k
-__global__ void ls_classify_kernel(const u64 *start, u64 *cls, u32 *ids, int topb) {
+__global__ void ls_classify_kernel(const u64 *start, u64 *cls, u32 *ids, int topb, u32 *big_ids, u64 *big_size) {
     const u32 b = blockIdx.x * blockDim.x + threadIdx.x;  // (the grid covers the buckets exactly)
     const u64 m = start[b + 1] - start[b];
     int k = -1;
@@ -537,25 +537,37 @@ __global__ void ls_classify_kernel(const u64 *start, u64 *cls, u32 *ids, int top
         at = __shfl(at, lead, 64) + (u64)__popcll(mask & lt);
         if (k == q) {
             if (q < LS_NCLASS) ids[(size_t)q << topb | at] = b;
-            else if (at < (u64)LS_MAX_BIG) cls[LS_NCLASS + 1 + at] = b;
+            else if (at < (u64)LS_MAX_BIG) big_ids[at] = b;
         }
     }
-    // keys in oversized buckets (cls[LS_NCLASS + 1 + LS_MAX_BIG]): one atomic per wave
+    // keys in oversized buckets (cls[LS_NCLASS + 1]): one atomic per wave; big_size[b] = the bucket's size if it is one of
+    // them, else 0: its exclusive scan is where every oversized bucket lies in the gathered array (bucket order)
     u64 big = k == LS_NCLASS ? m : 0;
+    big_size[b] = big;
     if (__ballot(big != 0) != 0ull) {
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) big += __shfl_xor(big, d, 64);
-        if (lane_id() == 0) atomicAdd((unsigned long long *)&cls[LS_NCLASS + 1 + LS_MAX_BIG], (unsigned long long)big);
+        if (lane_id() == 0) atomicAdd((unsigned long long *)&cls[LS_NCLASS + 1], (unsigned long long)big);
     }
 }
 
-// (begin, end) of the listed oversized buckets, for one read-back
-__global__ void ls_big_ranges_kernel(const u64 *start, const u64 *cls, u64 *out) {
-    const u32 i = threadIdx.x;
-    if (i < (u32)LS_MAX_BIG && (u64)i < cls[LS_NCLASS]) {
-        const u64 b = cls[LS_NCLASS + 1 + i];
-        out[2 * i] = start[b];
-        out[2 * i + 1] = start[b + 1];
+// the oversized buckets <-> one array in which they lie side by side in bucket order (BACK: the sorted array to the
+// caller's).  blockIdx.x = entry of the list, blockIdx.y = one of gridDim.y parts of the bucket (a single code with
+// millions of copies -- poly-A -- is one bucket)
+template <bool BACK>
+__global__ void ls_big_copy_kernel(const u32 *big_ids, const u64 *start, const u64 *big_off, const u64 *src, const u32 *vsrc,
+                                   u64 *dst, u32 *vdst) {
+    const u32 b = big_ids[blockIdx.x];
+    const u64 s0 = start[b], m = start[b + 1] - s0, o = big_off[b];
+    const u64 lo = m * blockIdx.y / gridDim.y, hi = m * (blockIdx.y + 1) / gridDim.y;
+    for (u64 i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+        if (BACK) {
+            dst[s0 + i] = src[o + i];
+            if (vsrc) vdst[s0 + i] = vsrc[o + i];
+        } else {
+            dst[o + i] = src[s0 + i];
+            if (vsrc) vdst[o + i] = vsrc[s0 + i];
+        }
     }
 }
 
@@ -743,15 +755,19 @@ int sort_top16_local(ukm_ctx *c, u64 *keys, u32 *vals, u64 n, int key_bits, bool
     // per class that occurs, and the few buckets beyond 4096 keys are sorted by the general route.
     u64 *cls = nullptr;
     u32 *ids = nullptr;
-    static_assert(LS_NCLASS + 2 + LS_MAX_BIG <= 64 && 2 * LS_MAX_BIG <= 64, "read-backs through the scratch");
-    UKM_TRY(ws_alloc_t(c, (size_t)LS_NCLASS + 3 + LS_MAX_BIG, &cls));
+    static_assert(LS_NCLASS + 2 <= 64, "read-back through the scratch");
+    u32 *big_ids = nullptr;
+    u64 *big_size = nullptr;
+    UKM_TRY(ws_alloc_t(c, (size_t)LS_NCLASS + 3, &cls));
     UKM_TRY(ws_alloc_t(c, (size_t)LS_NCLASS << topb, &ids));
-    UKM_HIP(hipMemsetAsync(cls, 0, (LS_NCLASS + 3 + LS_MAX_BIG) * sizeof(u64), c->stream));
-    hipLaunchKernelGGL(ls_classify_kernel, dim3(nbuckets / 256), dim3(256), 0, c->stream, start, cls, ids, topb);
+    UKM_TRY(ws_alloc_t(c, (size_t)LS_MAX_BIG, &big_ids));
+    UKM_TRY(ws_alloc_t(c, (size_t)nbuckets + 1, &big_size));
+    UKM_HIP(hipMemsetAsync(cls, 0, (LS_NCLASS + 3) * sizeof(u64), c->stream));
+    hipLaunchKernelGGL(ls_classify_kernel, dim3(nbuckets / 256), dim3(256), 0, c->stream, start, cls, ids, topb, big_ids, big_size);
     UKM_HIP(hipGetLastError());
-    u64 hc[LS_NCLASS + 2 + LS_MAX_BIG];
-    UKM_TRY(ukm_read_u64(c, cls, hc, LS_NCLASS + 2 + LS_MAX_BIG));
-    const u64 big_keys = hc[LS_NCLASS + 1 + LS_MAX_BIG];
+    u64 hc[LS_NCLASS + 2];
+    UKM_TRY(ukm_read_u64(c, cls, hc, LS_NCLASS + 2));
+    const u64 big_keys = hc[LS_NCLASS + 1];
     // oversized buckets are gathered and sorted by ONE call of the general route: worth it for a few of them holding a
     // minor share of the keys, else the general passes sort everything (keys crowded into few buckets)
     if (hc[LS_NCLASS] > (u64)LS_MAX_BIG || big_keys > n / 4) {
@@ -788,36 +804,29 @@ int sort_top16_local(ukm_ctx *c, u64 *keys, u32 *vals, u64 n, int key_bits, bool
     }
     UKM_HIP(hipGetLastError());
     if (hc[LS_NCLASS]) {
-        // the oversized buckets, in bucket order, side by side in a scratch array: sorted by the whole key they stay side by
-        // side (their top bits differ), each one sorted; one general sort instead of one per bucket (48 small sorts took 8 ms)
-        const int nb = (int)hc[LS_NCLASS];
-        u64 *rng = nullptr, *bk = nullptr;
+        // The oversized buckets -- low-complexity k-mers of a real genome crowd a few dozen to a few thousand of them --
+        // side by side in a scratch array, in bucket order: sorted by the whole key they stay side by side (their top bits
+        // differ), each one sorted; one general sort instead of one per bucket (48 small sorts took 8 ms).  Where a bucket
+        // lies in that array is the exclusive scan of the oversized buckets' sizes over the bucket index, so gather and
+        // scatter are one kernel each, whatever the number of buckets (round 3 read the list back and issued two copies
+        // per bucket from the host, which is why it gave up beyond 32 of them).
+        const unsigned nb = (unsigned)hc[LS_NCLASS];
+        u64 *big_off = nullptr, *bk = nullptr, *tot = nullptr;
         u32 *bv = nullptr;
-        UKM_TRY(ws_alloc_t(c, (size_t)2 * LS_MAX_BIG, &rng));
+        UKM_TRY(ws_alloc_t(c, (size_t)nbuckets + 1, &big_off));
+        UKM_TRY(ws_alloc_t(c, 1, &tot));
         UKM_TRY(ws_alloc_t(c, big_keys, &bk));
         if (vals) UKM_TRY(ws_alloc_t(c, big_keys, &bv));
-        hipLaunchKernelGGL(ls_big_ranges_kernel, dim3(1), dim3(64), 0, c->stream, start, cls, rng);
+        UKM_TRY(ukm_dev_exclusive_scan_u64(c, big_size, big_off, nbuckets, tot));
+        const dim3 cg(nb, 16);
+        hipLaunchKernelGGL(ls_big_copy_kernel<false>, cg, dim3(256), 0, c->stream, big_ids, start, big_off, src, vsrc, bk, bv);
         UKM_HIP(hipGetLastError());
-        u64 se[2 * LS_MAX_BIG];
-        UKM_TRY(ukm_read_u64(c, rng, se, 2 * nb));
-        std::vector<std::pair<u64, u64>> seg(nb);
-        for (int i = 0; i < nb; i++) seg[i] = {se[2 * i], se[2 * i + 1]};
-        std::sort(seg.begin(), seg.end());  // (the list is in the order the waves appended it)
-        u64 off = 0;
-        for (auto &sg : seg) {
-            const u64 m = sg.second - sg.first;
-            UKM_HIP(hipMemcpyAsync(bk + off, src + sg.first, m * sizeof(u64), hipMemcpyDeviceToDevice, c->stream));
-            if (vals) UKM_HIP(hipMemcpyAsync(bv + off, vsrc + sg.first, m * sizeof(u32), hipMemcpyDeviceToDevice, c->stream));
-            off += m;
-        }
-        UKM_TRY(ukm_dev_sort(c, bk, bv, big_keys, kb));
-        off = 0;
-        for (auto &sg : seg) {
-            const u64 m = sg.second - sg.first;
-            UKM_HIP(hipMemcpyAsync(keys + sg.first, bk + off, m * sizeof(u64), hipMemcpyDeviceToDevice, c->stream));
-            if (vals) UKM_HIP(hipMemcpyAsync(vals + sg.first, bv + off, m * sizeof(u32), hipMemcpyDeviceToDevice, c->stream));
-            off += m;
-        }
+        c->sort_general_only = true;  // (crowded by construction: not through this route again)
+        const int src_rc = ukm_dev_sort(c, bk, bv, big_keys, kb);
+        c->sort_general_only = false;
+        UKM_TRY(src_rc);
+        hipLaunchKernelGGL(ls_big_copy_kernel<true>, cg, dim3(256), 0, c->stream, big_ids, start, big_off, bk, bv, keys, vals);
+        UKM_HIP(hipGetLastError());
     }
 #undef LS_LAUNCH
     *done = true;
@@ -880,7 +889,7 @@ int ukm_dev_sort(ukm_ctx *c, u64 *keys, u32 *vals, u64 n, int key_bits) {
 #ifndef SORT_LOCAL_MIN
 #define SORT_LOCAL_MIN (1ull << 23)  // (measured: 1.2e7 keys 0.62 -> 0.50 ms, 6.7e6 equal, 1.5e6 slower)
 #endif
-    if (n >= SORT_LOCAL_MIN && RB == 8 && key_bits >= 32 && sort_local_enabled()) {
+    if (n >= SORT_LOCAL_MIN && RB == 8 && key_bits >= 32 && sort_local_enabled() && !c->sort_general_only) {
         // two passes over the top 16 bits, then every bucket in LDS (above); stable, so taxids may ride along
         WsMark mark = ws_mark(c);
         bool done = false;
