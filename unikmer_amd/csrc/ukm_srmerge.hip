@@ -687,21 +687,41 @@ __global__ __launch_bounds__(NT, (TAX ? SR_WAVES_TAX : SR_WAVES_PLAIN)) void sr_
                 }
                 __syncthreads();
                 if (multim) {
+                    // a thread's consecutive records of one run are folded in registers first: one pair of LDS atomics per
+                    // (thread, run) instead of per record (a code that is in 900 files puts 900 atomics on one address)
+                    u32 en[VT];
+#pragma unroll
+                    for (int s = 0; s < VT; s++) {  // (all of the thread's table reads in flight together; euler[0] = 0)
+                        const u32 t = ht[s];
+                        en[s] = p.tax.euler[((multim & (1u << s)) && t < p.tax.size) ? t : 0u];
+                    }
+                    u32 cw = 0xFFFFFFFFu, cmn = 0xFFFFFFFFu, cmx = 0u, cfl = 0u;
+                    auto flush = [&]() {
+                        if (cw == 0xFFFFFFFFu) return;
+                        if (cmx) {
+                            atomicMin(reinterpret_cast<u32 *>(&s_acc[cw]), cmn);
+                            atomicMax(reinterpret_cast<u32 *>(&s_acc[cw]) + 1, cmx);
+                        }
+                        if (cfl) atomicOr(&s_flag[cw], cfl);
+                    };
 #pragma unroll
                     for (int s = 0; s < VT; s++) {
                         if (multim & (1u << s)) {
                             const u32 w = hexcl + (u32)__popc(headm & ((2u << s) - 1u)) - 1u;
-                            const u32 t = ht[s];
-                            const u32 eu = t < p.tax.size ? p.tax.euler[t] : 0u;
-                            u32 fl = (neqm & (1u << s)) ? (u32)SR_NEQ : 0u;
-                            if (eu == 0) fl |= (u32)SR_BAD;
-                            else {
-                                atomicMin(reinterpret_cast<u32 *>(&s_acc[w]), eu);
-                                atomicMax(reinterpret_cast<u32 *>(&s_acc[w]) + 1, eu);
+                            if (w != cw) {
+                                flush();
+                                cw = w; cmn = 0xFFFFFFFFu; cmx = 0u; cfl = 0u;
                             }
-                            if (fl) atomicOr(&s_flag[w], fl);
+                            const u32 eu = en[s];
+                            cfl |= (neqm & (1u << s)) ? (u32)SR_NEQ : 0u;
+                            if (eu == 0) cfl |= (u32)SR_BAD;
+                            else {
+                                cmn = eu < cmn ? eu : cmn;
+                                cmx = eu > cmx ? eu : cmx;
+                            }
                         }
                     }
+                    flush();
                 }
                 __syncthreads();
 #pragma unroll
@@ -805,7 +825,7 @@ int ukm_dev_srmerge(ukm_ctx *c, int op, const u64 *const *keys, const u32 *const
         // The library's own choice, from measurements against the multi-level merge (profiles/r04_notes.md, 1e9 records):
         // this route costs the same per record whatever the number of streams (nine merge rounds per tile), the levels
         // cost one pass per factor of eight.  At 1000 streams x 1e6 records it wins with taxids (a level moves 24 B per
-        // record: merge 24.8 against 27.8 ms, union of files that overlap little 40 - 52 against 50 - 63 ms) and ties or
+        // record: merge 24.8 against 27.8 ms, union of files that overlap little 39 - 48 against 50 - 63 ms) and ties or
         // loses by a few per cent on plain codes (19.6 - 22.8 against 19.0 - 20.0 ms); at 300 streams it loses (24.2
         // against 21.7 ms), at 100 by far.
         if (!tax || S < 512 || N < (1ull << 24)) return UKM_OK;
