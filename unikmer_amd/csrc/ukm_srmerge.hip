@@ -724,19 +724,45 @@ __global__ __launch_bounds__(NT, (TAX ? SR_WAVES_TAX : SR_WAVES_PLAIN)) void sr_
                     flush();
                 }
                 __syncthreads();
+                // one table LCA per run head, THREE heads of a thread at a time with their reads in flight together: the two
+                // node_at reads of each, then the first root-path chunks of each pair (lca_begin), then the comparisons.  One
+                // head after the other was a chain of two dependent table reads per head, up to eighteen per thread
+                // (files that hardly overlap: most records are heads of runs of two or three).
 #pragma unroll
-                for (int s = 0; s < VT; s++) {
-                    if ((headm & multim) & (1u << s)) {
-                        const u32 w = hexcl + (u32)__popc(headm & ((2u << s) - 1u)) - 1u;
-                        const u32 fl = s_flag[w];
-                        if (fl & SR_NEQ) {
-                            if (fl & SR_BAD) ht[s] = 0;
-                            else {
-                                const u64 acc = s_acc[w];
-                                ht[s] = lca_dev(p.tax, p.tax.node_at[(u32)acc], p.tax.node_at[(u32)(acc >> 32)]);
+                for (int g0 = 0; g0 < VT; g0 += 3) {
+                    u32 na[3], nb[3];
+                    bool need[3];
+#pragma unroll
+                    for (int q = 0; q < 3; q++) {
+                        const int s = g0 + q;
+                        need[q] = false;
+                        na[q] = nb[q] = 0;
+                        if (s < VT && ((headm & multim) & (1u << s))) {
+                            const u32 w = hexcl + (u32)__popc(headm & ((2u << s) - 1u)) - 1u;
+                            const u32 fl = s_flag[w];
+                            if (fl & SR_NEQ) {
+                                if (fl & SR_BAD) ht[s] = 0;
+                                else {
+                                    const u64 acc = s_acc[w];
+                                    need[q] = true;
+                                    na[q] = (u32)acc;
+                                    nb[q] = (u32)(acc >> 32);
+                                }
                             }
                         }
                     }
+                    if (!(need[0] | need[1] | need[2])) continue;
+#pragma unroll
+                    for (int q = 0; q < 3; q++) {  // (node_at[0] is mapped: numbers start at 1)
+                        na[q] = p.tax.node_at[need[q] ? na[q] : 0u];
+                        nb[q] = p.tax.node_at[need[q] ? nb[q] : 0u];
+                    }
+                    LcaReq rq[3];
+#pragma unroll
+                    for (int q = 0; q < 3; q++) lca_begin(p.tax, need[q] ? na[q] : 0u, need[q] ? nb[q] : 0u, rq[q]);
+#pragma unroll
+                    for (int q = 0; q < 3; q++)
+                        if (g0 + q < VT && need[q]) ht[g0 + q] = lca_finish(p.tax, rq[q]);
                 }
                 __syncthreads();
             }
