@@ -16,6 +16,7 @@ pytestmark = pytest.mark.gpu
 
 SEED = 0x756E696B6D6572
 ROUTE_SR = 4
+ROUTE_SR_COMMON = 5
 
 
 @pytest.fixture(scope="module")
@@ -255,3 +256,47 @@ def test_streams_without_taxids_among_streams_with_taxids(env, monkeypatch):
     zt = [np.zeros(len(f), np.uint32) if t is None else t for f, t in zip(files, taxs)]
     ek, et = _stable(files, zt)
     assert np.array_equal(gk, ek) and np.array_equal(gt, et)
+
+
+@pytest.mark.parametrize("fill", [None, "400"])
+def test_common_below_the_number_of_files_counts_inside_the_tiles(env, monkeypatch, fill):
+    """common.go:220-344 with a threshold below the number of files: the single pass counts the records of every code and
+    writes the codes that reach it (route 5), plain and with the TaxId fold; thresholds from 2 to the number of files;
+    files with duplicates inside (the first file's count once: common.go:232,244, the others' every time); ranges of several
+    passes (UKM_SRMERGE_FILL)"""
+    O, L, ctx, tax, T = env
+    monkeypatch.setenv("UKM_SRMERGE", "1")
+    monkeypatch.setenv("UKM_COMMON_PROBE", "0")
+    if fill:
+        monkeypatch.setenv("UKM_SRMERGE_FILL", fill)
+    nfiles, p = 300, 0.3
+    U = _universe(20000)
+    core = U[::7]
+    files = []
+    rng = np.random.default_rng(5)
+    for f in range(nfiles):
+        x = U[_member(len(U), f, p, 11)]
+        if f % 3:
+            x = np.union1d(x, core)                       # a core that most files hold
+        if f % 50 == 0:
+            x = np.sort(np.concatenate([x, x[::9]]))      # duplicates inside a file (the first file among them)
+        files.append(x)
+    taxs = [_taxids(x + np.uint64(i), T, i) for i, x in enumerate(files)]
+    for thr in (2, 3, 60, 150, 199, 200, 201, nfiles - 1, nfiles):
+        g = ctx.common(files, thr)
+        assert ctx.last_route() == ROUTE_SR_COMMON, thr
+        assert np.array_equal(g, O.common(files, thr)), thr
+        gk, gt = ctx.common(files, thr, taxs)
+        assert ctx.last_route() == ROUTE_SR_COMMON, thr
+        ok, ot = O.common(files, thr, taxs, tax)
+        assert np.array_equal(gk, ok) and np.array_equal(gt, ot), thr
+    # some files without taxids (read as 0), and the multi-level route gives the same
+    taxs2 = [t if i % 4 else None for i, t in enumerate(taxs)]
+    gk, gt = ctx.common(files, 120, taxs2)
+    assert ctx.last_route() == ROUTE_SR_COMMON
+    ok, ot = O.common(files, 120, taxs2, tax)
+    assert np.array_equal(gk, ok) and np.array_equal(gt, ot)
+    monkeypatch.setenv("UKM_SRMERGE", "0")
+    gk2, gt2 = ctx.common(files, 120, taxs2)
+    assert ctx.last_route() != ROUTE_SR_COMMON
+    assert np.array_equal(gk2, ok) and np.array_equal(gt2, ot)

@@ -1,5 +1,6 @@
 """many-stream merge / union call times (and UKM_SRMERGE_DEBUG phases on stderr) over config-4-shaped files.
-usage: python tools/srmerge_bench.py NFILES PER_FILE P [tax] [merge|union|both] [reps]"""
+usage: python tools/srmerge_bench.py NFILES PER_FILE P [tax] [merge|union|both|common] [reps]
+(common: threshold = half the expected copies of a code, NFILES * P / 2, at least 2)"""
 import os, sys, time, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tools")); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -10,7 +11,7 @@ dev = torch.device("cuda", 0)
 ctx = lib.Context(0, stream=torch.cuda.current_stream(dev).cuda_stream)
 nfiles, per, P = int(sys.argv[1]), int(float(sys.argv[2])), float(sys.argv[3])
 tax = "tax" in sys.argv[4:]
-what = "union" if "union" in sys.argv[4:] else ("both" if "both" in sys.argv[4:] else "merge")
+what = "union" if "union" in sys.argv[4:] else ("both" if "both" in sys.argv[4:] else ("common" if "common" in sys.argv[4:] else "merge"))
 reps = int(sys.argv[-1]) if sys.argv[-1].isdigit() and len(sys.argv) > 4 else 3
 child, parent = synth_tree(7, 8); ctx.taxonomy_load(child, parent); T = len(child)
 nu = int(per / P)
@@ -58,3 +59,9 @@ if what in ("merge", "both"):
         del want
 if what in ("union", "both"):
     print("union  ", wall(lambda: ctx.union(files, tx, **kw)), "route", ctx.last_route(), flush=True)
+if what == "common":
+    cthr = max(2, int(nfiles * P / 2))
+    r = [None]
+    def f():
+        r[0] = ctx.common(files, cthr, tx, **kw)
+    print("common threshold", cthr, wall(f), "route", ctx.last_route(), "out", (r[0][0] if tax else r[0]).numel(), flush=True)

@@ -716,6 +716,34 @@ extern "C" int ukm_common(ukm_ctx *ctx, const uint64_t *const *keys, const uint3
                 ss[0] = Stream{k2, t2, nu};
             }
         }
+        if (threshold > 1 && ukm_kway_enabled()) {
+            // many files, a threshold below their number: the single-pass merge counts the records of every code inside
+            // its tiles and writes only the codes that reach the threshold (ukm_srmerge.hip) -- otherwise the whole
+            // merged sequence is written and read once more by the counting scan below.  It declines for few files,
+            // small inputs, an unsorted file and a code with thousands of copies.
+            std::vector<const u64 *> kp;
+            std::vector<const u32 *> tp;
+            std::vector<u64> ln;
+            for (auto &q : ss)
+                if (q.n) {
+                    kp.push_back(q.k);
+                    tp.push_back(q.t);
+                    ln.push_back(q.n);
+                }
+            if (kp.size() >= 3) {
+                WsMark pm = ws_mark(ctx);
+                bool fb = true;
+                const int src = ukm_dev_srmerge(ctx, UKM_KWAY_UNION, kp.data(), tax ? tp.data() : nullptr, ln.data(), (int)kp.size(), tax,
+                                                o.k, o.t, out_cap, n_out, &fb, threshold);
+                ws_release(ctx, pm);
+                UKM_TRY(src);
+                if (!fb) {
+                    ctx->last_route = 5;
+                    return UKM_OK;
+                }
+                *n_out = 0;
+            }
+        }
         u64 *k = nullptr;
         u32 *t = nullptr;
         u64 total = 0;

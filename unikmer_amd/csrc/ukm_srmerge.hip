@@ -43,7 +43,7 @@ namespace {
 
 constexpr u64 SR_MAX = ~0ull;
 enum { SR_FLAG_UNSORTED = 2, SR_FLAG_DEGENERATE = 8 };
-enum { SR_NEQ = 1, SR_BAD = 2 };
+enum { SR_NEQ = 1, SR_BAD = 2, SR_DEAD = 4 };
 
 constexpr int SR_MAX_STREAMS = 1024;  // two streams per thread, their cursors in registers
 constexpr int SR_SAMPLES_PER_RANGE = 128;
@@ -189,6 +189,7 @@ struct SrArgs {
     u64 *out_off;                 // [R] (UNION): where the range's slot begins
     u64 *result;                  // [1] |= flags
     u32 S, R, per_xcd;
+    u32 threshold;                // UNION: > 1 = only codes with at least this many records (`common`)
     TaxDev tax;
 };
 
@@ -646,7 +647,9 @@ __global__ __launch_bounds__(NT, (TAX ? SR_WAVES_TAX : SR_WAVES_PLAIN)) void sr_
             const int i0 = tf * VT;
             u64 hk[VT];
             u32 ht[VT];
-            u32 headm = 0, multim = 0, neqm = 0;
+            u32 headm = 0, multim = 0, neqm = 0, passm = 0;
+            const bool counted = p.threshold > 1;  // (uniform) `common`: a run is emitted when it has `threshold` records
+            const int need = counted ? (int)p.threshold - 1 : 0;
             {
                 u64 prevk = (i0 > 0 && i0 <= (int)n) ? s_key[i0 - 1] : 0;
                 u32 prevt = (TAX && i0 > 0 && i0 <= (int)n) ? s_tax[i0 - 1] : 0;
@@ -659,6 +662,8 @@ __global__ __launch_bounds__(NT, (TAX ? SR_WAVES_TAX : SR_WAVES_PLAIN)) void sr_
                     const bool head = in && (i == 0 || kcur != prevk);
                     hk[s] = kcur;
                     headm |= head ? (1u << s) : 0u;
+                    // (the tile is sorted: the run is that long iff the record `need` places on carries the same code)
+                    if (counted && head && i + need < (int)n && s_key[i + need] == kcur) passm |= 1u << s;
                     if (TAX) {
                         const u32 t = s_tax[i];
                         ht[s] = t;
@@ -672,6 +677,7 @@ __global__ __launch_bounds__(NT, (TAX ? SR_WAVES_TAX : SR_WAVES_PLAIN)) void sr_
                     kcur = knext;
                 }
             }
+            if (counted && !TAX) headm = passm;  // plain codes: the runs that fall short simply are no heads
             u32 tot;
             const u32 hexcl = block_excl_scan_u32<NT>((u32)__popc(headm), s_scan, &tot);
             // (the scan's barriers lie between every thread's last read of the tile and the writes below)
@@ -681,11 +687,34 @@ __global__ __launch_bounds__(NT, (TAX ? SR_WAVES_TAX : SR_WAVES_PLAIN)) void sr_
             if (TAX) {
                 u64 *s_acc = s_key;   // per output slot: [31:0] smallest, [63:32] largest pre-order number of the run
                 u32 *s_flag = s_tax;  // per output slot: SR_NEQ | SR_BAD
-                for (u32 w = (u32)tid; w < tot; w += NT) {
-                    s_acc[w] = 0x00000000FFFFFFFFull;
-                    s_flag[w] = 0;
+                if (!counted) {
+                    for (u32 w = (u32)tid; w < tot; w += NT) {
+                        s_acc[w] = 0x00000000FFFFFFFFull;
+                        s_flag[w] = 0;
+                    }
+                } else {
+                    // every head prepares its own slot and says whether its run counts; the records of a run that falls
+                    // short skip the fold (no pre-order look-up, no atomics, no table LCA)
+                    u32 w = hexcl;
+#pragma unroll
+                    for (int s = 0; s < VT; s++) {
+                        if (headm & (1u << s)) {
+                            s_acc[w] = 0x00000000FFFFFFFFull;
+                            s_flag[w] = (passm & (1u << s)) ? 0u : (u32)SR_DEAD;
+                            w++;
+                        }
+                    }
                 }
                 __syncthreads();
+                if (counted && multim) {
+#pragma unroll
+                    for (int s = 0; s < VT; s++) {
+                        if (multim & (1u << s)) {
+                            const u32 w = hexcl + (u32)__popc(headm & ((2u << s) - 1u)) - 1u;
+                            if (s_flag[w] & SR_DEAD) multim &= ~(1u << s);
+                        }
+                    }
+                }
                 if (multim) {
                     // a thread's consecutive records of one run are folded in registers first: one pair of LDS atomics per
                     // (thread, run) instead of per record (a code that is in 900 files puts 900 atomics on one address)
@@ -767,6 +796,10 @@ __global__ __launch_bounds__(NT, (TAX ? SR_WAVES_TAX : SR_WAVES_PLAIN)) void sr_
                 __syncthreads();
             }
             u32 w = hexcl;
+            if (counted && TAX) {  // the slots were per run: the runs that count are packed once more
+                headm = passm;
+                w = block_excl_scan_u32<NT>((u32)__popc(headm), s_scan, &tot);
+            }
 #pragma unroll
             for (int s = 0; s < VT; s++) {
                 if (headm & (1u << s)) {
@@ -836,7 +869,7 @@ int ukm_srmerge_mode() {  // read per call: the tests switch it
 }
 
 int ukm_dev_srmerge(ukm_ctx *c, int op, const u64 *const *keys, const u32 *const *taxids, const u64 *lens, int S, bool tax,
-                    u64 *out, u32 *tout, u64 out_cap, u64 *n_out, bool *fallback) {
+                    u64 *out, u32 *tout, u64 out_cap, u64 *n_out, bool *fallback, u32 threshold) {
     *fallback = true;
     *n_out = 0;
     const bool uni = op == UKM_KWAY_UNION;
@@ -854,7 +887,8 @@ int ukm_dev_srmerge(ukm_ctx *c, int op, const u64 *const *keys, const u32 *const
         // record: merge 24.8 against 27.8 ms, union of files that overlap little 39 - 48 against 50 - 63 ms) and ties or
         // loses by a few per cent on plain codes (19.6 - 22.8 against 19.0 - 20.0 ms); at 300 streams it loses (24.2
         // against 21.7 ms), at 100 by far.
-        if (!tax || S < 512 || N < (1ull << 24)) return UKM_OK;
+        // `common` below the number of files (threshold > 1) otherwise is the whole merge plus a counting scan of it.
+        if ((!tax && threshold <= 1) || S < 512 || N < (1ull << 24)) return UKM_OK;
     }
     if (tax && !tout) UKM_FAIL(UKM_ERR_INVALID, "merge: taxids given but out_taxids is NULL");
     if (tax && uni && c->tax_parent == nullptr)
@@ -983,6 +1017,7 @@ int ukm_dev_srmerge(ukm_ctx *c, int op, const u64 *const *keys, const u32 *const
     a.S = (u32)S;
     a.R = R;
     a.per_xcd = (R + 7) / 8;
+    a.threshold = uni ? threshold : 0;
     a.tax = ukm_taxdev(c);
     (void)hipEventRecord(c->ev_k0, c->stream);
     if (tax) {
