@@ -343,11 +343,134 @@ def test_probe_union_matches_oracle(env, monkeypatch):
     dirty = list(files)
     dirty[3] = rng.permutation(dirty[3])
     assert np.array_equal(ctx.union(dirty), O.union(dirty))
-    # with taxids the path does not apply (LCA fold): same answer as before
+    # with taxids: the same pass with the TaxId fold in the table (next test); UKM_PUNION_TAX=0 keeps them off it
     taxs = [_taxids(f, T, i) for i, f in enumerate(files)]
+    ok, ot = O.union(files, taxs, tax)
     gk, gt = ctx.union(files, taxs)
+    assert ctx.last_route() == 3
+    assert np.array_equal(gk, ok) and np.array_equal(gt, ot)
+    monkeypatch.setenv("UKM_PUNION_TAX", "0")
+    gk, gt = ctx.union(files, taxs)
+    assert ctx.last_route() != 3
+    assert np.array_equal(gk, ok) and np.array_equal(gt, ot)
+
+
+def test_probe_union_with_taxids_matches_oracle(env, monkeypatch):
+    """union.go:195-201 — the TaxId of a code is the LCA over every record that carries it — through the hash-probe pass:
+    every table entry keeps the TaxId it came with and the smallest / largest pre-order number of the records that differ
+    from it, one table LCA per entry at the end.  Shapes: uniformly random taxids; one taxid per file (k-mers of one
+    genome); files without taxids among files with; new codes (claimed with their fold), more new codes than a table
+    claims (listed record by record), all-ones codes, duplicates inside files, more later files than one launch holds"""
+    O, L, ctx, tax, T = env
+    rng = np.random.default_rng(43)
+    monkeypatch.setenv("UKM_PUNION", "1")
+    for n_univ, nfiles, p in ((60_000, 40, 0.5), (3_000, 30, 0.5), (200_000, 26, 0.35), (20_000, 600, 0.3)):
+        U = _universe(n_univ)
+        files = [U[_member(len(U), f, p, 78)] for f in range(nfiles)]
+        for kind in ("random", "file", "some"):
+            if kind == "random":
+                taxs = [_taxids(f, T, i) for i, f in enumerate(files)]
+            elif kind == "file":
+                taxs = [np.full(len(f), 1 + (i * 7919) % T, np.uint32) for i, f in enumerate(files)]
+            else:
+                taxs = [_taxids(f, T, i) if i % 3 else None for i, f in enumerate(files)]
+            gk, gt = ctx.union(files, taxs)
+            assert ctx.last_route() == 3, (n_univ, nfiles, kind)
+            ok, ot = O.union(files, taxs, tax)
+            assert np.array_equal(gk, ok) and np.array_equal(gt, ot), (n_univ, nfiles, kind)
+    # later files with private codes, duplicates inside files (their taxids differ), all-ones hashes
+    U = _universe(50_000, gap_bits=40)
+    files = [U[_member(len(U), f, 0.6, 5)] for f in range(30)]
+    extra = np.sort(rng.integers(0, 1 << 63, 3000, dtype=np.uint64) * np.uint64(2) + np.uint64(1))
+    files[12] = np.sort(np.concatenate([files[12], extra[:2000]]))
+    files[20] = np.sort(np.concatenate([files[20], extra[1000:], np.full(3, np.uint64(2**64 - 1))]))
+    files[25] = np.sort(np.concatenate([files[25], files[25][:700]]))
+    files[2] = np.sort(np.concatenate([files[2], np.full(2, np.uint64(2**64 - 1))]))
+    taxs = [(1 + rng.integers(0, T, len(f))).astype(np.uint32) for f in files]
+    ok, ot = O.union(files, taxs, tax)
+    for mode in ("1", "2"):
+        monkeypatch.setenv("UKM_PUNION", mode)
+        gk, gt = ctx.union(files, taxs)
+        assert ctx.last_route() == 3
+        assert np.array_equal(gk, ok) and np.array_equal(gt, ot), mode
+    # thousands of new codes per range: past the table's share the rest is listed record by record
+    Us = _universe(5_000, gap_bits=30)
+    small = [Us[_member(len(Us), f, 0.7, 9)] for f in range(8)]
+    fresh = np.unique(rng.integers(0, int(Us[-1]), 20_000).astype(np.uint64))
+    crowded = small + [np.sort(np.concatenate([Us[_member(len(Us), 8 + f, 0.7, 9)], fresh[_member(len(fresh), f, 0.6, 13)]]))
+                       for f in range(22)]
+    taxs = [(1 + rng.integers(0, T, len(f))).astype(np.uint32) for f in crowded]
+    gk, gt = ctx.union(crowded, taxs)
+    assert ctx.last_route() == 3
+    ok, ot = O.union(crowded, taxs, tax)
+    assert np.array_equal(gk, ok) and np.array_equal(gt, ot)
+    # disjoint files (every record a miss) and an unsorted later file
+    disjoint = [np.sort(rng.choice(1 << 40, 4000, replace=False).astype(np.uint64) + np.uint64(f << 44)) for f in range(20)]
+    taxs = [(1 + rng.integers(0, T, len(f))).astype(np.uint32) for f in disjoint]
+    gk, gt = ctx.union(disjoint, taxs)
+    ok, ot = O.union(disjoint, taxs, tax)
+    assert np.array_equal(gk, ok) and np.array_equal(gt, ot)
+    dirty = list(files)
+    taxs = [(1 + rng.integers(0, T, len(f))).astype(np.uint32) for f in dirty]
+    perm = rng.permutation(len(dirty[15]))
+    dirty[15], taxs[15] = dirty[15][perm], taxs[15][perm]
+    gk, gt = ctx.union(dirty, taxs)
+    assert ctx.last_route() != 3
+    ok, ot = O.union(dirty, taxs, tax)
+    assert np.array_equal(gk, ok) and np.array_equal(gt, ot)
+
+
+def test_probe_union_taxid_fold_on_a_forest_with_merged_zero_and_unknown_ids(monkeypatch):
+    """the fold in the probe table against the reference's record-by-record LCA on a forest of three trees, merged ids,
+    taxid 0, unknown ids (among them 2^32 - 2; 2^32 - 1 is the table's own marker: the call takes the general route),
+    codes whose every record carries the same awkward id"""
+    from oracle import oracle as O
+    from unikmer_amd import lib as L
+    monkeypatch.setenv("UKM_PUNION", "2")
+    c = L.Context(0)
+    child, parent = [], []
+    child.append(100); parent.append(100)
+    for i in range(101, 160):
+        child.append(i); parent.append(i - 1)
+    for i in range(100, 160, 5):
+        child.append(1000 + i); parent.append(i)
+    for t in range(1, 122):
+        child.append(4999 + t); parent.append(4999 + (1 if t == 1 else (t - 2) // 3 + 1))
+    child += [9001, 9002]; parent += [9000, 9001]
+    child, parent = np.array(child, np.uint32), np.array(parent, np.uint32)
+    mo, mn = np.array([50, 51, 52], np.uint32), np.array([159, 5003, 77777], np.uint32)
+    c.taxonomy_load(child, parent, mo, mn)
+    tax = O.Taxonomy(child, parent, mo, mn)
+    rng = np.random.default_rng(29)
+    pool = np.concatenate([child, [0, 50, 51, 52, 9000, 400, 99999, 2**32 - 2]]).astype(np.uint32)
+    U = _universe(5_000)
+    nfiles = 60
+    files = [U[_member(len(U), f, 0.4, 37)] for f in range(nfiles)]
+    files[30] = np.sort(np.concatenate([files[30], U[-1] + np.uint64(5) + np.arange(300, dtype=np.uint64)]))   # new codes
+    files[31] = np.sort(np.concatenate([files[31], U[-1] + np.uint64(5) + np.arange(0, 300, 2, dtype=np.uint64)]))
+    theme = {}
+    taxs = []
+    for f in range(nfiles):
+        t = rng.choice(pool, len(files[f]))
+        for i, x in enumerate(files[f]):
+            th = theme.setdefault(int(x), (int(rng.integers(0, 4)), int(rng.choice(pool))))
+            if th[0] == 0:
+                t[i] = th[1]                              # every record of the code carries the same id
+            elif th[0] == 1:
+                t[i] = rng.integers(100, 160)             # one chain
+            elif th[0] == 2:
+                t[i] = rng.integers(5000, 5121)           # one ternary tree
+        taxs.append(t.astype(np.uint32))
+    gk, gt = c.union(files, taxs)
+    assert c.last_route() == 3
+    ok, ot = O.union(files, taxs, tax)
+    assert len(ok) > 1000 and np.array_equal(gk, ok) and np.array_equal(gt, ot)
+    taxs[40][7] = np.uint32(2**32 - 1)
+    gk, gt = c.union(files, taxs)
+    assert c.last_route() != 3
     ok, ot = O.union(files, taxs, tax)
     assert np.array_equal(gk, ok) and np.array_equal(gt, ot)
+    c.close()
 
 
 # ---------------------------------------------------------- inter / diff by LDS hash probes (ukm_pfold.hip)

@@ -348,6 +348,9 @@ def test_random_probe_paths(env, seed, monkeypatch):
             files.append(x)
         taxs = [(1 + rng.integers(0, T, len(f))).astype(np.uint32) for f in files]
         assert np.array_equal(ctx.union(files), O.union(files)), (seed, it, "union", nf, space)
+        gk, gt = ctx.union(files, taxs)
+        ok, ot = O.union(files, taxs, tax)
+        assert np.array_equal(gk, ok) and np.array_equal(gt, ot), (seed, it, "union+tax", nf, space)
         live = [f for f in files if len(f)]
         ltax = [t for f, t in zip(files, taxs) if len(f)]
         if len(live) >= 4:

@@ -276,16 +276,17 @@ int try_kway(ukm_ctx *ctx, int op, const std::vector<Stream> &ss, bool tax, u64 
     return UKM_OK;
 }
 
-// `union` of many plain sets by LDS hash probes against the union of the first eight (ukm_punion.hip): the shape of an
-// n-file union over related genomes, where after a few files nearly every record is already in the result.  Taken
-// for >= PUNION_MIN_STREAMS streams without taxids and >= 2^27 records behind the first eight; the path itself
+// `union` of many sets by LDS hash probes against the union of the first eight (with TaxIds: four) files
+// (ukm_punion.hip): the shape of an n-file union over related genomes, where after a few files nearly every record is
+// already in the result.  Taken for >= PUNION_MIN_STREAMS streams and >= 2^27 records behind the first eight; the path itself
 // backs out (*done = false, nothing written) when a sample of the later files is not found in the base set, when a
 // stream is unsorted or when its miss list overflows, and the k-way merge below answers.
 constexpr int PUNION_MIN_STREAMS = 24;
-int try_probe_union(ukm_ctx *ctx, const std::vector<Stream> &ss, bool tax, u64 *fk, u64 fcap, u64 *n_out, bool *done) {
+int try_probe_union(ukm_ctx *ctx, const std::vector<Stream> &ss, bool tax, u64 *fk, u32 *ft, u64 fcap, u64 *n_out, bool *done) {
     *done = false;
     const int mode = ukm_punion_mode();
-    if (tax || mode == 0 || !ukm_kway_enabled()) return UKM_OK;
+    if (mode == 0 || !ukm_kway_enabled()) return UKM_OK;
+    if (tax && ukm_punion_tax_mode() == 0) return UKM_OK;
     if (mode < 1) {
         if ((int)ss.size() < PUNION_MIN_STREAMS) return UKM_OK;
         u64 later = 0;
@@ -293,14 +294,17 @@ int try_probe_union(ukm_ctx *ctx, const std::vector<Stream> &ss, bool tax, u64 *
         if (later < (1ull << 27)) return UKM_OK;
     }
     std::vector<const u64 *> kp(ss.size());
+    std::vector<const u32 *> tp(ss.size());
     std::vector<u64> ln(ss.size());
     for (size_t i = 0; i < ss.size(); i++) {
         kp[i] = ss[i].k;
+        tp[i] = ss[i].t;
         ln[i] = ss[i].n;
     }
     WsMark mark = ws_mark(ctx);
     bool fallback = false;
-    const int rc = ukm_dev_probe_union(ctx, kp.data(), ln.data(), (int)ss.size(), fk, fcap, n_out, &fallback);
+    const int rc = ukm_dev_probe_union(ctx, kp.data(), tax ? tp.data() : nullptr, ln.data(), (int)ss.size(), tax, fk, ft, fcap, n_out,
+                                       &fallback);
     ws_release(ctx, mark);
     UKM_TRY(rc);
     *done = !fallback;
@@ -490,7 +494,7 @@ extern "C" int ukm_union(ukm_ctx *ctx, const uint64_t *const *keys, const uint32
             return copy_result(ctx, ss[0], tax, o.k, o.t, out_cap, n_out);
         }
         bool done = false;
-        UKM_TRY(try_probe_union(ctx, ss, tax, o.k, out_cap, n_out, &done));
+        UKM_TRY(try_probe_union(ctx, ss, tax, o.k, o.t, out_cap, n_out, &done));
         if (done) return UKM_OK;
         UKM_TRY(try_kway(ctx, UKM_KWAY_UNION, ss, tax, o.k, o.t, out_cap, n_out, &done));
         if (done) return UKM_OK;

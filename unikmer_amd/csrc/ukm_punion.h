@@ -5,7 +5,10 @@
 // developer / test knob UKM_PUNION: 0 = never, 1 = whenever the shape allows it (size thresholds ignored),
 // 2 = as 1 and without the hit-rate guard.  Unset: the library's own choice.
 int ukm_punion_mode();
+// UKM_PUNION_TAX=0: records with TaxIds never take this path
+int ukm_punion_tax_mode();
 // *fallback = true: not applicable to these inputs (low overlap, unsorted stream, miss buffer overflow): the
 // caller's k-way merge answers; nothing was written that matters.
-int ukm_dev_probe_union(ukm_ctx *c, const u64 *const *keys, const u64 *lens, int S, u64 *out, u64 out_cap, u64 *n_out,
-                        bool *fallback);
+// tax: the records carry TaxIds (taxids[j] may be null: all 0); the result's TaxId is the LCA over every record of a code.
+int ukm_dev_probe_union(ukm_ctx *c, const u64 *const *keys, const u32 *const *taxids, const u64 *lens, int S, bool tax, u64 *out,
+                        u32 *tout, u64 out_cap, u64 *n_out, bool *fallback);

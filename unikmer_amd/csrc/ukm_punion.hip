@@ -15,9 +15,11 @@
 //      Records that are not in the table — not in BASE — are appended to a miss list (one atomic per 64 slots).
 //   4. Result = 2-way union of BASE and sort + unique of the miss list (ukm_sort.hip, ukm_scan.hip, ukm_setops.hip).
 // Whatever the data, BASE ∪ later records = BASE ∪ misses, because a hit is an exact 64-bit match; a bad hash or an
-// unlucky range only costs probes.  An unsorted file or a full miss list raise a flag and the caller falls back.  Plain sets only (no TaxId fold): LCA updates of table entries would
-// need per-entry atomics.
-// Algorithmic bytes: 8 B per input record read once (+ the base and miss passes); nothing is written per hit.
+// unlucky range only costs probes.  An unsorted file or a full miss list raise a flag and the caller falls back.
+// Records WITH TaxIds (round 4, pt_probe_kernel below): every table entry carries the TaxId it came with and the smallest /
+// largest pre-order number of the records that differ from it; one table LCA per entry when its range is done.
+// Algorithmic bytes: 8 B (12 B with TaxIds) per input record read once (+ the base and miss passes); nothing is written
+// per hit.
 #include <stdlib.h>
 
 #include <algorithm>
@@ -50,7 +52,7 @@ constexpr int PU_LMISS = 512;     // new codes a range keeps in LDS before they 
 constexpr u32 PU_CHUNK = 32;      // slots of the miss list a wave reserves at a time
 constexpr u64 PU_EMPTY = ~0ull;
 constexpr double PU_MIN_HIT = 0.90;
-enum { PU_FLAG_UNSORTED = 1, PU_FLAG_OVERFLOW = 2 };
+enum { PU_FLAG_UNSORTED = 1, PU_FLAG_OVERFLOW = 2, PU_FLAG_TAXID = 4 };
 
 struct PuArgs {
     const u64 *const *files;  // [S1] later files (device table of device pointers)
@@ -63,6 +65,12 @@ struct PuArgs {
     u64 *miss;
     u64 miss_cap;
     u64 *ctl;                 // [0] misses, [1] flags, [2] sample hits, [3] samples
+    u32 range;                // base entries per range (PU_RANGE; with TaxIds PT_RANGE)
+    // with TaxIds (pt_probe_kernel)
+    const u32 *const *tfiles; // [S1] TaxIds of the later files (an entry may be null: all 0)
+    u32 *base_tax;            // [n0] in: the fold over the base files, out: over every file
+    u32 *miss_tax;            // beside `miss`
+    TaxDev tax;
 };
 
 __device__ __forceinline__ u32 pu_hash(u64 x) {
@@ -92,7 +100,7 @@ __global__ void pu_cuts_kernel(PuArgs a) {
     } else if (r == a.R) {
         res = len;
     } else {
-        const u64 v = a.base[(u64)r * PU_RANGE];
+        const u64 v = a.base[(u64)r * a.range];
         const auto f = as_global(a.files[j]);
         u64 lo = 0, hi = len;
         while (lo < hi) {
@@ -386,6 +394,363 @@ __global__ __launch_bounds__(PU_NT) __attribute__((amdgpu_waves_per_eu(PU_WAVES,
         for (u32 i = (u32)tid; i < nl; i += PU_NT) a.miss[at + i] = s_miss[i];
 }
 
+// ---- the same pass over records WITH TaxIds (union.go:195-201: the TaxId of a code is the LCA over all its records) ----
+// Beside every table slot three words of LDS: the TaxId the entry came with (t0: the base files' fold, or the first
+// record of a new code), and the smallest / largest pre-order number (TaxDev::euler) among the records whose TaxId
+// differs from t0.  A hit is two LDS reads and — only while it still widens the interval — an LDS atomic; the LCA of a
+// set of nodes is the LCA of its members with the smallest and the largest number, so ONE table LCA per entry at the end
+// equals the reference's left fold (the contract of lca_dev: 0 / unknown ids absorb unless every TaxId is the same).
+// New codes are claimed in the table as in the plain pass and leave WITH their fold when the range is done; what
+// cannot be claimed (all-ones codes, a table that has doubled) is listed record by record and folded by the final
+// sort + unique + 2-way union.  The three words of a slot sit in ONE 16-byte LDS word (a hit reads them with one
+// ds_read_b128 beside the two of its bucket): 24 bytes per slot, 768 buckets of four (72 KB), two workgroups per CU.
+#ifndef PT_BUCKETS_N
+#define PT_BUCKETS_N 768
+#endif
+constexpr int PT_BUCKETS = PT_BUCKETS_N;
+constexpr int PT_SLOTS = 4 * PT_BUCKETS;
+constexpr int PT_RANGE = PT_BUCKETS;
+constexpr int PT_K0 = 4;               // files merged into the base set
+constexpr double PT_MIN_HIT = 0.70;   // (new codes are claimed in the tables with their fold: a lower bar than the plain pass)
+constexpr u32 PT_UNSET = 0xFFFFFFFFu;  // s_t0: nobody has set it yet; s_max: an unknown id was seen (never a number)
+
+__device__ __forceinline__ u32 pt_hash(u64 x) {
+    const u32 lo = (u32)x, hi = (u32)(x >> 32);
+    return (u32)(((u64)((lo ^ (hi * 0x85EBCA6Bu)) * 0x9E3779B1u) * (u64)PT_BUCKETS) >> 32);
+}
+
+typedef u32 pt_u32x2 __attribute__((ext_vector_type(2)));
+typedef pt_u32x2 __attribute__((aligned(4))) pt_tpair;  // 8 bytes at 4-byte alignment
+
+__global__ __launch_bounds__(PU_NT) __attribute__((amdgpu_waves_per_eu(PU_WAVES, PU_WAVES))) void pt_probe_kernel(PuArgs a) {
+    __shared__ __attribute__((aligned(32))) u64 s_tab[PT_SLOTS];
+    __shared__ __attribute__((aligned(16))) uint4 s_st[PT_SLOTS];  // x = t0, y = smallest, z = largest number
+    __shared__ u32 s_next, s_nins;
+    __shared__ u32 s_scan[PU_NT / 64 + 1];
+    __shared__ u64 s_flush_at;
+    const int tid = (int)threadIdx.x, lane = lane_id();
+    const u32 r = blockIdx.x, S1 = a.S1;
+    const TaxDev &T = a.tax;
+    for (int i = tid; i < PT_SLOTS; i += PU_NT) {
+        s_tab[i] = PU_EMPTY;
+        s_st[i] = make_uint4(PT_UNSET, 0xFFFFFFFFu, 0u, 0u);
+    }
+    if (tid == 0) { s_next = 0; s_nins = 0; }
+    __syncthreads();
+    auto next_bucket = [](u32 h) -> u32 { return h + 1 == (u32)PT_BUCKETS ? 0u : h + 1; };
+    // first free slot of the first bucket of the probe sequence that is not full, or the slot that already holds x
+    auto insert = [&](u64 x, bool &fresh) -> int {
+        u32 h = pt_hash(x);
+        for (;; h = next_bucket(h)) {
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const u64 old = atomicCAS((unsigned long long *)&s_tab[4 * h + k], (unsigned long long)PU_EMPTY, (unsigned long long)x);
+                if (old == PU_EMPTY || old == x) {
+                    fresh = old == PU_EMPTY;
+                    return (int)(4 * h + k);
+                }
+            }
+        }
+    };
+    const u64 b0 = (u64)r * PT_RANGE;
+    const u32 nb = (u32)((a.n0 - b0 < (u64)PT_RANGE) ? (a.n0 - b0) : (u64)PT_RANGE);
+    constexpr int PER = (PT_RANGE + PU_NT - 1) / PU_NT;
+    u64 ent[PER];
+    u32 et[PER];
+    bool bad = false, bad_t = false;  // an unsorted file; a TaxId of 2^32 - 1 (the table's own "not set")
+#pragma unroll
+    for (int i = 0; i < PER; i++) {
+        const u32 idx = (u32)tid + (u32)i * PU_NT;
+        ent[i] = a.base[b0 + (idx < nb ? idx : 0)];
+        et[i] = a.base_tax[b0 + (idx < nb ? idx : 0)];
+        if (idx >= nb) ent[i] = PU_EMPTY;
+        else bad_t |= et[i] == PT_UNSET;
+    }
+#pragma unroll
+    for (int i = 0; i < PER; i++) {
+        if (ent[i] == PU_EMPTY) continue;  // (an all-ones code: its records are listed, the final union folds them)
+        bool fresh;
+        const int slot = insert(ent[i], fresh);
+        s_st[slot].x = et[i];
+    }
+    __syncthreads();
+    auto find_from = [&](u64 x, u32 h) -> int {
+        for (;;) {
+            const ulonglong2 *b = reinterpret_cast<const ulonglong2 *>(&s_tab[4 * h]);
+            const ulonglong2 p = b[0], q = b[1];
+            const int k = p.x == x ? 0 : (p.y == x ? 1 : (q.x == x ? 2 : (q.y == x ? 3 : -1)));
+            if (k >= 0) return x != PU_EMPTY ? (int)(4 * h) + k : -1;
+            if (q.y == PU_EMPTY) return -1;
+            h = next_bucket(h);
+        }
+    };
+    auto find2 = [&](u64 xa, u64 xb, int &sa, int &sb) {
+        const u32 h0 = pt_hash(xa), h1 = pt_hash(xb);
+        const ulonglong2 *b0p = reinterpret_cast<const ulonglong2 *>(&s_tab[4 * h0]);
+        const ulonglong2 *b1p = reinterpret_cast<const ulonglong2 *>(&s_tab[4 * h1]);
+        const ulonglong2 p0 = b0p[0], q0 = b0p[1], p1 = b1p[0], q1 = b1p[1];
+        const int k0 = p0.x == xa ? 0 : (p0.y == xa ? 1 : (q0.x == xa ? 2 : (q0.y == xa ? 3 : -1)));
+        const int k1 = p1.x == xb ? 0 : (p1.y == xb ? 1 : (q1.x == xb ? 2 : (q1.y == xb ? 3 : -1)));
+        sa = (k0 >= 0 && xa != PU_EMPTY) ? (int)(4 * h0) + k0 : -1;
+        sb = (k1 >= 0 && xb != PU_EMPTY) ? (int)(4 * h1) + k1 : -1;
+        if (k0 < 0 && q0.y != PU_EMPTY) sa = find_from(xa, next_bucket(h0));
+        if (k1 < 0 && q1.y != PU_EMPTY) sb = find_from(xb, next_bucket(h1));
+    };
+    // one record's TaxId into its entry; e = its pre-order number (0: taxid 0 / unknown)
+    auto fold = [&](int slot, u32 t, u32 e) {
+        const uint4 st = s_st[slot];
+        u32 t0 = st.x;
+        if (t0 == PT_UNSET) {  // a new code: whoever comes first sets it (any order gives the same fold)
+            const u32 old = atomicCAS(&s_st[slot].x, PT_UNSET, t);
+            t0 = old == PT_UNSET ? t : old;
+        }
+        if (t == t0) return;
+        if (e == 0) {
+            if (st.z != PT_UNSET) atomicMax(&s_st[slot].z, PT_UNSET);
+        } else {
+            if (e < st.y) atomicMin(&s_st[slot].y, e);
+            if (e > st.z) atomicMax(&s_st[slot].z, e);
+        }
+    };
+    const u64 lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+    u64 chunk_at = 0, fill = 0;  // wave-uniform
+    u32 fill_t = 0;
+    u32 chunk_cap = 0, chunk_used = 0;
+    auto close_chunk = [&]() {
+        if ((u32)lane < chunk_cap - chunk_used) {
+            a.miss[chunk_at + chunk_used + (u32)lane] = fill;
+            a.miss_tax[chunk_at + chunk_used + (u32)lane] = fill_t;
+        }
+        chunk_cap = chunk_used = 0;
+    };
+    auto append_global = [&](bool m, u64 x, u32 t) {
+        const u64 mask = __ballot(m);
+        if (mask == 0ull) return;
+        const u32 n = (u32)__popcll(mask);
+        const int lead = __ffsll((long long)mask) - 1;
+        if (n > chunk_cap - chunk_used) {
+            close_chunk();
+            const u32 want = n > PU_CHUNK ? 64u : PU_CHUNK;
+            u64 at = 0;
+            if (lane == lead) at = atomicAdd((unsigned long long *)&a.ctl[0], (unsigned long long)want);
+            at = __shfl(at, lead, 64);
+            if (at + want > a.miss_cap) {
+                if (lane == lead) atomicOr((unsigned long long *)&a.ctl[1], (unsigned long long)PU_FLAG_OVERFLOW);
+                return;  // (the host discards everything)
+            }
+            chunk_at = at;
+            chunk_cap = want;
+        }
+        fill = __shfl(x, lead, 64);
+        fill_t = (u32)__shfl((int)t, lead, 64);
+        if (m) {
+            const u64 at = chunk_at + chunk_used + (u32)__popcll(mask & lt);
+            a.miss[at] = x;
+            a.miss_tax[at] = t;
+        }
+        chunk_used += n;
+    };
+    // a record: found -> fold; not found -> claim a slot for its code (then it is a hit like any other), or list it
+    auto record = [&](bool valid, int slot, u64 x, u32 t, u32 e) {
+        bool raw = false;
+        if (valid) {
+            if (slot < 0) {
+                if (x == PU_EMPTY || s_nins >= (u32)PT_RANGE) raw = true;
+                else {
+                    bool fresh;
+                    slot = insert(x, fresh);
+                    if (fresh) atomicAdd(&s_nins, 1u);
+                }
+            }
+            if (!raw) fold(slot, t, e);
+        }
+        append_global(raw, x, t);
+    };
+    // The lanes stream a slice 256 records per step.  A step is three things that each wait for the one before: the loads
+    // of codes and TaxIds (A), the pre-order numbers of those TaxIds (B: a second round trip), the probes (C).  Slices are
+    // short here (a range of 768 entries: a few hundred records per file), so a wave that did A, B, C one after the other
+    // spent its time waiting twice per step (24 ms on config 3's shape at half size).  The steps of ALL slices of the wave
+    // form one sequence instead and run as a pipeline: A of step i + 2 and B of step i + 1 are issued before C of step i.
+    constexpr int U = 2;
+    struct Desc { u64 f, tf, p0, end, len; bool valid; };  // wave-uniform
+    struct RegA { pu_pair pr[U]; pt_tpair tp[U]; u64 nx[U]; };
+    struct RegB { u32 eu[U][2]; };
+    auto issue_a = [&](const Desc &d, RegA &ra) {
+        if (!d.valid) return;
+        const auto f = as_global((const u64 *)(uintptr_t)d.f);
+        const bool has_t = d.tf != 0;
+        const auto tf = as_global((const u32 *)(uintptr_t)(has_t ? d.tf : d.f));
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const u64 pos = d.p0 + (u64)u * 128 + 2u * (u32)lane;
+            const u64 q = pos < d.len - 2 ? pos : d.len - 2;
+            const u64 q2 = pos + 2 < d.len ? pos + 2 : d.len - 1;
+            ra.pr[u] = *(const pu_pair __attribute__((address_space(1))) *)(f + q);
+            ra.nx[u] = f[q2];
+            ra.tp[u] = pt_tpair{0u, 0u};
+            if (has_t) ra.tp[u] = *(const pt_tpair __attribute__((address_space(1))) *)(tf + q);  // (wave-uniform branch)
+        }
+    };
+    auto issue_b = [&](const Desc &d, const RegA &ra, RegB &rb) {
+        if (!d.valid) return;
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const u32 ta = ra.tp[u].x, tb = ra.tp[u].y;
+            bad_t |= ta == PT_UNSET || tb == PT_UNSET;
+            rb.eu[u][0] = T.euler[ta < T.size ? ta : 0u];
+            rb.eu[u][1] = T.euler[tb < T.size ? tb : 0u];
+        }
+    };
+    auto process = [&](const Desc &d, const RegA &ra, const RegB &rb) {
+        const u64 p0 = d.p0, end = d.end, len = d.len;
+        if (p0 + (u64)U * 128 <= end && p0 + (u64)U * 128 + 2 <= len) {
+            // every lane has two records and a record behind them (wave-uniform test): no validity logic
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const u64 x0 = ra.pr[u].x, x1 = ra.pr[u].y;
+                bad |= x0 > x1 || x1 > ra.nx[u];
+                int s0, s1;
+                find2(x0, x1, s0, s1);
+                record(true, s0, x0, ra.tp[u].x, rb.eu[u][0]);
+                record(true, s1, x1, ra.tp[u].y, rb.eu[u][1]);  // (a code claimed a moment ago is found again by the insert)
+            }
+            return;
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const u64 pos = p0 + (u64)u * 128 + 2u * (u32)lane;
+            const u32 nv = pos + 1 < end ? 2u : (pos < end ? 1u : 0u);
+            const bool shifted = pos > len - 2;  // pos = len - 1 (or beyond: nv = 0): the record is the pair's second
+            const u64 x0 = shifted ? ra.pr[u].y : ra.pr[u].x;
+            const u32 y0 = shifted ? ra.tp[u].y : ra.tp[u].x, e0 = shifted ? rb.eu[u][1] : rb.eu[u][0];
+            const u64 x1 = nv == 2 ? ra.pr[u].y : x0;
+            // the record behind the last valid one (order check, also across slices); all ones behind the file
+            const u64 x2 = nv == 2 ? (pos + 2 < len ? ra.nx[u] : PU_EMPTY) : ((!shifted && pos + 1 < len) ? ra.pr[u].y : PU_EMPTY);
+            const bool v0 = nv >= 1, v1 = nv == 2;
+            if (v0) bad |= x0 > x1 || x1 > x2;
+            int s0, s1;
+            find2(x0, x1, s0, s1);
+            record(v0, s0, x0, y0, e0);
+            record(v1, s1, x1, ra.tp[u].y, rb.eu[u][1]);
+        }
+    };
+    auto take = [&]() -> u32 {
+        u32 j = 0;
+        if (lane == 0) j = atomicAdd(&s_next, 1u);
+        return (u32)__builtin_amdgcn_readfirstlane((int)j);
+    };
+    struct Meta { u64 beg, end, len, f, tf; };
+    auto fetch = [&](u32 j) -> Meta {
+        Meta m = {0, 0, 0, 0, 0};
+        if (j < S1) {
+            m.beg = sload_u64(&a.cuts[(u64)r * S1 + j]);
+            m.end = sload_u64(&a.cuts[(u64)(r + 1) * S1 + j]);
+            m.len = sload_u64(&a.lens[j]);
+            m.f = sload_u64((const u64 *)&a.files[j]);
+            m.tf = sload_u64((const u64 *)&a.tfiles[j]);
+        }
+        return m;
+    };
+    // the wave's sequence of steps: slices are taken from the workgroup's counter, the cut points of the slice after
+    // the current one are already on their way
+    u32 j = take();
+    Meta cur = fetch(j);
+    u32 jn = take();
+    Meta nxt = fetch(jn);
+    u64 pos = cur.beg;
+    auto next_desc = [&]() -> Desc {
+        for (;;) {
+            if (j >= S1) return Desc{0, 0, 0, 0, 0, false};
+            const u64 end = cur.end < cur.beg ? cur.beg : cur.end;
+            if (cur.len >= 2 && pos < end) {
+                const Desc d = {cur.f, cur.tf, pos, end, cur.len, true};
+                pos += (u64)U * 128;
+                return d;
+            }
+            if (cur.len < 2 && end > cur.beg) {  // a one-record file (no 16-byte load fits): done on the spot
+                const auto f = as_global((const u64 *)(uintptr_t)cur.f);
+                const u64 x = f[0];
+                const u32 t = cur.tf ? as_global((const u32 *)(uintptr_t)cur.tf)[0] : 0u;
+                bad_t |= t == PT_UNSET;
+                const u32 e = T.euler[t < T.size ? t : 0u];
+                record(lane == 0, lane == 0 ? find_from(x, pt_hash(x)) : -1, x, t, e);
+            }
+            j = jn;
+            cur = nxt;
+            jn = take();
+            nxt = fetch(jn);
+            pos = cur.beg;
+        }
+    };
+    {
+        Desc d0 = next_desc(), d1 = next_desc();
+        RegA a0, a1, a2;
+        RegB b0, b1;
+        issue_a(d0, a0);
+        issue_a(d1, a1);
+        issue_b(d0, a0, b0);
+        while (d0.valid) {
+            const Desc d2 = next_desc();
+            issue_a(d2, a2);
+            issue_b(d1, a1, b1);
+            process(d0, a0, b0);
+            d0 = d1; a0 = a1; b0 = b1;
+            d1 = d2; a1 = a2;
+        }
+    }
+    close_chunk();
+    if (bad) atomicOr((unsigned long long *)&a.ctl[1], (unsigned long long)PU_FLAG_UNSORTED);
+    if (bad_t) atomicOr((unsigned long long *)&a.ctl[1], (unsigned long long)PU_FLAG_TAXID);
+    __syncthreads();
+    // ---- the folds: one table LCA per entry that met a different TaxId -------------------------------------------------
+    auto settle = [&](int slot) -> u32 {
+        const uint4 st = s_st[slot];
+        const u32 t0 = st.x, mn = st.y, mx = st.z;
+        if (mn == 0xFFFFFFFFu && mx == 0u) return t0;  // every record carried t0
+        if (mx == PT_UNSET) return 0u;
+        const u32 e0 = t0 < T.size ? T.euler[t0] : 0u;
+        if (e0 == 0) return 0u;
+        return lca_dev(T, T.node_at[e0 < mn ? e0 : mn], T.node_at[e0 > mx ? e0 : mx]);
+    };
+#pragma unroll
+    for (int i = 0; i < PER; i++) {
+        if (ent[i] == PU_EMPTY) continue;
+        const int slot = find_from(ent[i], pt_hash(ent[i]));
+        const u32 res = settle(slot);
+        if (res != et[i]) a.base_tax[b0 + (u32)tid + (u32)i * PU_NT] = res;
+        s_st[slot].y = 0u;  // (never a number: this entry is done)
+    }
+    __syncthreads();
+    // what is left in the table are the new codes of this range
+    constexpr int SPT = (PT_SLOTS + PU_NT - 1) / PU_NT;
+    u32 mine = 0;
+#pragma unroll
+    for (int i = 0; i < SPT; i++) {
+        const int sl = tid * SPT + i;
+        if (sl < PT_SLOTS && s_tab[sl] != PU_EMPTY && s_st[sl].y != 0u) mine++;
+    }
+    u32 tot;
+    u32 at_l = block_excl_scan_u32<PU_NT>(mine, s_scan, &tot);
+    if (tot == 0) return;
+    if (tid == 0) {
+        const u64 at = atomicAdd((unsigned long long *)&a.ctl[0], (unsigned long long)tot);
+        if (at + tot > a.miss_cap) atomicOr((unsigned long long *)&a.ctl[1], (unsigned long long)PU_FLAG_OVERFLOW);
+        s_flush_at = at;
+    }
+    __syncthreads();
+    const u64 at = s_flush_at;
+    if (at + tot > a.miss_cap) return;
+#pragma unroll
+    for (int i = 0; i < SPT; i++) {
+        const int sl = tid * SPT + i;
+        if (sl < PT_SLOTS && s_tab[sl] != PU_EMPTY && s_st[sl].y != 0u) {
+            a.miss[at + at_l] = s_tab[sl];
+            a.miss_tax[at + at_l] = settle(sl);
+            at_l++;
+        }
+    }
+}
+
 double ms_since(std::chrono::steady_clock::time_point t0) {
     return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
 }
@@ -398,11 +763,27 @@ int ukm_punion_mode() {
     return atoi(e);
 }
 
-int ukm_dev_probe_union(ukm_ctx *c, const u64 *const *keys, const u64 *lens, int S, u64 *out, u64 out_cap, u64 *n_out,
-                        bool *fallback) {
+int ukm_punion_tax_mode() {
+    const char *e = getenv("UKM_PUNION_TAX");
+    if (!e || !*e) return -1;
+    return atoi(e);
+}
+
+int ukm_dev_probe_union(ukm_ctx *c, const u64 *const *keys, const u32 *const *taxids, const u64 *lens, int S, bool tax, u64 *out,
+                        u32 *tout, u64 out_cap, u64 *n_out, bool *fallback) {
     *fallback = true;
     *n_out = 0;
-    if (S < PU_K0 + 1) return UKM_OK;
+    // files of the base set: with TaxIds four (the base union pays an LCA per shared code: 8 files of config 3's shape
+    // took as long as a third of the probe pass; the codes the later files add are claimed in the tables anyway)
+    int k0 = tax ? PT_K0 : PU_K0;
+    if (tax && getenv("UKM_PUNION_K0")) k0 = std::max(3, std::min(64, atoi(getenv("UKM_PUNION_K0"))));  // developer knob
+    if (S < k0 + 1) return UKM_OK;
+    if (tax) {
+        if (!tout) UKM_FAIL(UKM_ERR_INVALID, "union: taxids given but out_taxids is NULL");
+        if (c->tax_parent == nullptr) UKM_FAIL(UKM_ERR_NO_TAXONOMY, "union: records carry taxids but no taxonomy is loaded");
+        if (c->tax_euler == nullptr || c->tax_node_at == nullptr) return UKM_OK;
+    }
+    const u32 range = tax ? (u32)PT_RANGE : (u32)PU_RANGE;
     const int mode = ukm_punion_mode();
     const bool dbg = getenv("UKM_PUNION_DEBUG") != nullptr;
     auto t0 = std::chrono::steady_clock::now();
@@ -414,24 +795,27 @@ int ukm_dev_probe_union(ukm_ctx *c, const u64 *const *keys, const u64 *lens, int
     };
     // 1. the base set
     u64 cap0 = 0, later = 0;
-    for (int j = 0; j < PU_K0; j++) cap0 += lens[j];
-    for (int j = PU_K0; j < S; j++) later += lens[j];
+    for (int j = 0; j < k0; j++) cap0 += lens[j];
+    for (int j = k0; j < S; j++) later += lens[j];
     u64 *base = nullptr;
+    u32 *base_tax = nullptr;
     UKM_TRY(ws_alloc_t(c, cap0 + 1, &base));
+    if (tax) UKM_TRY(ws_alloc_t(c, cap0 + 1, &base_tax));
     u64 n0 = 0;
     bool fb = false;
-    UKM_TRY(ukm_dev_kway(c, UKM_KWAY_UNION, keys, nullptr, lens, PU_K0, false, base, nullptr, cap0, &n0, &fb));
+    UKM_TRY(ukm_dev_kway(c, UKM_KWAY_UNION, keys, tax ? taxids : nullptr, lens, k0, tax, base, base_tax, cap0, &n0, &fb));
     if (fb || n0 == 0) return UKM_OK;
-    const u64 R64 = (n0 + PU_RANGE - 1) / PU_RANGE;
+    const u64 R64 = (n0 + range - 1) / range;
     if (R64 > 0x7FFFFFFEull) return UKM_OK;
     lap("base");
 
-    // device tables of the later files: [pointers S1][lens S1]
-    const int S1all = S - PU_K0;
-    std::vector<u64> tab((size_t)2 * S1all);
+    // device tables of the later files: [pointers S1][lens S1][TaxId pointers S1]
+    const int S1all = S - k0;
+    std::vector<u64> tab((size_t)3 * S1all);
     for (int j = 0; j < S1all; j++) {
-        tab[(size_t)j] = (u64)(uintptr_t)keys[PU_K0 + j];
-        tab[(size_t)S1all + j] = lens[PU_K0 + j];
+        tab[(size_t)j] = (u64)(uintptr_t)keys[k0 + j];
+        tab[(size_t)S1all + j] = lens[k0 + j];
+        tab[(size_t)2 * S1all + j] = (u64)(uintptr_t)((tax && taxids) ? taxids[k0 + j] : nullptr);
     }
     u64 *d_tab = nullptr, *ctl = nullptr;
     UKM_TRY(ws_alloc_t(c, tab.size(), &d_tab));
@@ -446,6 +830,9 @@ int ukm_dev_probe_union(ukm_ctx *c, const u64 *const *keys, const u64 *lens, int
     a.n0 = n0;
     a.R = (u32)R64;
     a.ctl = ctl;
+    a.range = range;
+    a.base_tax = base_tax;
+    if (tax) a.tax = ukm_taxdev(c);
 
     // 2. do the later files look like the base set?
     double miss_rate = 0.0;
@@ -462,7 +849,7 @@ int ukm_dev_probe_union(ukm_ctx *c, const u64 *const *keys, const u64 *lens, int
         miss_rate = 1.0 - (double)h[2] / (double)h[3];
         if (dbg) fprintf(stderr, "[punion] sample: %llu of %llu later records in the base set (n0 = %llu)\n",
                          (unsigned long long)h[2], (unsigned long long)h[3], (unsigned long long)n0);
-        if (mode != 2 && 1.0 - miss_rate < PU_MIN_HIT) return UKM_OK;
+        if (mode != 2 && 1.0 - miss_rate < (tax ? PT_MIN_HIT : PU_MIN_HIT)) return UKM_OK;
     }
     lap("sample");
 
@@ -471,12 +858,14 @@ int ukm_dev_probe_union(ukm_ctx *c, const u64 *const *keys, const u64 *lens, int
     u64 miss_cap = (u64)((double)later * std::min(1.0, 2.0 * miss_rate + 0.01)) + (1u << 20);
     miss_cap = std::min(miss_cap, later) + 64ull * (PU_NT / 64) * R64 * (u64)((S1all + PU_MAXS - 1) / PU_MAXS) + later / 32;
     UKM_TRY(ws_alloc_t(c, miss_cap + 1, &a.miss));
+    if (tax) UKM_TRY(ws_alloc_t(c, miss_cap + 1, &a.miss_tax));
     a.miss_cap = miss_cap;
     for (int s0 = 0; s0 < S1all; s0 += PU_MAXS) {
         const int s1 = std::min(PU_MAXS, S1all - s0);
         // (the pointer and length rows of a batch are not adjacent in d_tab: lens sits S1all entries behind)
         a.files = (const u64 *const *)(d_tab + s0);
         a.lens = d_tab + S1all + s0;
+        a.tfiles = (const u32 *const *)(d_tab + 2 * (size_t)S1all + s0);
         a.S1 = (u32)s1;
         WsMark mark = ws_mark(c);
         UKM_TRY(ws_alloc_t(c, ((size_t)a.R + 1) * s1, &a.cuts));
@@ -492,7 +881,7 @@ int ukm_dev_probe_union(ukm_ctx *c, const u64 *const *keys, const u64 *lens, int
             u64 heaviest = 0;
             UKM_TRY(ukm_read_u64(c, ctl + 4, &heaviest));
             u64 batch_records = 0;
-            for (int j = 0; j < s1; j++) batch_records += lens[PU_K0 + s0 + j];
+            for (int j = 0; j < s1; j++) batch_records += lens[k0 + s0 + j];
             const u64 avg = batch_records / a.R + 1;
             if (dbg) fprintf(stderr, "[punion] heaviest range %llu records, average %llu\n", (unsigned long long)heaviest, (unsigned long long)avg);
             if (mode != 2 && heaviest > 64 * avg + 65536) {
@@ -502,7 +891,8 @@ int ukm_dev_probe_union(ukm_ctx *c, const u64 *const *keys, const u64 *lens, int
             UKM_HIP(hipMemsetAsync(ctl + 4, 0, sizeof(u64), c->stream));
         }
         (void)hipEventRecord(c->ev_k0, c->stream);
-        hipLaunchKernelGGL(pu_probe_kernel, dim3(a.R), dim3(PU_NT), 0, c->stream, a);
+        if (tax) hipLaunchKernelGGL(pt_probe_kernel, dim3(a.R), dim3(PU_NT), 0, c->stream, a);
+        else hipLaunchKernelGGL(pu_probe_kernel, dim3(a.R), dim3(PU_NT), 0, c->stream, a);
         (void)hipEventRecord(c->ev_k1, c->stream);
         c->evk_valid = true;
         UKM_HIP(hipGetLastError());
@@ -522,17 +912,22 @@ int ukm_dev_probe_union(ukm_ctx *c, const u64 *const *keys, const u64 *lens, int
         if (n0 > out_cap)
             UKM_FAIL(UKM_ERR_CAPACITY, "output needs %llu records, capacity is %llu", (unsigned long long)n0, (unsigned long long)out_cap);
         UKM_HIP(hipMemcpyAsync(out, base, n0 * sizeof(u64), hipMemcpyDeviceToDevice, c->stream));
+        if (tax) UKM_HIP(hipMemcpyAsync(tout, base_tax, n0 * sizeof(u32), hipMemcpyDeviceToDevice, c->stream));
         *fallback = false;
         return UKM_OK;
     }
-    UKM_TRY(ukm_dev_sort(c, a.miss, nullptr, nm, 64));
+    // (with TaxIds: new codes arrive once per range and batch with their fold, unclaimed records one by one: the LCA
+    //  over equal codes of the sorted list and over the codes the list shares with the base set finishes the fold)
+    UKM_TRY(ukm_dev_sort(c, a.miss, tax ? a.miss_tax : nullptr, nm, 64));
     u64 *mu = nullptr;
+    u32 *mut = nullptr;
     UKM_TRY(ws_alloc_t(c, nm + 1, &mu));
+    if (tax) UKM_TRY(ws_alloc_t(c, nm + 1, &mut));
     u64 nmu = 0;
-    UKM_TRY(ukm_dev_unique(c, a.miss, nullptr, nm, UKM_UNIQUE, mu, nullptr, nm, &nmu));
+    UKM_TRY(ukm_dev_unique(c, a.miss, tax ? a.miss_tax : nullptr, nm, UKM_UNIQUE, mu, mut, nm, &nmu));
     lap("miss sort");
     // (capacity: the 2-way kernel reports the size it needs)
-    UKM_TRY(ukm_dev_setop2(c, UKM_OP_UNION, base, nullptr, n0, mu, nullptr, nmu, 0, out, nullptr, out_cap, n_out));
+    UKM_TRY(ukm_dev_setop2(c, UKM_OP_UNION, base, base_tax, n0, mu, mut, nmu, 0, out, tout, out_cap, n_out));
     lap("final");
     *fallback = false;
     return UKM_OK;
