@@ -82,6 +82,9 @@ int ukm_ctx_set_stream(ukm_ctx *ctx, void *hip_stream);
 int ukm_ctx_sync(ukm_ctx *ctx);
 /* pre-size the device workspace so that later calls do not allocate */
 int ukm_ctx_reserve(ukm_ctx *ctx, uint64_t bytes);
+/* give the device workspace back to the driver (it grows to what the largest call needed and is kept for the next one:
+ * a 100-file union of 1e10 records leaves 160 GB behind); the next call allocates again */
+int ukm_ctx_trim(ukm_ctx *ctx);
 /* device-memory helpers for hosts without their own allocator (the cgo shim) */
 int ukm_dev_alloc(ukm_ctx *ctx, uint64_t bytes, void **dptr);
 int ukm_dev_free(ukm_ctx *ctx, void *dptr);

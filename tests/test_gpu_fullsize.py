@@ -154,6 +154,76 @@ def test_config3_union_of_100_files_x_1e8_full_size(env, monkeypatch):
     assert acc.numel() == got.numel() and _xor(torch, acc) == x and bool((acc == got).all())
 
 
+def test_config3_union_with_taxids_full_size(env, monkeypatch):
+    """Config 3's files WITH taxids (union.go:195-201: the TaxId of a code is the LCA over every record that carries it),
+    100 x 1e8 records through the hash-probe pass with the TaxId fold in its tables (ukm_punion.hip, route 3).
+    (a) every record of file f carries that file's taxid (a leaf of the complete 8-ary tree): the expected TaxId of every
+    code is computed with torch from the membership bits — the smallest and the largest leaf among the files that hold
+    the code, climbed to their common ancestor by the tree's arithmetic; (b) uniformly random taxids: three windows of the
+    output against the oracle's hash-map union of the matching slices of all 100 files."""
+    torch, bench, lib, ctx, O, dev = env
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from conftest import synth_tree
+    child, parent = synth_tree(7, 8)
+    ctx.taxonomy_load(child, parent)
+    ctx.trim()   # (the plain test's k-way merge left 160 GB of workspace with the context)
+    torch.cuda.empty_cache()
+    tax = O.Taxonomy(child, parent)
+    T = len(child)
+    leaves0 = T - 8 ** 7 + 1
+    nfiles, per = 100, 100_000_000
+    nu = 2 * per
+    j = torch.arange(nu, dtype=torch.int64, device=dev)
+    Uv = torch.cumsum(1 + (bench.splitmix64_torch(j ^ bench._i64(bench.SEED)) & ((1 << 32) - 1)), 0)
+    files, taxs = [], []
+    anym = torch.zeros(nu, dtype=torch.bool, device=dev)
+    mn = torch.full((nu,), 1 << 40, dtype=torch.int64, device=dev)
+    mx = torch.zeros(nu, dtype=torch.int64, device=dev)
+    for f in range(nfiles):
+        m = (bench.splitmix64_torch(j ^ bench._i64(bench.SEED + 1000 * (f + 1))) & 1) == 1
+        k = Uv[m]
+        files.append(k)
+        tf = leaves0 + (f * 7919) % (8 ** 7)
+        taxs.append(torch.full((k.numel(),), tf, dtype=torch.int32, device=dev))
+        anym |= m
+        mn = torch.where(m & (mn > tf), torch.full_like(mn, tf), mn)
+        mx = torch.where(m & (mx < tf), torch.full_like(mx, tf), mx)
+    del j, m
+    a, b = mn[anym], mx[anym]
+    del mn, mx
+    for _ in range(7):   # leaves of one depth: climb both until they meet (parent(t) = (t - 2) // 8 + 1)
+        ne = a != b
+        a = torch.where(ne, (a - 2) // 8 + 1, a)
+        b = torch.where(ne, (b - 2) // 8 + 1, b)
+    assert bool((a == b).all())
+    expect_k, expect_t = Uv[anym], a.to(torch.int32)
+    del anym, b, Uv
+    out = torch.empty(nu + 8, dtype=torch.int64, device=dev)
+    outt = torch.empty(nu + 8, dtype=torch.int32, device=dev)
+    gk, gt = ctx.union(files, taxs, out=out, out_taxids=outt)
+    assert ctx.last_route() == 3
+    assert gk.numel() == expect_k.numel() and _strict(gk)
+    assert bool((gk == expect_k).all()) and bool((gt == expect_t).all())
+    del expect_k, expect_t, taxs
+    torch.cuda.empty_cache()
+    # (b) random taxids
+    taxs = [(1 + (bench.splitmix64_torch(k ^ bench._i64(bench.SEED + 2 + f)) & ((1 << 40) - 1)) % T).to(torch.int32)
+            for f, k in enumerate(files)]
+    gk, gt = ctx.union(files, taxs, out=out, out_taxids=outt)
+    assert ctx.last_route() == 3 and _strict(gk)
+    Ws = 200_000
+    for start in (0, gk.numel() // 2 - Ws // 2, gk.numel() - Ws):
+        wk, wt = gk[start:start + Ws], gt[start:start + Ws]
+        lo, hi = int(wk[0].item()), int(wk[-1].item())
+        sl, tl = [], []
+        for f, t in zip(files, taxs):
+            s0, s1 = _lower(torch, f, lo), _lower(torch, f, hi + 1)
+            sl.append(_np(f[s0:s1]))
+            tl.append(t[s0:s1].cpu().numpy().view(np.uint32))
+        ok, ot = O.union(sl, tl, tax)
+        assert np.array_equal(_np(wk), ok) and np.array_equal(wt.cpu().numpy().view(np.uint32), ot), start
+
+
 def test_config5_sketch_1e10_bases_full_size(env, monkeypatch):
     """BASELINE config 5: ntHash Scaled-MinHash sketch, k = 51, scale 1000, 1e10 bases of 150-bp reads.
     The rolling strip kernel against the prefix-XOR kernel over all 6.7e9 windows (two algorithms), the oracle on the

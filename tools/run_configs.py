@@ -145,7 +145,32 @@ def main():
                                                                   "note": "union by LDS hash probes against the union of the first eight files (ukm_punion.hip); "
                                                                           "ms_kway_merge_only = the k-way streaming merge (ukm_kway.hip, UKM_PUNION=0), same "
                                                                           "result (size and XOR checksum compared); round 1: 7-level pairwise tree, 78.7 ms"}
-        del files, U, out
+        del uk, u
+        ctx.trim()   # (the k-way merge's 160 GB of workspace)
+        torch.cuda.empty_cache()
+        # the same files WITH taxids (union.go:195-201: LCA over every record of a code): (i) every record of a file carries
+        # that file's taxid (k-mers of one genome, `count -t`), (ii) uniformly random taxids
+        child, parent = synth_tree(7, 8)
+        ctx.taxonomy_load(child, parent)
+        T = len(child)
+        leaves0 = T - 8 ** 7 + 1
+        outt = torch.empty(out.numel(), dtype=torch.int32, device=dev)
+        entry = res["config3_union_%d_files_x_%.0e" % (nfiles, per)]
+        for kind in ("one_taxid_per_file", "random_taxids"):
+            if kind == "one_taxid_per_file":
+                taxs = [torch.full((x.numel(),), leaves0 + (f * 7919) % (8 ** 7), dtype=torch.int32, device=dev) for f, x in enumerate(files)]
+            else:
+                taxs = [(1 + (bench.splitmix64_torch(x ^ bench._i64(bench.SEED + 2 + f)) & ((1 << 40) - 1)) % T).to(torch.int32)
+                        for f, x in enumerate(files)]
+            ctx.union(files, taxs, out=out, out_taxids=outt)
+            ms_t, ut = wall(lambda: ctx.union(files, taxs, out=out, out_taxids=outt), reps=args.reps)
+            assert ut[0].numel() == n_probe
+            entry["with_" + kind] = {"ms": ms_t, "route": ctx.last_route(), "kmers_per_s": total / ms_t * 1e3,
+                                     "roofline": roof_hbm(12 * total + 12 * n_probe, ms_t, "12 B (code + taxid) per input record read + 12 B per output record written")}
+            del taxs, ut
+        entry["note_taxids"] = ("route 3 = the hash-probe pass with the TaxId fold in its LDS tables (ukm_punion.hip, round 4); through the k-way "
+                                "merge the half-size shape took 106 / 124 ms against 31.5 / 87 ms (tools/c3_tax_bench.py)")
+        del files, U, out, outt
 
     if "4" in want:
         ctx.close()

@@ -192,6 +192,15 @@ static int ws_reset_top(ukm_ctx *c) {
     return UKM_OK;
 }
 
+extern "C" int ukm_ctx_trim(ukm_ctx *c) {
+    if (!c) UKM_FAIL(UKM_ERR_INVALID, "ukm_ctx_trim: ctx is NULL");
+    UKM_HIP(hipSetDevice(c->device));
+    UKM_HIP(hipStreamSynchronize(c->stream));
+    ws_free_all(c);
+    c->ws_high = 0;
+    return UKM_OK;
+}
+
 extern "C" int ukm_ctx_reserve(ukm_ctx *c, uint64_t bytes) {
     if (!c) UKM_FAIL(UKM_ERR_INVALID, "ukm_ctx_reserve: ctx is NULL");
     UKM_HIP(hipSetDevice(c->device));

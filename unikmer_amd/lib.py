@@ -24,7 +24,7 @@ F_DEVICE_STREAMS = 256   # every stream pointer of an n-way call is a device poi
 # every symbol include/unikmer_hip.h declares (checked by tests/test_abi.py)
 SYMBOLS = [
     "ukm_last_error", "ukm_version", "ukm_device_count", "ukm_ctx_create", "ukm_ctx_destroy",
-    "ukm_ctx_set_stream", "ukm_ctx_sync", "ukm_ctx_reserve", "ukm_dev_alloc", "ukm_dev_free",
+    "ukm_ctx_set_stream", "ukm_ctx_sync", "ukm_ctx_reserve", "ukm_ctx_trim", "ukm_dev_alloc", "ukm_dev_free",
     "ukm_copy", "ukm_host_alloc", "ukm_host_free", "ukm_copy_async", "ukm_copy_fence", "ukm_copy_sync", "ukm_last_kernel_ms", "ukm_last_call_ms", "ukm_last_route", "ukm_taxonomy_load", "ukm_taxonomy_max_taxid", "ukm_lca",
     "ukm_encode_kmers", "ukm_nthash", "ukm_minimizer", "ukm_max_hash", "ukm_sort_u64", "ukm_sort_pairs",
     "ukm_unique", "ukm_merge_k", "ukm_setop2", "ukm_union", "ukm_inter", "ukm_diff",
@@ -97,6 +97,7 @@ def load():
     L.ukm_ctx_set_stream.argtypes = [vp, vp]
     L.ukm_ctx_sync.argtypes = [vp]
     L.ukm_ctx_reserve.argtypes = [vp, u64]
+    L.ukm_ctx_trim.argtypes = [vp]
     L.ukm_dev_alloc.argtypes = [vp, u64, pvp]
     L.ukm_dev_free.argtypes = [vp, vp]
     L.ukm_copy.argtypes = [vp, vp, vp, u64]
@@ -226,6 +227,10 @@ class Context:
 
     def reserve(self, nbytes):
         _check(self.L.ukm_ctx_reserve(self.h, nbytes))
+
+    def trim(self):
+        """give the device workspace back (it is kept at the size the largest call needed)"""
+        _check(self.L.ukm_ctx_trim(self.h))
 
     def last_kernel_ms(self):
         ms = C.c_float()
