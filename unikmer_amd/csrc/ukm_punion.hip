@@ -395,24 +395,34 @@ __global__ __launch_bounds__(PU_NT) __attribute__((amdgpu_waves_per_eu(PU_WAVES,
 }
 
 // ---- the same pass over records WITH TaxIds (union.go:195-201: the TaxId of a code is the LCA over all its records) ----
-// Beside every table slot three words of LDS: the TaxId the entry came with (t0: the base files' fold, or the first
-// record of a new code), and the smallest / largest pre-order number (TaxDev::euler) among the records whose TaxId
-// differs from t0.  A hit is two LDS reads and — only while it still widens the interval — an LDS atomic; the LCA of a
-// set of nodes is the LCA of its members with the smallest and the largest number, so ONE table LCA per entry at the end
-// equals the reference's left fold (the contract of lca_dev: 0 / unknown ids absorb unless every TaxId is the same).
+// Beside every table slot one 16-byte word of LDS: the TaxId the entry came with (t0: the base files' fold, or the first
+// record of a new code), the smallest pre-order number (TaxDev::euler) among its records, the COMPLEMENT of the largest
+// (so that widening the interval at either end is the same instruction, an atomic minimum, on one of two words), and a
+// flag for the one case the interval cannot show: a record with another TaxId but the same number as everything so far
+// (an alias of a merged id; two different unknown ids).  A hit is one more LDS read and — only while it still widens the
+// interval — one LDS atomic; the LCA of a set of nodes is the LCA of its members with the smallest and the largest
+// number, so ONE table LCA per entry at the end equals the reference's left fold (the contract of lca_dev: 0 / unknown
+// ids absorb unless every TaxId is the same).
 // New codes are claimed in the table as in the plain pass and leave WITH their fold when the range is done; what
 // cannot be claimed (all-ones codes, a table that has doubled) is listed record by record and folded by the final
 // sort + unique + 2-way union.  The three words of a slot sit in ONE 16-byte LDS word (a hit reads them with one
-// ds_read_b128 beside the two of its bucket): 24 bytes per slot, 768 buckets of four (72 KB), two workgroups per CU.
+// ds_read_b128 beside the two of its bucket): 24 bytes per slot, 1536 buckets of four (144 KB), one workgroup of 1024
+// threads per CU (768 buckets and two workgroups of 512 measured the same probe time; the larger range halves the cut
+// points and the per-slice steps: 31.0 -> 29.9 ms on config 3's shape at half size).
 #ifndef PT_BUCKETS_N
-#define PT_BUCKETS_N 768
+#define PT_BUCKETS_N 1536
 #endif
+#ifndef PT_NT_N
+#define PT_NT_N 1024
+#endif
+constexpr int PT_NT = PT_NT_N;
+constexpr int PT_WAVES = PT_NT == 1024 ? 4 : PU_WAVES;
 constexpr int PT_BUCKETS = PT_BUCKETS_N;
 constexpr int PT_SLOTS = 4 * PT_BUCKETS;
 constexpr int PT_RANGE = PT_BUCKETS;
 constexpr int PT_K0 = 4;               // files merged into the base set
 constexpr double PT_MIN_HIT = 0.70;   // (new codes are claimed in the tables with their fold: a lower bar than the plain pass)
-constexpr u32 PT_UNSET = 0xFFFFFFFFu;  // s_t0: nobody has set it yet; s_max: an unknown id was seen (never a number)
+constexpr u32 PT_UNSET = 0xFFFFFFFFu;  // t0 of a slot: nobody has set it yet
 
 __device__ __forceinline__ u32 pt_hash(u64 x) {
     const u32 lo = (u32)x, hi = (u32)(x >> 32);
@@ -422,18 +432,18 @@ __device__ __forceinline__ u32 pt_hash(u64 x) {
 typedef u32 pt_u32x2 __attribute__((ext_vector_type(2)));
 typedef pt_u32x2 __attribute__((aligned(4))) pt_tpair;  // 8 bytes at 4-byte alignment
 
-__global__ __launch_bounds__(PU_NT) __attribute__((amdgpu_waves_per_eu(PU_WAVES, PU_WAVES))) void pt_probe_kernel(PuArgs a) {
+__global__ __launch_bounds__(PT_NT) __attribute__((amdgpu_waves_per_eu(PT_WAVES, PT_WAVES))) void pt_probe_kernel(PuArgs a) {
     __shared__ __attribute__((aligned(32))) u64 s_tab[PT_SLOTS];
-    __shared__ __attribute__((aligned(16))) uint4 s_st[PT_SLOTS];  // x = t0, y = smallest, z = largest number
+    __shared__ __attribute__((aligned(16))) uint4 s_st[PT_SLOTS];  // x = t0, y = smallest number, z = ~largest, w = flag (2: settled)
     __shared__ u32 s_next, s_nins;
-    __shared__ u32 s_scan[PU_NT / 64 + 1];
+    __shared__ u32 s_scan[PT_NT / 64 + 1];
     __shared__ u64 s_flush_at;
     const int tid = (int)threadIdx.x, lane = lane_id();
     const u32 r = blockIdx.x, S1 = a.S1;
     const TaxDev &T = a.tax;
-    for (int i = tid; i < PT_SLOTS; i += PU_NT) {
+    for (int i = tid; i < PT_SLOTS; i += PT_NT) {
         s_tab[i] = PU_EMPTY;
-        s_st[i] = make_uint4(PT_UNSET, 0xFFFFFFFFu, 0u, 0u);
+        s_st[i] = make_uint4(PT_UNSET, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u);  // (an empty interval)
     }
     if (tid == 0) { s_next = 0; s_nins = 0; }
     __syncthreads();
@@ -454,24 +464,27 @@ __global__ __launch_bounds__(PU_NT) __attribute__((amdgpu_waves_per_eu(PU_WAVES,
     };
     const u64 b0 = (u64)r * PT_RANGE;
     const u32 nb = (u32)((a.n0 - b0 < (u64)PT_RANGE) ? (a.n0 - b0) : (u64)PT_RANGE);
-    constexpr int PER = (PT_RANGE + PU_NT - 1) / PU_NT;
+    constexpr int PER = (PT_RANGE + PT_NT - 1) / PT_NT;
     u64 ent[PER];
     u32 et[PER];
     bool bad = false, bad_t = false;  // an unsorted file; a TaxId of 2^32 - 1 (the table's own "not set")
 #pragma unroll
     for (int i = 0; i < PER; i++) {
-        const u32 idx = (u32)tid + (u32)i * PU_NT;
+        const u32 idx = (u32)tid + (u32)i * PT_NT;
         ent[i] = a.base[b0 + (idx < nb ? idx : 0)];
         et[i] = a.base_tax[b0 + (idx < nb ? idx : 0)];
         if (idx >= nb) ent[i] = PU_EMPTY;
         else bad_t |= et[i] == PT_UNSET;
     }
+    u32 ee[PER];
+#pragma unroll
+    for (int i = 0; i < PER; i++) ee[i] = T.euler[et[i] < T.size ? et[i] : 0u];
 #pragma unroll
     for (int i = 0; i < PER; i++) {
         if (ent[i] == PU_EMPTY) continue;  // (an all-ones code: its records are listed, the final union folds them)
         bool fresh;
         const int slot = insert(ent[i], fresh);
-        s_st[slot].x = et[i];
+        s_st[slot] = make_uint4(et[i], ee[i], ~ee[i], 0u);
     }
     __syncthreads();
     auto find_from = [&](u64 x, u32 h) -> int {
@@ -498,18 +511,23 @@ __global__ __launch_bounds__(PU_NT) __attribute__((amdgpu_waves_per_eu(PU_WAVES,
     };
     // one record's TaxId into its entry; e = its pre-order number (0: taxid 0 / unknown)
     auto fold = [&](int slot, u32 t, u32 e) {
-        const uint4 st = s_st[slot];
-        u32 t0 = st.x;
-        if (t0 == PT_UNSET) {  // a new code: whoever comes first sets it (any order gives the same fold)
+        uint4 st = s_st[slot];
+        if (st.x == PT_UNSET) {  // a new code: whoever comes first gives it its TaxId (any order gives the same fold)
             const u32 old = atomicCAS(&s_st[slot].x, PT_UNSET, t);
-            t0 = old == PT_UNSET ? t : old;
+            if (old == PT_UNSET) {
+                atomicMin(&s_st[slot].y, e);
+                atomicMin(&s_st[slot].z, ~e);
+                return;
+            }
+            st = s_st[slot];
         }
-        if (t == t0) return;
-        if (e == 0) {
-            if (st.z != PT_UNSET) atomicMax(&s_st[slot].z, PT_UNSET);
-        } else {
-            if (e < st.y) atomicMin(&s_st[slot].y, e);
-            if (e > st.z) atomicMax(&s_st[slot].z, e);
+        if (t == st.x) return;
+        const bool lo = e < st.y, hi = ~e < st.z;
+        if (lo | hi) {
+            atomicMin(lo ? &s_st[slot].y : &s_st[slot].z, lo ? e : ~e);
+            if (lo & hi) atomicMin(&s_st[slot].z, ~e);  // (an interval that is still empty: a new code a moment after its claim)
+        } else if (st.y == e && st.z == ~e && st.w == 0u) {
+            s_st[slot].w = 1u;
         }
     };
     const u64 lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
@@ -568,7 +586,7 @@ __global__ __launch_bounds__(PU_NT) __attribute__((amdgpu_waves_per_eu(PU_WAVES,
     };
     // The lanes stream a slice 256 records per step.  A step is three things that each wait for the one before: the loads
     // of codes and TaxIds (A), the pre-order numbers of those TaxIds (B: a second round trip), the probes (C).  Slices are
-    // short here (a range of 768 entries: a few hundred records per file), so a wave that did A, B, C one after the other
+    // short here (a range of 1536 entries: several hundred records per file), so a wave that did A, B, C one after the other
     // spent its time waiting twice per step (24 ms on config 3's shape at half size).  The steps of ALL slices of the wave
     // form one sequence instead and run as a pipeline: A of step i + 2 and B of step i + 1 are issued before C of step i.
     constexpr int U = 2;
@@ -603,16 +621,18 @@ __global__ __launch_bounds__(PU_NT) __attribute__((amdgpu_waves_per_eu(PU_WAVES,
     };
     auto process = [&](const Desc &d, const RegA &ra, const RegB &rb) {
         const u64 p0 = d.p0, end = d.end, len = d.len;
-        if (p0 + (u64)U * 128 <= end && p0 + (u64)U * 128 + 2 <= len) {
-            // every lane has two records and a record behind them (wave-uniform test): no validity logic
+        if (p0 + (u64)U * 128 + 2 <= len) {
+            // every lane read two records of the file and the record behind them (wave-uniform test): the order check
+            // needs no validity logic (what lies behind the slice's end is still the file), the probes only `pos < end`
 #pragma unroll
             for (int u = 0; u < U; u++) {
+                const u64 pos = p0 + (u64)u * 128 + 2u * (u32)lane;
                 const u64 x0 = ra.pr[u].x, x1 = ra.pr[u].y;
                 bad |= x0 > x1 || x1 > ra.nx[u];
                 int s0, s1;
                 find2(x0, x1, s0, s1);
-                record(true, s0, x0, ra.tp[u].x, rb.eu[u][0]);
-                record(true, s1, x1, ra.tp[u].y, rb.eu[u][1]);  // (a code claimed a moment ago is found again by the insert)
+                record(pos < end, s0, x0, ra.tp[u].x, rb.eu[u][0]);
+                record(pos + 1 < end, s1, x1, ra.tp[u].y, rb.eu[u][1]);  // (a code claimed a moment ago is found again by the insert)
             }
             return;
         }
@@ -705,32 +725,30 @@ __global__ __launch_bounds__(PU_NT) __attribute__((amdgpu_waves_per_eu(PU_WAVES,
     // ---- the folds: one table LCA per entry that met a different TaxId -------------------------------------------------
     auto settle = [&](int slot) -> u32 {
         const uint4 st = s_st[slot];
-        const u32 t0 = st.x, mn = st.y, mx = st.z;
-        if (mn == 0xFFFFFFFFu && mx == 0u) return t0;  // every record carried t0
-        if (mx == PT_UNSET) return 0u;
-        const u32 e0 = t0 < T.size ? T.euler[t0] : 0u;
-        if (e0 == 0) return 0u;
-        return lca_dev(T, T.node_at[e0 < mn ? e0 : mn], T.node_at[e0 > mx ? e0 : mx]);
+        const u32 mn = st.y, mx = ~st.z;
+        if (mn == mx && st.w == 0u) return st.x;  // every record carried t0
+        if (mn == 0u) return 0u;                  // TaxId 0 / an unknown id among records that differ
+        return lca_dev(T, T.node_at[mn], T.node_at[mx]);
     };
 #pragma unroll
     for (int i = 0; i < PER; i++) {
         if (ent[i] == PU_EMPTY) continue;
         const int slot = find_from(ent[i], pt_hash(ent[i]));
         const u32 res = settle(slot);
-        if (res != et[i]) a.base_tax[b0 + (u32)tid + (u32)i * PU_NT] = res;
-        s_st[slot].y = 0u;  // (never a number: this entry is done)
+        if (res != et[i]) a.base_tax[b0 + (u32)tid + (u32)i * PT_NT] = res;
+        s_st[slot].w = 2u;  // (this entry is done)
     }
     __syncthreads();
     // what is left in the table are the new codes of this range
-    constexpr int SPT = (PT_SLOTS + PU_NT - 1) / PU_NT;
+    constexpr int SPT = (PT_SLOTS + PT_NT - 1) / PT_NT;
     u32 mine = 0;
 #pragma unroll
     for (int i = 0; i < SPT; i++) {
         const int sl = tid * SPT + i;
-        if (sl < PT_SLOTS && s_tab[sl] != PU_EMPTY && s_st[sl].y != 0u) mine++;
+        if (sl < PT_SLOTS && s_tab[sl] != PU_EMPTY && s_st[sl].w != 2u) mine++;
     }
     u32 tot;
-    u32 at_l = block_excl_scan_u32<PU_NT>(mine, s_scan, &tot);
+    u32 at_l = block_excl_scan_u32<PT_NT>(mine, s_scan, &tot);
     if (tot == 0) return;
     if (tid == 0) {
         const u64 at = atomicAdd((unsigned long long *)&a.ctl[0], (unsigned long long)tot);
@@ -743,7 +761,7 @@ __global__ __launch_bounds__(PU_NT) __attribute__((amdgpu_waves_per_eu(PU_WAVES,
 #pragma unroll
     for (int i = 0; i < SPT; i++) {
         const int sl = tid * SPT + i;
-        if (sl < PT_SLOTS && s_tab[sl] != PU_EMPTY && s_st[sl].y != 0u) {
+        if (sl < PT_SLOTS && s_tab[sl] != PU_EMPTY && s_st[sl].w != 2u) {
             a.miss[at + at_l] = s_tab[sl];
             a.miss_tax[at + at_l] = settle(sl);
             at_l++;
@@ -856,7 +874,7 @@ int ukm_dev_probe_union(ukm_ctx *c, const u64 *const *keys, const u32 *const *ta
     // 3. probe pass
     // (+ one partly used chunk of 64 per wave of the grid)
     u64 miss_cap = (u64)((double)later * std::min(1.0, 2.0 * miss_rate + 0.01)) + (1u << 20);
-    miss_cap = std::min(miss_cap, later) + 64ull * (PU_NT / 64) * R64 * (u64)((S1all + PU_MAXS - 1) / PU_MAXS) + later / 32;
+    miss_cap = std::min(miss_cap, later) + 64ull * (std::max(PU_NT, PT_NT) / 64) * R64 * (u64)((S1all + PU_MAXS - 1) / PU_MAXS) + later / 32;
     UKM_TRY(ws_alloc_t(c, miss_cap + 1, &a.miss));
     if (tax) UKM_TRY(ws_alloc_t(c, miss_cap + 1, &a.miss_tax));
     a.miss_cap = miss_cap;
@@ -891,7 +909,7 @@ int ukm_dev_probe_union(ukm_ctx *c, const u64 *const *keys, const u32 *const *ta
             UKM_HIP(hipMemsetAsync(ctl + 4, 0, sizeof(u64), c->stream));
         }
         (void)hipEventRecord(c->ev_k0, c->stream);
-        if (tax) hipLaunchKernelGGL(pt_probe_kernel, dim3(a.R), dim3(PU_NT), 0, c->stream, a);
+        if (tax) hipLaunchKernelGGL(pt_probe_kernel, dim3(a.R), dim3(PT_NT), 0, c->stream, a);
         else hipLaunchKernelGGL(pu_probe_kernel, dim3(a.R), dim3(PU_NT), 0, c->stream, a);
         (void)hipEventRecord(c->ev_k1, c->stream);
         c->evk_valid = true;
