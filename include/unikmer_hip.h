@@ -238,7 +238,11 @@ int ukm_shard_exchange(ukm_ctx *ctx, const uint64_t *keys, const uint32_t *taxid
  *      recv_counts[nfiles][nranks], ONE all-gather and host round trip for all files; size the receive buffers
  *      from it), then ukm_shard_exchange_known per file, which has no gather and no host round trip in front of the
  *      transfers (own slice: device-to-device copy; peers: one ncclSend / ncclRecv group on the context's stream; like
- *      every entry point the call returns when its stream work is done). */
+ *      every entry point the call returns when its stream work is done).  It takes no collective decision: a rank whose
+ *      buffer is too small, or whose own entries of send_counts / recv_counts disagree, still takes part (what arrives is
+ *      dropped in a scratch buffer of the largest slice) and returns UKM_ERR_CAPACITY / UKM_ERR_INVALID afterwards.  A
+ *      device failure in front of the transfers (no memory for staging) leaves the peers blocked in RCCL: destroy the
+ *      communicator, as after any lost rank. */
 int ukm_shard_plan(int nranks, int rank, const uint64_t *all, uint64_t *recv_counts, uint64_t *n_out);
 /*      Sampled splitters (k-mer codes are not uniform in their top bits -- README.md:177-180, sorted
  *      k-mers start AAAAAAAAA... -- so equal-width ranges leave the ranks unevenly loaded): ukm_shard_splitters is

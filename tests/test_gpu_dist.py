@@ -288,6 +288,12 @@ def test_c_abi_rccl_exchange_one_rank():
     # known counts with a short buffer: the rank still takes part (drains into workspace) and reports the error after
     assert L.ukm_shard_exchange_known(ctx.h, keys.ctypes.data, None, sc.ctypes.data, sc.ctypes.data, small.ctypes.data, None,
                                       10, C.byref(m)) == lib.ERR_CAPACITY
+    # ... and so does a rank whose own slice sizes disagree (counts that did not come from ukm_shard_counts)
+    wrong = np.array([len(keys) - 1], dtype=np.uint64)
+    assert L.ukm_shard_exchange_known(ctx.h, keys.ctypes.data, None, sc.ctypes.data, wrong.ctypes.data, full.ctypes.data, None,
+                                      len(full), C.byref(m)) == lib.ERR_INVALID
+    assert L.ukm_shard_exchange_known(ctx.h, keys.ctypes.data, None, sc.ctypes.data, sc.ctypes.data, full.ctypes.data, None,
+                                      len(full), C.byref(m)) == 0 and np.array_equal(full, keys)
     # sampled splitters (collective; one rank: the boundaries are [0, top]) through the device sampling kernel + all-gather,
     # host arrays and device tensors, an empty file among them
     sp = ctx.shard_splitters([keys, np.empty(0, np.uint64), keys[::2].copy()], 62)

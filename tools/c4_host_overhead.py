@@ -1,5 +1,5 @@
 """developer tool: config-4 (core shape) inter / diff call time against kernel time and library call time: where the rest goes.
-usage: python tools/c4_host_overhead.py"""
+usage: python tools/c4_host_overhead.py      (C4_TAX=file: every record of a file carries that file's taxid instead of a random one)"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -25,7 +25,10 @@ for f in range(nfiles):
     if f == 0:
         k = torch.cat([k, U[-1] + 1 + torch.arange(per // 10, dtype=torch.int64, device=dev) * 3])
     files.append(k)
-    taxs.append((1 + (bench.splitmix64_torch(k ^ bench._i64(bench.SEED + 2 + f)) & ((1 << 40) - 1)) % T).to(torch.int32))
+    if os.environ.get("C4_TAX") == "file":
+        taxs.append(torch.full((k.numel(),), T - 8 ** 7 + 1 + (f * 7919) % (8 ** 7), dtype=torch.int32, device=dev))
+    else:
+        taxs.append((1 + (bench.splitmix64_torch(k ^ bench._i64(bench.SEED + 2 + f)) & ((1 << 40) - 1)) % T).to(torch.int32))
 out = torch.empty(files[0].numel() + 8, dtype=torch.int64, device=dev)
 outt = torch.empty(files[0].numel() + 8, dtype=torch.int32, device=dev)
 for name, fn in (("inter+tax", lambda: ctx.inter(files, taxs, out=out, out_taxids=outt)), ("diff+tax", lambda: ctx.diff(files, taxs, out=out, out_taxids=outt)),

@@ -252,14 +252,17 @@ int gather_u64(ukm_ctx *c, Rccl *R, const u64 *mine, size_t per_rank, std::vecto
 // the data movement of one stream: the rank's own slice is a device-to-device copy, every other slice one
 // ncclSend + ncclRecv inside ONE group (every peer's transfers are posted before any of them blocks: full mesh over
 // xGMI).  Nothing in here waits on the host: the transfers are stream-ordered.
+// drain = true: this rank cannot keep what arrives (buffer too small, inconsistent arguments) but still takes part, so
+// that no peer waits for it: every peer's slice lands at the START of `ok` / `ot` (a scratch buffer of the largest
+// slice; the transfers overwrite each other, nothing is read) and the rank's own slice is not copied.
 int post_exchange(ukm_ctx *c, Rccl *R, const u64 *k, const u32 *t, const u64 *send_counts, const u64 *recv_counts, u64 *ok,
-                  u32 *ot) {
+                  u32 *ot, bool drain = false) {
     const int W = c->comm_size, me = c->comm_rank;
     UkmNcclComm comm = (UkmNcclComm)c->comm;
     u64 so = 0, ro = 0, my_so = 0, my_ro = 0;
     for (int g = 0; g < me; g++) { my_so += send_counts[g]; my_ro += recv_counts[g]; }
-    if (send_counts[me] != recv_counts[me]) UKM_FAIL(UKM_ERR_INVALID, "ukm_shard_exchange: own slice sizes disagree");
-    if (send_counts[me]) {
+    if (!drain && send_counts[me] != recv_counts[me]) UKM_FAIL(UKM_ERR_INVALID, "ukm_shard_exchange: own slice sizes disagree");
+    if (!drain && send_counts[me]) {
         UKM_HIP(hipMemcpyAsync(ok + my_ro, k + my_so, (size_t)send_counts[me] * sizeof(u64), hipMemcpyDeviceToDevice, c->stream));
         if (t) UKM_HIP(hipMemcpyAsync(ot + my_ro, t + my_so, (size_t)send_counts[me] * sizeof(u32), hipMemcpyDeviceToDevice, c->stream));
     }
@@ -269,9 +272,9 @@ int post_exchange(ukm_ctx *c, Rccl *R, const u64 *k, const u32 *t, const u64 *se
     for (int g = 0; g < W && !first_err; g++) {
         if (g != me) {
             if (send_counts[g]) first_err = R->Send(k + so, (size_t)send_counts[g], UKM_NCCL_UINT64, g, comm, c->stream);
-            if (!first_err && recv_counts[g]) first_err = R->Recv(ok + ro, (size_t)recv_counts[g], UKM_NCCL_UINT64, g, comm, c->stream);
+            if (!first_err && recv_counts[g]) first_err = R->Recv(ok + (drain ? 0 : ro), (size_t)recv_counts[g], UKM_NCCL_UINT64, g, comm, c->stream);
             if (!first_err && t && send_counts[g]) first_err = R->Send(t + so, (size_t)send_counts[g], UKM_NCCL_UINT32, g, comm, c->stream);
-            if (!first_err && t && recv_counts[g]) first_err = R->Recv(ot + ro, (size_t)recv_counts[g], UKM_NCCL_UINT32, g, comm, c->stream);
+            if (!first_err && t && recv_counts[g]) first_err = R->Recv(ot + (drain ? 0 : ro), (size_t)recv_counts[g], UKM_NCCL_UINT32, g, comm, c->stream);
         }
         so += send_counts[g];
         ro += recv_counts[g];
@@ -307,9 +310,12 @@ extern "C" int ukm_shard_counts(ukm_ctx *c, const uint64_t *send_counts, int nfi
 
 // The exchange with slice sizes that are already known on both sides (ukm_shard_counts): no all-gather and no host
 // round trip in front of the transfers (the call still ends with the stream synchronisation of every entry point).
-// A rank whose buffer is
-// too small still takes part (its slices land in workspace memory and are dropped) and reports UKM_ERR_CAPACITY
-// afterwards, so that its peers never wait for a rank that left.
+// There is no collective decision in this call, so a rank that cannot keep what arrives — its buffer is too small, or its
+// own slice sizes in send_counts / recv_counts disagree (arrays that did not come from ukm_shard_counts) — still takes
+// part: the peers' slices land in a scratch buffer of the largest single slice and are dropped, and the rank reports
+// UKM_ERR_CAPACITY / UKM_ERR_INVALID afterwards; its peers never wait for a rank that left.  What is left are failures
+// of the device itself in front of the transfers (no memory for that scratch buffer or for staging host arrays): the
+// peers then block in RCCL and the communicator has to be destroyed (ukm_comm_destroy), as after any lost rank.
 extern "C" int ukm_shard_exchange_known(ukm_ctx *c, const uint64_t *keys, const uint32_t *taxids, const uint64_t *send_counts,
                                         const uint64_t *recv_counts, uint64_t *out_keys, uint32_t *out_taxids,
                                         uint64_t out_cap, uint64_t *n_out) {
@@ -331,15 +337,24 @@ extern "C" int ukm_shard_exchange_known(ukm_ctx *c, const uint64_t *keys, const 
         u32 *ot = nullptr;
         UKM_TRY(ukm_in_t(c, keys, n, &k));
         if (taxids) UKM_TRY(ukm_in_t(c, taxids, n, &t));
+        const int me = c->comm_rank;
+        const bool own_ok = send_counts[me] == recv_counts[me];
         const bool fits = total <= out_cap;
-        if (fits) {
+        const bool drain = !fits || !own_ok;
+        if (!drain) {
             UKM_TRY(ukm_out_t(c, out_keys, out_cap, &ok));
             if (taxids) UKM_TRY(ukm_out_t(c, out_taxids, out_cap, &ot));
-        } else {  // drain
-            UKM_TRY(ws_alloc_t(c, (size_t)total + 1, &ok));
-            if (taxids) UKM_TRY(ws_alloc_t(c, (size_t)total + 1, &ot));
+        } else {
+            u64 largest = 0;
+            for (int g = 0; g < W; g++)
+                if (g != me) largest = std::max<u64>(largest, recv_counts[g]);
+            UKM_TRY(ws_alloc_t(c, (size_t)largest + 1, &ok));
+            if (taxids) UKM_TRY(ws_alloc_t(c, (size_t)largest + 1, &ot));
         }
-        UKM_TRY(post_exchange(c, R, k, t, send_counts, recv_counts, ok, ot));
+        UKM_TRY(post_exchange(c, R, k, t, send_counts, recv_counts, ok, ot, drain));
+        if (!own_ok)
+            UKM_FAIL(UKM_ERR_INVALID, "ukm_shard_exchange_known: own slice sizes disagree (send %llu, receive %llu): counts must come from ukm_shard_counts",
+                     (unsigned long long)send_counts[me], (unsigned long long)recv_counts[me]);
         if (!fits)
             UKM_FAIL(UKM_ERR_CAPACITY, "ukm_shard_exchange_known: %llu records arrived, capacity is %llu", (unsigned long long)total,
                      (unsigned long long)out_cap);
