@@ -403,6 +403,7 @@ def test_config4_inter_diff_common_1000_files_x_1e6_full_size(env, monkeypatch, 
     if core_share > 0:
         assert len(want["inter"][0]) > 200_000 and len(want["diff"][0]) >= per // 10    # results that survive every file
         want["common"] = O.common(hf, nfiles, ht, tax)
+        want["common_minus_1"] = O.common(hf, nfiles - 1, ht, tax)
     else:
         assert len(want["inter"][0]) == 0 and len(want["diff"][0]) == 0 and len(want["diff_t"][0]) > 0
     del hf, ht
@@ -432,4 +433,9 @@ def test_config4_inter_diff_common_1000_files_x_1e6_full_size(env, monkeypatch, 
         otc = torch.empty(total + 8, dtype=torch.int32, device=dev)
         monkeypatch.setenv("UKM_COMMON_PROBE", "0")
         same(ctx.common(files, nfiles, taxs, out=okc, out_taxids=otc), "common", "counting merge")
+        assert ctx.last_route() == 5   # (the single-pass merge counting inside its tiles, ukm_srmerge.hip)
         monkeypatch.delenv("UKM_COMMON_PROBE")
+        # one below the number of files: codes that one file lacks survive too
+        same(ctx.common(files, nfiles - 1, taxs, out=okc, out_taxids=otc), "common_minus_1", "counted single pass")
+        assert ctx.last_route() == 5
+        assert len(want["common_minus_1"][0]) >= len(want["common"][0])
