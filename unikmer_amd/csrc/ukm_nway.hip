@@ -278,7 +278,7 @@ int try_kway(ukm_ctx *ctx, int op, const std::vector<Stream> &ss, bool tax, u64 
 
 // `union` of many sets by LDS hash probes against the union of the first eight (with TaxIds: four) files
 // (ukm_punion.hip): the shape of an n-file union over related genomes, where after a few files nearly every record is
-// already in the result.  Taken for >= PUNION_MIN_STREAMS streams and >= 2^27 records behind the first eight; the path itself
+// already in the result.  Taken for >= PUNION_MIN_STREAMS streams and >= 2^27 (with TaxIds 2^26) records behind the first eight; the path itself
 // backs out (*done = false, nothing written) when a sample of the later files is not found in the base set, when a
 // stream is unsorted or when its miss list overflows, and the k-way merge below answers.
 constexpr int PUNION_MIN_STREAMS = 24;
@@ -291,7 +291,9 @@ int try_probe_union(ukm_ctx *ctx, const std::vector<Stream> &ss, bool tax, u64 *
         if ((int)ss.size() < PUNION_MIN_STREAMS) return UKM_OK;
         u64 later = 0;
         for (size_t i = 8; i < ss.size(); i++) later += ss[i].n;
-        if (later < (1ull << 27)) return UKM_OK;
+        // (with taxids the other routes cost more per record: 1e8 records in 100 - 1000 files 2.5 - 3.8 ms here against
+        //  3.3 - 4.8 ms; 3e7 records 1.4 - 3.5 against 1.3 - 2.8)
+        if (later < (tax ? (1ull << 26) : (1ull << 27))) return UKM_OK;
     }
     std::vector<const u64 *> kp(ss.size());
     std::vector<const u32 *> tp(ss.size());
