@@ -420,6 +420,70 @@ def test_probe_union_with_taxids_matches_oracle(env, monkeypatch):
     assert np.array_equal(gk, ok) and np.array_equal(gt, ot)
 
 
+def test_common_by_counting_probes_matches_oracle(env, monkeypatch):
+    """common.go:220-344 with a threshold below the number of files through the counting tables of the probe pass (route 6):
+    the first file's codes count once (duplicates in it collapse, the last TaxId wins), every record of the other files
+    counts (duplicates inside them twice), codes the first file lacks are claimed with their count and fold; plain, random
+    taxids, one taxid per file, files without taxids; thresholds from 2 to the number of files; inputs the path declines
+    (an unsorted later file, all-ones codes, files that share little with the first) give the same result another way"""
+    O, L, ctx, tax, T = env
+    rng = np.random.default_rng(47)
+    monkeypatch.setenv("UKM_PUNION", "1")
+    monkeypatch.setenv("UKM_COMMON_PROBE", "0")
+    # (p = 0.35 / 0.3: the first file alone holds too little of the others, the base set is the union of the first four and
+    #  every file is probed)
+    for n_univ, nfiles, p in ((60_000, 40, 0.7), (3_000, 30, 0.8), (200_000, 26, 0.6), (20_000, 300, 0.75), (50_000, 40, 0.35), (8_000, 200, 0.3)):
+        U = _universe(n_univ)
+        files = [U[_member(len(U), f, p, 79)] for f in range(nfiles)]
+        files[3] = np.sort(np.concatenate([files[3], files[3][::5]]))       # duplicates inside a later file count twice
+        files[0] = np.sort(np.concatenate([files[0], files[0][::7]]))       # ... inside the first file once
+        for kind in ("plain", "random", "file", "some"):
+            if kind == "plain":
+                taxs = None
+            elif kind == "random":
+                taxs = [_taxids(f, T, i) for i, f in enumerate(files)]
+            elif kind == "file":
+                taxs = [np.full(len(f), 1 + (i * 7919) % T, np.uint32) for i, f in enumerate(files)]
+            else:
+                taxs = [_taxids(f, T, i) if i % 3 else None for i, f in enumerate(files)]
+            for thr in (2, nfiles // 2, nfiles - 1, nfiles, nfiles + 1):
+                if taxs is None:
+                    g = ctx.common(files, thr)
+                    assert ctx.last_route() == 6, (n_univ, nfiles, kind, thr)
+                    assert np.array_equal(g, O.common(files, thr)), (n_univ, nfiles, kind, thr)
+                else:
+                    gk, gt = ctx.common(files, thr, taxs)
+                    assert ctx.last_route() == 6, (n_univ, nfiles, kind, thr)
+                    ok, ot = O.common(files, thr, taxs, tax)
+                    assert np.array_equal(gk, ok) and np.array_equal(gt, ot), (n_univ, nfiles, kind, thr)
+    # more new codes than a table claims, all-ones codes, an unsorted later file, files that share nothing: declined
+    U = _universe(30_000)
+    files = [U[_member(len(U), f, 0.7, 81)] for f in range(30)]
+    taxs = [_taxids(f, T, i) for i, f in enumerate(files)]
+    want = O.common(files, 20, taxs, tax)
+    cases = {}
+    extra = np.unique(rng.integers(0, int(U[-1]), 80_000).astype(np.uint64))
+    cases["crowded"] = [f if i < 8 else np.union1d(f, extra[_member(len(extra), i, 0.8, 83)]) for i, f in enumerate(files)]
+    cases["allones"] = [np.concatenate([f, np.full(2, np.uint64(2**64 - 1))]) if i in (0, 9, 12) else f for i, f in enumerate(files)]
+    for name, fs in cases.items():
+        ts = [_taxids(f, T, i) for i, f in enumerate(fs)]
+        gk, gt = ctx.common(fs, 3, ts)
+        ok, ot = O.common(fs, 3, ts, tax)
+        assert np.array_equal(gk, ok) and np.array_equal(gt, ot), name
+    dirty, dt = list(files), list(taxs)
+    perm = rng.permutation(len(dirty[15]))
+    dirty[15], dt[15] = dirty[15][perm], dt[15][perm]
+    gk, gt = ctx.common(dirty, 20, dt)
+    assert ctx.last_route() != 6
+    assert np.array_equal(gk, want[0]) and np.array_equal(gt, want[1])
+    disjoint = [np.sort(rng.choice(1 << 40, 4000, replace=False).astype(np.uint64) + np.uint64(f << 44)) for f in range(26)]
+    assert len(ctx.common(disjoint, 2)) == 0 and ctx.last_route() != 6
+    monkeypatch.setenv("UKM_PUNION", "0")
+    gk, gt = ctx.common(files, 20, taxs)
+    assert ctx.last_route() != 6
+    assert np.array_equal(gk, want[0]) and np.array_equal(gt, want[1])
+
+
 def test_probe_union_taxid_fold_on_a_forest_with_merged_zero_and_unknown_ids(monkeypatch):
     """the fold in the probe table against the reference's record-by-record LCA on a forest of three trees, merged ids,
     taxid 0, unknown ids (among them 2^32 - 2; 2^32 - 1 is the table's own marker: the call takes the general route),

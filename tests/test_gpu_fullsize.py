@@ -432,10 +432,15 @@ def test_config4_inter_diff_common_1000_files_x_1e6_full_size(env, monkeypatch, 
         okc = torch.empty(total + 8, dtype=torch.int64, device=dev)
         otc = torch.empty(total + 8, dtype=torch.int32, device=dev)
         monkeypatch.setenv("UKM_COMMON_PROBE", "0")
-        same(ctx.common(files, nfiles, taxs, out=okc, out_taxids=otc), "common", "counting merge")
-        assert ctx.last_route() == 5   # (the single-pass merge counting inside its tiles, ukm_srmerge.hip)
+        same(ctx.common(files, nfiles, taxs, out=okc, out_taxids=otc), "common", "counting probes")
+        assert ctx.last_route() == 6   # (hash probes against the first file with a record count per entry, ukm_punion.hip)
         monkeypatch.delenv("UKM_COMMON_PROBE")
         # one below the number of files: codes that one file lacks survive too
+        same(ctx.common(files, nfiles - 1, taxs, out=okc, out_taxids=otc), "common_minus_1", "counting probes")
+        assert ctx.last_route() == 6
+        assert len(want["common_minus_1"][0]) >= len(want["common"][0])
+        # ... and through the single-pass merge counting inside its tiles (ukm_srmerge.hip)
+        monkeypatch.setenv("UKM_PUNION", "0")
         same(ctx.common(files, nfiles - 1, taxs, out=okc, out_taxids=otc), "common_minus_1", "counted single pass")
         assert ctx.last_route() == 5
-        assert len(want["common_minus_1"][0]) >= len(want["common"][0])
+        monkeypatch.delenv("UKM_PUNION")

@@ -722,6 +722,32 @@ extern "C" int ukm_common(ukm_ctx *ctx, const uint64_t *const *keys, const uint3
                 ss[0] = Stream{k2, t2, nu};
             }
         }
+        if (threshold > 1 && ukm_kway_enabled() && ss[0].n) {
+            // files that share most of their codes with the first: one hash probe per record into tables that hold the
+            // first file's codes (and claim what the later files add), a record count and the TaxId fold per entry
+            // (ukm_punion.hip, pt_probe_kernel<true>).  It declines for few / small files, later files that share too
+            // little with the first, an unsorted file.
+            std::vector<const u64 *> kp;
+            std::vector<const u32 *> tp;
+            std::vector<u64> ln;
+            for (auto &q : ss)
+                if (q.n) {
+                    kp.push_back(q.k);
+                    tp.push_back(q.t);
+                    ln.push_back(q.n);
+                }
+            WsMark pm = ws_mark(ctx);
+            bool fb = true;
+            const int prc = ukm_dev_probe_common(ctx, kp.data(), tax ? tp.data() : nullptr, ln.data(), (int)kp.size(), tax, threshold, o.k,
+                                                 o.t, out_cap, n_out, &fb);
+            ws_release(ctx, pm);
+            UKM_TRY(prc);
+            if (!fb) {
+                ctx->last_route = 6;
+                return UKM_OK;
+            }
+            *n_out = 0;
+        }
         if (threshold > 1 && ukm_kway_enabled()) {
             // many files, a threshold below their number: the single-pass merge counts the records of every code inside
             // its tiles and writes only the codes that reach the threshold (ukm_srmerge.hip) -- otherwise the whole

@@ -52,7 +52,7 @@ constexpr int PU_LMISS = 512;     // new codes a range keeps in LDS before they 
 constexpr u32 PU_CHUNK = 32;      // slots of the miss list a wave reserves at a time
 constexpr u64 PU_EMPTY = ~0ull;
 constexpr double PU_MIN_HIT = 0.90;
-enum { PU_FLAG_UNSORTED = 1, PU_FLAG_OVERFLOW = 2, PU_FLAG_TAXID = 4 };
+enum { PU_FLAG_UNSORTED = 1, PU_FLAG_OVERFLOW = 2, PU_FLAG_TAXID = 4, PU_FLAG_RAW = 8 };
 
 struct PuArgs {
     const u64 *const *files;  // [S1] later files (device table of device pointers)
@@ -70,6 +70,8 @@ struct PuArgs {
     const u32 *const *tfiles; // [S1] TaxIds of the later files (an entry may be null: all 0)
     u32 *base_tax;            // [n0] in: the fold over the base files, out: over every file
     u32 *miss_tax;            // beside `miss`
+    u32 threshold;            // COUNT (`common`): a code leaves when at least this many records carried it
+    u32 count0;               // COUNT: records a base entry starts with (1: the base set is the first file; 0: every file is probed)
     TaxDev tax;
 };
 
@@ -436,9 +438,15 @@ __device__ __forceinline__ u32 pt_hash(u64 x) {
 typedef u32 pt_u32x2 __attribute__((ext_vector_type(2)));
 typedef pt_u32x2 __attribute__((aligned(4))) pt_tpair;  // 8 bytes at 4-byte alignment
 
+// COUNT = `common` (common.go:220-344) through the same tables: BASE is the first file (every code once: common.go:232,244),
+// every slot also counts its records ([31:2] of the flag word), and when the range is done the codes that reached the
+// threshold leave — base entries and new codes alike — with their fold; nothing is listed record by record (a record that
+// cannot be counted in a table raises PU_FLAG_RAW and the caller's counting merge answers).
+template <bool COUNT>
 __global__ __launch_bounds__(PT_NT) __attribute__((amdgpu_waves_per_eu(PT_WAVES, PT_WAVES))) void pt_probe_kernel(PuArgs a) {
     __shared__ __attribute__((aligned(32))) u64 s_tab[PT_SLOTS];
-    __shared__ __attribute__((aligned(16))) uint4 s_st[PT_SLOTS];  // x = t0, y = smallest number, z = ~largest, w = flag (2: settled)
+    // x = t0, y = smallest number, z = ~largest, w = [0] another TaxId with the same number was seen, [1] settled, [31:2] records (COUNT)
+    __shared__ __attribute__((aligned(16))) uint4 s_st[PT_SLOTS];
     __shared__ u32 s_next, s_nins;
     __shared__ u32 s_scan[PT_NT / 64 + 1];
     __shared__ u64 s_flush_at;
@@ -466,29 +474,29 @@ __global__ __launch_bounds__(PT_NT) __attribute__((amdgpu_waves_per_eu(PT_WAVES,
             }
         }
     };
-    const u64 b0 = (u64)r * PT_RANGE;
-    const u32 nb = (u32)((a.n0 - b0 < (u64)PT_RANGE) ? (a.n0 - b0) : (u64)PT_RANGE);
+    const u64 b0 = (u64)r * a.range;  // (a.range <= PT_RANGE: pt_range_for)
+    const u32 nb = (u32)((a.n0 - b0 < (u64)a.range) ? (a.n0 - b0) : (u64)a.range);
     constexpr int PER = (PT_RANGE + PT_NT - 1) / PT_NT;
     u64 ent[PER];
     u32 et[PER];
-    bool bad = false, bad_t = false;  // an unsorted file; a TaxId of 2^32 - 1 (the table's own "not set")
+    bool bad = false, bad_t = false, bad_raw = false;  // an unsorted file; a TaxId of 2^32 - 1 (the table's own "not set"); COUNT: a record no table could count
 #pragma unroll
     for (int i = 0; i < PER; i++) {
         const u32 idx = (u32)tid + (u32)i * PT_NT;
         ent[i] = a.base[b0 + (idx < nb ? idx : 0)];
-        et[i] = a.base_tax[b0 + (idx < nb ? idx : 0)];
+        et[i] = a.base_tax ? a.base_tax[b0 + (idx < nb ? idx : 0)] : 0u;  // (plain codes: COUNT only)
         if (idx >= nb) ent[i] = PU_EMPTY;
         else bad_t |= et[i] == PT_UNSET;
     }
     u32 ee[PER];
 #pragma unroll
-    for (int i = 0; i < PER; i++) ee[i] = T.euler[et[i] < T.size ? et[i] : 0u];
+    for (int i = 0; i < PER; i++) ee[i] = T.euler ? T.euler[et[i] < T.size ? et[i] : 0u] : 0u;
 #pragma unroll
     for (int i = 0; i < PER; i++) {
         if (ent[i] == PU_EMPTY) continue;  // (an all-ones code: its records are listed, the final union folds them)
         bool fresh;
         const int slot = insert(ent[i], fresh);
-        s_st[slot] = make_uint4(et[i], ee[i], ~ee[i], 0u);
+        s_st[slot] = make_uint4(et[i], ee[i], ~ee[i], COUNT ? 4u * a.count0 : 0u);
     }
     __syncthreads();
     auto find_from = [&](u64 x, u32 h) -> int {
@@ -515,6 +523,7 @@ __global__ __launch_bounds__(PT_NT) __attribute__((amdgpu_waves_per_eu(PT_WAVES,
     };
     // one record's TaxId into its entry; e = its pre-order number (0: taxid 0 / unknown)
     auto fold = [&](int slot, u32 t, u32 e) {
+        if (COUNT) atomicAdd(&s_st[slot].w, 4u);
         uint4 st = s_st[slot];
         if (st.x == PT_UNSET) {  // a new code: whoever comes first gives it its TaxId (any order gives the same fold)
             const u32 old = atomicCAS(&s_st[slot].x, PT_UNSET, t);
@@ -530,8 +539,8 @@ __global__ __launch_bounds__(PT_NT) __attribute__((amdgpu_waves_per_eu(PT_WAVES,
         if (lo | hi) {
             atomicMin(lo ? &s_st[slot].y : &s_st[slot].z, lo ? e : ~e);
             if (lo & hi) atomicMin(&s_st[slot].z, ~e);  // (an interval that is still empty: a new code a moment after its claim)
-        } else if (st.y == e && st.z == ~e && st.w == 0u) {
-            s_st[slot].w = 1u;
+        } else if (st.y == e && st.z == ~e && (st.w & 1u) == 0u) {
+            atomicOr(&s_st[slot].w, 1u);
         }
     };
     const u64 lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
@@ -586,7 +595,8 @@ __global__ __launch_bounds__(PT_NT) __attribute__((amdgpu_waves_per_eu(PT_WAVES,
             }
             if (!raw) fold(slot, t, e);
         }
-        append_global(raw, x, t);
+        if (COUNT) bad_raw |= raw;
+        else append_global(raw, x, t);
     };
     // The lanes stream a slice 256 records per step.  A step is three things that each wait for the one before: the loads
     // of codes and TaxIds (A), the pre-order numbers of those TaxIds (B: a second round trip), the probes (C).  Slices are
@@ -619,8 +629,11 @@ __global__ __launch_bounds__(PT_NT) __attribute__((amdgpu_waves_per_eu(PT_WAVES,
         for (int u = 0; u < U; u++) {
             const u32 ta = ra.tp[u].x, tb = ra.tp[u].y;
             bad_t |= ta == PT_UNSET || tb == PT_UNSET;
-            rb.eu[u][0] = T.euler[ta < T.size ? ta : 0u];
-            rb.eu[u][1] = T.euler[tb < T.size ? tb : 0u];
+            rb.eu[u][0] = rb.eu[u][1] = 0u;
+            if (d.tf != 0) {  // (wave-uniform; a file without TaxIds: all 0, and there may be no taxonomy at all)
+                rb.eu[u][0] = T.euler[ta < T.size ? ta : 0u];
+                rb.eu[u][1] = T.euler[tb < T.size ? tb : 0u];
+            }
         }
     };
     auto process = [&](const Desc &d, const RegA &ra, const RegB &rb) {
@@ -696,7 +709,7 @@ __global__ __launch_bounds__(PT_NT) __attribute__((amdgpu_waves_per_eu(PT_WAVES,
                 const u64 x = f[0];
                 const u32 t = cur.tf ? as_global((const u32 *)(uintptr_t)cur.tf)[0] : 0u;
                 bad_t |= t == PT_UNSET;
-                const u32 e = T.euler[t < T.size ? t : 0u];
+                const u32 e = cur.tf ? T.euler[t < T.size ? t : 0u] : 0u;
                 record(lane == 0, lane == 0 ? find_from(x, pt_hash(x)) : -1, x, t, e);
             }
             j = jn;
@@ -725,31 +738,39 @@ __global__ __launch_bounds__(PT_NT) __attribute__((amdgpu_waves_per_eu(PT_WAVES,
     close_chunk();
     if (bad) atomicOr((unsigned long long *)&a.ctl[1], (unsigned long long)PU_FLAG_UNSORTED);
     if (bad_t) atomicOr((unsigned long long *)&a.ctl[1], (unsigned long long)PU_FLAG_TAXID);
+    if (bad_raw) atomicOr((unsigned long long *)&a.ctl[1], (unsigned long long)PU_FLAG_RAW);
     __syncthreads();
     // ---- the folds: one table LCA per entry that met a different TaxId -------------------------------------------------
     auto settle = [&](int slot) -> u32 {
         const uint4 st = s_st[slot];
         const u32 mn = st.y, mx = ~st.z;
-        if (mn == mx && st.w == 0u) return st.x;  // every record carried t0
+        if (mn == mx && (st.w & 1u) == 0u) return st.x;  // every record carried t0
         if (mn == 0u) return 0u;                  // TaxId 0 / an unknown id among records that differ
         return lca_dev(T, T.node_at[mn], T.node_at[mx]);
     };
+    if (!COUNT) {
 #pragma unroll
-    for (int i = 0; i < PER; i++) {
-        if (ent[i] == PU_EMPTY) continue;
-        const int slot = find_from(ent[i], pt_hash(ent[i]));
-        const u32 res = settle(slot);
-        if (res != et[i]) a.base_tax[b0 + (u32)tid + (u32)i * PT_NT] = res;
-        s_st[slot].w = 2u;  // (this entry is done)
+        for (int i = 0; i < PER; i++) {
+            if (ent[i] == PU_EMPTY) continue;
+            const int slot = find_from(ent[i], pt_hash(ent[i]));
+            const u32 res = settle(slot);
+            if (res != et[i]) a.base_tax[b0 + (u32)tid + (u32)i * PT_NT] = res;
+            s_st[slot].w = 2u;  // (this entry is done)
+        }
+        __syncthreads();
     }
-    __syncthreads();
-    // what is left in the table are the new codes of this range
+    // what is left in the table are the new codes of this range (COUNT: every code that reached the threshold)
+    auto leaves = [&](int sl) -> bool {
+        if (sl >= PT_SLOTS || s_tab[sl] == PU_EMPTY) return false;
+        const u32 w = s_st[sl].w;
+        return COUNT ? (w >> 2) >= a.threshold : w != 2u;
+    };
     constexpr int SPT = (PT_SLOTS + PT_NT - 1) / PT_NT;
     u32 mine = 0;
 #pragma unroll
     for (int i = 0; i < SPT; i++) {
         const int sl = tid * SPT + i;
-        if (sl < PT_SLOTS && s_tab[sl] != PU_EMPTY && s_st[sl].w != 2u) mine++;
+        if (leaves(sl)) mine++;
     }
     u32 tot;
     u32 at_l = block_excl_scan_u32<PT_NT>(mine, s_scan, &tot);
@@ -765,12 +786,24 @@ __global__ __launch_bounds__(PT_NT) __attribute__((amdgpu_waves_per_eu(PT_WAVES,
 #pragma unroll
     for (int i = 0; i < SPT; i++) {
         const int sl = tid * SPT + i;
-        if (sl < PT_SLOTS && s_tab[sl] != PU_EMPTY && s_st[sl].w != 2u) {
+        if (leaves(sl)) {
             a.miss[at + at_l] = s_tab[sl];
-            a.miss_tax[at + at_l] = settle(sl);
+            if (a.miss_tax) a.miss_tax[at + at_l] = settle(sl);
             at_l++;
         }
     }
+}
+
+// Base entries per range of the TaxId / counting pass: PT_RANGE, or less when that leaves only a few rounds of workgroups
+// (one per CU) with the last one partly empty -- 1e6 base entries: 651 ranges are 2.54 rounds of 256, 768 ranges of 1302
+// entries are three full ones.
+u32 pt_range_for(const ukm_ctx *c, u64 n0) {
+    const u64 cus = (u64)std::max(1, c->num_cu);
+    const u64 r_full = (n0 + PT_RANGE - 1) / PT_RANGE;
+    if (r_full >= 16 * cus) return (u32)PT_RANGE;
+    const u64 rounds = (r_full + cus - 1) / cus;
+    const u64 range = (n0 + rounds * cus - 1) / (rounds * cus);
+    return (u32)std::min<u64>(PT_RANGE, std::max<u64>(range, 64));
 }
 
 double ms_since(std::chrono::steady_clock::time_point t0) {
@@ -805,7 +838,7 @@ int ukm_dev_probe_union(ukm_ctx *c, const u64 *const *keys, const u32 *const *ta
         if (c->tax_parent == nullptr) UKM_FAIL(UKM_ERR_NO_TAXONOMY, "union: records carry taxids but no taxonomy is loaded");
         if (c->tax_euler == nullptr || c->tax_node_at == nullptr) return UKM_OK;
     }
-    const u32 range = tax ? (u32)PT_RANGE : (u32)PU_RANGE;
+    u32 range = (u32)PU_RANGE;  // (with TaxIds: chosen below, when the base set's size is known)
     const int mode = ukm_punion_mode();
     const bool dbg = getenv("UKM_PUNION_DEBUG") != nullptr;
     auto t0 = std::chrono::steady_clock::now();
@@ -827,6 +860,7 @@ int ukm_dev_probe_union(ukm_ctx *c, const u64 *const *keys, const u32 *const *ta
     bool fb = false;
     UKM_TRY(ukm_dev_kway(c, UKM_KWAY_UNION, keys, tax ? taxids : nullptr, lens, k0, tax, base, base_tax, cap0, &n0, &fb));
     if (fb || n0 == 0) return UKM_OK;
+    if (tax) range = pt_range_for(c, n0);
     const u64 R64 = (n0 + range - 1) / range;
     if (R64 > 0x7FFFFFFEull) return UKM_OK;
     lap("base");
@@ -913,7 +947,7 @@ int ukm_dev_probe_union(ukm_ctx *c, const u64 *const *keys, const u32 *const *ta
             UKM_HIP(hipMemsetAsync(ctl + 4, 0, sizeof(u64), c->stream));
         }
         (void)hipEventRecord(c->ev_k0, c->stream);
-        if (tax) hipLaunchKernelGGL(pt_probe_kernel, dim3(a.R), dim3(PT_NT), 0, c->stream, a);
+        if (tax) hipLaunchKernelGGL(pt_probe_kernel<false>, dim3(a.R), dim3(PT_NT), 0, c->stream, a);
         else hipLaunchKernelGGL(pu_probe_kernel, dim3(a.R), dim3(PU_NT), 0, c->stream, a);
         (void)hipEventRecord(c->ev_k1, c->stream);
         c->evk_valid = true;
@@ -952,5 +986,143 @@ int ukm_dev_probe_union(ukm_ctx *c, const u64 *const *keys, const u32 *const *ta
     UKM_TRY(ukm_dev_setop2(c, UKM_OP_UNION, base, base_tax, n0, mu, mut, nmu, 0, out, tout, out_cap, n_out));
     lap("final");
     *fallback = false;
+    return UKM_OK;
+}
+
+// `common` with a threshold below the number of files by the counting tables of pt_probe_kernel<true>.  keys[0] must be
+// the first file as a sorted, duplicate-free set (ukm_common makes it one: every code of the first file counts once,
+// common.go:232,244); every record of every other file counts (common.go:262-266).  *fallback = true: not this path (few
+// or small files, more than PU_MAXS of them, later files that share too little with the first, an unsorted file, a record
+// no table could count): nothing that matters was written and the caller's counting merge answers.
+int ukm_dev_probe_common(ukm_ctx *c, const u64 *const *keys, const u32 *const *taxids, const u64 *lens, int S, bool tax,
+                         u32 threshold, u64 *out, u32 *tout, u64 out_cap, u64 *n_out, bool *fallback) {
+    *fallback = true;
+    *n_out = 0;
+    const int mode = ukm_punion_mode();
+    if (mode == 0 || S < 3 || S > PU_MAXS || lens[0] == 0) return UKM_OK;
+    u64 later = 0;
+    for (int j = 1; j < S; j++) later += lens[j];
+    if (mode < 1 && (S < 24 || later < (1ull << 26))) return UKM_OK;
+    if (tax) {
+        if (!tout) UKM_FAIL(UKM_ERR_INVALID, "common: taxids given but out_taxids is NULL");
+        if (c->tax_parent == nullptr) UKM_FAIL(UKM_ERR_NO_TAXONOMY, "common: records carry taxids but no taxonomy is loaded");
+        if (c->tax_euler == nullptr || c->tax_node_at == nullptr) return UKM_OK;
+    }
+    const bool dbg = getenv("UKM_PUNION_DEBUG") != nullptr;
+    // device tables of ALL files: [pointers S][lens S][TaxId pointers S]
+    std::vector<u64> tab((size_t)3 * S);
+    for (int j = 0; j < S; j++) {
+        tab[(size_t)j] = (u64)(uintptr_t)keys[j];
+        tab[(size_t)S + j] = lens[j];
+        tab[(size_t)2 * S + j] = (u64)(uintptr_t)((tax && taxids) ? taxids[j] : nullptr);
+    }
+    u64 *d_tab = nullptr, *ctl = nullptr;
+    UKM_TRY(ws_alloc_t(c, tab.size(), &d_tab));
+    UKM_TRY(ws_alloc_t(c, 8, &ctl));
+    UKM_HIP(hipMemcpyAsync(d_tab, tab.data(), tab.size() * sizeof(u64), hipMemcpyHostToDevice, c->stream));
+    UKM_HIP(hipMemsetAsync(ctl, 0, 8 * sizeof(u64), c->stream));
+    UKM_HIP(hipStreamSynchronize(c->stream));  // `tab` is a pageable host buffer of this frame
+    PuArgs a;
+    memset(&a, 0, sizeof(a));
+    a.ctl = ctl;
+    a.threshold = threshold;
+    if (tax) a.tax = ukm_taxdev(c);
+    // BASE = the first file, its codes counted once, the other files probed -- when they share enough with it.  Else
+    // BASE = the union of the first four files (the TaxIds folded; folding them once more is harmless: LCA(x, x) = x)
+    // with no record counted yet, and EVERY file is probed.
+    u64 n0 = 0;
+    int first = 1;
+    auto hit_rate = [&](double *rate) -> int {
+        const u32 nsamp = 1u << 16, nf = (u32)std::min((int)a.S1, 16);
+        UKM_HIP(hipMemsetAsync(ctl, 0, 8 * sizeof(u64), c->stream));
+        hipLaunchKernelGGL(pu_sample_kernel, dim3(nsamp / 256), dim3(256), 0, c->stream, a, nsamp, nf);
+        UKM_HIP(hipGetLastError());
+        u64 h[4] = {0, 0, 0, 0};
+        UKM_TRY(ukm_read_u64(c, ctl, h, 4));
+        *rate = h[3] ? (double)h[2] / (double)h[3] : 0.0;
+        if (dbg) fprintf(stderr, "[pcommon] sample: %llu of %llu records of the probed files in the base set (n0 = %llu)\n", (unsigned long long)h[2],
+                         (unsigned long long)h[3], (unsigned long long)a.n0);
+        UKM_HIP(hipMemsetAsync(ctl, 0, 8 * sizeof(u64), c->stream));
+        return UKM_OK;
+    };
+    {
+        a.base = keys[0];
+        a.base_tax = (tax && taxids) ? const_cast<u32 *>(taxids[0]) : nullptr;  // (read only in this mode)
+        a.n0 = n0 = lens[0];
+        a.count0 = 1;
+        a.files = (const u64 *const *)(d_tab + 1);
+        a.lens = d_tab + S + 1;
+        a.tfiles = (const u32 *const *)(d_tab + 2 * (size_t)S + 1);
+        a.S1 = (u32)(S - 1);
+        double rate = 0.0;
+        UKM_TRY(hit_rate(&rate));
+        if (mode != 2 && rate < PT_MIN_HIT) {
+            const int k0 = std::min(S, PT_K0);
+            u64 cap0 = 0;
+            for (int j = 0; j < k0; j++) cap0 += lens[j];
+            u64 *base = nullptr;
+            u32 *base_tax = nullptr;
+            UKM_TRY(ws_alloc_t(c, cap0 + 1, &base));
+            if (tax) UKM_TRY(ws_alloc_t(c, cap0 + 1, &base_tax));
+            bool fb = false;
+            UKM_TRY(ukm_dev_kway(c, UKM_KWAY_UNION, keys, tax ? taxids : nullptr, lens, k0, tax, base, base_tax, cap0, &n0, &fb));
+            if (fb || n0 == 0) return UKM_OK;
+            first = 0;
+            a.base = base;
+            a.base_tax = base_tax;
+            a.n0 = n0;
+            a.count0 = 0;
+            a.files = (const u64 *const *)d_tab;
+            a.lens = d_tab + S;
+            a.tfiles = (const u32 *const *)(d_tab + 2 * (size_t)S);
+            a.S1 = (u32)S;
+            UKM_TRY(hit_rate(&rate));
+            if (rate < PT_MIN_HIT) return UKM_OK;
+        }
+    }
+    const int S1 = (int)a.S1;
+    if (first == 0) later += lens[0];
+    const u32 range = pt_range_for(c, n0);
+    const u64 R64 = (n0 + range - 1) / range;
+    if (R64 > 0x7FFFFFFEull) return UKM_OK;
+    a.R = (u32)R64;
+    a.range = range;
+    // every code leaves at most once: the first file's codes and what the tables claim (as many again at most)
+    const u64 list_cap = 2 * n0 + 64 * R64 + 64;
+    UKM_TRY(ws_alloc_t(c, list_cap + 1, &a.miss));
+    if (tax) UKM_TRY(ws_alloc_t(c, list_cap + 1, &a.miss_tax));
+    a.miss_cap = list_cap;
+    UKM_TRY(ws_alloc_t(c, ((size_t)a.R + 1) * S1, &a.cuts));
+    const u64 ncuts = ((u64)a.R + 1) * (u64)S1;
+    hipLaunchKernelGGL(pu_cuts_kernel, dim3((unsigned)((ncuts + 255) / 256)), dim3(256), 0, c->stream, a);
+    {
+        hipLaunchKernelGGL(pu_load_kernel, dim3((a.R + 255) / 256), dim3(256), 0, c->stream, a);
+        UKM_HIP(hipGetLastError());
+        u64 heaviest = 0;
+        UKM_TRY(ukm_read_u64(c, ctl + 4, &heaviest));
+        const u64 avg = later / a.R + 1;
+        if (mode != 2 && heaviest > 64 * avg + 65536) return UKM_OK;  // (one workgroup would stream most of the input)
+    }
+    (void)hipEventRecord(c->ev_k0, c->stream);
+    hipLaunchKernelGGL(pt_probe_kernel<true>, dim3(a.R), dim3(PT_NT), 0, c->stream, a);
+    (void)hipEventRecord(c->ev_k1, c->stream);
+    c->evk_valid = true;
+    UKM_HIP(hipGetLastError());
+    u64 h[2] = {0, 0};
+    UKM_TRY(ukm_read_u64(c, ctl, h, 2));
+    if (dbg) fprintf(stderr, "[pcommon] S=%d n0=%llu R=%u later=%llu threshold=%u out=%llu flags=%llu\n", S, (unsigned long long)n0, a.R,
+                     (unsigned long long)later, threshold, (unsigned long long)h[0], (unsigned long long)h[1]);
+    if (h[1] != 0) return UKM_OK;
+    const u64 nm = h[0];
+    *fallback = false;
+    *n_out = nm;
+    if (nm > out_cap)
+        UKM_FAIL(UKM_ERR_CAPACITY, "common: output needs %llu records, capacity is %llu", (unsigned long long)nm, (unsigned long long)out_cap);
+    if (nm == 0) return UKM_OK;
+    // the ranges wrote their codes in the order they finished: one sort puts them in code order (every code is in the
+    // list once)
+    UKM_TRY(ukm_dev_sort(c, a.miss, tax ? a.miss_tax : nullptr, nm, 64));
+    UKM_HIP(hipMemcpyAsync(out, a.miss, nm * sizeof(u64), hipMemcpyDeviceToDevice, c->stream));
+    if (tax) UKM_HIP(hipMemcpyAsync(tout, a.miss_tax, nm * sizeof(u32), hipMemcpyDeviceToDevice, c->stream));
     return UKM_OK;
 }
