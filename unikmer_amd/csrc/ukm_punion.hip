@@ -550,7 +550,7 @@ __global__ __launch_bounds__(PT_NT) __attribute__((amdgpu_waves_per_eu(PT_WAVES,
     auto close_chunk = [&]() {
         if ((u32)lane < chunk_cap - chunk_used) {
             a.miss[chunk_at + chunk_used + (u32)lane] = fill;
-            a.miss_tax[chunk_at + chunk_used + (u32)lane] = fill_t;
+            if (a.miss_tax) a.miss_tax[chunk_at + chunk_used + (u32)lane] = fill_t;
         }
         chunk_cap = chunk_used = 0;
     };
@@ -577,7 +577,7 @@ __global__ __launch_bounds__(PT_NT) __attribute__((amdgpu_waves_per_eu(PT_WAVES,
         if (m) {
             const u64 at = chunk_at + chunk_used + (u32)__popcll(mask & lt);
             a.miss[at] = x;
-            a.miss_tax[at] = t;
+            if (a.miss_tax) a.miss_tax[at] = t;
         }
         chunk_used += n;
     };
@@ -754,7 +754,7 @@ __global__ __launch_bounds__(PT_NT) __attribute__((amdgpu_waves_per_eu(PT_WAVES,
             if (ent[i] == PU_EMPTY) continue;
             const int slot = find_from(ent[i], pt_hash(ent[i]));
             const u32 res = settle(slot);
-            if (res != et[i]) a.base_tax[b0 + (u32)tid + (u32)i * PT_NT] = res;
+            if (a.base_tax && res != et[i]) a.base_tax[b0 + (u32)tid + (u32)i * PT_NT] = res;
             s_st[slot].w = 2u;  // (this entry is done)
         }
         __syncthreads();
@@ -860,9 +860,6 @@ int ukm_dev_probe_union(ukm_ctx *c, const u64 *const *keys, const u32 *const *ta
     bool fb = false;
     UKM_TRY(ukm_dev_kway(c, UKM_KWAY_UNION, keys, tax ? taxids : nullptr, lens, k0, tax, base, base_tax, cap0, &n0, &fb));
     if (fb || n0 == 0) return UKM_OK;
-    if (tax) range = pt_range_for(c, n0);
-    const u64 R64 = (n0 + range - 1) / range;
-    if (R64 > 0x7FFFFFFEull) return UKM_OK;
     lap("base");
 
     // device tables of the later files: [pointers S1][lens S1][TaxId pointers S1]
@@ -884,9 +881,7 @@ int ukm_dev_probe_union(ukm_ctx *c, const u64 *const *keys, const u32 *const *ta
     memset(&a, 0, sizeof(a));
     a.base = base;
     a.n0 = n0;
-    a.R = (u32)R64;
     a.ctl = ctl;
-    a.range = range;
     a.base_tax = base_tax;
     if (tax) a.tax = ukm_taxdev(c);
 
@@ -905,9 +900,18 @@ int ukm_dev_probe_union(ukm_ctx *c, const u64 *const *keys, const u32 *const *ta
         miss_rate = 1.0 - (double)h[2] / (double)h[3];
         if (dbg) fprintf(stderr, "[punion] sample: %llu of %llu later records in the base set (n0 = %llu)\n",
                          (unsigned long long)h[2], (unsigned long long)h[3], (unsigned long long)n0);
-        if (mode != 2 && 1.0 - miss_rate < (tax ? PT_MIN_HIT : PU_MIN_HIT)) return UKM_OK;
+        if (mode != 2 && 1.0 - miss_rate < PT_MIN_HIT) return UKM_OK;
     }
     lap("sample");
+    // The plain pass keeps at most 512 new codes per range of 2048 in LDS and lists the rest record by record: it wants
+    // later files that add little (>= 90 % hits).  Between 55 % and 90 % plain files take the tables of the TaxId pass
+    // (they claim as many new codes as they have base entries; without TaxId pointers the fold is skipped wave by wave).
+    const bool claiming = tax || (mode != 2 && 1.0 - miss_rate < PU_MIN_HIT);
+    if (claiming) range = pt_range_for(c, n0);
+    const u64 R64 = (n0 + range - 1) / range;
+    if (R64 > 0x7FFFFFFEull) return UKM_OK;
+    a.R = (u32)R64;
+    a.range = range;
 
     // 3. probe pass
     // (+ one partly used chunk of 64 per wave of the grid)
@@ -947,7 +951,7 @@ int ukm_dev_probe_union(ukm_ctx *c, const u64 *const *keys, const u32 *const *ta
             UKM_HIP(hipMemsetAsync(ctl + 4, 0, sizeof(u64), c->stream));
         }
         (void)hipEventRecord(c->ev_k0, c->stream);
-        if (tax) hipLaunchKernelGGL(pt_probe_kernel<false>, dim3(a.R), dim3(PT_NT), 0, c->stream, a);
+        if (claiming) hipLaunchKernelGGL(pt_probe_kernel<false>, dim3(a.R), dim3(PT_NT), 0, c->stream, a);
         else hipLaunchKernelGGL(pu_probe_kernel, dim3(a.R), dim3(PU_NT), 0, c->stream, a);
         (void)hipEventRecord(c->ev_k1, c->stream);
         c->evk_valid = true;
