@@ -523,7 +523,6 @@ __global__ __launch_bounds__(PT_NT) __attribute__((amdgpu_waves_per_eu(PT_WAVES,
     };
     // one record's TaxId into its entry; e = its pre-order number (0: taxid 0 / unknown)
     auto fold = [&](int slot, u32 t, u32 e) {
-        if (COUNT) atomicAdd(&s_st[slot].w, 4u);
         uint4 st = s_st[slot];
         if (st.x == PT_UNSET) {  // a new code: whoever comes first gives it its TaxId (any order gives the same fold)
             const u32 old = atomicCAS(&s_st[slot].x, PT_UNSET, t);
@@ -582,6 +581,8 @@ __global__ __launch_bounds__(PT_NT) __attribute__((amdgpu_waves_per_eu(PT_WAVES,
         chunk_used += n;
     };
     // a record: found -> fold; not found -> claim a slot for its code (then it is a hit like any other), or list it
+    // (plain codes -- no file has TaxIds -- through these tables: a hit has nothing to do beyond the count)
+    const bool folds = a.base_tax != nullptr || a.miss_tax != nullptr;
     auto record = [&](bool valid, int slot, u64 x, u32 t, u32 e) {
         bool raw = false;
         if (valid) {
@@ -593,7 +594,10 @@ __global__ __launch_bounds__(PT_NT) __attribute__((amdgpu_waves_per_eu(PT_WAVES,
                     if (fresh) atomicAdd(&s_nins, 1u);
                 }
             }
-            if (!raw) fold(slot, t, e);
+            if (!raw) {
+                if (COUNT) atomicAdd(&s_st[slot].w, 4u);
+                if (folds) fold(slot, t, e);
+            }
         }
         if (COUNT) bad_raw |= raw;
         else append_global(raw, x, t);
@@ -831,7 +835,7 @@ int ukm_dev_probe_union(ukm_ctx *c, const u64 *const *keys, const u32 *const *ta
     // files of the base set: with TaxIds four (the base union pays an LCA per shared code: 8 files of config 3's shape
     // took as long as a third of the probe pass; the codes the later files add are claimed in the tables anyway)
     int k0 = tax ? PT_K0 : PU_K0;
-    if (tax && getenv("UKM_PUNION_K0")) k0 = std::max(3, std::min(64, atoi(getenv("UKM_PUNION_K0"))));  // developer knob
+    if (getenv("UKM_PUNION_K0")) k0 = std::max(3, std::min(64, atoi(getenv("UKM_PUNION_K0"))));  // developer knob
     if (S < k0 + 1) return UKM_OK;
     if (tax) {
         if (!tout) UKM_FAIL(UKM_ERR_INVALID, "union: taxids given but out_taxids is NULL");
@@ -906,7 +910,7 @@ int ukm_dev_probe_union(ukm_ctx *c, const u64 *const *keys, const u32 *const *ta
     // The plain pass keeps at most 512 new codes per range of 2048 in LDS and lists the rest record by record: it wants
     // later files that add little (>= 90 % hits).  Between 55 % and 90 % plain files take the tables of the TaxId pass
     // (they claim as many new codes as they have base entries; without TaxId pointers the fold is skipped wave by wave).
-    const bool claiming = tax || (mode != 2 && 1.0 - miss_rate < PU_MIN_HIT);
+    const bool claiming = tax || (mode != 2 && 1.0 - miss_rate < PU_MIN_HIT) || getenv("UKM_PUNION_CLAIM") != nullptr;  // (developer knob)
     if (claiming) range = pt_range_for(c, n0);
     const u64 R64 = (n0 + range - 1) / range;
     if (R64 > 0x7FFFFFFEull) return UKM_OK;
