@@ -298,8 +298,7 @@ def test_probe_union_matches_oracle(env, monkeypatch):
     O, L, ctx, tax, T = env
     rng = np.random.default_rng(41)
     monkeypatch.setenv("UKM_PUNION", "1")
-    # (p = 0.15 / 0.1: 73 % / 57 % of the later records are in the base set -- below the plain pass's 90 %: the tables of the
-    #  TaxId pass, which claim as many new codes as they have base entries, take the plain files)
+    # (p = 0.15 / 0.1: 73 % / 57 % of the later records are in the base set: hundreds of new codes per range are claimed)
     for n_univ, nfiles, p in ((60_000, 40, 0.5), (3_000, 30, 0.5), (200_000, 26, 0.35), (20_000, 600, 0.3), (100_000, 40, 0.15),
                               (30_000, 300, 0.1)):
         U = _universe(n_univ)

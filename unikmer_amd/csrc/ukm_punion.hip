@@ -51,7 +51,7 @@ constexpr int PU_MAXS = 4096;     // later files per launch
 constexpr int PU_LMISS = 512;     // new codes a range keeps in LDS before they go out in one piece
 constexpr u32 PU_CHUNK = 32;      // slots of the miss list a wave reserves at a time
 constexpr u64 PU_EMPTY = ~0ull;
-constexpr double PU_MIN_HIT = 0.90;
+constexpr double PU_MIN_HIT = 0.55;  // (a table takes as many new codes as it has base entries: see PT_MIN_HIT)
 enum { PU_FLAG_UNSORTED = 1, PU_FLAG_OVERFLOW = 2, PU_FLAG_TAXID = 4, PU_FLAG_RAW = 8 };
 
 struct PuArgs {
@@ -904,13 +904,14 @@ int ukm_dev_probe_union(ukm_ctx *c, const u64 *const *keys, const u32 *const *ta
         miss_rate = 1.0 - (double)h[2] / (double)h[3];
         if (dbg) fprintf(stderr, "[punion] sample: %llu of %llu later records in the base set (n0 = %llu)\n",
                          (unsigned long long)h[2], (unsigned long long)h[3], (unsigned long long)n0);
-        if (mode != 2 && 1.0 - miss_rate < PT_MIN_HIT) return UKM_OK;
+        if (mode != 2 && 1.0 - miss_rate < (tax ? PT_MIN_HIT : PU_MIN_HIT)) return UKM_OK;
     }
     lap("sample");
-    // The plain pass keeps at most 512 new codes per range of 2048 in LDS and lists the rest record by record: it wants
-    // later files that add little (>= 90 % hits).  Between 55 % and 90 % plain files take the tables of the TaxId pass
-    // (they claim as many new codes as they have base entries; without TaxId pointers the fold is skipped wave by wave).
-    const bool claiming = tax || (mode != 2 && 1.0 - miss_rate < PU_MIN_HIT) || getenv("UKM_PUNION_CLAIM") != nullptr;  // (developer knob)
+    // (Plain files stay with the plain kernel down to the same hit rate: its tables claim new codes too -- 2048 per range,
+    //  512 of them listed from LDS, the rest in chunks -- and a record costs half of what it costs in the tables of the
+    //  TaxId pass even without TaxIds: 1000 files x 1e6, a fifth / an eighth of a universe each: 4.1 / 5.9 ms against
+    //  5.9 / 7.7.  UKM_PUNION_CLAIM=1: plain files through the TaxId pass's tables all the same, an experiment.)
+    const bool claiming = tax || getenv("UKM_PUNION_CLAIM") != nullptr;
     if (claiming) range = pt_range_for(c, n0);
     const u64 R64 = (n0 + range - 1) / range;
     if (R64 > 0x7FFFFFFEull) return UKM_OK;
