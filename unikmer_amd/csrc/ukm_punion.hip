@@ -602,12 +602,18 @@ __global__ __launch_bounds__(PT_NT) __attribute__((amdgpu_waves_per_eu(PT_WAVES,
         if (COUNT) bad_raw |= raw;
         else append_global(raw, x, t);
     };
-    // The lanes stream a slice 256 records per step.  A step is three things that each wait for the one before: the loads
+    // The lanes stream a slice 128 records per step.  A step is three things that each wait for the one before: the loads
     // of codes and TaxIds (A), the pre-order numbers of those TaxIds (B: a second round trip), the probes (C).  Slices are
     // short here (a range of 1536 entries: several hundred records per file), so a wave that did A, B, C one after the other
     // spent its time waiting twice per step (24 ms on config 3's shape at half size).  The steps of ALL slices of the wave
     // form one sequence instead and run as a pipeline: A of step i + 2 and B of step i + 1 are issued before C of step i.
-    constexpr int U = 2;
+#ifndef PT_U
+#define PT_U 1     /* 16-byte loads per lane and step (2: 31.0 ms on config 3's shape at half size with one taxid per file, 1: 29.5; without the pipeline 2: 33.6, 4: 31.9; one stage deeper 1: 29.9, 2: 34.2) */
+#endif
+#ifndef PT_PIPE
+#define PT_PIPE 1  /* experiments: 0 = loads, look-ups and probes of a step one after the other */
+#endif
+    constexpr int U = PT_U;
     struct Desc { u64 f, tf, p0, end, len; bool valid; };  // wave-uniform
     struct RegA { pu_pair pr[U]; pt_tpair tp[U]; u64 nx[U]; };
     struct RegB { u32 eu[U][2]; };
@@ -723,6 +729,35 @@ __global__ __launch_bounds__(PT_NT) __attribute__((amdgpu_waves_per_eu(PT_WAVES,
             pos = cur.beg;
         }
     };
+#if !PT_PIPE
+    for (Desc d = next_desc(); d.valid; d = next_desc()) {
+        RegA ra;
+        RegB rb;
+        issue_a(d, ra);
+        issue_b(d, ra, rb);
+        process(d, ra, rb);
+    }
+#elif PT_PIPE == 2
+    {   // one stage deeper: loads three steps ahead, look-ups two
+        Desc d0 = next_desc(), d1 = next_desc(), d2 = next_desc();
+        RegA a0, a1, a2, a3;
+        RegB b0, b1, b2;
+        issue_a(d0, a0);
+        issue_a(d1, a1);
+        issue_a(d2, a2);
+        issue_b(d0, a0, b0);
+        issue_b(d1, a1, b1);
+        while (d0.valid) {
+            const Desc d3 = next_desc();
+            issue_a(d3, a3);
+            issue_b(d2, a2, b2);
+            process(d0, a0, b0);
+            d0 = d1; a0 = a1; b0 = b1;
+            d1 = d2; a1 = a2; b1 = b2;
+            d2 = d3; a2 = a3;
+        }
+    }
+#else
     {
         Desc d0 = next_desc(), d1 = next_desc();
         RegA a0, a1, a2;
@@ -739,6 +774,7 @@ __global__ __launch_bounds__(PT_NT) __attribute__((amdgpu_waves_per_eu(PT_WAVES,
             d1 = d2; a1 = a2;
         }
     }
+#endif
     close_chunk();
     if (bad) atomicOr((unsigned long long *)&a.ctl[1], (unsigned long long)PU_FLAG_UNSORTED);
     if (bad_t) atomicOr((unsigned long long *)&a.ctl[1], (unsigned long long)PU_FLAG_TAXID);
