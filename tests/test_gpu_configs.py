@@ -381,6 +381,17 @@ def test_probe_union_with_taxids_matches_oracle(env, monkeypatch):
             assert ctx.last_route() == 3, (n_univ, nfiles, kind)
             ok, ot = O.union(files, taxs, tax)
             assert np.array_equal(gk, ok) and np.array_equal(gt, ot), (n_univ, nfiles, kind)
+    # tiny files in front (a plasmid before the genomes): the base set is built from the LARGEST files
+    U = _universe(40_000)
+    files = [U[_member(len(U), f, 0.5, 6)] for f in range(30)]
+    for i in (0, 1, 2, 5):
+        files[i] = files[i][:7 + i]
+    taxs = [_taxids(f, T, i) for i, f in enumerate(files)]
+    assert np.array_equal(ctx.union(files), O.union(files)) and ctx.last_route() == 3
+    gk, gt = ctx.union(files, taxs)
+    assert ctx.last_route() == 3
+    ok, ot = O.union(files, taxs, tax)
+    assert np.array_equal(gk, ok) and np.array_equal(gt, ot)
     # later files with private codes, duplicates inside files (their taxids differ), all-ones hashes
     U = _universe(50_000, gap_bits=40)
     files = [U[_member(len(U), f, 0.6, 5)] for f in range(30)]

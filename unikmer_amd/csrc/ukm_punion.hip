@@ -878,6 +878,30 @@ int ukm_dev_probe_union(ukm_ctx *c, const u64 *const *keys, const u32 *const *ta
         if (c->tax_parent == nullptr) UKM_FAIL(UKM_ERR_NO_TAXONOMY, "union: records carry taxids but no taxonomy is loaded");
         if (c->tax_euler == nullptr || c->tax_node_at == nullptr) return UKM_OK;
     }
+    // The base set is built from the k0 LARGEST files (a union does not depend on the order of its files, and neither does
+    // the TaxId fold): a small first file -- a plasmid in front of the genomes -- would leave the tables nearly empty
+    // and every later record a new code.  Files of one size keep their order.
+    std::vector<const u64 *> keys_v(keys, keys + S);
+    std::vector<const u32 *> tax_v((size_t)S, nullptr);
+    std::vector<u64> lens_v(lens, lens + S);
+    if (tax && taxids) tax_v.assign(taxids, taxids + S);
+    {
+        std::vector<int> ord((size_t)S);
+        for (int j = 0; j < S; j++) ord[(size_t)j] = j;
+        std::stable_sort(ord.begin(), ord.end(), [&](int x, int y) { return lens[x] > lens[y]; });
+        std::vector<char> in_base((size_t)S, 0);
+        for (int j = 0; j < k0; j++) in_base[(size_t)ord[(size_t)j]] = 1;
+        size_t b = 0, l = (size_t)k0;
+        for (int j = 0; j < S; j++) {
+            const size_t at = in_base[(size_t)j] ? b++ : l++;
+            keys_v[at] = keys[j];
+            lens_v[at] = lens[j];
+            if (tax && taxids) tax_v[at] = taxids[j];
+        }
+    }
+    keys = keys_v.data();
+    lens = lens_v.data();
+    if (tax && taxids) taxids = tax_v.data();
     u32 range = (u32)PU_RANGE;  // (with TaxIds: chosen below, when the base set's size is known)
     const int mode = ukm_punion_mode();
     const bool dbg = getenv("UKM_PUNION_DEBUG") != nullptr;
