@@ -351,6 +351,14 @@ def test_random_probe_paths(env, seed, monkeypatch):
         gk, gt = ctx.union(files, taxs)
         ok, ot = O.union(files, taxs, tax)
         assert np.array_equal(gk, ok) and np.array_equal(gt, ot), (seed, it, "union+tax", nf, space)
+        # `common` through the counting probes (guards off): any threshold, files with duplicates inside, empty files
+        dup = [np.sort(np.concatenate([f, f[::3]])) if (i % 4 == 1 and len(f)) else f for i, f in enumerate(files)]
+        for thr in {1, 2, int(rng.integers(1, nf + 2)), nf}:
+            assert np.array_equal(ctx.common(dup, thr), O.common(dup, thr)), (seed, it, "common", thr, nf, space)
+            dtax = [(1 + rng.integers(0, T, len(f))).astype(np.uint32) for f in dup]
+            gk, gt = ctx.common(dup, thr, dtax)
+            ok, ot = O.common(dup, thr, dtax, tax)
+            assert np.array_equal(gk, ok) and np.array_equal(gt, ot), (seed, it, "common+tax", thr, nf, space)
         live = [f for f in files if len(f)]
         ltax = [t for f, t in zip(files, taxs) if len(f)]
         if len(live) >= 4:
