@@ -100,7 +100,7 @@ void pf_probe_kernel(PfArgs a) {
     __shared__ u32 s_tax[TAX ? MAXL : 1];
     __shared__ u32 s_min[EULER ? MAXL : 1], s_max[EULER ? MAXL : 1];
     __shared__ u32 s_scan[PF_NT / 64 + 1];
-    __shared__ u32 s_next, s_done;
+    __shared__ u32 s_next, s_done, s_dead;  // s_dead: no record of the range can survive any more
     constexpr bool FOLD_TAX = TAX && (OP == UKM_OP_INTER || CMP);  // the later files' taxids are read
     const int tid = (int)threadIdx.x, lane = lane_id();
     const u32 r = blockIdx.x, S = a.S, S1 = S - 1, L = a.L;
@@ -110,7 +110,7 @@ void pf_probe_kernel(PfArgs a) {
     const u64 e0 = (u64)r * L;
     const u32 ne = (u32)((len0 - e0 < (u64)L) ? (len0 - e0) : (u64)L);
     for (int i = tid; i < PF_SLOTS; i += PF_NT) s_tab[i] = PF_EMPTY;
-    if (tid == 0) { s_next = 0; s_done = 0; }
+    if (tid == 0) { s_next = 0; s_done = 0; s_dead = 0; }
     u32 flags = 0;
     u64 ent[PER];
 #pragma unroll
@@ -193,7 +193,7 @@ void pf_probe_kernel(PfArgs a) {
             atomicAdd(&s_cnt[idx], 1u);  // (inter with taxids does not come here: see the step)
         }
     };
-    auto step = [&](auto UU, const ukm_gptr<u64> f, const ukm_gptr<u32> t, u64 p0, u64 end, u64 len) {
+    auto step = [&](auto UU, const ukm_gptr<u64> f, const ukm_gptr<u32> t, u64 p0, u64 end, u64 len, bool dead) {
         constexpr int U = decltype(UU)::value;
         pf_pair pr[U];
         pf_tpair tq[U];
@@ -208,7 +208,7 @@ void pf_probe_kernel(PfArgs a) {
             pr[u] = *(const pf_pair __attribute__((address_space(1))) *)(f + q);
             nx[u] = f[q2];
             tq[u] = pf_tpair{0, 0};
-            if (FOLD_TAX && t) tq[u] = *(const pf_tpair __attribute__((address_space(1))) *)(t + q);  // (wave-uniform test)
+            if (FOLD_TAX && t && !dead) tq[u] = *(const pf_tpair __attribute__((address_space(1))) *)(t + q);  // (wave-uniform test)
         }
 #pragma unroll
         for (int u = 0; u < U; u++) {
@@ -237,6 +237,10 @@ void pf_probe_kernel(PfArgs a) {
                 if (x0 == x1) flags |= PF_FLAG_DUP;
                 if (x0 > x1) flags |= PF_FLAG_UNSORTED;
             }
+            if (dead) {  // (wave-uniform) nothing of this range is left: the file is only checked for its order
+                if constexpr (OP == UKM_OP_INTER && TAX) li[2 * u] = li[2 * u + 1] = -1;
+                continue;
+            }
             if constexpr (OP == UKM_OP_INTER && TAX) {
                 // inter with taxids: count the hits now, fold the taxids below with the table reads of all of the
                 // step's LCAs in flight together
@@ -255,6 +259,7 @@ void pf_probe_kernel(PfArgs a) {
                 }
             }
         }
+        if (dead) return;
         if constexpr (OP == UKM_OP_INTER && TAX) {
             // The LCA of a SET of taxids is the LCA of its members with the smallest and the largest pre-order number
             // (TaxDev::euler): a hit only has to fold its taxid's number into the record's minimum and maximum — two
@@ -303,6 +308,21 @@ void pf_probe_kernel(PfArgs a) {
         }
         return m;
     };
+    // The reference stops reading when its result is empty (inter.go:268-278, diff.go:441-452).  Here every file is still
+    // read and checked for its order -- an unsorted or duplicated file must send the call to the exact routes whatever the
+    // result -- but a range none of whose records can survive any more stops PROBING: its later slices are streamed with
+    // the order check alone (no taxid loads, no table, no LDS).  A wave looks every eighth slice: inter: no record has a
+    // hit from every file finished so far; diff: every record has been hit.
+    u32 slices = 0;
+    auto range_is_dead = [&]() -> bool {
+        const u32 finished = OP == UKM_OP_INTER ? __hip_atomic_load(&s_done, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) : 0u;
+        bool any = false;
+        for (u32 i = (u32)lane; i < ne; i += 64) {
+            const u32 w = s_cnt[i];
+            any |= OP == UKM_OP_INTER ? ((EULER ? (w & PF_CNT_MASK) : w) >= finished) : w == 0;
+        }
+        return __ballot(any) == 0ull;
+    };
     u32 j = take();
     Meta cur = fetch(j);
     while (j < S1) {
@@ -311,8 +331,13 @@ void pf_probe_kernel(PfArgs a) {
         const auto f = as_global((const u64 *)(uintptr_t)cur.f);
         const auto t = as_global((const u32 *)(uintptr_t)cur.t);
         const u64 len = cur.len, end = cur.end < cur.beg ? cur.beg : cur.end;
+        bool dead = __builtin_amdgcn_readfirstlane((int)s_dead) != 0;
+        if (!dead && (++slices & 7u) == 0 && range_is_dead()) {
+            dead = true;
+            if (lane == 0) s_dead = 1;
+        }
         if (len < 2) {  // (a one-record file: no 16-byte load fits)
-            if (end > cur.beg && lane == 0) {
+            if (!dead && end > cur.beg && lane == 0) {
                 const int i0 = find(f[0]);
                 if (i0 >= 0) hit(i0, (FOLD_TAX && t) ? t[0] : 0u);
             }
@@ -320,9 +345,9 @@ void pf_probe_kernel(PfArgs a) {
             u64 p0 = cur.beg;
             while (p0 < end) {
                 const u64 rem = end - p0;
-                if (rem > 256) { step(std::integral_constant<int, 4>{}, f, t, p0, end, len); p0 += 512; }
-                else if (rem > 128) { step(std::integral_constant<int, 2>{}, f, t, p0, end, len); p0 += 256; }
-                else { step(std::integral_constant<int, 1>{}, f, t, p0, end, len); p0 += 128; }
+                if (rem > 256) { step(std::integral_constant<int, 4>{}, f, t, p0, end, len, dead); p0 += 512; }
+                else if (rem > 128) { step(std::integral_constant<int, 2>{}, f, t, p0, end, len, dead); p0 += 256; }
+                else { step(std::integral_constant<int, 1>{}, f, t, p0, end, len, dead); p0 += 128; }
             }
         }
         // RELEASE: the wave's hit atomics on s_cnt are ordered before the count of finished files that the `need` shortcut
