@@ -460,6 +460,16 @@ def test_common_by_counting_probes_matches_oracle(env, monkeypatch):
                 taxs = [np.full(len(f), 1 + (i * 7919) % T, np.uint32) for i, f in enumerate(files)]
             else:
                 taxs = [_taxids(f, T, i) if i % 3 else None for i, f in enumerate(files)]
+            # `merge -d` in its final round (util-sort.go:519-530): the codes with at least two records, every record of
+            # every file counted (the duplicates inside the first file too) -- the same tables with a threshold of two
+            if taxs is None:
+                assert np.array_equal(ctx.merge_k(files, mode=L.REPEATED), O.merge_k(files, mode=O.REPEATED)), (n_univ, nfiles, kind)
+                assert ctx.last_route() == 6, (n_univ, nfiles, kind)
+            else:
+                gk, gt = ctx.merge_k(files, taxs, mode=L.REPEATED)
+                assert ctx.last_route() == 6, (n_univ, nfiles, kind)
+                ok, ot = O.merge_k(files, taxs, mode=O.REPEATED, tax=tax)
+                assert np.array_equal(gk, ok) and np.array_equal(gt, ot), (n_univ, nfiles, kind)
             for thr in (2, nfiles // 2, nfiles - 1, nfiles, nfiles + 1):
                 if taxs is None:
                     g = ctx.common(files, thr)

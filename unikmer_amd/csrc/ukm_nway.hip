@@ -803,6 +803,34 @@ extern "C" int ukm_merge_k(ukm_ctx *ctx, const uint64_t *const *keys, const uint
         // util-sort.go:377-388,519-530: in a non-final round the one/two-copy protocol is kept
         int m = mode;
         if (mode == UKM_REPEATED && !final_round) m = UKM_REPEATED_CHUNK;
+        if (m == UKM_REPEATED && ukm_kway_enabled()) {
+            // -d in the final round = the codes that have at least two records, TaxId = LCA over all of them
+            // (util-sort.go:519-530): for many files that share most of their codes the counting hash probes of
+            // ukm_punion.hip with a threshold of two (every record of every file counts); it declines for few / small /
+            // unsorted files and files that share little, and the merge + scan below answers.
+            std::vector<const u64 *> kp;
+            std::vector<const u32 *> tp;
+            std::vector<u64> ln;
+            for (auto &q : all)
+                if (q.n) {
+                    kp.push_back(q.k);
+                    tp.push_back(q.t);
+                    ln.push_back(q.n);
+                }
+            if (kp.size() >= 3) {
+                WsMark pm = ws_mark(ctx);
+                bool fb = true;
+                const int prc = ukm_dev_probe_common(ctx, kp.data(), tax ? tp.data() : nullptr, ln.data(), (int)kp.size(), tax, 2u, o.k, o.t,
+                                                     out_cap, n_out, &fb, false);
+                ws_release(ctx, pm);
+                UKM_TRY(prc);
+                if (!fb) {
+                    ctx->last_route = 6;
+                    return UKM_OK;
+                }
+                *n_out = 0;
+            }
+        }
         u64 *k = nullptr;
         u32 *t = nullptr;
         u64 total = 0, need = 0;

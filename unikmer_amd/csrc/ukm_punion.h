@@ -13,6 +13,6 @@ int ukm_punion_tax_mode();
 int ukm_dev_probe_union(ukm_ctx *c, const u64 *const *keys, const u32 *const *taxids, const u64 *lens, int S, bool tax, u64 *out,
                         u32 *tout, u64 out_cap, u64 *n_out, bool *fallback);
 // `common` below the number of files through the same tables with a record count per entry; keys[0] = the first file as a
-// sorted duplicate-free set.  *fallback as above.
+// sorted duplicate-free set (first_once), or -- !first_once -- every record of every file counts (`merge -d`).  *fallback as above.
 int ukm_dev_probe_common(ukm_ctx *c, const u64 *const *keys, const u32 *const *taxids, const u64 *lens, int S, bool tax,
-                         u32 threshold, u64 *out, u32 *tout, u64 out_cap, u64 *n_out, bool *fallback);
+                         u32 threshold, u64 *out, u32 *tout, u64 out_cap, u64 *n_out, bool *fallback, bool first_once = true);

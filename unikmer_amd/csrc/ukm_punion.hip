@@ -1058,13 +1058,14 @@ int ukm_dev_probe_union(ukm_ctx *c, const u64 *const *keys, const u32 *const *ta
     return UKM_OK;
 }
 
-// `common` with a threshold below the number of files by the counting tables of pt_probe_kernel<true>.  keys[0] must be
-// the first file as a sorted, duplicate-free set (ukm_common makes it one: every code of the first file counts once,
-// common.go:232,244); every record of every other file counts (common.go:262-266).  *fallback = true: not this path (few
+// `common` with a threshold below the number of files by the counting tables of pt_probe_kernel<true>.  first_once: keys[0]
+// is the first file as a sorted, duplicate-free set (ukm_common makes it one: every code of the first file counts once,
+// common.go:232,244); every record of every other file counts (common.go:262-266).  !first_once: every record of every
+// file counts (`merge -d` in its final round = the codes with at least two records, util-sort.go:519-530).  *fallback = true: not this path (few
 // or small files, more than PU_MAXS of them, later files that share too little with the first, an unsorted file, a record
 // no table could count): nothing that matters was written and the caller's counting merge answers.
 int ukm_dev_probe_common(ukm_ctx *c, const u64 *const *keys, const u32 *const *taxids, const u64 *lens, int S, bool tax,
-                         u32 threshold, u64 *out, u32 *tout, u64 out_cap, u64 *n_out, bool *fallback) {
+                         u32 threshold, u64 *out, u32 *tout, u64 out_cap, u64 *n_out, bool *fallback, bool first_once) {
     *fallback = true;
     *n_out = 0;
     const int mode = ukm_punion_mode();
@@ -1124,8 +1125,8 @@ int ukm_dev_probe_common(ukm_ctx *c, const u64 *const *keys, const u32 *const *t
         a.tfiles = (const u32 *const *)(d_tab + 2 * (size_t)S + 1);
         a.S1 = (u32)(S - 1);
         double rate = 0.0;
-        UKM_TRY(hit_rate(&rate));
-        if (mode != 2 && rate < PT_MIN_HIT) {
+        if (first_once) UKM_TRY(hit_rate(&rate));
+        if (!first_once || (mode != 2 && rate < PT_MIN_HIT)) {
             const int k0 = std::min(S, PT_K0);
             u64 cap0 = 0;
             for (int j = 0; j < k0; j++) cap0 += lens[j];
@@ -1146,7 +1147,7 @@ int ukm_dev_probe_common(ukm_ctx *c, const u64 *const *keys, const u32 *const *t
             a.tfiles = (const u32 *const *)(d_tab + 2 * (size_t)S);
             a.S1 = (u32)S;
             UKM_TRY(hit_rate(&rate));
-            if (rate < PT_MIN_HIT) return UKM_OK;
+            if (mode != 2 && rate < PT_MIN_HIT) return UKM_OK;
         }
     }
     const int S1 = (int)a.S1;
