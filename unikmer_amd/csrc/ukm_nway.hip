@@ -252,6 +252,22 @@ int try_kway(ukm_ctx *ctx, int op, const std::vector<Stream> &ss, bool tax, u64 
     }
     WsMark mark = ws_mark(ctx);
     bool fallback = true;
+    if (op == UKM_KWAY_MERGE) {
+        // many files that share most of their codes: the records of every code are placed behind one another file by file
+        // (ukm_punion.hip, pl_merge_kernel); it declines for few / small files, files that share little, a duplicate
+        // inside a file, an unsorted file
+        const int prc = ukm_dev_place_merge(ctx, kp.data(), tax ? tp.data() : nullptr, ln.data(), (int)ss.size(), tax, fk, ft, fcap, n_out,
+                                            &fallback);
+        if (prc != UKM_OK || !fallback) {
+            ws_release(ctx, mark);
+            UKM_TRY(prc);
+            ctx->last_route = 7;
+            *done = true;
+            return UKM_OK;
+        }
+        ws_release(ctx, mark);
+        fallback = true;
+    }
     {
         // many short streams: one pass over HBM, every value range ordered inside LDS (ukm_srmerge.hip); it declines
         // (*fallback) for few streams, small inputs, unsorted streams and one code with thousands of copies

@@ -16,3 +16,8 @@ int ukm_dev_probe_union(ukm_ctx *c, const u64 *const *keys, const u32 *const *ta
 // sorted duplicate-free set (first_once), or -- !first_once -- every record of every file counts (`merge -d`).  *fallback as above.
 int ukm_dev_probe_common(ukm_ctx *c, const u64 *const *keys, const u32 *const *taxids, const u64 *lens, int S, bool tax,
                          u32 threshold, u64 *out, u32 *tout, u64 out_cap, u64 *n_out, bool *fallback, bool first_once = true);
+// Keep-everything merge of many files that share most of their codes, by placement (ukm_punion.hip, pl_merge_kernel):
+// developer knob UKM_PLACE: 0 = never, 1 = whenever the shape allows it.  *fallback as above.
+int ukm_place_mode();
+int ukm_dev_place_merge(ukm_ctx *c, const u64 *const *keys, const u32 *const *taxids, const u64 *lens, int S, bool tax, u64 *out,
+                        u32 *tout, u64 out_cap, u64 *n_out, bool *fallback);

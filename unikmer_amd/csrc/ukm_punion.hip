@@ -70,6 +70,8 @@ struct PuArgs {
     const u32 *const *tfiles; // [S1] TaxIds of the later files (an entry may be null: all 0)
     u32 *base_tax;            // [n0] in: the fold over the base files, out: over every file
     u32 *miss_tax;            // beside `miss`
+    unsigned short *rec_idx;  // placement merge: [all records, file by file] the record's code as an index into its range
+    const u64 *rec_off;       // [S1]: where file j's records begin in rec_idx
     u32 threshold;            // COUNT (`common`): a code leaves when at least this many records carried it
     u32 count0;               // COUNT: records a base entry starts with (1: the base set is the first file; 0: every file is probed)
     TaxDev tax;
@@ -834,6 +836,260 @@ __global__ __launch_bounds__(PT_NT) __attribute__((amdgpu_waves_per_eu(PT_WAVES,
     }
 }
 
+// ---- keep-everything merge of MANY files that share most of their codes, by placement (`merge` / mergeChunksFile's heap,
+// util-sort.go:196-225,289-351, when a code is in hundreds of the files) --------------------------------------------------
+// The merged sequence is, code by code, the records of that code in file order.  With the sorted distinct codes (BASE, the
+// plain probe union above) cut into ranges of PL_RANGE, one workgroup per range
+//   A. counts the records of every code of its range (one hash probe per record, as in the counting pass) and scans the
+//      counts: where every code's run begins -- the range's own beginning is the sum of its cut points;
+//   B. goes through the files in ORDER, PL_BATCH at a time: the batch's records are probed again and their TaxIds put
+//      into an LDS cell [code][file of the batch]; then every code's records of the batch -- they are neighbours in the
+//      result -- are written in one piece behind what the earlier batches wrote (up to 128 + 64 contiguous bytes).
+// Every record is read twice and written once; no sorting, no merge rounds.  Files must be strictly increasing (a code
+// twice in one file would share a cell): a duplicate, an unsorted file or a code the tables do not know raise a flag and
+// the caller's merge answers.
+#ifndef PL_PER_N
+#define PL_PER_N 1
+#endif
+#ifndef PL_BATCH_N
+#define PL_BATCH_N 16
+#endif
+constexpr int PL_NT = 512;
+constexpr int PL_PER = PL_PER_N;             // codes per thread
+constexpr int PL_RANGE = PL_NT * PL_PER;     // codes per range
+constexpr int PL_BUCKET_BITS = PL_PER == 1 ? 9 : (PL_PER == 2 ? 10 : 11);
+constexpr int PL_BUCKETS = 1 << PL_BUCKET_BITS;
+constexpr int PL_SLOTS = 4 * PL_BUCKETS;
+constexpr int PL_BATCH = PL_BATCH_N;         // files per batch (one bit each in a code's word; one TaxId cell each)
+enum { PL_FLAG_ORDER = 1, PL_FLAG_UNKNOWN = 2 };
+
+__device__ __forceinline__ u32 pl_hash(u64 x) {
+    const u32 lo = (u32)x, hi = (u32)(x >> 32);
+    return ((lo ^ (hi * 0x85EBCA6Bu)) * 0x9E3779B1u) >> (32 - PL_BUCKET_BITS);
+}
+
+template <bool TAX>
+__global__ __launch_bounds__(PL_NT) void pl_merge_kernel(PuArgs a) {
+    __shared__ __attribute__((aligned(32))) u64 s_tab[PL_SLOTS];
+    __shared__ unsigned short s_idx[PL_SLOTS];
+    __shared__ u32 s_cnt[PL_RANGE];   // A: records of the code; B: where its next record goes (relative to the range)
+    __shared__ u32 s_mask[PL_RANGE];  // B: the files of the batch that hold the code
+    __shared__ u32 s_btax[TAX ? PL_RANGE * PL_BATCH : 1];  // B: their TaxIds
+    __shared__ u64 s_code[PL_RANGE];
+    __shared__ u32 s_seg[PL_RANGE], s_n[PL_RANGE];         // B: where the batch's records of the code go, how many
+    __shared__ u32 s_scan[PL_NT / 64 + 1];
+    __shared__ u32 s_next;
+    __shared__ unsigned long long s_gbase;
+    const int tid = (int)threadIdx.x, lane = lane_id(), wave = tid >> 6;
+    const u32 r = blockIdx.x, S1 = a.S1;
+    const u64 b0 = (u64)r * a.range;
+    const u32 ne = (u32)((a.n0 - b0 < (u64)a.range) ? (a.n0 - b0) : (u64)a.range);
+    for (int i = tid; i < PL_SLOTS; i += PL_NT) s_tab[i] = PU_EMPTY;
+    for (int i = tid; i < PL_RANGE; i += PL_NT) { s_cnt[i] = 0; s_mask[i] = 0; }
+    if (tid == 0) { s_next = 0; s_gbase = 0ull; }
+    u32 flags = 0;
+    __syncthreads();
+    u64 code[PL_PER];  // thread t owns the codes t * PL_PER .. (consecutive: one block scan gives their places)
+#pragma unroll
+    for (int k = 0; k < PL_PER; k++) {
+        const u32 i = (u32)tid * PL_PER + (u32)k;
+        code[k] = i < ne ? a.base[b0 + i] : PU_EMPTY;
+        s_code[i] = code[k];
+        if (i >= ne) continue;
+        if (code[k] == PU_EMPTY) { flags |= PL_FLAG_UNKNOWN; continue; }  // (an all-ones code is the table's empty marker)
+        u32 h = pl_hash(code[k]);
+        for (bool placed = false; !placed; h = (h + 1) & (PL_BUCKETS - 1)) {
+#pragma unroll
+            for (int q = 0; q < 4 && !placed; q++) {
+                const u64 old = atomicCAS((unsigned long long *)&s_tab[4 * h + q], (unsigned long long)PU_EMPTY, (unsigned long long)code[k]);
+                if (old == PU_EMPTY) { s_idx[4 * h + q] = (unsigned short)i; placed = true; }
+            }
+        }
+    }
+    {   // where the range begins in the result: everything the files hold below its first code
+        unsigned long long mine = 0;
+        for (u32 j = (u32)tid; j < S1; j += PL_NT) mine += a.cuts[(u64)r * S1 + j];
+        if (mine) atomicAdd(&s_gbase, mine);
+    }
+    __syncthreads();
+    auto find = [&](u64 x) -> int {
+        u32 h = pl_hash(x);
+        for (;;) {
+            const ulonglong2 *b = reinterpret_cast<const ulonglong2 *>(&s_tab[4 * h]);
+            const ulonglong2 p = b[0], q = b[1];
+            const bool m0 = p.x == x, m1 = p.y == x, m2 = q.x == x, m3 = q.y == x;
+            if (m0 | m1 | m2 | m3) return x == PU_EMPTY ? -1 : (int)s_idx[4 * h + (m0 ? 0 : (m1 ? 1 : (m2 ? 2 : 3)))];
+            if (q.y == PU_EMPTY) return -1;
+            h = (h + 1) & (PL_BUCKETS - 1);
+        }
+    };
+    // A. one slice of one file, 256 records per step: the file's order is checked, every record's code is looked up, counted
+    // and its index kept for the second pass (2 bytes per record instead of the code, and no second look-up)
+    auto count_slice = [&](u32 j) {
+        const u64 beg = a.cuts[(u64)r * S1 + j], end0 = a.cuts[(u64)(r + 1) * S1 + j], len = a.lens[j];
+        const u64 end = end0 < beg ? beg : end0;
+        const auto f = as_global(a.files[j]);
+        unsigned short *ri = a.rec_idx + a.rec_off[j];
+        for (u64 p0 = beg; p0 < end; p0 += 256) {
+            u64 x[2][2], nx[2];
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+                const u64 pos = p0 + (u64)u * 128 + 2u * (u32)lane;
+                const u64 q0 = pos < len ? pos : len - 1, q1 = pos + 1 < len ? pos + 1 : len - 1, q2 = pos + 2 < len ? pos + 2 : len - 1;
+                x[u][0] = f[q0];
+                x[u][1] = f[q1];
+                nx[u] = f[q2];
+            }
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+                const u64 pos = p0 + (u64)u * 128 + 2u * (u32)lane;
+                const bool v0 = pos < end, v1 = pos + 1 < end;
+                // strictly increasing, every neighbouring pair of the file once (also across slices)
+                if (v0 && pos + 1 < len && x[u][0] >= x[u][1]) flags |= PL_FLAG_ORDER;
+                if (v1 && pos + 2 < len && x[u][1] >= nx[u]) flags |= PL_FLAG_ORDER;
+#pragma unroll
+                for (int w = 0; w < 2; w++) {
+                    if (!(w ? v1 : v0)) continue;
+                    const int i = find(x[u][w]);
+                    if (i < 0) { flags |= PL_FLAG_UNKNOWN; continue; }
+                    atomicAdd(&s_cnt[i], 1u);
+                    ri[pos + (u64)w] = (unsigned short)i;
+                }
+            }
+        }
+    };
+    for (;;) {
+        u32 j = 0;
+        if (lane == 0) j = atomicAdd(&s_next, 1u);
+        j = (u32)__builtin_amdgcn_readfirstlane((int)j);
+        if (j >= S1) break;
+        count_slice(j);
+    }
+    __syncthreads();
+    {   // where every code's run begins (relative to the range): exclusive scan of the counts in code order
+        u32 v[PL_PER], sum = 0;
+#pragma unroll
+        for (int k = 0; k < PL_PER; k++) {
+            const u32 i = (u32)tid * PL_PER + (u32)k;
+            v[k] = i < ne ? s_cnt[i] : 0u;
+            sum += v[k];
+        }
+        u32 tot;
+        u32 ex = block_excl_scan_u32<PL_NT>(sum, s_scan, &tot);
+#pragma unroll
+        for (int k = 0; k < PL_PER; k++) {
+            s_cnt[(u32)tid * PL_PER + (u32)k] = ex;
+            s_n[(u32)tid * PL_PER + (u32)k] = v[k];
+            ex += v[k];
+        }
+    }
+    __syncthreads();
+    const u64 gbase = (u64)s_gbase;
+    // The CODES of the result need no placement: a code's run is that code, count times -- written here in one piece per
+    // code, a wave at a time (1 KB per store), instead of 16 records at a time with the batches below.  Plain codes are
+    // done after this.
+    for (u32 i = (u32)wave; i < ne; i += PL_NT / 64) {
+        const u64 at = gbase + s_cnt[i], cd = s_code[i];
+        const u32 n = s_n[i];
+        for (u32 q = 2u * (u32)lane; q < n; q += 128) {
+            if (q + 1 < n) {
+                typedef u64 pl_k2 __attribute__((ext_vector_type(2)));
+                typedef pl_k2 __attribute__((aligned(8))) pl_kpair;
+                *reinterpret_cast<pl_kpair *>(a.miss + at + q) = pl_kpair{cd, cd};
+            } else {
+                a.miss[at + q] = cd;
+            }
+        }
+    }
+    if (!TAX) {
+        if (flags) atomicOr((unsigned long long *)&a.ctl[1], (unsigned long long)flags);
+        return;
+    }
+    __syncthreads();  // (s_n is reused by the batches)
+#ifndef PL_ABL_NOB
+    // B. the files in order, PL_BATCH at a time: index and TaxId of every record of the batch into its code's cells; then the
+    // owner of a code writes the batch's records of that code -- neighbours in the result -- in one piece.  (Every record
+    // written by the thread that read it, at the place the complete words give it, was measured at 20.6 - 24.7 ms
+    // against 14.3: 64 lanes storing 8 bytes into 64 different lines.)
+    auto place_slice = [&](u32 j, u32 fj) {
+        const u64 beg = a.cuts[(u64)r * S1 + j], end0 = a.cuts[(u64)(r + 1) * S1 + j];
+        const u64 end = end0 < beg ? beg : end0;
+        const unsigned short *ri = a.rec_idx + a.rec_off[j];
+        const u32 *tp = TAX ? a.tfiles[j] : nullptr;
+        for (u64 p0 = beg; p0 < end; p0 += 512) {
+            u32 i[8], t[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const u64 pos = p0 + (u64)u * 64 + (u32)lane;
+                const u64 q = pos < end ? pos : beg;
+                i[u] = ri[q];
+                t[u] = (TAX && tp) ? tp[q] : 0u;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const u64 pos = p0 + (u64)u * 64 + (u32)lane;
+                if (pos >= end) continue;
+                atomicOr(&s_mask[i[u]], 1u << fj);
+                if (TAX) s_btax[i[u] * PL_BATCH + (int)fj] = t[u];
+            }
+        }
+    };
+    for (u32 bj = 0; bj < S1; bj += PL_BATCH) {
+#ifndef PL_ABL_NOREAD
+        for (u32 fj = (u32)wave; fj < (u32)PL_BATCH && bj + fj < S1; fj += PL_NT / 64) place_slice(bj + fj, fj);
+#else
+        if (tid < (int)ne) s_mask[tid] = 0xFFFFu;
+#endif
+        __syncthreads();
+        // the owner of a code: the batch's TaxIds of the code side by side, its place, its count
+#pragma unroll
+        for (int k = 0; k < PL_PER; k++) {
+            const u32 i = (u32)tid * PL_PER + (u32)k;
+            u32 m = s_mask[i];
+            s_n[i] = (u32)__popc(m);
+            if (m) {
+                s_seg[i] = s_cnt[i];
+                s_cnt[i] += (u32)__popc(m);
+                s_mask[i] = 0;
+                if (TAX) {
+                    int q = 0;
+                    while (m) {
+                        const int fj = __ffs((int)m) - 1;
+                        m &= m - 1;
+                        s_btax[i * PL_BATCH + q] = s_btax[i * PL_BATCH + fj];  // (q <= fj: moving forward in place)
+                        q++;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+#ifndef PL_ABL_NOWRITE
+        // The batch's TaxIds of a code are written by EIGHT lanes, two each: one or two cache lines, and the lanes that share
+        // a line share the request.  (One thread writing its code's records -- codes and TaxIds -- one after the other
+        // was 32 requests per code and batch: 10.4 of the kernel's 14.2 ms were those stores, at 1.2 TB/s.)
+        constexpr u32 LPC = PL_BATCH / 2, CPW = 64 / LPC;  // lanes per code, codes per wave and step
+        static_assert(PL_BATCH == 8 || PL_BATCH == 16 || PL_BATCH == 32, "two records per lane");
+        for (u32 c0 = (u32)wave * CPW; c0 < (u32)PL_RANGE; c0 += (PL_NT / 64) * CPW) {
+            const u32 i = c0 + (u32)lane / LPC, part = (u32)lane % LPC;
+            const u32 n = s_n[i], q0 = 2u * part;
+            if (q0 < n) {
+                const u64 pos = gbase + s_seg[i] + q0;
+                if (q0 + 1 < n) {
+                    typedef u32 pl_t2 __attribute__((ext_vector_type(2)));
+                    typedef pl_t2 __attribute__((aligned(4))) pl_tpair;
+                    *reinterpret_cast<pl_tpair *>(a.miss_tax + pos) = pl_tpair{s_btax[i * PL_BATCH + q0], s_btax[i * PL_BATCH + q0 + 1]};
+                } else {
+                    a.miss_tax[pos] = s_btax[i * PL_BATCH + q0];
+                }
+            }
+        }
+#endif
+        __syncthreads();
+    }
+#endif
+    if (flags) atomicOr((unsigned long long *)&a.ctl[1], (unsigned long long)flags);
+}
+
 // Base entries per range of the TaxId / counting pass: PT_RANGE, or less when that leaves only a few rounds of workgroups
 // (one per CU) with the last one partly empty -- 1e6 base entries: 651 ranges are 2.54 rounds of 256, 768 ranges of 1302
 // entries are three full ones.
@@ -1194,5 +1450,108 @@ int ukm_dev_probe_common(ukm_ctx *c, const u64 *const *keys, const u32 *const *t
     UKM_TRY(ukm_dev_sort(c, a.miss, tax ? a.miss_tax : nullptr, nm, 64));
     UKM_HIP(hipMemcpyAsync(out, a.miss, nm * sizeof(u64), hipMemcpyDeviceToDevice, c->stream));
     if (tax) UKM_HIP(hipMemcpyAsync(tout, a.miss_tax, nm * sizeof(u32), hipMemcpyDeviceToDevice, c->stream));
+    return UKM_OK;
+}
+
+int ukm_place_mode() {
+    const char *e = getenv("UKM_PLACE");
+    if (!e || !*e) return -1;
+    return atoi(e);
+}
+
+// Keep-everything merge by placement (pl_merge_kernel).  *fallback = true: not this path (few or small files, files that
+// share too little, a duplicate inside a file, an unsorted file): nothing that matters was written.
+int ukm_dev_place_merge(ukm_ctx *c, const u64 *const *keys, const u32 *const *taxids, const u64 *lens, int S, bool tax, u64 *out,
+                        u32 *tout, u64 out_cap, u64 *n_out, bool *fallback) {
+    *fallback = true;
+    *n_out = 0;
+    const int mode = ukm_place_mode();
+    if (mode == 0 || S < 3 || S > PU_MAXS) return UKM_OK;
+    u64 N = 0;
+    for (int j = 0; j < S; j++) {
+        if (lens[j] == 0) return UKM_OK;  // (callers drop empty streams)
+        N += lens[j];
+    }
+    if (mode < 1 && (S < 64 || N < (1ull << 26))) return UKM_OK;
+    if (tax && !tout) UKM_FAIL(UKM_ERR_INVALID, "merge: taxids given but out_taxids is NULL");
+    if (N > out_cap) {
+        *n_out = N;
+        UKM_FAIL(UKM_ERR_CAPACITY, "merge: output needs %llu records, capacity is %llu", (unsigned long long)N, (unsigned long long)out_cap);
+    }
+    const bool dbg = getenv("UKM_PUNION_DEBUG") != nullptr;
+    auto t0 = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {
+        if (!dbg) return;
+        (void)hipStreamSynchronize(c->stream);
+        fprintf(stderr, "[place] %-10s %8.3f ms\n", what, ms_since(t0));
+        t0 = std::chrono::steady_clock::now();
+    };
+    // 1. the distinct codes: at most a sixteenth of the records, or the runs are too short for this path
+    const u64 cap0 = mode >= 1 ? N : N / 16 + 1024;
+    u64 *base = nullptr;
+    UKM_TRY(ws_alloc_t(c, cap0 + 1, &base));
+    u64 n0 = 0;
+    {
+        bool fb = true;
+        WsMark m = ws_mark(c);
+        const int rc = ukm_dev_probe_union(c, keys, nullptr, lens, S, false, base, nullptr, cap0, &n0, &fb);
+        ws_release(c, m);
+        if (rc == UKM_ERR_CAPACITY) return UKM_OK;
+        UKM_TRY(rc);
+        if (fb || n0 == 0) return UKM_OK;
+    }
+    lap("union");
+    // 2. cut points of every file at the ranges' first codes
+    const u32 range = (u32)PL_RANGE;
+    const u64 R64 = (n0 + range - 1) / range;
+    if (R64 > 0x7FFFFFFEull) return UKM_OK;
+    std::vector<u64> tab((size_t)4 * S);
+    u64 off = 0;
+    for (int j = 0; j < S; j++) {
+        tab[(size_t)j] = (u64)(uintptr_t)keys[j];
+        tab[(size_t)S + j] = lens[j];
+        tab[(size_t)2 * S + j] = (u64)(uintptr_t)((tax && taxids) ? taxids[j] : nullptr);
+        tab[(size_t)3 * S + j] = off;
+        off += lens[j];
+    }
+    u64 *d_tab = nullptr, *ctl = nullptr;
+    UKM_TRY(ws_alloc_t(c, tab.size(), &d_tab));
+    UKM_TRY(ws_alloc_t(c, 8, &ctl));
+    UKM_HIP(hipMemcpyAsync(d_tab, tab.data(), tab.size() * sizeof(u64), hipMemcpyHostToDevice, c->stream));
+    UKM_HIP(hipMemsetAsync(ctl, 0, 8 * sizeof(u64), c->stream));
+    UKM_HIP(hipStreamSynchronize(c->stream));  // `tab` is a pageable host buffer of this frame
+    PuArgs a;
+    memset(&a, 0, sizeof(a));
+    a.files = (const u64 *const *)d_tab;
+    a.lens = d_tab + S;
+    a.tfiles = (const u32 *const *)(d_tab + 2 * (size_t)S);
+    a.rec_off = d_tab + 3 * (size_t)S;
+    UKM_TRY(ws_alloc_t(c, N + 8, &a.rec_idx));
+    a.S1 = (u32)S;
+    a.base = base;
+    a.n0 = n0;
+    a.R = (u32)R64;
+    a.range = range;
+    a.ctl = ctl;
+    a.miss = out;
+    a.miss_tax = tax ? tout : nullptr;
+    UKM_TRY(ws_alloc_t(c, ((size_t)a.R + 1) * S, &a.cuts));
+    const u64 ncuts = ((u64)a.R + 1) * (u64)S;
+    hipLaunchKernelGGL(pu_cuts_kernel, dim3((unsigned)((ncuts + 255) / 256)), dim3(256), 0, c->stream, a);
+    lap("cuts");
+    (void)hipEventRecord(c->ev_k0, c->stream);
+    if (tax) hipLaunchKernelGGL(pl_merge_kernel<true>, dim3(a.R), dim3(PL_NT), 0, c->stream, a);
+    else hipLaunchKernelGGL(pl_merge_kernel<false>, dim3(a.R), dim3(PL_NT), 0, c->stream, a);
+    (void)hipEventRecord(c->ev_k1, c->stream);
+    c->evk_valid = true;
+    UKM_HIP(hipGetLastError());
+    lap("place");
+    u64 h[2] = {0, 0};
+    UKM_TRY(ukm_read_u64(c, ctl, h, 2));
+    if (dbg) fprintf(stderr, "[place] S=%d N=%llu n0=%llu R=%u flags=%llu\n", S, (unsigned long long)N, (unsigned long long)n0, a.R,
+                     (unsigned long long)h[1]);
+    if (h[1] != 0) return UKM_OK;
+    *fallback = false;
+    *n_out = N;
     return UKM_OK;
 }
