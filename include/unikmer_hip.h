@@ -109,8 +109,8 @@ int ukm_last_call_ms(ukm_ctx *ctx, float *ms);
 /* diagnostic: which internal route answered the most recent n-way call (ukm_union / ukm_merge_k / ukm_common):
  * 0 none / 2-way only, 1 pairwise tree of 2-way kernels, 2 multi-level k-way streaming merge, 3 LDS hash-probe union,
  * 4 single-pass range merge (one LDS tile per value range), 5 the same pass counting the records of every code
- * (ukm_common below the number of files), 6 ukm_common by counting hash probes against the first file.  Tests use it to
- * see that a knob took effect. */
+ * (ukm_common below the number of files), 6 ukm_common / ukm_merge_k -d by counting hash probes, 7 keep-everything merge
+ * by placement (counts per code, runs written in one piece).  Tests use it to see that a knob took effect. */
 int ukm_last_route(ukm_ctx *ctx);
 
 /* ---- taxonomy: replaces taxdump.NewTaxonomyFromNCBI / LoadMergedNodesFromNCBI / LCA

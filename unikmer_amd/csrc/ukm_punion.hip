@@ -1472,7 +1472,7 @@ int ukm_dev_place_merge(ukm_ctx *c, const u64 *const *keys, const u32 *const *ta
         if (lens[j] == 0) return UKM_OK;  // (callers drop empty streams)
         N += lens[j];
     }
-    if (mode < 1 && (S < 64 || N < (1ull << 26))) return UKM_OK;
+    if (mode < 1 && (S < 96 || N < (1ull << 26))) return UKM_OK;  // (64 files x 4e6: 4.7 ms against the k-way merge's 3.7)
     if (tax && !tout) UKM_FAIL(UKM_ERR_INVALID, "merge: taxids given but out_taxids is NULL");
     if (N > out_cap) {
         *n_out = N;
@@ -1486,8 +1486,8 @@ int ukm_dev_place_merge(ukm_ctx *c, const u64 *const *keys, const u32 *const *ta
         fprintf(stderr, "[place] %-10s %8.3f ms\n", what, ms_since(t0));
         t0 = std::chrono::steady_clock::now();
     };
-    // 1. the distinct codes: at most a sixteenth of the records, or the runs are too short for this path
-    const u64 cap0 = mode >= 1 ? N : N / 16 + 1024;
+    // 1. the distinct codes: at most an eighth of the records, or the runs are too short for this path
+    const u64 cap0 = mode >= 1 ? N : N / 8 + 1024;
     u64 *base = nullptr;
     UKM_TRY(ws_alloc_t(c, cap0 + 1, &base));
     u64 n0 = 0;
@@ -1501,6 +1501,15 @@ int ukm_dev_place_merge(ukm_ctx *c, const u64 *const *keys, const u32 *const *ta
         if (fb || n0 == 0) return UKM_OK;
     }
     lap("union");
+    if (mode < 1 && S <= 1024) {
+        // What a workgroup reads of one file for its 512 codes: 512 x (records per code) / files.  Short slices leave the
+        // pass to its per-slice work (three loads and, with TaxIds, a share of three barriers per batch): 1000 files x
+        // 1e6 with taxids, a fifth of a universe each (102 records per slice) 23.6 ms against the single pass's 26.3, a
+        // tenth each (51) 40.5 against 26.9; plain codes 17.6 against 19.1 there.  (More than 1024 files: the other
+        // routes end in the pairwise tree -- 3000 x 3e5: 19 ms here, 200 ms there.)
+        const double per_slice = (double)PL_RANGE * ((double)N / (double)n0) / (double)S;
+        if (per_slice < (tax ? 96.0 : 40.0)) return UKM_OK;
+    }
     // 2. cut points of every file at the ranges' first codes
     const u32 range = (u32)PL_RANGE;
     const u64 R64 = (n0 + range - 1) / range;
