@@ -1068,7 +1068,7 @@ __global__ __launch_bounds__(PL_NT) void pl_merge_kernel(PuArgs a) {
         // a line share the request.  (One thread writing its code's records -- codes and TaxIds -- one after the other
         // was 32 requests per code and batch: 10.4 of the kernel's 14.2 ms were those stores, at 1.2 TB/s.)
         constexpr u32 LPC = PL_BATCH / 2, CPW = 64 / LPC;  // lanes per code, codes per wave and step
-        static_assert(PL_BATCH == 8 || PL_BATCH == 16 || PL_BATCH == 32, "two records per lane");
+        static_assert(PL_BATCH == 4 || PL_BATCH == 8 || PL_BATCH == 16 || PL_BATCH == 32, "two records per lane");
         for (u32 c0 = (u32)wave * CPW; c0 < (u32)PL_RANGE; c0 += (PL_NT / 64) * CPW) {
             const u32 i = c0 + (u32)lane / LPC, part = (u32)lane % LPC;
             const u32 n = s_n[i], q0 = 2u * part;
