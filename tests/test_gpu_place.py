@@ -1,6 +1,6 @@
 """The keep-everything merge of many files that share their codes, by PLACEMENT (csrc/ukm_punion.hip, pl_merge_kernel;
 `merge` = mergeChunksFile's heap, util-sort.go:196-225,289-351): the distinct codes from the probe union, a count per code
-from one probe pass, every code's run written in one piece, the TaxIds placed sixteen files at a time -- against a stable
+from one probe pass, every code's run written in one piece, the TaxIds placed eight files at a time -- against a stable
 sort of the concatenation (= the heap's order: equal codes in file order) and the oracle's modes.
 
 UKM_PLACE=1 / UKM_PUNION=1 force the routes at test sizes (the library takes them from 96 files and 2^26 records on when a
@@ -52,7 +52,7 @@ def _stable(streams, taxs=None):
 @pytest.mark.parametrize("n_univ,nfiles,p", [(3000, 40, 0.7), (20000, 100, 0.5), (1500, 300, 0.8), (50000, 33, 0.6), (700, 17, 0.9),
                                               (2000, 1500, 0.6)])
 def test_placement_merge_equals_the_stable_sort(env, monkeypatch, n_univ, nfiles, p):
-    """plain and with taxids; one range and many; 17 and 33 files (one record past a batch of sixteen); 1500 files (more than
+    """plain and with taxids; one range and many; 17 and 33 files (one file past a batch); 1500 files (more than
     the single-pass merge takes); the -u / -d scans behind the merged sequence"""
     O, L, ctx, tax, T = env
     monkeypatch.setenv("UKM_PLACE", "1")

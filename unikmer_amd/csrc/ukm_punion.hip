@@ -840,19 +840,21 @@ __global__ __launch_bounds__(PT_NT) __attribute__((amdgpu_waves_per_eu(PT_WAVES,
 // util-sort.go:196-225,289-351, when a code is in hundreds of the files) --------------------------------------------------
 // The merged sequence is, code by code, the records of that code in file order.  With the sorted distinct codes (BASE, the
 // plain probe union above) cut into ranges of PL_RANGE, one workgroup per range
-//   A. counts the records of every code of its range (one hash probe per record, as in the counting pass) and scans the
-//      counts: where every code's run begins -- the range's own beginning is the sum of its cut points;
-//   B. goes through the files in ORDER, PL_BATCH at a time: the batch's records are probed again and their TaxIds put
-//      into an LDS cell [code][file of the batch]; then every code's records of the batch -- they are neighbours in the
-//      result -- are written in one piece behind what the earlier batches wrote (up to 128 + 64 contiguous bytes).
-// Every record is read twice and written once; no sorting, no merge rounds.  Files must be strictly increasing (a code
+//   A. streams its slice of every file once: the file's order is checked, every record's code is looked up (one hash
+//      probe), counted, and the code's INDEX in the range (2 bytes) is kept in a scratch array; a scan of the counts says
+//      where every code's run begins -- the range's own beginning is the sum of its cut points;
+//   B. writes every code's run of CODES in one piece (a wave per code): plain codes are done here;
+//   C. goes through the files in ORDER, PL_BATCH at a time: index and TaxId of the batch's records set a bit and a TaxId
+//      cell [code][file of the batch] in LDS; then every code's TaxIds of the batch -- neighbours in the result -- are
+//      written in one piece behind what the earlier batches wrote.
+// Codes are read once, TaxIds once, 2 bytes per record go to scratch and back; no sorting, no merge rounds.  Files must be strictly increasing (a code
 // twice in one file would share a cell): a duplicate, an unsorted file or a code the tables do not know raise a flag and
 // the caller's merge answers.
 #ifndef PL_PER_N
 #define PL_PER_N 1
 #endif
 #ifndef PL_BATCH_N
-#define PL_BATCH_N 16
+#define PL_BATCH_N 8   /* 16: 9.4 / 10.4 / 16.9 ms for the kernel on 1000 files x 1e6 (90 / 50 / 20 % of a universe each), 8: 8.6 / 10.1 / 16.5, 4: 9.7 / 11.7 / 21.4, 32 (one workgroup per CU): 13.0 / 15.6 */
 #endif
 constexpr int PL_NT = 512;
 constexpr int PL_PER = PL_PER_N;             // codes per thread
@@ -1064,7 +1066,7 @@ __global__ __launch_bounds__(PL_NT) void pl_merge_kernel(PuArgs a) {
         }
         __syncthreads();
 #ifndef PL_ABL_NOWRITE
-        // The batch's TaxIds of a code are written by EIGHT lanes, two each: one or two cache lines, and the lanes that share
+        // The batch's TaxIds of a code are written by PL_BATCH / 2 lanes, two each: one or two cache lines, and the lanes that share
         // a line share the request.  (One thread writing its code's records -- codes and TaxIds -- one after the other
         // was 32 requests per code and batch: 10.4 of the kernel's 14.2 ms were those stores, at 1.2 TB/s.)
         constexpr u32 LPC = PL_BATCH / 2, CPW = 64 / LPC;  // lanes per code, codes per wave and step
