@@ -952,8 +952,11 @@ __global__ __launch_bounds__(PL_NT) void pl_merge_kernel(PuArgs a) {
 #pragma unroll
                 for (int w = 0; w < 2; w++) {
                     if (!(w ? v1 : v0)) continue;
-                    const int i = find(x[u][w]);
-                    if (i < 0) { flags |= PL_FLAG_UNKNOWN; continue; }
+                    int i = find(x[u][w]);
+                    if (i < 0) {  // (an unsorted file's cut points, an all-ones code: the result is dropped, but every index
+                        flags |= PL_FLAG_UNKNOWN;  //  the second pass reads has to be one of the range's)
+                        i = 0;
+                    }
                     atomicAdd(&s_cnt[i], 1u);
                     ri[pos + (u64)w] = (unsigned short)i;
                 }
@@ -1025,6 +1028,7 @@ __global__ __launch_bounds__(PL_NT) void pl_merge_kernel(PuArgs a) {
                 const u64 pos = p0 + (u64)u * 64 + (u32)lane;
                 const u64 q = pos < end ? pos : beg;
                 i[u] = ri[q];
+                i[u] = i[u] < (u32)PL_RANGE ? i[u] : 0u;
                 t[u] = (TAX && tp) ? tp[q] : 0u;
             }
 #pragma unroll
