@@ -928,10 +928,11 @@ __global__ __launch_bounds__(PL_NT) void pl_merge_kernel(PuArgs a) {
     // A. one slice of one file, 256 records per step: the file's order is checked, every record's code is looked up, counted
     // and its index kept for the second pass (2 bytes per record instead of the code, and no second look-up)
     auto count_slice = [&](u32 j) {
-        const u64 beg = a.cuts[(u64)r * S1 + j], end0 = a.cuts[(u64)(r + 1) * S1 + j], len = a.lens[j];
+        // (everything about a slice is wave-uniform: scalar loads)
+        const u64 beg = sload_u64(&a.cuts[(u64)r * S1 + j]), end0 = sload_u64(&a.cuts[(u64)(r + 1) * S1 + j]), len = sload_u64(&a.lens[j]);
         const u64 end = end0 < beg ? beg : end0;
-        const auto f = as_global(a.files[j]);
-        unsigned short *ri = a.rec_idx + a.rec_off[j];
+        const auto f = as_global((const u64 *)(uintptr_t)sload_u64((const u64 *)&a.files[j]));
+        unsigned short *ri = a.rec_idx + sload_u64(&a.rec_off[j]);
         for (u64 p0 = beg; p0 < end; p0 += 256) {
             u64 x[2][2], nx[2];
 #pragma unroll
@@ -1017,10 +1018,10 @@ __global__ __launch_bounds__(PL_NT) void pl_merge_kernel(PuArgs a) {
     // written by the thread that read it, at the place the complete words give it, was measured at 20.6 - 24.7 ms
     // against 14.3: 64 lanes storing 8 bytes into 64 different lines.)
     auto place_slice = [&](u32 j, u32 fj) {
-        const u64 beg = a.cuts[(u64)r * S1 + j], end0 = a.cuts[(u64)(r + 1) * S1 + j];
+        const u64 beg = sload_u64(&a.cuts[(u64)r * S1 + j]), end0 = sload_u64(&a.cuts[(u64)(r + 1) * S1 + j]);
         const u64 end = end0 < beg ? beg : end0;
-        const unsigned short *ri = a.rec_idx + a.rec_off[j];
-        const u32 *tp = TAX ? a.tfiles[j] : nullptr;
+        const unsigned short *ri = a.rec_idx + sload_u64(&a.rec_off[j]);
+        const u32 *tp = TAX ? (const u32 *)(uintptr_t)sload_u64((const u64 *)&a.tfiles[j]) : nullptr;
         for (u64 p0 = beg; p0 < end; p0 += 512) {
             u32 i[8], t[8];
 #pragma unroll
