@@ -1127,14 +1127,12 @@ int ukm_punion_tax_mode() {
     return atoi(e);
 }
 
-int ukm_dev_probe_union(ukm_ctx *c, const u64 *const *keys, const u32 *const *taxids, const u64 *lens, int S, bool tax, u64 *out,
-                        u32 *tout, u64 out_cap, u64 *n_out, bool *fallback) {
+// one attempt with a base set of k0 files; *low_hit: the later files share too little with it (the caller may try more files)
+static int probe_union_k0(ukm_ctx *c, const u64 *const *keys, const u32 *const *taxids, const u64 *lens, int S, bool tax, u64 *out,
+                          u32 *tout, u64 out_cap, u64 *n_out, bool *fallback, int k0, bool *low_hit, double *hit_rate) {
     *fallback = true;
     *n_out = 0;
-    // files of the base set: with TaxIds four (the base union pays an LCA per shared code: 8 files of config 3's shape
-    // took as long as a third of the probe pass; the codes the later files add are claimed in the tables anyway)
-    int k0 = tax ? PT_K0 : PU_K0;
-    if (getenv("UKM_PUNION_K0")) k0 = std::max(3, std::min(64, atoi(getenv("UKM_PUNION_K0"))));  // developer knob
+    *low_hit = false;
     if (S < k0 + 1) return UKM_OK;
     if (tax) {
         if (!tout) UKM_FAIL(UKM_ERR_INVALID, "union: taxids given but out_taxids is NULL");
@@ -1227,7 +1225,11 @@ int ukm_dev_probe_union(ukm_ctx *c, const u64 *const *keys, const u32 *const *ta
         miss_rate = 1.0 - (double)h[2] / (double)h[3];
         if (dbg) fprintf(stderr, "[punion] sample: %llu of %llu later records in the base set (n0 = %llu)\n",
                          (unsigned long long)h[2], (unsigned long long)h[3], (unsigned long long)n0);
-        if (mode != 2 && 1.0 - miss_rate < (tax ? PT_MIN_HIT : PU_MIN_HIT)) return UKM_OK;
+        *hit_rate = 1.0 - miss_rate;
+        if (mode != 2 && 1.0 - miss_rate < (tax ? PT_MIN_HIT : PU_MIN_HIT)) {
+            *low_hit = true;
+            return UKM_OK;
+        }
     }
     lap("sample");
     // (Plain files stay with the plain kernel down to the same hit rate: its tables claim new codes too -- 2048 per range,
@@ -1321,6 +1323,34 @@ int ukm_dev_probe_union(ukm_ctx *c, const u64 *const *keys, const u32 *const *ta
     return UKM_OK;
 }
 
+int ukm_dev_probe_union(ukm_ctx *c, const u64 *const *keys, const u32 *const *taxids, const u64 *lens, int S, bool tax, u64 *out,
+                        u32 *tout, u64 out_cap, u64 *n_out, bool *fallback) {
+    // files of the base set: eight, with TaxIds four (the base union pays an LCA per shared code: 8 files of config 3's
+    // shape took as long as a third of the probe pass; the codes the later files add are claimed in the tables anyway).
+    // When the later files share too little with it, ONE more attempt with four times as many files -- if the first
+    // sample promises enough: files that each hold a share p of a collection hit a base set of k of them with probability
+    // 1 - (1 - p)^k, so the next set is expected at 1 - (1 - hit)^4.  (1000 files x 1e6, a tenth / a twentieth of a
+    // collection each: with taxids 20.7 / 25.7 ms against 35.2 / 36.1 through the single-pass merge, plain 7.1 / 7.7 against
+    // 10.8 / 13.2; a fiftieth each would need 64 files with taxids -- their union with its LCAs alone is 15 ms -- and is
+    // left to the merges: 46.4 against 38.3.)
+    int k0 = tax ? PT_K0 : PU_K0;
+    if (getenv("UKM_PUNION_K0")) k0 = std::max(3, std::min(64, atoi(getenv("UKM_PUNION_K0"))));  // developer knob
+    for (int attempt = 0; attempt < 2; attempt++) {
+        bool low_hit = false;
+        double hit = 0.0;
+        WsMark m = ws_mark(c);
+        const int rc = probe_union_k0(c, keys, taxids, lens, S, tax, out, tout, out_cap, n_out, fallback, k0, &low_hit, &hit);
+        if (rc != UKM_OK || !*fallback || !low_hit) return rc;
+        ws_release(c, m);
+        const double miss4 = (1.0 - hit) * (1.0 - hit) * (1.0 - hit) * (1.0 - hit);
+        k0 *= 4;
+        if (1.0 - miss4 < (tax ? PT_MIN_HIT : PU_MIN_HIT) || k0 > S / 4) break;
+    }
+    *fallback = true;
+    *n_out = 0;
+    return UKM_OK;
+}
+
 // `common` with a threshold below the number of files by the counting tables of pt_probe_kernel<true>.  first_once: keys[0]
 // is the first file as a sorted, duplicate-free set (ukm_common makes it one: every code of the first file counts once,
 // common.go:232,244); every record of every other file counts (common.go:262-266).  !first_once: every record of every
@@ -1390,27 +1420,35 @@ int ukm_dev_probe_common(ukm_ctx *c, const u64 *const *keys, const u32 *const *t
         double rate = 0.0;
         if (first_once) UKM_TRY(hit_rate(&rate));
         if (!first_once || (mode != 2 && rate < PT_MIN_HIT)) {
-            const int k0 = std::min(S, PT_K0);
-            u64 cap0 = 0;
-            for (int j = 0; j < k0; j++) cap0 += lens[j];
-            u64 *base = nullptr;
-            u32 *base_tax = nullptr;
-            UKM_TRY(ws_alloc_t(c, cap0 + 1, &base));
-            if (tax) UKM_TRY(ws_alloc_t(c, cap0 + 1, &base_tax));
-            bool fb = false;
-            UKM_TRY(ukm_dev_kway(c, UKM_KWAY_UNION, keys, tax ? taxids : nullptr, lens, k0, tax, base, base_tax, cap0, &n0, &fb));
-            if (fb || n0 == 0) return UKM_OK;
-            first = 0;
-            a.base = base;
-            a.base_tax = base_tax;
-            a.n0 = n0;
-            a.count0 = 0;
-            a.files = (const u64 *const *)d_tab;
-            a.lens = d_tab + S;
-            a.tfiles = (const u32 *const *)(d_tab + 2 * (size_t)S);
-            a.S1 = (u32)S;
-            UKM_TRY(hit_rate(&rate));
-            if (mode != 2 && rate < PT_MIN_HIT) return UKM_OK;
+            // (four files, or -- when their sample promises enough, see ukm_dev_probe_union -- sixteen)
+            int k0 = std::min(S, PT_K0);
+            for (int attempt = 0;; attempt++) {
+                u64 cap0 = 0;
+                for (int j = 0; j < k0; j++) cap0 += lens[j];
+                u64 *base = nullptr;
+                u32 *base_tax = nullptr;
+                WsMark bm = ws_mark(c);
+                UKM_TRY(ws_alloc_t(c, cap0 + 1, &base));
+                if (tax) UKM_TRY(ws_alloc_t(c, cap0 + 1, &base_tax));
+                bool fb = false;
+                UKM_TRY(ukm_dev_kway(c, UKM_KWAY_UNION, keys, tax ? taxids : nullptr, lens, k0, tax, base, base_tax, cap0, &n0, &fb));
+                if (fb || n0 == 0) return UKM_OK;
+                first = 0;
+                a.base = base;
+                a.base_tax = base_tax;
+                a.n0 = n0;
+                a.count0 = 0;
+                a.files = (const u64 *const *)d_tab;
+                a.lens = d_tab + S;
+                a.tfiles = (const u32 *const *)(d_tab + 2 * (size_t)S);
+                a.S1 = (u32)S;
+                UKM_TRY(hit_rate(&rate));
+                if (mode == 2 || rate >= PT_MIN_HIT) break;
+                const double miss4 = (1.0 - rate) * (1.0 - rate) * (1.0 - rate) * (1.0 - rate);
+                if (attempt > 0 || 1.0 - miss4 < PT_MIN_HIT || 4 * k0 > S / 4) return UKM_OK;
+                ws_release(c, bm);
+                k0 *= 4;
+            }
         }
     }
     const int S1 = (int)a.S1;
