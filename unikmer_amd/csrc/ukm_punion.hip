@@ -836,6 +836,35 @@ __global__ __launch_bounds__(PT_NT) __attribute__((amdgpu_waves_per_eu(PT_WAVES,
     }
 }
 
+// Do the files share codes at all?  Records drawn from random files are looked up in ONE other random file each: the
+// share that is found estimates how much of a collection a file holds.  (The chunk files of an out-of-core sort share
+// nothing: without this look the placement merge below would build a base set and sample it before it declines.)
+__global__ void pu_overlap_kernel(PuArgs a, u32 nsamp) {
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    bool tested = false, hit = false;
+    if (i < nsamp && a.S1 >= 2) {
+        const u64 h = pu_splitmix(i);
+        const u32 fa = (u32)(h % a.S1), fb = (fa + 1 + (u32)((h >> 20) % (a.S1 - 1))) % a.S1;
+        const u64 la = a.lens[fa], lb = a.lens[fb];
+        if (la && lb) {
+            const u64 key = as_global(a.files[fa])[pu_splitmix(h) % la];
+            const auto f = as_global(a.files[fb]);
+            u64 lo = 0, hi = lb;
+            while (lo < hi) {
+                const u64 mid = (lo + hi) >> 1;
+                if (f[mid] < key) lo = mid + 1; else hi = mid;
+            }
+            tested = true;
+            hit = lo < lb && f[lo] == key;
+        }
+    }
+    const u64 mh = __ballot(hit), mt = __ballot(tested);
+    if (lane_id() == 0 && mt) {
+        atomicAdd((unsigned long long *)&a.ctl[2], (unsigned long long)__popcll(mh));
+        atomicAdd((unsigned long long *)&a.ctl[3], (unsigned long long)__popcll(mt));
+    }
+}
+
 // ---- keep-everything merge of MANY files that share most of their codes, by placement (`merge` / mergeChunksFile's heap,
 // util-sort.go:196-225,289-351, when a code is in hundreds of the files) --------------------------------------------------
 // The merged sequence is, code by code, the records of that code in file order.  With the sorted distinct codes (BASE, the
@@ -1531,6 +1560,44 @@ int ukm_dev_place_merge(ukm_ctx *c, const u64 *const *keys, const u32 *const *ta
         fprintf(stderr, "[place] %-10s %8.3f ms\n", what, ms_since(t0));
         t0 = std::chrono::steady_clock::now();
     };
+    // 0. device tables of the files: [pointers S][lens S][TaxId pointers S][offsets of the files' records S]
+    std::vector<u64> tab((size_t)4 * S);
+    u64 off = 0;
+    for (int j = 0; j < S; j++) {
+        tab[(size_t)j] = (u64)(uintptr_t)keys[j];
+        tab[(size_t)S + j] = lens[j];
+        tab[(size_t)2 * S + j] = (u64)(uintptr_t)((tax && taxids) ? taxids[j] : nullptr);
+        tab[(size_t)3 * S + j] = off;
+        off += lens[j];
+    }
+    u64 *d_tab = nullptr, *ctl = nullptr;
+    UKM_TRY(ws_alloc_t(c, tab.size(), &d_tab));
+    UKM_TRY(ws_alloc_t(c, 8, &ctl));
+    UKM_HIP(hipMemcpyAsync(d_tab, tab.data(), tab.size() * sizeof(u64), hipMemcpyHostToDevice, c->stream));
+    UKM_HIP(hipMemsetAsync(ctl, 0, 8 * sizeof(u64), c->stream));
+    UKM_HIP(hipStreamSynchronize(c->stream));  // `tab` is a pageable host buffer of this frame
+    PuArgs a;
+    memset(&a, 0, sizeof(a));
+    a.files = (const u64 *const *)d_tab;
+    a.lens = d_tab + S;
+    a.tfiles = (const u32 *const *)(d_tab + 2 * (size_t)S);
+    a.rec_off = d_tab + 3 * (size_t)S;
+    a.S1 = (u32)S;
+    a.ctl = ctl;
+    if (mode < 1) {
+        // files that share (next to) nothing -- the chunks of an out-of-core sort -- are not for this path: one small kernel
+        // says so before a base set is built
+        const u32 nsamp = 1u << 14;
+        hipLaunchKernelGGL(pu_overlap_kernel, dim3(nsamp / 256), dim3(256), 0, c->stream, a, nsamp);
+        UKM_HIP(hipGetLastError());
+        u64 h[4] = {0, 0, 0, 0};
+        UKM_TRY(ukm_read_u64(c, ctl, h, 4));
+        if (dbg) fprintf(stderr, "[place] overlap sample: %llu of %llu records found in another file\n", (unsigned long long)h[2],
+                         (unsigned long long)h[3]);
+        if (h[3] == 0 || (double)h[2] < 0.05 * (double)h[3]) return UKM_OK;
+        UKM_HIP(hipMemsetAsync(ctl, 0, 8 * sizeof(u64), c->stream));
+    }
+    lap("overlap");
     // 1. the distinct codes: at most an eighth of the records, or the runs are too short for this path
     const u64 cap0 = mode >= 1 ? N : N / 8 + 1024;
     u64 *base = nullptr;
@@ -1559,27 +1626,6 @@ int ukm_dev_place_merge(ukm_ctx *c, const u64 *const *keys, const u32 *const *ta
     const u32 range = (u32)PL_RANGE;
     const u64 R64 = (n0 + range - 1) / range;
     if (R64 > 0x7FFFFFFEull) return UKM_OK;
-    std::vector<u64> tab((size_t)4 * S);
-    u64 off = 0;
-    for (int j = 0; j < S; j++) {
-        tab[(size_t)j] = (u64)(uintptr_t)keys[j];
-        tab[(size_t)S + j] = lens[j];
-        tab[(size_t)2 * S + j] = (u64)(uintptr_t)((tax && taxids) ? taxids[j] : nullptr);
-        tab[(size_t)3 * S + j] = off;
-        off += lens[j];
-    }
-    u64 *d_tab = nullptr, *ctl = nullptr;
-    UKM_TRY(ws_alloc_t(c, tab.size(), &d_tab));
-    UKM_TRY(ws_alloc_t(c, 8, &ctl));
-    UKM_HIP(hipMemcpyAsync(d_tab, tab.data(), tab.size() * sizeof(u64), hipMemcpyHostToDevice, c->stream));
-    UKM_HIP(hipMemsetAsync(ctl, 0, 8 * sizeof(u64), c->stream));
-    UKM_HIP(hipStreamSynchronize(c->stream));  // `tab` is a pageable host buffer of this frame
-    PuArgs a;
-    memset(&a, 0, sizeof(a));
-    a.files = (const u64 *const *)d_tab;
-    a.lens = d_tab + S;
-    a.tfiles = (const u32 *const *)(d_tab + 2 * (size_t)S);
-    a.rec_off = d_tab + 3 * (size_t)S;
     UKM_TRY(ws_alloc_t(c, N + 8, &a.rec_idx));
     a.S1 = (u32)S;
     a.base = base;
