@@ -1156,6 +1156,37 @@ int ukm_punion_tax_mode() {
     return atoi(e);
 }
 
+// the share of sampled records that are found in another file (pu_overlap_kernel); the workspace it takes is given back
+static int pu_overlap_share(ukm_ctx *c, const u64 *const *keys, const u64 *lens, int S, double *share) {
+    *share = 0.0;
+    WsMark m = ws_mark(c);
+    std::vector<u64> tab((size_t)2 * S);
+    for (int j = 0; j < S; j++) {
+        tab[(size_t)j] = (u64)(uintptr_t)keys[j];
+        tab[(size_t)S + j] = lens[j];
+    }
+    u64 *d_tab = nullptr, *ctl = nullptr;
+    UKM_TRY(ws_alloc_t(c, tab.size(), &d_tab));
+    UKM_TRY(ws_alloc_t(c, 8, &ctl));
+    UKM_HIP(hipMemcpyAsync(d_tab, tab.data(), tab.size() * sizeof(u64), hipMemcpyHostToDevice, c->stream));
+    UKM_HIP(hipMemsetAsync(ctl, 0, 8 * sizeof(u64), c->stream));
+    UKM_HIP(hipStreamSynchronize(c->stream));  // `tab` is a pageable host buffer of this frame
+    PuArgs a;
+    memset(&a, 0, sizeof(a));
+    a.files = (const u64 *const *)d_tab;
+    a.lens = d_tab + S;
+    a.S1 = (u32)S;
+    a.ctl = ctl;
+    const u32 nsamp = 1u << 14;
+    hipLaunchKernelGGL(pu_overlap_kernel, dim3(nsamp / 256), dim3(256), 0, c->stream, a, nsamp);
+    UKM_HIP(hipGetLastError());
+    u64 h[4] = {0, 0, 0, 0};
+    UKM_TRY(ukm_read_u64(c, ctl, h, 4));
+    ws_release(c, m);
+    if (h[3]) *share = (double)h[2] / (double)h[3];
+    return UKM_OK;
+}
+
 // one attempt with a base set of k0 files; *low_hit: the later files share too little with it (the caller may try more files)
 static int probe_union_k0(ukm_ctx *c, const u64 *const *keys, const u32 *const *taxids, const u64 *lens, int S, bool tax, u64 *out,
                           u32 *tout, u64 out_cap, u64 *n_out, bool *fallback, int k0, bool *low_hit, double *hit_rate) {
@@ -1364,6 +1395,15 @@ int ukm_dev_probe_union(ukm_ctx *c, const u64 *const *keys, const u32 *const *ta
     // left to the merges: 46.4 against 38.3.)
     int k0 = tax ? PT_K0 : PU_K0;
     if (getenv("UKM_PUNION_K0")) k0 = std::max(3, std::min(64, atoi(getenv("UKM_PUNION_K0"))));  // developer knob
+    *fallback = true;
+    *n_out = 0;
+    if (ukm_punion_mode() < 1 && S >= 2) {
+        // files that share next to nothing (a record of one is in another with less than 3 % probability: even 32 of them
+        // would cover too little): one small kernel says so before a base set is built
+        double share = 0.0;
+        UKM_TRY(pu_overlap_share(c, keys, lens, S, &share));
+        if (share < 0.03) return UKM_OK;
+    }
     for (int attempt = 0; attempt < 2; attempt++) {
         bool low_hit = false;
         double hit = 0.0;
@@ -1401,6 +1441,11 @@ int ukm_dev_probe_common(ukm_ctx *c, const u64 *const *keys, const u32 *const *t
         if (c->tax_euler == nullptr || c->tax_node_at == nullptr) return UKM_OK;
     }
     const bool dbg = getenv("UKM_PUNION_DEBUG") != nullptr;
+    if (mode < 1) {
+        double share = 0.0;
+        UKM_TRY(pu_overlap_share(c, keys, lens, S, &share));
+        if (share < 0.03) return UKM_OK;  // (files that share next to nothing: see ukm_dev_probe_union)
+    }
     // device tables of ALL files: [pointers S][lens S][TaxId pointers S]
     std::vector<u64> tab((size_t)3 * S);
     for (int j = 0; j < S; j++) {
