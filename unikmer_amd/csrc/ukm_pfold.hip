@@ -275,7 +275,10 @@ void pf_probe_kernel(PfArgs a) {
                     // record that is in every file has one hit from each of them in its counter by now, so a counter
                     // that is not above that number belongs to a record some finished file did not have — dead
                     const u32 finished = __hip_atomic_load(&s_done, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    need = ((atomicAdd(&s_cnt[li[q]], 1u) + 1) & PF_CNT_MASK) > finished && lt[q] != s_tax[li[q]];
+                    // (a record that is already behind -- most hits in a collection's non-core codes are on such records --
+                    //  needs no count any more: a plain read instead of an atomic with a return value)
+                    if ((s_cnt[li[q]] & PF_CNT_MASK) >= finished)
+                        need = ((atomicAdd(&s_cnt[li[q]], 1u) + 1) & PF_CNT_MASK) > finished && lt[q] != s_tax[li[q]];
                 }
                 if (!need) li[q] = -1;
                 en[q] = a.T.euler[(need && lt[q] < a.T.size) ? lt[q] : 0u];  // (all of the step's table reads in flight; euler[0] = 0)
