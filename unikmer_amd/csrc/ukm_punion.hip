@@ -612,9 +612,6 @@ __global__ __launch_bounds__(PT_NT) __attribute__((amdgpu_waves_per_eu(PT_WAVES,
 #ifndef PT_U
 #define PT_U 1     /* 16-byte loads per lane and step (2: 31.0 ms on config 3's shape at half size with one taxid per file, 1: 29.5; without the pipeline 2: 33.6, 4: 31.9; one stage deeper 1: 29.9, 2: 34.2) */
 #endif
-#ifndef PT_PIPE
-#define PT_PIPE 1  /* experiments: 0 = loads, look-ups and probes of a step one after the other */
-#endif
     constexpr int U = PT_U;
     struct Desc { u64 f, tf, p0, end, len; bool valid; };  // wave-uniform
     struct RegA { pu_pair pr[U]; pt_tpair tp[U]; u64 nx[U]; };
@@ -731,35 +728,6 @@ __global__ __launch_bounds__(PT_NT) __attribute__((amdgpu_waves_per_eu(PT_WAVES,
             pos = cur.beg;
         }
     };
-#if !PT_PIPE
-    for (Desc d = next_desc(); d.valid; d = next_desc()) {
-        RegA ra;
-        RegB rb;
-        issue_a(d, ra);
-        issue_b(d, ra, rb);
-        process(d, ra, rb);
-    }
-#elif PT_PIPE == 2
-    {   // one stage deeper: loads three steps ahead, look-ups two
-        Desc d0 = next_desc(), d1 = next_desc(), d2 = next_desc();
-        RegA a0, a1, a2, a3;
-        RegB b0, b1, b2;
-        issue_a(d0, a0);
-        issue_a(d1, a1);
-        issue_a(d2, a2);
-        issue_b(d0, a0, b0);
-        issue_b(d1, a1, b1);
-        while (d0.valid) {
-            const Desc d3 = next_desc();
-            issue_a(d3, a3);
-            issue_b(d2, a2, b2);
-            process(d0, a0, b0);
-            d0 = d1; a0 = a1; b0 = b1;
-            d1 = d2; a1 = a2; b1 = b2;
-            d2 = d3; a2 = a3;
-        }
-    }
-#else
     {
         Desc d0 = next_desc(), d1 = next_desc();
         RegA a0, a1, a2;
@@ -776,7 +744,6 @@ __global__ __launch_bounds__(PT_NT) __attribute__((amdgpu_waves_per_eu(PT_WAVES,
             d1 = d2; a1 = a2;
         }
     }
-#endif
     close_chunk();
     if (bad) atomicOr((unsigned long long *)&a.ctl[1], (unsigned long long)PU_FLAG_UNSORTED);
     if (bad_t) atomicOr((unsigned long long *)&a.ctl[1], (unsigned long long)PU_FLAG_TAXID);
@@ -1041,7 +1008,6 @@ __global__ __launch_bounds__(PL_NT) void pl_merge_kernel(PuArgs a) {
         return;
     }
     __syncthreads();  // (s_n is reused by the batches)
-#ifndef PL_ABL_NOB
     // B. the files in order, PL_BATCH at a time: index and TaxId of every record of the batch into its code's cells; then the
     // owner of a code writes the batch's records of that code -- neighbours in the result -- in one piece.  (Every record
     // written by the thread that read it, at the place the complete words give it, was measured at 20.6 - 24.7 ms
@@ -1071,11 +1037,7 @@ __global__ __launch_bounds__(PL_NT) void pl_merge_kernel(PuArgs a) {
         }
     };
     for (u32 bj = 0; bj < S1; bj += PL_BATCH) {
-#ifndef PL_ABL_NOREAD
         for (u32 fj = (u32)wave; fj < (u32)PL_BATCH && bj + fj < S1; fj += PL_NT / 64) place_slice(bj + fj, fj);
-#else
-        if (tid < (int)ne) s_mask[tid] = 0xFFFFu;
-#endif
         __syncthreads();
         // the owner of a code: the batch's TaxIds of the code side by side, its place, its count
 #pragma unroll
@@ -1099,7 +1061,6 @@ __global__ __launch_bounds__(PL_NT) void pl_merge_kernel(PuArgs a) {
             }
         }
         __syncthreads();
-#ifndef PL_ABL_NOWRITE
         // The batch's TaxIds of a code are written by PL_BATCH / 2 lanes, two each: one or two cache lines, and the lanes that share
         // a line share the request.  (One thread writing its code's records -- codes and TaxIds -- one after the other
         // was 32 requests per code and batch: 10.4 of the kernel's 14.2 ms were those stores, at 1.2 TB/s.)
@@ -1119,10 +1080,8 @@ __global__ __launch_bounds__(PL_NT) void pl_merge_kernel(PuArgs a) {
                 }
             }
         }
-#endif
         __syncthreads();
     }
-#endif
     if (flags) atomicOr((unsigned long long *)&a.ctl[1], (unsigned long long)flags);
 }
 
