@@ -206,6 +206,39 @@ int ukm_common(ukm_ctx *ctx, const uint64_t *const *keys, const uint32_t *const 
                uint64_t *out_keys, uint32_t *out_taxids, uint64_t out_cap, uint64_t *n_out);
 uint32_t ukm_common_threshold(uint32_t nfiles, double proportion, uint32_t number);
 
+/* ---- per-FILE taxids (round 5).  The reference's documented taxid workflow is ONE taxid per file: `unikmer count -t 511145`
+ *      (README.md:170) stores it in the .unik header (count.go:466-468 writer.SetGlobalTaxid) and unik.Reader.ReadCodeWithTaxid
+ *      then hands that value out with EVERY record, so union.go:187-201, inter.go:190,211-239, diff.go:404-409 and
+ *      common.go:262-266 fold it like a per-record taxid.  The _ft entry points take that value as a scalar instead of an
+ *      n-element array of copies:
+ *        file_taxids (host array [nstreams], or NULL) / a_file_taxid, b_file_taxid: the taxid of every record of a stream
+ *        whose per-record pointer (taxids[i] / a_taxids / b_taxids) is NULL; 0 = the stream has no taxid information (what
+ *        a NULL pointer alone means in the entry points above, which are these with file_taxids = NULL).
+ *      Results are identical to passing the expanded arrays.  What the device does instead: two streams with one taxid
+ *      each run the plain-key kernel and write one of three values (A's, B's, their LCA) per output record; `inter`,
+ *      `diff` (also -t: whether file j can take a matched code away is one decision per file) and `common` over all files
+ *      are the plain operation and a fill with one value worked out once; the hash-probe `union` / `common` below the number
+ *      of files / `merge -d` read no taxid and look no pre-order number up for such a file; the k-way merges get the array
+ *      built on the device.  Streams with per-record taxids and streams with one per file may be mixed freely. */
+int ukm_setop2_ft(ukm_ctx *ctx, int op, const uint64_t *a_keys, const uint32_t *a_taxids, uint32_t a_file_taxid,
+                  uint64_t na, const uint64_t *b_keys, const uint32_t *b_taxids, uint32_t b_file_taxid, uint64_t nb,
+                  uint32_t flags, uint64_t *out_keys, uint32_t *out_taxids, uint64_t out_cap, uint64_t *n_out);
+int ukm_union_ft(ukm_ctx *ctx, const uint64_t *const *keys, const uint32_t *const *taxids, const uint32_t *file_taxids,
+                 const uint64_t *lens, int nstreams, uint32_t flags, uint64_t *out_keys, uint32_t *out_taxids,
+                 uint64_t out_cap, uint64_t *n_out);
+int ukm_inter_ft(ukm_ctx *ctx, const uint64_t *const *keys, const uint32_t *const *taxids, const uint32_t *file_taxids,
+                 const uint64_t *lens, int nstreams, uint32_t flags, uint64_t *out_keys, uint32_t *out_taxids,
+                 uint64_t out_cap, uint64_t *n_out);
+int ukm_diff_ft(ukm_ctx *ctx, const uint64_t *const *keys, const uint32_t *const *taxids, const uint32_t *file_taxids,
+                const uint64_t *lens, int nstreams, const uint8_t *sorted_flags, uint32_t flags, uint64_t *out_keys,
+                uint32_t *out_taxids, uint64_t out_cap, uint64_t *n_out);
+int ukm_common_ft(ukm_ctx *ctx, const uint64_t *const *keys, const uint32_t *const *taxids, const uint32_t *file_taxids,
+                  const uint64_t *lens, int nstreams, uint32_t threshold, uint32_t flags, uint64_t *out_keys,
+                  uint32_t *out_taxids, uint64_t out_cap, uint64_t *n_out);
+int ukm_merge_k_ft(ukm_ctx *ctx, const uint64_t *const *keys, const uint32_t *const *taxids, const uint32_t *file_taxids,
+                   const uint64_t *lens, int nstreams, int mode, int final_round, uint64_t *out_keys,
+                   uint32_t *out_taxids, uint64_t out_cap, uint64_t *n_out);
+
 /* ---- multi-GPU helper: split points of a sorted stream for prefix sharding (SURVEY.md
  *      §8(e)): cuts[g] = lower_bound(keys, splitters[g]) for g in [0, n_split). */
 int ukm_partition_points(ukm_ctx *ctx, const uint64_t *keys, uint64_t n,

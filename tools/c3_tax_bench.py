@@ -1,6 +1,7 @@
 """config 3's shape (files that are random halves of one universe) WITH taxids: call ms of `union`.
-usage: python tools/c3_tax_bench.py [NFILES=100] [PER_FILE=5e7] [file|random|none] [reps=3]
-file = every record of a file carries that file's taxid (k-mers of one genome: `count -t`), random = uniformly random"""
+usage: python tools/c3_tax_bench.py [NFILES=100] [PER_FILE=5e7] [file|scalar|random|none] [reps=3]
+file = every record of a file carries that file's taxid (k-mers of one genome: `count -t`) as an ARRAY of copies, scalar = the
+same taxids handed over as ONE number per file (ukm_union_ft; the checksums of the two must agree), random = uniformly random"""
 import os, sys, time, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tools")); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -27,6 +28,8 @@ for f in range(nfiles):
     files.append(k)
     if kind == "file":
         taxs.append(torch.full((k.numel(),), leaves + (f * 7919) % (8 ** 7), dtype=torch.int32, device=dev))
+    elif kind == "scalar":
+        taxs.append(int(leaves + (f * 7919) % (8 ** 7)))
     elif kind == "random":
         taxs.append((1 + (bench.splitmix64_torch(k ^ bench._i64(bench.SEED + 2 + f)) & ((1 << 40) - 1)) % T).to(torch.int32))
 del j, U, h

@@ -97,6 +97,24 @@ def main():
                 tk, _ = best(f, kernel=True)
                 byt = 12 * (na + nb) + 12 * r[0]
                 res[name + ":" + sname] = {"kernel_ms": tk, "GBps_kernel": byt / tk / 1e6, "kmers_per_s": (na + nb) / tk * 1e3}
+        # round 5: the same files with their ONE taxid handed over as a scalar (ukm_setop2_ft); algorithmic bytes: 8 B per
+        # input record, 12 per output record
+        fa, fb = int(leaves + 5), int(leaves + 77)
+        for name, op, fl in (("union_tax", lib.OP_UNION, 0), ("inter_tax", lib.OP_INTER, 0), ("diff_tax", lib.OP_DIFF, 0), ("diff_t_tax", lib.OP_DIFF, lib.F_CMP_TAXID)):
+            def f():
+                r[0] = ctx.setop2(op, A, B, fa, fb, flags=fl, out=out, out_taxids=outt)[0].numel()
+            f()
+            tk, _ = best(f, kernel=True)
+            tc, _ = best(f)
+            byt = 8 * (na + nb) + 12 * r[0]
+            res[name + ":file_taxid_scalar"] = {"kernel_ms": tk, "call_ms": tc, "GBps_kernel": byt / tk / 1e6, "kmers_per_s": (na + nb) / tk * 1e3}
+        for name, op in (("union_tax", lib.OP_UNION), ("inter_tax", lib.OP_INTER)):
+            def f():
+                r[0] = ctx.setop2(op, A, B, ta, fb, out=out, out_taxids=outt)[0].numel()
+            f()
+            tk, _ = best(f, kernel=True)
+            byt = 12 * na + 8 * nb + 12 * r[0]
+            res[name + ":per_record_x_file_taxid"] = {"kernel_ms": tk, "GBps_kernel": byt / tk / 1e6, "kmers_per_s": (na + nb) / tk * 1e3}
     if "unique" in ops:
         cat = torch.cat([A, B])
         ctx.sort_u64(cat, 62)

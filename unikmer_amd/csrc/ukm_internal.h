@@ -203,8 +203,18 @@ void ukm_switch_to_tickets(ukm_ctx *c, const char *where);
 int ukm_dev_setop2(ukm_ctx *c, int op, const u64 *a, const u32 *ta, u64 na, const u64 *b,
                    const u32 *tb, u64 nb, u32 flags, u64 *out, u32 *tout, u64 out_cap,
                    u64 *n_out);
+// (cta, ctb): the taxid of every record of a stream whose per-record pointer is null -- the file's global taxid
+// (round 5; 0 = none).  Both constant: the plain-key kernel with a taxid epilogue.
+int ukm_dev_setop2_ct(ukm_ctx *c, int op, const u64 *a, const u32 *ta, u32 cta, u64 na, const u64 *b,
+                      const u32 *tb, u32 ctb, u64 nb, u32 flags, u64 *out, u32 *tout, u64 out_cap,
+                      u64 *n_out);
 int ukm_dev_setop2_link(ukm_ctx *c, int op, const u64 *a, const u32 *ta, u64 na_max, const u64 *na_dev, const u64 *b,
-                        const u32 *tb, u64 nb, u32 flags, u64 *out, u32 *tout, u64 out_cap, u64 *ctl);
+                        const u32 *tb, u64 nb, u32 flags, u64 *out, u32 *tout, u64 out_cap, u64 *ctl, u32 cta = 0, u32 ctb = 0);
+// fill n words with one value on the context's stream (file taxids; ukm_scan.hip)
+int ukm_dev_fill_u32(ukm_ctx *c, u32 *dst, u64 n, u32 value);
+// decisions over per-file taxids on the device (ukm_tax.hip): plan[0] = inter's left LCA fold, plan[2 + j] = diff -t keeps
+int ukm_dev_ct_plan(ukm_ctx *c, const u32 *ct_host, int n, bool mix, u32 **plan);
+int ukm_dev_fill_u32_from(ukm_ctx *c, u32 *dst, u64 n, u32 value, const u32 *value_dev);  // value_dev != null: the value is read there
 // flag bits of the set-op result word [1]
 enum { UKM_SETOP_FLAG_DUP = 1, UKM_SETOP_FLAG_UNSORTED = 2, UKM_SETOP_FLAG_TIMEOUT = 4 };
 int ukm_dev_sort(ukm_ctx *c, u64 *keys, u32 *vals, u64 n, int key_bits);

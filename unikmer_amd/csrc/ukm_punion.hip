@@ -74,6 +74,10 @@ struct PuArgs {
     const u64 *rec_off;       // [S1]: where file j's records begin in rec_idx
     u32 threshold;            // COUNT (`common`): a code leaves when at least this many records carried it
     u32 count0;               // COUNT: records a base entry starts with (1: the base set is the first file; 0: every file is probed)
+    // files with ONE taxid each (round 5; the .unik header's global taxid): tfiles[j] is null and cte[j] = taxid | its
+    // pre-order number << 32 (pu_cte_kernel) -- a slice of such a file loads no taxids and looks no number up
+    const u64 *cte;           // [S1], or null: files without per-record taxids have taxid 0
+    u32 base_ct;              // COUNT with the first file as the base set and no base_tax: its file taxid
     TaxDev tax;
 };
 
@@ -151,6 +155,15 @@ __global__ void pu_sample_kernel(PuArgs a, u32 nsamp, u32 nfiles_s) {
         atomicAdd((unsigned long long *)&a.ctl[2], (unsigned long long)__popcll(mh));
         atomicAdd((unsigned long long *)&a.ctl[3], (unsigned long long)__popcll(mt));
     }
+}
+
+// cte[j]: the file taxid in the low word (host) gets its pre-order number in the high word
+__global__ void pu_cte_kernel(u64 *cte, u32 n, TaxDev T) {
+    const u32 j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    const u32 t = (u32)cte[j];
+    const u32 e = T.euler ? T.euler[t < T.size ? t : 0u] : 0u;
+    cte[j] = (u64)t | ((u64)e << 32);
 }
 
 typedef u64 pu_u64x2 __attribute__((ext_vector_type(2)));
@@ -486,7 +499,7 @@ __global__ __launch_bounds__(PT_NT) __attribute__((amdgpu_waves_per_eu(PT_WAVES,
     for (int i = 0; i < PER; i++) {
         const u32 idx = (u32)tid + (u32)i * PT_NT;
         ent[i] = a.base[b0 + (idx < nb ? idx : 0)];
-        et[i] = a.base_tax ? a.base_tax[b0 + (idx < nb ? idx : 0)] : 0u;  // (plain codes: COUNT only)
+        et[i] = a.base_tax ? a.base_tax[b0 + (idx < nb ? idx : 0)] : a.base_ct;  // (no array: COUNT only -- plain codes, or the first file's one taxid)
         if (idx >= nb) ent[i] = PU_EMPTY;
         else bad_t |= et[i] == PT_UNSET;
     }
@@ -540,6 +553,12 @@ __global__ __launch_bounds__(PT_NT) __attribute__((amdgpu_waves_per_eu(PT_WAVES,
         if (lo | hi) {
             atomicMin(lo ? &s_st[slot].y : &s_st[slot].z, lo ? e : ~e);
             if (lo & hi) atomicMin(&s_st[slot].z, ~e);  // (an interval that is still empty: a new code a moment after its claim)
+            // The snapshot was taken between the claimer's CAS on x and its two minima (empty or half-written interval:
+            // smallest > largest): this record's number may be the CLAIMER'S -- the alias of a merged id, another unknown
+            // id -- and the interval would then never show that two different taxids met.  Say so; a flag too many only
+            // sends settle() through LCA(node_at[min], node_at[max]), which is always right.  (Base entries are written
+            // in front of the barrier and are never seen half-way.)
+            if (st.y > ~st.z && (st.w & 1u) == 0u) atomicOr(&s_st[slot].w, 1u);
         } else if (st.y == e && st.z == ~e && (st.w & 1u) == 0u) {
             atomicOr(&s_st[slot].w, 1u);
         }
@@ -613,7 +632,7 @@ __global__ __launch_bounds__(PT_NT) __attribute__((amdgpu_waves_per_eu(PT_WAVES,
 #define PT_U 1     /* 16-byte loads per lane and step (2: 31.0 ms on config 3's shape at half size with one taxid per file, 1: 29.5; without the pipeline 2: 33.6, 4: 31.9; one stage deeper 1: 29.9, 2: 34.2) */
 #endif
     constexpr int U = PT_U;
-    struct Desc { u64 f, tf, p0, end, len; bool valid; };  // wave-uniform
+    struct Desc { u64 f, tf, p0, end, len; u32 ct, ce; bool valid; };  // wave-uniform (ct, ce: the file's own taxid and its number when tf == 0)
     struct RegA { pu_pair pr[U]; pt_tpair tp[U]; u64 nx[U]; };
     struct RegB { u32 eu[U][2]; };
     auto issue_a = [&](const Desc &d, RegA &ra) {
@@ -628,7 +647,7 @@ __global__ __launch_bounds__(PT_NT) __attribute__((amdgpu_waves_per_eu(PT_WAVES,
             const u64 q2 = pos + 2 < d.len ? pos + 2 : d.len - 1;
             ra.pr[u] = *(const pu_pair __attribute__((address_space(1))) *)(f + q);
             ra.nx[u] = f[q2];
-            ra.tp[u] = pt_tpair{0u, 0u};
+            ra.tp[u] = pt_tpair{d.ct, d.ct};
             if (has_t) ra.tp[u] = *(const pt_tpair __attribute__((address_space(1))) *)(tf + q);  // (wave-uniform branch)
         }
     };
@@ -638,8 +657,8 @@ __global__ __launch_bounds__(PT_NT) __attribute__((amdgpu_waves_per_eu(PT_WAVES,
         for (int u = 0; u < U; u++) {
             const u32 ta = ra.tp[u].x, tb = ra.tp[u].y;
             bad_t |= ta == PT_UNSET || tb == PT_UNSET;
-            rb.eu[u][0] = rb.eu[u][1] = 0u;
-            if (d.tf != 0) {  // (wave-uniform; a file without TaxIds: all 0, and there may be no taxonomy at all)
+            rb.eu[u][0] = rb.eu[u][1] = d.ce;
+            if (d.tf != 0) {  // (wave-uniform; a file without per-record TaxIds: its own one's number -- 0 without any, and there may be no taxonomy at all)
                 rb.eu[u][0] = T.euler[ta < T.size ? ta : 0u];
                 rb.eu[u][1] = T.euler[tb < T.size ? tb : 0u];
             }
@@ -685,15 +704,16 @@ __global__ __launch_bounds__(PT_NT) __attribute__((amdgpu_waves_per_eu(PT_WAVES,
         if (lane == 0) j = atomicAdd(&s_next, 1u);
         return (u32)__builtin_amdgcn_readfirstlane((int)j);
     };
-    struct Meta { u64 beg, end, len, f, tf; };
+    struct Meta { u64 beg, end, len, f, tf, cte; };
     auto fetch = [&](u32 j) -> Meta {
-        Meta m = {0, 0, 0, 0, 0};
+        Meta m = {0, 0, 0, 0, 0, 0};
         if (j < S1) {
             m.beg = sload_u64(&a.cuts[(u64)r * S1 + j]);
             m.end = sload_u64(&a.cuts[(u64)(r + 1) * S1 + j]);
             m.len = sload_u64(&a.lens[j]);
             m.f = sload_u64((const u64 *)&a.files[j]);
             m.tf = sload_u64((const u64 *)&a.tfiles[j]);
+            if (a.cte) m.cte = sload_u64(&a.cte[j]);
         }
         return m;
     };
@@ -706,19 +726,20 @@ __global__ __launch_bounds__(PT_NT) __attribute__((amdgpu_waves_per_eu(PT_WAVES,
     u64 pos = cur.beg;
     auto next_desc = [&]() -> Desc {
         for (;;) {
-            if (j >= S1) return Desc{0, 0, 0, 0, 0, false};
+            if (j >= S1) return Desc{0, 0, 0, 0, 0, 0u, 0u, false};
             const u64 end = cur.end < cur.beg ? cur.beg : cur.end;
+            const u32 fct = cur.tf ? 0u : (u32)cur.cte, fce = cur.tf ? 0u : (u32)(cur.cte >> 32);
             if (cur.len >= 2 && pos < end) {
-                const Desc d = {cur.f, cur.tf, pos, end, cur.len, true};
+                const Desc d = {cur.f, cur.tf, pos, end, cur.len, fct, fce, true};
                 pos += (u64)U * 128;
                 return d;
             }
             if (cur.len < 2 && end > cur.beg) {  // a one-record file (no 16-byte load fits): done on the spot
                 const auto f = as_global((const u64 *)(uintptr_t)cur.f);
                 const u64 x = f[0];
-                const u32 t = cur.tf ? as_global((const u32 *)(uintptr_t)cur.tf)[0] : 0u;
+                const u32 t = cur.tf ? as_global((const u32 *)(uintptr_t)cur.tf)[0] : fct;
                 bad_t |= t == PT_UNSET;
-                const u32 e = cur.tf ? T.euler[t < T.size ? t : 0u] : 0u;
+                const u32 e = cur.tf ? T.euler[t < T.size ? t : 0u] : fce;
                 record(lane == 0, lane == 0 ? find_from(x, pt_hash(x)) : -1, x, t, e);
             }
             j = jn;
@@ -1147,8 +1168,9 @@ static int pu_overlap_share(ukm_ctx *c, const u64 *const *keys, const u64 *lens,
 }
 
 // one attempt with a base set of k0 files; *low_hit: the later files share too little with it (the caller may try more files)
+// ctax (may be null): the file taxid of a stream whose taxids[j] is null
 static int probe_union_k0(ukm_ctx *c, const u64 *const *keys, const u32 *const *taxids, const u64 *lens, int S, bool tax, u64 *out,
-                          u32 *tout, u64 out_cap, u64 *n_out, bool *fallback, int k0, bool *low_hit, double *hit_rate) {
+                          u32 *tout, u64 out_cap, u64 *n_out, bool *fallback, int k0, bool *low_hit, double *hit_rate, const u32 *ctax) {
     *fallback = true;
     *n_out = 0;
     *low_hit = false;
@@ -1164,6 +1186,7 @@ static int probe_union_k0(ukm_ctx *c, const u64 *const *keys, const u32 *const *
     std::vector<const u64 *> keys_v(keys, keys + S);
     std::vector<const u32 *> tax_v((size_t)S, nullptr);
     std::vector<u64> lens_v(lens, lens + S);
+    std::vector<u32> ct_v((size_t)S, 0u);
     if (tax && taxids) tax_v.assign(taxids, taxids + S);
     {
         std::vector<int> ord((size_t)S);
@@ -1177,11 +1200,23 @@ static int probe_union_k0(ukm_ctx *c, const u64 *const *keys, const u32 *const *
             keys_v[at] = keys[j];
             lens_v[at] = lens[j];
             if (tax && taxids) tax_v[at] = taxids[j];
+            if (tax && ctax && !(taxids && taxids[j])) ct_v[at] = ctax[j];
         }
     }
     keys = keys_v.data();
     lens = lens_v.data();
-    if (tax && taxids) taxids = tax_v.data();
+    if (tax && (taxids || ctax)) {
+        // the base files go through the k-way union, which reads a taxid per record: a base file with ONE taxid gets its array
+        for (int j = 0; j < k0; j++)
+            if (!tax_v[(size_t)j] && ct_v[(size_t)j] != 0 && lens[j]) {
+                u32 *t = nullptr;
+                UKM_TRY(ws_alloc_t(c, lens[j], &t));
+                UKM_TRY(ukm_dev_fill_u32(c, t, lens[j], ct_v[(size_t)j]));
+                tax_v[(size_t)j] = t;
+                ct_v[(size_t)j] = 0;
+            }
+        taxids = tax_v.data();
+    }
     u32 range = (u32)PU_RANGE;  // (with TaxIds: chosen below, when the base set's size is known)
     const int mode = ukm_punion_mode();
     const bool dbg = getenv("UKM_PUNION_DEBUG") != nullptr;
@@ -1206,13 +1241,16 @@ static int probe_union_k0(ukm_ctx *c, const u64 *const *keys, const u32 *const *
     if (fb || n0 == 0) return UKM_OK;
     lap("base");
 
-    // device tables of the later files: [pointers S1][lens S1][TaxId pointers S1]
+    // device tables of the later files: [pointers S1][lens S1][TaxId pointers S1][file taxid | its number << 32, S1]
     const int S1all = S - k0;
-    std::vector<u64> tab((size_t)3 * S1all);
+    std::vector<u64> tab((size_t)4 * S1all);
+    bool any_ct = false;
     for (int j = 0; j < S1all; j++) {
         tab[(size_t)j] = (u64)(uintptr_t)keys[k0 + j];
         tab[(size_t)S1all + j] = lens[k0 + j];
         tab[(size_t)2 * S1all + j] = (u64)(uintptr_t)((tax && taxids) ? taxids[k0 + j] : nullptr);
+        tab[(size_t)3 * S1all + j] = tax ? (u64)ct_v[(size_t)(k0 + j)] : 0ull;
+        any_ct = any_ct || tab[(size_t)3 * S1all + j] != 0;
     }
     u64 *d_tab = nullptr, *ctl = nullptr;
     UKM_TRY(ws_alloc_t(c, tab.size(), &d_tab));
@@ -1220,6 +1258,11 @@ static int probe_union_k0(ukm_ctx *c, const u64 *const *keys, const u32 *const *
     UKM_HIP(hipMemcpyAsync(d_tab, tab.data(), tab.size() * sizeof(u64), hipMemcpyHostToDevice, c->stream));
     UKM_HIP(hipMemsetAsync(ctl, 0, 8 * sizeof(u64), c->stream));
     UKM_HIP(hipStreamSynchronize(c->stream));  // `tab` is a pageable host buffer of this frame
+    if (any_ct) {
+        hipLaunchKernelGGL(pu_cte_kernel, dim3((unsigned)((S1all + 255) / 256)), dim3(256), 0, c->stream, d_tab + 3 * (size_t)S1all, (u32)S1all,
+                           ukm_taxdev(c));
+        UKM_HIP(hipGetLastError());
+    }
 
     PuArgs a;
     memset(&a, 0, sizeof(a));
@@ -1275,6 +1318,7 @@ static int probe_union_k0(ukm_ctx *c, const u64 *const *keys, const u32 *const *
         a.files = (const u64 *const *)(d_tab + s0);
         a.lens = d_tab + S1all + s0;
         a.tfiles = (const u32 *const *)(d_tab + 2 * (size_t)S1all + s0);
+        a.cte = any_ct ? d_tab + 3 * (size_t)S1all + s0 : nullptr;
         a.S1 = (u32)s1;
         WsMark mark = ws_mark(c);
         UKM_TRY(ws_alloc_t(c, ((size_t)a.R + 1) * s1, &a.cuts));
@@ -1343,7 +1387,7 @@ static int probe_union_k0(ukm_ctx *c, const u64 *const *keys, const u32 *const *
 }
 
 int ukm_dev_probe_union(ukm_ctx *c, const u64 *const *keys, const u32 *const *taxids, const u64 *lens, int S, bool tax, u64 *out,
-                        u32 *tout, u64 out_cap, u64 *n_out, bool *fallback) {
+                        u32 *tout, u64 out_cap, u64 *n_out, bool *fallback, const u32 *ctax) {
     // files of the base set: eight, with TaxIds four (the base union pays an LCA per shared code: 8 files of config 3's
     // shape took as long as a third of the probe pass; the codes the later files add are claimed in the tables anyway).
     // When the later files share too little with it, ONE more attempt with four times as many files -- if the first
@@ -1367,7 +1411,7 @@ int ukm_dev_probe_union(ukm_ctx *c, const u64 *const *keys, const u32 *const *ta
         bool low_hit = false;
         double hit = 0.0;
         WsMark m = ws_mark(c);
-        const int rc = probe_union_k0(c, keys, taxids, lens, S, tax, out, tout, out_cap, n_out, fallback, k0, &low_hit, &hit);
+        const int rc = probe_union_k0(c, keys, taxids, lens, S, tax, out, tout, out_cap, n_out, fallback, k0, &low_hit, &hit, ctax);
         if (rc != UKM_OK || !*fallback || !low_hit) return rc;
         ws_release(c, m);
         const double miss4 = (1.0 - hit) * (1.0 - hit) * (1.0 - hit) * (1.0 - hit);
@@ -1386,7 +1430,7 @@ int ukm_dev_probe_union(ukm_ctx *c, const u64 *const *keys, const u32 *const *ta
 // or small files, more than PU_MAXS of them, later files that share too little with the first, an unsorted file, a record
 // no table could count): nothing that matters was written and the caller's counting merge answers.
 int ukm_dev_probe_common(ukm_ctx *c, const u64 *const *keys, const u32 *const *taxids, const u64 *lens, int S, bool tax,
-                         u32 threshold, u64 *out, u32 *tout, u64 out_cap, u64 *n_out, bool *fallback, bool first_once) {
+                         u32 threshold, u64 *out, u32 *tout, u64 out_cap, u64 *n_out, bool *fallback, bool first_once, const u32 *ctax) {
     *fallback = true;
     *n_out = 0;
     const int mode = ukm_punion_mode();
@@ -1405,12 +1449,17 @@ int ukm_dev_probe_common(ukm_ctx *c, const u64 *const *keys, const u32 *const *t
         UKM_TRY(pu_overlap_share(c, keys, lens, S, &share));
         if (share < 0.03) return UKM_OK;  // (files that share next to nothing: see ukm_dev_probe_union)
     }
-    // device tables of ALL files: [pointers S][lens S][TaxId pointers S]
-    std::vector<u64> tab((size_t)3 * S);
+    // device tables of ALL files: [pointers S][lens S][TaxId pointers S][file taxid | its number << 32, S]
+    std::vector<u64> tab((size_t)4 * S);
+    std::vector<u32> ct_v((size_t)S, 0u);
+    bool any_ct = false;
     for (int j = 0; j < S; j++) {
         tab[(size_t)j] = (u64)(uintptr_t)keys[j];
         tab[(size_t)S + j] = lens[j];
         tab[(size_t)2 * S + j] = (u64)(uintptr_t)((tax && taxids) ? taxids[j] : nullptr);
+        if (tax && ctax && !(taxids && taxids[j])) ct_v[(size_t)j] = ctax[j];
+        tab[(size_t)3 * S + j] = (u64)ct_v[(size_t)j];
+        any_ct = any_ct || ct_v[(size_t)j] != 0;
     }
     u64 *d_tab = nullptr, *ctl = nullptr;
     UKM_TRY(ws_alloc_t(c, tab.size(), &d_tab));
@@ -1418,6 +1467,10 @@ int ukm_dev_probe_common(ukm_ctx *c, const u64 *const *keys, const u32 *const *t
     UKM_HIP(hipMemcpyAsync(d_tab, tab.data(), tab.size() * sizeof(u64), hipMemcpyHostToDevice, c->stream));
     UKM_HIP(hipMemsetAsync(ctl, 0, 8 * sizeof(u64), c->stream));
     UKM_HIP(hipStreamSynchronize(c->stream));  // `tab` is a pageable host buffer of this frame
+    if (any_ct) {
+        hipLaunchKernelGGL(pu_cte_kernel, dim3((unsigned)((S + 255) / 256)), dim3(256), 0, c->stream, d_tab + 3 * (size_t)S, (u32)S, ukm_taxdev(c));
+        UKM_HIP(hipGetLastError());
+    }
     PuArgs a;
     memset(&a, 0, sizeof(a));
     a.ctl = ctl;
@@ -1444,11 +1497,13 @@ int ukm_dev_probe_common(ukm_ctx *c, const u64 *const *keys, const u32 *const *t
     {
         a.base = keys[0];
         a.base_tax = (tax && taxids) ? const_cast<u32 *>(taxids[0]) : nullptr;  // (read only in this mode)
+        a.base_ct = ct_v[0];
         a.n0 = n0 = lens[0];
         a.count0 = 1;
         a.files = (const u64 *const *)(d_tab + 1);
         a.lens = d_tab + S + 1;
         a.tfiles = (const u32 *const *)(d_tab + 2 * (size_t)S + 1);
+        a.cte = any_ct ? d_tab + 3 * (size_t)S + 1 : nullptr;
         a.S1 = (u32)(S - 1);
         double rate = 0.0;
         if (first_once) UKM_TRY(hit_rate(&rate));
@@ -1464,16 +1519,29 @@ int ukm_dev_probe_common(ukm_ctx *c, const u64 *const *keys, const u32 *const *t
                 UKM_TRY(ws_alloc_t(c, cap0 + 1, &base));
                 if (tax) UKM_TRY(ws_alloc_t(c, cap0 + 1, &base_tax));
                 bool fb = false;
-                UKM_TRY(ukm_dev_kway(c, UKM_KWAY_UNION, keys, tax ? taxids : nullptr, lens, k0, tax, base, base_tax, cap0, &n0, &fb));
+                // (the k-way union reads a taxid per record: a base file with ONE taxid gets its array)
+                std::vector<const u32 *> bt((size_t)k0, nullptr);
+                for (int j = 0; j < k0 && tax; j++) {
+                    bt[(size_t)j] = taxids ? taxids[j] : nullptr;
+                    if (!bt[(size_t)j] && ct_v[(size_t)j] != 0 && lens[j]) {
+                        u32 *t = nullptr;
+                        UKM_TRY(ws_alloc_t(c, lens[j], &t));
+                        UKM_TRY(ukm_dev_fill_u32(c, t, lens[j], ct_v[(size_t)j]));
+                        bt[(size_t)j] = t;
+                    }
+                }
+                UKM_TRY(ukm_dev_kway(c, UKM_KWAY_UNION, keys, tax ? bt.data() : nullptr, lens, k0, tax, base, base_tax, cap0, &n0, &fb));
                 if (fb || n0 == 0) return UKM_OK;
                 first = 0;
                 a.base = base;
                 a.base_tax = base_tax;
+                a.base_ct = 0;
                 a.n0 = n0;
                 a.count0 = 0;
                 a.files = (const u64 *const *)d_tab;
                 a.lens = d_tab + S;
                 a.tfiles = (const u32 *const *)(d_tab + 2 * (size_t)S);
+                a.cte = any_ct ? d_tab + 3 * (size_t)S : nullptr;
                 a.S1 = (u32)S;
                 UKM_TRY(hit_rate(&rate));
                 if (mode == 2 || rate >= PT_MIN_HIT) break;
@@ -1610,7 +1678,7 @@ int ukm_dev_place_merge(ukm_ctx *c, const u64 *const *keys, const u32 *const *ta
     {
         bool fb = true;
         WsMark m = ws_mark(c);
-        const int rc = ukm_dev_probe_union(c, keys, nullptr, lens, S, false, base, nullptr, cap0, &n0, &fb);
+        const int rc = ukm_dev_probe_union(c, keys, nullptr, lens, S, false, base, nullptr, cap0, &n0, &fb, nullptr);
         ws_release(c, m);
         if (rc == UKM_ERR_CAPACITY) return UKM_OK;
         UKM_TRY(rc);

@@ -368,7 +368,35 @@ __global__ __launch_bounds__(NT) void excl_scan_u64_kernel(const u64 *in, u64 *o
     if (tid == 0 && tile == ntiles - 1 && total_out) *total_out = s_misc[1] + tot;
 }
 
+// dst[i] = value (or *value_dev when that is given: a taxid an earlier kernel of the stream worked out), 16 bytes per store
+// on the aligned middle
+__global__ void fill_u32_kernel(u32 *dst, u64 n, u32 value, const u32 *value_dev) {
+    const u32 v = value_dev ? *value_dev : value;
+    const u64 mis = (u64)((4 - (((uintptr_t)dst >> 2) & 3)) & 3);
+    const u64 head = n < mis ? n : mis;
+    const u64 nq = (n - head) / 4;
+    uint4 *q = reinterpret_cast<uint4 *>(dst + head);
+    const uint4 vv = make_uint4(v, v, v, v);
+    const u64 stride = (u64)gridDim.x * blockDim.x;
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < nq; i += stride) q[i] = vv;
+    if (blockIdx.x == 0) {
+        if (threadIdx.x < head) dst[threadIdx.x] = v;
+        const u64 tail = head + 4 * nq;
+        if (tail + threadIdx.x < n && threadIdx.x < 4) dst[tail + threadIdx.x] = v;
+    }
+}
+
 }  // namespace
+
+int ukm_dev_fill_u32(ukm_ctx *c, u32 *dst, u64 n, u32 value) { return ukm_dev_fill_u32_from(c, dst, n, value, nullptr); }
+
+int ukm_dev_fill_u32_from(ukm_ctx *c, u32 *dst, u64 n, u32 value, const u32 *value_dev) {
+    if (n == 0) return UKM_OK;
+    const unsigned blocks = (unsigned)std::min<u64>((n / 4 + 255) / 256 + 1, (u64)c->num_cu * 16);
+    hipLaunchKernelGGL(fill_u32_kernel, dim3(blocks), dim3(256), 0, c->stream, dst, n, value, value_dev);
+    UKM_HIP(hipGetLastError());
+    return UKM_OK;
+}
 
 int ukm_dev_check_sorted(ukm_ctx *c, const u64 *keys, u64 n, bool *sorted, bool *strict) {
     *sorted = true;

@@ -54,6 +54,13 @@ struct SetopArgs {
     // on the device; na / ntiles above are then upper bounds used for the launch geometry only
     const u64 *na_dev;
     u32 zero_status;  // chained links with few tiles: the partition kernel clears this many status lines (one launch less)
+    // Per-FILE taxids (round 5; the .unik header's global taxid, count.go:466-468: the reader hands the same value to the
+    // set operation for every record of the file): a stream whose taxid pointer is null carries `cta` / `ctb` in every
+    // record.  One such stream beside per-record taxids: the tile loader fills the constant in (no loads).  BOTH streams
+    // constant: the plain-key kernel runs (CT instantiation: LDS-DMA staging, 19 items per thread, no taxid in LDS) and the
+    // output taxid is one of three values -- A's, B's, or LCA(A's, B's) on a match -- resolved ONCE by setop_ct_kernel into
+    // result[4] = lca | keep << 32 (keep: diff -t leaves a matched code in the result, diff.go:404-409).
+    u32 cta, ctb;
 };
 
 // the actual sizes of a chained call (workgroup-uniform: one scalar load)
@@ -399,8 +406,9 @@ __device__ __forceinline__ void tile_load(const SetopArgs &p, const TileGeom &g,
             const bool h0 = ts && v0, h1 = ts && v1;
             t0 = *(h0 ? ts + s0 : safe32);
             t1 = *(h1 ? ts + s1 : safe32);
-            t0 = ts ? t0 : 0u;  // a stream without taxids contributes taxid 0 (mix-taxid)
-            t1 = ts ? t1 : 0u;
+            const u32 tc = in_a ? p.cta : p.ctb;  // a stream without per-record taxids carries its file's taxid (0: none, mix-taxid)
+            t0 = ts ? t0 : tc;
+            t1 = ts ? t1 : tc;
         }
         if (RANK) {
             const u32 *rs = in_a ? pra : prb;
@@ -543,10 +551,13 @@ __device__ __forceinline__ u32 tile_check_order_lds(const TileGeom &g, int tid, 
 // halo) and every A item left is <= B[b1] (the nextB halo), so comparing against the halo picks
 // the right side by itself, and the equality test against the nextB halo is a real match test.
 // That removes ~10 of the ~29 instructions of a step; edge tiles take the checked loop.
-template <int OP, bool TAX, bool RANK, bool INTERIOR, int VT>
+// CT (both streams carry one taxid per FILE): the step also records which side an item came from (amask) and whether it
+// was a matched pair (mmask) -- two bit masks instead of a taxid per item; ct_keep (diff -t, resolved once per call)
+// leaves matched codes in the result.
+template <int OP, bool TAX, bool RANK, bool INTERIOR, bool CT, int VT>
 __device__ __forceinline__ void tile_merge_loop(const SetopArgs &p, const TileGeom &g, int pa, int pb,
                                                 const u64 *s_keys, const u32 *s_tax, const u32 *s_rank,
-                                                u64 (&ok)[VT], u32 (&ot)[VT], u32 &mask) {
+                                                u64 (&ok)[VT], u32 (&ot)[VT], u32 &mask, u32 &amask, u32 &mmask, bool ct_keep) {
     const int base_a = g.base_a, end_a = g.end_a, end_b = g.end_b;
     const int end_bx = end_b + (g.has_next_b ? 1 : 0);
     u64 ak = s_keys[pa], bk = s_keys[pb];
@@ -571,6 +582,8 @@ __device__ __forceinline__ void tile_merge_loop(const SetopArgs &p, const TileGe
         return memo_l;
     };
     mask = 0;
+    amask = 0;
+    mmask = 0;
 #pragma unroll
     for (int s = 0; s < VT; s++) {
         bool take_a, take_b, match;
@@ -598,6 +611,11 @@ __device__ __forceinline__ void tile_merge_loop(const SetopArgs &p, const TileGe
             ek = take_a ? ak : bk;
         } else {
             emit = take_a && !match;
+            if (CT) emit = take_a && (!match || ct_keep);
+        }
+        if (CT) {
+            amask |= take_a ? (1u << s) : 0u;
+            mmask |= match ? (1u << s) : 0u;
         }
         if (TAX) {
             const u32 ta = s_tax[pa], tb = s_tax[pb];
@@ -634,10 +652,10 @@ __device__ __forceinline__ void tile_merge_loop(const SetopArgs &p, const TileGe
     }
 }
 
-template <int OP, bool TAX, bool RANK, int NTH, int VT>
+template <int OP, bool TAX, bool RANK, bool CT, int NTH, int VT>
 __device__ __forceinline__ void tile_merge(const SetopArgs &p, const TileGeom &g, int tid, const u64 *s_keys,
                                            const u32 *s_tax, const u32 *s_rank, u64 (&ok)[VT], u32 (&ot)[VT],
-                                           u32 &mask) {
+                                           u32 &mask, u32 &amask, u32 &mmask, bool ct_keep) {
     const int na_t = g.na_t, nb_t = g.nb_t, total = na_t + nb_t;
     const int base_a = g.base_a, base_b = g.base_b;
     int diag = tid * VT;
@@ -654,9 +672,9 @@ __device__ __forceinline__ void tile_merge(const SetopArgs &p, const TileGeom &g
     const int pa = base_a + lo, pb = base_b + diag - lo;
     // wave-uniform choice (tile geometry): no divergence
     if (total == NTH * VT && g.has_next_a && g.has_next_b)
-        tile_merge_loop<OP, TAX, RANK, true, VT>(p, g, pa, pb, s_keys, s_tax, s_rank, ok, ot, mask);
+        tile_merge_loop<OP, TAX, RANK, true, CT, VT>(p, g, pa, pb, s_keys, s_tax, s_rank, ok, ot, mask, amask, mmask, ct_keep);
     else
-        tile_merge_loop<OP, TAX, RANK, false, VT>(p, g, pa, pb, s_keys, s_tax, s_rank, ok, ot, mask);
+        tile_merge_loop<OP, TAX, RANK, false, CT, VT>(p, g, pa, pb, s_keys, s_tax, s_rank, ok, ot, mask, amask, mmask, ct_keep);
 }
 
 // compact the emitted items of this thread into LDS at its exclusive offset
@@ -705,6 +723,45 @@ __device__ __forceinline__ void tile_flush(const SetopArgs &p, int tid, u64 base
     }
 }
 
+// Both streams carry one taxid per FILE (CT): the taxids of the tile's output.  inter: every record gets LCA(A's, B's)
+// (mix-taxid rule included), diff: A's own -- a fill.  union / keep-everything merge: A's, B's or the LCA by where the
+// record came from; the values go through the LDS words the compacted keys have just left (no LDS beyond the plain
+// kernel's), so that the stores are as coalesced as the keys'.
+template <int OP, int NTH, int VT>
+__device__ __forceinline__ void tile_flush_ct(const SetopArgs &p, int tid, u64 base, u32 count, u32 excl, u32 mask, u32 amask,
+                                              u32 mmask, u32 ct_lca, u32 *s_t32) {
+    if (OP == UKM_OP_INTER || OP == UKM_OP_DIFF) {
+        const u32 v = OP == UKM_OP_INTER ? ct_lca : p.cta;
+        for (u32 i = (u32)tid; i < count; i += NTH)
+            if (base + i < p.out_cap) p.tout[base + i] = v;
+        return;
+    }
+    __syncthreads();  // every thread has stored its share of the compacted keys
+#pragma unroll
+    for (int s = 0; s < VT; s++) {
+        if (mask & (1u << s)) {
+            const u32 w = excl + (u32)__popc(mask & ((1u << s) - 1u));
+            const bool m = OP == UKM_OP_UNION && ((mmask >> s) & 1u);
+            s_t32[w] = m ? ct_lca : (((amask >> s) & 1u) ? p.cta : p.ctb);
+        }
+    }
+    __syncthreads();
+    for (u32 i = (u32)tid; i < count; i += NTH)
+        if (base + i < p.out_cap) p.tout[base + i] = s_t32[i];
+}
+
+// result[4] of a CT call: [31:0] the taxid of a matched pair (inter --mix-taxid: a zero on either side yields the other,
+// inter.go:229-236), [32] diff -t keeps matched codes (diff.go:404-409: the later file's taxid equals the first file's or
+// lies below it).  One thread; runs between the partition launch (which clears the control words) and the tile kernel.
+__global__ void setop_ct_kernel(SetopArgs p, int op) {
+    const u32 a = p.cta, b = p.ctb;
+    u32 l;
+    if (op == UKM_OP_INTER && (p.flags & UKM_F_MIX_TAXID)) l = a == 0 ? b : (b == 0 ? a : lca_dev(p.tax, a, b));
+    else l = lca_dev(p.tax, a, b);
+    const bool keep = op == UKM_OP_DIFF && (p.flags & UKM_F_CMP_TAXID) && (a == b || lca_dev(p.tax, b, a) == a);
+    p.result[4] = (u64)l | ((u64)(keep ? 1u : 0u) << 32);
+}
+
 // ---- the tile kernel: one workgroup per tile of NTH*VT merged items ------------------------------------
 // TICKET = false (default): tile id = blockIdx.x, so the partition words are fetched with scalar
 //   loads at kernel entry and no atomic sits in front of the tile loads (measured -0.7 ms of
@@ -722,9 +779,10 @@ __device__ __forceinline__ void tile_flush(const SetopArgs &p, int tid, u64 base
 #ifndef SETOP_WAVES
 #define SETOP_WAVES 4  /* experiments only: 6 = three workgroups per CU (needs SETOP_VT <= 12) */
 #endif
-template <int OP, bool TAX, bool RANK, bool TICKET, int NTH, int VT>
+template <int OP, bool TAX, bool RANK, bool TICKET, int NTH, int VT, bool CT = false>
 __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu((TAX && RANK) ? 2 : SETOP_WAVES, (TAX && RANK) ? 8 : SETOP_WAVES)))
 void setop_tile_kernel(SetopArgs p) {
+    static_assert(!(CT && TAX), "CT: no per-record taxids");
     constexpr int TILE = NTH * VT;
     constexpr int SLOTS = TILE + 8;
     constexpr int NP = TilePairs<NTH, VT>::NP;
@@ -769,13 +827,20 @@ void setop_tile_kernel(SetopArgs p) {
     }
     u64 ok[VT];
     u32 ot[VT];
-    u32 mask;
+    u32 mask, amask = 0, mmask = 0;
+    u32 ct_lca = 0;
+    bool ct_keep = false;
+    if (CT) {  // (written by setop_ct_kernel in front of this launch: a scalar load)
+        const u64 w = sload_u64(&p.result[4]);
+        ct_lca = (u32)w;
+        ct_keep = ((w >> 32) & 1ull) != 0;
+    }
 #ifdef SETOP_ABL_NOMERGE  // experiment only: timing without the search + serial merge
     mask = 0xAAAAu | (u32)(tid & 1);
 #pragma unroll
     for (int s = 0; s < VT; s++) { ok[s] = s_keys[tid * VT + s]; ot[s] = 0; }
 #else
-    tile_merge<OP, TAX, RANK, NTH, VT>(p, g, tid, s_keys, s_tax, s_rank, ok, ot, mask);
+    tile_merge<OP, TAX, RANK, CT, NTH, VT>(p, g, tid, s_keys, s_tax, s_rank, ok, ot, mask, amask, mmask, ct_keep);
 #endif
     PH(2);
     u32 tile_total;
@@ -839,6 +904,7 @@ void setop_tile_kernel(SetopArgs p) {
     const u64 base = s_misc[1];
 #ifndef SETOP_ABL_NOFLUSH
     tile_flush<TAX, NTH>(p, tid, base, tile_total, s_keys, s_tax);
+    if (CT) tile_flush_ct<OP, NTH, VT>(p, tid, base, tile_total, excl, mask, amask, mmask, ct_lca, reinterpret_cast<u32 *>(s_keys));
 #endif
     if (tid == 0 && tile == p.ntiles - 1) p.result[0] = base + tile_total;
     PH(5);
@@ -879,21 +945,22 @@ __global__ void lower_bound_kernel(const u64 *k, u64 n, const u64 *q, int nq, u6
     out[i] = lo;
 }
 
-template <int OP, bool TAX, bool RANK, int NTH, int VT>
+template <int OP, bool TAX, bool RANK, int NTH, int VT, bool CT = false>
 void launch_tile(const SetopArgs &p, hipStream_t st, bool ticket) {
+    if (CT) hipLaunchKernelGGL(setop_ct_kernel, dim3(1), dim3(1), 0, st, p, OP);
     if (ticket)
-        hipLaunchKernelGGL((setop_tile_kernel<OP, TAX, RANK, true, NTH, VT>), dim3((unsigned)p.ntiles), dim3(NTH), 0, st, p);
+        hipLaunchKernelGGL((setop_tile_kernel<OP, TAX, RANK, true, NTH, VT, CT>), dim3((unsigned)p.ntiles), dim3(NTH), 0, st, p);
     else
-        hipLaunchKernelGGL((setop_tile_kernel<OP, TAX, RANK, false, NTH, VT>), dim3((unsigned)p.ntiles), dim3(NTH), 0, st, p);
+        hipLaunchKernelGGL((setop_tile_kernel<OP, TAX, RANK, false, NTH, VT, CT>), dim3((unsigned)p.ntiles), dim3(NTH), 0, st, p);
 }
 
-template <bool TAX, bool RANK, int NTH, int VT>
+template <bool TAX, bool RANK, int NTH, int VT, bool CT = false>
 void launch_op(int op, const SetopArgs &p, hipStream_t st, bool ticket) {
-    if (op == UKM_OP_UNION) launch_tile<UKM_OP_UNION, TAX, RANK, NTH, VT>(p, st, ticket);
-    else if (op == UKM_OP_INTER) launch_tile<UKM_OP_INTER, TAX, RANK, NTH, VT>(p, st, ticket);
+    if (op == UKM_OP_UNION) launch_tile<UKM_OP_UNION, TAX, RANK, NTH, VT, CT>(p, st, ticket);
+    else if (op == UKM_OP_INTER) launch_tile<UKM_OP_INTER, TAX, RANK, NTH, VT, CT>(p, st, ticket);
     else if (op == UKM_OP_MERGE_INTERNAL) {
-        if constexpr (!RANK) launch_tile<UKM_OP_MERGE_INTERNAL, TAX, false, NTH, VT>(p, st, ticket);
-    } else launch_tile<UKM_OP_DIFF, TAX, RANK, NTH, VT>(p, st, ticket);
+        if constexpr (!RANK) launch_tile<UKM_OP_MERGE_INTERNAL, TAX, false, NTH, VT, CT>(p, st, ticket);
+    } else launch_tile<UKM_OP_DIFF, TAX, RANK, NTH, VT, CT>(p, st, ticket);
 }
 
 constexpr int NTS = SETOP_NT;       // threads per workgroup (512: two workgroups per CU)
@@ -904,10 +971,13 @@ constexpr int VT_PLAIN = SETOP_VT;  // 19 items per thread: 76 KiB of keys in LD
 constexpr int VT_TAX = SETOP_VT_TAX;     // fewer when taxids/ranks ride along
 
 // One pass of the tiled set operation.  result_host[0] = total, [1] = flags.
+// (cta, ctb): the file taxid of a stream whose ta / tb is null (SetopArgs); tax && !ta && !tb = the CT instantiation
 int run_setop_pass(ukm_ctx *c, int op, const u64 *a, const u32 *ta, const u32 *ra, u64 na,
                    const u64 *b, const u32 *tb, const u32 *rb, u64 nb, bool tax, u32 flags,
-                   u64 *out, u32 *tout, u64 out_cap, u64 result_host[2]) {
+                   u64 *out, u32 *tout, u64 out_cap, u64 result_host[2], u32 cta = 0, u32 ctb = 0) {
     const bool rank = ra != nullptr;
+    const bool ct = tax && !ta && !tb;
+    if (ct) tax = false;  // the plain-key kernel; the taxids are an epilogue of it
     const int vt = (tax || rank) ? VT_TAX : VT_PLAIN;
     const u64 tile_items = (u64)NTS * vt;
     const u64 N = na + nb;
@@ -919,6 +989,8 @@ int run_setop_pass(ukm_ctx *c, int op, const u64 *a, const u32 *ta, const u32 *r
     p.ntiles = (N + tile_items - 1) / tile_items;
     p.tax = ukm_taxdev(c);
     p.flags = flags;
+    p.cta = cta;
+    p.ctb = ctb;
     if (p.ntiles > 0xFFFFFFFFull) UKM_FAIL(UKM_ERR_INVALID, "setop: input too large");
 
     // control block: [result 2 x u64 | ticket | pad][status: one 64-byte line per tile][mp ntiles+1]
@@ -945,6 +1017,7 @@ int run_setop_pass(ukm_ctx *c, int op, const u64 *a, const u32 *ta, const u32 *r
             const unsigned sblocks = (unsigned)((p.ntiles + PART_COARSE - 1) / PART_COARSE);
             if (rank) hipLaunchKernelGGL((setop_partition_fused_kernel<true>), dim3(sblocks), dim3(256), 0, c->stream, p, (int)tile_items, 8u);
             else hipLaunchKernelGGL((setop_partition_fused_kernel<false>), dim3(sblocks), dim3(256), 0, c->stream, p, (int)tile_items, 8u);
+            UKM_HIP(hipGetLastError());
         } else {
         UKM_HIP(hipMemsetAsync(ctl, 0, nzero * sizeof(u64), c->stream));
         if (first) {
@@ -967,9 +1040,11 @@ int run_setop_pass(ukm_ctx *c, int op, const u64 *a, const u32 *ta, const u32 *r
         (void)hipEventRecord(c->ev_k0, c->stream);
         if (rank) {
             if (tax) launch_op<true, true, NTS, VT_TAX>(op, p, c->stream, ticket);
+            else if (ct) launch_op<false, true, NTS, VT_TAX, true>(op, p, c->stream, ticket);
             else launch_op<false, true, NTS, VT_TAX>(op, p, c->stream, ticket);
         } else {
             if (tax) launch_op<true, false, NTS, VT_TAX>(op, p, c->stream, ticket);
+            else if (ct) launch_op<false, false, NTS, VT_PLAIN, true>(op, p, c->stream, ticket);
             else launch_op<false, false, NTS, VT_PLAIN>(op, p, c->stream, ticket);
         }
         (void)hipEventRecord(c->ev_k1, c->stream);
@@ -1003,8 +1078,10 @@ int run_setop_pass(ukm_ctx *c, int op, const u64 *a, const u32 *ta, const u32 *r
 // status lines and partition points come from the arena (the caller marks / releases around the call: the
 // stream orders the next link's memset after this link's kernels).  Plain sets only (no rank path).
 int ukm_dev_setop2_link(ukm_ctx *c, int op, const u64 *a, const u32 *ta, u64 na_max, const u64 *na_dev, const u64 *b,
-                        const u32 *tb, u64 nb, u32 flags, u64 *out, u32 *tout, u64 out_cap, u64 *ctl) {
-    const bool tax = (ta != nullptr) || (tb != nullptr);
+                        const u32 *tb, u64 nb, u32 flags, u64 *out, u32 *tout, u64 out_cap, u64 *ctl, u32 cta, u32 ctb) {
+    bool tax = (ta != nullptr) || (tb != nullptr) || cta != 0 || ctb != 0;
+    const bool ct = tax && !ta && !tb;  // both streams carry one taxid per file: plain kernel + taxid epilogue (ctl[4])
+    if (ct) tax = false;
     const int vt = tax ? VT_TAX : VT_PLAIN;
     const u64 tile_items = (u64)NTS * vt;
     SetopArgs p;
@@ -1015,6 +1092,8 @@ int ukm_dev_setop2_link(ukm_ctx *c, int op, const u64 *a, const u32 *ta, u64 na_
     p.ntiles = (na_max + nb + tile_items - 1) / tile_items;
     p.tax = ukm_taxdev(c);
     p.flags = flags;
+    p.cta = cta;
+    p.ctb = ctb;
     if (p.ntiles == 0) return UKM_OK;
     u64 *st = nullptr;
     const unsigned pblocks = (unsigned)((p.ntiles + 1 + 255) / 256);
@@ -1041,6 +1120,7 @@ int ukm_dev_setop2_link(ukm_ctx *c, int op, const u64 *a, const u32 *ta, u64 na_
         hipLaunchKernelGGL((setop_partition_coop_kernel<false, 0>), dim3(wblocks), dim3(256), 0, c->stream, p, (int)tile_items);
     }
     if (tax) launch_op<true, false, NTS, VT_TAX>(op, p, c->stream, c->setop_force_ticket);
+    else if (ct) launch_op<false, false, NTS, VT_PLAIN, true>(op, p, c->stream, c->setop_force_ticket);
     else launch_op<false, false, NTS, VT_PLAIN>(op, p, c->stream, c->setop_force_ticket);
     UKM_HIP(hipGetLastError());
     return UKM_OK;
@@ -1048,9 +1128,17 @@ int ukm_dev_setop2_link(ukm_ctx *c, int op, const u64 *a, const u32 *ta, u64 na_
 
 int ukm_dev_setop2(ukm_ctx *c, int op, const u64 *a, const u32 *ta, u64 na, const u64 *b,
                    const u32 *tb, u64 nb, u32 flags, u64 *out, u32 *tout, u64 out_cap, u64 *n_out) {
+    return ukm_dev_setop2_ct(c, op, a, ta, 0u, na, b, tb, 0u, nb, flags, out, tout, out_cap, n_out);
+}
+
+// cta / ctb: the file taxid of a stream without per-record taxids (ta / tb null); 0 = the stream has no taxid at all
+int ukm_dev_setop2_ct(ukm_ctx *c, int op, const u64 *a, const u32 *ta, u32 cta, u64 na, const u64 *b,
+                      const u32 *tb, u32 ctb, u64 nb, u32 flags, u64 *out, u32 *tout, u64 out_cap, u64 *n_out) {
     if (op != UKM_OP_UNION && op != UKM_OP_INTER && op != UKM_OP_DIFF && op != UKM_OP_MERGE_INTERNAL)
         UKM_FAIL(UKM_ERR_INVALID, "ukm_setop2: unknown op %d", op);
-    const bool tax = (ta != nullptr) || (tb != nullptr);
+    if (ta) cta = 0;
+    if (tb) ctb = 0;
+    const bool tax = (ta != nullptr) || (tb != nullptr) || cta != 0 || ctb != 0;
     if (tax && !tout) UKM_FAIL(UKM_ERR_INVALID, "ukm_setop2: taxids given but out_taxids is NULL");
     const bool need_lca = tax && op != UKM_OP_MERGE_INTERNAL && (op != UKM_OP_DIFF || (flags & UKM_F_CMP_TAXID));
     if (need_lca && c->tax_parent == nullptr)
@@ -1061,7 +1149,7 @@ int ukm_dev_setop2(ukm_ctx *c, int op, const u64 *a, const u32 *ta, u64 na, cons
 
     u64 res[2] = {0, 0};
     UKM_TRY(run_setop_pass(c, op, a, ta, nullptr, na, b, tb, nullptr, nb, tax, flags, out, tout,
-                           out_cap, res));
+                           out_cap, res, cta, ctb));
     if (res[1] & FLAG_UNSORTED) UKM_FAIL(UKM_ERR_UNSORTED, "ukm_setop2: an input stream is not sorted");
     if ((res[1] & FLAG_DUP) && op != UKM_OP_MERGE_INTERNAL) {
         // multiset inputs: redo with the exact reference semantics
@@ -1074,10 +1162,11 @@ int ukm_dev_setop2(ukm_ctx *c, int op, const u64 *a, const u32 *ta, u64 na, cons
             UKM_TRY(ws_alloc_t(c, nb + 1, &ub));
             if (ta) UKM_TRY(ws_alloc_t(c, na + 1, &uta));
             if (tb) UKM_TRY(ws_alloc_t(c, nb + 1, &utb));
+            // (a stream with one taxid per file keeps it: LCA(x, x) = x)
             UKM_TRY(ukm_dev_unique(c, a, ta, na, UKM_UNIQUE, ua, uta, na, &nua));
             UKM_TRY(ukm_dev_unique(c, b, tb, nb, UKM_UNIQUE, ub, utb, nb, &nub));
             UKM_TRY(run_setop_pass(c, op, ua, uta, nullptr, nua, ub, utb, nullptr, nub, tax, flags,
-                                   out, tout, out_cap, res));
+                                   out, tout, out_cap, res, cta, ctb));
         } else {
             u32 *ra = nullptr, *rb = nullptr;
             UKM_TRY(ws_alloc_t(c, na + 1, &ra));
@@ -1091,7 +1180,7 @@ int ukm_dev_setop2(ukm_ctx *c, int op, const u64 *a, const u32 *ta, u64 na, cons
                 u32 *tt = nullptr;
                 UKM_TRY(ws_alloc_t(c, na + 1, &tk));
                 if (tax) UKM_TRY(ws_alloc_t(c, na + 1, &tt));
-                UKM_TRY(run_setop_pass(c, op, a, ta, ra, na, b, tb, rb, nb, tax, flags, tk, tt, na, res));
+                UKM_TRY(run_setop_pass(c, op, a, ta, ra, na, b, tb, rb, nb, tax, flags, tk, tt, na, res, cta, ctb));
                 if (!(res[1] & FLAG_UNSORTED)) {
                     u64 nu = 0;
                     UKM_TRY(ukm_dev_unique(c, tk, tax ? tt : nullptr, res[0], 5 /*UNIQUE_LAST*/, out, tout, out_cap, &nu));
@@ -1099,7 +1188,7 @@ int ukm_dev_setop2(ukm_ctx *c, int op, const u64 *a, const u32 *ta, u64 na, cons
                 }
             } else {
                 UKM_TRY(run_setop_pass(c, op, a, ta, ra, na, b, tb, rb, nb, tax, flags, out, tout,
-                                       out_cap, res));
+                                       out_cap, res, cta, ctb));
             }
         }
         if (res[1] & FLAG_UNSORTED) UKM_FAIL(UKM_ERR_UNSORTED, "ukm_setop2: an input stream is not sorted");
@@ -1111,10 +1200,10 @@ int ukm_dev_setop2(ukm_ctx *c, int op, const u64 *a, const u32 *ta, u64 na, cons
     return UKM_OK;
 }
 
-extern "C" int ukm_setop2(ukm_ctx *ctx, int op, const uint64_t *a_keys, const uint32_t *a_taxids,
-                          uint64_t na, const uint64_t *b_keys, const uint32_t *b_taxids,
-                          uint64_t nb, uint32_t flags, uint64_t *out_keys, uint32_t *out_taxids,
-                          uint64_t out_cap, uint64_t *n_out) {
+extern "C" int ukm_setop2_ft(ukm_ctx *ctx, int op, const uint64_t *a_keys, const uint32_t *a_taxids, uint32_t a_file_taxid,
+                             uint64_t na, const uint64_t *b_keys, const uint32_t *b_taxids, uint32_t b_file_taxid,
+                             uint64_t nb, uint32_t flags, uint64_t *out_keys, uint32_t *out_taxids,
+                             uint64_t out_cap, uint64_t *n_out) {
     if (!ctx || !n_out || (!a_keys && na) || (!b_keys && nb) || (!out_keys && out_cap))
         UKM_FAIL(UKM_ERR_INVALID, "ukm_setop2: NULL argument");
     if (op != UKM_OP_UNION && op != UKM_OP_INTER && op != UKM_OP_DIFF)
@@ -1132,16 +1221,25 @@ extern "C" int ukm_setop2(ukm_ctx *ctx, int op, const uint64_t *a_keys, const ui
         UKM_TRY(ukm_in_t(ctx, b_taxids, nb, &tb));
         UKM_TRY(ukm_out_t(ctx, out_keys, out_cap, &out));
         UKM_TRY(ukm_out_t(ctx, out_taxids, out_cap, &tout));
-        int r = ukm_dev_setop2(ctx, op, a, ta, na, b, tb, nb, flags, out, tout, out_cap, n_out);
+        // (an empty stream's per-record pointer may be null: its file taxid plays no part then)
+        const u32 cta = ta ? 0u : a_file_taxid, ctb = tb ? 0u : b_file_taxid;
+        int r = ukm_dev_setop2_ct(ctx, op, a, ta, cta, na, b, tb, ctb, nb, flags, out, tout, out_cap, n_out);
         u64 n = (r == UKM_OK) ? *n_out : 0;
         // the caller asked for taxids but no record carries one (e.g. the only stream with taxids is
         // empty): records without a taxid have taxid 0
-        if (r == UKM_OK && tout && !ta && !tb && n) UKM_HIP(hipMemsetAsync(tout, 0, n * sizeof(u32), ctx->stream));
+        if (r == UKM_OK && tout && !ta && !tb && !cta && !ctb && n) UKM_HIP(hipMemsetAsync(tout, 0, n * sizeof(u32), ctx->stream));
         ukm_out_resize(ctx, out_keys, n * sizeof(u64));
         if (out_taxids) ukm_out_resize(ctx, out_taxids, n * sizeof(u32));
         return r;
     }();
     return ukm_finish(&s, rc);
+}
+
+extern "C" int ukm_setop2(ukm_ctx *ctx, int op, const uint64_t *a_keys, const uint32_t *a_taxids,
+                          uint64_t na, const uint64_t *b_keys, const uint32_t *b_taxids,
+                          uint64_t nb, uint32_t flags, uint64_t *out_keys, uint32_t *out_taxids,
+                          uint64_t out_cap, uint64_t *n_out) {
+    return ukm_setop2_ft(ctx, op, a_keys, a_taxids, 0u, na, b_keys, b_taxids, 0u, nb, flags, out_keys, out_taxids, out_cap, n_out);
 }
 
 extern "C" int ukm_partition_points(ukm_ctx *ctx, const uint64_t *keys, uint64_t n,

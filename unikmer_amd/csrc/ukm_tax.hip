@@ -31,6 +31,46 @@ __global__ void build_anc_kernel(const u32 *parent, const u8 *depth, u32 size, u
     }
 }
 
+// Decisions over FILE taxids (one per stream, round 5), by ONE thread with the device's own lca_dev so that they agree
+// with what the kernels would work out record by record:
+//   plan[0]     the left fold LCA(LCA(t0, t1), t2) ... of `inter` / `common` (inter.go:229-239; mix: a zero on either
+//               side yields the other)
+//   plan[2 + j] diff -t: file j takes no matched code away from file 0 (its taxid equals file 0's or lies below it,
+//               diff.go:404-409)
+__global__ __launch_bounds__(256) void ct_plan_kernel(TaxDev T, const u32 *ct, u32 n, u32 mix, u32 *plan) {
+    __shared__ u32 s_min, s_max, s_zero, s_diff;
+    const u32 tid = threadIdx.x;
+    const u32 t0 = n ? ct[0] : 0u;
+    if (tid == 0) { s_min = 0xFFFFFFFFu; s_max = 0u; s_zero = 0u; s_diff = 0u; }
+    __syncthreads();
+    // (1000 files: a thread per file -- one thread walking them is a chain of a thousand dependent table reads)
+    for (u32 j = tid; j < n; j += 256) {
+        const u32 t = ct[j];
+        plan[2 + j] = (t0 == t || lca_dev(T, t, t0) == t0) ? 1u : 0u;
+        const u32 e = (T.euler && t < T.size) ? T.euler[t] : 0u;
+        atomicMin(&s_min, e);
+        atomicMax(&s_max, e);
+        if (e == 0) s_zero = 1u;
+        if (t != t0) s_diff = 1u;
+    }
+    __syncthreads();
+    if (tid != 0) return;
+    u32 acc = t0;
+    if (mix) {
+        // (a zero on either side yields the other -- and the LCA of two trees is a zero: the rule depends on the order)
+        for (u32 j = 1; j < n; j++) {
+            const u32 b = ct[j];
+            acc = acc == 0 ? b : (b == 0 ? acc : lca_dev(T, acc, b));
+        }
+    } else if (s_diff) {
+        // the left fold of lca_dev over a set: 0 when one member has no pre-order number (taxid 0, unknown ids), else the LCA
+        // of the members with the smallest and the largest number (the argument of ukm_pfold.hip)
+        acc = s_zero ? 0u : lca_dev(T, T.node_at[s_min], T.node_at[s_max]);
+    }
+    plan[0] = acc;
+    plan[1] = 0;
+}
+
 // copy a (host or device) array to a host vector
 template <typename T>
 int to_host(ukm_ctx *c, const T *p, u64 n, std::vector<T> &v) {
@@ -219,6 +259,20 @@ extern "C" int ukm_taxonomy_load(ukm_ctx *c, const uint32_t *child, const uint32
     c->tax_nchunks = nchunks;
     c->tax_size = (u32)size;
     c->tax_max = mx_node;
+    return UKM_OK;
+}
+
+// *plan: a workspace array of 2 + n words (see ct_plan_kernel), valid until the enclosing top-level call returns
+int ukm_dev_ct_plan(ukm_ctx *c, const u32 *ct_host, int n, bool mix, u32 **plan) {
+    u32 *d = nullptr;
+    UKM_TRY(ws_alloc_t(c, (size_t)2 * n + 2, &d));
+    if (n) {
+        UKM_HIP(hipMemcpyAsync(d + 2 + n, ct_host, (size_t)n * sizeof(u32), hipMemcpyHostToDevice, c->stream));
+        UKM_HIP(hipStreamSynchronize(c->stream));  // (ct_host is a pageable buffer of the caller's frame)
+    }
+    hipLaunchKernelGGL(ct_plan_kernel, dim3(1), dim3(256), 0, c->stream, ukm_taxdev(c), d + 2 + n, (u32)n, mix ? 1u : 0u, d);
+    UKM_HIP(hipGetLastError());
+    *plan = d;
     return UKM_OK;
 }
 

@@ -32,6 +32,7 @@ SYMBOLS = [
     "ukm_comm_get_unique_id", "ukm_comm_init", "ukm_comm_destroy", "ukm_comm_info", "ukm_prefix_splitters",
     "ukm_shard_exchange", "ukm_shard_plan", "ukm_shard_counts", "ukm_shard_exchange_known",
     "ukm_shard_splitters", "ukm_shard_splitters_plan",
+    "ukm_setop2_ft", "ukm_union_ft", "ukm_inter_ft", "ukm_diff_ft", "ukm_common_ft", "ukm_merge_k_ft",
 ]
 
 
@@ -126,6 +127,13 @@ def load():
         f.argtypes = [vp, pvp, pvp, pu64, i32, u32, vp, vp, u64, pu64]
     L.ukm_diff.argtypes = [vp, pvp, pvp, pu64, i32, vp, u32, vp, vp, u64, pu64]
     L.ukm_common.argtypes = [vp, pvp, pvp, pu64, i32, u32, u32, vp, vp, u64, pu64]
+    # per-FILE taxids (one value per stream: the .unik header's global taxid)
+    L.ukm_merge_k_ft.argtypes = [vp, pvp, pvp, vp, pu64, i32, i32, i32, vp, vp, u64, pu64]
+    L.ukm_setop2_ft.argtypes = [vp, i32, vp, vp, u32, u64, vp, vp, u32, u64, u32, vp, vp, u64, pu64]
+    for f in (L.ukm_union_ft, L.ukm_inter_ft):
+        f.argtypes = [vp, pvp, pvp, vp, pu64, i32, u32, vp, vp, u64, pu64]
+    L.ukm_diff_ft.argtypes = [vp, pvp, pvp, vp, pu64, i32, vp, u32, vp, vp, u64, pu64]
+    L.ukm_common_ft.argtypes = [vp, pvp, pvp, vp, pu64, i32, u32, u32, vp, vp, u64, pu64]
     L.ukm_common_threshold.argtypes = [u32, C.c_double, u32]
     L.ukm_common_threshold.restype = u32
     L.ukm_partition_points.argtypes = [vp, vp, u64, vp, i32, vp]
@@ -163,6 +171,11 @@ def _check(rc):
 
 def _is_torch(x):
     return type(x).__module__.startswith("torch")
+
+
+def _is_file_taxid(t):
+    """a stream's taxids given as ONE number: the file's global taxid (every record carries it)"""
+    return isinstance(t, (int, np.integer))
 
 
 _NP2TORCH = {np.dtype(np.uint64): "int64", np.dtype(np.uint32): "int32", np.dtype(np.uint8): "uint8"}
@@ -353,11 +366,16 @@ class Context:
 
     # ---- set operations ----
     def setop2(self, op, a, b, a_taxids=None, b_taxids=None, flags=0, out=None, out_taxids=None):
+        """a_taxids / b_taxids: an array (one taxid per record), an int (ONE taxid for the whole file: the .unik
+        header's global taxid -- nothing is expanded, the kernels take the scalar) or None"""
         pa, na, k1 = _ptr(a, np.uint64)
         pb, nb, k2 = _ptr(b, np.uint64)
-        pta, _, k3 = _ptr(a_taxids, np.uint32)
-        ptb, _, k4 = _ptr(b_taxids, np.uint32)
-        tax = a_taxids is not None or b_taxids is not None
+        fa = int(a_taxids) if _is_file_taxid(a_taxids) else 0
+        fb = int(b_taxids) if _is_file_taxid(b_taxids) else 0
+        pta, _, k3 = _ptr(None if _is_file_taxid(a_taxids) else a_taxids, np.uint32)
+        ptb, _, k4 = _ptr(None if _is_file_taxid(b_taxids) else b_taxids, np.uint32)
+        tax = (a_taxids is not None and not (_is_file_taxid(a_taxids) and fa == 0)) or \
+              (b_taxids is not None and not (_is_file_taxid(b_taxids) and fb == 0))
         bound = na + nb if op == OP_UNION else na
         if out is None:
             out = _empty_like_kind(a, bound, np.uint64)
@@ -366,7 +384,7 @@ class Context:
         po, cap, _ = _ptr(out, np.uint64)
         pot, _, _ = _ptr(out_taxids, np.uint32)
         n = C.c_uint64()
-        _check(self.L.ukm_setop2(self.h, op, pa, pta, na, pb, ptb, nb, flags, po, pot, cap, C.byref(n)))
+        _check(self.L.ukm_setop2_ft(self.h, op, pa, pta, fa, na, pb, ptb, fb, nb, flags, po, pot, cap, C.byref(n)))
         return (out[: n.value], out_taxids[: n.value]) if tax else out[: n.value]
 
     def stream_table(self, keys_list, taxids_list=None):
@@ -380,6 +398,13 @@ class Context:
         if isinstance(keys_list, StreamTable):
             return keys_list.args
         n = len(keys_list)
+        # entries of taxids_list that are plain ints are FILE taxids (one value for every record of the stream): they go to
+        # the C ABI's file_taxids[] as they are
+        ft = None
+        if taxids_list is not None and any(_is_file_taxid(t) for t in taxids_list):
+            ft_np = np.array([int(t) if _is_file_taxid(t) else 0 for t in taxids_list], dtype=np.uint32)
+            taxids_list = [None if _is_file_taxid(t) else t for t in taxids_list]
+            ft = (ft_np, bool(ft_np.any()))
         tax0 = taxids_list is not None and any(t is not None for t in taxids_list)
         if n >= 64 and all(_is_torch(k) for k in keys_list) and (not tax0 or all(t is None or _is_torch(t) for t in taxids_list)):
             # many device tensors (a 1000-file fold): the tables are built with numpy, not element by element through
@@ -396,7 +421,7 @@ class Context:
             tp = (C.c_void_p * n).from_buffer(tp_np) if tp_np is not None else None
             lens = (C.c_uint64 * n).from_buffer(lens_np)
             on_device = all(k.is_cuda for k in keys_list) and (not tax0 or all(t is None or t.is_cuda for t in taxids_list))
-            return kp, tp, lens, n, tax0, int(lens_np.sum()), [keys_list, taxids_list, kp_np, tp_np, lens_np, "device" if on_device else "host"]
+            return kp, tp, lens, n, tax0 or bool(ft and ft[1]), int(lens_np.sum()), [keys_list, taxids_list, kp_np, tp_np, lens_np, "device" if on_device else "host"], ft
         keep = []
         kp = (C.c_void_p * max(n, 1))()
         tp = (C.c_void_p * max(n, 1))()
@@ -413,10 +438,11 @@ class Context:
                 tp[i] = pt
                 keep.append(kt)
         total = sum(int(lens[i]) for i in range(n))
-        return kp, (tp if tax else None), lens, n, tax, total, keep
+        return kp, (tp if tax else None), lens, n, tax or bool(ft and ft[1]), total, keep, ft
 
     def _nway(self, which, keys_list, taxids_list, bound, extra, flags, out, out_taxids):
-        kp, tp, lens, n, tax, total, keep = self._nway_args(keys_list, taxids_list)
+        kp, tp, lens, n, tax, total, keep, ft = self._nway_args(keys_list, taxids_list)
+        pft = ft[0].ctypes.data if ft is not None else None
         if (len(keep) and isinstance(keep[-1], str) and keep[-1] == "device" and which != "merge"
                 and not os.environ.get("UKM_PY_NO_DEVICE_FLAG")):
             flags |= F_DEVICE_STREAMS      # all inputs are CUDA tensors: the library need not classify 2 x n pointers
@@ -433,21 +459,21 @@ class Context:
         tpp = C.cast(tp, C.POINTER(C.c_void_p)) if tp is not None else None
         L = self.L
         if which == "union":
-            rc = L.ukm_union(self.h, kpp, tpp, lens, n, flags, po, pot, cap, C.byref(m))
+            rc = L.ukm_union_ft(self.h, kpp, tpp, pft, lens, n, flags, po, pot, cap, C.byref(m))
         elif which == "inter":
-            rc = L.ukm_inter(self.h, kpp, tpp, lens, n, flags, po, pot, cap, C.byref(m))
+            rc = L.ukm_inter_ft(self.h, kpp, tpp, pft, lens, n, flags, po, pot, cap, C.byref(m))
         elif which == "diff":
             sf = extra
             psf = None
             if sf is not None:
                 sf = np.ascontiguousarray(sf, dtype=np.uint8)
                 psf = sf.ctypes.data
-            rc = L.ukm_diff(self.h, kpp, tpp, lens, n, psf, flags, po, pot, cap, C.byref(m))
+            rc = L.ukm_diff_ft(self.h, kpp, tpp, pft, lens, n, psf, flags, po, pot, cap, C.byref(m))
         elif which == "common":
-            rc = L.ukm_common(self.h, kpp, tpp, lens, n, extra, flags, po, pot, cap, C.byref(m))
+            rc = L.ukm_common_ft(self.h, kpp, tpp, pft, lens, n, extra, flags, po, pot, cap, C.byref(m))
         else:
             mode, final_round = extra
-            rc = L.ukm_merge_k(self.h, kpp, tpp, lens, n, mode, int(final_round), po, pot, cap, C.byref(m))
+            rc = L.ukm_merge_k_ft(self.h, kpp, tpp, pft, lens, n, mode, int(final_round), po, pot, cap, C.byref(m))
         _check(rc)
         return (out[: m.value], out_taxids[: m.value]) if tax else out[: m.value]
 
@@ -522,7 +548,7 @@ class Context:
 
     def shard_splitters(self, keys_list, key_bits):
         """collective (RCCL communicator of this context): sampled splitters for the sorted files this rank holds"""
-        kp, _, lens, n, _, _, keep = self._nway_args(list(keys_list), None)
+        kp, _, lens, n, _, _, keep, _ft = self._nway_args(list(keys_list), None)
         out = np.zeros(self.comm_info()[0] + 1, dtype=np.uint64)
         _check(self.L.ukm_shard_splitters(self.h, C.cast(kp, C.POINTER(C.c_void_p)), lens, n, int(key_bits), out.ctypes.data))
         sp = [int(x) for x in out]
