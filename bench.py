@@ -278,6 +278,70 @@ def main():
     ms_pre = dt * 1e3 / args.steps
     value_pre = 2.0 * tot_in * args.steps / dt  # each op consumes |A|+|B| input k-mers
 
+    # ---- taxid variant (OUTSIDE the timed region; rank 0): the same two sets with taxids, so that a driver-run number exists
+    # for the paths north_star names ("with per-k-mer TaxId LCA reduction").  (a) per-RECORD taxids, SURVEY 8(d)'s generator:
+    # taxid = 1 + splitmix64(seed3 ^ code) mod T on the complete 8-ary tree of depth 7 (uniformly random: the adversarial
+    # case, every match is an LCA of two unrelated leaves); (b) ONE taxid per file (the reference's documented workflow:
+    # `count -t`, the .unik header's global taxid) handed over as a scalar (ukm_setop2_ft).  Kernel ms by hipEvents.
+    taxid_variant = None
+    if rank == 0 and os.environ.get("UKM_BENCH_NO_TAXID") != "1":
+        try:
+            T = sum(8 ** d for d in range(8))
+            child = np.arange(1, T + 1, dtype=np.uint32)
+            parent = ((child.astype(np.int64) - 2) // 8 + 1).astype(np.uint32)
+            parent[0] = 1
+            ctx.taxonomy_load(child, parent)
+            tout_u = torch.zeros(na + nb, dtype=torch.int32, device=dev)
+            tout_i = torch.zeros(min(na, nb), dtype=torch.int32, device=dev)
+
+            def kms(fn, reps=3):
+                best = None
+                for _ in range(reps + 1):
+                    r = fn()
+                    k = ctx.last_kernel_ms()
+                    best = k if best is None else min(best, k)
+                return best, r
+            leaves = T - 8 ** 7 + 1
+            fa, fb = int(leaves + 5), int(leaves + 77)          # two leaves under different children of the root
+            tu, ru = kms(lambda: ctx.setop2(lib.OP_UNION, A, B, fa, fb, out=out_u, out_taxids=tout_u))
+            ti, ri = kms(lambda: ctx.setop2(lib.OP_INTER, A, B, fa, fb, out=out_i, out_taxids=tout_i))
+            assert ru[0].numel() == nu and ri[0].numel() == ni
+            # the taxids of the union: A's own, B's own, or the root on the codes both hold -- counted at full size
+            cu = ru[1]
+            n_root, n_a, n_b = int((cu == 1).sum().item()), int((cu == fa).sum().item()), int((cu == fb).sum().item())
+            assert (n_root, n_a, n_b) == (ni, na - ni, nb - ni), "per-file taxids of the union are wrong"
+            assert bool((ri[1] == 1).all()), "per-file taxids of the intersection are wrong"
+            per_file = {"union_kernel_ms": tu, "inter_kernel_ms": ti,
+                        "union_frac": (8.0 * (na + nb) + 12.0 * nu) / (tu * 1e-3) / 1e9 / 8000.0,
+                        "inter_frac": (8.0 * (na + nb) + 12.0 * ni) / (ti * 1e-3) / 1e9 / 8000.0,
+                        "algorithmic_bytes": "8 B per input record (no taxid is read: one value per file), 12 B per output record",
+                        "checked": "taxid histogram of the full-size outputs (A's / B's / LCA = root)"}
+            del cu
+            # (SURVEY 8(d) words the generator as a function of the code alone; with ONE seed both files would give a shared
+            #  code the same taxid and every LCA would be the trivial LCA(x, x) -- the two files get their own seeds instead)
+            ta = (1 + (splitmix64_torch(A ^ _i64(SEED + 2)) & ((1 << 40) - 1)) % T).to(torch.int32)
+            tb = (1 + (splitmix64_torch(B ^ _i64(SEED + 3)) & ((1 << 40) - 1)) % T).to(torch.int32)
+            tu2, ru2 = kms(lambda: ctx.setop2(lib.OP_UNION, A, B, ta, tb, out=out_u, out_taxids=tout_u))
+            ti2, ri2 = kms(lambda: ctx.setop2(lib.OP_INTER, A, B, ta, tb, out=out_i, out_taxids=tout_i))
+            assert ru2[0].numel() == nu and ri2[0].numel() == ni
+            # a window of the intersection against the bulk LCA entry point on the taxids of the matching input records
+            w = min(2_000_000, ni)
+            ia, ib = torch.searchsorted(A, ri2[0][:w]), torch.searchsorted(B, ri2[0][:w])
+            exp = ctx.lca(ta[ia].contiguous(), tb[ib].contiguous())
+            assert torch.equal(ri2[1][:w], exp), "per-record taxids of the intersection are wrong"
+            del ia, ib
+            per_record = {"union_kernel_ms": tu2, "inter_kernel_ms": ti2,
+                          "union_frac": (12.0 * (na + nb) + 12.0 * nu) / (tu2 * 1e-3) / 1e9 / 8000.0,
+                          "inter_frac": (12.0 * (na + nb) + 12.0 * ni) / (ti2 * 1e-3) / 1e9 / 8000.0,
+                          "algorithmic_bytes": "12 B per input and output record (u64 code + u32 taxid)",
+                          "generator": "taxid = 1 + splitmix64(seed ^ code) mod T with one seed per file, complete 8-ary tree of depth 7 "
+                                       "(SURVEY 8(d)): uniformly random, every match is an LCA of two unrelated nodes"}
+            taxid_variant = {"outside_timed_region": True, "set_size": n, "one_taxid_per_file": per_file, "per_record_taxids": per_record,
+                             "unit": "kernel ms by hipEvents (best of 4); frac = algorithmic bytes / kernel time / 8 TB/s"}
+            del ta, tb, tout_u, tout_i, exp
+        except Exception as e:  # never in the way of the headline
+            taxid_variant = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
+
     res = None
     if rank == 0:
         # roofline of the dominant kernel (union tile kernel): algorithmic bytes per launch
@@ -330,7 +394,7 @@ def main():
                        "k": 31, "per_gpu_set_size": n, "global_set_size": n * world,
                        "parallelism": "prefix-sharded x%d" % world,
                        "ops_per_step": ["ukm_setop2(UNION)", "ukm_setop2(INTER)"]},
-            "roofline": roofline, "roofline_inter": roofline_inter, "cpu_baseline": cpu,
+            "roofline": roofline, "roofline_inter": roofline_inter, "cpu_baseline": cpu, "taxid_variant": taxid_variant,
             "union_kmers_per_s_kernel": (na + nb) / ku, "inter_kmers_per_s_kernel": (na + nb) / ki,
             "value_prepartitioned": value_pre, "ms_per_step_prepartitioned": ms_pre,
             "parity_checked": "inclusion-exclusion, strict order, XOR checksum of checksums, 6 numpy-checked windows of 1e6 "

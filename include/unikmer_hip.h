@@ -113,6 +113,27 @@ int ukm_last_call_ms(ukm_ctx *ctx, float *ms);
  * by placement (counts per code, runs written in one piece).  Tests use it to see that a knob took effect. */
 int ukm_last_route(ukm_ctx *ctx);
 
+/* ---- route policy as API (round 5).  The n-way entry points choose between several internal routes (ukm_last_route) by
+ *      the shape of their inputs; the thresholds can be overridden PER CONTEXT:
+ *        ukm_ctx_set_option(ctx, key, value) / ukm_ctx_unset_option / ukm_ctx_get_option (is_set = 0: the library decides).
+ *      Keys a host may care about (value semantics as the UKM_<KEY> developer variables of DESIGN.md 4.12):
+ *        "punion"  0 never take the hash-probe union / counting probes, 1 whenever the shape allows (size thresholds
+ *                  ignored), 2 also without the hit-rate and load guards;   "punion_tax" 0: records with taxids never;
+ *        "punion_ranked" 0: files with one taxid each go through the generic taxid tables;
+ *        "place" 0 / 1 keep-everything merge by placement never / whenever possible;   "srmerge" 0 / 1 single-pass merge;
+ *        "kway" 1 k-way merge also for tiny inputs;   "no_kway" 1 pairwise tree only;   "no_fold" / "no_pfold" 1 the
+ *        one-launch range / probe folds of inter and diff off;   "pfold_tax" 0;   "common_probe" 0;   "sort_local" 0 all
+ *        radix passes through HBM;   "win_strip" / "nthash_strip" 0 / 1;   "force_ticket" 1 dispatch-order independent kernels.
+ *      The environment is read ONCE, when a context is created: every UKM_* variable present then is the context's default
+ *      for the matching key; no compute call calls getenv (a context created under UKM_ENV_LIVE=1 -- the test suite, which
+ *      flips knobs between calls -- keeps looking).  An explicitly set option always wins.
+ *      ukm_ctx_get_stat: "punion_attempts" = base sets the last hash-probe union / counting-probe call built (2: its retry
+ *      with four times the files ran), "workspace_bytes" = device workspace currently held by the context. */
+int ukm_ctx_set_option(ukm_ctx *ctx, const char *key, long long value);
+int ukm_ctx_unset_option(ukm_ctx *ctx, const char *key);
+int ukm_ctx_get_option(ukm_ctx *ctx, const char *key, long long *value, int *is_set);
+int ukm_ctx_get_stat(ukm_ctx *ctx, const char *key, unsigned long long *value);
+
 /* ---- taxonomy: replaces taxdump.NewTaxonomyFromNCBI / LoadMergedNodesFromNCBI / LCA
  *      (util.go:119-171; 14 taxondb.LCA call sites).
  *      child/parent = the first two columns of nodes.dmp; merged_* = merged.dmp (may be NULL).

@@ -11,6 +11,11 @@ if ROOT not in sys.path:
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
+# The library reads the UKM_* knobs of the environment ONCE per context, at ukm_ctx_create (a host steers a context with
+# ukm_ctx_set_option).  The tests flip knobs with monkeypatch.setenv between calls on one module-scoped context: contexts
+# created under UKM_ENV_LIVE=1 keep looking at the environment (tests/test_gpu_options.py covers the production behaviour).
+os.environ.setdefault("UKM_ENV_LIVE", "1")
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")

@@ -458,3 +458,77 @@ def test_hashed_text_paths_on_gpu(cli, tmp_path):
     cli("dump", "--hashed", "-k", 31, d + "/one.txt", "-o", d + "/one")
     p = cli("view", "-g", _fa(AMUC), d + "/one.unik")
     assert p.stdout.decode().strip() == "12345" and b"not found in given genomes" in p.stderr
+
+
+@pytest.mark.gpu
+def test_global_taxids_through_set_operations(cli, tmp_path):
+    """The reference's documented taxid workflow (README.md:170: `count ... -t 511145`): ONE taxid per file in the .unik
+    header (count.go:466-468), handed out with every record by the reader and folded by union / inter / diff -t / common /
+    merge like a per-record taxid.  The driver passes it to the library as one number per file (ukm_*_ft); expected values:
+    the oracle over the EXPANDED arrays.  One file with per-record taxids beside the global ones, too."""
+    from conftest import synth_tree
+    from oracle import oracle as O
+    d = str(tmp_path)
+    child, parent = synth_tree(depth=4, arity=4)
+    os.makedirs(d + "/tax")
+    with open(d + "/tax/nodes.dmp", "w") as fh:
+        for c, p in zip(child, parent):
+            fh.write("%d\t|\t%d\t|\tno rank\t|\n" % (c, p))
+    with open(d + "/tax/merged.dmp", "w") as fh:
+        fh.write("9000\t|\t7\t|\n")
+    tax = O.Taxonomy(child, parent, [9000], [7])
+    T = len(child)
+    rng = np.random.default_rng(11)
+    k = 13
+    gtax = [int(T - 3), int(T - 2), 9000, 7, int(T - 40)]           # siblings, a merged id and its target, a cousin
+    files, taxs = [], []
+    for f in range(5):
+        codes = np.unique(rng.integers(0, 4000, 2200).astype(np.uint64))
+        files.append(codes)
+        kmers = ["".join("ACGT"[(int(c) >> (2 * (k - 1 - i))) & 3] for i in range(k)) for c in codes]
+        if f == 4:   # per-record taxids in the last file
+            t = rng.integers(1, T + 1, len(codes)).astype(np.uint32)
+            txt = "".join("%s\t%d\n" % (km, tt) for km, tt in zip(kmers, t)).encode()
+            cli("dump", "-s", "-o", d + "/g%d" % f, stdin=txt)
+        else:
+            t = np.full(len(codes), gtax[f], np.uint32)
+            cli("dump", "-s", "-t", gtax[f], "-o", d + "/g%d" % f, stdin=("\n".join(kmers) + "\n").encode())
+        taxs.append(t)
+    fs = [d + "/g%d.unik" % f for f in range(5)]
+
+    def view(name):
+        out = cli("view", "-N", name).stdout.split()
+        tx = cli("view", "-T", name).stdout.split()
+        return np.array([int(x) for x in out], dtype=np.uint64), np.array([int(x) for x in tx], dtype=np.uint32)
+
+    for nf in (4, 5):   # global taxids only; then the per-record file among them
+        cli("union", "-s", "--data-dir", d + "/tax", *fs[:nf], "-o", d + "/u")
+        gk, gt = view(d + "/u.unik")
+        ok, ot = O.union(files[:nf], taxs[:nf], tax)
+        assert np.array_equal(gk, ok) and np.array_equal(gt, ot), nf
+        cli("inter", "--data-dir", d + "/tax", *fs[:nf], "-o", d + "/i")
+        gk, gt = view(d + "/i.unik")
+        ok, ot = O.inter(files[:nf], taxs[:nf], tax)
+        assert len(ok) > 0 and np.array_equal(gk, ok) and np.array_equal(gt, ot), nf
+        cli("diff", "-s", "-t", "--data-dir", d + "/tax", *fs[:nf], "-o", d + "/d")
+        gk, gt = view(d + "/d.unik")
+        ok, ot = O.diff(files[:nf], taxs[:nf], tax, compare_taxid=True)
+        assert np.array_equal(gk, ok) and np.array_equal(gt, ot), nf
+        cli("diff", "-s", "--data-dir", d + "/tax", *fs[:nf], "-o", d + "/d2")
+        gk, gt = view(d + "/d2.unik")
+        ok, ot = O.diff(files[:nf], taxs[:nf], tax)
+        assert np.array_equal(gk, ok) and np.array_equal(gt, ot), nf
+        for extra in ([], ["-n", 2]):
+            cli("common", "--data-dir", d + "/tax", *extra, *fs[:nf], "-o", d + "/c")
+            gk, gt = view(d + "/c.unik")
+            ok, ot = O.common(files[:nf], 2 if extra else nf, taxs[:nf], tax)
+            assert np.array_equal(gk, ok) and np.array_equal(gt, ot), (nf, extra)
+        cli("merge", "-u", "--data-dir", d + "/tax", *fs[:nf], "-o", d + "/m")
+        gk, gt = view(d + "/m.unik")
+        ok, ot = O.union(files[:nf], taxs[:nf], tax)
+        assert np.array_equal(gk, ok) and np.array_equal(gt, ot), nf
+    # the 3rd file's taxid is a merged id whose target is the 4th file's: diff -t of those two keeps everything
+    cli("diff", "-s", "-t", "--data-dir", d + "/tax", fs[3], fs[2], "-o", d + "/d3")
+    gk, gt = view(d + "/d3.unik")
+    ok, ot = O.diff([files[3], files[2]], [taxs[3], taxs[2]], tax, compare_taxid=True)
+    assert np.array_equal(gk, ok) and np.array_equal(gt, ot)

@@ -241,13 +241,15 @@ def test_nway_file_taxids_quirks(env):
 
 
 @pytest.mark.parametrize("knob,value,route", [("UKM_PUNION", "2", 3), ("UKM_PUNION", "1", 3), ("UKM_SRMERGE", "1", 4), ("UKM_KWAY", "1", 2),
-                                              ("UKM_NO_KWAY", "1", 1)])
+                                              ("UKM_NO_KWAY", "1", 1), ("UKM_PUNION_RANKED", "0", 3)])
 def test_union_file_taxids_every_route(env, monkeypatch, knob, value, route):
     """the n-file union with one taxid per file through the hash probes (the file's taxid and pre-order number as scalars),
     the single-pass merge, the k-way merge and the pairwise tree (the arrays are built on the device for the merges)"""
     O, L, ctx, tax, pool, kind = env
     monkeypatch.setenv(knob, value)
-    if knob != "UKM_PUNION":
+    if knob == "UKM_PUNION_RANKED":
+        monkeypatch.setenv("UKM_PUNION", "2")    # (the generic taxid tables with the files' taxids as scalars)
+    elif knob != "UKM_PUNION":
         monkeypatch.setenv("UKM_PUNION", "0")
     rng = np.random.default_rng(3)
     for nfiles, nu, p in ((40, 40_000, 0.5), (600, 9_000, 0.3), (30, 3_000, 0.6)):
@@ -258,7 +260,7 @@ def test_union_file_taxids_every_route(env, monkeypatch, knob, value, route):
             if name == "same":
                 continue
             gk, gt = ctx.union(files, taxs)
-            if name != "mixed" or knob != "UKM_PUNION":
+            if name != "mixed" or not knob.startswith("UKM_PUNION"):
                 assert ctx.last_route() == route, (knob, nfiles, name, ctx.last_route())
             _eq((gk, gt), O.union(files, _expand(files, taxs), tax), (knob, nfiles, name))
 

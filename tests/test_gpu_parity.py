@@ -302,6 +302,12 @@ def test_nway_edge_cases(ctx, O, L):
     assert np.array_equal(ctx.diff([files[0], e, files[1]]), O.diff([files[0], e, files[1]]))
     with pytest.raises(L.UnsortedError):
         ctx.diff([rng.permutation(files[0]), files[1]])
+    # diff: a first file with duplicate codes keeps every record BETWEEN the files (diff.go:437 mc1 = mc2: a second copy
+    # outlives a file that holds the code once and meets the next file) and collapses to one record per code at the end
+    dup0 = [np.sort(np.concatenate([files[0], files[0][:700], files[0][:200]])), files[1], files[2], files[3]]
+    assert np.array_equal(ctx.diff(dup0), O.diff(dup0))
+    assert np.array_equal(ctx.diff(dup0[:3]), O.diff(dup0[:3]))
+    assert np.array_equal(ctx.diff(dup0[:2]), O.diff(dup0[:2]))
     # common threshold helper
     assert ctx.common_threshold(4, 0.6) == O.common_threshold(4, 0.6)
 

@@ -31,6 +31,73 @@ extern "C" int ukm_device_count(int *n) {
     return UKM_OK;
 }
 
+// ---- knobs and options ------------------------------------------------------------------------------------------------
+extern char **environ;
+
+// the option keys a host may set (ukm_ctx_set_option): key "punion" is knob UKM_PUNION, and so on
+static const char *const UKM_OPTION_KEYS[] = {
+    "punion", "punion_tax", "punion_ranked", "place", "srmerge", "kway", "no_kway", "no_fold", "no_pfold", "pfold_tax", "common_probe",
+    "sort_local", "win_strip", "nthash_strip", "force_ticket",
+    // tuning / diagnostics (developer)
+    "punion_k0", "punion_claim", "punion_debug", "kway_k", "kway_r", "kway_top2", "kway_debug", "srmerge_fill", "srmerge_spr",
+    "srmerge_debug", "fold_debug", "sort_debug", "strip_l", "win_strip_l", "setop_fused_part",
+};
+
+static std::string knob_name(const char *key) {
+    std::string n = "UKM_";
+    for (const char *p = key; *p; p++) n.push_back((char)toupper((unsigned char)*p));
+    return n;
+}
+
+const char *ukm_env(const ukm_ctx *c, const char *name) {
+    if (c) {
+        auto o = c->opts.find(name);
+        if (o != c->opts.end()) return o->second.c_str();
+        if (!c->env_live) {
+            auto k = c->knobs.find(name);
+            return k == c->knobs.end() ? nullptr : k->second.c_str();
+        }
+    }
+    return getenv(name);  // (no context, or a context created under UKM_ENV_LIVE=1: the test suite)
+}
+
+extern "C" int ukm_ctx_set_option(ukm_ctx *c, const char *key, long long value) {
+    if (!c || !key) UKM_FAIL(UKM_ERR_INVALID, "ukm_ctx_set_option: NULL argument");
+    for (const char *k : UKM_OPTION_KEYS)
+        if (strcmp(k, key) == 0) {
+            c->opts[knob_name(key)] = std::to_string(value);
+            if (strcmp(key, "force_ticket") == 0) c->setop_force_ticket = value != 0;
+            return UKM_OK;
+        }
+    UKM_FAIL(UKM_ERR_INVALID, "ukm_ctx_set_option: unknown option '%s'", key);
+}
+
+extern "C" int ukm_ctx_unset_option(ukm_ctx *c, const char *key) {
+    if (!c || !key) UKM_FAIL(UKM_ERR_INVALID, "ukm_ctx_unset_option: NULL argument");
+    c->opts.erase(knob_name(key));
+    return UKM_OK;
+}
+
+extern "C" int ukm_ctx_get_option(ukm_ctx *c, const char *key, long long *value, int *is_set) {
+    if (!c || !key || !value || !is_set) UKM_FAIL(UKM_ERR_INVALID, "ukm_ctx_get_option: NULL argument");
+    const std::string n = knob_name(key);
+    const char *e = ukm_env(c, n.c_str());
+    *is_set = (e && *e) ? 1 : 0;
+    *value = *is_set ? atoll(e) : 0;
+    return UKM_OK;
+}
+
+extern "C" int ukm_ctx_get_stat(ukm_ctx *c, const char *key, unsigned long long *value) {
+    if (!c || !key || !value) UKM_FAIL(UKM_ERR_INVALID, "ukm_ctx_get_stat: NULL argument");
+    if (strcmp(key, "punion_attempts") == 0) *value = c->stat_punion_attempts;
+    else if (strcmp(key, "workspace_bytes") == 0) {
+        u64 t = 0;
+        for (auto &b : c->blocks) t += b.cap;
+        *value = t;
+    } else UKM_FAIL(UKM_ERR_INVALID, "ukm_ctx_get_stat: unknown statistic '%s'", key);
+    return UKM_OK;
+}
+
 extern "C" int ukm_ctx_create(int device, ukm_ctx **out) {
     if (!out) UKM_FAIL(UKM_ERR_INVALID, "ukm_ctx_create: out is NULL");
     *out = nullptr;
@@ -59,9 +126,15 @@ extern "C" int ukm_ctx_create(int device, ukm_ctx **out) {
         UKM_FAIL(UKM_ERR_HIP, "ukm_ctx_create: stream/event/pinned allocation failed");
     }
     c->own_stream = true;
+    // the knobs of this context: every UKM_* variable as it is NOW (no later call looks at the environment)
+    for (char **e = environ; e && *e; e++) {
+        if (strncmp(*e, "UKM_", 4) != 0) continue;
+        const char *eq = strchr(*e, '=');
+        if (eq) c->knobs[std::string(*e, (size_t)(eq - *e))] = std::string(eq + 1);
+    }
+    c->env_live = ukm_env_is(c, "UKM_ENV_LIVE", '1');
     // developer/test knob: exercise the ticketed (dispatch-order independent) set-op kernel
-    const char *ft = getenv("UKM_FORCE_TICKET");
-    c->setop_force_ticket = ft && ft[0] == '1';
+    c->setop_force_ticket = ukm_env_is(c, "UKM_FORCE_TICKET", '1');
     *out = c;
     return UKM_OK;
 }

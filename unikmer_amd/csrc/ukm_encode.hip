@@ -704,7 +704,7 @@ int run_strip_filter(ukm_ctx *c, const u8 *bases, const u64 *rec_off, u64 n_rec,
                      u64 *out, u64 out_cap, u64 *n_out, u64 total_bases, bool *done) {
     *done = false;
     // developer / test knob: UKM_NTHASH_STRIP=0 never, =1 always (whatever the scale; overflow still falls back)
-    const char *fe = getenv("UKM_NTHASH_STRIP");
+    const char *fe = ukm_env(c, "UKM_NTHASH_STRIP");
     const int force = fe ? atoi(fe) : -1;
     if (force == 0) return UKM_OK;
     if (((uintptr_t)bases & 3) != 0) return UKM_OK;
@@ -717,7 +717,7 @@ int run_strip_filter(ukm_ctx *c, const u8 *bases, const u64 *rec_off, u64 n_rec,
     // (the count is Poisson: 0.6 x capacity leaves more than ten standard deviations of head room)
     while (L > 64 && (double)ST_NT * L * frac > ST_CAP * 0.6) L >>= 1;
     if (force != 1 && ((double)ST_NT * L * frac > ST_CAP * 0.6 || L < 256)) return UKM_OK;  // small --scale: general kernel
-    if (const char *le = getenv("UKM_STRIP_L")) L = std::min(1024, std::max(64, atoi(le) / 64 * 64));  // developer knob; s_ci packs the window index into 11 bits
+    if (const char *le = ukm_env(c, "UKM_STRIP_L")) L = std::min(1024, std::max(64, atoi(le) / 64 * 64));  // developer knob; s_ci packs the window index into 11 bits
     const u64 tile_pos = (u64)ST_NT * (u64)L;
     const u64 ntiles = (total_bases + tile_pos - 1) / tile_pos;
     if (ntiles > 0x7FFFFFFFull) return UKM_OK;
@@ -1044,7 +1044,7 @@ __global__ __launch_bounds__(SW_NT) __attribute__((amdgpu_waves_per_eu(HASH ? 3 
 int run_strip_windows(ukm_ctx *c, bool hash, const u8 *bases, const u64 *rec_off, const u64 *out_off, u64 n_rec, int k,
                       int canonical, u64 *out, u64 total_bases, u64 *ctl, bool *done) {
     *done = false;
-    const char *fe = getenv("UKM_WIN_STRIP");  // developer / test knob: 0 never, 1 whenever it is correct
+    const char *fe = ukm_env(c, "UKM_WIN_STRIP");  // developer / test knob: 0 never, 1 whenever it is correct
     const int force = fe ? atoi(fe) : -1;
     if (force == 0) return UKM_OK;
     if (((uintptr_t)bases & 3) != 0 || (!hash && k > 32)) return UKM_OK;
@@ -1063,7 +1063,7 @@ int run_strip_windows(ukm_ctx *c, bool hash, const u8 *bases, const u64 *rec_off
     // (1e9 bases: codes 1.71 / 1.84 / 1.94 ms, ntHash k = 51 2.23 / 1.89 / 1.96 ms: short strips keep a wave's 64 output
     // rows close together in memory, which is worth more than the shorter warm-up of long ones)
     int L = (k <= 32) ? 64 : 128;  // twice the warm-up
-    if (const char *le = getenv("UKM_WIN_STRIP_L")) L = std::max(64, atoi(le) / 64 * 64);
+    if (const char *le = ukm_env(c, "UKM_WIN_STRIP_L")) L = std::max(64, atoi(le) / 64 * 64);
     const u64 tile_pos = (u64)SW_NT * (u64)L;
     const u64 ntiles = (total_bases + tile_pos - 1) / tile_pos;
     if (ntiles > 0x7FFFFFFFull) return UKM_OK;

@@ -481,10 +481,7 @@ __global__ void fd_gather_kernel(const u64 *tmp_k, const u32 *tmp_t, const u64 *
 
 }  // namespace
 
-bool ukm_fold_enabled() {
-    const char *e = getenv("UKM_NO_FOLD");
-    return !(e && e[0] == '1');
-}
+bool ukm_fold_enabled(const ukm_ctx *c) { return !ukm_env_is(c, "UKM_NO_FOLD", '1'); }
 
 // All pointers are device pointers; every stream is non-empty, sorted (the kernel verifies it) and the fold is the
 // reference's left fold of streams[1..] into streams[0].  *fallback: a duplicate code was seen (the caller takes the
@@ -585,7 +582,7 @@ int ukm_dev_range_fold(ukm_ctx *c, int op, const u64 *const *keys, const u32 *co
     UKM_HIP(hipGetLastError());
     u64 h[2] = {0, 0};
     UKM_TRY(ukm_read_u64(c, a.ctl, h, 2));
-    if (getenv("UKM_FOLD_DEBUG"))
+    if (ukm_env(c, "UKM_FOLD_DEBUG"))
         fprintf(stderr, "[fold] op=%d S=%d R=%u range_len=%llu slots=%llu tax=%d flags=%llu out=%llu\n", op, S, R,
                 (unsigned long long)range_len, (unsigned long long)slots, (int)tax, (unsigned long long)h[1], (unsigned long long)h[0]);
     if (h[1] & FD_FLAG_UNSORTED) UKM_FAIL(UKM_ERR_UNSORTED, "ukm_setop2: an input stream is not sorted");

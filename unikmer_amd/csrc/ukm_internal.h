@@ -5,8 +5,10 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
+#include <map>
 #include <string>
 #include <vector>
 
@@ -110,6 +112,15 @@ struct ukm_ctx {
 
     int num_cu = 256;
 
+    // Route policy and developer knobs (round 5): the UKM_* variables of the environment are read ONCE, when the context is
+    // created (knobs), and ukm_ctx_set_option overrides them per context (opts: "punion" <-> UKM_PUNION ...).  No compute
+    // call reads the environment -- unless the context was created under UKM_ENV_LIVE=1 (the test suite, whose cases flip
+    // knobs between calls on one context).
+    std::map<std::string, std::string> knobs, opts;
+    bool env_live = false;
+    // statistics a host or a test may ask for (ukm_ctx_get_stat)
+    u64 stat_punion_attempts = 0;  // base sets the last probe union / counting probes built (2: the retry with 4 x the files ran)
+
     // set once the blockIdx-ordered set-op kernel hit its watchdog on this device
     bool setop_force_ticket = false;
     // set once a sort found its keys crowded into few top-16-bit buckets (ukm_sort.hip): later sorts look at a sample first
@@ -117,6 +128,18 @@ struct ukm_ctx {
     // set around the sort of the gathered oversized buckets: those keys are crowded by construction, the general passes take them
     bool sort_general_only = false;
 };
+
+// The value of knob UKM_<NAME> for this context (see ukm_ctx::knobs): nullptr when it is not set.  The pointer stays valid
+// until the next ukm_ctx_set_option on the context.
+const char *ukm_env(const ukm_ctx *c, const char *name);
+static inline bool ukm_env_is(const ukm_ctx *c, const char *name, char v) {
+    const char *e = ukm_env(c, name);
+    return e && e[0] == v;
+}
+static inline int ukm_env_int(const ukm_ctx *c, const char *name, int unset) {
+    const char *e = ukm_env(c, name);
+    return (e && *e) ? atoi(e) : unset;
+}
 
 // Arena API.  Pointers stay valid until the enclosing top-level call returns.
 int ws_alloc(ukm_ctx *c, size_t bytes, void **out);
@@ -215,6 +238,10 @@ int ukm_dev_fill_u32(ukm_ctx *c, u32 *dst, u64 n, u32 value);
 // decisions over per-file taxids on the device (ukm_tax.hip): plan[0] = inter's left LCA fold, plan[2 + j] = diff -t keeps
 int ukm_dev_ct_plan(ukm_ctx *c, const u32 *ct_host, int n, bool mix, u32 **plan);
 int ukm_dev_fill_u32_from(ukm_ctx *c, u32 *dst, u64 n, u32 value, const u32 *value_dev);  // value_dev != null: the value is read there
+// internal flag of ukm_dev_setop2 / _ct (op DIFF, first stream with duplicate codes): the survivors are NOT collapsed to one
+// record per code -- the caller is in the middle of an n-file fold (diff.go:437: mc1 = mc2 keeps every record; the map of
+// diff.go:449-453 only shapes the final result) and collapses once at the end
+#define UKM_F_INTERNAL_KEEP_DUPS 0x10000u
 // flag bits of the set-op result word [1]
 enum { UKM_SETOP_FLAG_DUP = 1, UKM_SETOP_FLAG_UNSORTED = 2, UKM_SETOP_FLAG_TIMEOUT = 4 };
 int ukm_dev_sort(ukm_ctx *c, u64 *keys, u32 *vals, u64 n, int key_bits);

@@ -621,29 +621,14 @@ void kw_launch_k(const KwArgs &a, bool tax, bool uni, bool leaf, unsigned grid, 
 
 }  // namespace
 
-int ukm_kway_fanin() {  // 0 = automatic
-    static int k = -1;
-    if (k < 0) {
-        const char *e = getenv("UKM_KWAY_K");
-        k = e ? atoi(e) : 0;
-        if (k != 4 && k != 8 && k != 16) k = 0;
-    }
-    return k;
+int ukm_kway_fanin(const ukm_ctx *c) {  // 0 = automatic
+    const int k = ukm_env_int(c, "UKM_KWAY_K", 0);
+    return (k == 4 || k == 8 || k == 16) ? k : 0;
 }
 
-static bool kw_top2_enabled() {
-    static const bool on = !(getenv("UKM_KWAY_TOP2") && getenv("UKM_KWAY_TOP2")[0] == '0');  // developer knob
-    return on;
-}
+static bool kw_top2_enabled(const ukm_ctx *c) { return !ukm_env_is(c, "UKM_KWAY_TOP2", '0'); }  // developer knob
 
-bool ukm_kway_enabled() {
-    static int on = -1;
-    if (on < 0) {
-        const char *e = getenv("UKM_NO_KWAY");
-        on = (e && e[0] == '1') ? 0 : 1;
-    }
-    return on != 0;
-}
+bool ukm_kway_enabled(const ukm_ctx *c) { return !ukm_env_is(c, "UKM_NO_KWAY", '1'); }
 
 // All pointers are device pointers.  op: UKM_KWAY_UNION / UKM_KWAY_MERGE.  *fallback is set when the inputs
 // need the caller's general route (unsorted stream, degenerate run); the output is then undefined.
@@ -670,7 +655,7 @@ int ukm_dev_kway(ukm_ctx *c, int op, const u64 *const *keys, const u32 *const *t
     // fan-in per level: 4 for <= 4 children, else 8.  (16 — one level less for 100 files — was measured slower: its
     // level 0 costs 12.6 ms per 2e9 records against 9.1 ms, more than the saved level; UKM_KWAY_K=16 selects it for plain
     // keys, the TaxId shape does not fit LDS at that fan-in.)
-    const int kpref = ukm_kway_fanin();
+    const int kpref = ukm_kway_fanin(c);
     auto pick_k = [&](u64 nchildren) -> int {
         if (nchildren <= 4 || kpref == 4) return 4;
         if (nchildren <= 8 || tax) return 8;
@@ -678,7 +663,7 @@ int ukm_dev_kway(ukm_ctx *c, int op, const u64 *const *keys, const u32 *const *t
     };
     int K = pick_k((u64)S);
     // UKM_KWAY_DEBUG=1: per-phase device times on stderr (developer knob; adds events + one sync)
-    static const bool dbg = getenv("UKM_KWAY_DEBUG") != nullptr;
+    const bool dbg = ukm_env(c, "UKM_KWAY_DEBUG") != nullptr;
     std::vector<std::pair<const char *, hipEvent_t>> marks;
     auto mark = [&](const char *name) {
         if (!dbg) return;
@@ -712,7 +697,7 @@ int ukm_dev_kway(ukm_ctx *c, int op, const u64 *const *keys, const u32 *const *t
     R64 = std::min<u64>(R64, ((u64)1 << 22) / ((u64)S + 1));
     if (R64 < 1) R64 = 1;
     {
-        const char *e = getenv("UKM_KWAY_R");  // developer knob
+        const char *e = ukm_env(c, "UKM_KWAY_R");  // developer knob
         if (e && atoll(e) > 0) R64 = std::min<u64>((u64)atoll(e), ((u64)1 << 22) / ((u64)S + 1));
     }
     u64 D = 1, ns = 0;
@@ -793,7 +778,7 @@ int ukm_dev_kway(ukm_ctx *c, int op, const u64 *const *keys, const u32 *const *t
             ok = tk[lv & 1];
             ot = tt[lv & 1];
         }
-        if (final_lv && !uni && nprev == 2 && lv > 0 && N >= (1u << 20) && kw_top2_enabled()) {
+        if (final_lv && !uni && nprev == 2 && lv > 0 && N >= (1u << 20) && kw_top2_enabled(c)) {
             // A keep-everything merge leaves every node's output as ONE sorted array (slot = rank among the node's
             // leaves), so a top level of two children is a plain 2-way merge: the merge-path tile kernel of
             // ukm_setops.hip (every record kept, the first child's copies of a code first = stream order) runs it at

@@ -267,14 +267,13 @@ int tree_reduce(ukm_ctx *ctx, std::vector<Stream> ss, int op, u32 flags, bool ta
 int try_kway(ukm_ctx *ctx, int op, std::vector<Stream> ss, bool tax, u64 *fk, u32 *ft, u64 fcap, u64 *n_out,
              bool *done) {
     *done = false;
-    if (ss.size() < 3 || !ukm_kway_enabled()) return UKM_OK;
+    if (ss.size() < 3 || !ukm_kway_enabled(ctx)) return UKM_OK;
     {
         // a handful of tiny streams: the pairwise tree (a few 60-us calls) beats the k-way set-up (sample, sort,
         // cuts, several small launches and read-backs).  UKM_KWAY=1 forces the k-way path (tests).
         u64 total = 0;
         for (auto &x : ss) total += x.n;
-        const char *fe = getenv("UKM_KWAY");
-        const bool forced = fe != nullptr && fe[0] == '1';
+        const bool forced = ukm_env_is(ctx, "UKM_KWAY", '1');
         if (!forced && ss.size() <= 4 && total < (1u << 16)) return UKM_OK;
     }
     UKM_TRY(materialise_all(ctx, ss, tax));  // (these merges read a taxid per record)
@@ -336,9 +335,9 @@ int try_kway(ukm_ctx *ctx, int op, std::vector<Stream> ss, bool tax, u64 *fk, u3
 constexpr int PUNION_MIN_STREAMS = 24;
 int try_probe_union(ukm_ctx *ctx, const std::vector<Stream> &ss, bool tax, u64 *fk, u32 *ft, u64 fcap, u64 *n_out, bool *done) {
     *done = false;
-    const int mode = ukm_punion_mode();
-    if (mode == 0 || !ukm_kway_enabled()) return UKM_OK;
-    if (tax && ukm_punion_tax_mode() == 0) return UKM_OK;
+    const int mode = ukm_punion_mode(ctx);
+    if (mode == 0 || !ukm_kway_enabled(ctx)) return UKM_OK;
+    if (tax && ukm_punion_tax_mode(ctx) == 0) return UKM_OK;
     if (mode < 1) {
         if ((int)ss.size() < PUNION_MIN_STREAMS) return UKM_OK;
         u64 later = 0;
@@ -496,7 +495,7 @@ constexpr u64 FOLD_MAX_FIRST = 1ull << 24;  // larger first files: the 2-way til
 int try_range_fold(ukm_ctx *ctx, int op, std::vector<Stream> ss, u32 flags, bool tax, u64 *fk, u32 *ft, u64 fcap,
                    u64 *n_out, bool *done) {
     *done = false;
-    if (!ukm_fold_enabled() || ss.size() < (size_t)CHAIN_MIN_STREAMS || ss[0].n == 0 || ss[0].n > FOLD_MAX_FIRST) return UKM_OK;
+    if (!ukm_fold_enabled(ctx) || ss.size() < (size_t)CHAIN_MIN_STREAMS || ss[0].n == 0 || ss[0].n > FOLD_MAX_FIRST) return UKM_OK;
     UKM_TRY(materialise_all(ctx, ss, tax));  // (files with one taxid each beside files with one per record: rare; all per file: the callers' fills)
     std::vector<const u64 *> kp(ss.size());
     std::vector<const u32 *> tp(ss.size());
@@ -506,7 +505,7 @@ int try_range_fold(ukm_ctx *ctx, int op, std::vector<Stream> ss, u32 flags, bool
         tp[i] = ss[i].t;
         ln[i] = ss[i].n;
     }
-    if (ukm_pfold_enabled()) {
+    if (ukm_pfold_enabled(ctx)) {
         // the order-independent rules (inter without --mix-taxid, diff without -t) by hash probes (ukm_pfold.hip)
         WsMark pm = ws_mark(ctx);
         bool fb = true;
@@ -734,8 +733,10 @@ int diff_body(ukm_ctx *ctx, std::vector<Stream> &ss, const std::vector<u8> &sort
         WsMark mark = ws_mark(ctx);
         if (have_flags && !sorted_flags[(size_t)i]) UKM_TRY(sorted_copy(q));  // unsorted file (diff.go:341-378)
         u64 n = 0;
-        UKM_TRY(ukm_dev_setop2_ct(ctx, UKM_OP_DIFF, acc.k, acc.t, tax ? acc.ct : 0u, acc.n, q.k, q.t, tax ? q.ct : 0u, q.n, flags, bk[flip],
-                                  tax ? bt[flip] : nullptr, acc.n, &n));
+        // (a first file with duplicate codes: every record stays in the running list between the files, diff.go:437; the
+        //  collapse to one record per code follows once, below)
+        UKM_TRY(ukm_dev_setop2_ct(ctx, UKM_OP_DIFF, acc.k, acc.t, tax ? acc.ct : 0u, acc.n, q.k, q.t, tax ? q.ct : 0u, q.n,
+                                  flags | UKM_F_INTERNAL_KEEP_DUPS, bk[flip], tax ? bt[flip] : nullptr, acc.n, &n));
         acc = Stream{bk[flip], tax ? bt[flip] : nullptr, n, 0u};
         flip ^= 1;
         ws_release(ctx, mark);
@@ -812,10 +813,7 @@ extern "C" uint32_t ukm_common_threshold(uint32_t nfiles, double proportion, uin
     return (uint32_t)(uint16_t)number;
 }
 
-static bool common_probe_enabled() {
-    const char *e = getenv("UKM_COMMON_PROBE");  // developer knob: 0 = `common` always by the counting merge
-    return !(e && e[0] == '0');
-}
+static bool common_probe_enabled(const ukm_ctx *c) { return !ukm_env_is(c, "UKM_COMMON_PROBE", '0'); }  // 0 = `common` always by the counting merge
 
 namespace {
 
@@ -844,7 +842,7 @@ int common_body(ukm_ctx *ctx, std::vector<Stream> &ss, u32 threshold, bool tax, 
     // inter.go:252-262) -> the hash-probe fold of ukm_pfold.hip answers in one pass over the files.  It checks the
     // strict order of every file on the way; a duplicate, an unsorted or an empty file, an all-ones code in the
     // first file or an unsuitable shape leave the call to the counting merge below.
-    if (threshold == (u32)nstreams && nstreams >= CHAIN_MIN_STREAMS && ukm_pfold_enabled() && common_probe_enabled()) {
+    if (threshold == (u32)nstreams && nstreams >= CHAIN_MIN_STREAMS && ukm_pfold_enabled(ctx) && common_probe_enabled(ctx)) {
         bool eligible = ss[0].n <= FOLD_MAX_FIRST;
         for (auto &q : ss) eligible = eligible && q.n > 0 && (!tax || q.t != nullptr);
         if (eligible) {
@@ -885,7 +883,7 @@ int common_body(ukm_ctx *ctx, std::vector<Stream> &ss, u32 threshold, bool tax, 
             ss[0] = Stream{k2, t2, nu, ss[0].ct};
         }
     }
-    if (threshold > 1 && ukm_kway_enabled() && ss[0].n) {
+    if (threshold > 1 && ukm_kway_enabled(ctx) && ss[0].n) {
         // files that share most of their codes with the first: one hash probe per record into tables that hold the
         // first file's codes (and claim what the later files add), a record count and the TaxId fold per entry
         // (ukm_punion.hip, pt_probe_kernel<true>).  It declines for few / small files, later files that share too
@@ -904,7 +902,7 @@ int common_body(ukm_ctx *ctx, std::vector<Stream> &ss, u32 threshold, bool tax, 
         *n_out = 0;
     }
     UKM_TRY(materialise_all(ctx, ss, tax));  // (the merges below read a taxid per record)
-    if (threshold > 1 && ukm_kway_enabled()) {
+    if (threshold > 1 && ukm_kway_enabled(ctx)) {
         // many files, a threshold below their number: the single-pass merge counts the records of every code inside
         // its tiles and writes only the codes that reach the threshold (ukm_srmerge.hip) -- otherwise the whole
         // merged sequence is written and read once more by the counting scan below.  It declines for few files,
@@ -994,7 +992,7 @@ extern "C" int ukm_merge_k_ft(ukm_ctx *ctx, const uint64_t *const *keys, const u
         // util-sort.go:377-388,519-530: in a non-final round the one/two-copy protocol is kept
         int m = mode;
         if (mode == UKM_REPEATED && !final_round) m = UKM_REPEATED_CHUNK;
-        if (m == UKM_REPEATED && ukm_kway_enabled()) {
+        if (m == UKM_REPEATED && ukm_kway_enabled(ctx)) {
             // -d in the final round = the codes that have at least two records, TaxId = LCA over all of them
             // (util-sort.go:519-530): for many files that share most of their codes the counting hash probes of
             // ukm_punion.hip with a threshold of two (every record of every file counts); it declines for few / small /

@@ -405,10 +405,7 @@ __global__ void pf_gather_kernel(const u64 *tmp_k, const u32 *tmp_t, const u64 *
 
 }  // namespace
 
-bool ukm_pfold_enabled() {
-    const char *e = getenv("UKM_NO_PFOLD");
-    return !(e && e[0] == '1');
-}
+bool ukm_pfold_enabled(const ukm_ctx *c) { return !ukm_env_is(c, "UKM_NO_PFOLD", '1'); }
 
 int ukm_dev_probe_fold(ukm_ctx *c, int op, const u64 *const *keys, const u32 *const *taxids, const u64 *lens, int S, bool tax,
                        u32 flags, u64 *out, u32 *tout, u64 out_cap, u64 *n_out, bool *fallback) {
@@ -418,7 +415,7 @@ int ukm_dev_probe_fold(ukm_ctx *c, int op, const u64 *const *keys, const u32 *co
     if (op == UKM_OP_INTER && (flags & UKM_F_MIX_TAXID)) return UKM_OK;
     const bool cmp = op == UKM_OP_DIFF && tax && (flags & UKM_F_CMP_TAXID);
     {
-        const char *e = getenv("UKM_PFOLD_TAX");  // developer knob: 0 = inter with taxids through the range fold of ukm_fold.hip
+        const char *e = ukm_env(c, "UKM_PFOLD_TAX");  // developer knob: 0 = inter with taxids through the range fold of ukm_fold.hip
         if (op == UKM_OP_INTER && tax && e && e[0] == '0') return UKM_OK;
     }
     if (S < 2 || lens[0] == 0) return UKM_OK;
@@ -496,7 +493,7 @@ int ukm_dev_probe_fold(ukm_ctx *c, int op, const u64 *const *keys, const u32 *co
     UKM_HIP(hipGetLastError());
     u64 h[2] = {0, 0};
     UKM_TRY(ukm_read_u64(c, a.ctl, h, 2));
-    if (getenv("UKM_FOLD_DEBUG"))
+    if (ukm_env(c, "UKM_FOLD_DEBUG"))
         fprintf(stderr, "[pfold] op=%d S=%d R=%u L=%u slots=%llu tax=%d flags=%llu out=%llu\n", op, S, a.R, a.L, (unsigned long long)slots,
                 (int)tax, (unsigned long long)h[1], (unsigned long long)h[0]);
     if (h[1] != 0) return UKM_OK;  // duplicate / unsorted / empty marker: the routes behind this one handle and report it

@@ -4,9 +4,9 @@
 
 // developer / test knob UKM_PUNION: 0 = never, 1 = whenever the shape allows it (size thresholds ignored),
 // 2 = as 1 and without the hit-rate guard.  Unset: the library's own choice.
-int ukm_punion_mode();
+int ukm_punion_mode(const ukm_ctx *c);
 // UKM_PUNION_TAX=0: records with TaxIds never take this path
-int ukm_punion_tax_mode();
+int ukm_punion_tax_mode(const ukm_ctx *c);
 // *fallback = true: not applicable to these inputs (low overlap, unsorted stream, miss buffer overflow): the
 // caller's k-way merge answers; nothing was written that matters.
 // tax: the records carry TaxIds (taxids[j] may be null: all 0); the result's TaxId is the LCA over every record of a code.
@@ -21,6 +21,6 @@ int ukm_dev_probe_common(ukm_ctx *c, const u64 *const *keys, const u32 *const *t
                          const u32 *ctax = nullptr);
 // Keep-everything merge of many files that share most of their codes, by placement (ukm_punion.hip, pl_merge_kernel):
 // developer knob UKM_PLACE: 0 = never, 1 = whenever the shape allows it.  *fallback as above.
-int ukm_place_mode();
+int ukm_place_mode(const ukm_ctx *c);
 int ukm_dev_place_merge(ukm_ctx *c, const u64 *const *keys, const u32 *const *taxids, const u64 *lens, int S, bool tax, u64 *out,
                         u32 *tout, u64 out_cap, u64 *n_out, bool *fallback);

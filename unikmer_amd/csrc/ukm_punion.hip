@@ -824,6 +824,360 @@ __global__ __launch_bounds__(PT_NT) __attribute__((amdgpu_waves_per_eu(PT_WAVES,
     }
 }
 
+// ---- every file carries ONE taxid (round 5: the .unik header's global taxid, `count -t`) ---------------------------------
+// union.go:195-201 then folds, for every code, the taxids of the FILES that hold it.  The distinct taxid values of a call
+// are few (at most one per file), so the host RANKS them: sorted by (pre-order number, taxid value), rank 1 .. D.  The LCA
+// of a set of nodes is the LCA of its members with the smallest and the largest pre-order number, and ranks order the
+// values by that number -- so all an entry has to keep is the smallest and the largest RANK among the files that hold its
+// code: one 32-bit word per slot ([15:0] smallest rank, [31:16] the complement of the largest; 0xFFFFFFFF = no file yet).
+// A record costs its hash probe (the plain kernel's: one 32-byte bucket read) and ONE more 4-byte LDS read; the rank of
+// its file is a wave-uniform scalar, and the word only changes while the file's rank lies outside the entry's interval --
+// the host hands the files over in the order lowest rank, highest, second lowest, second highest ..., so after an entry's
+// first two or three files hardly any does (a CAS loop then; no atomic otherwise).  No taxid is loaded, no pre-order
+// number looked up, no LCA evaluated while the files stream.
+// BASE is the PLAIN union of the largest files (no LCA in its k-way union) and EVERY file is probed, the base files
+// included: their ranks are folded like anybody's.  The entries' words live in base_st[] between launches (more files than
+// one launch takes: the next batch starts from them); pr_settle_kernel turns them into taxids at the end -- one rank: that
+// taxid itself (LCA(x, x) = x, also for an unknown id); else 0 when the smallest number is 0 (taxid 0 / unknown ids among
+// files that differ); else LCA(node_at[smallest number], node_at[largest]) -- the left fold of lca_dev, as in ukm_pfold.hip.
+// New codes are claimed in the table as in the other kernels and leave with their settled taxid when the range is done;
+// what cannot be claimed (all-ones codes, a table that has doubled) is listed record by record with the file's taxid and
+// the final sort + unique + 2-way union folds it (associativity is all that is used).
+constexpr int PR_NT = 512;
+constexpr int PR_BUCKETS = 1536;     // x 4 slots x (8 + 4) bytes = 72 KB of LDS: two workgroups per CU
+constexpr int PR_SLOTS = 4 * PR_BUCKETS;
+constexpr int PR_RANGE = PR_BUCKETS; // base entries per range (a table takes as many new codes again)
+constexpr u32 PR_NONE = 0xFFFFFFFFu; // no file yet
+constexpr u32 PR_MAX_RANK = 0xFFFEu;
+
+__device__ __forceinline__ u32 pr_hash(u64 x) {
+    const u32 lo = (u32)x, hi = (u32)(x >> 32);
+    return (u32)(((u64)((lo ^ (hi * 0x85EBCA6Bu)) * 0x9E3779B1u) * (u64)PR_BUCKETS) >> 32);
+}
+
+struct PrTables {
+    const u32 *tax_of_rank;  // [D + 1]
+    const u32 *eul_of_rank;  // [D + 1]: the pre-order number of the rank's taxid (non-decreasing in the rank)
+    u32 *base_st;            // [n0] in / out: the rank interval of every base entry
+};
+
+__device__ __forceinline__ u32 pr_settle(const PrTables &t, const TaxDev &T, u32 w) {
+    const u32 mn = w & 0xFFFFu, mx = 0xFFFFu - (w >> 16);
+    if (w == PR_NONE) return 0u;  // (no file held the code: cannot happen for an entry that is in the table)
+    if (mn == mx) return t.tax_of_rank[mn];
+    const u32 en = t.eul_of_rank[mn], ex = t.eul_of_rank[mx];
+    if (en == 0u) return 0u;
+    return lca_dev(T, T.node_at[en], T.node_at[ex]);
+}
+
+__global__ void pr_settle_kernel(PrTables t, TaxDev T, u64 n0, u32 *base_tax) {
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n0) base_tax[i] = pr_settle(t, T, t.base_st[i]);
+}
+
+// A bucket = four codes AND their four rank words, 48 bytes side by side: a record's look-up reads the words with the codes
+// (three ds_read_b128 issued together) instead of going back for one word once the code has been found -- one LDS round trip
+// per record, as in the plain kernel.
+struct __attribute__((aligned(16))) PrBucket {
+    u64 k[4];
+    u32 st[4];
+};
+
+__global__ __launch_bounds__(PR_NT) __attribute__((amdgpu_waves_per_eu(4, 4))) void pr_probe_kernel(PuArgs a, PrTables t) {
+    __shared__ PrBucket s_b[PR_BUCKETS];
+    __shared__ u32 s_next, s_nins;
+    __shared__ u32 s_scan[PR_NT / 64 + 1];
+    __shared__ u64 s_flush_at;
+    const int tid = (int)threadIdx.x, lane = lane_id();
+    const u32 r = blockIdx.x, S1 = a.S1;
+    for (int i = tid; i < PR_BUCKETS; i += PR_NT) {
+        uint4 *bp = reinterpret_cast<uint4 *>(&s_b[i]);
+        bp[0] = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);  // (PU_EMPTY, PU_EMPTY)
+        bp[1] = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
+        bp[2] = make_uint4(PR_NONE, PR_NONE, PR_NONE, PR_NONE);
+    }
+    if (tid == 0) { s_next = 0; s_nins = 0; }
+    __syncthreads();
+    auto next_bucket = [](u32 h) -> u32 { return h + 1 == (u32)PR_BUCKETS ? 0u : h + 1; };
+    // first free slot of the first bucket of the probe sequence that is not full, or the slot that already holds x
+    auto insert = [&](u64 x, bool &fresh) -> int {
+        u32 h = pr_hash(x);
+        for (;; h = next_bucket(h)) {
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const u64 old = atomicCAS((unsigned long long *)&s_b[h].k[k], (unsigned long long)PU_EMPTY, (unsigned long long)x);
+                if (old == PU_EMPTY || old == x) {
+                    fresh = old == PU_EMPTY;
+                    return (int)(4 * h + k);
+                }
+            }
+        }
+    };
+    const u64 b0 = (u64)r * a.range;
+    const u32 nb = (u32)((a.n0 - b0 < (u64)a.range) ? (a.n0 - b0) : (u64)a.range);
+    constexpr int PER = (PR_RANGE + PR_NT - 1) / PR_NT;
+    u64 ent[PER];
+    u32 est[PER];
+    int eslot[PER];
+#pragma unroll
+    for (int i = 0; i < PER; i++) {
+        const u32 idx = (u32)tid + (u32)i * PR_NT;
+        ent[i] = a.base[b0 + (idx < nb ? idx : 0)];
+        est[i] = t.base_st[b0 + (idx < nb ? idx : 0)];
+        if (idx >= nb) ent[i] = PU_EMPTY;
+    }
+#pragma unroll
+    for (int i = 0; i < PER; i++) {
+        eslot[i] = -1;
+        if (ent[i] == PU_EMPTY) continue;  // (an all-ones code: its records are listed, the final union folds them)
+        bool fresh;
+        eslot[i] = insert(ent[i], fresh);
+        s_b[eslot[i] >> 2].st[eslot[i] & 3] = est[i];
+    }
+    __syncthreads();
+    // (the slow way: the first bucket of x's probe sequence was full and did not hold it)
+    auto find_from = [&](u64 x, u32 h) -> int {
+        for (;;) {
+            const ulonglong2 *b = reinterpret_cast<const ulonglong2 *>(&s_b[h]);
+            const ulonglong2 p = b[0], q = b[1];
+            const int k = p.x == x ? 0 : (p.y == x ? 1 : (q.x == x ? 2 : (q.y == x ? 3 : -1)));
+            if (k >= 0) return x != PU_EMPTY ? (int)(4 * h) + k : -1;
+            if (q.y == PU_EMPTY) return -1;
+            h = next_bucket(h);
+        }
+    };
+    const u64 lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+    u64 chunk_at = 0, fill = 0;  // wave-uniform
+    u32 fill_t = 0;
+    u32 chunk_cap = 0, chunk_used = 0;
+    auto close_chunk = [&]() {
+        if ((u32)lane < chunk_cap - chunk_used) {
+            a.miss[chunk_at + chunk_used + (u32)lane] = fill;
+            a.miss_tax[chunk_at + chunk_used + (u32)lane] = fill_t;
+        }
+        chunk_cap = chunk_used = 0;
+    };
+    auto append_global = [&](bool m, u64 x, u32 tx) {
+        const u64 mask = __ballot(m);
+        if (mask == 0ull) return;
+        const u32 n = (u32)__popcll(mask);
+        const int lead = __ffsll((long long)mask) - 1;
+        if (n > chunk_cap - chunk_used) {
+            close_chunk();
+            const u32 want = n > PU_CHUNK ? 64u : PU_CHUNK;
+            u64 at = 0;
+            if (lane == lead) at = atomicAdd((unsigned long long *)&a.ctl[0], (unsigned long long)want);
+            at = __shfl(at, lead, 64);
+            if (at + want > a.miss_cap) {
+                if (lane == lead) atomicOr((unsigned long long *)&a.ctl[1], (unsigned long long)PU_FLAG_OVERFLOW);
+                return;  // (the host discards everything)
+            }
+            chunk_at = at;
+            chunk_cap = want;
+        }
+        fill = __shfl(x, lead, 64);
+        fill_t = tx;  // (wave-uniform: the file's taxid)
+        if (m) {
+            const u64 at = chunk_at + chunk_used + (u32)__popcll(mask & lt);
+            a.miss[at] = x;
+            a.miss_tax[at] = tx;
+        }
+        chunk_used += n;
+    };
+    // widen the interval of `slot` by a file of rank rk (crk = its complement); only called when it does widen or may
+    auto widen = [&](int slot, u32 rk, u32 crk) {
+        u32 *w = &s_b[slot >> 2].st[slot & 3];
+        u32 old = *w;
+        for (;;) {
+            const u32 mn = old & 0xFFFFu, cmx = old >> 16;
+            const u32 nw = (mn < rk ? mn : rk) | ((cmx < crk ? cmx : crk) << 16);
+            if (nw == old) break;
+            const u32 prev = atomicCAS(w, old, nw);
+            if (prev == old) break;
+            old = prev;
+        }
+    };
+    // the rare part of a record: not settled by the first bucket read (`slot` from the slow search, or -1), or its rank lies
+    // outside the entry's interval
+    auto rare = [&](bool valid, int slot, u64 x, u32 rk, u32 crk, u32 ftax) {
+        bool raw = false;
+        if (valid) {
+            if (slot < 0) {
+                if (x == PU_EMPTY || s_nins >= (u32)PR_RANGE) raw = true;
+                else {
+                    bool fresh;
+                    slot = insert(x, fresh);
+                    if (fresh) atomicAdd(&s_nins, 1u);
+                }
+            }
+            if (!raw) widen(slot, rk, crk);
+        }
+        append_global(raw, x, ftax);
+    };
+    bool bad = false;
+    // One step = 128 x U records of one file of rank rk: all the codes are loaded, then ALL the bucket reads of the step are
+    // issued (three 16-byte LDS reads per record, nothing between them that could alias), then every record is judged from
+    // registers; only records that need more -- a new code, a full bucket, a rank outside the interval -- touch LDS again.
+    auto step = [&](auto UU, const ukm_gptr<u64> f, u64 p0, u64 end, u64 len, u32 rk, u32 crk, u32 ftax) {
+        constexpr int U = decltype(UU)::value;
+        pu_pair pr[U];
+        u64 nx[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {  // branch-free loads from addresses clamped into the file (see pu_probe_kernel)
+            const u64 pos = p0 + (u64)u * 128 + 2u * (u32)lane;
+            const u64 q = pos < len - 2 ? pos : len - 2;
+            const u64 q2 = pos + 2 < len ? pos + 2 : len - 1;
+            pr[u] = *(const pu_pair __attribute__((address_space(1))) *)(f + q);
+            nx[u] = f[q2];
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            u64 t0 = pr[u].x, t1 = pr[u].y;
+            asm volatile("" : "+v"(t0), "+v"(t1), "+v"(nx[u]));
+            pr[u].x = t0;
+            pr[u].y = t1;
+        }
+        const bool whole = p0 + (u64)U * 128 <= end && p0 + (u64)U * 128 + 2 <= len;  // (wave-uniform) two records and one behind them in every lane
+        u64 x[2 * U];
+        bool v[2 * U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const u64 pos = p0 + (u64)u * 128 + 2u * (u32)lane;
+            if (whole) {
+                x[2 * u] = pr[u].x;
+                x[2 * u + 1] = pr[u].y;
+                v[2 * u] = v[2 * u + 1] = true;
+                bad |= pr[u].x > pr[u].y || pr[u].y > nx[u];
+            } else {
+                const u32 nv = pos + 1 < end ? 2u : (pos < end ? 1u : 0u);
+                const bool shifted = pos > len - 2;  // pos = len - 1 (or beyond: nv = 0): the record is the pair's second
+                const u64 x0 = shifted ? pr[u].y : pr[u].x;
+                const u64 x1 = nv == 2 ? pr[u].y : x0;
+                const u64 x2 = nv == 2 ? (pos + 2 < len ? nx[u] : PU_EMPTY) : ((!shifted && pos + 1 < len) ? pr[u].y : PU_EMPTY);
+                x[2 * u] = x0;
+                x[2 * u + 1] = x1;
+                v[2 * u] = nv >= 1;
+                v[2 * u + 1] = nv == 2;
+                if (nv >= 1) bad |= x0 > x1 || x1 > x2;
+            }
+        }
+        uint4 q0[2 * U], q1[2 * U], q2[2 * U];
+        u32 hh[2 * U];
+#pragma unroll
+        for (int i = 0; i < 2 * U; i++) {
+            hh[i] = pr_hash(x[i]);
+            const uint4 *bp = reinterpret_cast<const uint4 *>(&s_b[hh[i]]);
+            q0[i] = bp[0];
+            q1[i] = bp[1];
+            q2[i] = bp[2];
+        }
+        bool more[2 * U];
+        int slot[2 * U];
+        bool any = false;
+#pragma unroll
+        for (int i = 0; i < 2 * U; i++) {
+            const u32 xl = (u32)x[i], xh = (u32)(x[i] >> 32);
+            const bool m0 = q0[i].x == xl && q0[i].y == xh, m1 = q0[i].z == xl && q0[i].w == xh;
+            const bool m2 = q1[i].x == xl && q1[i].y == xh, m3 = q1[i].z == xl && q1[i].w == xh;
+            const bool hit = (m0 | m1 | m2 | m3) && x[i] != PU_EMPTY;
+            const u32 w = m0 ? q2[i].x : (m1 ? q2[i].y : (m2 ? q2[i].z : q2[i].w));
+            const bool full = (q1[i].z & q1[i].w) != 0xFFFFFFFFu;  // slot 3 taken: the probe sequence goes on
+            const bool outside = rk < (w & 0xFFFFu) || crk < (w >> 16);
+            slot[i] = hit ? (int)(4 * hh[i]) + (m0 ? 0 : (m1 ? 1 : (m2 ? 2 : 3))) : (full ? -2 : -1);
+            more[i] = v[i] && (!hit || outside);
+            any |= more[i];
+        }
+        if (__ballot(any) == 0ull) return;
+#pragma unroll
+        for (int i = 0; i < 2 * U; i++) {
+            if (__ballot(more[i]) == 0ull) continue;
+            int sl = slot[i];
+            if (more[i] && sl == -2) sl = find_from(x[i], next_bucket(hh[i]));
+            rare(more[i], sl, x[i], rk, crk, ftax);
+        }
+    };
+    auto take = [&]() -> u32 {
+        u32 j = 0;
+        if (lane == 0) j = atomicAdd(&s_next, 1u);
+        return (u32)__builtin_amdgcn_readfirstlane((int)j);
+    };
+    struct Meta { u64 beg, end, len, f, cte; };
+    auto fetch = [&](u32 j) -> Meta {
+        Meta m = {0, 0, 0, 0, 0};
+        if (j < S1) {
+            m.beg = sload_u64(&a.cuts[(u64)r * S1 + j]);
+            m.end = sload_u64(&a.cuts[(u64)(r + 1) * S1 + j]);
+            m.len = sload_u64(&a.lens[j]);
+            m.f = sload_u64((const u64 *)&a.files[j]);
+            m.cte = sload_u64(&a.cte[j]);  // [31:0] the file's taxid, [63:32] its rank
+        }
+        return m;
+    };
+    u32 j = take();
+    Meta cur = fetch(j);
+    while (j < S1) {
+        const u32 jn = take();
+        const Meta nxt = fetch(jn);
+        const auto f = as_global((const u64 *)(uintptr_t)cur.f);
+        const u64 len = cur.len, end = cur.end < cur.beg ? cur.beg : cur.end;
+        const u32 ftax = (u32)cur.cte, rk = (u32)(cur.cte >> 32), crk = 0xFFFFu - rk;
+        if (len < 2) {  // (a one-record file: no 16-byte load fits)
+            if (end > cur.beg) {
+                const u64 x = f[0];
+                rare(lane == 0, lane == 0 ? find_from(x, pr_hash(x)) : -1, x, rk, crk, ftax);
+            }
+        } else {
+            u64 p0 = cur.beg;
+            while (p0 < end) {
+                const u64 rem = end - p0;
+                if (rem > 128) { step(std::integral_constant<int, 2>{}, f, p0, end, len, rk, crk, ftax); p0 += 256; }
+                else { step(std::integral_constant<int, 1>{}, f, p0, end, len, rk, crk, ftax); p0 += 128; }
+            }
+        }
+        j = jn;
+        cur = nxt;
+    }
+    close_chunk();
+    if (bad) atomicOr((unsigned long long *)&a.ctl[1], (unsigned long long)PU_FLAG_UNSORTED);
+    __syncthreads();
+    // the base entries hand their intervals back (the next batch of files, or pr_settle_kernel, goes on from them) ...
+#pragma unroll
+    for (int i = 0; i < PER; i++) {
+        if (eslot[i] < 0) continue;
+        const u32 w = s_b[eslot[i] >> 2].st[eslot[i] & 3];
+        if (w != est[i]) t.base_st[b0 + (u32)tid + (u32)i * PR_NT] = w;
+        s_b[eslot[i] >> 2].k[eslot[i] & 3] = PU_EMPTY;  // (... and leave the table: what is left are the new codes of this range)
+    }
+    __syncthreads();
+    constexpr int SPT = (PR_SLOTS + PR_NT - 1) / PR_NT;
+    u32 mine = 0;
+#pragma unroll
+    for (int i = 0; i < SPT; i++) {
+        const int sl = tid * SPT + i;
+        if (sl < PR_SLOTS && s_b[sl >> 2].k[sl & 3] != PU_EMPTY) mine++;
+    }
+    u32 tot;
+    u32 at_l = block_excl_scan_u32<PR_NT>(mine, s_scan, &tot);
+    if (tot == 0) return;
+    if (tid == 0) {
+        const u64 at = atomicAdd((unsigned long long *)&a.ctl[0], (unsigned long long)tot);
+        if (at + tot > a.miss_cap) atomicOr((unsigned long long *)&a.ctl[1], (unsigned long long)PU_FLAG_OVERFLOW);
+        s_flush_at = at;
+    }
+    __syncthreads();
+    const u64 at = s_flush_at;
+    if (at + tot > a.miss_cap) return;
+#pragma unroll
+    for (int i = 0; i < SPT; i++) {
+        const int sl = tid * SPT + i;
+        if (sl < PR_SLOTS && s_b[sl >> 2].k[sl & 3] != PU_EMPTY) {
+            a.miss[at + at_l] = s_b[sl >> 2].k[sl & 3];
+            a.miss_tax[at + at_l] = pr_settle(t, a.tax, s_b[sl >> 2].st[sl & 3]);
+            at_l++;
+        }
+    }
+}
+
 // Do the files share codes at all?  Records drawn from random files are looked up in ONE other random file each: the
 // share that is found estimates how much of a collection a file holds.  (The chunk files of an out-of-core sort share
 // nothing: without this look the placement merge below would build a base set and sample it before it declines.)
@@ -1124,17 +1478,9 @@ double ms_since(std::chrono::steady_clock::time_point t0) {
 
 }  // namespace
 
-int ukm_punion_mode() {
-    const char *e = getenv("UKM_PUNION");
-    if (!e || !*e) return -1;
-    return atoi(e);
-}
+int ukm_punion_mode(const ukm_ctx *c) { return ukm_env_int(c, "UKM_PUNION", -1); }
 
-int ukm_punion_tax_mode() {
-    const char *e = getenv("UKM_PUNION_TAX");
-    if (!e || !*e) return -1;
-    return atoi(e);
-}
+int ukm_punion_tax_mode(const ukm_ctx *c) { return ukm_env_int(c, "UKM_PUNION_TAX", -1); }
 
 // the share of sampled records that are found in another file (pu_overlap_kernel); the workspace it takes is given back
 static int pu_overlap_share(ukm_ctx *c, const u64 *const *keys, const u64 *lens, int S, double *share) {
@@ -1218,8 +1564,8 @@ static int probe_union_k0(ukm_ctx *c, const u64 *const *keys, const u32 *const *
         taxids = tax_v.data();
     }
     u32 range = (u32)PU_RANGE;  // (with TaxIds: chosen below, when the base set's size is known)
-    const int mode = ukm_punion_mode();
-    const bool dbg = getenv("UKM_PUNION_DEBUG") != nullptr;
+    const int mode = ukm_punion_mode(c);
+    const bool dbg = ukm_env(c, "UKM_PUNION_DEBUG") != nullptr;
     auto t0 = std::chrono::steady_clock::now();
     auto lap = [&](const char *what) {
         if (!dbg) return;
@@ -1298,7 +1644,7 @@ static int probe_union_k0(ukm_ctx *c, const u64 *const *keys, const u32 *const *
     //  512 of them listed from LDS, the rest in chunks -- and a record costs half of what it costs in the tables of the
     //  TaxId pass even without TaxIds: 1000 files x 1e6, a fifth / an eighth of a universe each: 4.1 / 5.9 ms against
     //  5.9 / 7.7.  UKM_PUNION_CLAIM=1: plain files through the TaxId pass's tables all the same, an experiment.)
-    const bool claiming = tax || getenv("UKM_PUNION_CLAIM") != nullptr;
+    const bool claiming = tax || ukm_env(c, "UKM_PUNION_CLAIM") != nullptr;
     if (claiming) range = pt_range_for(c, n0);
     const u64 R64 = (n0 + range - 1) / range;
     if (R64 > 0x7FFFFFFEull) return UKM_OK;
@@ -1386,6 +1732,242 @@ static int probe_union_k0(ukm_ctx *c, const u64 *const *keys, const u32 *const *
     return UKM_OK;
 }
 
+// Base entries per range of the ranked pass (pt_range_for's rule with its own table size)
+static u32 pr_range_for(const ukm_ctx *c, u64 n0) {
+    const u64 slots = 2ull * (u64)std::max(1, c->num_cu);  // (two workgroups per CU)
+    const u64 r_full = (n0 + PR_RANGE - 1) / PR_RANGE;
+    if (r_full >= 16 * slots) return (u32)PR_RANGE;
+    const u64 rounds = (r_full + slots - 1) / slots;
+    const u64 range = (n0 + rounds * slots - 1) / (rounds * slots);
+    return (u32)std::min<u64>(PR_RANGE, std::max<u64>(range, 64));
+}
+
+// `union` of files that carry ONE taxid each (ctax[j]; pr_probe_kernel).  Same contract as probe_union_k0.
+static int probe_union_ranked(ukm_ctx *c, const u64 *const *keys_in, const u64 *lens_in, int S, const u32 *ctax, u64 *out, u32 *tout,
+                              u64 out_cap, u64 *n_out, bool *fallback, int k0, bool *low_hit, double *hit_rate) {
+    *fallback = true;
+    *n_out = 0;
+    *low_hit = false;
+    if (S < k0 + 1) return UKM_OK;
+    if (!tout) UKM_FAIL(UKM_ERR_INVALID, "union: taxids given but out_taxids is NULL");
+    if (c->tax_parent == nullptr) UKM_FAIL(UKM_ERR_NO_TAXONOMY, "union: records carry taxids but no taxonomy is loaded");
+    if (c->tax_euler == nullptr || c->tax_node_at == nullptr) return UKM_OK;
+    const int mode = ukm_punion_mode(c);
+    const bool dbg = ukm_env(c, "UKM_PUNION_DEBUG") != nullptr;
+    auto t0 = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {
+        if (!dbg) return;
+        (void)hipStreamSynchronize(c->stream);
+        fprintf(stderr, "[punion/ranked] %-10s %8.3f ms\n", what, ms_since(t0));
+        t0 = std::chrono::steady_clock::now();
+    };
+    // 0. the distinct taxid values, ranked by (pre-order number, value)
+    std::vector<u32> vals(ctax, ctax + S);
+    std::sort(vals.begin(), vals.end());
+    vals.erase(std::unique(vals.begin(), vals.end()), vals.end());
+    const size_t D = vals.size();
+    if (D > (size_t)PR_MAX_RANK) return UKM_OK;
+    std::vector<u64> ve(D);
+    for (size_t i = 0; i < D; i++) ve[i] = (u64)vals[i];
+    u64 *d_ve = nullptr;
+    UKM_TRY(ws_alloc_t(c, D, &d_ve));
+    UKM_HIP(hipMemcpyAsync(d_ve, ve.data(), D * sizeof(u64), hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(pu_cte_kernel, dim3((unsigned)((D + 255) / 256)), dim3(256), 0, c->stream, d_ve, (u32)D, ukm_taxdev(c));
+    UKM_HIP(hipGetLastError());
+    UKM_HIP(hipMemcpyAsync(ve.data(), d_ve, D * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
+    UKM_HIP(hipStreamSynchronize(c->stream));
+    std::vector<size_t> byrank(D);
+    for (size_t i = 0; i < D; i++) byrank[i] = i;
+    std::sort(byrank.begin(), byrank.end(), [&](size_t x, size_t y) {
+        const u32 ex = (u32)(ve[x] >> 32), ey = (u32)(ve[y] >> 32);
+        return ex != ey ? ex < ey : vals[x] < vals[y];
+    });
+    std::vector<u32> rank_of_val(D), tor(D + 1, 0u), eor(D + 1, 0u);
+    for (size_t rnk = 0; rnk < D; rnk++) {
+        rank_of_val[byrank[rnk]] = (u32)rnk + 1;
+        tor[rnk + 1] = vals[byrank[rnk]];
+        eor[rnk + 1] = (u32)(ve[byrank[rnk]] >> 32);
+    }
+    std::vector<u32> rank_of_file((size_t)S);
+    for (int j = 0; j < S; j++)
+        rank_of_file[(size_t)j] = rank_of_val[(size_t)(std::lower_bound(vals.begin(), vals.end(), ctax[j]) - vals.begin())];
+    // 1. the base set: the PLAIN union of the k0 largest files (files of one size in their order)
+    std::vector<int> ord((size_t)S);
+    for (int j = 0; j < S; j++) ord[(size_t)j] = j;
+    std::stable_sort(ord.begin(), ord.end(), [&](int x, int y) { return lens_in[x] > lens_in[y]; });
+    std::vector<char> in_base((size_t)S, 0);
+    std::vector<const u64 *> bkeys((size_t)k0);
+    std::vector<u64> blens((size_t)k0);
+    u64 cap0 = 0, later = 0, total = 0;
+    for (int j = 0; j < k0; j++) {
+        in_base[(size_t)ord[(size_t)j]] = 1;
+        bkeys[(size_t)j] = keys_in[ord[(size_t)j]];
+        blens[(size_t)j] = lens_in[ord[(size_t)j]];
+        cap0 += blens[(size_t)j];
+    }
+    for (int j = 0; j < S; j++) {
+        total += lens_in[j];
+        if (!in_base[(size_t)j]) later += lens_in[j];
+    }
+    u64 *base = nullptr;
+    UKM_TRY(ws_alloc_t(c, cap0 + 1, &base));
+    u64 n0 = 0;
+    bool fb = false;
+    UKM_TRY(ukm_dev_kway(c, UKM_KWAY_UNION, bkeys.data(), nullptr, blens.data(), k0, false, base, nullptr, cap0, &n0, &fb));
+    if (fb || n0 == 0) return UKM_OK;
+    lap("base");
+    // 2. device tables.  [0, S): every file in the order lowest rank, highest, second lowest, second highest ... (an entry's
+    // interval is then final after its first two or three files); [S, 2S): lengths; [2S, 3S): taxid | rank << 32;
+    // [3S, 3S + 2 S1): the files outside the base set and their lengths, for the hit-rate sample
+    std::vector<int> byr((size_t)S);
+    for (int j = 0; j < S; j++) byr[(size_t)j] = j;
+    std::stable_sort(byr.begin(), byr.end(), [&](int x, int y) { return rank_of_file[(size_t)x] < rank_of_file[(size_t)y]; });
+    std::vector<int> visit;
+    visit.reserve((size_t)S);
+    for (int lo = 0, hi = S - 1; lo <= hi; lo++, hi--) {
+        visit.push_back(byr[(size_t)lo]);
+        if (hi != lo) visit.push_back(byr[(size_t)hi]);
+    }
+    const int S1 = S - k0;
+    std::vector<u64> tab((size_t)3 * S + 2 * (size_t)S1);
+    for (int q = 0; q < S; q++) {
+        const int j = visit[(size_t)q];
+        tab[(size_t)q] = (u64)(uintptr_t)keys_in[j];
+        tab[(size_t)S + q] = lens_in[j];
+        tab[(size_t)2 * S + q] = (u64)ctax[j] | ((u64)rank_of_file[(size_t)j] << 32);
+    }
+    for (int j = 0, q = 0; j < S; j++)
+        if (!in_base[(size_t)j]) {
+            tab[(size_t)3 * S + q] = (u64)(uintptr_t)keys_in[j];
+            tab[(size_t)3 * S + S1 + q] = lens_in[j];
+            q++;
+        }
+    u64 *d_tab = nullptr, *ctl = nullptr;
+    u32 *d_rank = nullptr;
+    UKM_TRY(ws_alloc_t(c, tab.size(), &d_tab));
+    UKM_TRY(ws_alloc_t(c, 8, &ctl));
+    UKM_TRY(ws_alloc_t(c, 2 * (D + 1), &d_rank));
+    UKM_HIP(hipMemcpyAsync(d_tab, tab.data(), tab.size() * sizeof(u64), hipMemcpyHostToDevice, c->stream));
+    UKM_HIP(hipMemcpyAsync(d_rank, tor.data(), (D + 1) * sizeof(u32), hipMemcpyHostToDevice, c->stream));
+    UKM_HIP(hipMemcpyAsync(d_rank + D + 1, eor.data(), (D + 1) * sizeof(u32), hipMemcpyHostToDevice, c->stream));
+    UKM_HIP(hipMemsetAsync(ctl, 0, 8 * sizeof(u64), c->stream));
+    UKM_HIP(hipStreamSynchronize(c->stream));  // (pageable host buffers of this frame)
+    PuArgs a;
+    memset(&a, 0, sizeof(a));
+    a.base = base;
+    a.n0 = n0;
+    a.ctl = ctl;
+    a.tax = ukm_taxdev(c);
+    // 3. do the other files look like the base set?
+    double miss_rate = 0.0;
+    {
+        a.files = (const u64 *const *)(d_tab + 3 * (size_t)S);
+        a.lens = d_tab + 3 * (size_t)S + S1;
+        a.S1 = (u32)S1;
+        const u32 nsamp = 1u << 16, nf = (u32)std::min(S1, 16);
+        hipLaunchKernelGGL(pu_sample_kernel, dim3(nsamp / 256), dim3(256), 0, c->stream, a, nsamp, nf);
+        UKM_HIP(hipGetLastError());
+        u64 h[4] = {0, 0, 0, 0};
+        UKM_TRY(ukm_read_u64(c, ctl, h, 4));
+        if (h[3] == 0) return UKM_OK;
+        miss_rate = 1.0 - (double)h[2] / (double)h[3];
+        if (dbg) fprintf(stderr, "[punion/ranked] sample: %llu of %llu later records in the base set (n0 = %llu, %zu distinct taxids)\n",
+                         (unsigned long long)h[2], (unsigned long long)h[3], (unsigned long long)n0, D);
+        *hit_rate = 1.0 - miss_rate;
+        if (mode != 2 && 1.0 - miss_rate < PT_MIN_HIT) {
+            *low_hit = true;
+            return UKM_OK;
+        }
+        UKM_HIP(hipMemsetAsync(ctl, 0, 8 * sizeof(u64), c->stream));
+    }
+    lap("sample");
+    const u32 range = pr_range_for(c, n0);
+    const u64 R64 = (n0 + range - 1) / range;
+    if (R64 > 0x7FFFFFFEull) return UKM_OK;
+    a.R = (u32)R64;
+    a.range = range;
+    PrTables t;
+    t.tax_of_rank = d_rank;
+    t.eul_of_rank = d_rank + D + 1;
+    UKM_TRY(ws_alloc_t(c, n0 + 1, &t.base_st));
+    UKM_HIP(hipMemsetAsync(t.base_st, 0xFF, (n0 + 1) * sizeof(u32), c->stream));
+    // 4. the probe pass over EVERY file
+    u64 miss_cap = (u64)((double)later * std::min(1.0, 2.0 * miss_rate + 0.01)) + (1u << 20);
+    miss_cap = std::min(miss_cap, total) + 64ull * (PR_NT / 64) * R64 * (u64)((S + PU_MAXS - 1) / PU_MAXS) + total / 32;
+    UKM_TRY(ws_alloc_t(c, miss_cap + 1, &a.miss));
+    UKM_TRY(ws_alloc_t(c, miss_cap + 1, &a.miss_tax));
+    a.miss_cap = miss_cap;
+    for (int s0 = 0; s0 < S; s0 += PU_MAXS) {
+        const int s1 = std::min(PU_MAXS, S - s0);
+        a.files = (const u64 *const *)(d_tab + s0);
+        a.lens = d_tab + S + s0;
+        a.cte = d_tab + 2 * (size_t)S + s0;
+        a.S1 = (u32)s1;
+        WsMark mark = ws_mark(c);
+        UKM_TRY(ws_alloc_t(c, ((size_t)a.R + 1) * s1, &a.cuts));
+        const u64 ncuts = ((u64)a.R + 1) * (u64)s1;
+        hipLaunchKernelGGL(pu_cuts_kernel, dim3((unsigned)((ncuts + 255) / 256)), dim3(256), 0, c->stream, a);
+        lap("cuts");
+        {
+            hipLaunchKernelGGL(pu_load_kernel, dim3((a.R + 255) / 256), dim3(256), 0, c->stream, a);
+            UKM_HIP(hipGetLastError());
+            u64 heaviest = 0;
+            UKM_TRY(ukm_read_u64(c, ctl + 4, &heaviest));
+            u64 batch_records = 0;
+            for (int q = 0; q < s1; q++) batch_records += tab[(size_t)S + s0 + q];
+            const u64 avg = batch_records / a.R + 1;
+            if (mode != 2 && heaviest > 64 * avg + 65536) {
+                ws_release(c, mark);
+                return UKM_OK;
+            }
+            UKM_HIP(hipMemsetAsync(ctl + 4, 0, sizeof(u64), c->stream));
+        }
+        (void)hipEventRecord(c->ev_k0, c->stream);
+        hipLaunchKernelGGL(pr_probe_kernel, dim3(a.R), dim3(PR_NT), 0, c->stream, a, t);
+        (void)hipEventRecord(c->ev_k1, c->stream);
+        c->evk_valid = true;
+        UKM_HIP(hipGetLastError());
+        lap("probe");
+        ws_release(c, mark);
+    }
+    // (an all-ones code is the tables' empty marker: none of its records was folded into its base entry -- every one of
+    //  them is in the list instead --, so the entry, the base set's last, stays out of the final union)
+    u64 h[2] = {0, 0}, last = 0;
+    UKM_TRY(ukm_read_u64(c, ctl, h, 2));
+    UKM_TRY(ukm_read_u64(c, base + n0 - 1, &last));
+    if (dbg) fprintf(stderr, "[punion/ranked] S=%d n0=%llu R=%u range=%u records=%llu listed=%llu (cap %llu) flags=%llu\n", S, (unsigned long long)n0,
+                     a.R, range, (unsigned long long)total, (unsigned long long)h[0], (unsigned long long)miss_cap, (unsigned long long)h[1]);
+    if (h[1] != 0) return UKM_OK;  // unsorted input / overflow: the general route reports or handles it
+    const u64 n0e = last == PU_EMPTY ? n0 - 1 : n0;
+    u32 *base_tax = nullptr;
+    UKM_TRY(ws_alloc_t(c, n0 + 1, &base_tax));
+    if (n0e) hipLaunchKernelGGL(pr_settle_kernel, dim3((unsigned)((n0e + 255) / 256)), dim3(256), 0, c->stream, t, a.tax, n0e, base_tax);
+    UKM_HIP(hipGetLastError());
+    lap("settle");
+    const u64 nm = h[0];
+    if (nm == 0) {
+        *n_out = n0e;
+        if (n0e > out_cap)
+            UKM_FAIL(UKM_ERR_CAPACITY, "output needs %llu records, capacity is %llu", (unsigned long long)n0e, (unsigned long long)out_cap);
+        UKM_HIP(hipMemcpyAsync(out, base, n0e * sizeof(u64), hipMemcpyDeviceToDevice, c->stream));
+        UKM_HIP(hipMemcpyAsync(tout, base_tax, n0e * sizeof(u32), hipMemcpyDeviceToDevice, c->stream));
+        *fallback = false;
+        return UKM_OK;
+    }
+    UKM_TRY(ukm_dev_sort(c, a.miss, a.miss_tax, nm, 64));
+    u64 *mu = nullptr;
+    u32 *mut = nullptr;
+    UKM_TRY(ws_alloc_t(c, nm + 1, &mu));
+    UKM_TRY(ws_alloc_t(c, nm + 1, &mut));
+    u64 nmu = 0;
+    UKM_TRY(ukm_dev_unique(c, a.miss, a.miss_tax, nm, UKM_UNIQUE, mu, mut, nm, &nmu));
+    lap("list sort");
+    UKM_TRY(ukm_dev_setop2(c, UKM_OP_UNION, base, base_tax, n0e, mu, mut, nmu, 0, out, tout, out_cap, n_out));
+    lap("final");
+    *fallback = false;
+    return UKM_OK;
+}
+
 int ukm_dev_probe_union(ukm_ctx *c, const u64 *const *keys, const u32 *const *taxids, const u64 *lens, int S, bool tax, u64 *out,
                         u32 *tout, u64 out_cap, u64 *n_out, bool *fallback, const u32 *ctax) {
     // files of the base set: eight, with TaxIds four (the base union pays an LCA per shared code: 8 files of config 3's
@@ -1397,21 +1979,28 @@ int ukm_dev_probe_union(ukm_ctx *c, const u64 *const *keys, const u32 *const *ta
     // 10.8 / 13.2; a fiftieth each would need 64 files with taxids -- their union with its LCAs alone is 15 ms -- and is
     // left to the merges: 46.4 against 38.3.)
     int k0 = tax ? PT_K0 : PU_K0;
-    if (getenv("UKM_PUNION_K0")) k0 = std::max(3, std::min(64, atoi(getenv("UKM_PUNION_K0"))));  // developer knob
+    if (ukm_env(c, "UKM_PUNION_K0")) k0 = std::max(3, std::min(64, atoi(ukm_env(c, "UKM_PUNION_K0"))));  // developer knob
     *fallback = true;
     *n_out = 0;
-    if (ukm_punion_mode() < 1 && S >= 2) {
+    if (ukm_punion_mode(c) < 1 && S >= 2) {
         // files that share next to nothing (a record of one is in another with less than 3 % probability: even 32 of them
         // would cover too little): one small kernel says so before a base set is built
         double share = 0.0;
         UKM_TRY(pu_overlap_share(c, keys, lens, S, &share));
         if (share < 0.03) return UKM_OK;
     }
+    // every file carries ONE taxid: the ranked pass (its base set is a plain union: eight files)
+    bool ranked = tax && ctax != nullptr && !ukm_env_is(c, "UKM_PUNION_RANKED", '0');
+    for (int j = 0; j < S && ranked; j++) ranked = !(taxids && taxids[j]);
+    if (ranked && !ukm_env(c, "UKM_PUNION_K0")) k0 = PU_K0;
+    c->stat_punion_attempts = 0;
     for (int attempt = 0; attempt < 2; attempt++) {
         bool low_hit = false;
         double hit = 0.0;
         WsMark m = ws_mark(c);
-        const int rc = probe_union_k0(c, keys, taxids, lens, S, tax, out, tout, out_cap, n_out, fallback, k0, &low_hit, &hit, ctax);
+        c->stat_punion_attempts++;
+        const int rc = ranked ? probe_union_ranked(c, keys, lens, S, ctax, out, tout, out_cap, n_out, fallback, k0, &low_hit, &hit)
+                              : probe_union_k0(c, keys, taxids, lens, S, tax, out, tout, out_cap, n_out, fallback, k0, &low_hit, &hit, ctax);
         if (rc != UKM_OK || !*fallback || !low_hit) return rc;
         ws_release(c, m);
         const double miss4 = (1.0 - hit) * (1.0 - hit) * (1.0 - hit) * (1.0 - hit);
@@ -1433,7 +2022,7 @@ int ukm_dev_probe_common(ukm_ctx *c, const u64 *const *keys, const u32 *const *t
                          u32 threshold, u64 *out, u32 *tout, u64 out_cap, u64 *n_out, bool *fallback, bool first_once, const u32 *ctax) {
     *fallback = true;
     *n_out = 0;
-    const int mode = ukm_punion_mode();
+    const int mode = ukm_punion_mode(c);
     if (mode == 0 || S < 3 || S > PU_MAXS || lens[0] == 0) return UKM_OK;
     u64 later = 0;
     for (int j = 1; j < S; j++) later += lens[j];
@@ -1443,7 +2032,7 @@ int ukm_dev_probe_common(ukm_ctx *c, const u64 *const *keys, const u32 *const *t
         if (c->tax_parent == nullptr) UKM_FAIL(UKM_ERR_NO_TAXONOMY, "common: records carry taxids but no taxonomy is loaded");
         if (c->tax_euler == nullptr || c->tax_node_at == nullptr) return UKM_OK;
     }
-    const bool dbg = getenv("UKM_PUNION_DEBUG") != nullptr;
+    const bool dbg = ukm_env(c, "UKM_PUNION_DEBUG") != nullptr;
     if (mode < 1) {
         double share = 0.0;
         UKM_TRY(pu_overlap_share(c, keys, lens, S, &share));
@@ -1510,7 +2099,9 @@ int ukm_dev_probe_common(ukm_ctx *c, const u64 *const *keys, const u32 *const *t
         if (!first_once || (mode != 2 && rate < PT_MIN_HIT)) {
             // (four files, or -- when their sample promises enough, see ukm_dev_probe_union -- sixteen)
             int k0 = std::min(S, PT_K0);
+            c->stat_punion_attempts = 0;
             for (int attempt = 0;; attempt++) {
+                c->stat_punion_attempts++;
                 u64 cap0 = 0;
                 for (int j = 0; j < k0; j++) cap0 += lens[j];
                 u64 *base = nullptr;
@@ -1599,11 +2190,7 @@ int ukm_dev_probe_common(ukm_ctx *c, const u64 *const *keys, const u32 *const *t
     return UKM_OK;
 }
 
-int ukm_place_mode() {
-    const char *e = getenv("UKM_PLACE");
-    if (!e || !*e) return -1;
-    return atoi(e);
-}
+int ukm_place_mode(const ukm_ctx *c) { return ukm_env_int(c, "UKM_PLACE", -1); }
 
 // Keep-everything merge by placement (pl_merge_kernel).  *fallback = true: not this path (few or small files, files that
 // share too little, a duplicate inside a file, an unsorted file): nothing that matters was written.
@@ -1611,7 +2198,7 @@ int ukm_dev_place_merge(ukm_ctx *c, const u64 *const *keys, const u32 *const *ta
                         u32 *tout, u64 out_cap, u64 *n_out, bool *fallback) {
     *fallback = true;
     *n_out = 0;
-    const int mode = ukm_place_mode();
+    const int mode = ukm_place_mode(c);
     if (mode == 0 || S < 3 || S > PU_MAXS) return UKM_OK;
     u64 N = 0;
     for (int j = 0; j < S; j++) {
@@ -1624,7 +2211,7 @@ int ukm_dev_place_merge(ukm_ctx *c, const u64 *const *keys, const u32 *const *ta
         *n_out = N;
         UKM_FAIL(UKM_ERR_CAPACITY, "merge: output needs %llu records, capacity is %llu", (unsigned long long)N, (unsigned long long)out_cap);
     }
-    const bool dbg = getenv("UKM_PUNION_DEBUG") != nullptr;
+    const bool dbg = ukm_env(c, "UKM_PUNION_DEBUG") != nullptr;
     auto t0 = std::chrono::steady_clock::now();
     auto lap = [&](const char *what) {
         if (!dbg) return;

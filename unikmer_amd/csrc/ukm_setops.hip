@@ -1010,7 +1010,7 @@ int run_setop_pass(ukm_ctx *c, int op, const u64 *a, const u32 *ta, const u32 *r
     // re-runs with ticketed tile ids, which cannot stall whatever the dispatch order is.
     for (int attempt = c->setop_force_ticket ? 1 : 0; attempt < 2; attempt++) {
         const bool ticket = attempt == 1;
-        static const bool fused_on = !(getenv("UKM_SETOP_FUSED_PART") && getenv("UKM_SETOP_FUSED_PART")[0] == '0');  // developer knob
+        const bool fused_on = !ukm_env_is(c, "UKM_SETOP_FUSED_PART", '0');  // developer knob
         const bool first = attempt == (c->setop_force_ticket ? 1 : 0);
         if (first && fused_on && p.ntiles >= 4 * PART_COARSE) {
             // status lines, control words and both partition levels in one launch
@@ -1173,9 +1173,10 @@ int ukm_dev_setop2_ct(ukm_ctx *c, int op, const u64 *a, const u32 *ta, u32 cta, 
             UKM_TRY(ws_alloc_t(c, nb + 1, &rb));
             if (na) hipLaunchKernelGGL(rank_in_run_kernel, dim3((unsigned)((na + 255) / 256)), dim3(256), 0, c->stream, a, na, ra);
             if (nb) hipLaunchKernelGGL(rank_in_run_kernel, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, c->stream, b, nb, rb);
-            if (op == UKM_OP_DIFF) {
+            if (op == UKM_OP_DIFF && !(flags & UKM_F_INTERNAL_KEEP_DUPS)) {
                 // the reference's survivor map collapses duplicate codes (diff.go:449-453);
-                // the last record of a run wins
+                // the last record of a run wins.  (ONE later file: the n-file fold keeps the running list as it is between
+                // its files -- mc1 = mc2, diff.go:437 -- and collapses once at the end: UKM_F_INTERNAL_KEEP_DUPS)
                 u64 *tk = nullptr;
                 u32 *tt = nullptr;
                 UKM_TRY(ws_alloc_t(c, na + 1, &tk));
@@ -1223,7 +1224,7 @@ extern "C" int ukm_setop2_ft(ukm_ctx *ctx, int op, const uint64_t *a_keys, const
         UKM_TRY(ukm_out_t(ctx, out_taxids, out_cap, &tout));
         // (an empty stream's per-record pointer may be null: its file taxid plays no part then)
         const u32 cta = ta ? 0u : a_file_taxid, ctb = tb ? 0u : b_file_taxid;
-        int r = ukm_dev_setop2_ct(ctx, op, a, ta, cta, na, b, tb, ctb, nb, flags, out, tout, out_cap, n_out);
+        int r = ukm_dev_setop2_ct(ctx, op, a, ta, cta, na, b, tb, ctb, nb, flags & (UKM_F_MIX_TAXID | UKM_F_CMP_TAXID), out, tout, out_cap, n_out);
         u64 n = (r == UKM_OK) ? *n_out : 0;
         // the caller asked for taxids but no record carries one (e.g. the only stream with taxids is
         // empty): records without a taxid have taxid 0

@@ -651,10 +651,7 @@ __global__ __launch_bounds__(LS_NT) void ls_sort_kernel(LocalSortArgs a) {
     }
 }
 
-bool sort_local_enabled() {
-    const char *e = getenv("UKM_SORT_LOCAL");  // developer knob: 0 = all passes through HBM
-    return !(e && e[0] == '0');
-}
+bool sort_local_enabled(const ukm_ctx *c) { return !ukm_env_is(c, "UKM_SORT_LOCAL", '0'); }  // developer knob: 0 = all passes through HBM
 
 // 2^23 <= n < 2^32.  *done = false: not this route (narrow keys, too many oversized buckets): the caller runs the
 // general passes over the keys as they are now (a permutation of the input).
@@ -694,7 +691,7 @@ int sort_top16_local(ukm_ctx *c, u64 *keys, u32 *vals, u64 n, int key_bits, bool
         UKM_HIP(hipGetLastError());
         u64 heavy[2] = {0, 0};
         UKM_TRY(ukm_read_u64(c, sout, heavy, 2));
-        if (getenv("UKM_SORT_DEBUG"))
+        if (ukm_env(c, "UKM_SORT_DEBUG"))
             fprintf(stderr, "[sort] sample: %llu buckets look heavier than %u samples, %llu of %u samples in them\n", (unsigned long long)heavy[0], thr,
                     (unsigned long long)heavy[1], nsamp);
         heavy_seen = heavy[0] > (u64)LS_MAX_BIG || heavy[1] > (u64)nsamp / 4;
@@ -772,7 +769,7 @@ int sort_top16_local(ukm_ctx *c, u64 *keys, u32 *vals, u64 n, int key_bits, bool
     // minor share of the keys, else the general passes sort everything (keys crowded into few buckets)
     if (hc[LS_NCLASS] > (u64)LS_MAX_BIG || big_keys > n / 4) {
         c->sort_skew_seen = true;        // (and the next sort on this context looks at a sample before it tries)
-        if (getenv("UKM_SORT_DEBUG")) fprintf(stderr, "[sort] %llu buckets beyond every class: general route\n", (unsigned long long)hc[LS_NCLASS]);
+        if (ukm_env(c, "UKM_SORT_DEBUG")) fprintf(stderr, "[sort] %llu buckets beyond every class: general route\n", (unsigned long long)hc[LS_NCLASS]);
         return give_up();
     }
     LocalSortArgs a;
@@ -889,7 +886,7 @@ int ukm_dev_sort(ukm_ctx *c, u64 *keys, u32 *vals, u64 n, int key_bits) {
 #ifndef SORT_LOCAL_MIN
 #define SORT_LOCAL_MIN (1ull << 23)  // (measured: 1.2e7 keys 0.62 -> 0.50 ms, 6.7e6 equal, 1.5e6 slower)
 #endif
-    if (n >= SORT_LOCAL_MIN && RB == 8 && key_bits >= 32 && sort_local_enabled() && !c->sort_general_only) {
+    if (n >= SORT_LOCAL_MIN && RB == 8 && key_bits >= 32 && sort_local_enabled(c) && !c->sort_general_only) {
         // two passes over the top 16 bits, then every bucket in LDS (above); stable, so taxids may ride along
         WsMark mark = ws_mark(c);
         bool done = false;

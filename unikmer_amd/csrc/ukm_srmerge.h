@@ -5,7 +5,7 @@
 
 // developer / test knob UKM_SRMERGE: 0 = never, 1 = whenever the shape allows it (size thresholds ignored).
 // Unset: the library's own choice (many streams, enough records).
-int ukm_srmerge_mode();
+int ukm_srmerge_mode(const ukm_ctx *c);
 // Same contract as ukm_dev_kway: all pointers are device pointers; *fallback = true: the inputs are not for this
 // path (too few / too many streams, an unsorted stream, one code with more copies than a tile holds) and the caller's
 // multi-level merge answers; nothing that matters was written.

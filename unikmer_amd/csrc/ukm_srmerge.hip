@@ -863,17 +863,14 @@ constexpr int SR_CAP = SR_NT * SR_VT;
 
 }  // namespace
 
-int ukm_srmerge_mode() {  // read per call: the tests switch it
-    const char *e = getenv("UKM_SRMERGE");
-    return e ? atoi(e) : -1;
-}
+int ukm_srmerge_mode(const ukm_ctx *c) { return ukm_env_int(c, "UKM_SRMERGE", -1); }
 
 int ukm_dev_srmerge(ukm_ctx *c, int op, const u64 *const *keys, const u32 *const *taxids, const u64 *lens, int S, bool tax,
                     u64 *out, u32 *tout, u64 out_cap, u64 *n_out, bool *fallback, u32 threshold) {
     *fallback = true;
     *n_out = 0;
     const bool uni = op == UKM_KWAY_UNION;
-    const int mode = ukm_srmerge_mode();
+    const int mode = ukm_srmerge_mode(c);
     if (mode == 0 || S < 2 || S > SR_MAX_STREAMS) return UKM_OK;
     u64 N = 0;
     for (int j = 0; j < S; j++) {
@@ -900,13 +897,13 @@ int ukm_dev_srmerge(ukm_ctx *c, int op, const u64 *const *keys, const u32 *const
                  (unsigned long long)out_cap);
     }
     // ---- ranges: ~85 % of a tile on average, splitters from 128 samples per range -------------------------------------
-    const int fill_pct = getenv("UKM_SRMERGE_FILL") ? std::max(10, std::min(400, atoi(getenv("UKM_SRMERGE_FILL")))) : 85;  // developer knob
+    const int fill_pct = ukm_env(c, "UKM_SRMERGE_FILL") ? std::max(10, std::min(400, atoi(ukm_env(c, "UKM_SRMERGE_FILL")))) : 85;  // developer knob
     const u64 target = std::max<u64>(1, (u64)SR_CAP * (u64)fill_pct / 100);
     u64 R64 = (N + target - 1) / target;
     u64 D = 1, ns = 0;
     std::vector<u64> sample_base((size_t)S + 1, 0);
     if (R64 > 1) {
-        const u64 spr = getenv("UKM_SRMERGE_SPR") ? std::max(8, atoi(getenv("UKM_SRMERGE_SPR"))) : SR_SAMPLES_PER_RANGE;  // developer knob
+        const u64 spr = ukm_env(c, "UKM_SRMERGE_SPR") ? std::max(8, atoi(ukm_env(c, "UKM_SRMERGE_SPR"))) : SR_SAMPLES_PER_RANGE;  // developer knob
         D = std::max<u64>(1, N / (R64 * spr));
         for (int j = 0; j < S; j++) sample_base[(size_t)j + 1] = sample_base[(size_t)j] + lens[j] / D;
         ns = sample_base[(size_t)S];
@@ -917,7 +914,7 @@ int ukm_dev_srmerge(ukm_ctx *c, int op, const u64 *const *keys, const u32 *const
     const u32 R = (u32)R64;
     const u32 RP = R + 1;
 
-    static const bool dbg = getenv("UKM_SRMERGE_DEBUG") != nullptr;
+    const bool dbg = ukm_env(c, "UKM_SRMERGE_DEBUG") != nullptr;
     std::vector<std::pair<const char *, hipEvent_t>> marks;
     auto mark = [&](const char *name) {
         if (!dbg) return;

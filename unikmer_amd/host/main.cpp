@@ -249,15 +249,21 @@ static u32 load_taxonomy(Gpu &g, const Options &o) {
 struct Loaded {
     unik::Header h;
     vector<u64> codes;
-    vector<u32> taxids;  // filled when has_taxid
+    vector<u32> taxids;  // filled when has_taxid and the records carry their own (UnikIncludeTaxID)
+    // the header's global taxid (`count -t`, count.go:466-468) when the records carry none: unik.Reader hands it out with
+    // every record; the library takes it as ONE number per file (ukm_*_ft) -- nothing is expanded on the host
+    u32 file_taxid = 0;
     bool has_taxid = false;
+    bool per_record() const { return has_taxid && h.is_include_taxid(); }
+    u32 taxid_of(size_t i) const { return per_record() ? taxids[i] : file_taxid; }
 };
 static Loaded load_unik(const string &file, const Options &o) {
     unik::Reader r(file);
     Loaded L;
     L.h = r.h;
     L.has_taxid = !o.ignore_taxid && r.h.has_taxid_info();
-    r.read_all(L.codes, L.has_taxid ? &L.taxids : nullptr);
+    r.read_all(L.codes, L.per_record() ? &L.taxids : nullptr);
+    if (L.has_taxid && !L.per_record()) L.file_taxid = r.h.global_taxid;
     return L;
 }
 static void check_compat(const unik::Header &a, const unik::Header &b, const string &file) {  // util-binary-file.go:31-44
@@ -832,13 +838,15 @@ static Inputs load_inputs(const vector<string> &files, const Options &o, bool re
 struct Ptrs {
     vector<const u64 *> k;
     vector<const u32 *> t;
+    vector<u32> ft;  // per-file taxids (ukm_*_ft): the global taxid of a file whose records carry none
     vector<u64> n;
 };
 static Ptrs ptrs_of(const Inputs &in, bool tax) {
     Ptrs p;
     for (auto &L : in.files) {
         p.k.push_back(L.codes.data());
-        p.t.push_back(tax && L.has_taxid ? L.taxids.data() : nullptr);
+        p.t.push_back(tax && L.per_record() ? L.taxids.data() : nullptr);
+        p.ft.push_back(tax && L.has_taxid && !L.per_record() ? L.file_taxid : 0u);
         p.n.push_back(L.codes.size());
     }
     return p;
@@ -869,15 +877,20 @@ static u64 merge_files_once(Gpu &g, const Options &o, const ChunkJob &j, const v
         if (j.tax && !ls.back().has_taxid) die("taxid information found in previous files, but missing in this: %s", f.c_str());
         total += ls.back().codes.size();
     }
-    vector<const u64 *> pk; vector<const u32 *> pt; vector<u64> pn;
-    for (auto &L : ls) { pk.push_back(L.codes.data()); pt.push_back(j.tax ? L.taxids.data() : nullptr); pn.push_back(L.codes.size()); }
+    vector<const u64 *> pk; vector<const u32 *> pt; vector<u32> pf; vector<u64> pn;
+    for (auto &L : ls) {
+        pk.push_back(L.codes.data());
+        pt.push_back(j.tax && L.per_record() ? L.taxids.data() : nullptr);
+        pf.push_back(j.tax && !L.per_record() ? L.file_taxid : 0u);
+        pn.push_back(L.codes.size());
+    }
     const u64 cap = 2 * total + 1;
     vector<u64> out(cap);
     vector<u32> tout(j.tax ? cap : 0);
     u64 n = 0;
     if (!ls.empty())
-        ck(ukm_merge_k(g.c, pk.data(), j.tax ? pt.data() : nullptr, pn.data(), (int)ls.size(), j.uniq ? UKM_UNIQUE : (j.rep ? UKM_REPEATED : UKM_PLAIN),
-                       final_round ? 1 : 0, out.data(), j.tax ? tout.data() : nullptr, cap, &n));
+        ck(ukm_merge_k_ft(g.c, pk.data(), j.tax ? pt.data() : nullptr, j.tax ? pf.data() : nullptr, pn.data(), (int)ls.size(),
+                          j.uniq ? UKM_UNIQUE : (j.rep ? UKM_REPEATED : UKM_PLAIN), final_round ? 1 : 0, out.data(), j.tax ? tout.data() : nullptr, cap, &n));
     write_unik(out_file, o, j.k, j.mode, j.max_taxid, 0, j.h0, out.data(), j.tax ? tout.data() : nullptr, n);
     return n;
 }
@@ -1016,14 +1029,15 @@ static int cmd_setop(SetCmd which, int argc, char **argv) {
     u64 n = 0;
     const bool with_t = tax || cmp_taxid;
     const u32 *const *tp = with_t ? p.t.data() : nullptr;
+    const u32 *fp = with_t ? p.ft.data() : nullptr;
     bool sorted_out = true;
     switch (which) {
     case C_UNION:
-        ck(ukm_union(g.c, p.k.data(), tp, p.n.data(), ns, 0, out.data(), with_t ? tout.data() : nullptr, cap, &n));
+        ck(ukm_union_ft(g.c, p.k.data(), tp, fp, p.n.data(), ns, 0, out.data(), with_t ? tout.data() : nullptr, cap, &n));
         sorted_out = a.has("sort");  // same stream; the flag/encoding follow -s (union.go:220-235)
         break;
     case C_INTER:
-        ck(ukm_inter(g.c, p.k.data(), tp, p.n.data(), ns, mix ? UKM_F_MIX_TAXID : 0, out.data(), with_t ? tout.data() : nullptr, cap, &n));
+        ck(ukm_inter_ft(g.c, p.k.data(), tp, fp, p.n.data(), ns, mix ? UKM_F_MIX_TAXID : 0, out.data(), with_t ? tout.data() : nullptr, cap, &n));
         if (n == 0) info("no intersection found");
         break;
     case C_DIFF: {
@@ -1031,9 +1045,9 @@ static int cmd_setop(SetCmd which, int argc, char **argv) {
         for (auto &L : in.files) sf.push_back(L.h.is_sorted() ? 1 : 0);
         // files equal (by path) to the first one are skipped (diff.go:464-466)
         Ptrs q; vector<uint8_t> sf2;
-        for (int i = 0; i < ns; i++) if (i == 0 || files[(size_t)i] != files[0]) { q.k.push_back(p.k[(size_t)i]); q.t.push_back(p.t[(size_t)i]); q.n.push_back(p.n[(size_t)i]); sf2.push_back(sf[(size_t)i]); }
-        ck(ukm_diff(g.c, q.k.data(), with_t ? q.t.data() : nullptr, q.n.data(), (int)q.k.size(), sf2.data(),
-                    cmp_taxid ? UKM_F_CMP_TAXID : 0, out.data(), with_t ? tout.data() : nullptr, cap, &n));
+        for (int i = 0; i < ns; i++) if (i == 0 || files[(size_t)i] != files[0]) { q.k.push_back(p.k[(size_t)i]); q.t.push_back(p.t[(size_t)i]); q.ft.push_back(p.ft[(size_t)i]); q.n.push_back(p.n[(size_t)i]); sf2.push_back(sf[(size_t)i]); }
+        ck(ukm_diff_ft(g.c, q.k.data(), with_t ? q.t.data() : nullptr, with_t ? q.ft.data() : nullptr, q.n.data(), (int)q.k.size(), sf2.data(),
+                       cmp_taxid ? UKM_F_CMP_TAXID : 0, out.data(), with_t ? tout.data() : nullptr, cap, &n));
         if (n == 0) fprintf(stderr, "[WARN] no set difference found\n");
         sorted_out = a.has("sort");
         tax = in.has_taxid;
@@ -1045,7 +1059,7 @@ static int cmd_setop(SetCmd which, int argc, char **argv) {
         if (ns > 65535) die("at most 65535 files supported");
         const u32 thr = ukm_common_threshold((u32)ns, prop, (u32)a.num("number", 0));
         info("searching k-mers shared by >= %u files ...", thr);
-        ck(ukm_common(g.c, p.k.data(), tp, p.n.data(), ns, thr, 0, out.data(), with_t ? tout.data() : nullptr, cap, &n));
+        ck(ukm_common_ft(g.c, p.k.data(), tp, fp, p.n.data(), ns, thr, 0, out.data(), with_t ? tout.data() : nullptr, cap, &n));
         break;
     }
     case C_SPLIT:
@@ -1088,7 +1102,7 @@ static int cmd_setop(SetCmd which, int argc, char **argv) {
             for (auto &L : in.files)
                 for (size_t i = 0; i < L.codes.size(); i++) {
                     cc.push_back(L.codes[i]);
-                    if (tax) ct.push_back(L.taxids[i]);
+                    if (tax) ct.push_back(L.taxid_of(i));
                     if (cc.size() >= step) flush_chunk();
                 }
             flush_chunk();
@@ -1100,7 +1114,13 @@ static int cmd_setop(SetCmd which, int argc, char **argv) {
         }
         vector<u64> all; vector<u32> allt;
         all.reserve(in.total);
-        for (auto &L : in.files) { all.insert(all.end(), L.codes.begin(), L.codes.end()); if (tax) allt.insert(allt.end(), L.taxids.begin(), L.taxids.end()); }
+        for (auto &L : in.files) {
+            all.insert(all.end(), L.codes.begin(), L.codes.end());
+            if (tax) {
+                if (L.per_record()) allt.insert(allt.end(), L.taxids.begin(), L.taxids.end());
+                else allt.insert(allt.end(), L.codes.size(), L.file_taxid);  // (one sort over all inputs: the array is what it takes)
+            }
+        }
         const int key_bits = in.hashed ? 64 : 2 * in.k;
         if (!all.empty()) {
             if (tax) ck(ukm_sort_pairs(g.c, all.data(), allt.data(), all.size(), key_bits));

@@ -32,6 +32,7 @@ SYMBOLS = [
     "ukm_comm_get_unique_id", "ukm_comm_init", "ukm_comm_destroy", "ukm_comm_info", "ukm_prefix_splitters",
     "ukm_shard_exchange", "ukm_shard_plan", "ukm_shard_counts", "ukm_shard_exchange_known",
     "ukm_shard_splitters", "ukm_shard_splitters_plan",
+    "ukm_ctx_set_option", "ukm_ctx_unset_option", "ukm_ctx_get_option", "ukm_ctx_get_stat",
     "ukm_setop2_ft", "ukm_union_ft", "ukm_inter_ft", "ukm_diff_ft", "ukm_common_ft", "ukm_merge_k_ft",
 ]
 
@@ -110,6 +111,10 @@ def load():
     L.ukm_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
     L.ukm_last_call_ms.argtypes = [vp, C.POINTER(C.c_float)]
     L.ukm_last_route.argtypes = [vp]
+    L.ukm_ctx_set_option.argtypes = [vp, C.c_char_p, C.c_longlong]
+    L.ukm_ctx_unset_option.argtypes = [vp, C.c_char_p]
+    L.ukm_ctx_get_option.argtypes = [vp, C.c_char_p, C.POINTER(C.c_longlong), C.POINTER(i32)]
+    L.ukm_ctx_get_stat.argtypes = [vp, C.c_char_p, C.POINTER(C.c_ulonglong)]
     L.ukm_taxonomy_load.argtypes = [vp, vp, vp, u64, vp, vp, u64]
     L.ukm_taxonomy_max_taxid.argtypes = [vp, C.POINTER(u32)]
     L.ukm_lca.argtypes = [vp, vp, vp, u64, vp]
@@ -253,6 +258,23 @@ class Context:
     def last_route(self):
         """which internal route answered the last n-way call (include/unikmer_hip.h: ukm_last_route)"""
         return int(self.L.ukm_last_route(self.h))
+
+    def set_option(self, key, value):
+        """route policy of this context (include/unikmer_hip.h: ukm_ctx_set_option); value None removes the override"""
+        if value is None:
+            _check(self.L.ukm_ctx_unset_option(self.h, key.encode()))
+        else:
+            _check(self.L.ukm_ctx_set_option(self.h, key.encode(), int(value)))
+
+    def get_option(self, key):
+        v, s = C.c_longlong(), C.c_int()
+        _check(self.L.ukm_ctx_get_option(self.h, key.encode(), C.byref(v), C.byref(s)))
+        return int(v.value) if s.value else None
+
+    def stat(self, key):
+        v = C.c_ulonglong()
+        _check(self.L.ukm_ctx_get_stat(self.h, key.encode(), C.byref(v)))
+        return int(v.value)
 
     def last_call_ms(self):
         ms = C.c_float()
