@@ -452,3 +452,77 @@ def test_config4_inter_diff_common_1000_files_x_1e6_full_size(env, monkeypatch, 
         same(ctx.common(files, nfiles - 1, taxs, out=okc, out_taxids=otc), "common_minus_1", "counted single pass")
         assert ctx.last_route() == 5
         monkeypatch.delenv("UKM_PUNION")
+
+
+def _draw_files(torch, bench, dev, nfiles, nu, p, T, salt):
+    """nfiles independent membership draws (probability p) over ONE universe of nu codes, a per-record taxid each"""
+    j = torch.arange(nu, dtype=torch.int64, device=dev)
+    U = torch.cumsum(1 + (bench.splitmix64_torch(j ^ bench._i64(bench.SEED + salt)) & ((1 << 32) - 1)), 0)
+    thr = int(p * (1 << 24))
+    files, taxs = [], []
+    for f in range(nfiles):
+        h = bench.splitmix64_torch(j ^ bench._i64(bench.SEED + salt + 1000 * (f + 1)))
+        k = U[((h >> 11) & ((1 << 24) - 1)) < thr]
+        files.append(k)
+        taxs.append((1 + (bench.splitmix64_torch(k ^ bench._i64(bench.SEED + 2 + f)) & ((1 << 40) - 1)) % T).to(torch.int32))
+    return files, taxs
+
+
+def test_default_routes_1000_files_x_1e6_full_size(env, monkeypatch):
+    """The routes the library picks BY DEFAULT for 1000 files x 1e6 records with taxids, at the size where it picks them, each
+    element for element against the oracle (round-4 review: they were only compared forced, on universes of <= 50,000 codes):
+      * keep-everything `merge` (mergeChunksFile's heap, util-sort.go:196-225,289-351) of files that share their codes
+        -> placement (route 7: range lengths, TaxIds eight files at a time, 16-bit code indices);
+      * the same of files that hold a fiftieth of a universe each -> the single pass (route 4: by-value passes of ranges
+        that do not fit a tile);
+      * `union` (union.go:186-305) of files that hold a tenth of a universe each -> the hash-probe union, whose first base
+        set misses the hit-rate guard and whose SECOND attempt with four times the files runs (ukm_ctx_get_stat).
+    No knob is set.  The oracle's heap merges of 1e9 records run in threads beside one another."""
+    torch, bench, lib, ctx, O, dev = env
+    from conftest import synth_tree
+    from concurrent.futures import ThreadPoolExecutor
+    for v in ("UKM_PUNION", "UKM_PLACE", "UKM_SRMERGE", "UKM_KWAY", "UKM_NO_KWAY", "UKM_PUNION_TAX"):
+        monkeypatch.delenv(v, raising=False)
+    child, parent = synth_tree(7, 8)
+    ctx.taxonomy_load(child, parent)
+    tax = O.Taxonomy(child, parent)
+    T = len(child)
+    nfiles, per = 1000, 1_000_000
+    shapes = {
+        "place": _config4_files(torch, bench, dev, nfiles, per, T, 0.3),                    # 90 % of a universe + a core
+        "single": _draw_files(torch, bench, dev, nfiles, 50 * per, 0.02, T, 31),            # a fiftieth of a universe each
+        "probe": _draw_files(torch, bench, dev, nfiles, 10 * per, 0.1, T, 47),              # a tenth each
+    }
+    host = {k: ([_np(x) for x in fs], [t.cpu().numpy().view(np.uint32) for t in ts]) for k, (fs, ts) in shapes.items()}
+    jobs = {
+        "place": lambda: O.merge_k(host["place"][0], host["place"][1], mode=O.PLAIN, tax=tax),
+        "single": lambda: O.merge_k(host["single"][0], host["single"][1], mode=O.PLAIN, tax=tax),
+        "probe": lambda: O.union(host["probe"][0], host["probe"][1], tax),
+    }
+    pool = ThreadPoolExecutor(len(jobs))
+    futs = {k: pool.submit(f) for k, f in jobs.items()}
+
+    def same(got, name):
+        gk, gt = got
+        wk, wt = futs[name].result()
+        assert gk.numel() == len(wk), (name, gk.numel(), len(wk))
+        assert np.array_equal(_np(gk), wk), name
+        assert np.array_equal(gt.cpu().numpy().view(np.uint32), wt), name
+    for name, route in (("place", 7), ("single", 4)):
+        files, taxs = shapes[name]
+        total = sum(x.numel() for x in files)
+        assert 0.8e9 < total < 1.3e9
+        ok = torch.empty(total + 8, dtype=torch.int64, device=dev)
+        ot = torch.empty(total + 8, dtype=torch.int32, device=dev)
+        got = ctx.merge_k(files, taxs, mode=lib.PLAIN, out=ok, out_taxids=ot)
+        assert ctx.last_route() == route, (name, ctx.last_route())
+        same(got, name)
+        del ok, ot, got
+    files, taxs = shapes["probe"]
+    total = sum(x.numel() for x in files)
+    ok = torch.empty(10 * per + 8, dtype=torch.int64, device=dev)
+    ot = torch.empty(10 * per + 8, dtype=torch.int32, device=dev)
+    got = ctx.union(files, taxs, out=ok, out_taxids=ot)
+    assert ctx.last_route() == 3 and ctx.stat("punion_attempts") == 2, (ctx.last_route(), ctx.stat("punion_attempts"))
+    same(got, "probe")
+    pool.shutdown()

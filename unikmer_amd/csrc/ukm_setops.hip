@@ -1121,7 +1121,11 @@ int ukm_dev_setop2_link(ukm_ctx *c, int op, const u64 *a, const u32 *ta, u64 na_
     }
     if (tax) launch_op<true, false, NTS, VT_TAX>(op, p, c->stream, c->setop_force_ticket);
     else if (ct) launch_op<false, false, NTS, VT_PLAIN, true>(op, p, c->stream, c->setop_force_ticket);
-    else launch_op<false, false, NTS, VT_PLAIN>(op, p, c->stream, c->setop_force_ticket);
+    else {
+        launch_op<false, false, NTS, VT_PLAIN>(op, p, c->stream, c->setop_force_ticket);
+        // (neither stream carries taxids but the fold's later files do: these records have taxid 0)
+        if (tout && out_cap) UKM_HIP(hipMemsetAsync(tout, 0, out_cap * sizeof(u32), c->stream));
+    }
     UKM_HIP(hipGetLastError());
     return UKM_OK;
 }
@@ -1198,6 +1202,9 @@ int ukm_dev_setop2_ct(ukm_ctx *c, int op, const u64 *a, const u32 *ta, u32 cta, 
     if (res[0] > out_cap)
         UKM_FAIL(UKM_ERR_CAPACITY, "ukm_setop2: output needs %llu records, capacity is %llu",
                  (unsigned long long)res[0], (unsigned long long)out_cap);
+    // the caller wants taxids but neither stream carries any (two files without taxid information inside an n-file
+    // operation whose other files have some; the only stream with taxids is empty): such records have taxid 0
+    if (!tax && tout && res[0]) UKM_HIP(hipMemsetAsync(tout, 0, res[0] * sizeof(u32), c->stream));
     return UKM_OK;
 }
 
@@ -1226,9 +1233,6 @@ extern "C" int ukm_setop2_ft(ukm_ctx *ctx, int op, const uint64_t *a_keys, const
         const u32 cta = ta ? 0u : a_file_taxid, ctb = tb ? 0u : b_file_taxid;
         int r = ukm_dev_setop2_ct(ctx, op, a, ta, cta, na, b, tb, ctb, nb, flags & (UKM_F_MIX_TAXID | UKM_F_CMP_TAXID), out, tout, out_cap, n_out);
         u64 n = (r == UKM_OK) ? *n_out : 0;
-        // the caller asked for taxids but no record carries one (e.g. the only stream with taxids is
-        // empty): records without a taxid have taxid 0
-        if (r == UKM_OK && tout && !ta && !tb && !cta && !ctb && n) UKM_HIP(hipMemsetAsync(tout, 0, n * sizeof(u32), ctx->stream));
         ukm_out_resize(ctx, out_keys, n * sizeof(u64));
         if (out_taxids) ukm_out_resize(ctx, out_taxids, n * sizeof(u32));
         return r;
