@@ -504,6 +504,38 @@ def main():
                 del Ao, Bo
             except Exception as e:
                 incl["offset_sharded_start"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
+            # The same end-to-end step through the LIBRARY'S OWN exchange -- ukm_comm_init + ukm_shard_counts +
+            # ukm_shard_exchange_known (grouped ncclSend / ncclRecv in ukm_comm.hip), the calls INTEGRATION.md's Go host
+            # makes; torch.distributed only hands the communicator id over.  RCCL wants one device per rank, so the 1-GPU
+            # test hook skips it.
+            if one_gpu:
+                incl["exchange_cabi"] = {"skipped": "UKM_BENCH_ONE_GPU: RCCL does not take two ranks on one device"}
+            else:
+                try:
+                    ud.comm_init_from_dist(ctx)
+
+                    def step_cabi():
+                        (Al, Bl), _ = ud.redistribute_cabi(ctx, [Af, Bf], 62)
+                        u = ctx.setop2(lib.OP_UNION, Al, Bl, out=out_u)
+                        i = ctx.setop2(lib.OP_INTER, Al, Bl, out=out_i)
+                        return Al, Bl, u, i
+                    Al, Bl, cu, ci = step_cabi()
+                    assert torch.equal(Al, A) and torch.equal(Bl, B), "C-ABI redistribution did not rebuild the rank's range"
+                    assert cu.numel() == nu and ci.numel() == ni
+                    del Al, Bl
+                    barrier()
+                    t3 = time.perf_counter()
+                    for _ in range(args.steps):
+                        step_cabi()
+                    barrier()
+                    t3 = max_over_ranks(time.perf_counter() - t3)
+                    incl["exchange_cabi"] = {
+                        "value": 2.0 * g_in * args.steps / t3, "unit": "k-mers/s", "ms_per_step": t3 * 1e3 / args.steps,
+                        "note": "the end-to-end step with the exchange behind the C ABI (ukm_shard_counts + "
+                                "ukm_shard_exchange_known per set, ukm_merge_k of the received slices): what a Go host runs"}
+                    ctx.comm_destroy()
+                except Exception as e:
+                    incl["exchange_cabi"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
             # the bare all-to-all-v of one set, for the link rate
             counts = ud.cuts_to_counts(ctx.partition_points(Af, spl), Af.numel())
             barrier()
@@ -538,6 +570,8 @@ def main():
                 res["incl_exchange"] = incl
                 if "value" in incl.get("offset_sharded_start", {}):
                     res["value_offset_sharded_start"] = incl["offset_sharded_start"]["value"]
+                if "value" in incl.get("exchange_cabi", {}):
+                    res["value_exchange_cabi"] = incl["exchange_cabi"]["value"]
             else:
                 res["value_is"] = ("PRE-PARTITIONED (no redistribution in the timed region): " +
                                    ("--no-exchange was given" if args.no_exchange else "the end-to-end leg failed, see `exchange`"))

@@ -141,8 +141,10 @@ int ukm_ctx_get_stat(ukm_ctx *ctx, const char *key, unsigned long long *value);
  *      merged ids are remapped; ids absent from nodes.dmp -> 0.
  *      The device tables are dense in the taxid (>= 25 bytes per id up to the largest one, 16 more per id for every four
  *      levels of depth): NCBI's dump takes ~0.7 GB; a dump with sparse huge ids is refused (UKM_ERR_NOMEM, message says
- *      how much it would need) when that exceeds the device's free memory.  A load either replaces the context's taxonomy
- *      completely or, on any error, leaves the previous one in place. */
+ *      how much it would need) when that exceeds the device's free memory -- counted after the context's cached workspace
+ *      has been given back and with the tables being replaced credited.  A load either replaces the context's taxonomy
+ *      completely or, on any error, leaves the previous one in place (one exception: new tables that only fit WITHOUT the
+ *      old ones make the old ones go first; a failure after that leaves the context without a taxonomy). */
 int ukm_taxonomy_load(ukm_ctx *ctx, const uint32_t *child, const uint32_t *parent, uint64_t n,
                       const uint32_t *merged_old, const uint32_t *merged_new, uint64_t m);
 int ukm_taxonomy_max_taxid(ukm_ctx *ctx, uint32_t *max_taxid); /* taxdump.MaxTaxid, util.go:169 */
@@ -303,7 +305,10 @@ int ukm_shard_plan(int nranks, int rank, const uint64_t *all, uint64_t *recv_cou
  *      k-mers start AAAAAAAAA... -- so equal-width ranges leave the ranks unevenly loaded): ukm_shard_splitters is
  *      collective; every rank passes the sorted files it holds and gets the same nranks + 1 boundaries, cut so that the
  *      ranks receive about the same number of records (1024 regular samples per rank, one all-gather).  Use them in
- *      place of ukm_prefix_splitters; any non-decreasing boundaries give the same concatenated result.
+ *      place of ukm_prefix_splitters; any non-decreasing boundaries give the same concatenated result.  A rank that
+ *      fails locally (bad argument, no memory for staging) still takes part in the gather with no records and returns its
+ *      error afterwards, so its peers are not left waiting; only a rank that cannot even allocate the 8 KB gather buffers
+ *      hangs them (destroy the communicator, as after any lost rank).  Host arrays are sampled where they lie.
  *      ukm_shard_splitters_plan is the decision as a pure host function over the gathered words
  *      ([rank][1 + per_rank] = record count, samples). */
 int ukm_shard_splitters(ukm_ctx *ctx, const uint64_t *const *keys, const uint64_t *lens, int nfiles, int key_bits,

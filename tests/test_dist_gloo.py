@@ -396,3 +396,31 @@ def test_shard_splitters_plan_weights_and_empty_ranks():
     assert 300 <= sp[1] <= 400 and 600 <= sp[2] <= 700           # thirds of the WEIGHTED mass, not of the sample list
     assert lib.Context.shard_splitters_plan(4, np.zeros((4, M + 1), np.uint64), 62) == ud.prefix_splitters(62, 4)
     assert lib.Context.shard_splitters_plan(2, np.zeros((2, M + 1), np.uint64), 64) == ud.prefix_splitters(64, 2)
+
+
+@pytest.mark.parametrize("world", [4, 8])
+@pytest.mark.parametrize("sharding", ["stride", "offset"])
+def test_sampled_splitters_balance_w4_w8_simulated_ranks(world, sharding):
+    """SURVEY 8(e) at the widths the metric names (4 and 8 GPUs): the boundaries ukm_shard_splitters_plan cuts from 1024
+    samples per rank leave every rank within 5 % of the mean on the distinct canonical 31-mers of the fixture genome
+    (equal-width prefix ranges: the largest rank holds 1.6 x / 1.9 x the mean).  The ranks are simulated: each one's gathered
+    words (record count + samples at the positions dist.sampled_splitters / ukm_shard_splitters take) are built here and
+    handed to the pure host function both of them call."""
+    from unikmer_amd import lib
+    codes = _canonical_kmers()
+    S = ud.SPLIT_SAMPLES
+    g = np.zeros((world, S + 1), np.uint64)
+    for r in range(world):
+        mine = codes[r::world] if sharding == "stride" else codes[r * len(codes) // world:(r + 1) * len(codes) // world]
+        n = len(mine)
+        g[r, 0] = n
+        g[r, 1:] = mine[[((2 * i + 1) * n) // (2 * S) for i in range(S)]]
+    sp = lib.Context.shard_splitters_plan(world, g, 62)
+    assert sp[0] == 0 and sp[-1] == 1 << 62 and all(a <= b for a, b in zip(sp, sp[1:]))
+    cuts = np.searchsorted(codes, np.array(sp[1:-1], dtype=np.uint64))
+    sizes = np.diff(np.concatenate([[0], cuts, [len(codes)]])).astype(np.float64)
+    assert sizes.max() / sizes.mean() < 1.05, (world, sharding, sizes.max() / sizes.mean())
+    eq = ud.prefix_splitters(62, world)
+    ecuts = np.searchsorted(codes, np.array(eq[1:-1], dtype=np.uint64))
+    esizes = np.diff(np.concatenate([[0], ecuts, [len(codes)]])).astype(np.float64)
+    assert esizes.max() / esizes.mean() > (1.5 if world == 4 else 1.8)

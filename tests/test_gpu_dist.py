@@ -223,6 +223,9 @@ def test_bench_two_ranks_incl_exchange():
     off = res["incl_exchange"]["offset_sharded_start"]
     assert "error" not in off, off
     assert off["value"] > 0 and res["value_offset_sharded_start"] == off["value"]
+    # the leg through the library's own exchange needs one device per rank (RCCL): recorded as skipped on this box;
+    # tests/test_gpu_dist.py::test_redistribute_through_the_c_abi_one_rank runs the same calls on a one-rank communicator
+    assert "skipped" in res["incl_exchange"]["exchange_cabi"]
     assert res["incl_exchange"]["steps"] == 2 and res["config"]["per_gpu_set_size"] == 1_000_000
     assert res["config"]["global_set_size"] == 2_000_000
     assert res["roofline"]["frac"] > 0 and res["cpu_baseline"] is None
@@ -308,4 +311,29 @@ def test_c_abi_rccl_exchange_one_rank():
     ctx.comm_destroy()
     with pytest.raises(lib.UkmError):
         ctx.shard_exchange(keys, [len(keys)])
+    ctx.close()
+
+
+def test_redistribute_through_the_c_abi_one_rank():
+    """dist.redistribute_cabi = INTEGRATION.md's Go loop (ukm_partition_points -> ONE ukm_shard_counts for all files ->
+    ukm_shard_exchange_known per file -> ukm_merge_k of the received slices), the leg bench.py --gpus N times beside the
+    torch.distributed one.  One GPU allows a one-rank communicator only: the calls, the count tables and the rebuild run;
+    the result is the input."""
+    import torch
+    from unikmer_amd import dist as ud
+    from unikmer_amd import lib
+    dev = torch.device("cuda", 0)
+    ctx = lib.Context(0, stream=torch.cuda.current_stream(dev).cuda_stream)
+    ctx.comm_init(1, 0, lib.Context.comm_unique_id())
+    rng = np.random.default_rng(9)
+    files = [np.unique(rng.integers(0, 1 << 62, n, dtype=np.uint64)) for n in (200_000, 1, 50_000)]
+    taxs = [rng.integers(1, 999, len(f)).astype(np.uint32) for f in files]
+    tf = [torch.from_numpy(f.view(np.int64)).to(dev) for f in files]
+    tt = [torch.from_numpy(t.view(np.int32)).to(dev) for t in taxs]
+    local, local_t = ud.redistribute_cabi(ctx, tf, 62, tt)
+    for f, t, lk, lt in zip(files, taxs, local, local_t):
+        assert np.array_equal(lk.cpu().numpy().view(np.uint64), f) and np.array_equal(lt.cpu().numpy().view(np.uint32), t)
+    local, none = ud.redistribute_cabi(ctx, tf, 62)
+    assert none is None and all(np.array_equal(lk.cpu().numpy().view(np.uint64), f) for f, lk in zip(files, local))
+    ctx.comm_destroy()
     ctx.close()

@@ -405,7 +405,9 @@ extern "C" int ukm_shard_exchange(ukm_ctx *c, const uint64_t *keys, const uint32
 }
 
 // Collective: splitters[nranks + 1] (host) for this rank's sorted files `keys` (host or device pointers).  One small
-// kernel, one all-gather of 1025 words per rank, one host synchronisation; every rank returns the same array.
+// kernel (device files; host files are sampled where they lie), one all-gather of 1025 words per rank; every rank that
+// succeeds returns the same array.  A rank that fails locally still takes part in the gather (with no records) and returns
+// its error afterwards.
 extern "C" int ukm_shard_splitters(ukm_ctx *c, const uint64_t *const *keys, const uint64_t *lens, int nfiles, int key_bits,
                                    uint64_t *splitters) {
     if (!c || !splitters || nfiles < 0 || (nfiles && (!keys || !lens)) || key_bits < 1 || key_bits > 64)
@@ -417,35 +419,90 @@ extern "C" int ukm_shard_splitters(ukm_ctx *c, const uint64_t *const *keys, cons
     CallScope s;
     UKM_TRY(ukm_begin(c, &s));
     int rc = [&]() -> int {
-        // staged pointer / offset table: [keys nfiles][base nfiles + 1]
-        std::vector<u64> tab((size_t)2 * nfiles + 1, 0);
-        u64 n = 0;
-        int live = 0;
-        for (int f = 0; f < nfiles; f++) {
-            if (lens[f] == 0) continue;
-            const u64 *dk = nullptr;
-            UKM_TRY(ukm_in_t(c, keys[f], lens[f], &dk));
-            tab[(size_t)live] = (u64)(uintptr_t)dk;
-            tab[(size_t)nfiles + live] = n;
-            n += lens[f];
-            live++;
-        }
-        tab[(size_t)nfiles + live] = n;
-        u64 *d_mine = nullptr, *d_all = nullptr, *d_tab = nullptr;
+        // The gather buffers first: without them this rank cannot take part at all (the one failure that leaves the
+        // peers waiting in RCCL -- destroy the communicator, as after any lost rank).  Everything that can fail LOCALLY
+        // after this point (staging, the sample kernel) happens in `prep`; a rank whose prep failed still joins the
+        // all-gather, with a record count of 0, and reports its error afterwards: its peers get splitters from the ranks
+        // that did contribute and nobody hangs (round-4 advice).
+        u64 *d_mine = nullptr, *d_all = nullptr;
         UKM_TRY(ws_alloc_t(c, (size_t)M + 1, &d_mine));
         UKM_TRY(ws_alloc_t(c, ((size_t)M + 1) * W, &d_all));
-        UKM_TRY(ws_alloc_t(c, tab.size(), &d_tab));
-        UKM_HIP(hipMemsetAsync(d_mine, 0, ((size_t)M + 1) * sizeof(u64), c->stream));
-        UKM_HIP(hipMemcpyAsync(d_mine, &n, sizeof(u64), hipMemcpyHostToDevice, c->stream));
-        UKM_HIP(hipMemcpyAsync(d_tab, tab.data(), tab.size() * sizeof(u64), hipMemcpyHostToDevice, c->stream));
-        if (n)
-            hipLaunchKernelGGL(shard_sample_kernel, dim3((M + 255) / 256), dim3(256), 0, c->stream,
-                               reinterpret_cast<const u64 *const *>(d_tab), d_tab + nfiles, live, n, M, d_mine);
-        UKM_HIP(hipGetLastError());
+        std::vector<u64> mine((size_t)M + 1, 0);
+        bool mine_on_host = false;
+        const int prc = [&]() -> int {
+            u64 n = 0;
+            int live = 0;
+            bool all_host = true;
+            for (int f = 0; f < nfiles; f++)
+                if (lens[f]) {
+                    if (!keys[f]) UKM_FAIL(UKM_ERR_INVALID, "ukm_shard_splitters: file %d: keys is NULL", f);
+                    all_host = all_host && !ukm_is_device_ptr(keys[f]);
+                    n += lens[f];
+                    live++;
+                }
+            if (all_host) {
+                // host arrays: the M samples are read where they lie -- nothing is staged (the whole files used to be)
+                mine[0] = n;
+                std::vector<u64> base((size_t)live + 1, 0);
+                std::vector<const u64 *> kp((size_t)live);
+                for (int f = 0, q = 0; f < nfiles; f++)
+                    if (lens[f]) {
+                        kp[(size_t)q] = keys[f];
+                        base[(size_t)q + 1] = base[(size_t)q] + lens[f];
+                        q++;
+                    }
+                for (int i = 0, f = 0; i < M && n; i++) {
+                    const u64 pos = (u64)(((unsigned __int128)(2 * (u64)i + 1) * n) / (2 * (u64)M));
+                    while (pos >= base[(size_t)f + 1]) f++;
+                    mine[(size_t)1 + i] = kp[(size_t)f][pos - base[(size_t)f]];
+                }
+                mine_on_host = true;
+                return UKM_OK;
+            }
+            // staged pointer / offset table: [keys nfiles][base nfiles + 1]
+            std::vector<u64> tab((size_t)2 * nfiles + 1, 0);
+            n = 0;
+            live = 0;
+            for (int f = 0; f < nfiles; f++) {
+                if (lens[f] == 0) continue;
+                const u64 *dk = nullptr;
+                UKM_TRY(ukm_in_t(c, keys[f], lens[f], &dk));
+                tab[(size_t)live] = (u64)(uintptr_t)dk;
+                tab[(size_t)nfiles + live] = n;
+                n += lens[f];
+                live++;
+            }
+            tab[(size_t)nfiles + live] = n;
+            u64 *d_tab = nullptr;
+            UKM_TRY(ws_alloc_t(c, tab.size(), &d_tab));
+            UKM_HIP(hipMemsetAsync(d_mine, 0, ((size_t)M + 1) * sizeof(u64), c->stream));
+            UKM_HIP(hipMemcpyAsync(d_mine, &n, sizeof(u64), hipMemcpyHostToDevice, c->stream));
+            UKM_HIP(hipMemcpyAsync(d_tab, tab.data(), tab.size() * sizeof(u64), hipMemcpyHostToDevice, c->stream));
+            if (n)
+                hipLaunchKernelGGL(shard_sample_kernel, dim3((M + 255) / 256), dim3(256), 0, c->stream,
+                                   reinterpret_cast<const u64 *const *>(d_tab), d_tab + nfiles, live, n, M, d_mine);
+            UKM_HIP(hipGetLastError());
+            UKM_HIP(hipStreamSynchronize(c->stream));  // (`n` and `tab` are host objects of this frame)
+            return UKM_OK;
+        }();
+        std::string perr;
+        if (prc != UKM_OK) {
+            perr = ukm_last_error();
+            std::fill(mine.begin(), mine.end(), 0);  // contributes nothing: the plan ignores ranks without records
+            mine_on_host = true;
+        }
+        if (mine_on_host) {
+            UKM_HIP(hipMemcpyAsync(d_mine, mine.data(), mine.size() * sizeof(u64), hipMemcpyHostToDevice, c->stream));
+            UKM_HIP(hipStreamSynchronize(c->stream));
+        }
         UKM_NCCL(R->AllGather(d_mine, d_all, (size_t)M + 1, UKM_NCCL_UINT64, (UkmNcclComm)c->comm, c->stream));
         std::vector<u64> all(((size_t)M + 1) * W);
         UKM_HIP(hipMemcpyAsync(all.data(), d_all, all.size() * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
-        UKM_HIP(hipStreamSynchronize(c->stream));  // (`n` and `tab` are host objects of this frame)
+        UKM_HIP(hipStreamSynchronize(c->stream));
+        if (prc != UKM_OK) {
+            ukm_set_error("%s", perr.c_str());
+            return prc;
+        }
         return ukm_shard_splitters_plan(W, M, all.data(), key_bits, splitters);
     }();
     return ukm_finish(&s, rc);

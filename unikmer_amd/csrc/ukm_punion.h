@@ -11,7 +11,7 @@ int ukm_punion_tax_mode(const ukm_ctx *c);
 // caller's k-way merge answers; nothing was written that matters.
 // tax: the records carry TaxIds (taxids[j] may be null: all 0); the result's TaxId is the LCA over every record of a code.
 int ukm_dev_probe_union(ukm_ctx *c, const u64 *const *keys, const u32 *const *taxids, const u64 *lens, int S, bool tax, u64 *out,
-                        u32 *tout, u64 out_cap, u64 *n_out, bool *fallback, const u32 *ctax = nullptr);
+                        u32 *tout, u64 out_cap, u64 *n_out, bool *fallback, const u32 *ctax = nullptr, bool overlap_known = false);
 // (ctax, may be null: the ONE taxid of a file whose taxids[j] is null -- the .unik header's global taxid; such a file's
 //  records load no taxid and look no pre-order number up)
 // `common` below the number of files through the same tables with a record count per entry; keys[0] = the first file as a

@@ -843,31 +843,40 @@ __global__ __launch_bounds__(PT_NT) __attribute__((amdgpu_waves_per_eu(PT_WAVES,
 // New codes are claimed in the table as in the other kernels and leave with their settled taxid when the range is done;
 // what cannot be claimed (all-ones codes, a table that has doubled) is listed record by record with the file's taxid and
 // the final sort + unique + 2-way union folds it (associativity is all that is used).
-constexpr int PR_NT = 512;
-constexpr int PR_BUCKETS = 1536;     // x 4 slots x (8 + 4) bytes = 72 KB of LDS: two workgroups per CU
-constexpr int PR_SLOTS = 4 * PR_BUCKETS;
-constexpr int PR_RANGE = PR_BUCKETS; // base entries per range (a table takes as many new codes again)
 constexpr u32 PR_NONE = 0xFFFFFFFFu; // no file yet
 constexpr u32 PR_MAX_RANK = 0xFFFEu;
-
-__device__ __forceinline__ u32 pr_hash(u64 x) {
-    const u32 lo = (u32)x, hi = (u32)(x >> 32);
-    return (u32)(((u64)((lo ^ (hi * 0x85EBCA6Bu)) * 0x9E3779B1u) * (u64)PR_BUCKETS) >> 32);
-}
 
 struct PrTables {
     const u32 *tax_of_rank;  // [D + 1]
     const u32 *eul_of_rank;  // [D + 1]: the pre-order number of the rank's taxid (non-decreasing in the rank)
     u32 *base_st;            // [n0] in / out: the rank interval of every base entry
+    // the settled taxid of every (smallest rank, largest rank) pair, [D + 1][D + 1], when the call has at most PR_PAIR_MAX
+    // distinct taxids (pr_pairs_kernel): 2e8 entries then settle with one cached read instead of an LCA each
+    u32 *pair;
+    u32 D;
 };
+constexpr u32 PR_PAIR_MAX = 1024;
 
-__device__ __forceinline__ u32 pr_settle(const PrTables &t, const TaxDev &T, u32 w) {
-    const u32 mn = w & 0xFFFFu, mx = 0xFFFFu - (w >> 16);
-    if (w == PR_NONE) return 0u;  // (no file held the code: cannot happen for an entry that is in the table)
+__device__ __forceinline__ u32 pr_settle_pair(const PrTables &t, const TaxDev &T, u32 mn, u32 mx) {
     if (mn == mx) return t.tax_of_rank[mn];
     const u32 en = t.eul_of_rank[mn], ex = t.eul_of_rank[mx];
     if (en == 0u) return 0u;
     return lca_dev(T, T.node_at[en], T.node_at[ex]);
+}
+
+__device__ __forceinline__ u32 pr_settle(const PrTables &t, const TaxDev &T, u32 w) {
+    const u32 mn = w & 0xFFFFu, mx = 0xFFFFu - (w >> 16);
+    if (w == PR_NONE || mn > mx || mx > t.D) return 0u;  // (no file held the code: cannot happen for an entry that is in the table)
+    if (t.pair) return t.pair[(size_t)mn * (t.D + 1) + mx];
+    return pr_settle_pair(t, T, mn, mx);
+}
+
+__global__ void pr_pairs_kernel(PrTables t, TaxDev T) {
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    const u32 W = t.D + 1;
+    if (i >= W * W) return;
+    const u32 mn = i / W, mx = i % W;
+    t.pair[i] = (mn >= 1 && mn <= mx) ? pr_settle_pair(t, T, mn, mx) : 0u;
 }
 
 __global__ void pr_settle_kernel(PrTables t, TaxDev T, u64 n0, u32 *base_tax) {
@@ -875,53 +884,80 @@ __global__ void pr_settle_kernel(PrTables t, TaxDev T, u64 n0, u32 *base_tax) {
     if (i < n0) base_tax[i] = pr_settle(t, T, t.base_st[i]);
 }
 
-// A bucket = four codes AND their four rank words, 48 bytes side by side: a record's look-up reads the words with the codes
-// (three ds_read_b128 issued together) instead of going back for one word once the code has been found -- one LDS round trip
-// per record, as in the plain kernel.
-struct __attribute__((aligned(16))) PrBucket {
-    u64 k[4];
-    u32 st[4];
-};
+// Table layout (round 5, after the PMC of the other probe kernels: LDS 60-70 % busy, two thirds of it bank conflicts of the
+// random 16-byte reads -- the bytes a record reads from LDS are what the pass costs): per bucket of four slots ONE 16-byte
+// word of 4-byte TAGS (a second hash of the code, never 0; 0 = slot free), the 8-byte codes and the 4-byte rank words in
+// arrays of their own.  A record reads its bucket's tags (16 bytes), then -- only of the slot whose tag matches -- the code
+// (8 bytes, the exact check) and the rank word (4 bytes): 28 bytes instead of the 48 of codes + words side by side.  The
+// CODES stay the authority: a slot is claimed by a 64-bit CAS on its code, its tag is stored afterwards; a reader that
+// misses a tag that is not there yet (or meets a false positive) falls through to the claim, which walks the codes.
+constexpr int PR_TNT = 1024;          // one workgroup of 16 waves per CU
+constexpr int PR_TBUCKETS = 2304;     // x 4 slots x (4 + 8 + 4) bytes = 144 KB of LDS
+constexpr int PR_TSLOTS = 4 * PR_TBUCKETS;
+__device__ __forceinline__ u32 prt_bucket(u64 x) {
+    const u32 lo = (u32)x, hi = (u32)(x >> 32);
+    return (u32)(((u64)((lo ^ (hi * 0x85EBCA6Bu)) * 0x9E3779B1u) * (u64)PR_TBUCKETS) >> 32);
+}
+__device__ __forceinline__ u32 prt_tag(u64 x) {
+    const u32 lo = (u32)x, hi = (u32)(x >> 32);
+    const u32 t = (hi * 0xC2B2AE35u) ^ (lo * 0x27D4EB2Fu) ^ (lo >> 15);
+    return t ? t : 1u;
+}
 
-__global__ __launch_bounds__(PR_NT) __attribute__((amdgpu_waves_per_eu(4, 4))) void pr_probe_kernel(PuArgs a, PrTables t) {
-    __shared__ PrBucket s_b[PR_BUCKETS];
+__global__ __launch_bounds__(PR_TNT) __attribute__((amdgpu_waves_per_eu(4, 4))) void pr_probe_kernel(PuArgs a, PrTables t) {
+    __shared__ __attribute__((aligned(16))) u32 s_tag[PR_TSLOTS];
+    __shared__ __attribute__((aligned(16))) u64 s_key[PR_TSLOTS];
+    __shared__ u32 s_st[PR_TSLOTS];
     __shared__ u32 s_next, s_nins;
-    __shared__ u32 s_scan[PR_NT / 64 + 1];
+    __shared__ u32 s_scan[PR_TNT / 64 + 1];
     __shared__ u64 s_flush_at;
     const int tid = (int)threadIdx.x, lane = lane_id();
     const u32 r = blockIdx.x, S1 = a.S1;
-    for (int i = tid; i < PR_BUCKETS; i += PR_NT) {
-        uint4 *bp = reinterpret_cast<uint4 *>(&s_b[i]);
-        bp[0] = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);  // (PU_EMPTY, PU_EMPTY)
-        bp[1] = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
-        bp[2] = make_uint4(PR_NONE, PR_NONE, PR_NONE, PR_NONE);
+    for (int i = tid; i < PR_TSLOTS; i += PR_TNT) {
+        s_tag[i] = 0u;
+        s_key[i] = PU_EMPTY;
+        s_st[i] = PR_NONE;
     }
     if (tid == 0) { s_next = 0; s_nins = 0; }
     __syncthreads();
-    auto next_bucket = [](u32 h) -> u32 { return h + 1 == (u32)PR_BUCKETS ? 0u : h + 1; };
-    // first free slot of the first bucket of the probe sequence that is not full, or the slot that already holds x
+    auto next_bucket = [](u32 h) -> u32 { return h + 1 == (u32)PR_TBUCKETS ? 0u : h + 1; };
+    // first free slot of the first bucket of the probe sequence that is not full, or the slot that already holds x (the
+    // codes are the authority; the tag of a fresh slot is stored behind the claim)
     auto insert = [&](u64 x, bool &fresh) -> int {
-        u32 h = pr_hash(x);
+        u32 h = prt_bucket(x);
         for (;; h = next_bucket(h)) {
 #pragma unroll
             for (int k = 0; k < 4; k++) {
-                const u64 old = atomicCAS((unsigned long long *)&s_b[h].k[k], (unsigned long long)PU_EMPTY, (unsigned long long)x);
+                const u64 old = atomicCAS((unsigned long long *)&s_key[4 * h + k], (unsigned long long)PU_EMPTY, (unsigned long long)x);
                 if (old == PU_EMPTY || old == x) {
                     fresh = old == PU_EMPTY;
+                    if (fresh) s_tag[4 * h + k] = prt_tag(x);
                     return (int)(4 * h + k);
                 }
             }
         }
     };
+    // (the slow, exact way: walk the codes of x's probe sequence)
+    auto find_codes = [&](u64 x) -> int {
+        if (x == PU_EMPTY) return -1;
+        u32 h = prt_bucket(x);
+        for (;; h = next_bucket(h)) {
+            const ulonglong2 *b = reinterpret_cast<const ulonglong2 *>(&s_key[4 * h]);
+            const ulonglong2 p = b[0], q = b[1];
+            const int k = p.x == x ? 0 : (p.y == x ? 1 : (q.x == x ? 2 : (q.y == x ? 3 : -1)));
+            if (k >= 0) return (int)(4 * h) + k;
+            if (q.y == PU_EMPTY) return -1;
+        }
+    };
     const u64 b0 = (u64)r * a.range;
     const u32 nb = (u32)((a.n0 - b0 < (u64)a.range) ? (a.n0 - b0) : (u64)a.range);
-    constexpr int PER = (PR_RANGE + PR_NT - 1) / PR_NT;
+    constexpr int PER = (PR_TBUCKETS + PR_TNT - 1) / PR_TNT;
     u64 ent[PER];
     u32 est[PER];
     int eslot[PER];
 #pragma unroll
     for (int i = 0; i < PER; i++) {
-        const u32 idx = (u32)tid + (u32)i * PR_NT;
+        const u32 idx = (u32)tid + (u32)i * PR_TNT;
         ent[i] = a.base[b0 + (idx < nb ? idx : 0)];
         est[i] = t.base_st[b0 + (idx < nb ? idx : 0)];
         if (idx >= nb) ent[i] = PU_EMPTY;
@@ -932,20 +968,9 @@ __global__ __launch_bounds__(PR_NT) __attribute__((amdgpu_waves_per_eu(4, 4))) v
         if (ent[i] == PU_EMPTY) continue;  // (an all-ones code: its records are listed, the final union folds them)
         bool fresh;
         eslot[i] = insert(ent[i], fresh);
-        s_b[eslot[i] >> 2].st[eslot[i] & 3] = est[i];
+        s_st[eslot[i]] = est[i];
     }
     __syncthreads();
-    // (the slow way: the first bucket of x's probe sequence was full and did not hold it)
-    auto find_from = [&](u64 x, u32 h) -> int {
-        for (;;) {
-            const ulonglong2 *b = reinterpret_cast<const ulonglong2 *>(&s_b[h]);
-            const ulonglong2 p = b[0], q = b[1];
-            const int k = p.x == x ? 0 : (p.y == x ? 1 : (q.x == x ? 2 : (q.y == x ? 3 : -1)));
-            if (k >= 0) return x != PU_EMPTY ? (int)(4 * h) + k : -1;
-            if (q.y == PU_EMPTY) return -1;
-            h = next_bucket(h);
-        }
-    };
     const u64 lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
     u64 chunk_at = 0, fill = 0;  // wave-uniform
     u32 fill_t = 0;
@@ -984,9 +1009,9 @@ __global__ __launch_bounds__(PR_NT) __attribute__((amdgpu_waves_per_eu(4, 4))) v
         }
         chunk_used += n;
     };
-    // widen the interval of `slot` by a file of rank rk (crk = its complement); only called when it does widen or may
+    // widen the interval of `slot` by a file of rank rk (crk = its complement)
     auto widen = [&](int slot, u32 rk, u32 crk) {
-        u32 *w = &s_b[slot >> 2].st[slot & 3];
+        u32 *w = &s_st[slot];
         u32 old = *w;
         for (;;) {
             const u32 mn = old & 0xFFFFu, cmx = old >> 16;
@@ -997,13 +1022,14 @@ __global__ __launch_bounds__(PR_NT) __attribute__((amdgpu_waves_per_eu(4, 4))) v
             old = prev;
         }
     };
-    // the rare part of a record: not settled by the first bucket read (`slot` from the slow search, or -1), or its rank lies
-    // outside the entry's interval
+    // the rare part of a record: the tags did not settle it (slot < 0: look the codes up, claim a slot or list the record), or
+    // its file's rank lies outside the entry's interval
     auto rare = [&](bool valid, int slot, u64 x, u32 rk, u32 crk, u32 ftax) {
         bool raw = false;
         if (valid) {
+            if (slot < 0) slot = find_codes(x);
             if (slot < 0) {
-                if (x == PU_EMPTY || s_nins >= (u32)PR_RANGE) raw = true;
+                if (x == PU_EMPTY || s_nins >= (u32)PR_TBUCKETS) raw = true;
                 else {
                     bool fresh;
                     slot = insert(x, fresh);
@@ -1015,9 +1041,8 @@ __global__ __launch_bounds__(PR_NT) __attribute__((amdgpu_waves_per_eu(4, 4))) v
         append_global(raw, x, ftax);
     };
     bool bad = false;
-    // One step = 128 x U records of one file of rank rk: all the codes are loaded, then ALL the bucket reads of the step are
-    // issued (three 16-byte LDS reads per record, nothing between them that could alias), then every record is judged from
-    // registers; only records that need more -- a new code, a full bucket, a rank outside the interval -- touch LDS again.
+    // One step = 128 x U records of one file of rank rk: the codes are loaded; the tag words of ALL the step's records are
+    // read; then, of the slots whose tag matched, the codes and rank words; then every record is judged from registers.
     auto step = [&](auto UU, const ukm_gptr<u64> f, u64 p0, u64 end, u64 len, u32 rk, u32 crk, u32 ftax) {
         constexpr int U = decltype(UU)::value;
         pu_pair pr[U];
@@ -1061,29 +1086,33 @@ __global__ __launch_bounds__(PR_NT) __attribute__((amdgpu_waves_per_eu(4, 4))) v
                 if (nv >= 1) bad |= x0 > x1 || x1 > x2;
             }
         }
-        uint4 q0[2 * U], q1[2 * U], q2[2 * U];
-        u32 hh[2 * U];
+        uint4 tg[2 * U];
+        u32 hh[2 * U], tt[2 * U];
 #pragma unroll
         for (int i = 0; i < 2 * U; i++) {
-            hh[i] = pr_hash(x[i]);
-            const uint4 *bp = reinterpret_cast<const uint4 *>(&s_b[hh[i]]);
-            q0[i] = bp[0];
-            q1[i] = bp[1];
-            q2[i] = bp[2];
+            hh[i] = prt_bucket(x[i]);
+            tt[i] = prt_tag(x[i]);
+            tg[i] = *reinterpret_cast<const uint4 *>(&s_tag[4 * hh[i]]);
+        }
+        int sl[2 * U];
+        bool mt[2 * U];
+        u64 kk[2 * U];
+        u32 ww[2 * U];
+#pragma unroll
+        for (int i = 0; i < 2 * U; i++) {
+            const bool m0 = tg[i].x == tt[i], m1 = tg[i].y == tt[i], m2 = tg[i].z == tt[i], m3 = tg[i].w == tt[i];
+            mt[i] = m0 | m1 | m2 | m3;
+            sl[i] = (int)(4 * hh[i]) + (m0 ? 0 : (m1 ? 1 : (m2 ? 2 : 3)));  // (no match: slot 3, harmless)
+            kk[i] = s_key[sl[i]];
+            ww[i] = s_st[sl[i]];
         }
         bool more[2 * U];
-        int slot[2 * U];
         bool any = false;
 #pragma unroll
         for (int i = 0; i < 2 * U; i++) {
-            const u32 xl = (u32)x[i], xh = (u32)(x[i] >> 32);
-            const bool m0 = q0[i].x == xl && q0[i].y == xh, m1 = q0[i].z == xl && q0[i].w == xh;
-            const bool m2 = q1[i].x == xl && q1[i].y == xh, m3 = q1[i].z == xl && q1[i].w == xh;
-            const bool hit = (m0 | m1 | m2 | m3) && x[i] != PU_EMPTY;
-            const u32 w = m0 ? q2[i].x : (m1 ? q2[i].y : (m2 ? q2[i].z : q2[i].w));
-            const bool full = (q1[i].z & q1[i].w) != 0xFFFFFFFFu;  // slot 3 taken: the probe sequence goes on
-            const bool outside = rk < (w & 0xFFFFu) || crk < (w >> 16);
-            slot[i] = hit ? (int)(4 * hh[i]) + (m0 ? 0 : (m1 ? 1 : (m2 ? 2 : 3))) : (full ? -2 : -1);
+            const bool hit = mt[i] && kk[i] == x[i] && x[i] != PU_EMPTY;
+            const bool outside = rk < (ww[i] & 0xFFFFu) || crk < (ww[i] >> 16);
+            if (!hit) sl[i] = -1;  // (no tag, a tag that is not stored yet, a false positive, a full bucket: the codes decide)
             more[i] = v[i] && (!hit || outside);
             any |= more[i];
         }
@@ -1091,9 +1120,7 @@ __global__ __launch_bounds__(PR_NT) __attribute__((amdgpu_waves_per_eu(4, 4))) v
 #pragma unroll
         for (int i = 0; i < 2 * U; i++) {
             if (__ballot(more[i]) == 0ull) continue;
-            int sl = slot[i];
-            if (more[i] && sl == -2) sl = find_from(x[i], next_bucket(hh[i]));
-            rare(more[i], sl, x[i], rk, crk, ftax);
+            rare(more[i], sl[i], x[i], rk, crk, ftax);
         }
     };
     auto take = [&]() -> u32 {
@@ -1124,7 +1151,7 @@ __global__ __launch_bounds__(PR_NT) __attribute__((amdgpu_waves_per_eu(4, 4))) v
         if (len < 2) {  // (a one-record file: no 16-byte load fits)
             if (end > cur.beg) {
                 const u64 x = f[0];
-                rare(lane == 0, lane == 0 ? find_from(x, pr_hash(x)) : -1, x, rk, crk, ftax);
+                rare(lane == 0, -1, x, rk, crk, ftax);
             }
         } else {
             u64 p0 = cur.beg;
@@ -1144,20 +1171,20 @@ __global__ __launch_bounds__(PR_NT) __attribute__((amdgpu_waves_per_eu(4, 4))) v
 #pragma unroll
     for (int i = 0; i < PER; i++) {
         if (eslot[i] < 0) continue;
-        const u32 w = s_b[eslot[i] >> 2].st[eslot[i] & 3];
-        if (w != est[i]) t.base_st[b0 + (u32)tid + (u32)i * PR_NT] = w;
-        s_b[eslot[i] >> 2].k[eslot[i] & 3] = PU_EMPTY;  // (... and leave the table: what is left are the new codes of this range)
+        const u32 w = s_st[eslot[i]];
+        if (w != est[i]) t.base_st[b0 + (u32)tid + (u32)i * PR_TNT] = w;
+        s_key[eslot[i]] = PU_EMPTY;  // (... and leave the table: what is left are the new codes of this range)
     }
     __syncthreads();
-    constexpr int SPT = (PR_SLOTS + PR_NT - 1) / PR_NT;
+    constexpr int SPT = (PR_TSLOTS + PR_TNT - 1) / PR_TNT;
     u32 mine = 0;
 #pragma unroll
     for (int i = 0; i < SPT; i++) {
-        const int sl = tid * SPT + i;
-        if (sl < PR_SLOTS && s_b[sl >> 2].k[sl & 3] != PU_EMPTY) mine++;
+        const int q = tid * SPT + i;
+        if (q < PR_TSLOTS && s_key[q] != PU_EMPTY) mine++;
     }
     u32 tot;
-    u32 at_l = block_excl_scan_u32<PR_NT>(mine, s_scan, &tot);
+    u32 at_l = block_excl_scan_u32<PR_TNT>(mine, s_scan, &tot);
     if (tot == 0) return;
     if (tid == 0) {
         const u64 at = atomicAdd((unsigned long long *)&a.ctl[0], (unsigned long long)tot);
@@ -1169,10 +1196,10 @@ __global__ __launch_bounds__(PR_NT) __attribute__((amdgpu_waves_per_eu(4, 4))) v
     if (at + tot > a.miss_cap) return;
 #pragma unroll
     for (int i = 0; i < SPT; i++) {
-        const int sl = tid * SPT + i;
-        if (sl < PR_SLOTS && s_b[sl >> 2].k[sl & 3] != PU_EMPTY) {
-            a.miss[at + at_l] = s_b[sl >> 2].k[sl & 3];
-            a.miss_tax[at + at_l] = pr_settle(t, a.tax, s_b[sl >> 2].st[sl & 3]);
+        const int q = tid * SPT + i;
+        if (q < PR_TSLOTS && s_key[q] != PU_EMPTY) {
+            a.miss[at + at_l] = s_key[q];
+            a.miss_tax[at + at_l] = pr_settle(t, a.tax, s_st[q]);
             at_l++;
         }
     }
@@ -1734,12 +1761,12 @@ static int probe_union_k0(ukm_ctx *c, const u64 *const *keys, const u32 *const *
 
 // Base entries per range of the ranked pass (pt_range_for's rule with its own table size)
 static u32 pr_range_for(const ukm_ctx *c, u64 n0) {
-    const u64 slots = 2ull * (u64)std::max(1, c->num_cu);  // (two workgroups per CU)
-    const u64 r_full = (n0 + PR_RANGE - 1) / PR_RANGE;
-    if (r_full >= 16 * slots) return (u32)PR_RANGE;
+    const u64 slots = (u64)std::max(1, c->num_cu);  // (one workgroup per CU)
+    const u64 r_full = (n0 + PR_TBUCKETS - 1) / PR_TBUCKETS;
+    if (r_full >= 16 * slots) return (u32)PR_TBUCKETS;
     const u64 rounds = (r_full + slots - 1) / slots;
     const u64 range = (n0 + rounds * slots - 1) / (rounds * slots);
-    return (u32)std::min<u64>(PR_RANGE, std::max<u64>(range, 64));
+    return (u32)std::min<u64>(PR_TBUCKETS, std::max<u64>(range, 64));
 }
 
 // `union` of files that carry ONE taxid each (ctax[j]; pr_probe_kernel).  Same contract as probe_union_k0.
@@ -1889,11 +1916,20 @@ static int probe_union_ranked(ukm_ctx *c, const u64 *const *keys_in, const u64 *
     PrTables t;
     t.tax_of_rank = d_rank;
     t.eul_of_rank = d_rank + D + 1;
+    t.D = (u32)D;
+    t.pair = nullptr;
+    if (D <= (size_t)PR_PAIR_MAX) {
+        u32 *pair = nullptr;
+        UKM_TRY(ws_alloc_t(c, (D + 1) * (D + 1), &pair));
+        t.pair = pair;
+        hipLaunchKernelGGL(pr_pairs_kernel, dim3((unsigned)(((D + 1) * (D + 1) + 255) / 256)), dim3(256), 0, c->stream, t, a.tax);
+        UKM_HIP(hipGetLastError());
+    }
     UKM_TRY(ws_alloc_t(c, n0 + 1, &t.base_st));
     UKM_HIP(hipMemsetAsync(t.base_st, 0xFF, (n0 + 1) * sizeof(u32), c->stream));
     // 4. the probe pass over EVERY file
     u64 miss_cap = (u64)((double)later * std::min(1.0, 2.0 * miss_rate + 0.01)) + (1u << 20);
-    miss_cap = std::min(miss_cap, total) + 64ull * (PR_NT / 64) * R64 * (u64)((S + PU_MAXS - 1) / PU_MAXS) + total / 32;
+    miss_cap = std::min(miss_cap, total) + 64ull * (PR_TNT / 64) * R64 * (u64)((S + PU_MAXS - 1) / PU_MAXS) + total / 32;
     UKM_TRY(ws_alloc_t(c, miss_cap + 1, &a.miss));
     UKM_TRY(ws_alloc_t(c, miss_cap + 1, &a.miss_tax));
     a.miss_cap = miss_cap;
@@ -1923,7 +1959,7 @@ static int probe_union_ranked(ukm_ctx *c, const u64 *const *keys_in, const u64 *
             UKM_HIP(hipMemsetAsync(ctl + 4, 0, sizeof(u64), c->stream));
         }
         (void)hipEventRecord(c->ev_k0, c->stream);
-        hipLaunchKernelGGL(pr_probe_kernel, dim3(a.R), dim3(PR_NT), 0, c->stream, a, t);
+        hipLaunchKernelGGL(pr_probe_kernel, dim3(a.R), dim3(PR_TNT), 0, c->stream, a, t);
         (void)hipEventRecord(c->ev_k1, c->stream);
         c->evk_valid = true;
         UKM_HIP(hipGetLastError());
@@ -1969,7 +2005,7 @@ static int probe_union_ranked(ukm_ctx *c, const u64 *const *keys_in, const u64 *
 }
 
 int ukm_dev_probe_union(ukm_ctx *c, const u64 *const *keys, const u32 *const *taxids, const u64 *lens, int S, bool tax, u64 *out,
-                        u32 *tout, u64 out_cap, u64 *n_out, bool *fallback, const u32 *ctax) {
+                        u32 *tout, u64 out_cap, u64 *n_out, bool *fallback, const u32 *ctax, bool overlap_known) {
     // files of the base set: eight, with TaxIds four (the base union pays an LCA per shared code: 8 files of config 3's
     // shape took as long as a third of the probe pass; the codes the later files add are claimed in the tables anyway).
     // When the later files share too little with it, ONE more attempt with four times as many files -- if the first
@@ -1982,7 +2018,7 @@ int ukm_dev_probe_union(ukm_ctx *c, const u64 *const *keys, const u32 *const *ta
     if (ukm_env(c, "UKM_PUNION_K0")) k0 = std::max(3, std::min(64, atoi(ukm_env(c, "UKM_PUNION_K0"))));  // developer knob
     *fallback = true;
     *n_out = 0;
-    if (ukm_punion_mode(c) < 1 && S >= 2) {
+    if (ukm_punion_mode(c) < 1 && S >= 2 && !overlap_known) {  // (overlap_known: the caller has just taken this sample itself)
         // files that share next to nothing (a record of one is in another with less than 3 % probability: even 32 of them
         // would cover too little): one small kernel says so before a base set is built
         double share = 0.0;
@@ -2265,7 +2301,7 @@ int ukm_dev_place_merge(ukm_ctx *c, const u64 *const *keys, const u32 *const *ta
     {
         bool fb = true;
         WsMark m = ws_mark(c);
-        const int rc = ukm_dev_probe_union(c, keys, nullptr, lens, S, false, base, nullptr, cap0, &n0, &fb, nullptr);
+        const int rc = ukm_dev_probe_union(c, keys, nullptr, lens, S, false, base, nullptr, cap0, &n0, &fb, nullptr, mode < 1);
         ws_release(c, m);
         if (rc == UKM_ERR_CAPACITY) return UKM_OK;
         UKM_TRY(rc);

@@ -110,6 +110,10 @@ extern "C" int ukm_taxonomy_load(ukm_ctx *c, const uint32_t *child, const uint32
         // are built): refuse sparse huge ids here, before any of it is allocated
         size_t free_b = 0, total_b = 0;
         UKM_HIP(hipMemGetInfo(&free_b, &total_b));
+        if (size * 25 > (u64)free_b / 10 * 9) {  // (the context's cached workspace counts as free: give it back and look again)
+            (void)ukm_ctx_trim(c);
+            UKM_HIP(hipMemGetInfo(&free_b, &total_b));
+        }
         if (size * 25 > (u64)free_b / 10 * 9)
             UKM_FAIL(UKM_ERR_NOMEM,
                      "ukm_taxonomy_load: dense tables for the largest taxid %u need at least %.2f GB, the device has %.2f GB free; "
@@ -198,8 +202,30 @@ extern "C" int ukm_taxonomy_load(ukm_ctx *c, const uint32_t *child, const uint32
     const u64 anc_bytes = (u64)nchunks * size * sizeof(uint4);
     const u64 need = size * (sizeof(u32) + sizeof(u8) + (m ? sizeof(u32) : 0) + sizeof(u32)) + N.size() * sizeof(u32) + anc_bytes;
     {
+        // free memory as the driver sees it -- plus what this context can give back: its cached workspace (kept at the
+        // high-water mark of the largest call, up to 160 GB) is released before the load is refused, and the taxonomy that
+        // is being replaced is credited (it is freed as soon as the new tables stand)
         size_t free_b = 0, total_b = 0;
         UKM_HIP(hipMemGetInfo(&free_b, &total_b));
+        u64 old_bytes = 0;
+        if (c->tax_parent)
+            old_bytes = (u64)c->tax_size * (sizeof(u32) + sizeof(u8) + (c->tax_merged ? sizeof(u32) : 0) + 2 * sizeof(u32)) +
+                        (u64)c->tax_nchunks * c->tax_size * sizeof(uint4);
+        if (need > (u64)free_b / 10 * 9) {
+            (void)ukm_ctx_trim(c);
+            UKM_HIP(hipMemGetInfo(&free_b, &total_b));
+        }
+        const bool fits_beside = need <= (u64)free_b / 10 * 9;
+        if (!fits_beside && need <= ((u64)free_b + old_bytes) / 10 * 9) {
+            // only WITHOUT the old tables: they go first (the one case in which a failed load leaves no taxonomy behind)
+            UKM_HIP(hipStreamSynchronize(c->stream));
+            (void)hipFree(c->tax_parent); (void)hipFree(c->tax_depth);
+            if (c->tax_merged) (void)hipFree(c->tax_merged);
+            (void)hipFree(c->tax_anc); (void)hipFree(c->tax_euler); (void)hipFree(c->tax_node_at);
+            c->tax_parent = nullptr; c->tax_depth = nullptr; c->tax_merged = nullptr; c->tax_anc = nullptr;
+            c->tax_euler = nullptr; c->tax_node_at = nullptr; c->tax_size = 0; c->tax_nchunks = 0; c->tax_max = 0;
+            UKM_HIP(hipMemGetInfo(&free_b, &total_b));
+        }
         if (need > (u64)free_b / 10 * 9)
             UKM_FAIL(UKM_ERR_NOMEM,
                      "ukm_taxonomy_load: the dense tables need %.2f GB (largest taxid %u, depth %d: 16 B per id per 4 levels), the "

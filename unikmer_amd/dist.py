@@ -213,7 +213,13 @@ def redistribute(ctx, files_keys, key_bits, files_taxids=None, group=None, with_
     afterwards and `inter` / `diff` keep the reference's multiset behaviour (inter.go:228-257) across ranks.  Returns the
     list of local sorted files (and the list of their taxids, or None): the inputs of any number of single-GPU
     operations on this rank's range -- `union` AND `inter` of the same two sets need one exchange of each, not one per
-    operation."""
+    operation.
+
+    PRECONDITION: the per-rank chunks of one logical file are DISJOINT (each record of the file lives on exactly one rank:
+    stride-, offset- or hash-sharded reads of one .unik file).  Chunks that overlap would come back as duplicates inside
+    the rebuilt file -- the keep-everything merge cannot tell them from a file that really holds a code twice -- and
+    `common` would then count such a code once per chunk.  Callers whose chunks may overlap rebuild with ctx.union instead.
+    (The value-order check costs one 2 * world element read-back per file on the exchange pipeline.)"""
     it = _exchange_files(ctx, files_keys, key_bits, files_taxids, group, splitters)
     info = next(it)
     local, local_t = [], ([] if files_taxids is not None else None)
@@ -235,7 +241,52 @@ def redistribute(ctx, files_keys, key_bits, files_taxids=None, group=None, with_
     return (local, local_t, info["global_sizes"]) if with_sizes else (local, local_t)
 
 
-def _joined(pieces):
+def comm_init_from_dist(ctx, group=None):
+    """Bring up the LIBRARY'S OWN RCCL communicator (ukm_comm_init, what a Go / C host calls) for the ranks of a
+    torch.distributed group: rank 0 makes the unique id, torch.distributed hands it to the others (the reference host would
+    use a file or a socket), every rank calls ukm_comm_init -- collective."""
+    from . import lib
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    box = [lib.Context.comm_unique_id() if rank == 0 else None]
+    dist.broadcast_object_list(box, src=0, group=group)
+    ctx.comm_init(world, rank, box[0])
+
+
+def redistribute_cabi(ctx, files_keys, key_bits, files_taxids=None, splitters=None):
+    """redistribute() through the C ABI alone -- ukm_partition_points, ONE ukm_shard_counts for all files, one
+    ukm_shard_exchange_known per file (grouped ncclSend / ncclRecv inside the library, ukm_comm.hip), the rebuild by
+    ukm_merge_k -- i.e. exactly the calls of INTEGRATION.md's Go loop; torch.distributed plays no part (the context's
+    communicator must be up: comm_init_from_dist).  splitters: None = equal-width prefix ranges, or world + 1 boundaries."""
+    world, _ = ctx.comm_info()
+    spl = (prefix_splitters(key_bits, world) if splitters is None else list(splitters))[:-1]
+    nfiles = len(files_keys)
+    if nfiles == 0:
+        return [], ([] if files_taxids is not None else None)
+    import numpy as np
+    send = np.array([cuts_to_counts(ctx.partition_points(k, spl), k.numel()) for k in files_keys], dtype=np.uint64)
+    recv = ctx.shard_counts(send)                                  # [file][source rank]: one gather, one host round trip
+    local, local_t = [], ([] if files_taxids is not None else None)
+    for i, k in enumerate(files_keys):
+        t = files_taxids[i] if files_taxids is not None else None
+        rk, rt, rc = ctx.shard_exchange(k, send[i], t, recv_counts=recv[i])
+        counts = [int(x) for x in rc]
+        if pieces_in_value_order(rk, counts):
+            local.append(rk)
+            if rt is not None:
+                local_t.append(rt)
+            continue
+        pieces = split_by_counts(rk, counts)
+        tpieces = split_by_counts(rt, counts) if rt is not None else None
+        merged = ctx.merge_k(pieces, tpieces)
+        if tpieces is not None:
+            local.append(merged[0])
+            local_t.append(merged[1])
+        else:
+            local.append(merged)
+    return local, local_t
+
+
+def _joined(pieces):def _joined(pieces):
     """the tensor the back-to-back views `pieces` were cut from (split_by_counts), or None if they are not adjacent"""
     base = pieces[0]
     total = sum(x.numel() for x in pieces)
@@ -266,6 +317,8 @@ def sharded_setop(ctx, op, files_keys, key_bits, files_taxids=None, group=None, 
 
     splitters: None = equal-width prefix ranges (right for hashes), "sampled" = boundaries from a sample of all ranks'
     files that balance the ranks' record counts (k-mer codes), or an explicit list of world + 1 boundaries.
+
+    The per-rank chunks of one logical file must be disjoint (see redistribute).
 
     files_keys: list of 1-D int64 device tensors; every rank must pass the SAME number of
     files (file i of every rank are the per-rank chunks of logical input i).  `ctx` must run on
