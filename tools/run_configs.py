@@ -156,8 +156,11 @@ def main():
         leaves0 = T - 8 ** 7 + 1
         outt = torch.empty(out.numel(), dtype=torch.int32, device=dev)
         entry = res["config3_union_%d_files_x_%.0e" % (nfiles, per)]
-        for kind in ("one_taxid_per_file", "random_taxids"):
-            if kind == "one_taxid_per_file":
+        for kind in ("one_taxid_per_file_scalar", "one_taxid_per_file", "random_taxids"):
+            if kind == "one_taxid_per_file_scalar":
+                # round 5: the file's taxid handed over as ONE number (ukm_union_ft), nothing expanded
+                taxs = [int(leaves0 + (f * 7919) % (8 ** 7)) for f in range(len(files))]
+            elif kind == "one_taxid_per_file":
                 taxs = [torch.full((x.numel(),), leaves0 + (f * 7919) % (8 ** 7), dtype=torch.int32, device=dev) for f, x in enumerate(files)]
             else:
                 taxs = [(1 + (bench.splitmix64_torch(x ^ bench._i64(bench.SEED + 2 + f)) & ((1 << 40) - 1)) % T).to(torch.int32)
@@ -165,8 +168,10 @@ def main():
             ctx.union(files, taxs, out=out, out_taxids=outt)
             ms_t, ut = wall(lambda: ctx.union(files, taxs, out=out, out_taxids=outt), reps=args.reps)
             assert ut[0].numel() == n_probe
+            bpr = 8 if kind.endswith("scalar") else 12
             entry["with_" + kind] = {"ms": ms_t, "route": ctx.last_route(), "kmers_per_s": total / ms_t * 1e3,
-                                     "roofline": roof_hbm(12 * total + 12 * n_probe, ms_t, "12 B (code + taxid) per input record read + 12 B per output record written")}
+                                     "checksum": int(ut[0].sum().item()) ^ int(ut[1].to(torch.int64).sum().item()),
+                                     "roofline": roof_hbm(bpr * total + 12 * n_probe, ms_t, "%d B per input record read + 12 B per output record written" % bpr)}
             del taxs, ut
         entry["note_taxids"] = ("route 3 = the hash-probe pass with the TaxId fold in its LDS tables (ukm_punion.hip, round 4); through the k-way "
                                 "merge the half-size shape took 106 / 124 ms against 31.5 / 87 ms (tools/c3_tax_bench.py)")
@@ -254,6 +259,26 @@ def main():
                 "roofline_common_threshold_minus_1": roof_hbm(12 * total2 + 12 * rc1[0].numel(), ms_c1, "12 B per input record + 12 B per output record"),
                 "roofline_union": roof_hbm(12 * total2 + 12 * ru[0].numel(), ms_u, "12 B per input record + 12 B per output record"),
                 "note": "route 4 = single-pass range merge (ukm_srmerge.hip), 2 = multi-level k-way merge (ukm_kway.hip)"}
+        # round 5: the same files with ONE taxid per file handed over as a scalar (ukm_*_ft) beside the plain operations:
+        # inter / diff / diff -t / common of all files are the plain operation and a fill
+        ftax = [int(1 + (f * 7919) % T) for f in range(nfiles)]
+        tabf = ctx.stream_table(files2, ftax)
+        tabp = ctx.stream_table(files2)
+        per_file = {}
+        for name, fn_t, fn_p in (
+                ("inter", lambda: ctx.inter(tabf, out=ok, out_taxids=ot), lambda: ctx.inter(tabp, out=ok)),
+                ("diff", lambda: ctx.diff(tabf, out=ok, out_taxids=ot), lambda: ctx.diff(tabp, out=ok)),
+                ("diff_compare_taxid", lambda: ctx.diff(tabf, compare_taxid=True, out=ok, out_taxids=ot), lambda: ctx.diff(tabp, out=ok)),
+                ("common_all_files", lambda: ctx.common(tabf, nfiles, out=okc, out_taxids=otc), lambda: ctx.common(tabp, nfiles, out=okc)),
+                ("common_threshold_minus_1", lambda: ctx.common(tabf, nfiles - 1, out=okc, out_taxids=otc), lambda: ctx.common(tabp, nfiles - 1, out=okc)),
+                ("union", lambda: ctx.union(tabf, out=okc, out_taxids=otc), lambda: ctx.union(tabp, out=okc)),
+                ("merge", lambda: ctx.merge_k(tabf, out=okc, out_taxids=otc), lambda: ctx.merge_k(tabp, out=okc))):
+            fn_t(); fn_p()
+            mt, rt = wall(fn_t, reps=max(1, args.reps - 1))
+            rte = ctx.last_route()
+            mp, rp = wall(fn_p, reps=max(1, args.reps - 1))
+            per_file[name] = {"ms": mt, "plain_ms": mp, "ratio": mt / mp, "out": rt[0].numel(), "route": rte}
+        many["one_taxid_per_file_scalar"] = per_file
         del okc, otc
         res["config4_core_files_merge_common_union"] = many
         res["config4_core_inter_diff_%d_files_taxids" % nfiles] = {

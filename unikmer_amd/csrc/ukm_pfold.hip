@@ -54,7 +54,7 @@ struct PfArgs {
 
 __device__ __forceinline__ u32 pf_hash(u64 x) {
     const u32 lo = (u32)x, hi = (u32)(x >> 32);
-    return ((lo ^ (hi * 0x85EBCA6Bu)) * 0x9E3779B1u) >> (32 - PF_BUCKET_BITS);
+    return ((lo ^ __builtin_rotateleft32(hi, 15) ^ (hi >> 3)) * 0x9E3779B1u) >> (32 - PF_BUCKET_BITS);
 }
 
 __global__ void pf_cuts_kernel(PfArgs a) {

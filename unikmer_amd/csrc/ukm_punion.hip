@@ -83,7 +83,7 @@ struct PuArgs {
 
 __device__ __forceinline__ u32 pu_hash(u64 x) {
     const u32 lo = (u32)x, hi = (u32)(x >> 32);
-    return ((lo ^ (hi * 0x85EBCA6Bu)) * 0x9E3779B1u) >> (32 - PU_BUCKET_BITS);
+    return ((lo ^ __builtin_rotateleft32(hi, 15) ^ (hi >> 3)) * 0x9E3779B1u) >> (32 - PU_BUCKET_BITS);
 }
 
 __device__ __forceinline__ u64 pu_splitmix(u64 x) {
@@ -447,7 +447,7 @@ constexpr u32 PT_UNSET = 0xFFFFFFFFu;  // t0 of a slot: nobody has set it yet
 
 __device__ __forceinline__ u32 pt_hash(u64 x) {
     const u32 lo = (u32)x, hi = (u32)(x >> 32);
-    return (u32)(((u64)((lo ^ (hi * 0x85EBCA6Bu)) * 0x9E3779B1u) * (u64)PT_BUCKETS) >> 32);
+    return (u32)(((u64)((lo ^ __builtin_rotateleft32(hi, 15) ^ (hi >> 3)) * 0x9E3779B1u) * (u64)PT_BUCKETS) >> 32);
 }
 
 typedef u32 pt_u32x2 __attribute__((ext_vector_type(2)));
@@ -891,20 +891,35 @@ __global__ void pr_settle_kernel(PrTables t, TaxDev T, u64 n0, u32 *base_tax) {
 // (8 bytes, the exact check) and the rank word (4 bytes): 28 bytes instead of the 48 of codes + words side by side.  The
 // CODES stay the authority: a slot is claimed by a 64-bit CAS on its code, its tag is stored afterwards; a reader that
 // misses a tag that is not there yet (or meets a false positive) falls through to the claim, which walks the codes.
-constexpr int PR_TNT = 1024;          // one workgroup of 16 waves per CU
-constexpr int PR_TBUCKETS = 2304;     // x 4 slots x (4 + 8 + 4) bytes = 144 KB of LDS
+#ifndef PR_TNT_N
+#define PR_TNT_N 1024
+#endif
+#ifndef PR_TBUCKETS_N
+#define PR_TBUCKETS_N 1152
+#endif
+#ifndef PR_TWAVES
+#define PR_TWAVES 8
+#endif
+// (measured on config 3's shape at half size, probe pass: 2304 buckets x 1024 threads, one workgroup per CU = 4 waves per SIMD
+//  14.3 ms; 1152 x 512 x 2 workgroups 14.9; 768 x 512 x 3 = 6 waves 12.6; 1152 x 1024 x 2 = 8 waves per SIMD 12.55)
+constexpr int PR_TNT = PR_TNT_N;               // threads of a workgroup
+constexpr int PR_TBUCKETS = PR_TBUCKETS_N;     // x 4 slots x (4 + 8 + 4) bytes = 72 KB of LDS: two workgroups of 16 waves per CU
 constexpr int PR_TSLOTS = 4 * PR_TBUCKETS;
-__device__ __forceinline__ u32 prt_bucket(u64 x) {
+// ONE multiplicative hash per code (v_mul_lo_u32 runs at a quarter of the VALU rate: the two products + the mul_hi of
+// the first version were a fifth of the kernel's vector work): its top bits pick the bucket, the word itself (odd: never
+// 0) is the tag -- inside a bucket the tags still differ in 21 bits, and a false positive only costs the exact look-up.
+__device__ __forceinline__ u32 prt_hash(u64 x) {
     const u32 lo = (u32)x, hi = (u32)(x >> 32);
-    return (u32)(((u64)((lo ^ (hi * 0x85EBCA6Bu)) * 0x9E3779B1u) * (u64)PR_TBUCKETS) >> 32);
+    return (lo ^ __builtin_rotateleft32(hi, 15) ^ (hi >> 3)) * 0x9E3779B1u;
 }
-__device__ __forceinline__ u32 prt_tag(u64 x) {
-    const u32 lo = (u32)x, hi = (u32)(x >> 32);
-    const u32 t = (hi * 0xC2B2AE35u) ^ (lo * 0x27D4EB2Fu) ^ (lo >> 15);
-    return t ? t : 1u;
+__device__ __forceinline__ u32 prt_bucket_of(u32 h) {
+    if ((PR_TBUCKETS & (PR_TBUCKETS - 1)) == 0) return h >> (32 - __builtin_ctz((unsigned)PR_TBUCKETS));
+    return (u32)(((u64)h * (u64)PR_TBUCKETS) >> 32);
 }
+__device__ __forceinline__ u32 prt_bucket(u64 x) { return prt_bucket_of(prt_hash(x)); }
+__device__ __forceinline__ u32 prt_tag(u64 x) { return prt_hash(x) | 1u; }
 
-__global__ __launch_bounds__(PR_TNT) __attribute__((amdgpu_waves_per_eu(4, 4))) void pr_probe_kernel(PuArgs a, PrTables t) {
+__global__ __launch_bounds__(PR_TNT) __attribute__((amdgpu_waves_per_eu(PR_TWAVES, PR_TWAVES))) void pr_probe_kernel(PuArgs a, PrTables t) {
     __shared__ __attribute__((aligned(16))) u32 s_tag[PR_TSLOTS];
     __shared__ __attribute__((aligned(16))) u64 s_key[PR_TSLOTS];
     __shared__ u32 s_st[PR_TSLOTS];
@@ -1090,8 +1105,9 @@ __global__ __launch_bounds__(PR_TNT) __attribute__((amdgpu_waves_per_eu(4, 4))) 
         u32 hh[2 * U], tt[2 * U];
 #pragma unroll
         for (int i = 0; i < 2 * U; i++) {
-            hh[i] = prt_bucket(x[i]);
-            tt[i] = prt_tag(x[i]);
+            const u32 hx = prt_hash(x[i]);
+            hh[i] = prt_bucket_of(hx);
+            tt[i] = hx | 1u;
             tg[i] = *reinterpret_cast<const uint4 *>(&s_tag[4 * hh[i]]);
         }
         int sl[2 * U];
@@ -1265,7 +1281,7 @@ enum { PL_FLAG_ORDER = 1, PL_FLAG_UNKNOWN = 2 };
 
 __device__ __forceinline__ u32 pl_hash(u64 x) {
     const u32 lo = (u32)x, hi = (u32)(x >> 32);
-    return ((lo ^ (hi * 0x85EBCA6Bu)) * 0x9E3779B1u) >> (32 - PL_BUCKET_BITS);
+    return ((lo ^ __builtin_rotateleft32(hi, 15) ^ (hi >> 3)) * 0x9E3779B1u) >> (32 - PL_BUCKET_BITS);
 }
 
 template <bool TAX>
@@ -1761,7 +1777,7 @@ static int probe_union_k0(ukm_ctx *c, const u64 *const *keys, const u32 *const *
 
 // Base entries per range of the ranked pass (pt_range_for's rule with its own table size)
 static u32 pr_range_for(const ukm_ctx *c, u64 n0) {
-    const u64 slots = (u64)std::max(1, c->num_cu);  // (one workgroup per CU)
+    const u64 slots = (u64)std::max(1, c->num_cu) * (u64)std::max(1, (160 * 1024) / (PR_TSLOTS * 16 + 1024));  // (workgroups resident at once)
     const u64 r_full = (n0 + PR_TBUCKETS - 1) / PR_TBUCKETS;
     if (r_full >= 16 * slots) return (u32)PR_TBUCKETS;
     const u64 rounds = (r_full + slots - 1) / slots;
