@@ -302,15 +302,16 @@ def main():
                     best = k if best is None else min(best, k)
                 return best, r
             leaves = T - 8 ** 7 + 1
-            fa, fb = int(leaves + 5), int(leaves + 77)          # two leaves under different children of the root
+            fa, fb = int(leaves + 5), int(leaves + 8 ** 6 + 77)  # two leaves under different children of the root
+            lab = int(ctx.lca(np.array([fa], dtype=np.uint32), np.array([fb], dtype=np.uint32))[0])
             tu, ru = kms(lambda: ctx.setop2(lib.OP_UNION, A, B, fa, fb, out=out_u, out_taxids=tout_u))
             ti, ri = kms(lambda: ctx.setop2(lib.OP_INTER, A, B, fa, fb, out=out_i, out_taxids=tout_i))
             assert ru[0].numel() == nu and ri[0].numel() == ni
             # the taxids of the union: A's own, B's own, or the root on the codes both hold -- counted at full size
             cu = ru[1]
-            n_root, n_a, n_b = int((cu == 1).sum().item()), int((cu == fa).sum().item()), int((cu == fb).sum().item())
-            assert (n_root, n_a, n_b) == (ni, na - ni, nb - ni), "per-file taxids of the union are wrong"
-            assert bool((ri[1] == 1).all()), "per-file taxids of the intersection are wrong"
+            n_root, n_a, n_b = int((cu == lab).sum().item()), int((cu == fa).sum().item()), int((cu == fb).sum().item())
+            assert lab == 1 and (n_root, n_a, n_b) == (ni, na - ni, nb - ni), "per-file taxids of the union are wrong"
+            assert bool((ri[1] == lab).all()), "per-file taxids of the intersection are wrong"
             per_file = {"union_kernel_ms": tu, "inter_kernel_ms": ti,
                         "union_frac": (8.0 * (na + nb) + 12.0 * nu) / (tu * 1e-3) / 1e9 / 8000.0,
                         "inter_frac": (8.0 * (na + nb) + 12.0 * ni) / (ti * 1e-3) / 1e9 / 8000.0,

@@ -9,6 +9,9 @@ mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 CMD="python $R/bench.py --steps 5 --warmup 2 --cpu-sample 0"
 timeout 500 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -o bench -- $CMD > $O/trace.log 2>&1
+# (the PMC passes leave the taxid variant out -- UKM_BENCH_NO_TAXID=1: it lies outside the timed region and only adds launches
+#  of OTHER kernels; the kernel-trace pass above runs the default command as it is)
+export UKM_BENCH_NO_TAXID=1
 timeout 500 rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE -d $O/pmc_fetch -o bench -- $CMD > $O/pmc_fetch.log 2>&1
 timeout 500 rocprofv3 --kernel-trace --output-format csv --pmc WRITE_SIZE -d $O/pmc_write -o bench -- $CMD > $O/pmc_write.log 2>&1
 timeout 500 rocprofv3 --kernel-trace --output-format csv --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_VALU -d $O/pmc_sq1 -o bench -- $CMD > $O/pmc_sq1.log 2>&1

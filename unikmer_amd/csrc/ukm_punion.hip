@@ -387,7 +387,10 @@ __global__ __launch_bounds__(PU_NT) __attribute__((amdgpu_waves_per_eu(PU_WAVES,
             u64 p0 = cur.beg;
             while (p0 < end) {
                 const u64 rem = end - p0;
-                if (rem > 256) { step(std::integral_constant<int, 4>{}, f, p0, end, len); p0 += 512; }
+#ifndef PU_MAXU
+#define PU_MAXU 4
+#endif
+                if (PU_MAXU >= 4 && rem > 256) { step(std::integral_constant<int, 4>{}, f, p0, end, len); p0 += 512; }
                 else if (rem > 128) { step(std::integral_constant<int, 2>{}, f, p0, end, len); p0 += 256; }
                 else { step(std::integral_constant<int, 1>{}, f, p0, end, len); p0 += 128; }
             }
