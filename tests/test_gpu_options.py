@@ -67,3 +67,94 @@ def test_options_steer_routes_and_environment_is_read_once(monkeypatch):
         assert np.array_equal(ctx2.union(files), exp) and ctx2.last_route() == 2
     finally:
         ctx2.close()
+
+
+def test_oversized_call_is_a_clean_nomem_error():
+    """A call whose device workspace cannot be had returns UKM_ERR_NOMEM (message says how much) -- no crash, no exit --
+    and the context goes on working once memory is there again (round-4 review: config 3 with taxids through the merges
+    needs inputs + ~2 x workspace; what happens when that does not fit was untested)."""
+    import torch
+    from unikmer_amd import lib as L
+    dev = torch.device("cuda", 0)
+    ctx = L.Context(0, stream=torch.cuda.current_stream(dev).cuda_stream)
+    try:
+        with pytest.raises(L.UkmError) as e:
+            ctx.reserve(1 << 42)                      # 4 TB
+        assert e.value.code == L.ERR_NOMEM
+        rng = np.random.default_rng(1)
+        keys = torch.from_numpy(rng.integers(0, 1 << 62, 60_000_000, dtype=np.int64)).to(dev)
+        free, total = torch.cuda.mem_get_info(dev)
+        hog = torch.empty(int(free) - (128 << 20), dtype=torch.uint8, device=dev)    # leave 128 MB: the sort wants 0.5 GB of scratch
+        work = keys
+        with pytest.raises(L.UkmError) as e:
+            ctx.sort_u64(work, 62)
+        assert e.value.code == L.ERR_NOMEM and "allocation" in str(e.value)
+        del hog
+        torch.cuda.empty_cache()
+        ctx.sort_u64(work, 62)                        # the same context, the same call: fine now
+        assert bool((work[1:] >= work[:-1]).all())
+    finally:
+        ctx.close()
+
+
+def test_default_route_on_related_genomes_is_among_the_fastest(genomes):
+    """The thresholds between the routes were fitted to one synthetic generator (round-4 review).  Here: the distinct
+    canonical 31-mers of the fixture genome, `mutated` into 100 related strains (each drops 3 % of the k-mers and adds 3 % of
+    its own), union and keep-everything merge: the route the library picks by itself is within 15 % of the fastest of the
+    routes a host can force, and every route gives the same result."""
+    import time
+    import torch
+    from conftest import MG1655
+    from unikmer_amd import lib as L
+    dev = torch.device("cuda", 0)
+    ctx = L.Context(0, stream=torch.cuda.current_stream(dev).cuda_stream)
+    try:
+        seq, off = genomes(MG1655)
+        codes = ctx.encode_kmers(torch.from_numpy(seq.copy()).to(dev), torch.from_numpy(off.view(np.int64).copy()).to(dev), 31)
+        ctx.sort_u64(codes, 62)
+        base = ctx.unique(codes)
+        n = base.numel()
+        g = torch.Generator(device=dev)
+        g.manual_seed(7)
+        strains = []
+        for s in range(100):
+            keep = torch.rand(n, device=dev, generator=g) >= 0.03
+            own = torch.randint(0, 1 << 62, (int(0.03 * n),), dtype=torch.int64, device=dev, generator=g)
+            k = torch.cat([base[keep], own])
+            ctx.sort_u64(k, 62)
+            strains.append(ctx.unique(k).clone())
+        total = sum(x.numel() for x in strains)
+        out = torch.empty(total + 8, dtype=torch.int64, device=dev)
+
+        def timed(fn):
+            best = None
+            for _ in range(3):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                r = fn()
+                torch.cuda.synchronize()
+                dt = time.perf_counter() - t0
+                best = dt if best is None else min(best, dt)
+            return best, r
+        for name, fn, forced in (
+                ("union", lambda: ctx.union(strains, out=out), [("punion", 0), ("punion", 2), ("srmerge", 1)]),
+                ("merge", lambda: ctx.merge_k(strains, mode=L.PLAIN, out=out), [("place", 0), ("place", 1), ("srmerge", 1)])):
+            fn()
+            t_def, r_def = timed(fn)
+            route_def = ctx.last_route()
+            ref = (int(r_def.numel()), int(r_def.sum().item()))
+            times = {"default(route %d)" % route_def: t_def}
+            for key, val in forced:
+                ctx.set_option(key, val)
+                if key == "srmerge":
+                    ctx.set_option("punion", 0)
+                    ctx.set_option("place", 0)
+                fn()
+                t, r = timed(fn)
+                times["%s=%d(route %d)" % (key, val, ctx.last_route())] = t
+                assert (int(r.numel()), int(r.sum().item())) == ref, (name, key, val)
+                for k2 in ("punion", "place", "srmerge"):
+                    ctx.set_option(k2, None)
+            assert t_def <= 1.15 * min(times.values()), (name, {k: round(v * 1e3, 2) for k, v in times.items()})
+    finally:
+        ctx.close()
