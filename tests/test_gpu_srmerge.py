@@ -52,12 +52,17 @@ def _stable(streams, taxs=None):
     return (cat[o], np.concatenate(taxs)[o]) if taxs is not None else cat[o]
 
 
-@pytest.mark.parametrize("nfiles,per,p", [(200, 3000, 0.02), (1000, 700, 0.002), (1024, 300, 0.5), (65, 20000, 0.3)])
-def test_merge_modes_and_union_many_streams(env, monkeypatch, nfiles, per, p):
+@pytest.mark.parametrize("buckets", [None, "1", "0"])
+@pytest.mark.parametrize("nfiles,per,p", [(200, 3000, 0.02), (1000, 700, 0.002), (1024, 300, 0.5), (65, 20000, 0.3), (700, 2500, 0.0008)])
+def test_merge_modes_and_union_many_streams(env, monkeypatch, nfiles, per, p, buckets):
     """every mode of the merge and the union, plain and with taxids; files that hardly overlap, that overlap heavily
-    (runs of hundreds of equal codes across files), 1024 = the most streams the route takes"""
+    (runs of hundreds of equal codes across files), 1024 = the most streams the route takes.  buckets: the tiles ordered by
+    the library's own choice, by counting placement wherever a tile allows it (tiles with a crowded bucket fall back to the
+    merge rounds one by one: both orders in one launch), by the merge rounds alone"""
     O, L, ctx, tax, T = env
     monkeypatch.setenv("UKM_SRMERGE", "1")
+    if buckets is not None:
+        monkeypatch.setenv("UKM_SRMERGE_BUCKETS", buckets)
     U = _universe(int(per / p))
     files = [U[_member(len(U), f, p, 7)] for f in range(nfiles)]
     files = [f for f in files if len(f)]

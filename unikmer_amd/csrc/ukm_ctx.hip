@@ -39,7 +39,7 @@ static const char *const UKM_OPTION_KEYS[] = {
     "punion", "punion_tax", "punion_ranked", "place", "srmerge", "kway", "no_kway", "no_fold", "no_pfold", "pfold_tax", "common_probe",
     "sort_local", "win_strip", "nthash_strip", "force_ticket",
     // tuning / diagnostics (developer)
-    "punion_k0", "punion_claim", "punion_debug", "kway_k", "kway_r", "kway_top2", "kway_debug", "srmerge_fill", "srmerge_spr",
+    "punion_k0", "punion_claim", "punion_debug", "kway_k", "kway_r", "kway_top2", "kway_debug", "srmerge_fill", "srmerge_spr", "srmerge_buckets",
     "srmerge_debug", "fold_debug", "sort_debug", "strip_l", "win_strip_l", "setop_fused_part",
 };
 

@@ -64,6 +64,14 @@ __global__ void sr_sample_kernel(const u64 *const *leaf_keys, const u64 *sample_
     samples[g] = leaf_keys[lo][(i + 1) * D - 1 - phase];
 }
 
+// how many samples equal their predecessor in the sorted sample: an estimate of how many copies a code has among the streams
+__global__ void sr_dupcount_kernel(const u64 *samples, u64 ns, u64 *out) {
+    const u64 g = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool eq = g > 0 && g < ns && samples[g] == samples[g - 1];
+    const u64 m = __ballot(eq);
+    if (m && lane_id() == 0) atomicAdd((unsigned long long *)out, (unsigned long long)__popcll(m));
+}
+
 // splitter r (1 <= r < R) = the sample of rank r * ns / R; spl[0] is unused
 __global__ void sr_splitters_kernel(const u64 *samples, u64 ns, u32 R, u64 *spl) {
     const u64 r = (u64)blockIdx.x * blockDim.x + threadIdx.x;
@@ -190,6 +198,7 @@ struct SrArgs {
     u64 *result;                  // [1] |= flags
     u32 S, R, per_xcd;
     u32 threshold;                // UNION: > 1 = only codes with at least this many records (`common`)
+    u32 buckets;                  // 1: tiles are ordered by counting placement (files that share next to nothing), 0: by the merge rounds
     TaxDev tax;
 };
 
@@ -346,6 +355,12 @@ typedef u32 sr_u32x4 __attribute__((ext_vector_type(4), aligned(4)));
 #ifndef SR_SPT_N
 #define SR_SPT_N 2
 #endif
+#ifndef SR_NB
+#define SR_NB 4096          /* value buckets of the counting placement */
+#endif
+#ifndef SR_BUCKET_LIMIT
+#define SR_BUCKET_LIMIT 15  /* a fuller bucket: the tile takes the merge rounds (the arrival number has four bits) */
+#endif
 constexpr int SR_SPT = SR_SPT_N;  // streams per thread (their cursors and pointers live in registers): S <= NT * SR_SPT
 
 template <bool TAX, bool UNION, int NT, int VT, int LOGNT>
@@ -360,6 +375,11 @@ __global__ __launch_bounds__(NT, (TAX ? SR_WAVES_TAX : SR_WAVES_PLAIN)) void sr_
     __shared__ __attribute__((aligned(16))) u32 s_tax[TAX ? BUF : 4];
     __shared__ u32 s_scan[NT / 64 + 1];
     __shared__ u64 s_red[NT / 64];
+#ifndef SR_NO_BUCKETS
+    __shared__ u32 s_bkt[SR_NB / 2 + 1];      // counting placement: records per value bucket (two 16-bit counters per word), then the buckets' places
+    __shared__ unsigned short s_ba[BUF];      // ... a record's bucket << 4 | arrival number, later its final place
+    __shared__ u32 s_aux[TAX ? 4 : BUF];      // ... the staged records' tile positions (with taxids: s_tax, free at that point)
+#endif
 
     const int tid = (int)threadIdx.x;
     const u32 r = (blockIdx.x & 7u) * p.per_xcd + (blockIdx.x >> 3);  // an XCD works through CONSECUTIVE ranges: the
@@ -571,7 +591,121 @@ __global__ __launch_bounds__(NT, (TAX ? SR_WAVES_TAX : SR_WAVES_PLAIN)) void sr_
         }
         __syncthreads();
         SR_PH(1);
+        // ---- the tile in stable order, the cheap way (round 5): COUNTING PLACEMENT by value buckets -------------------------
+        // A tile of files that share little holds ~n distinct codes spread evenly over its value span, so SR_NB = 4096
+        // buckets of equal width take about one record each.  Every record counts itself into its bucket (one LDS atomic),
+        // a scan of the counters gives the buckets' places, the records are staged bucket by bucket, and a record's final
+        // place is its bucket's place + the number of records of the same bucket that come before it by (code, tile
+        // position) -- the order a stable merge gives -- found by walking the bucket (1 - 2 records).  ~60 lane-instructions
+        // per record instead of the ~280 of the per-thread rank sort + nine merge rounds below, and 6 barriers instead of 20.
+        // Codes that many files share crowd one bucket (the walk is quadratic in its size): a tile whose fullest bucket
+        // holds more than SR_BUCKET_LIMIT records takes the merge rounds, which do not care.
+        bool placed = false;
+#ifndef SR_NO_BUCKETS
+        if (p.buckets && n > (u32)VT) {  // (the host's choice, from the share of equal neighbours in its sorted sample)
+            // (what a record needs between the phases -- its bucket, its arrival number, later its final place -- lives in
+            //  the 16-bit array s_ba, and the counters are 16-bit halves of 32-bit words: the records themselves are the
+            //  only thing a thread keeps in registers across the barriers, as in the merge rounds)
+            auto bkt_get = [&](u32 b) -> u32 {
+                const u32 w = s_bkt[b >> 1];
+                return (b & 1u) ? (w >> 16) : (w & 0xFFFFu);
+            };
+            int tr = tid;
+            asm volatile("" : "+v"(tr));
+            const int p0 = tr * VT;
+            u64 mn = SR_MAX, mx = 0;
+#pragma unroll
+            for (int i = 0; i < VT; i++) {
+                const bool valid = p0 + i < (int)n;
+                const u64 k = valid ? s_key[p0 + i] : SR_MAX;
+                mn = k < mn ? k : mn;                            // (an invalid slot counts as 2^64 - 1: no effect on the minimum)
+                mx = (valid && k > mx) ? k : mx;
+            }
+            for (int i = tid; i <= SR_NB / 2; i += NT) s_bkt[i] = 0;
+            mn = sr_block_min_u64<NT>(mn, s_red);
+            mx = ~sr_block_min_u64<NT>(~mx, s_red);
+            // bucket = floor((code - mn) * SR_NB / (mx - mn + 1)) in single precision: monotone in the code (conversion,
+            // product with a positive constant and truncation all are), which is all the order needs
+            const float sc = (float)SR_NB / ((float)(mx - mn) + 1.0f);
+            u32 worst = 0;
+#pragma unroll
+            for (int i = 0; i < VT; i++) {
+                if (p0 + i < (int)n) {
+                    u32 b = (u32)((float)(s_key[p0 + i] - mn) * sc);
+                    b = b < (u32)SR_NB - 1u ? b : (u32)SR_NB - 1u;
+                    const u32 w = atomicAdd(&s_bkt[b >> 1], (b & 1u) ? 0x10000u : 1u);
+                    const u32 arr = (b & 1u) ? (w >> 16) : (w & 0xFFFFu);  // its arrival number in the bucket
+                    worst = arr > worst ? arr : worst;
+                    s_ba[p0 + i] = (unsigned short)((arr < 15u ? arr : 15u) | (b << 4));
+                }
+            }
+            worst = (u32)__syncthreads_or(worst >= (u32)SR_BUCKET_LIMIT ? 1 : 0);
+            if (!worst) {
+                // the buckets' places: exclusive scan of the counters (SR_NB / NT consecutive counters per thread)
+                constexpr int WPT = SR_NB / 2 / NT;  // counter words per thread
+                u32 cw[WPT], sum = 0;
+#pragma unroll
+                for (int q = 0; q < WPT; q++) {
+                    cw[q] = s_bkt[tid * WPT + q];
+                    sum += (cw[q] & 0xFFFFu) + (cw[q] >> 16);
+                }
+                u32 tot;
+                u32 ex = block_excl_scan_u32<NT>(sum, s_scan, &tot);
+#pragma unroll
+                for (int q = 0; q < WPT; q++) {
+                    const u32 c0 = cw[q] & 0xFFFFu, c1 = cw[q] >> 16;
+                    s_bkt[tid * WPT + q] = ex | ((ex + c0) << 16);
+                    ex += c0 + c1;
+                }
+                if (tid == NT - 1) s_bkt[SR_NB / 2] = n;
+                u64 kk[VT];
+                u32 tt[VT];
+#pragma unroll
+                for (int i = 0; i < VT; i++) {
+                    const bool valid = p0 + i < (int)n;
+                    kk[i] = valid ? s_key[p0 + i] : SR_MAX;
+                    if (TAX) tt[i] = valid ? s_tax[p0 + i] : 0u;
+                }
+                __syncthreads();
+                // staged bucket by bucket in arrival order: the code and the record's tile position (the tie-break)
+                u32 *s_pos = TAX ? s_tax : s_aux;
+#pragma unroll
+                for (int i = 0; i < VT; i++)
+                    if (p0 + i < (int)n) {
+                        const u32 ba = s_ba[p0 + i];
+                        const u32 at = bkt_get(ba >> 4) + (ba & 15u);
+                        s_key[at] = kk[i];
+                        s_pos[at] = (u32)(p0 + i);
+                    }
+                __syncthreads();
+#pragma unroll
+                for (int i = 0; i < VT; i++)
+                    if (p0 + i < (int)n) {
+                        const u32 b = (u32)s_ba[p0 + i] >> 4;
+                        const u32 beg = bkt_get(b), end = bkt_get(b + 1);
+                        u32 before = 0;
+                        for (u32 j = beg; j < end; j++) {
+                            const u64 kj = s_key[j];
+                            const u32 pj = s_pos[j];
+                            before += (kj < kk[i] || (kj == kk[i] && pj < (u32)(p0 + i))) ? 1u : 0u;
+                        }
+                        s_ba[p0 + i] = (unsigned short)(beg + before);
+                    }
+                __syncthreads();
+#pragma unroll
+                for (int i = 0; i < VT; i++)
+                    if (p0 + i < (int)n) {
+                        const u32 fin = s_ba[p0 + i];
+                        s_key[fin] = kk[i];
+                        if (TAX) s_tax[fin] = tt[i];
+                    }
+                __syncthreads();
+                placed = true;
+            }
+        }
+#endif
         // ---- a thread's VT consecutive tile positions in stable order: rank = #smaller + #equal in front ------------------
+        if (!placed) {
         {
             u64 kk[VT];
             u32 tt[VT];
@@ -637,6 +771,7 @@ __global__ __launch_bounds__(NT, (TAX ? SR_WAVES_TAX : SR_WAVES_PLAIN)) void sr_
                 __syncthreads();
             }
         }
+        }  // (!placed)
 
         SR_PH(3);
         // ---- emit: the merged tile is s_key / s_tax [0, n) ---------------------------------------------------------------
@@ -955,6 +1090,7 @@ int ukm_dev_srmerge(ukm_ctx *c, int op, const u64 *const *keys, const u32 *const
     const u64 *d_segbase = d_tab + 4 * (size_t)S + 1;
 
     u64 *ctl = nullptr, *spl = nullptr;
+    u64 sample_dups = 0;
     u32 *cuts = nullptr;
     UKM_TRY(ws_alloc_t(c, 32, &ctl));
     UKM_HIP(hipMemsetAsync(ctl, 0, 32 * sizeof(u64), c->stream));
@@ -967,6 +1103,7 @@ int ukm_dev_srmerge(ukm_ctx *c, int op, const u64 *const *keys, const u32 *const
                            ns, samples);
         UKM_TRY(ukm_dev_sort(c, samples, nullptr, ns, 64));
         hipLaunchKernelGGL(sr_splitters_kernel, dim3((R + 255) / 256), dim3(256), 0, c->stream, samples, ns, R, spl);
+        hipLaunchKernelGGL(sr_dupcount_kernel, dim3((unsigned)((ns + 255) / 256)), dim3(256), 0, c->stream, samples, ns, ctl + 2);
     }
     mark("sample+sort");
     {
@@ -984,8 +1121,14 @@ int ukm_dev_srmerge(ukm_ctx *c, int op, const u64 *const *keys, const u32 *const
     }
     mark("cuts");
     {
-        u64 fl = 0;
-        UKM_TRY(ukm_read_u64(c, ctl + 1, &fl));
+        u64 fl2[2] = {0, 0};
+        UKM_TRY(ukm_read_u64(c, ctl + 1, fl2, 2));
+        const u64 fl = fl2[0];
+        // Counting placement or merge rounds?  A code with c copies among the streams shows up ~(c - 1) / (2 D) times as
+        // an equal neighbour in the sorted sample (every D-th record).  Placement wins while tiles hold next to no equal
+        // codes (1000 files x 1e6 with taxids, merge pass: 1.6 copies per code 19.6 against 24.3 ms, 4 copies 23.5 against
+        // 23.9) and loses its counting phase when buckets overflow (20 copies: 22.5 against 19.7): up to ~2.5 copies.
+        sample_dups = fl2[1];
         if (fl & SR_FLAG_UNSORTED) {
             drop_marks();
             return UKM_OK;  // *fallback: the caller's general route sorts / reports it
@@ -1015,6 +1158,13 @@ int ukm_dev_srmerge(ukm_ctx *c, int op, const u64 *const *keys, const u32 *const
     a.R = R;
     a.per_xcd = (R + 7) / 8;
     a.threshold = uni ? threshold : 0;
+    {
+        const int force = ukm_env_int(c, "UKM_SRMERGE_BUCKETS", -1);  // developer knob
+        const double dup_share = ns ? (double)sample_dups / (double)ns : 0.0;
+        a.buckets = force >= 0 ? (u32)(force != 0) : (u32)(R > 1 && dup_share * 2.0 * (double)D < 1.5);
+        if (dbg) fprintf(stderr, "[srmerge] %llu of %llu samples equal their predecessor: ~%.1f copies per code -> %s\n", (unsigned long long)sample_dups,
+                         (unsigned long long)ns, 1.0 + dup_share * 2.0 * (double)D, a.buckets ? "counting placement" : "merge rounds");
+    }
     a.tax = ukm_taxdev(c);
     (void)hipEventRecord(c->ev_k0, c->stream);
     if (tax) {
