@@ -505,6 +505,29 @@ def main():
                 del Ao, Bo
             except Exception as e:
                 incl["offset_sharded_start"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
+            # The same step with each rank's range exchanged in FOUR sub-ranges by value: the rebuild of the slices that have
+            # arrived overlaps the transfer of the next sub-range (dist.redistribute_pipelined)
+            try:
+                def step_pipe():
+                    (Al, Bl), _ = ud.redistribute(ctx, [Af, Bf], 62, pipeline=4)
+                    u = ctx.setop2(lib.OP_UNION, Al, Bl, out=out_u)
+                    i = ctx.setop2(lib.OP_INTER, Al, Bl, out=out_i)
+                    return Al, Bl, u, i
+                Al, Bl, pu, pi = step_pipe()
+                assert torch.equal(Al, A) and torch.equal(Bl, B), "pipelined redistribution did not rebuild the rank's range"
+                assert pu.numel() == nu and pi.numel() == ni
+                del Al, Bl
+                barrier()
+                t4 = time.perf_counter()
+                for _ in range(args.steps):
+                    step_pipe()
+                barrier()
+                t4 = max_over_ranks(time.perf_counter() - t4)
+                incl["pipelined_4_subranges"] = {
+                    "value": 2.0 * g_in * args.steps / t4, "unit": "k-mers/s", "ms_per_step": t4 * 1e3 / args.steps,
+                    "note": "the end-to-end step with every input exchanged sub-range by sub-range (4 per rank): transfers overlap rebuilds"}
+            except Exception as e:
+                incl["pipelined_4_subranges"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
             # The same end-to-end step through the LIBRARY'S OWN exchange -- ukm_comm_init + ukm_shard_counts +
             # ukm_shard_exchange_known (grouped ncclSend / ncclRecv in ukm_comm.hip), the calls INTEGRATION.md's Go host
             # makes; torch.distributed only hands the communicator id over.  RCCL wants one device per rank, so the 1-GPU
@@ -571,6 +594,8 @@ def main():
                 res["incl_exchange"] = incl
                 if "value" in incl.get("offset_sharded_start", {}):
                     res["value_offset_sharded_start"] = incl["offset_sharded_start"]["value"]
+                if "value" in incl.get("pipelined_4_subranges", {}):
+                    res["value_pipelined_exchange"] = incl["pipelined_4_subranges"]["value"]
                 if "value" in incl.get("exchange_cabi", {}):
                     res["value_exchange_cabi"] = incl["exchange_cabi"]["value"]
             else:

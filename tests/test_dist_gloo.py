@@ -118,14 +118,20 @@ class _NumpyCtx:
     def partition_points(self, keys, splitters):
         return np.searchsorted(self._u(keys), np.array(splitters, dtype=np.uint64), side="left")
 
-    def merge_k(self, pieces, tpieces=None):
+    def merge_k(self, pieces, tpieces=None, out=None, out_taxids=None):
         cat = np.concatenate([self._u(p) for p in pieces]) if pieces else np.empty(0, np.uint64)
         o = np.argsort(cat, kind="stable")
         k = torch.from_numpy(cat[o].view(np.int64))
+        if out is not None:
+            out[:k.numel()].copy_(k)
+            k = out[:k.numel()]
         if tpieces is None:
             return k
-        t = np.concatenate([p.numpy() for p in tpieces])[o]
-        return k, torch.from_numpy(t)
+        t = torch.from_numpy(np.concatenate([p.numpy() for p in tpieces])[o])
+        if out_taxids is not None:
+            out_taxids[:t.numel()].copy_(t)
+            t = out_taxids[:t.numel()]
+        return k, t
 
     def unique(self, keys, taxids=None, mode=1):
         assert taxids is None and mode == 1
@@ -321,6 +327,13 @@ def _kmers_worker(rank, world, port, path, ret):
             out[name + "_A"] = local[0].numpy().view(np.uint64).copy()
             out[name + "_B"] = local[1].numpy().view(np.uint64).copy()
             out[name + "_merges"] = _CountingCtx.merges
+        # the exchange sub-range by sub-range (rebuild of what has arrived overlaps the next transfer): the same files
+        for Q in (3, 8):
+            lp, ltp = ud.redistribute(_NumpyCtx(), [t(A), t(B)], 62, files_taxids=[t(A).to(torch.int32) * 0 + rank, t(B).to(torch.int32) * 0 + 7],
+                                      splitters=spl, pipeline=Q)
+            out["pipe%d_A" % Q] = lp[0].numpy().view(np.uint64).copy()
+            out["pipe%d_B" % Q] = lp[1].numpy().view(np.uint64).copy()
+            out["pipe%d_tA" % Q] = ltp[0].numpy().copy()
         out["inter"] = ud.sharded_setop(_NumpyCtx(), "inter", [t(A), t(B)], 62, splitters="sampled").numpy().view(np.uint64).copy()
         out["union"] = ud.sharded_setop(_NumpyCtx(), "union", [t(A), t(B)], 62, splitters="sampled").numpy().view(np.uint64).copy()
         # a multiset file (every 5th code twice), stride-sharded: the rebuild keeps both copies
@@ -359,6 +372,14 @@ def test_sampled_splitters_balance_canonical_kmers_world2(tmp_path):
         assert np.array_equal(np.concatenate([r0[name + "_B"], r1[name + "_B"]]), B)
         # file A (stride-sharded) needs one merge per rank, file B (offset-sharded) none
         assert r0[name + "_merges"] == 1 and r1[name + "_merges"] == 1
+    for Q in (3, 8):
+        assert np.array_equal(r0["pipe%d_A" % Q], r0["sampled_A"]) and np.array_equal(r1["pipe%d_A" % Q], r1["sampled_A"])
+        assert np.array_equal(r0["pipe%d_B" % Q], r0["sampled_B"]) and np.array_equal(r1["pipe%d_B" % Q], r1["sampled_B"])
+        # file A is stride-sharded: equal-length runs never occur, every code keeps the taxid (= source rank) it came with
+        for r in (r0, r1):
+            ka, ta = r["pipe%d_A" % Q], r["pipe%d_tA" % Q]
+            pos = np.searchsorted(codes, ka)
+            assert np.array_equal(ta, (pos % world).astype(ta.dtype))
     eq = np.array([sum(r0["equal_sizes"]), sum(r1["equal_sizes"])], dtype=np.float64)
     sm = np.array([sum(r0["sampled_sizes"]), sum(r1["sampled_sizes"])], dtype=np.float64)
     assert eq.max() / eq.mean() > 1.2          # equal-width halves of the 62-bit code space: the low half is crowded

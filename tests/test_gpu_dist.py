@@ -226,6 +226,10 @@ def test_bench_two_ranks_incl_exchange():
     # the leg through the library's own exchange needs one device per rank (RCCL): recorded as skipped on this box;
     # tests/test_gpu_dist.py::test_redistribute_through_the_c_abi_one_rank runs the same calls on a one-rank communicator
     assert "skipped" in res["incl_exchange"]["exchange_cabi"]
+    # the sub-range pipeline (transfers overlap rebuilds) gives the same result sizes and a figure of its own
+    pipe = res["incl_exchange"]["pipelined_4_subranges"]
+    assert "error" not in pipe, pipe
+    assert pipe["value"] > 0 and res["value_pipelined_exchange"] == pipe["value"]
     assert res["incl_exchange"]["steps"] == 2 and res["config"]["per_gpu_set_size"] == 1_000_000
     assert res["config"]["global_set_size"] == 2_000_000
     assert res["roofline"]["frac"] > 0 and res["cpu_baseline"] is None

@@ -205,7 +205,103 @@ def pieces_in_value_order(recv, counts):
     return all(u[i] <= u[i + 1] for i in range(1, len(u) - 1, 2))
 
 
-def redistribute(ctx, files_keys, key_bits, files_taxids=None, group=None, with_sizes=False, splitters=None):
+def redistribute_pipelined(ctx, files_keys, key_bits, files_taxids=None, group=None, with_sizes=False, splitters=None, chunks=4):
+    """redistribute() with every rank's range cut into `chunks` sub-ranges BY VALUE and the exchange done sub-range by
+    sub-range: while the slices of sub-range q that have arrived are rebuilt (k-way merge of one piece per source rank, or
+    nothing when they arrive in value order), the all-to-all-v of sub-range q + 1 is already travelling (SURVEY 8(e):
+    "overlap per-peer transfers with merging of already-arrived ranges").  With two files (the metric) the plain pipeline
+    only hides file B's exchange behind file A's rebuild; here every exchange but the first hides behind a rebuild, and a
+    rank's peak receive buffer is 1 / chunks of a file.  The rebuilt sub-ranges are written side by side into one
+    preallocated tensor per file (they are disjoint, ascending value ranges), so the result is what redistribute() returns,
+    bit for bit.  One small all-to-all carries the slice sizes of all files and sub-ranges."""
+    world = dist.get_world_size(group)
+    Q = max(1, int(chunks))
+    spl_full = _resolve_splitters(files_keys, key_bits, splitters, group)
+    fine = []
+    for g in range(world):
+        lo, hi = int(spl_full[g]), int(spl_full[g + 1])
+        fine += [lo + ((hi - lo) * q) // Q for q in range(Q)]
+    nfiles = len(files_keys)
+    if nfiles == 0:
+        return ([], ([] if files_taxids is not None else None), []) if with_sizes else ([], ([] if files_taxids is not None else None))
+    dev = files_keys[0].device
+    cuts = []
+    for k in files_keys:
+        c = [int(x) for x in ctx.partition_points(k, fine)] + [k.numel()]
+        cuts.append(c)
+    # counts[i][g][q]: records of my file i for sub-range q of rank g
+    send = torch.tensor([[cuts[i][g * Q + q + 1] - cuts[i][g * Q + q] for i in range(nfiles) for q in range(Q)] for g in range(world)],
+                        dtype=torch.int64, device=dev)                       # [dest rank][file * Q + q]
+    recv = torch.empty_like(send)
+    _all_to_all(recv, send, group=group)
+    rc = recv.cpu().tolist()                                                 # [source rank][file * Q + q]
+    global_sizes = None
+    if with_sizes:
+        gs = torch.tensor([k.numel() for k in files_keys], dtype=torch.int64, device=dev if dist.get_backend(group) != "gloo" else "cpu")
+        dist.all_reduce(gs, op=dist.ReduceOp.SUM, group=group)
+        global_sizes = [int(x) for x in gs.cpu()]
+    units = [(i, q) for i in range(nfiles) for q in range(Q)]
+
+    def counts_of(i, q):
+        return [int(rc[src][i * Q + q]) for src in range(world)]
+
+    def issue(i, q):
+        k = files_keys[i]
+        c = cuts[i]
+        ins = [c[g * Q + q + 1] - c[g * Q + q] for g in range(world)]
+        sk = torch.cat([k[c[g * Q + q]:c[g * Q + q + 1]] for g in range(world)])   # the sub-range's slices, destination by destination
+        rcv = counts_of(i, q)
+        out = torch.empty(sum(rcv), dtype=k.dtype, device=k.device)
+        works = [_all_to_all(out, sk, rcv, ins, group, async_op=True)]
+        keep = [sk]
+        out_t = None
+        if files_taxids is not None:
+            t = files_taxids[i]
+            st = torch.cat([t[c[g * Q + q]:c[g * Q + q + 1]] for g in range(world)])
+            out_t = torch.empty(sum(rcv), dtype=t.dtype, device=t.device)
+            works.append(_all_to_all(out_t, st, rcv, ins, group, async_op=True))
+            keep.append(st)
+        return works, out, out_t, keep
+    totals = [sum(sum(counts_of(i, q)) for q in range(Q)) for i in range(nfiles)]
+    local = [torch.empty(totals[i], dtype=files_keys[i].dtype, device=dev) for i in range(nfiles)]
+    local_t = [torch.empty(totals[i], dtype=files_taxids[i].dtype, device=dev) for i in range(nfiles)] if files_taxids is not None else None
+    offs = [0] * nfiles
+    pending = issue(*units[0])
+    for u, (i, q) in enumerate(units):
+        nxt = issue(*units[u + 1]) if u + 1 < len(units) else None             # sub-range u + 1 travels while u is rebuilt
+        works, rk, rt, _keep = pending
+        for w in works:
+            w.wait()
+        counts = counts_of(i, q)
+        n = sum(counts)
+        dst = local[i][offs[i]:offs[i] + n]
+        dst_t = local_t[i][offs[i]:offs[i] + n] if local_t is not None else None
+        if n:
+            if pieces_in_value_order(rk, counts):
+                dst.copy_(rk)
+                if dst_t is not None:
+                    dst_t.copy_(rt)
+            else:
+                pieces = split_by_counts(rk, counts)
+                tpieces = split_by_counts(rt, counts) if rt is not None else None
+                merged = ctx.merge_k(pieces, tpieces, out=dst, out_taxids=dst_t) if dst_t is not None else ctx.merge_k(pieces, None, out=dst)
+                mk = merged[0] if dst_t is not None else merged
+                if mk.data_ptr() != dst.data_ptr():                             # (a context that ignores `out`)
+                    dst.copy_(mk)
+                    if dst_t is not None:
+                        dst_t.copy_(merged[1])
+        offs[i] += n
+        pending = nxt
+    return (local, local_t, global_sizes) if with_sizes else (local, local_t)
+
+
+def redistribute(ctx, files_keys, key_bits, files_taxids=None, group=None, with_sizes=False, splitters=None, pipeline=1):
+    if pipeline and int(pipeline) > 1:
+        return redistribute_pipelined(ctx, files_keys, key_bits, files_taxids, group, with_sizes, splitters, int(pipeline))
+    return _redistribute_whole(ctx, files_keys, key_bits, files_taxids, group, with_sizes, splitters)
+
+
+def _redistribute_whole(ctx, files_keys, key_bits, files_taxids=None, group=None, with_sizes=False, splitters=None):
     """Prefix redistribution of FILE-sharded sorted files: every logical file is exchanged ONCE and rebuilt on its
     range owner.  Slices that arrive already in value order (offset-sharded inputs) are the rebuilt file as they lie in
     the receive buffer; otherwise the slices, which overlap in value, go through the keep-EVERYTHING k-way merge
@@ -286,7 +382,7 @@ def redistribute_cabi(ctx, files_keys, key_bits, files_taxids=None, splitters=No
     return local, local_t
 
 
-def _joined(pieces):def _joined(pieces):
+def _joined(pieces):
     """the tensor the back-to-back views `pieces` were cut from (split_by_counts), or None if they are not adjacent"""
     base = pieces[0]
     total = sum(x.numel() for x in pieces)
