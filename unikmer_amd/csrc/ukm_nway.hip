@@ -276,33 +276,37 @@ int try_kway(ukm_ctx *ctx, int op, std::vector<Stream> ss, bool tax, u64 *fk, u3
         const bool forced = ukm_env_is(ctx, "UKM_KWAY", '1');
         if (!forced && ss.size() <= 4 && total < (1u << 16)) return UKM_OK;
     }
-    UKM_TRY(materialise_all(ctx, ss, tax));  // (these merges read a taxid per record)
     std::vector<const u64 *> kp(ss.size());
     std::vector<const u32 *> tp(ss.size());
     std::vector<u64> ln(ss.size());
+    std::vector<u32> cv(ss.size());
     for (size_t i = 0; i < ss.size(); i++) {
         kp[i] = ss[i].k;
         tp[i] = ss[i].t;
         ln[i] = ss[i].n;
+        cv[i] = ss[i].t ? 0u : ss[i].ct;
     }
-    WsMark mark = ws_mark(ctx);
     bool fallback = true;
     if (op == UKM_KWAY_MERGE) {
         // many files that share most of their codes: the records of every code are placed behind one another file by file
         // (ukm_punion.hip, pl_merge_kernel); it declines for few / small files, files that share little, a duplicate
-        // inside a file, an unsorted file
+        // inside a file, an unsorted file.  (A file with ONE taxid goes in as it is: the kernel writes the scalar.)
+        WsMark pmark = ws_mark(ctx);
         const int prc = ukm_dev_place_merge(ctx, kp.data(), tax ? tp.data() : nullptr, ln.data(), (int)ss.size(), tax, fk, ft, fcap, n_out,
-                                            &fallback);
+                                            &fallback, tax ? cv.data() : nullptr);
         if (prc != UKM_OK || !fallback) {
-            ws_release(ctx, mark);
+            ws_release(ctx, pmark);
             UKM_TRY(prc);
             ctx->last_route = 7;
             *done = true;
             return UKM_OK;
         }
-        ws_release(ctx, mark);
+        ws_release(ctx, pmark);
         fallback = true;
     }
+    UKM_TRY(materialise_all(ctx, ss, tax));  // (the merges below read a taxid per record)
+    for (size_t i = 0; i < ss.size(); i++) tp[i] = ss[i].t;
+    WsMark mark = ws_mark(ctx);
     {
         // many short streams: one pass over HBM, every value range ordered inside LDS (ukm_srmerge.hip); it declines
         // (*fallback) for few streams, small inputs, unsorted streams and one code with thousands of copies
@@ -1012,7 +1016,29 @@ extern "C" int ukm_merge_k_ft(ukm_ctx *ctx, const uint64_t *const *keys, const u
                 *n_out = 0;
             }
         }
-        UKM_TRY(materialise_all(ctx, all, tax));  // (the merges and the run scan read a taxid per record)
+        {
+            // every file carries the SAME one taxid (the chunk files of `sort -m` over a `count -t` file: util-sort.go writes
+            // the input's global taxid into every chunk): whatever the mode folds, LCA(x, x) = x -- the PLAIN merge and a fill
+            std::vector<Stream> live;
+            for (auto &q : all)
+                if (q.n) live.push_back(q);
+            bool same = all_per_file(live, tax) && !live.empty();
+            for (auto &q : live) same = same && q.ct == live[0].ct;
+            if (same) {
+                const u32 ct = live[0].ct;
+                strip_taxids(all);
+                u64 *k = nullptr;
+                u32 *t = nullptr;
+                u64 total = 0, need = 0;
+                for (auto &s : all) need += s.n;
+                const bool direct = m == UKM_PLAIN && need <= out_cap;
+                UKM_TRY(merged_sequence(ctx, all, false, &k, &t, &total, direct ? o.k : nullptr, nullptr));
+                if (total == 0) return UKM_OK;
+                if (direct && k == o.k) *n_out = total;
+                else UKM_TRY(ukm_dev_unique(ctx, k, nullptr, total, m, o.k, nullptr, out_cap, n_out));
+                return ukm_dev_fill_u32(ctx, o.t, *n_out, ct);
+            }
+        }
         u64 *k = nullptr;
         u32 *t = nullptr;
         u64 total = 0, need = 0;

@@ -23,4 +23,4 @@ int ukm_dev_probe_common(ukm_ctx *c, const u64 *const *keys, const u32 *const *t
 // developer knob UKM_PLACE: 0 = never, 1 = whenever the shape allows it.  *fallback as above.
 int ukm_place_mode(const ukm_ctx *c);
 int ukm_dev_place_merge(ukm_ctx *c, const u64 *const *keys, const u32 *const *taxids, const u64 *lens, int S, bool tax, u64 *out,
-                        u32 *tout, u64 out_cap, u64 *n_out, bool *fallback);
+                        u32 *tout, u64 out_cap, u64 *n_out, bool *fallback, const u32 *ctax = nullptr);

@@ -1449,6 +1449,7 @@ __global__ __launch_bounds__(PL_NT) void pl_merge_kernel(PuArgs a) {
         const u64 end = end0 < beg ? beg : end0;
         const unsigned short *ri = a.rec_idx + sload_u64(&a.rec_off[j]);
         const u32 *tp = TAX ? (const u32 *)(uintptr_t)sload_u64((const u64 *)&a.tfiles[j]) : nullptr;
+        const u32 ftax = (TAX && a.cte) ? (u32)sload_u64(&a.cte[j]) : 0u;  // the file's ONE taxid when it has no array (round 5)
         for (u64 p0 = beg; p0 < end; p0 += 512) {
             u32 i[8], t[8];
 #pragma unroll
@@ -1457,7 +1458,7 @@ __global__ __launch_bounds__(PL_NT) void pl_merge_kernel(PuArgs a) {
                 const u64 q = pos < end ? pos : beg;
                 i[u] = ri[q];
                 i[u] = i[u] < (u32)PL_RANGE ? i[u] : 0u;
-                t[u] = (TAX && tp) ? tp[q] : 0u;
+                t[u] = (TAX && tp) ? tp[q] : ftax;
             }
 #pragma unroll
             for (int u = 0; u < 8; u++) {
@@ -2332,7 +2333,7 @@ int ukm_place_mode(const ukm_ctx *c) { return ukm_env_int(c, "UKM_PLACE", -1); }
 // Keep-everything merge by placement (pl_merge_kernel).  *fallback = true: not this path (few or small files, files that
 // share too little, a duplicate inside a file, an unsorted file): nothing that matters was written.
 int ukm_dev_place_merge(ukm_ctx *c, const u64 *const *keys, const u32 *const *taxids, const u64 *lens, int S, bool tax, u64 *out,
-                        u32 *tout, u64 out_cap, u64 *n_out, bool *fallback) {
+                        u32 *tout, u64 out_cap, u64 *n_out, bool *fallback, const u32 *ctax) {
     *fallback = true;
     *n_out = 0;
     const int mode = ukm_place_mode(c);
@@ -2356,14 +2357,17 @@ int ukm_dev_place_merge(ukm_ctx *c, const u64 *const *keys, const u32 *const *ta
         fprintf(stderr, "[place] %-10s %8.3f ms\n", what, ms_since(t0));
         t0 = std::chrono::steady_clock::now();
     };
-    // 0. device tables of the files: [pointers S][lens S][TaxId pointers S][offsets of the files' records S]
-    std::vector<u64> tab((size_t)4 * S);
+    // 0. device tables of the files: [pointers S][lens S][TaxId pointers S][offsets of the files' records S][file taxids S]
+    std::vector<u64> tab((size_t)5 * S);
     u64 off = 0;
+    bool any_ct = false;
     for (int j = 0; j < S; j++) {
         tab[(size_t)j] = (u64)(uintptr_t)keys[j];
         tab[(size_t)S + j] = lens[j];
         tab[(size_t)2 * S + j] = (u64)(uintptr_t)((tax && taxids) ? taxids[j] : nullptr);
         tab[(size_t)3 * S + j] = off;
+        tab[(size_t)4 * S + j] = (tax && ctax && !(taxids && taxids[j])) ? (u64)ctax[j] : 0ull;
+        any_ct = any_ct || tab[(size_t)4 * S + j] != 0;
         off += lens[j];
     }
     u64 *d_tab = nullptr, *ctl = nullptr;
@@ -2378,6 +2382,7 @@ int ukm_dev_place_merge(ukm_ctx *c, const u64 *const *keys, const u32 *const *ta
     a.lens = d_tab + S;
     a.tfiles = (const u32 *const *)(d_tab + 2 * (size_t)S);
     a.rec_off = d_tab + 3 * (size_t)S;
+    a.cte = any_ct ? d_tab + 4 * (size_t)S : nullptr;
     a.S1 = (u32)S;
     a.ctl = ctl;
     if (mode < 1) {
