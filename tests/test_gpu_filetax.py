@@ -320,3 +320,22 @@ def test_inter_diff_common_file_taxids_many_files(env, monkeypatch):
         _eq(ctx.diff(files[:40], taxs[:40], compare_taxid=True), exp_dt, ("diff -t", no_pf, no_fold))
         _eq(ctx.common(files[:200], 200, taxs[:200]), exp_c, ("common", no_pf, no_fold))
     assert len(exp_i[0]) > 100 and len(exp_c[0]) > 100
+
+
+def test_merge_by_placement_with_file_taxids(env, monkeypatch):
+    """keep-everything `merge` (mergeChunksFile, util-sort.go:196-225,289-351) of files with ONE taxid each through the
+    placement route: the kernel writes the file's taxid as a scalar (no array is built); files that all carry the same taxid
+    -- the chunk files of `sort -m` over a `count -t` file -- are the plain merge and a fill"""
+    O, L, ctx, tax, pool, kind = env
+    monkeypatch.setenv("UKM_PLACE", "1")
+    files = _files(120, 9_000, 0.8, seed=3)
+    per_file = [int(pool[(5 * i + 2) % len(pool)]) for i in range(len(files))]
+    mixed = [per_file[i] if i % 3 else _taxids(f, pool, i) for i, f in enumerate(files)]
+    for name, taxs in (("per file", per_file), ("mixed", mixed), ("same", [int(pool[3])] * len(files))):
+        ex = _expand(files, taxs)
+        for mode in (L.PLAIN, L.UNIQUE, L.REPEATED):
+            gk, gt = ctx.merge_k(files, taxs, mode=mode)
+            if mode == L.PLAIN and name != "same":
+                assert ctx.last_route() == 7, (name, ctx.last_route())
+            ok, ot = O.merge_k(files, ex, mode=mode, tax=tax)
+            assert np.array_equal(gk, ok) and np.array_equal(gt, ot), (name, mode)
