@@ -52,13 +52,14 @@ def _stable(streams, taxs=None):
     return (cat[o], np.concatenate(taxs)[o]) if taxs is not None else cat[o]
 
 
-@pytest.mark.parametrize("buckets", [None, "1", "0"])
+@pytest.mark.parametrize("buckets", [None, "1", "0", "2"])
 @pytest.mark.parametrize("nfiles,per,p", [(200, 3000, 0.02), (1000, 700, 0.002), (1024, 300, 0.5), (65, 20000, 0.3), (700, 2500, 0.0008)])
 def test_merge_modes_and_union_many_streams(env, monkeypatch, nfiles, per, p, buckets):
     """every mode of the merge and the union, plain and with taxids; files that hardly overlap, that overlap heavily
     (runs of hundreds of equal codes across files), 1024 = the most streams the route takes.  buckets: the tiles ordered by
     the library's own choice, by counting placement wherever a tile allows it (tiles with a crowded bucket fall back to the
-    merge rounds one by one: both orders in one launch), by the merge rounds alone"""
+    merge rounds one by one: both orders in one launch), by the merge rounds alone, by the dense code numbers wherever a
+    tile holds at most 256 distinct codes (the other tiles are put back for the merge rounds)"""
     O, L, ctx, tax, T = env
     monkeypatch.setenv("UKM_SRMERGE", "1")
     if buckets is not None:
@@ -98,13 +99,16 @@ def test_merge_modes_and_union_many_streams(env, monkeypatch, nfiles, per, p, bu
     assert np.array_equal(gk2, ek) and np.array_equal(gt2, et)
 
 
+@pytest.mark.parametrize("order", [None, "2"])
 @pytest.mark.parametrize("fill", ["150", "400"])
-def test_ranges_that_do_not_fit_a_tile_are_worked_off_by_value(env, monkeypatch, fill):
+def test_ranges_that_do_not_fit_a_tile_are_worked_off_by_value(env, monkeypatch, fill, order):
     """UKM_SRMERGE_FILL = 150 / 400 % of a tile per range on average: every range takes two to five passes (quota rule);
     multiset streams and ties across many streams included"""
     O, L, ctx, tax, T = env
     monkeypatch.setenv("UKM_SRMERGE", "1")
     monkeypatch.setenv("UKM_SRMERGE_FILL", fill)
+    if order is not None:
+        monkeypatch.setenv("UKM_SRMERGE_BUCKETS", order)
     rng = np.random.default_rng(int(fill))
     nfiles = 300
     streams = [np.sort(rng.integers(0, 1 << 20, 900 + 7 * i).astype(np.uint64)) for i in range(nfiles)]   # many ties, duplicates inside
@@ -122,12 +126,15 @@ def test_ranges_that_do_not_fit_a_tile_are_worked_off_by_value(env, monkeypatch,
     assert np.array_equal(gk, ok) and np.array_equal(gt, ot)
 
 
-def test_uneven_streams_all_ones_codes_and_a_crowded_code(env, monkeypatch):
+@pytest.mark.parametrize("order", [None, "2"])
+def test_uneven_streams_all_ones_codes_and_a_crowded_code(env, monkeypatch, order):
     """stream sizes from 1 record to 60 000; real 2^64-1 codes (the kernel's own sentinel value); one code present in
     every stream several times (a run longer than a thread's share, shorter than a tile); then the same with one code in
     MORE copies than a tile holds: the route declines and the multi-level merge answers, same result"""
     O, L, ctx, tax, T = env
     monkeypatch.setenv("UKM_SRMERGE", "1")
+    if order is not None:
+        monkeypatch.setenv("UKM_SRMERGE_BUCKETS", order)
     rng = np.random.default_rng(9)
     sizes = [1, 2, 3, 60_000, 17, 9, 4608, 4609, 512, 1, 30_000] + [int(x) for x in rng.integers(1, 400, 190)]
     allones = np.uint64(0xFFFFFFFFFFFFFFFF)
