@@ -326,6 +326,11 @@ def test_sort_top16_then_lds_buckets(env, monkeypatch):
     y[:5] = -1                                                                # all ones (as 64-bit patterns)
     cases.append((y, 64))
     cases.append((torch.full((n,), 123456789, dtype=torch.int64, device=dev), 62))
+    # the buckets' counting step (round 5): keys of a bucket that differ in their lowest 20 bits only share ONE bin (the
+    # bucket takes the digit passes), and keys with ~40 copies each fill bins up to and beyond the walk's limit
+    cases.append((rnd(62) & ~(((1 << 26) - 1) << 20), 62))
+    z = rnd(62, n // 40).repeat(40)
+    cases.append((z[torch.randperm(z.numel(), device=dev, generator=g)], 62))
     for x, bits in cases:
         exp = usort(x)
         for knob in (None, "0"):

@@ -157,6 +157,7 @@ extern "C" int ukm_ctx_destroy(ukm_ctx *c) {
     if (c->tax_euler) (void)hipFree(c->tax_euler);
     if (c->tax_node_at) (void)hipFree(c->tax_node_at);
     if (c->h_scratch) (void)hipHostFree(c->h_scratch);
+    if (c->sort_stat_dev) (void)hipFree(c->sort_stat_dev);
     if (c->ev_start) (void)hipEventDestroy(c->ev_start);
     if (c->ev_stop) (void)hipEventDestroy(c->ev_stop);
     if (c->ev_k0) (void)hipEventDestroy(c->ev_k0);

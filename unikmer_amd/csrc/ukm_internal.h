@@ -125,6 +125,13 @@ struct ukm_ctx {
     bool setop_force_ticket = false;
     // set once a sort found its keys crowded into few top-16-bit buckets (ukm_sort.hip): later sorts look at a sample first
     bool sort_skew_seen = false;
+    // buckets of the last bucket-route sort that fell back from the counting step to the digit passes (device word, bumped by
+    // ls_sort_kernel, fetched by the NEXT sort's classify kernel so that it rides on that call's read-back): keys with many
+    // copies each (k-mers of reads at coverage) make every bucket fall back, and the next calls skip the attempt
+    u64 *sort_stat_dev = nullptr;
+    bool sort_last_counting = false;
+    u64 sort_last_buckets = 0;
+    int sort_counting_skip = 0;
     // set around the sort of the gathered oversized buckets: those keys are crowded by construction, the general passes take them
     bool sort_general_only = false;
 };

@@ -465,6 +465,8 @@ struct LocalSortArgs {
     const u64 *start;  // [2^topb + 1]
     int low_bits;      // bits below the bucket bits
     const u32 *ids;    // the buckets of this launch's size class
+    int counting;      // 1: one counting step + a walk inside the bins (round 5); 0: digit passes only
+    u64 *stat;         // [0] += 1 per bucket that fell back from the counting step
 };
 
 // start[b] = first index whose bucket value (key >> low_bits) is >= b (b = 0 .. 2^topb)
@@ -518,8 +520,9 @@ __global__ void ls_sample_count_kernel(const u32 *cnt, u32 thr, u64 *out) {  // 
 
 // size class of every bucket: cls[k] = number of buckets of class k (k = LS_NCLASS: beyond every class, their ids in
 // cls[LS_NCLASS + 1 ...]); ids[k][...] = the buckets of class k
-__global__ void ls_classify_kernel(const u64 *start, u64 *cls, u32 *ids, int topb, u32 *big_ids, u64 *big_size) {
+__global__ void ls_classify_kernel(const u64 *start, u64 *cls, u32 *ids, int topb, u32 *big_ids, u64 *big_size, u64 *stat) {
     const u32 b = blockIdx.x * blockDim.x + threadIdx.x;  // (the grid covers the buckets exactly)
+    if (b == 0) cls[LS_NCLASS + 2] = (u64)atomicExch((unsigned long long *)stat, 0ull);  // the previous call's fall-backs
     const u64 m = start[b + 1] - start[b];
     int k = -1;
     if (m > 0) {  // (a bucket of one key still has to reach the caller's array when the sorted-by-top-bits copy is the scratch)
@@ -571,10 +574,29 @@ __global__ void ls_big_copy_kernel(const u32 *big_ids, const u64 *start, const u
     }
 }
 
+// Round 5: ONE counting step instead of the six digit passes.  The bucket's keys are spread over NBIN >= capacity bins
+// by the bits right below the bucket bits (an LDS atomic per key: its arrival number inside the bin), the bin sizes are
+// scanned, every key is put into its bin's range, and its place INSIDE the bin is the number of the bin's keys that
+// precede it -- a walk over 1.4 keys on average for evenly spread low bits (k-mer codes, hashes), instead of five more
+// passes of 8 ballots, two counter updates, four barriers and an LDS round trip each.  Equal keys are ordered by their
+// place in the input (pairs: the sort stays stable; plain keys: any order).  A bucket with a bin of more than LS_BIN_MAX
+// keys (a repeated k-mer, keys that differ in their lowest bits only) takes the digit passes as before.
+constexpr u32 LS_BIN_MAX = 64;
+#ifndef LS_WALK_MAX
+#define LS_WALK_MAX 4u  /* keys read by the walks, per key of the bucket, beyond which the bucket takes the digit passes (1.75 on evenly spread keys) */
+#endif
+template <int CAP> struct LsBins {
+    static constexpr int NBIN = CAP <= 256 ? 256 : CAP <= 512 ? 512 : CAP <= 1024 ? 1024 : CAP <= 2048 ? 2048 : 4096;
+    static constexpr int HB = CAP <= 256 ? 8 : CAP <= 512 ? 9 : CAP <= 1024 ? 10 : CAP <= 2048 ? 11 : 12;
+};
+
 template <int LS_KPT, bool PAIRS = false>
 __global__ __launch_bounds__(LS_NT) void ls_sort_kernel(LocalSortArgs a) {
     constexpr int LS_CAP = LS_NT * LS_KPT;
-    __shared__ u64 s_buf[2][LS_CAP];
+    constexpr int NBIN = LsBins<LS_CAP>::NBIN, HB = LsBins<LS_CAP>::HB, BPT = NBIN / LS_NT;
+    static_assert((NBIN + 1) * 4 <= LS_CAP * 8, "the bin counters live in the second key buffer");
+    static_assert(LS_CAP <= 65536, "16-bit input positions");
+    __shared__ __attribute__((aligned(16))) u64 s_buf[2][LS_CAP];
     __shared__ u32 s_vbuf[PAIRS ? 2 : 1][PAIRS ? LS_CAP : 1];
     __shared__ unsigned short s_wh[LS_NW][RADIX];
     __shared__ u32 s_dex[RADIX];
@@ -593,6 +615,89 @@ __global__ __launch_bounds__(LS_NT) void ls_sort_kernel(LocalSortArgs a) {
         const u32 i = wbase + j * 64;
         key[j] = i < m ? a.src[beg + i] : ~0ull;  // padding: the highest digit in every pass, last in tile order
         if (PAIRS) val[j] = i < m ? a.vsrc[beg + i] : 0u;
+    }
+    if (a.counting && a.low_bits >= HB) {
+        u32 *s_cnt = reinterpret_cast<u32 *>(&s_buf[1][0]);                         // [NBIN + 1]
+        unsigned short *s_idx = reinterpret_cast<unsigned short *>(&s_vbuf[PAIRS ? 1 : 0][0]);  // (pairs) input position of the key at a place
+        u64 *grp = &s_buf[0][0];
+        const int bshift = a.low_bits - HB;
+        for (int i = tid; i < NBIN + 1; i += LS_NT) s_cnt[i] = 0;
+        __syncthreads();
+        u32 pos[LS_KPT];
+#pragma unroll
+        for (int j = 0; j < LS_KPT; j++) {
+            const u32 bin = (u32)(key[j] >> bshift) & (u32)(NBIN - 1);
+            pos[j] = 0;
+            if (wbase + j * 64 < m) pos[j] = atomicAdd(&s_cnt[bin], 1u);
+        }
+        __syncthreads();
+        u32 c[BPT], sum = 0, mx = 0, sq = 0;
+#pragma unroll
+        for (int q = 0; q < BPT; q++) {
+            c[q] = s_cnt[tid * BPT + q];
+            sum += c[q];
+            mx = c[q] > mx ? c[q] : mx;
+            sq += c[q] * c[q];  // the walks below read (bin size)^2 keys per bin
+        }
+        u32 total = 0;
+        u32 run = block_excl_scan_u32<LS_NT>(sum, s_scan, &total);
+        const u32 wsq = wave_incl_scan_u32(sq);
+        if (lane == 63) s_scan[wave] = wsq;
+        int heavy = __syncthreads_or(mx > LS_BIN_MAX);
+        u32 walk = 0;
+#pragma unroll
+        for (int w = 0; w < LS_NW; w++) walk += s_scan[w];
+        heavy |= walk > LS_WALK_MAX * m + 512u;  // (workgroup-uniform) e.g. every key four times: the digit passes are cheaper
+        if (heavy && tid == 0) atomicAdd((unsigned long long *)a.stat, 1ull);
+        if (!heavy) {
+#pragma unroll
+            for (int q = 0; q < BPT; q++) {
+                s_cnt[tid * BPT + q] = run;
+                run += c[q];
+            }
+            if (tid == LS_NT - 1) s_cnt[NBIN] = run;
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < LS_KPT; j++) {
+                const u32 i = wbase + j * 64;
+                if (i < m) {
+                    const u32 bin = (u32)(key[j] >> bshift) & (u32)(NBIN - 1);
+                    pos[j] += s_cnt[bin];
+                    grp[pos[j]] = key[j];
+                    if (PAIRS) s_idx[pos[j]] = (unsigned short)i;
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < LS_KPT; j++) {
+                const u32 i = wbase + j * 64;
+                if (i < m) {
+                    const u32 bin = (u32)(key[j] >> bshift) & (u32)(NBIN - 1);
+                    const u32 s = s_cnt[bin], e = s_cnt[bin + 1];
+                    u32 r = s;
+                    for (u32 t = s; t < e; t++) {
+                        const u64 k2 = grp[t];
+                        const bool first = PAIRS ? (u32)s_idx[t] < i : t < pos[j];
+                        r += (k2 < key[j] || (k2 == key[j] && first)) ? 1u : 0u;
+                    }
+                    pos[j] = r;
+                }
+            }
+            __syncthreads();  // every walk is over: the final order goes into the same buffer
+#pragma unroll
+            for (int j = 0; j < LS_KPT; j++) {
+                if (wbase + j * 64 < m) {
+                    grp[pos[j]] = key[j];
+                    if (PAIRS) s_vbuf[0][pos[j]] = val[j];
+                }
+            }
+            __syncthreads();
+            for (u32 i = (u32)tid; i < m; i += LS_NT) {
+                a.keys[beg + i] = grp[i];
+                if (PAIRS) a.vals[beg + i] = s_vbuf[0][i];
+            }
+            return;
+        }
     }
     const u32 lt_lo = lane < 32 ? ((1u << lane) - 1u) : ~0u;
     const u32 lt_hi = lane < 32 ? 0u : ((1u << (lane - 32)) - 1u);
@@ -752,7 +857,11 @@ int sort_top16_local(ukm_ctx *c, u64 *keys, u32 *vals, u64 n, int key_bits, bool
     // per class that occurs, and the few buckets beyond 4096 keys are sorted by the general route.
     u64 *cls = nullptr;
     u32 *ids = nullptr;
-    static_assert(LS_NCLASS + 2 <= 64, "read-back through the scratch");
+    static_assert(LS_NCLASS + 3 <= 64, "read-back through the scratch");
+    if (!c->sort_stat_dev) {
+        UKM_HIP(hipMalloc((void **)&c->sort_stat_dev, 64));
+        UKM_HIP(hipMemsetAsync(c->sort_stat_dev, 0, 64, c->stream));
+    }
     u32 *big_ids = nullptr;
     u64 *big_size = nullptr;
     UKM_TRY(ws_alloc_t(c, (size_t)LS_NCLASS + 3, &cls));
@@ -760,10 +869,13 @@ int sort_top16_local(ukm_ctx *c, u64 *keys, u32 *vals, u64 n, int key_bits, bool
     UKM_TRY(ws_alloc_t(c, (size_t)LS_MAX_BIG, &big_ids));
     UKM_TRY(ws_alloc_t(c, (size_t)nbuckets + 1, &big_size));
     UKM_HIP(hipMemsetAsync(cls, 0, (LS_NCLASS + 3) * sizeof(u64), c->stream));
-    hipLaunchKernelGGL(ls_classify_kernel, dim3(nbuckets / 256), dim3(256), 0, c->stream, start, cls, ids, topb, big_ids, big_size);
+    hipLaunchKernelGGL(ls_classify_kernel, dim3(nbuckets / 256), dim3(256), 0, c->stream, start, cls, ids, topb, big_ids, big_size, c->sort_stat_dev);
     UKM_HIP(hipGetLastError());
-    u64 hc[LS_NCLASS + 2];
-    UKM_TRY(ukm_read_u64(c, cls, hc, LS_NCLASS + 2));
+    u64 hc[LS_NCLASS + 3];
+    UKM_TRY(ukm_read_u64(c, cls, hc, LS_NCLASS + 3));
+    // (hc[LS_NCLASS + 2]: buckets of the PREVIOUS bucket-route sort on this context that fell back to the digit passes.  More
+    //  than half of them: keys with several copies each, the next 15 sorts do not try the counting step)
+    if (c->sort_last_counting && hc[LS_NCLASS + 2] * 2 > c->sort_last_buckets) c->sort_counting_skip = 15;
     const u64 big_keys = hc[LS_NCLASS + 1];
     // oversized buckets are gathered and sorted by ONE call of the general route: worth it for a few of them holding a
     // minor share of the keys, else the general passes sort everything (keys crowded into few buckets)
@@ -774,6 +886,15 @@ int sort_top16_local(ukm_ctx *c, u64 *keys, u32 *vals, u64 n, int key_bits, bool
     }
     LocalSortArgs a;
     a.src = src; a.vsrc = vsrc; a.keys = keys; a.vals = vals; a.n = n; a.start = start; a.low_bits = low_bits;
+    a.counting = ukm_env_is(c, "UKM_SORT_COUNTING", '0') ? 0 : 1;  // developer knob: 0 = digit passes in every bucket
+    if (a.counting && c->sort_counting_skip > 0 && !ukm_env_is(c, "UKM_SORT_COUNTING", '1')) {
+        a.counting = 0;
+        c->sort_counting_skip--;
+    }
+    a.stat = c->sort_stat_dev;
+    c->sort_last_counting = a.counting != 0;
+    c->sort_last_buckets = 0;
+    for (int k = 0; k < LS_NCLASS; k++) c->sort_last_buckets += hc[k];
     const dim3 block(LS_NT);
 #define LS_LAUNCH(K)                                                                                          \
     do {                                                                                                      \
