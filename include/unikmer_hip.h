@@ -139,7 +139,7 @@ int ukm_ctx_get_stat(ukm_ctx *ctx, const char *key, unsigned long long *value);
  *      child/parent = the first two columns of nodes.dmp; merged_* = merged.dmp (may be NULL).
  *      Contract (taxdump parity is unpinned): LCA(0,x)=LCA(x,0)=0; LCA(x,x)=x;
  *      merged ids are remapped; ids absent from nodes.dmp -> 0.
- *      The device tables are dense in the taxid (>= 25 bytes per id up to the largest one, 16 more per id for every four
+ *      The device tables are dense in the taxid (>= 27 bytes per id up to the largest one, 16 more per id for every four
  *      levels of depth): NCBI's dump takes ~0.7 GB; a dump with sparse huge ids is refused (UKM_ERR_NOMEM, message says
  *      how much it would need) when that exceeds the device's free memory -- counted after the context's cached workspace
  *      has been given back and with the tables being replaced credited.  A load either replaces the context's taxonomy

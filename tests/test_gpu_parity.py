@@ -170,6 +170,63 @@ def test_lca_merged_and_forest(ctx, O):
     c.close()
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", ["wide_root", "forest_300", "forest_70000", "bushy"])
+def test_lca_clade_code_forms(O, L, shape):
+    """Round 5: pairs of unrelated taxids are settled by per-id clade codes (ukm_tax.hip: the ancestor at depth <= D as a
+    one-byte or two-byte index, D chosen by what fits) and the rest by the root paths.  Every form against the oracle's
+    ancestor walk: a root with 400 children (one byte holds the root alone: every pair takes the root paths), a forest of
+    300 trees (two-byte codes), one of 70,000 roots (no table at all), a bushy tree (one byte, depth 2); with ids that
+    are zero, unknown, absent inside the range and merged."""
+    child, parent = [], []
+    nxt = [1]
+
+    def new(par=None):
+        t = nxt[0]; nxt[0] += 1
+        if t % 37 == 0:              # (a gap: an id that is absent inside the range)
+            t = nxt[0]; nxt[0] += 1
+        child.append(t); parent.append(t if par is None else par)
+        return t
+
+    def subtree(par, fan, depth):
+        if depth == 0:
+            return
+        for _ in range(fan):
+            subtree(new(par), fan, depth - 1)
+
+    if shape == "wide_root":
+        r = new()
+        for _ in range(400):
+            subtree(new(r), 3, 1)
+    elif shape == "forest_300":
+        for _ in range(300):
+            subtree(new(), 3, 3)
+    elif shape == "forest_70000":
+        for i in range(70000):
+            r = new()
+            if i % 100 == 0:
+                subtree(r, 2, 2)
+    else:
+        subtree(new(), 6, 5)
+    child, parent = np.array(child, dtype=np.uint32), np.array(parent, dtype=np.uint32)
+    top = int(child.max())
+    mo = np.array([top + 5, top + 6, top + 7], dtype=np.uint32)
+    mn = np.array([child[len(child) // 2], child[3], top + 900], dtype=np.uint32)   # (the last one: merged into nothing)
+    c = L.Context(0)
+    c.taxonomy_load(child, parent, mo, mn)
+    tax = O.Taxonomy(child, parent, mo, mn)
+    rng = np.random.default_rng(17)
+    a = rng.integers(0, top + 12, 30000).astype(np.uint32)
+    b = rng.integers(0, top + 12, 30000).astype(np.uint32)
+    b[::11] = a[::11]
+    # relatives: a node against a node a few ids away (same subtree more often than not)
+    a[1::5] = child[rng.integers(0, len(child), len(a[1::5]))]
+    b[1::5] = np.minimum(a[1::5] + rng.integers(0, 4, len(a[1::5])).astype(np.uint32), top)
+    exp = np.array([tax.lca(x, y) for x, y in zip(a, b)], dtype=np.uint32)
+    assert np.array_equal(c.lca(a, b), exp)
+    c.close()
+
+
 def test_failed_taxonomy_load_leaves_the_previous_one(O, L):
     """A load either replaces the taxonomy completely or not at all (round-3 advice): a dump whose dense tables do not fit
     the device's free memory (a sparse huge taxid), a cyclic dump and taxid 0 are refused with an error, and the context

@@ -214,20 +214,41 @@ __device__ __forceinline__ u64 lb_lookback(u64 *status, u64 tile, u64 agg) {
 struct LcaReq {
     u32 a, b;
     uint4 pa, pb;
+    u32 ca, cb;  // clade codes (when the taxonomy has them the root-path rows are fetched by lca_finish, and only for relatives)
 };
+__device__ __forceinline__ bool tax_has_clades(const TaxDev &T) {
+#ifdef UKM_NO_CLADE
+    return false;
+#else
+    return T.clade != nullptr || T.clade8 != nullptr;
+#endif
+}
 __device__ __forceinline__ void lca_begin(const TaxDev &T, u32 a, u32 b, LcaReq &q) {
     const uint4 zero = make_uint4(0, 0, 0, 0);
     q.a = a;
     q.b = b;
     const bool trivial = a == 0 || b == 0 || a == b;
+    q.ca = q.cb = 0;
+    q.pa = q.pb = zero;
+    if (tax_has_clades(T)) {  // (uniform over the launch)
+        const bool go = !trivial && a < T.size && b < T.size;
+        if (T.clade8) { q.ca = go ? T.clade8[a] : 0u; q.cb = go ? T.clade8[b] : 0u; }
+        else { q.ca = go ? T.clade[a] : 0u; q.cb = go ? T.clade[b] : 0u; }
+        return;
+    }
     q.pa = (!trivial && a < T.size) ? T.anc[a] : zero;
     q.pb = (!trivial && b < T.size) ? T.anc[b] : zero;
 }
-__device__ __forceinline__ u32 lca_finish(const TaxDev &T, const LcaReq &q) {
-    u32 a = q.a, b = q.b;
-    if (a == 0 || b == 0) return 0;
-    if (a == b) return a;
-    uint4 pa = q.pa, pb = q.pb;
+// the LCA of two clade nodes with different codes: their root paths (at most four levels) part, or one of them ends
+__device__ __forceinline__ u32 lca_clade_pair(const TaxDev &T, u32 ca, u32 cb) {
+    const uint4 ta = T.top[ca], tb = T.top[cb];
+    if (ta.x != tb.x) return 0;  // different trees
+    if (ta.y != tb.y || ta.y == 0) return ta.x;
+    if (ta.z != tb.z || ta.z == 0) return ta.y;
+    return ta.z;
+}
+// a != b, both non-zero; pa / pb = their first root-path rows (all 0: absent or beyond the table)
+__device__ __forceinline__ u32 lca_from_rows(const TaxDev &T, u32 a, u32 b, uint4 pa, uint4 pb) {
     if (pa.x == 0) {  // absent: merged into another taxid?
         const u32 m = (a < T.size && T.merged) ? T.merged[a] : 0u;
         a = (m && m < T.size) ? m : 0u;
@@ -257,8 +278,30 @@ __device__ __forceinline__ u32 lca_finish(const TaxDev &T, const LcaReq &q) {
         last = pa.x;
     }
 }
+__device__ __forceinline__ u32 lca_finish(const TaxDev &T, const LcaReq &q) {
+    const u32 a = q.a, b = q.b;
+    if (a == 0 || b == 0) return 0;
+    if (a == b) return a;
+    uint4 pa = q.pa, pb = q.pb;
+    if (tax_has_clades(T)) {
+        if (q.ca != q.cb && q.ca != 0 && q.cb != 0) return lca_clade_pair(T, q.ca, q.cb);  // unrelated
+        const uint4 zero = make_uint4(0, 0, 0, 0);
+        pa = a < T.size ? T.anc[a] : zero;
+        pb = b < T.size ? T.anc[b] : zero;
+    }
+    return lca_from_rows(T, a, b, pa, pb);
+}
+// With clade codes: unrelated pairs -- different codes -- are settled by two small reads and two rows of the `top` table,
+// relatives (and absent / merged ids) take the root paths behind them.
 __device__ __forceinline__ u32 lca_dev(const TaxDev &T, u32 a, u32 b) {
-    LcaReq q;
-    lca_begin(T, a, b, q);
-    return lca_finish(T, q);
+    if (a == 0 || b == 0) return 0;
+    if (a == b) return a;
+    const uint4 zero = make_uint4(0, 0, 0, 0);
+    if (tax_has_clades(T) && a < T.size && b < T.size) {
+        u32 ca, cb;
+        if (T.clade8) { ca = T.clade8[a]; cb = T.clade8[b]; }  // (uniform over the launch)
+        else { ca = T.clade[a]; cb = T.clade[b]; }
+        if (ca != cb && ca != 0 && cb != 0) return lca_clade_pair(T, ca, cb);
+    }
+    return lca_from_rows(T, a, b, a < T.size ? T.anc[a] : zero, b < T.size ? T.anc[b] : zero);
 }

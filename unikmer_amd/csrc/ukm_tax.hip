@@ -106,19 +106,19 @@ extern "C" int ukm_taxonomy_load(ukm_ctx *c, const uint32_t *child, const uint32
     for (u64 i = 0; i < m; i++) mx = std::max(mx, std::max(mo[i], mn[i]));
     const u64 size = (u64)mx + 1;
     {
-        // the tables are dense in the taxid (at least 25 bytes per id on the device, about as much on the host while they
+        // the tables are dense in the taxid (at least 27 bytes per id on the device, about as much on the host while they
         // are built): refuse sparse huge ids here, before any of it is allocated
         size_t free_b = 0, total_b = 0;
         UKM_HIP(hipMemGetInfo(&free_b, &total_b));
-        if (size * 25 > (u64)free_b / 10 * 9) {  // (the context's cached workspace counts as free: give it back and look again)
+        if (size * 27 > (u64)free_b / 10 * 9) {  // (the context's cached workspace counts as free: give it back and look again)
             (void)ukm_ctx_trim(c);
             UKM_HIP(hipMemGetInfo(&free_b, &total_b));
         }
-        if (size * 25 > (u64)free_b / 10 * 9)
+        if (size * 27 > (u64)free_b / 10 * 9)
             UKM_FAIL(UKM_ERR_NOMEM,
                      "ukm_taxonomy_load: dense tables for the largest taxid %u need at least %.2f GB, the device has %.2f GB free; "
                      "renumber sparse taxids densely",
-                     mx, size * 25 / 1e9, free_b / 1e9);
+                     mx, size * 27 / 1e9, free_b / 1e9);
     }
     std::vector<u32> P(size, 0), M;
     std::vector<u8> D(size, 0);
@@ -189,6 +189,48 @@ extern "C" int ukm_taxonomy_load(ukm_ctx *c, const uint32_t *child, const uint32
             for (u64 t = 1; t < size; t++)
                 if (P[t] == 0 && M[t] != 0 && M[t] < size && P[M[t]] != 0) E[t] = E[M[t]];  // (lca_dev resolves exactly these)
     }
+    // Clade codes (TaxDev::clade / top): D = the deepest level <= 3 whose nodes of depth <= D fit 16 bits; every present
+    // id gets the index of its ancestor at depth min(own depth, D) -- the pre-order list N hands parents out before their
+    // children.  A forest with more than 65535 roots gets no table (Q stays empty: lca_dev goes to the root paths).
+    std::vector<unsigned short> Q;
+    std::vector<unsigned char> Q8;
+    bool one_byte = false;
+    std::vector<uint4> T4(1, make_uint4(0, 0, 0, 0));
+    {
+        u64 by_depth[4] = {0, 0, 0, 0};
+        for (size_t i = 1; i < N.size(); i++)
+            if (D[N[i]] < 4) by_depth[D[N[i]]]++;
+        int Dq = -1;
+        u64 acc = 0;
+        for (int d = 0; d < 4; d++) {
+            acc += by_depth[d];
+            if (acc <= 65535) Dq = d; else break;
+        }
+        // one byte per id whenever some level's nodes fit it (8-ary tree: depth <= 2 = 73 nodes, 63 of 64 random pairs part
+        // above it; NCBI: the superkingdoms and what hangs directly below them)
+        acc = 0;
+        int D8 = -1;
+        for (int d = 0; d < 3; d++) {
+            acc += by_depth[d];
+            if (acc <= 255) D8 = d; else break;
+        }
+        if (D8 >= 0) { Dq = D8; one_byte = true; }
+        if (Dq >= 0) {
+            Q.assign(size, 0);
+            for (size_t i = 1; i < N.size(); i++) {
+                const u32 t = N[i];
+                if ((int)D[t] <= Dq) {
+                    uint4 row = D[t] == 0 ? make_uint4(0, 0, 0, 0) : T4[Q[P[t]]];
+                    (D[t] == 0 ? row.x : D[t] == 1 ? row.y : D[t] == 2 ? row.z : row.w) = t;
+                    Q[t] = (unsigned short)T4.size();
+                    T4.push_back(row);
+                } else {
+                    Q[t] = Q[P[t]];
+                }
+            }
+            if (one_byte) Q8.assign(Q.begin(), Q.end());
+        }
+    }
     // ---- device tables: ALL of them are built beside the context's current ones and swapped in only when every
     // allocation, copy and kernel has succeeded; a failed load leaves the context exactly as it was (a half-replaced
     // taxonomy would pass the `tax_parent != nullptr` guards and send the kernels through a null root-path table).
@@ -200,7 +242,8 @@ extern "C" int ukm_taxonomy_load(ukm_ctx *c, const uint32_t *child, const uint32
     for (u64 t = 0; t < size; t++) maxd = std::max(maxd, (int)D[t]);
     const u32 nchunks = (u32)(maxd + 1 + 3) / 4;
     const u64 anc_bytes = (u64)nchunks * size * sizeof(uint4);
-    const u64 need = size * (sizeof(u32) + sizeof(u8) + (m ? sizeof(u32) : 0) + sizeof(u32)) + N.size() * sizeof(u32) + anc_bytes;
+    const u64 need = size * (sizeof(u32) + sizeof(u8) + (m ? sizeof(u32) : 0) + sizeof(u32) + sizeof(unsigned short)) + N.size() * sizeof(u32) +
+                     T4.size() * sizeof(uint4) + anc_bytes;
     {
         // free memory as the driver sees it -- plus what this context can give back: its cached workspace (kept at the
         // high-water mark of the largest call, up to 160 GB) is released before the load is refused, and the taxonomy that
@@ -209,7 +252,7 @@ extern "C" int ukm_taxonomy_load(ukm_ctx *c, const uint32_t *child, const uint32
         UKM_HIP(hipMemGetInfo(&free_b, &total_b));
         u64 old_bytes = 0;
         if (c->tax_parent)
-            old_bytes = (u64)c->tax_size * (sizeof(u32) + sizeof(u8) + (c->tax_merged ? sizeof(u32) : 0) + 2 * sizeof(u32)) +
+            old_bytes = (u64)c->tax_size * (sizeof(u32) + sizeof(u8) + (c->tax_merged ? sizeof(u32) : 0) + 2 * sizeof(u32) + (c->tax_clade ? 2 : (c->tax_clade8 ? 1 : 0))) +
                         (u64)c->tax_nchunks * c->tax_size * sizeof(uint4);
         if (need > (u64)free_b / 10 * 9) {
             (void)ukm_ctx_trim(c);
@@ -222,6 +265,10 @@ extern "C" int ukm_taxonomy_load(ukm_ctx *c, const uint32_t *child, const uint32
             (void)hipFree(c->tax_parent); (void)hipFree(c->tax_depth);
             if (c->tax_merged) (void)hipFree(c->tax_merged);
             (void)hipFree(c->tax_anc); (void)hipFree(c->tax_euler); (void)hipFree(c->tax_node_at);
+            if (c->tax_clade) (void)hipFree(c->tax_clade);
+            if (c->tax_top) (void)hipFree(c->tax_top);
+            if (c->tax_clade8) (void)hipFree(c->tax_clade8);
+            c->tax_clade = nullptr; c->tax_top = nullptr; c->tax_clade8 = nullptr;
             c->tax_parent = nullptr; c->tax_depth = nullptr; c->tax_merged = nullptr; c->tax_anc = nullptr;
             c->tax_euler = nullptr; c->tax_node_at = nullptr; c->tax_size = 0; c->tax_nchunks = 0; c->tax_max = 0;
             UKM_HIP(hipMemGetInfo(&free_b, &total_b));
@@ -235,8 +282,13 @@ extern "C" int ukm_taxonomy_load(ukm_ctx *c, const uint32_t *child, const uint32
     UKM_HIP(hipStreamSynchronize(c->stream));
     u32 *n_parent = nullptr, *n_merged = nullptr, *n_euler = nullptr, *n_node_at = nullptr;
     u8 *n_depth = nullptr;
-    uint4 *n_anc = nullptr;
+    uint4 *n_anc = nullptr, *n_top = nullptr;
+    unsigned short *n_clade = nullptr;
+    unsigned char *n_clade8 = nullptr;
     auto drop_new = [&]() {
+        if (n_clade) (void)hipFree(n_clade);
+        if (n_clade8) (void)hipFree(n_clade8);
+        if (n_top) (void)hipFree(n_top);
         if (n_parent) (void)hipFree(n_parent);
         if (n_depth) (void)hipFree(n_depth);
         if (n_merged) (void)hipFree(n_merged);
@@ -257,6 +309,17 @@ extern "C" int ukm_taxonomy_load(ukm_ctx *c, const uint32_t *child, const uint32
         UKM_HIP(hipMalloc((void **)&n_node_at, N.size() * sizeof(u32)));
         UKM_HIP(hipMemcpy(n_euler, E.data(), size * sizeof(u32), hipMemcpyHostToDevice));
         UKM_HIP(hipMemcpy(n_node_at, N.data(), N.size() * sizeof(u32), hipMemcpyHostToDevice));
+        if (!Q.empty()) {
+            if (one_byte) {
+                UKM_HIP(hipMalloc((void **)&n_clade8, size));
+                UKM_HIP(hipMemcpy(n_clade8, Q8.data(), size, hipMemcpyHostToDevice));
+            } else {
+                UKM_HIP(hipMalloc((void **)&n_clade, size * sizeof(unsigned short)));
+                UKM_HIP(hipMemcpy(n_clade, Q.data(), size * sizeof(unsigned short), hipMemcpyHostToDevice));
+            }
+            UKM_HIP(hipMalloc((void **)&n_top, T4.size() * sizeof(uint4)));
+            UKM_HIP(hipMemcpy(n_top, T4.data(), T4.size() * sizeof(uint4), hipMemcpyHostToDevice));
+        }
         UKM_HIP(hipMalloc((void **)&n_anc, anc_bytes));
         UKM_HIP(hipMemsetAsync(n_anc, 0, anc_bytes, c->stream));
         hipLaunchKernelGGL(build_anc_kernel, dim3((unsigned)((size + 255) / 256)), dim3(256), 0, c->stream, n_parent, n_depth,
@@ -276,6 +339,12 @@ extern "C" int ukm_taxonomy_load(ukm_ctx *c, const uint32_t *child, const uint32
     if (c->tax_anc) (void)hipFree(c->tax_anc);
     if (c->tax_euler) (void)hipFree(c->tax_euler);
     if (c->tax_node_at) (void)hipFree(c->tax_node_at);
+    if (c->tax_clade) (void)hipFree(c->tax_clade);
+    if (c->tax_top) (void)hipFree(c->tax_top);
+    if (c->tax_clade8) (void)hipFree(c->tax_clade8);
+    c->tax_clade = n_clade;
+    c->tax_clade8 = n_clade8;
+    c->tax_top = n_top;
     c->tax_parent = n_parent;
     c->tax_depth = n_depth;
     c->tax_merged = n_merged;
