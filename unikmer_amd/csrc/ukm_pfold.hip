@@ -125,7 +125,9 @@ void pf_probe_kernel(PfArgs a) {
                 const u32 tf = t0 ? t0[e0 + i] : 0u;
                 s_tax[i] = tf;
                 if (EULER) {
-                    const u32 ef = tf < a.T.size ? a.T.euler[tf] : 0u;
+                    u32 ef = tf < a.T.size ? a.T.euler[tf] : 0u;
+                    // (with one-byte clade codes the words hold clade << 24 | number: see the step)
+                    if (ef && a.T.clade8) ef |= (u32)a.T.clade8[tf] << 24;
                     s_min[i] = ef ? ef : 0xFFFFFFFFu;
                     s_max[i] = ef;
                     if (!ef) s_cnt[i] = PF_BAD;
@@ -267,6 +269,11 @@ void pf_probe_kernel(PfArgs a) {
             // unknown ids (number 0) make the result 0 (lca_dev: absorbing) unless every taxid of the record is the
             // same (lca_dev: a == b -> a), which the NEQ flag keeps track of.
             u32 en[2 * U];
+            const bool byc = a.T.clade8 != nullptr;  // (uniform over the launch)
+            // hits whose taxid has to be folded, as a bit mask.  (Marking the others by li[q] = -1, as rounds 3-4 did, let a hit
+            // that carries the record's own taxid through to the fold below once that fold had two branches: such hits came
+            // with the table's entry for taxid 0 and voided the record -- found by test_range_fold_equals_chained_fold_large)
+            u32 needm = 0;
 #pragma unroll
             for (int q = 0; q < 2 * U; q++) {
                 bool need = false;
@@ -280,16 +287,40 @@ void pf_probe_kernel(PfArgs a) {
                     if ((s_cnt[li[q]] & PF_CNT_MASK) >= finished)
                         need = ((atomicAdd(&s_cnt[li[q]], 1u) + 1) & PF_CNT_MASK) > finished && lt[q] != s_tax[li[q]];
                 }
-                if (!need) li[q] = -1;
-                en[q] = a.T.euler[(need && lt[q] < a.T.size) ? lt[q] : 0u];  // (all of the step's table reads in flight; euler[0] = 0)
+                needm |= need ? (1u << q) : 0u;
+                const u32 tq_ = (need && lt[q] < a.T.size) ? lt[q] : 0u;
+                // (all of the step's table reads in flight; euler[0] = 0, clade8[0] = 0)
+                en[q] = byc ? (u32)a.T.clade8[tq_] : a.T.euler[tq_];
             }
 #pragma unroll
             for (int q = 0; q < 2 * U; q++) {
-                if (li[q] < 0) continue;
-                atomicOr(&s_cnt[li[q]], en[q] ? PF_NEQ : (PF_NEQ | PF_BAD));
-                if (en[q]) {
-                    atomicMin(&s_min[li[q]], en[q]);
-                    atomicMax(&s_max[li[q]], en[q]);
+                if (!((needm >> q) & 1u)) continue;
+                if (!byc) {
+                    atomicOr(&s_cnt[li[q]], en[q] ? PF_NEQ : (PF_NEQ | PF_BAD));
+                    if (en[q]) {
+                        atomicMin(&s_min[li[q]], en[q]);
+                        atomicMax(&s_max[li[q]], en[q]);
+                    }
+                    continue;
+                }
+                // Round 5: a taxid's CLADE code (one byte of a table that stays in L2; codes are handed out in pre-order, so
+                // they order taxids as the numbers do) in the top byte of the two words.  A record whose taxids span two
+                // clades has the LCA of those two clade nodes whatever the exact numbers are: the 4-byte number of a
+                // taxid (a random read of a table of 4 B x ids) is only fetched while the record's interval lies inside
+                // ONE clade and the taxid is of that clade -- for taxids that are not related, next to never -- and a taxid
+                // inside an interval of several clades costs two LDS reads and no atomic at all.  (The interval only ever
+                // widens: a record that is still inside one clade at the end has had every one of its taxids folded exactly.)
+                const u32 c = en[q];
+                if (c == 0) { atomicOr(&s_cnt[li[q]], PF_NEQ | PF_BAD); continue; }
+                if (!(s_cnt[li[q]] & PF_NEQ)) atomicOr(&s_cnt[li[q]], PF_NEQ);
+                const u32 cmn = s_min[li[q]] >> 24, cmx = s_max[li[q]] >> 24;
+                if (cmn == cmx && c == cmn) {
+                    const u32 e = (c << 24) | a.T.euler[lt[q]];
+                    atomicMin(&s_min[li[q]], e);
+                    atomicMax(&s_max[li[q]], e);
+                } else {
+                    if (c < cmn) atomicMin(&s_min[li[q]], (c << 24) | 0xFFFFFFu);
+                    if (c > cmx) atomicMax(&s_max[li[q]], c << 24);
                 }
             }
         }
@@ -380,7 +411,13 @@ void pf_probe_kernel(PfArgs a) {
             a.tmp_k[o] = ent[k];
             if (TAX) {
                 u32 tx = s_tax[i];
-                if (EULER && (w & PF_NEQ)) tx = (w & PF_BAD) ? 0u : lca_dev(a.T, a.T.node_at[s_min[i]], a.T.node_at[s_max[i]]);
+                if (EULER && (w & PF_NEQ)) {
+                    const u32 mn = s_min[i], mx = s_max[i];
+                    if (w & PF_BAD) tx = 0u;
+                    else if (a.T.clade8 == nullptr) tx = lca_dev(a.T, a.T.node_at[mn], a.T.node_at[mx]);
+                    else if ((mn >> 24) != (mx >> 24)) tx = lca_clade_pair(a.T, mn >> 24, mx >> 24);
+                    else tx = lca_dev(a.T, a.T.node_at[mn & 0xFFFFFFu], a.T.node_at[mx & 0xFFFFFFu]);
+                }
                 a.tmp_t[o] = tx;
             }
         }

@@ -214,7 +214,8 @@ extern "C" int ukm_taxonomy_load(ukm_ctx *c, const uint32_t *child, const uint32
             acc += by_depth[d];
             if (acc <= 255) D8 = d; else break;
         }
-        if (D8 >= 0) { Dq = D8; one_byte = true; }
+        // (the folds over pre-order numbers keep code << 24 | number in one word: ukm_pfold.hip)
+        if (D8 >= 0 && N.size() < (1u << 24)) { Dq = D8; one_byte = true; }
         if (Dq >= 0) {
             Q.assign(size, 0);
             for (size_t i = 1; i < N.size(); i++) {
@@ -228,6 +229,11 @@ extern "C" int ukm_taxonomy_load(ukm_ctx *c, const uint32_t *child, const uint32
                     Q[t] = Q[P[t]];
                 }
             }
+            // a merged id has its target's code (and its target's pre-order number, above): pairs with an unrelated id are
+            // settled by the codes, anything closer resolves the id on the way to the root paths
+            if (m)
+                for (u64 t = 1; t < size; t++)
+                    if (P[t] == 0 && M[t] != 0 && M[t] < size && P[M[t]] != 0) Q[t] = Q[M[t]];
             if (one_byte) Q8.assign(Q.begin(), Q.end());
         }
     }
