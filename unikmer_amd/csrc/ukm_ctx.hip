@@ -158,6 +158,7 @@ extern "C" int ukm_ctx_destroy(ukm_ctx *c) {
     if (c->tax_node_at) (void)hipFree(c->tax_node_at);
     if (c->tax_clade) (void)hipFree(c->tax_clade);
     if (c->tax_clade8) (void)hipFree(c->tax_clade8);
+    if (c->tax_pair) (void)hipFree(c->tax_pair);
     if (c->tax_top) (void)hipFree(c->tax_top);
     if (c->h_scratch) (void)hipHostFree(c->h_scratch);
     if (c->sort_stat_dev) (void)hipFree(c->sort_stat_dev);

@@ -241,6 +241,7 @@ __device__ __forceinline__ void lca_begin(const TaxDev &T, u32 a, u32 b, LcaReq 
 }
 // the LCA of two clade nodes with different codes: their root paths (at most four levels) part, or one of them ends
 __device__ __forceinline__ u32 lca_clade_pair(const TaxDev &T, u32 ca, u32 cb) {
+    if (T.pair) return T.pair[ca * T.kp + cb];  // (uniform; the one-byte form comes with the table of all pairs)
     const uint4 ta = T.top[ca], tb = T.top[cb];
     if (ta.x != tb.x) return 0;  // different trees
     if (ta.y != tb.y || ta.y == 0) return ta.x;

@@ -69,6 +69,10 @@ struct TaxDev {
     // the same codes in ONE byte per id when the nodes of depth <= 2 (or 1, or 0) are at most 255: a table a quarter the size
     // of a 4-byte column stays in L2 beside the streams (2.4 MB for 2.4 M ids); `clade` is null then
     const unsigned char *clade8;
+    // beside clade8: pair[ca * kp + cb] = the LCA of clade nodes ca and cb (0 on the diagonal and in row / column 0: same
+    // clade or no code -> the root paths answer); at most 256 x 256 words, one read instead of two rows of `top`
+    const u32 *pair;
+    u32 kp;
 };
 
 // ---- workspace arena: chunked bump allocator on the ctx's device ------------------------------
@@ -115,6 +119,8 @@ struct ukm_ctx {
     u32 *tax_euler = nullptr, *tax_node_at = nullptr;  // pre-order numbers, see TaxDev
     unsigned short *tax_clade = nullptr;                // clade codes, see TaxDev (tax_clade8: the one-byte form)
     unsigned char *tax_clade8 = nullptr;
+    u32 *tax_pair = nullptr;
+    u32 tax_kp = 0;
     uint4 *tax_top = nullptr;
     u32 tax_nchunks = 0;
     u32 tax_size = 0;
@@ -234,6 +240,8 @@ static inline TaxDev ukm_taxdev(const ukm_ctx *c) {
     t.node_at = c->tax_node_at;
     t.clade = c->tax_clade;
     t.clade8 = c->tax_clade8;
+    t.pair = c->tax_pair;
+    t.kp = c->tax_kp;
     t.top = c->tax_top;
     t.nchunks = c->tax_nchunks;
     t.size = c->tax_size;

@@ -194,6 +194,7 @@ extern "C" int ukm_taxonomy_load(ukm_ctx *c, const uint32_t *child, const uint32
     // children.  A forest with more than 65535 roots gets no table (Q stays empty: lca_dev goes to the root paths).
     std::vector<unsigned short> Q;
     std::vector<unsigned char> Q8;
+    std::vector<u32> PAIR;
     bool one_byte = false;
     std::vector<uint4> T4(1, make_uint4(0, 0, 0, 0));
     {
@@ -234,7 +235,23 @@ extern "C" int ukm_taxonomy_load(ukm_ctx *c, const uint32_t *child, const uint32
             if (m)
                 for (u64 t = 1; t < size; t++)
                     if (P[t] == 0 && M[t] != 0 && M[t] < size && P[M[t]] != 0) Q[t] = Q[M[t]];
-            if (one_byte) Q8.assign(Q.begin(), Q.end());
+            if (one_byte) {
+                Q8.assign(Q.begin(), Q.end());
+                // the LCA of every pair of clade nodes (at most 256 x 256): what lca_clade_pair works out from two rows
+                const u32 kp = (u32)T4.size();
+                PAIR.assign((size_t)kp * kp, 0u);
+                for (u32 i = 1; i < kp; i++)
+                    for (u32 j = 1; j < kp; j++) {
+                        if (i == j) continue;
+                        const uint4 ra = T4[i], rb = T4[j];
+                        u32 l;
+                        if (ra.x != rb.x) l = 0;
+                        else if (ra.y != rb.y || ra.y == 0) l = ra.x;
+                        else if (ra.z != rb.z || ra.z == 0) l = ra.y;
+                        else l = ra.z;
+                        PAIR[(size_t)i * kp + j] = l;
+                    }
+            }
         }
     }
     // ---- device tables: ALL of them are built beside the context's current ones and swapped in only when every
@@ -274,7 +291,8 @@ extern "C" int ukm_taxonomy_load(ukm_ctx *c, const uint32_t *child, const uint32
             if (c->tax_clade) (void)hipFree(c->tax_clade);
             if (c->tax_top) (void)hipFree(c->tax_top);
             if (c->tax_clade8) (void)hipFree(c->tax_clade8);
-            c->tax_clade = nullptr; c->tax_top = nullptr; c->tax_clade8 = nullptr;
+            if (c->tax_pair) (void)hipFree(c->tax_pair);
+            c->tax_clade = nullptr; c->tax_top = nullptr; c->tax_clade8 = nullptr; c->tax_pair = nullptr; c->tax_kp = 0;
             c->tax_parent = nullptr; c->tax_depth = nullptr; c->tax_merged = nullptr; c->tax_anc = nullptr;
             c->tax_euler = nullptr; c->tax_node_at = nullptr; c->tax_size = 0; c->tax_nchunks = 0; c->tax_max = 0;
             UKM_HIP(hipMemGetInfo(&free_b, &total_b));
@@ -291,7 +309,9 @@ extern "C" int ukm_taxonomy_load(ukm_ctx *c, const uint32_t *child, const uint32
     uint4 *n_anc = nullptr, *n_top = nullptr;
     unsigned short *n_clade = nullptr;
     unsigned char *n_clade8 = nullptr;
+    u32 *n_pair = nullptr;
     auto drop_new = [&]() {
+        if (n_pair) (void)hipFree(n_pair);
         if (n_clade) (void)hipFree(n_clade);
         if (n_clade8) (void)hipFree(n_clade8);
         if (n_top) (void)hipFree(n_top);
@@ -319,6 +339,8 @@ extern "C" int ukm_taxonomy_load(ukm_ctx *c, const uint32_t *child, const uint32
             if (one_byte) {
                 UKM_HIP(hipMalloc((void **)&n_clade8, size));
                 UKM_HIP(hipMemcpy(n_clade8, Q8.data(), size, hipMemcpyHostToDevice));
+                UKM_HIP(hipMalloc((void **)&n_pair, PAIR.size() * sizeof(u32)));
+                UKM_HIP(hipMemcpy(n_pair, PAIR.data(), PAIR.size() * sizeof(u32), hipMemcpyHostToDevice));
             } else {
                 UKM_HIP(hipMalloc((void **)&n_clade, size * sizeof(unsigned short)));
                 UKM_HIP(hipMemcpy(n_clade, Q.data(), size * sizeof(unsigned short), hipMemcpyHostToDevice));
@@ -348,6 +370,9 @@ extern "C" int ukm_taxonomy_load(ukm_ctx *c, const uint32_t *child, const uint32
     if (c->tax_clade) (void)hipFree(c->tax_clade);
     if (c->tax_top) (void)hipFree(c->tax_top);
     if (c->tax_clade8) (void)hipFree(c->tax_clade8);
+    if (c->tax_pair) (void)hipFree(c->tax_pair);
+    c->tax_pair = n_pair;
+    c->tax_kp = n_pair ? (u32)T4.size() : 0u;
     c->tax_clade = n_clade;
     c->tax_clade8 = n_clade8;
     c->tax_top = n_top;
