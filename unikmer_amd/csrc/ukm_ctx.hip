@@ -171,6 +171,11 @@ extern "C" int ukm_ctx_destroy(ukm_ctx *c) {
         (void)hipStreamDestroy(c->xfer);
     }
     if (c->ev_xfer) (void)hipEventDestroy(c->ev_xfer);
+    for (int i = 0; i < 2; i++) {
+        if (c->side[i]) { (void)hipStreamSynchronize(c->side[i]); (void)hipStreamDestroy(c->side[i]); }
+        if (c->ev_side[i]) (void)hipEventDestroy(c->ev_side[i]);
+    }
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_comp) (void)hipEventDestroy(c->ev_comp);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;

@@ -94,6 +94,10 @@ struct ukm_ctx {
     hipStream_t xfer = nullptr;
     hipEvent_t ev_xfer = nullptr, ev_comp = nullptr;
     bool xfer_pending = false;
+    // two more streams for launches that do not depend on each other (the bucket sort's size classes): forked from and
+    // joined to `stream` by events inside one call
+    hipStream_t side[2] = {nullptr, nullptr};
+    hipEvent_t ev_fork = nullptr, ev_side[2] = {nullptr, nullptr};
     // RCCL communicator of the multi-GPU exchange (ukm_comm.hip); nullptr until ukm_comm_init
     void *comm = nullptr;
     int comm_size = 0, comm_rank = 0;

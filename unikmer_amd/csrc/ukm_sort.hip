@@ -896,13 +896,35 @@ int sort_top16_local(ukm_ctx *c, u64 *keys, u32 *vals, u64 n, int key_bits, bool
     c->sort_last_buckets = 0;
     for (int k = 0; k < LS_NCLASS; k++) c->sort_last_buckets += hc[k];
     const dim3 block(LS_NT);
+    // The classes' launches do not depend on each other and the small ones leave most of the chip idle (canonical k-mers:
+    // ten classes occur, eight of them 16-60 us each): they go round robin over the call's stream and two side streams,
+    // largest class first, forked from / joined to the call's stream by events.
+    int nocc = 0;
+    for (int k = 0; k < LS_NCLASS; k++) nocc += hc[k] != 0;
+    const bool fan = nocc >= 3 && !ukm_env_is(c, "UKM_SORT_FAN", '0');
+    if (fan) {
+        if (!c->ev_fork) {
+            UKM_HIP(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+            for (int i = 0; i < 2; i++) {
+                UKM_HIP(hipStreamCreateWithFlags(&c->side[i], hipStreamNonBlocking));
+                UKM_HIP(hipEventCreateWithFlags(&c->ev_side[i], hipEventDisableTiming));
+            }
+        }
+        UKM_HIP(hipEventRecord(c->ev_fork, c->stream));
+        for (int i = 0; i < 2; i++) UKM_HIP(hipStreamWaitEvent(c->side[i], c->ev_fork, 0));
+    }
+    int turn = 0;
+    hipStream_t lst = c->stream;
 #define LS_LAUNCH(K)                                                                                          \
     do {                                                                                                      \
-        if (vals) hipLaunchKernelGGL((ls_sort_kernel<K, true>), grid, block, 0, c->stream, a);                \
-        else hipLaunchKernelGGL((ls_sort_kernel<K, false>), grid, block, 0, c->stream, a);                    \
+        if (vals) hipLaunchKernelGGL((ls_sort_kernel<K, true>), grid, block, 0, lst, a);                      \
+        else hipLaunchKernelGGL((ls_sort_kernel<K, false>), grid, block, 0, lst, a);                          \
     } while (0)
-    for (int k = 0; k < LS_NCLASS; k++) {
+    for (int kk = 0; kk < LS_NCLASS; kk++) {
+        const int k = LS_NCLASS - 1 - kk;  // (the classes with the most keys per bucket first)
         if (hc[k] == 0) continue;
+        if (fan) lst = turn % 3 == 0 ? c->stream : c->side[turn % 3 - 1];
+        turn++;
         a.ids = ids + ((size_t)k << topb);
         const dim3 grid((unsigned)hc[k]);
         switch (LS_CLASS_KPT[k]) {
@@ -921,6 +943,11 @@ int sort_top16_local(ukm_ctx *c, u64 *keys, u32 *vals, u64 n, int key_bits, bool
         }
     }
     UKM_HIP(hipGetLastError());
+    if (fan)
+        for (int i = 0; i < 2; i++) {
+            UKM_HIP(hipEventRecord(c->ev_side[i], c->side[i]));
+            UKM_HIP(hipStreamWaitEvent(c->stream, c->ev_side[i], 0));
+        }
     if (hc[LS_NCLASS]) {
         // The oversized buckets -- low-complexity k-mers of a real genome crowd a few dozen to a few thousand of them --
         // side by side in a scratch array, in bucket order: sorted by the whole key they stay side by side (their top bits
