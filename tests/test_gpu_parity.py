@@ -143,6 +143,51 @@ def test_setop2_taxids_lca(ctx, O, L, tree, n):
     assert np.array_equal(ik, ok) and np.array_equal(it, ot)
 
 
+@pytest.mark.parametrize("mode", ["0", "1", "2"])
+def test_setop2_per_record_taxids_source_words(ctx, O, L, tree, monkeypatch, mode):
+    """Round 5: `inter` with per-record taxids runs the plain-key kernel, whose epilogue writes one SOURCE WORD per output
+    record, and a second launch turns the words into taxids (ukm_setops.hip: tile_flush_src / setop_taxid_gather_kernel).
+    UKM_SETOP_SRC: 0 = the taxid instantiation everywhere, 1 = the default (inter), 2 = every operation that allows it.
+    All three against the oracle on sizes around tile boundaries (a tile is 9728 merged records), on one-sided taxids
+    (a file taxid on the other stream), zeros (mix-taxid), a match at a tile's last place, and empty inputs."""
+    tax, T = tree
+    monkeypatch.setenv("UKM_SETOP_SRC", mode)
+    rng = np.random.default_rng(5)
+    for n in (1, 9727, 9728, 9729, 40_000, 250_000):
+        A, B = synth_sets(n, 20)
+        ta, tb = taxids_for(A, T), taxids_for(B, T, SEED + 5)
+        ta[::7] = 0
+        tb[::5] = 0
+        for op, ofn, kw in ((L.OP_UNION, O.union, {}), (L.OP_INTER, O.inter, {}), (L.OP_DIFF, O.diff, {})):
+            gk, gt = ctx.setop2(op, A, B, ta, tb)
+            ek, et = ofn([A, B], [ta, tb], tax, **kw)
+            assert np.array_equal(gk, ek) and np.array_equal(gt, et), (mode, n, op)
+        gk, gt = ctx.setop2(L.OP_INTER, A, B, ta, tb, flags=L.F_MIX_TAXID)
+        ek, et = O.inter([A, B], [ta, tb], tax, mix_taxid=True)
+        assert np.array_equal(gk, ek) and np.array_equal(gt, et), (mode, n, "mix")
+        # per-record taxids on ONE stream, a file taxid on the other
+        ft = int(rng.integers(1, T))
+        gk, gt = ctx.setop2(L.OP_INTER, A, B, ta, ft)
+        ek, et = O.inter([A, B], [ta, np.full(len(B), ft, np.uint32)], tax)
+        assert np.array_equal(gk, ek) and np.array_equal(gt, et), (mode, n, "one-sided")
+    # identical sets: every record a match, also the one at each tile's last place; and an empty side
+    A = np.arange(1, 30001, dtype=np.uint64) * 3
+    ta, tb = taxids_for(A, T), taxids_for(A, T, SEED + 9)
+    gk, gt = ctx.setop2(L.OP_INTER, A, A, ta, tb)
+    ek, et = O.inter([A, A], [ta, tb], tax)
+    assert np.array_equal(gk, ek) and np.array_equal(gt, et)
+    # (one more record in front of A: every tile's last place now holds the A half of a pair whose B half opens the next tile)
+    A1 = np.concatenate([np.array([1], np.uint64), A])
+    ta1 = taxids_for(A1, T)
+    for op, ofn in ((L.OP_INTER, O.inter), (L.OP_UNION, O.union)):
+        gk, gt = ctx.setop2(op, A1, A, ta1, tb)
+        ek, et = ofn([A1, A], [ta1, tb], tax)
+        assert np.array_equal(gk, ek) and np.array_equal(gt, et), (mode, op, "pair across a tile boundary")
+    e = np.empty(0, np.uint64)
+    gk, gt = ctx.setop2(L.OP_INTER, A, e, ta, np.empty(0, np.uint32))
+    assert len(gk) == 0 and len(gt) == 0
+
+
 def test_lca_matches_oracle(ctx, O, tree):
     tax, T = tree
     rng = np.random.default_rng(3)

@@ -655,7 +655,7 @@ __device__ __forceinline__ void tile_merge_loop(const SetopArgs &p, const TileGe
 template <int OP, bool TAX, bool RANK, bool CT, int NTH, int VT>
 __device__ __forceinline__ void tile_merge(const SetopArgs &p, const TileGeom &g, int tid, const u64 *s_keys,
                                            const u32 *s_tax, const u32 *s_rank, u64 (&ok)[VT], u32 (&ot)[VT],
-                                           u32 &mask, u32 &amask, u32 &mmask, bool ct_keep) {
+                                           u32 &mask, u32 &amask, u32 &mmask, bool ct_keep, int &ia0, int &ib0) {
     const int na_t = g.na_t, nb_t = g.nb_t, total = na_t + nb_t;
     const int base_a = g.base_a, base_b = g.base_b;
     int diag = tid * VT;
@@ -670,6 +670,8 @@ __device__ __forceinline__ void tile_merge(const SetopArgs &p, const TileGeom &g
         hi = le ? hi : mid;
     }
     const int pa = base_a + lo, pb = base_b + diag - lo;
+    ia0 = lo;         // the thread's first A / B record, counted from the tile's first (source words, below)
+    ib0 = diag - lo;
     // wave-uniform choice (tile geometry): no divergence
     if (total == NTH * VT && g.has_next_a && g.has_next_b)
         tile_merge_loop<OP, TAX, RANK, true, CT, VT>(p, g, pa, pb, s_keys, s_tax, s_rank, ok, ot, mask, amask, mmask, ct_keep);
@@ -750,6 +752,120 @@ __device__ __forceinline__ void tile_flush_ct(const SetopArgs &p, int tid, u64 b
         if (base + i < p.out_cap) p.tout[base + i] = s_t32[i];
 }
 
+// ---- per-record taxids on plain sets, in two launches (round 5) ---------------------------------------------------------
+// The taxid instantiation carries the taxids through the merge: 13 items per thread instead of 19, 80 KB of LDS, no LDS-DMA,
+// 128 registers with spills, and the LCA of a matched pair -- two dependent table reads -- inside a thread's SERIAL merge
+// loop: 132 vector and 85 scalar lane-instructions per record against 67 / 22 for plain codes (profiles/r05_setop_tax_pmc.txt).
+// Which input an output record came from does not depend on any taxid (union, inter, diff without -t, the keep-everything
+// merge), so: launch 1 = the PLAIN-key kernel, whose epilogue writes one SOURCE WORD per output record where its taxid will
+// stand ([13:0] the record's place in the tile's A range, [27:14] in its B range, [28] a matched pair, [29] taken from
+// B; put together from the two bit masks of the thread's steps: ~10 instructions per step); launch 2 = one workgroup per
+// tile turns the words into taxids IN PLACE: a thread per output record, every taxid read and every LCA independent of
+// every other -- the table reads of a whole tile are in flight together instead of one pair at a time per thread.
+// 8 more bytes of HBM traffic per output record (the word written and read back).
+constexpr u32 SRC_MATCH = 1u << 28, SRC_FROM_B = 1u << 29;
+template <int OP, int NTH, int VT>
+__device__ __forceinline__ void tile_flush_src(const SetopArgs &p, int tid, u64 base, u32 count, u32 excl, u32 mask, u32 amask,
+                                               u32 mmask, int ia0, int ib0, u32 *s_t32) {
+    static_assert(NTH * VT + 8 < (1 << 14), "a place in the tile takes 14 bits");
+    __syncthreads();  // every thread has stored its share of the compacted codes
+#pragma unroll
+    for (int s = 0; s < VT; s++) {
+        if (mask & (1u << s)) {
+            const u32 below = (1u << s) - 1u;
+            const int na_before = __popc(amask & below);
+            const u32 ia = (u32)(ia0 + na_before), ib = (u32)(ib0 + s - na_before);
+            const bool at = (amask >> s) & 1u, m = (mmask >> s) & 1u;
+            s_t32[excl + (u32)__popc(mask & below)] = ia | (ib << 14) | (m ? SRC_MATCH : 0u) | (at ? 0u : SRC_FROM_B);
+        }
+    }
+    __syncthreads();
+    for (u32 i = (u32)tid; i < count; i += NTH)
+        if (base + i < p.out_cap) p.tout[base + i] = s_t32[i];
+}
+
+constexpr int GATHER_NT = 256;
+template <int OP, int TILE>
+__global__ __launch_bounds__(GATHER_NT) void setop_taxid_gather_kernel(SetopArgs p) {
+    setop_resolve_sizes(p, (u64)TILE);
+    const u64 tile = blockIdx.x;
+    if (tile >= p.ntiles) return;
+    if (sload_u64(&p.result[1]) & FLAG_TIMEOUT) return;  // (the host runs the pass again: the status words are incomplete)
+    u64 base, end;
+    if (OP == UKM_OP_MERGE_INTERNAL) {
+        base = tile * (u64)TILE;
+        end = base + TILE < p.na + p.nb ? base + TILE : p.na + p.nb;
+    } else {
+        base = tile ? (lb_load(&p.status[(tile - 1) * LB_STRIDE]) & LB_VAL) : 0ull;
+        end = lb_load(&p.status[tile * LB_STRIDE]) & LB_VAL;
+    }
+    if (end > p.out_cap) end = p.out_cap;
+    if (end <= base) return;
+    const u64 a0 = p.mp[tile], b0 = tile * (u64)TILE - a0;
+    const bool mix = (p.flags & UKM_F_MIX_TAXID) != 0;
+    const u32 *safe32 = reinterpret_cast<const u32 *>(p.result);  // (always mapped: where a lane has nothing to read)
+    // U records per thread and step: four rounds of loads -- the words, the taxids, the clade codes, the clade pairs -- each
+    // round with all of its reads in flight, none inside a branch.  (Measured at 2 x 1e8, inter with one taxid per file as arrays:
+    // 256 threads x 8 records 0.99 ms, x 4 1.06, x 2 1.13; a whole tile per 1024-thread workgroup in ONE step 1.22.)
+#ifndef GATHER_U
+#define GATHER_U 8
+#endif
+    constexpr int U = GATHER_U;
+    constexpr bool LCA = OP == UKM_OP_UNION || OP == UKM_OP_INTER;
+    for (u64 i0 = base + threadIdx.x; i0 < end; i0 += (u64)GATHER_NT * U) {
+    u32 w[U], va[U], vb[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+        const u64 i = i0 + (u64)u * GATHER_NT;
+        w[u] = p.tout[i < end ? i : base];
+    }
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+        const u32 ia = w[u] & 0x3FFFu, ib = (w[u] >> 14) & 0x3FFFu;
+        // Every lane reads BOTH inputs' taxid at its place, needed or not: the places of neighbouring records are neighbours, so
+        // the unneeded reads fall into lines the wave fetches anyway.  A place beyond its input (the B record behind the last
+        // one; an unsorted input, whose result the host discards) is clamped into it.
+        const u64 ga = a0 + ia, gb = b0 + ib;
+        va[u] = p.cta;
+        vb[u] = p.ctb;
+        if (p.ta) va[u] = *(p.na ? p.ta + (ga < p.na ? ga : p.na - 1) : safe32);  // (uniform branches)
+        if (p.tb) vb[u] = *(p.nb ? p.tb + (gb < p.nb ? gb : p.nb - 1) : safe32);
+    }
+    u32 quick[U];
+    u32 qmask = 0;
+    if (LCA && p.tax.pair != nullptr && p.tax.clade8 != nullptr) {  // (uniform)
+        u32 ca[U], cb[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const bool look = (w[u] & SRC_MATCH) != 0 && va[u] != vb[u] && va[u] != 0 && vb[u] != 0 && va[u] < p.tax.size && vb[u] < p.tax.size;
+            ca[u] = p.tax.clade8[look ? va[u] : 0u];
+            cb[u] = p.tax.clade8[look ? vb[u] : 0u];
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const bool q = ca[u] != cb[u] && ca[u] != 0 && cb[u] != 0;
+            qmask |= q ? (1u << u) : 0u;
+            quick[u] = p.tax.pair[q ? ca[u] * p.tax.kp + cb[u] : 0u];
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+        const u64 i = i0 + (u64)u * GATHER_NT;
+        if (i >= end) continue;
+        const bool from_b = (w[u] & SRC_FROM_B) != 0, m = (w[u] & SRC_MATCH) != 0;
+        u32 tv;
+        if (LCA && m) {
+            if (OP == UKM_OP_INTER && mix && (va[u] == 0 || vb[u] == 0)) tv = va[u] == 0 ? vb[u] : va[u];
+            else if ((qmask >> u) & 1u) tv = quick[u];
+            else tv = lca_dev(p.tax, va[u], vb[u]);  // relatives, zero / unknown / merged ids, no clade tables
+        } else {
+            tv = from_b ? vb[u] : va[u];
+        }
+        p.tout[i] = tv;
+    }
+    }
+}
+
 // result[4] of a CT call: [31:0] the taxid of a matched pair (inter --mix-taxid: a zero on either side yields the other,
 // inter.go:229-236), [32] diff -t keeps matched codes (diff.go:404-409: the later file's taxid equals the first file's or
 // lies below it).  One thread; runs between the partition launch (which clears the control words) and the tile kernel.
@@ -828,6 +944,7 @@ void setop_tile_kernel(SetopArgs p) {
     u64 ok[VT];
     u32 ot[VT];
     u32 mask, amask = 0, mmask = 0;
+    int ia0 = 0, ib0 = 0;
     u32 ct_lca = 0;
     bool ct_keep = false;
     if (CT) {  // (written by setop_ct_kernel in front of this launch: a scalar load)
@@ -840,7 +957,7 @@ void setop_tile_kernel(SetopArgs p) {
 #pragma unroll
     for (int s = 0; s < VT; s++) { ok[s] = s_keys[tid * VT + s]; ot[s] = 0; }
 #else
-    tile_merge<OP, TAX, RANK, CT, NTH, VT>(p, g, tid, s_keys, s_tax, s_rank, ok, ot, mask, amask, mmask, ct_keep);
+    tile_merge<OP, TAX, RANK, CT, NTH, VT>(p, g, tid, s_keys, s_tax, s_rank, ok, ot, mask, amask, mmask, ct_keep, ia0, ib0);
 #endif
     PH(2);
     u32 tile_total;
@@ -904,7 +1021,12 @@ void setop_tile_kernel(SetopArgs p) {
     const u64 base = s_misc[1];
 #ifndef SETOP_ABL_NOFLUSH
     tile_flush<TAX, NTH>(p, tid, base, tile_total, s_keys, s_tax);
-    if (CT) tile_flush_ct<OP, NTH, VT>(p, tid, base, tile_total, excl, mask, amask, mmask, ct_lca, reinterpret_cast<u32 *>(s_keys));
+    if (CT) {
+        if (p.ta != nullptr || p.tb != nullptr)  // (uniform) per-record taxids on a stream: source words now, setop_taxid_gather_kernel next
+            tile_flush_src<OP, NTH, VT>(p, tid, base, tile_total, excl, mask, amask, mmask, ia0, ib0, reinterpret_cast<u32 *>(s_keys));
+        else
+            tile_flush_ct<OP, NTH, VT>(p, tid, base, tile_total, excl, mask, amask, mmask, ct_lca, reinterpret_cast<u32 *>(s_keys));
+    }
 #endif
     if (tid == 0 && tile == p.ntiles - 1) p.result[0] = base + tile_total;
     PH(5);
@@ -952,6 +1074,10 @@ void launch_tile(const SetopArgs &p, hipStream_t st, bool ticket) {
         hipLaunchKernelGGL((setop_tile_kernel<OP, TAX, RANK, true, NTH, VT, CT>), dim3((unsigned)p.ntiles), dim3(NTH), 0, st, p);
     else
         hipLaunchKernelGGL((setop_tile_kernel<OP, TAX, RANK, false, NTH, VT, CT>), dim3((unsigned)p.ntiles), dim3(NTH), 0, st, p);
+    if constexpr (CT && !RANK) {
+        if (p.ta != nullptr || p.tb != nullptr)  // the source words of the launch above -> taxids
+            hipLaunchKernelGGL((setop_taxid_gather_kernel<OP, NTH * VT>), dim3((unsigned)p.ntiles), dim3(GATHER_NT), 0, st, p);
+    }
 }
 
 template <bool TAX, bool RANK, int NTH, int VT, bool CT = false>
@@ -976,7 +1102,15 @@ int run_setop_pass(ukm_ctx *c, int op, const u64 *a, const u32 *ta, const u32 *r
                    const u64 *b, const u32 *tb, const u32 *rb, u64 nb, bool tax, u32 flags,
                    u64 *out, u32 *tout, u64 out_cap, u64 result_host[2], u32 cta = 0, u32 ctb = 0) {
     const bool rank = ra != nullptr;
-    const bool ct = tax && !ta && !tb;
+    bool ct = tax && !ta && !tb;
+    // per-record taxids on plain sets, `inter`: the plain-key kernel writes source words, a second launch turns them into
+    // taxids (tile_flush_src / setop_taxid_gather_kernel).  Measured at 2 x 1e8 records against the taxid instantiation
+    // (profiles/r05_notes.md, section 9): inter 1.60 against 1.78 ms with random taxids, 0.99 against 1.24 with taxids a
+    // thread's memo answers; diff 0.67 = 0.67; union 2.04 against 1.95 and 1.59 against 1.38 -- twice the output records go
+    // through the second launch, which runs at ~130 G records/s -- so only `inter` takes it (UKM_SETOP_SRC: 0 = never, 2 =
+    // every operation but diff -t, whose survivors depend on their taxids; never the multiset re-run with ranks).
+    const int src_mode = ukm_env_int(c, "UKM_SETOP_SRC", 1);
+    if (tax && !ct && !rank && src_mode != 0 && (op == UKM_OP_INTER || (src_mode == 2 && !(op == UKM_OP_DIFF && (flags & UKM_F_CMP_TAXID))))) ct = true;
     if (ct) tax = false;  // the plain-key kernel; the taxids are an epilogue of it
     const int vt = (tax || rank) ? VT_TAX : VT_PLAIN;
     const u64 tile_items = (u64)NTS * vt;
