@@ -1,5 +1,2 @@
 cd $GRAFT_REPO_ROOT
-for P in 0.1 0.02 0.005 0.001; do
- echo "== P=$P"
- python tools/srmerge_bench.py 1000 1e6 $P tax both 3 2>/dev/null | tail -3
-done
+UKM_FORCE_TICKET=1 timeout 1500 python -m pytest tests/test_gpu_parity.py tests/test_gpu_filetax.py tests/test_golden_vectors.py -m gpu -x -q > gpurun_out/t.log 2>&1; grep -E "passed|failed|Error" gpurun_out/t.log | tail -5
