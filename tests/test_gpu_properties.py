@@ -290,6 +290,71 @@ def test_range_fold_equals_chained_fold_large(env, monkeypatch):
         assert a.numel() == b.numel() and bool((a == b).all())
 
 
+def test_inter_per_record_taxids_two_launches_equal_the_taxid_kernel_large(env, monkeypatch):
+    """Round 5: 2-way `inter` with per-record taxids = the plain-key kernel writing source words + a gather launch
+    (UKM_SETOP_SRC default) against the taxid instantiation (UKM_SETOP_SRC=0) -- two independent device paths -- on the
+    module's two sets (~2e7 records each, 2000+ tiles: source words of every tile shape, pairs split across tile
+    boundaries) with uniformly random taxids that include zeros, ids beyond the taxonomy, absent ids inside it and merged
+    ids; plain and --mix-taxid; and with a file taxid on one side.  The taxonomy is reloaded in all three clade-code forms
+    on the SAME context (one byte + pair table, two bytes + root-path rows of the clade nodes, none)."""
+    torch, bench, lib, ctx, A, B = env
+    import numpy as np
+    dev = A.device
+
+    def tree(kind):
+        child, parent = [], []
+        if kind == "u8":        # one root, 6-ary, depth 6: 43 nodes of depth <= 2
+            nodes = sum(6 ** d for d in range(7))
+            child = np.arange(1, nodes + 1, dtype=np.uint32)
+            parent = ((child.astype(np.int64) - 2) // 6 + 1).astype(np.uint32)
+            parent[0] = 1
+        elif kind == "u16":     # 300 roots with a binary tree of depth 5 below each
+            per = sum(2 ** d for d in range(6))
+            ids = np.arange(1, 300 * per + 1, dtype=np.uint32).reshape(300, per)
+            loc = np.arange(per, dtype=np.int64)
+            par_loc = np.where(loc == 0, 0, (loc - 1) // 2)
+            child = ids.ravel()
+            parent = ids[:, par_loc].ravel()
+        else:                   # 70,000 roots (no clade table), every 50th with two children
+            roots = np.arange(1, 70001, dtype=np.uint32)
+            kids = np.arange(70001, 70001 + 2 * 1400, dtype=np.uint32)
+            child = np.concatenate([roots, kids])
+            parent = np.concatenate([roots, np.repeat(roots[::50], 2)])
+        leaf = ~np.isin(child, parent[parent != child])
+        keep = np.ones(len(child), dtype=bool)
+        keep[np.flatnonzero(leaf)[5::41]] = False   # absent ids inside the range (leaves: nothing hangs below them)
+        child, parent = child[keep], parent[keep]
+        top = int(child.max())
+        mo = np.array([top + 3, top + 4], dtype=np.uint32)
+        mn = np.array([child[len(child) // 3], top + 500], dtype=np.uint32)
+        return child, parent, mo, mn, top
+
+    for kind in ("u8", "u16", "roots", "u8"):
+        child, parent, mo, mn, top = tree(kind)
+        ctx.taxonomy_load(child, parent, mo, mn)
+        T = top + 6
+        ta = (bench.splitmix64_torch(A ^ 12345) & ((1 << 40) - 1)) % T
+        tb = (bench.splitmix64_torch(B ^ 54321) & ((1 << 40) - 1)) % T
+        ta, tb = ta.to(torch.int32), tb.to(torch.int32)
+        res = {}
+        for mode in ("1", "0"):
+            monkeypatch.setenv("UKM_SETOP_SRC", mode)
+            k1, t1 = ctx.setop2(lib.OP_INTER, A, B, ta, tb)
+            k2, t2 = ctx.setop2(lib.OP_INTER, A, B, ta, tb, flags=lib.F_MIX_TAXID)
+            k3, t3 = ctx.setop2(lib.OP_INTER, A, B, ta, 7)
+            res[mode] = [x.clone() for x in (k1, t1, k2, t2, k3, t3)]
+        monkeypatch.delenv("UKM_SETOP_SRC", raising=False)
+        assert res["1"][0].numel() > 1_000_000
+        for x, y in zip(res["1"], res["0"]):
+            assert x.numel() == y.numel() and bool((x == y).all()), kind
+        # and a slice of it against the oracle-free definition: lca of the two records' taxids through ukm_lca
+        k, t = res["1"][0], res["1"][1]
+        ia = torch.searchsorted(A, k[:200000])
+        ib = torch.searchsorted(B, k[:200000])
+        exp = ctx.lca(ta[ia].cpu().numpy().view(np.uint32), tb[ib].cpu().numpy().view(np.uint32))
+        assert np.array_equal(t[:200000].cpu().numpy().view(np.uint32), exp), kind
+
+
 def test_sort_top16_then_lds_buckets(env, monkeypatch):
     """Keys-only sorts of >= 2^24 keys take two scatter passes over the top 16 bits and then sort every bucket inside LDS
     (ukm_sort.hip).  Against torch.sort and against the all-passes route (UKM_SORT_LOCAL=0): evenly spread 62-bit and
