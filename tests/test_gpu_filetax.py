@@ -298,6 +298,44 @@ def test_probe_paths_file_taxids_new_codes_and_aliases(env, monkeypatch):
         _eq((gk, gt), O.merge_k(files, ex, mode=O.REPEATED, tax=tax), ("merge -d alias", rep))
 
 
+@pytest.mark.parametrize("clade", ["0", "1", None])
+def test_probe_tables_clade_mode_per_record_taxids(env, monkeypatch, clade):
+    """Round 5: the probe union's / counting probes' tables with per-record taxids in CLADE MODE (ukm_punion.hip: a record
+    brings the one-byte clade code of its taxid; its 4-byte pre-order number is fetched only while the entry's interval
+    lies inside one clade) -- UKM_PUNION_CLADE = 1 forces it, 0 forbids it, unset = the sample decides.  Against the oracle
+    on files whose later ones bring new codes (claims), with taxids that are unrelated (a hash of the code over the whole
+    pool: zeros, unknown and merged ids in the forest), related (drawn from one small clade: every hit needs its number),
+    equal within a file, and mixed with files that carry ONE taxid; `union`, `common` below the number of files, `merge -d`."""
+    O, L, ctx, tax, pool, kind = env
+    monkeypatch.setenv("UKM_PUNION", "2")
+    if clade is None:
+        monkeypatch.delenv("UKM_PUNION_CLADE", raising=False)
+    else:
+        monkeypatch.setenv("UKM_PUNION_CLADE", clade)
+    U = _universe(40_000, 20)
+    nfiles = 30
+    base = [U[_member(len(U), f, 0.5, 140)][:8000] for f in range(8)]
+    fresh = U[_member(len(U), 99, 0.4, 141)][9000:]
+    later = [np.sort(np.unique(np.concatenate([U[_member(len(U), f, 0.5, 140)][:7000], fresh[_member(len(fresh), f, 0.6, 19)]])))
+             for f in range(8, nfiles)]
+    files = base + later
+    related = pool[-6:] if kind == "tree" else np.array([4, 5, 6, 7], dtype=np.uint32)   # (one small clade)
+    shapes = {
+        "unrelated": [_taxids(f, pool, i) for i, f in enumerate(files)],
+        "related": [_taxids(f, related, i) for i, f in enumerate(files)],
+        "one_per_file_arrays": [np.full(len(f), int(pool[(3 * i + 1) % len(pool)]), np.uint32) for i, f in enumerate(files)],
+        "mixed": [(_taxids(f, pool, i) if i % 3 else int(pool[(5 * i + 2) % len(pool)])) for i, f in enumerate(files)],
+    }
+    for name, taxs in shapes.items():
+        ex = _expand(files, taxs)
+        gk, gt = ctx.union(files, taxs)
+        assert ctx.last_route() == 3, name
+        _eq((gk, gt), O.union(files, ex, tax), ("union", name, clade))
+        for thr in (2, nfiles // 2, nfiles - 1):
+            _eq(ctx.common(files, thr, taxs), O.common(files, thr, ex, tax), ("common", name, thr, clade))
+        _eq(ctx.merge_k(files, taxs, mode=L.REPEATED), O.merge_k(files, ex, mode=O.REPEATED, tax=tax), ("merge -d", name, clade))
+
+
 def test_inter_diff_common_file_taxids_many_files(env, monkeypatch):
     """1000 files with one taxid each: `inter`, `diff`, `diff -t` and `common` of all files are the PLAIN operation and a
     fill (the probe fold, the chained fold and the synchronous fold in turn); results against the oracle's file-by-file

@@ -79,6 +79,9 @@ struct PuArgs {
     // pre-order number << 32 (pu_cte_kernel) -- a slice of such a file loads no taxids and looks no number up
     const u64 *cte;           // [S1], or null: files without per-record taxids have taxid 0
     u32 base_ct;              // COUNT with the first file as the base set and no base_tax: its file taxid
+    // Round 5, pt_probe_kernel: the taxids of the later records look UNRELATED to the entries' (the sample: ctl[6]): a record
+    // brings the one-byte CLADE code of its taxid instead of the 4-byte pre-order number (see the kernel's fold)
+    u32 clade_mode;
     TaxDev tax;
 };
 
@@ -136,7 +139,7 @@ __global__ void pu_load_kernel(PuArgs a) {
 // hit rate of a sample of later records in the base set
 __global__ void pu_sample_kernel(PuArgs a, u32 nsamp, u32 nfiles_s) {
     const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
-    bool tested = false, hit = false;
+    bool tested = false, hit = false, same = false, run = false;
     if (i < nsamp) {
         const u32 j = (u32)(((u64)(i % nfiles_s) * a.S1) / nfiles_s);
         const u64 len = a.lens[j];
@@ -153,6 +156,18 @@ __global__ void pu_sample_kernel(PuArgs a, u32 nsamp, u32 nfiles_s) {
             }
             tested = true;
             hit = lo < a.n0 && a.base[lo] == key;
+            // (records with taxids: does the record's taxid differ from the entry's and lie in the entry's clade?  Those are
+            //  the records that need their exact pre-order number in the fold: PuArgs::clade_mode)
+            if (hit && a.tax.clade8 && a.tfiles && (a.base_tax || a.base_ct)) {
+                const u32 *tf = a.tfiles[j];
+                const u64 at = hi_p > lo_p ? lo_p + pu_splitmix(i) % (hi_p - lo_p) : (lo_p < len ? lo_p : len - 1);
+                const u32 t = tf ? tf[at] : (a.cte ? (u32)a.cte[j] : 0u);
+                const u32 bt = a.base_tax ? a.base_tax[lo] : a.base_ct;
+                same = t != bt && t < a.tax.size && bt < a.tax.size && a.tax.clade8[t] == a.tax.clade8[bt];
+                // (and does the file's NEXT record carry the same taxid?  Files whose neighbouring records share their taxid -- one
+                //  taxid per genome, taxids assigned by clade -- read the 4-byte numbers from lines they have just used)
+                run = !tf || (at + 1 < len && tf[at + 1] == t);
+            }
             // (the sampled records the base set lacks are kept: how many DISTINCT new codes the files bring is read off
             //  the equal pairs among them, pu_new_codes)
             if (!hit && a.miss) {
@@ -161,24 +176,42 @@ __global__ void pu_sample_kernel(PuArgs a, u32 nsamp, u32 nfiles_s) {
             }
         }
     }
-    const u64 mh = __ballot(hit), mt = __ballot(tested);
+    const u64 mh = __ballot(hit), mt = __ballot(tested), ms = __ballot(same), mr = __ballot(run);
     if (lane_id() == 0 && mt) {
         atomicAdd((unsigned long long *)&a.ctl[2], (unsigned long long)__popcll(mh));
         atomicAdd((unsigned long long *)&a.ctl[3], (unsigned long long)__popcll(mt));
+        if (ms) atomicAdd((unsigned long long *)&a.ctl[6], (unsigned long long)__popcll(ms));
+        if (mr) atomicAdd((unsigned long long *)&a.ctl[7], (unsigned long long)__popcll(mr));
     }
 }
 
 // cte[j]: the file taxid in the low word (host) gets its pre-order number in the high word
-__global__ void pu_cte_kernel(u64 *cte, u32 n, TaxDev T) {
+__global__ void pu_cte_kernel(u64 *cte, u32 n, TaxDev T, u32 clade_mode = 0) {
     const u32 j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n) return;
     const u32 t = (u32)cte[j];
-    const u32 e = T.euler ? T.euler[t < T.size ? t : 0u] : 0u;
+    u32 e = T.euler ? T.euler[t < T.size ? t : 0u] : 0u;
+    if (clade_mode && e) e |= (u32)T.clade8[t] << 24;  // (PuArgs::clade_mode: the numbers carry their clade code)
     cte[j] = (u64)t | ((u64)e << 32);
 }
 
 typedef u64 pu_u64x2 __attribute__((ext_vector_type(2)));
 typedef pu_u64x2 __attribute__((aligned(8))) pu_pair;  // 16 bytes at 8-byte alignment
+
+// PuArgs::clade_mode from the sample (hits: sampled later records found in the base set, same: those of them whose taxid
+// differs from the entry's and lies in the entry's clade -- the records whose exact number the fold would have to fetch on
+// the spot).  Unrelated taxa: next to none.  Related taxa (one species' strains): most -- the numbers are then read for
+// every record in the pipeline's second stage, as in rounds 4-5.  UKM_PUNION_CLADE=0 / 1: never / always.
+// runs: hits whose file's next record carries the same taxid: with most of them the numbers come from lines the wave has just
+// used and the plain fold is the faster one (config 3's files with one taxid each as arrays: probe pass 27.5 ms against 34.0 in
+// clade mode; uniformly random taxids: 67.8 against 41.7).
+static u32 pu_clade_mode(const ukm_ctx *c, const TaxDev &T, bool tax, u64 hits, u64 same, u64 runs) {
+    if (!tax || T.clade8 == nullptr || T.pair == nullptr || T.euler == nullptr) return 0u;
+    const int k = ukm_env_int(c, "UKM_PUNION_CLADE", -1);
+    if (k == 0) return 0u;
+    if (k == 1) return 1u;
+    return (hits > 0 && same * 16 < hits && runs * 2 < hits) ? 1u : 0u;
+}
 
 __global__ __launch_bounds__(PU_NT) __attribute__((amdgpu_waves_per_eu(PU_WAVES, PU_WAVES))) void pu_probe_kernel(PuArgs a) {
     __shared__ __attribute__((aligned(32))) u64 s_tab[PU_SLOTS];
@@ -471,7 +504,7 @@ typedef pt_u32x2 __attribute__((aligned(4))) pt_tpair;  // 8 bytes at 4-byte ali
 // every slot also counts its records ([31:2] of the flag word), and when the range is done the codes that reached the
 // threshold leave — base entries and new codes alike — with their fold; nothing is listed record by record (a record that
 // cannot be counted in a table raises PU_FLAG_RAW and the caller's counting merge answers).
-template <bool COUNT>
+template <bool COUNT, bool CM = false>
 __global__ __launch_bounds__(PT_NT) __attribute__((amdgpu_waves_per_eu(PT_WAVES, PT_WAVES))) void pt_probe_kernel(PuArgs a) {
     __shared__ __attribute__((aligned(32))) u64 s_tab[PT_SLOTS];
     // x = t0, y = smallest number, z = ~largest, w = [0] another TaxId with the same number was seen, [1] settled, [31:2] records (COUNT)
@@ -517,9 +550,17 @@ __global__ __launch_bounds__(PT_NT) __attribute__((amdgpu_waves_per_eu(PT_WAVES,
         if (idx >= nb) ent[i] = PU_EMPTY;
         else bad_t |= et[i] == PT_UNSET;
     }
+    // Clade mode (PuArgs::clade_mode, round 5): a number is `clade code << 24 | pre-order number` -- codes are handed out in
+    // pre-order, so the composite orders taxids as the numbers do -- and a record of a file with per-record taxids brings only
+    // the code (one byte of a table that stays in L2, instead of 4 bytes of one that does not): see fold.
+    constexpr bool cm = CM;  // (an instantiation of its own: the plain fold keeps its instruction count)
     u32 ee[PER];
 #pragma unroll
-    for (int i = 0; i < PER; i++) ee[i] = T.euler ? T.euler[et[i] < T.size ? et[i] : 0u] : 0u;
+    for (int i = 0; i < PER; i++) {
+        const u32 tq = et[i] < T.size ? et[i] : 0u;
+        ee[i] = T.euler ? T.euler[tq] : 0u;
+        if (cm && ee[i]) ee[i] |= (u32)T.clade8[tq] << 24;
+    }
 #pragma unroll
     for (int i = 0; i < PER; i++) {
         if (ent[i] == PU_EMPTY) continue;  // (an all-ones code: its records are listed, the final union folds them)
@@ -551,11 +592,18 @@ __global__ __launch_bounds__(PT_NT) __attribute__((amdgpu_waves_per_eu(PT_WAVES,
         if (k1 < 0 && q1.y != PU_EMPTY) sb = find_from(xb, next_bucket(h1));
     };
     // one record's TaxId into its entry; e = its pre-order number (0: taxid 0 / unknown)
-    auto fold = [&](int slot, u32 t, u32 e) {
+    // Clade mode: e = code << 24 | number when `exact`, else code << 24 (the number was not read).  An entry whose interval
+    // spans two clades has the LCA of those two clade nodes whatever the exact numbers are, so a record needs its number
+    // only while the entry's interval lies inside ONE clade and the record is of that clade (or the interval is not written
+    // yet): then -- for unrelated taxa next to never -- it is fetched here; a record outside the interval widens it with a
+    // sentinel number (all ones below / zero above the code), one inside an interval of several clades does nothing.  The
+    // interval only ever widens, so an entry that is still inside one clade at the end had every record folded exactly.
+    auto fold = [&](int slot, u32 t, u32 e, bool exact) {
         uint4 st = s_st[slot];
         if (st.x == PT_UNSET) {  // a new code: whoever comes first gives it its TaxId (any order gives the same fold)
             const u32 old = atomicCAS(&s_st[slot].x, PT_UNSET, t);
             if (old == PT_UNSET) {
+                if (cm && !exact && e != 0) e |= T.euler[t];  // (the claimer's own number: e != 0 says t is inside the table)
                 atomicMin(&s_st[slot].y, e);
                 atomicMin(&s_st[slot].z, ~e);
                 return;
@@ -563,17 +611,28 @@ __global__ __launch_bounds__(PT_NT) __attribute__((amdgpu_waves_per_eu(PT_WAVES,
             st = s_st[slot];
         }
         if (t == st.x) return;
-        const bool lo = e < st.y, hi = ~e < st.z;
+        u32 e_lo = e, e_hi = e;  // what the record puts to the interval's two ends
+        if (cm && !exact && e != 0) {
+            const u32 c = e >> 24;
+            if (st.y > ~st.z || ((st.y >> 24) == c && ((~st.z) >> 24) == c)) {
+                e |= T.euler[t];
+                e_lo = e_hi = e;
+                exact = true;
+            } else {
+                e_lo = e | 0xFFFFFFu;
+            }
+        }
+        const bool lo = e_lo < st.y, hi = ~e_hi < st.z;
         if (lo | hi) {
-            atomicMin(lo ? &s_st[slot].y : &s_st[slot].z, lo ? e : ~e);
-            if (lo & hi) atomicMin(&s_st[slot].z, ~e);  // (an interval that is still empty: a new code a moment after its claim)
+            atomicMin(lo ? &s_st[slot].y : &s_st[slot].z, lo ? e_lo : ~e_hi);
+            if (lo & hi) atomicMin(&s_st[slot].z, ~e_hi);  // (an interval that is still empty: a new code a moment after its claim)
             // The snapshot was taken between the claimer's CAS on x and its two minima (empty or half-written interval:
             // smallest > largest): this record's number may be the CLAIMER'S -- the alias of a merged id, another unknown
             // id -- and the interval would then never show that two different taxids met.  Say so; a flag too many only
             // sends settle() through LCA(node_at[min], node_at[max]), which is always right.  (Base entries are written
             // in front of the barrier and are never seen half-way.)
             if (st.y > ~st.z && (st.w & 1u) == 0u) atomicOr(&s_st[slot].w, 1u);
-        } else if (st.y == e && st.z == ~e && (st.w & 1u) == 0u) {
+        } else if ((!cm || exact || e == 0) && st.y == e && st.z == ~e && (st.w & 1u) == 0u) {
             atomicOr(&s_st[slot].w, 1u);
         }
     };
@@ -618,7 +677,7 @@ __global__ __launch_bounds__(PT_NT) __attribute__((amdgpu_waves_per_eu(PT_WAVES,
     // a record: found -> fold; not found -> claim a slot for its code (then it is a hit like any other), or list it
     // (plain codes -- no file has TaxIds -- through these tables: a hit has nothing to do beyond the count)
     const bool folds = a.base_tax != nullptr || a.miss_tax != nullptr;
-    auto record = [&](bool valid, int slot, u64 x, u32 t, u32 e) {
+    auto record = [&](bool valid, int slot, u64 x, u32 t, u32 e, bool exact) {
         bool raw = false;
         if (valid) {
             if (slot < 0) {
@@ -631,7 +690,7 @@ __global__ __launch_bounds__(PT_NT) __attribute__((amdgpu_waves_per_eu(PT_WAVES,
             }
             if (!raw) {
                 if (COUNT) atomicAdd(&s_st[slot].w, 4u);
-                if (folds) fold(slot, t, e);
+                if (folds) fold(slot, t, e, exact);
             }
         }
         if (COUNT) bad_raw |= raw;
@@ -673,8 +732,13 @@ __global__ __launch_bounds__(PT_NT) __attribute__((amdgpu_waves_per_eu(PT_WAVES,
             bad_t |= ta == PT_UNSET || tb == PT_UNSET;
             rb.eu[u][0] = rb.eu[u][1] = d.ce;
             if (d.tf != 0) {  // (wave-uniform; a file without per-record TaxIds: its own one's number -- 0 without any, and there may be no taxonomy at all)
-                rb.eu[u][0] = T.euler[ta < T.size ? ta : 0u];
-                rb.eu[u][1] = T.euler[tb < T.size ? tb : 0u];
+                if (cm) {     // the clade codes alone (fold fetches a number where it matters)
+                    rb.eu[u][0] = (u32)T.clade8[ta < T.size ? ta : 0u] << 24;
+                    rb.eu[u][1] = (u32)T.clade8[tb < T.size ? tb : 0u] << 24;
+                } else {
+                    rb.eu[u][0] = T.euler[ta < T.size ? ta : 0u];
+                    rb.eu[u][1] = T.euler[tb < T.size ? tb : 0u];
+                }
             }
         }
     };
@@ -690,8 +754,8 @@ __global__ __launch_bounds__(PT_NT) __attribute__((amdgpu_waves_per_eu(PT_WAVES,
                 bad |= x0 > x1 || x1 > ra.nx[u];
                 int s0, s1;
                 find2(x0, x1, s0, s1);
-                record(pos < end, s0, x0, ra.tp[u].x, rb.eu[u][0]);
-                record(pos + 1 < end, s1, x1, ra.tp[u].y, rb.eu[u][1]);  // (a code claimed a moment ago is found again by the insert)
+                record(pos < end, s0, x0, ra.tp[u].x, rb.eu[u][0], d.tf == 0);
+                record(pos + 1 < end, s1, x1, ra.tp[u].y, rb.eu[u][1], d.tf == 0);  // (a code claimed a moment ago is found again by the insert)
             }
             return;
         }
@@ -709,8 +773,8 @@ __global__ __launch_bounds__(PT_NT) __attribute__((amdgpu_waves_per_eu(PT_WAVES,
             if (v0) bad |= x0 > x1 || x1 > x2;
             int s0, s1;
             find2(x0, x1, s0, s1);
-            record(v0, s0, x0, y0, e0);
-            record(v1, s1, x1, ra.tp[u].y, rb.eu[u][1]);
+            record(v0, s0, x0, y0, e0, d.tf == 0);
+            record(v1, s1, x1, ra.tp[u].y, rb.eu[u][1], d.tf == 0);
         }
     };
     auto take = [&]() -> u32 {
@@ -753,8 +817,9 @@ __global__ __launch_bounds__(PT_NT) __attribute__((amdgpu_waves_per_eu(PT_WAVES,
                 const u64 x = f[0];
                 const u32 t = cur.tf ? as_global((const u32 *)(uintptr_t)cur.tf)[0] : fct;
                 bad_t |= t == PT_UNSET;
-                const u32 e = cur.tf ? T.euler[t < T.size ? t : 0u] : fce;
-                record(lane == 0, lane == 0 ? find_from(x, pt_hash(x)) : -1, x, t, e);
+                u32 e = cur.tf ? T.euler[t < T.size ? t : 0u] : fce;
+                if (cm && cur.tf && e) e |= (u32)T.clade8[t] << 24;
+                record(lane == 0, lane == 0 ? find_from(x, pt_hash(x)) : -1, x, t, e, true);
             }
             j = jn;
             cur = nxt;
@@ -790,6 +855,10 @@ __global__ __launch_bounds__(PT_NT) __attribute__((amdgpu_waves_per_eu(PT_WAVES,
         const u32 mn = st.y, mx = ~st.z;
         if (mn == mx && (st.w & 1u) == 0u) return st.x;  // every record carried t0
         if (mn == 0u) return 0u;                  // TaxId 0 / an unknown id among records that differ
+        if (cm) {
+            if ((mn >> 24) != (mx >> 24)) return lca_clade_pair(T, mn >> 24, mx >> 24);
+            return lca_dev(T, T.node_at[mn & 0xFFFFFFu], T.node_at[mx & 0xFFFFFFu]);
+        }
         return lca_dev(T, T.node_at[mn], T.node_at[mx]);
     };
     if (!COUNT) {
@@ -1744,16 +1813,24 @@ static int probe_union_k0(ukm_ctx *c, const u64 *const *keys, const u32 *const *
     {
         a.files = (const u64 *const *)d_tab;
         a.lens = d_tab + S1all;
+        a.tfiles = (const u32 *const *)(d_tab + 2 * (size_t)S1all);  // (the sample also looks at the taxids: clade_mode)
+        a.cte = any_ct ? d_tab + 3 * (size_t)S1all : nullptr;
         a.S1 = (u32)S1all;
         const u32 nsamp = 1u << 16, nf = (u32)std::min(S1all, 16);
         hipLaunchKernelGGL(pu_sample_kernel, dim3(nsamp / 256), dim3(256), 0, c->stream, a, nsamp, nf);
         UKM_HIP(hipGetLastError());
-        u64 h[4] = {0, 0, 0, 0};
-        UKM_TRY(ukm_read_u64(c, ctl, h, 4));
+        u64 h[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        UKM_TRY(ukm_read_u64(c, ctl, h, 8));
         if (h[3] == 0) return UKM_OK;
         miss_rate = 1.0 - (double)h[2] / (double)h[3];
-        if (dbg) fprintf(stderr, "[punion] sample: %llu of %llu later records in the base set (n0 = %llu)\n",
-                         (unsigned long long)h[2], (unsigned long long)h[3], (unsigned long long)n0);
+        a.clade_mode = pu_clade_mode(c, a.tax, tax, h[2], h[6], h[7]);
+        if (a.clade_mode && any_ct) {  // (the file taxids' numbers with their clade codes)
+            hipLaunchKernelGGL(pu_cte_kernel, dim3((unsigned)((S1all + 255) / 256)), dim3(256), 0, c->stream, d_tab + 3 * (size_t)S1all, (u32)S1all,
+                               a.tax, 1u);
+            UKM_HIP(hipGetLastError());
+        }
+        if (dbg) fprintf(stderr, "[punion] sample: %llu of %llu later records in the base set (n0 = %llu); %llu of them in the entry's clade with another taxid: clade mode %u\n",
+                         (unsigned long long)h[2], (unsigned long long)h[3], (unsigned long long)n0, (unsigned long long)h[6], a.clade_mode);
         *hit_rate = 1.0 - miss_rate;
         if (mode != 2 && 1.0 - miss_rate < (tax ? PT_MIN_HIT : PU_MIN_HIT)) {
             *low_hit = true;
@@ -1814,7 +1891,8 @@ static int probe_union_k0(ukm_ctx *c, const u64 *const *keys, const u32 *const *
             UKM_HIP(hipMemsetAsync(ctl + 4, 0, sizeof(u64), c->stream));
         }
         (void)hipEventRecord(c->ev_k0, c->stream);
-        if (claiming) hipLaunchKernelGGL(pt_probe_kernel<false>, dim3(a.R), dim3(PT_NT), 0, c->stream, a);
+        if (claiming && a.clade_mode) hipLaunchKernelGGL((pt_probe_kernel<false, true>), dim3(a.R), dim3(PT_NT), 0, c->stream, a);
+        else if (claiming) hipLaunchKernelGGL((pt_probe_kernel<false, false>), dim3(a.R), dim3(PT_NT), 0, c->stream, a);
         else hipLaunchKernelGGL(pu_probe_kernel, dim3(a.R), dim3(PU_NT), 0, c->stream, a);
         (void)hipEventRecord(c->ev_k1, c->stream);
         c->evk_valid = true;
@@ -2213,11 +2291,12 @@ int ukm_dev_probe_common(ukm_ctx *c, const u64 *const *keys, const u32 *const *t
         UKM_HIP(hipMemsetAsync(ctl, 0, 8 * sizeof(u64), c->stream));
         hipLaunchKernelGGL(pu_sample_kernel, dim3(nsamp / 256), dim3(256), 0, c->stream, a, nsamp, nf);
         UKM_HIP(hipGetLastError());
-        u64 h[4] = {0, 0, 0, 0};
-        UKM_TRY(ukm_read_u64(c, ctl, h, 4));
+        u64 h[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        UKM_TRY(ukm_read_u64(c, ctl, h, 8));
         *rate = h[3] ? (double)h[2] / (double)h[3] : 0.0;
-        if (dbg) fprintf(stderr, "[pcommon] sample: %llu of %llu records of the probed files in the base set (n0 = %llu)\n", (unsigned long long)h[2],
-                         (unsigned long long)h[3], (unsigned long long)a.n0);
+        a.clade_mode = pu_clade_mode(c, a.tax, tax, h[2], h[6], h[7]);  // (the last sample in front of the launch decides)
+        if (dbg) fprintf(stderr, "[pcommon] sample: %llu of %llu records of the probed files in the base set (n0 = %llu); clade mode %u\n", (unsigned long long)h[2],
+                         (unsigned long long)h[3], (unsigned long long)a.n0, a.clade_mode);
         UKM_HIP(hipMemsetAsync(ctl, 0, 8 * sizeof(u64), c->stream));
         return UKM_OK;
     };
@@ -2304,8 +2383,13 @@ int ukm_dev_probe_common(ukm_ctx *c, const u64 *const *keys, const u32 *const *t
         const u64 avg = later / a.R + 1;
         if (mode != 2 && heaviest > 64 * avg + 65536) return UKM_OK;  // (one workgroup would stream most of the input)
     }
+    if (a.clade_mode && a.cte) {  // (the file taxids' numbers with their clade codes)
+        hipLaunchKernelGGL(pu_cte_kernel, dim3((unsigned)((S1 + 255) / 256)), dim3(256), 0, c->stream, const_cast<u64 *>(a.cte), (u32)S1, a.tax, 1u);
+        UKM_HIP(hipGetLastError());
+    }
     (void)hipEventRecord(c->ev_k0, c->stream);
-    hipLaunchKernelGGL(pt_probe_kernel<true>, dim3(a.R), dim3(PT_NT), 0, c->stream, a);
+    if (a.clade_mode) hipLaunchKernelGGL((pt_probe_kernel<true, true>), dim3(a.R), dim3(PT_NT), 0, c->stream, a);
+    else hipLaunchKernelGGL((pt_probe_kernel<true, false>), dim3(a.R), dim3(PT_NT), 0, c->stream, a);
     (void)hipEventRecord(c->ev_k1, c->stream);
     c->evk_valid = true;
     UKM_HIP(hipGetLastError());
