@@ -43,7 +43,7 @@ namespace {
 
 constexpr u64 SR_MAX = ~0ull;
 enum { SR_FLAG_UNSORTED = 2, SR_FLAG_DEGENERATE = 8 };
-enum { SR_NEQ = 1, SR_BAD = 2, SR_DEAD = 4 };
+enum { SR_NEQ = 1, SR_BAD = 2, SR_DEAD = 4, SR_EXACT = 8 };
 
 constexpr int SR_MAX_STREAMS = 1024;  // two streams per thread, their cursors in registers
 constexpr int SR_SAMPLES_PER_RANGE = 128;
@@ -73,6 +73,30 @@ __global__ void sr_dupcount_kernel(const u64 *samples, u64 ns, u64 *out) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) cnt += (u32)__shfl_xor((int)cnt, o);
     if (cnt && lane_id() == 0) atomicAdd((unsigned long long *)out, (unsigned long long)cnt);
+}
+
+// Are the taxids of the streams' records related?  Pairs of records drawn from two random streams at random places: out[0] +=
+// pairs, out[1] += pairs with two different taxids of one clade (TaxDev::clade8).  Unrelated taxa: ~ 1 / clades.  Related
+// (one species' strains, taxids by clade): most.  Decides SrArgs::clade_emit.
+__global__ void sr_taxsample_kernel(const u32 *const *leaf_tax, const u64 *leaf_len, u32 S, TaxDev T, u64 *out) {
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    u64 h = ((u64)i + 1) * 0x9E3779B97F4A7C15ull;
+    h ^= h >> 29; h *= 0xBF58476D1CE4E5B9ull; h ^= h >> 32;
+    const u32 f = (u32)(h % S), g = (u32)((h >> 20) % S);
+    const u32 *tf = leaf_tax[f], *tg = leaf_tax[g];
+    const u64 lf = leaf_len[f], lg = leaf_len[g];
+    bool pair = false, same = false;
+    if (tf && tg && lf && lg && f != g) {
+        const u64 h2 = h * 0x94D049BB133111EBull;
+        const u32 a = tf[(h2 >> 7) % lf], b = tg[(h2 >> 31) % lg];
+        pair = true;
+        same = a != b && a < T.size && b < T.size && T.clade8[a] != 0 && T.clade8[a] == T.clade8[b];
+    }
+    const u64 mp = __ballot(pair), ms = __ballot(same);
+    if (lane_id() == 0 && mp) {
+        atomicAdd((unsigned long long *)&out[0], (unsigned long long)__popcll(mp));
+        if (ms) atomicAdd((unsigned long long *)&out[1], (unsigned long long)__popcll(ms));
+    }
 }
 
 // splitter r (1 <= r < R) = the sample of rank r * ns / R; spl[0] is unused
@@ -202,6 +226,7 @@ struct SrArgs {
     u32 S, R, per_xcd;
     u32 threshold;                // UNION: > 1 = only codes with at least this many records (`common`)
     u32 buckets;                  // 1: tiles are ordered by counting placement (files that share next to nothing), 0: by the merge rounds
+    u32 clade_emit;               // UNION with taxids: the runs' taxids are folded by their one-byte clade codes first (round 5; see the emit)
     TaxDev tax;
 };
 
@@ -1054,6 +1079,120 @@ __global__ __launch_bounds__(NT, (TAX ? SR_WAVES_TAX : SR_WAVES_PLAIN)) void sr_
                         }
                     }
                 }
+                if (p.clade_emit) {
+                    // Round 5, taxids of unrelated taxa (the host's sample: SrArgs::clade_emit): a record brings the one-byte
+                    // CLADE code of its taxid (a 2.4 MB table that stays in L2) instead of its 4-byte pre-order number; the
+                    // run's two words hold `code << 24 | number` with a sentinel number (all ones in the minimum, zero in
+                    // the maximum).  A run whose taxids span two clades has the LCA of those two clade nodes -- one read of the
+                    // clade-pair table per head, no node_at / root-path reads; runs that stayed inside ONE clade are marked,
+                    // and only their records fetch their numbers in a second, sparse pass and fold them exactly.
+                    u32 en[VT];
+#pragma unroll
+                    for (int s = 0; s < VT; s++) {  // (all of the thread's table reads in flight together; clade8[0] = 0)
+                        const u32 t = ht[s];
+                        en[s] = (u32)p.tax.clade8[((multim & (1u << s)) && t < p.tax.size) ? t : 0u] << 24;
+                    }
+                    {
+                        u32 cw = 0xFFFFFFFFu, cmn = 0xFFFFFFFFu, cmx = 0u, cfl = 0u;
+                        auto flush = [&]() {
+                            if (cw == 0xFFFFFFFFu) return;
+                            if (cmx) {
+                                atomicMin(reinterpret_cast<u32 *>(&s_acc[cw]), cmn);
+                                atomicMax(reinterpret_cast<u32 *>(&s_acc[cw]) + 1, cmx);
+                            }
+                            if (cfl) atomicOr(&s_flag[cw], cfl);
+                        };
+#pragma unroll
+                        for (int s = 0; s < VT; s++) {
+                            if (multim & (1u << s)) {
+                                const u32 w = hexcl + (u32)__popc(headm & ((2u << s) - 1u)) - 1u;
+                                if (w != cw) {
+                                    flush();
+                                    cw = w; cmn = 0xFFFFFFFFu; cmx = 0u; cfl = 0u;
+                                }
+                                const u32 eu = en[s];
+                                cfl |= (neqm & (1u << s)) ? (u32)SR_NEQ : 0u;
+                                if (eu == 0) cfl |= (u32)SR_BAD;
+                                else {
+                                    cmn = (eu | 0xFFFFFFu) < cmn ? (eu | 0xFFFFFFu) : cmn;
+                                    cmx = eu > cmx ? eu : cmx;
+                                }
+                            }
+                        }
+                        flush();
+                    }
+                    __syncthreads();
+                    // heads: which runs stayed inside one clade?
+                    bool any_exact = false;
+#pragma unroll
+                    for (int s = 0; s < VT; s++) {
+                        if ((headm & multim) & (1u << s)) {
+                            const u32 w = hexcl + (u32)__popc(headm & ((2u << s) - 1u)) - 1u;
+                            const u32 fl = s_flag[w];
+                            const u64 acc = s_acc[w];
+                            if ((fl & SR_NEQ) && !(fl & SR_BAD) && ((u32)acc >> 24) == ((u32)(acc >> 32) >> 24)) {
+                                s_flag[w] = fl | (u32)SR_EXACT;  // (its only writer now: every fold lies in front of the barrier)
+                                any_exact = true;
+                            }
+                        }
+                    }
+                    if (__syncthreads_or(any_exact ? 1 : 0)) {
+                        u32 ex[VT];
+                        u32 xm = 0;
+#pragma unroll
+                        for (int s = 0; s < VT; s++) {
+                            bool x = false;
+                            if (multim & (1u << s)) {
+                                const u32 w = hexcl + (u32)__popc(headm & ((2u << s) - 1u)) - 1u;
+                                x = (s_flag[w] & SR_EXACT) != 0 && en[s] != 0;
+                            }
+                            xm |= x ? (1u << s) : 0u;
+                            ex[s] = p.tax.euler[x ? ht[s] : 0u];
+                        }
+#pragma unroll
+                        for (int s = 0; s < VT; s++) {
+                            if (xm & (1u << s)) {
+                                const u32 w = hexcl + (u32)__popc(headm & ((2u << s) - 1u)) - 1u;
+                                const u32 e = en[s] | ex[s];
+                                atomicMin(reinterpret_cast<u32 *>(&s_acc[w]), e);
+                                atomicMax(reinterpret_cast<u32 *>(&s_acc[w]) + 1, e);
+                            }
+                        }
+                        __syncthreads();
+                    }
+                    // one read of the clade-pair table per head whose run spans two clades (all of a thread's in flight)
+                    u32 qi[VT];
+#pragma unroll
+                    for (int s = 0; s < VT; s++) {
+                        qi[s] = 0;
+                        if ((headm & multim) & (1u << s)) {
+                            const u32 w = hexcl + (u32)__popc(headm & ((2u << s) - 1u)) - 1u;
+                            const u32 fl = s_flag[w];
+                            if ((fl & SR_NEQ) && !(fl & (SR_BAD | SR_EXACT))) {
+                                const u64 acc = s_acc[w];
+                                qi[s] = ((u32)acc >> 24) * p.tax.kp + ((u32)(acc >> 32) >> 24);
+                            }
+                        }
+                    }
+                    u32 qv[VT];
+#pragma unroll
+                    for (int s = 0; s < VT; s++) qv[s] = p.tax.pair[qi[s]];
+#pragma unroll
+                    for (int s = 0; s < VT; s++) {
+                        if ((headm & multim) & (1u << s)) {
+                            const u32 w = hexcl + (u32)__popc(headm & ((2u << s) - 1u)) - 1u;
+                            const u32 fl = s_flag[w];
+                            if (fl & SR_NEQ) {
+                                if (fl & SR_BAD) ht[s] = 0;
+                                else if (fl & SR_EXACT) {
+                                    const u64 acc = s_acc[w];
+                                    ht[s] = lca_dev(p.tax, p.tax.node_at[(u32)acc & 0xFFFFFFu], p.tax.node_at[(u32)(acc >> 32) & 0xFFFFFFu]);
+                                } else ht[s] = qv[s];
+                            }
+                        }
+                    }
+                    __syncthreads();
+                } else {
                 if (multim) {
                     // a thread's consecutive records of one run are folded in registers first: one pair of LDS atomics per
                     // (thread, run) instead of per record (a code that is in 900 files puts 900 atomics on one address)
@@ -1133,6 +1272,7 @@ __global__ __launch_bounds__(NT, (TAX ? SR_WAVES_TAX : SR_WAVES_PLAIN)) void sr_
                         if (g0 + q < VT && need[q]) ht[g0 + q] = lca_finish(p.tax, rq[q]);
                 }
                 __syncthreads();
+                }  // (!clade_emit)
             }
             u32 w = hexcl;
             if (counted && TAX) {  // the slots were per run: the runs that count are packed once more
@@ -1326,9 +1466,18 @@ int ukm_dev_srmerge(ukm_ctx *c, int op, const u64 *const *keys, const u32 *const
         UKM_HIP(hipGetLastError());
     }
     mark("cuts");
+    const TaxDev taxd = ukm_taxdev(c);
+    const bool clade_able = uni && tax && taxids && taxd.clade8 != nullptr && taxd.pair != nullptr && taxd.euler != nullptr && S >= 2;
+    if (clade_able) {  // (rides on the read-back below)
+        hipLaunchKernelGGL(sr_taxsample_kernel, dim3(16), dim3(256), 0, c->stream, d_tax, d_len, (u32)S, taxd, ctl + 4);
+        UKM_HIP(hipGetLastError());
+    }
+    u64 tax_pairs = 0, tax_same = 0;
     {
-        u64 fl2[2] = {0, 0};
-        UKM_TRY(ukm_read_u64(c, ctl + 1, fl2, 2));
+        u64 fl2[5] = {0, 0, 0, 0, 0};
+        UKM_TRY(ukm_read_u64(c, ctl + 1, fl2, 5));
+        tax_pairs = fl2[3];
+        tax_same = fl2[4];
         const u64 fl = fl2[0];
         // Counting placement or merge rounds?  A code with c copies among the streams shows up ~(c - 1) / (2 D) times as
         // an equal neighbour in the sorted sample (every D-th record).  Placement wins while tiles hold next to no equal
@@ -1375,7 +1524,15 @@ int ukm_dev_srmerge(ukm_ctx *c, int op, const u64 *const *keys, const u32 *const
                          (unsigned long long)ns, 1.0 + extra,
                          a.buckets == 1 ? "counting placement by value" : (a.buckets == 2 ? "counting placement by dense code numbers" : "merge rounds"));
     }
-    a.tax = ukm_taxdev(c);
+    a.tax = taxd;
+    {
+        // taxids of unrelated taxa: the emit folds clade codes (one byte per record) and fetches a number only for the runs
+        // that stay inside one clade; related taxa would send most runs through that second pass (UKM_SRMERGE_CLADE = 0 / 1)
+        const int k = ukm_env_int(c, "UKM_SRMERGE_CLADE", -1);
+        a.clade_emit = (clade_able && k != 0 && (k == 1 || (tax_pairs >= 256 && tax_same * 8 < tax_pairs))) ? 1u : 0u;
+        if (dbg) fprintf(stderr, "[srmerge] taxid sample: %llu of %llu pairs in one clade with different taxids: clade emit %u\n",
+                         (unsigned long long)tax_same, (unsigned long long)tax_pairs, a.clade_emit);
+    }
     (void)hipEventRecord(c->ev_k0, c->stream);
     if (tax) {
         if (uni) sr_launch<true, true, SR_NT, SR_VT, SR_LOGNT>(a, c->stream);
