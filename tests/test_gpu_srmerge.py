@@ -99,6 +99,43 @@ def test_merge_modes_and_union_many_streams(env, monkeypatch, nfiles, per, p, bu
     assert np.array_equal(gk2, ek) and np.array_equal(gt2, et)
 
 
+@pytest.mark.parametrize("clade", ["1", "0", None])
+@pytest.mark.parametrize("nfiles,per,p", [(300, 2500, 0.02), (900, 900, 0.002), (600, 400, 0.4)])
+def test_union_emit_with_clade_codes(env, monkeypatch, nfiles, per, p, clade):
+    """Round 5: the single pass's `union` / `common` emit folding one-byte CLADE codes (UKM_SRMERGE_CLADE=1), pre-order numbers
+    (0), or whichever its taxid sample picks (unset), against the oracle: taxids over the whole tree (unrelated: runs span
+    clades), from one small clade (related: every run goes through the second, exact pass), with zeros and ids beyond the
+    taxonomy (a run with one of them and another taxid folds to 0), and all records of a code carrying the same taxid."""
+    O, L, ctx, tax, T = env
+    monkeypatch.setenv("UKM_SRMERGE", "1")
+    if clade is None:
+        monkeypatch.delenv("UKM_SRMERGE_CLADE", raising=False)
+    else:
+        monkeypatch.setenv("UKM_SRMERGE_CLADE", clade)
+    U = _universe(int(per / p))
+    files = [U[_member(len(U), f, p, 17)] for f in range(nfiles)]
+    files = [f for f in files if len(f)]
+    shapes = {
+        "unrelated": [_taxids(f + np.uint64(i), T, i) for i, f in enumerate(files)],
+        "related": [(np.uint64(T - 40) + splitmix64(np.uint64(SEED + i) ^ f) % np.uint64(40)).astype(np.uint32) for i, f in enumerate(files)],
+        "by_code": [_taxids(f, T, 0) for f in files],            # (every record of a code carries the same taxid)
+    }
+    holes = [t.copy() for t in shapes["unrelated"]]
+    for i, t in enumerate(holes):
+        t[i % 5::11] = 0
+        t[(i + 3) % 7::13] = np.uint32(T + 100 + i % 3)
+    shapes["zeros_and_unknown"] = holes
+    for name, taxs in shapes.items():
+        gk, gt = ctx.union(files, taxs)
+        assert ctx.last_route() == ROUTE_SR
+        ok, ot = O.union(files, taxs, tax)
+        assert np.array_equal(gk, ok) and np.array_equal(gt, ot), (name, clade)
+        thr = max(2, int(len(files) * p * 0.8))
+        gk, gt = ctx.common(files, thr, taxs)
+        ok, ot = O.common(files, thr, taxs, tax)
+        assert np.array_equal(gk, ok) and np.array_equal(gt, ot), (name, clade, "common")
+
+
 @pytest.mark.parametrize("order", [None, "2"])
 @pytest.mark.parametrize("fill", ["150", "400"])
 def test_ranges_that_do_not_fit_a_tile_are_worked_off_by_value(env, monkeypatch, fill, order):
