@@ -336,6 +336,71 @@ def test_probe_tables_clade_mode_per_record_taxids(env, monkeypatch, clade):
         _eq(ctx.merge_k(files, taxs, mode=L.REPEATED), O.merge_k(files, ex, mode=O.REPEATED, tax=tax), ("merge -d", name, clade))
 
 
+def test_clade_folds_on_a_skewed_taxonomy(monkeypatch):
+    """The one-byte clade codes are a CUT of the forest that follows its shape (ukm_tax.hip: the clade node with the most ids
+    below it is replaced by all of its children while 255 fit), so clade nodes sit at different depths.  The folds that keep
+    `code << 24 | number` (probe tables in clade mode, the single pass's emit, the many-file inter) rely on the codes being
+    monotone in the pre-order numbers and on different codes implying the LCA of the clade nodes: all three against the oracle
+    on a taxonomy with one large kingdom, small ones, a node with 300 children and a chain, taxids over all of it."""
+    from oracle import oracle as O
+    from unikmer_amd import lib as L
+    child, parent = [], []
+    nxt = [1]
+
+    def new(par=None):
+        t = nxt[0]; nxt[0] += 1
+        child.append(t); parent.append(t if par is None else par)
+        return t
+
+    def subtree(par, fan, depth):
+        if depth:
+            for _ in range(fan):
+                subtree(new(par), fan, depth - 1)
+
+    r = new()
+    big = new(r)
+    for _ in range(12):
+        subtree(new(big), 7, 3)
+    subtree(new(r), 3, 2)
+    wide = new(r)
+    for _ in range(300):
+        new(wide)
+    x = new(r)
+    for _ in range(30):
+        x = new(x)
+    child, parent = np.array(child, dtype=np.uint32), np.array(parent, dtype=np.uint32)
+    T = int(child.max())
+    ctx = L.Context(0)
+    ctx.taxonomy_load(child, parent)
+    tax = O.Taxonomy(child, parent)
+    ids = np.arange(0, T + 3, dtype=np.uint32)      # (0 and two unknown ids among them)
+    U = _universe(40_000, 20)
+    nfiles = 40
+    files = [U[_member(len(U), f, 0.5, 240)] for f in range(nfiles)]
+    taxs = [_taxids(f, ids, i) for i, f in enumerate(files)]
+    monkeypatch.setenv("UKM_PUNION", "2")
+    monkeypatch.setenv("UKM_PUNION_CLADE", "1")
+    _eq(ctx.union(files, taxs), O.union(files, taxs, tax), "probe union, clade mode")
+    assert ctx.last_route() == 3
+    _eq(ctx.common(files, nfiles // 2, taxs), O.common(files, nfiles // 2, taxs, tax), "counting probes, clade mode")
+    monkeypatch.setenv("UKM_PUNION", "0")
+    monkeypatch.setenv("UKM_SRMERGE", "1")
+    monkeypatch.setenv("UKM_SRMERGE_CLADE", "1")
+    _eq(ctx.union(files, taxs), O.union(files, taxs, tax), "single pass, clade emit")
+    assert ctx.last_route() == 4
+    monkeypatch.delenv("UKM_SRMERGE", raising=False)
+    core = _member(len(U), 0, 0.3, 277)
+    cfiles = [U[core | _member(len(U), f + 1, 0.6, 278)] for f in range(nfiles)]
+    ctaxs = [_taxids(f, ids[1:T + 1], i) for i, f in enumerate(cfiles)]
+    exp = O.inter(cfiles, ctaxs, tax)
+    assert len(exp[0]) > 1000
+    _eq(ctx.inter(cfiles, ctaxs), exp, "many-file inter")
+    a, b = cfiles[0], cfiles[1]
+    _eq(ctx.setop2(L.OP_UNION, a, b, ctaxs[0], ctaxs[1]), O.union([a, b], [ctaxs[0], ctaxs[1]], tax), "2-way union")
+    _eq(ctx.setop2(L.OP_INTER, a, b, ctaxs[0], ctaxs[1]), O.inter([a, b], [ctaxs[0], ctaxs[1]], tax), "2-way inter")
+    ctx.close()
+
+
 def test_inter_diff_common_file_taxids_many_files(env, monkeypatch):
     """1000 files with one taxid each: `inter`, `diff`, `diff -t` and `common` of all files are the PLAIN operation and a
     fill (the probe fold, the chained fold and the synchronous fold in turn); results against the oracle's file-by-file

@@ -216,13 +216,14 @@ def test_lca_merged_and_forest(ctx, O):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("shape", ["wide_root", "forest_300", "forest_70000", "bushy"])
+@pytest.mark.parametrize("shape", ["wide_root", "forest_300", "forest_70000", "bushy", "skewed"])
 def test_lca_clade_code_forms(O, L, shape):
     """Round 5: pairs of unrelated taxids are settled by per-id clade codes (ukm_tax.hip: the ancestor at depth <= D as a
     one-byte or two-byte index, D chosen by what fits) and the rest by the root paths.  Every form against the oracle's
     ancestor walk: a root with 400 children (one byte holds the root alone: every pair takes the root paths), a forest of
-    300 trees (two-byte codes), one of 70,000 roots (no table at all), a bushy tree (one byte, depth 2); with ids that
-    are zero, unknown, absent inside the range and merged."""
+    300 trees (two-byte codes), one of 70,000 roots (no table at all), a bushy tree (one byte), a skewed one (the one-byte
+    cut splits the large kingdom deeper than the small ones); with ids that are zero, unknown, absent inside the range and
+    merged."""
     child, parent = [], []
     nxt = [1]
 
@@ -251,6 +252,21 @@ def test_lca_clade_code_forms(O, L, shape):
             r = new()
             if i % 100 == 0:
                 subtree(r, 2, 2)
+    elif shape == "skewed":
+        # one large kingdom beside small ones and a chain: the one-byte cut follows the shape (the large kingdom is split
+        # three levels down, the small ones stay whole, a node with 300 children is never split)
+        r = new()
+        big = new(r)
+        for _ in range(12):
+            subtree(new(big), 7, 3)
+        small = new(r)
+        subtree(small, 3, 2)
+        wide = new(r)
+        for _ in range(300):
+            new(wide)
+        x = new(r)
+        for _ in range(30):
+            x = new(x)
     else:
         subtree(new(), 6, 5)
     child, parent = np.array(child, dtype=np.uint32), np.array(parent, dtype=np.uint32)

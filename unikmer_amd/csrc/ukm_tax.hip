@@ -207,17 +207,82 @@ extern "C" int ukm_taxonomy_load(ukm_ctx *c, const uint32_t *child, const uint32
             acc += by_depth[d];
             if (acc <= 65535) Dq = d; else break;
         }
-        // one byte per id whenever some level's nodes fit it (8-ary tree: depth <= 2 = 73 nodes, 63 of 64 random pairs part
-        // above it; NCBI: the superkingdoms and what hangs directly below them)
-        acc = 0;
-        int D8 = -1;
-        for (int d = 0; d < 3; d++) {
-            acc += by_depth[d];
-            if (acc <= 255) D8 = d; else break;
-        }
-        // (the folds over pre-order numbers keep code << 24 | number in one word: ukm_pfold.hip)
-        if (D8 >= 0 && N.size() < (1u << 24)) { Dq = D8; one_byte = true; }
-        if (Dq >= 0) {
+        // ONE byte per id (the form the kernels prefer: a table a quarter the size of a 4-byte column stays in L2, and the
+        // folds keep code << 24 | number in one word): up to 255 clade nodes chosen as a CUT of the forest that follows its
+        // shape instead of one depth -- start from the roots and keep replacing the clade node with the most ids below it by
+        // ALL of its children while the total fits (NCBI: the cut runs through the phyla and classes of the large kingdoms
+        // and stays high in the small ones; the 8-ary tree: the 73 nodes of depth <= 2 and 22 of them split once more).  What
+        // the kernels rely on: the set is closed upwards and a clade node has either all of its children in it or none, so
+        // (1) two ids with different codes have the LCA of their clade nodes, (2) codes handed out in pre-order are monotone
+        // in the pre-order numbers.
+        u64 nroots = 0;
+        for (size_t i2 = 1; i2 < N.size(); i2++) nroots += P[N[i2]] == N[i2] ? 1u : 0u;
+        if (nroots >= 1 && nroots <= 255 && N.size() < (1u << 24)) {
+            one_byte = true;
+            std::vector<u32> below(size, 0), nchild(size, 0);
+            for (size_t i2 = N.size() - 1; i2 >= 1; i2--) {  // (reverse pre-order: children in front of their parents)
+                const u32 t = N[i2];
+                below[t] += 1;
+                if (P[t] != t) { below[P[t]] += below[t]; nchild[P[t]]++; }
+            }
+            std::vector<char> expanded(size, 0);
+            std::vector<std::pair<u32, u32>> heap;  // (ids below, node)
+            u64 total = nroots;
+            for (size_t i2 = 1; i2 < N.size(); i2++)
+                if (P[N[i2]] == N[i2] && nchild[N[i2]]) heap.emplace_back(below[N[i2]], N[i2]);
+            std::make_heap(heap.begin(), heap.end());
+            // (children of the node that was split join the heap; a node whose children do not fit any more is dropped)
+            std::vector<u32> first2(size + 1, 0), kids2;
+            for (u64 t = 1; t < size; t++)
+                if (P[t] != 0 && P[t] != t) first2[P[t] + 1]++;
+            for (u64 t = 0; t < size; t++) first2[t + 1] += first2[t];
+            kids2.resize(first2[size]);
+            {
+                std::vector<u32> fill(first2.begin(), first2.end() - 1);
+                for (u64 t = 1; t < size; t++)
+                    if (P[t] != 0 && P[t] != t) kids2[fill[P[t]]++] = (u32)t;
+            }
+            while (!heap.empty()) {
+                std::pop_heap(heap.begin(), heap.end());
+                const u32 node = heap.back().second;
+                heap.pop_back();
+                if (total + nchild[node] > 255) continue;
+                expanded[node] = 1;
+                total += nchild[node];
+                for (u32 q = first2[node]; q < first2[node + 1]; q++) {
+                    const u32 k = kids2[q];
+                    if (nchild[k]) { heap.emplace_back(below[k], k); std::push_heap(heap.begin(), heap.end()); }
+                }
+            }
+            Q.assign(size, 0);
+            std::vector<u32> fnode(1, 0);  // clade node of a code
+            for (size_t i2 = 1; i2 < N.size(); i2++) {
+                const u32 t = N[i2];
+                if (P[t] == t || expanded[P[t]]) {
+                    Q[t] = (unsigned short)fnode.size();
+                    fnode.push_back(t);
+                } else {
+                    Q[t] = Q[P[t]];
+                }
+            }
+            if (m)
+                for (u64 t = 1; t < size; t++)
+                    if (P[t] == 0 && M[t] != 0 && M[t] < size && P[M[t]] != 0) Q[t] = Q[M[t]];
+            Q8.assign(Q.begin(), Q.end());
+            // the LCA of every pair of clade nodes (at most 256 x 256), by the parent / depth climb
+            const u32 kp = (u32)fnode.size();
+            T4.assign(kp, make_uint4(0, 0, 0, 0));  // (the two-byte form's rows: not used beside the pair table)
+            PAIR.assign((size_t)kp * kp, 0u);
+            for (u32 i2 = 1; i2 < kp; i2++)
+                for (u32 j2 = 1; j2 < kp; j2++) {
+                    if (i2 == j2) continue;
+                    u32 a = fnode[i2], b = fnode[j2];
+                    while (depth[a] > depth[b]) a = P[a];
+                    while (depth[b] > depth[a]) b = P[b];
+                    while (a != b && P[a] != a && P[b] != b) { a = P[a]; b = P[b]; }
+                    PAIR[(size_t)i2 * kp + j2] = a == b ? a : 0u;  // (different trees: 0)
+                }
+        } else if (Dq >= 0) {
             Q.assign(size, 0);
             for (size_t i = 1; i < N.size(); i++) {
                 const u32 t = N[i];
@@ -235,23 +300,6 @@ extern "C" int ukm_taxonomy_load(ukm_ctx *c, const uint32_t *child, const uint32
             if (m)
                 for (u64 t = 1; t < size; t++)
                     if (P[t] == 0 && M[t] != 0 && M[t] < size && P[M[t]] != 0) Q[t] = Q[M[t]];
-            if (one_byte) {
-                Q8.assign(Q.begin(), Q.end());
-                // the LCA of every pair of clade nodes (at most 256 x 256): what lca_clade_pair works out from two rows
-                const u32 kp = (u32)T4.size();
-                PAIR.assign((size_t)kp * kp, 0u);
-                for (u32 i = 1; i < kp; i++)
-                    for (u32 j = 1; j < kp; j++) {
-                        if (i == j) continue;
-                        const uint4 ra = T4[i], rb = T4[j];
-                        u32 l;
-                        if (ra.x != rb.x) l = 0;
-                        else if (ra.y != rb.y || ra.y == 0) l = ra.x;
-                        else if (ra.z != rb.z || ra.z == 0) l = ra.y;
-                        else l = ra.z;
-                        PAIR[(size_t)i * kp + j] = l;
-                    }
-            }
         }
     }
     // ---- device tables: ALL of them are built beside the context's current ones and swapped in only when every
