@@ -785,6 +785,9 @@ __device__ __forceinline__ void tile_flush_src(const SetopArgs &p, int tid, u64 
 }
 
 constexpr int GATHER_NT = 256;
+#ifndef GATHER_U
+#define GATHER_U 8  /* records per thread and step (experiments: 2, 4, 8) */
+#endif
 template <int OP, int TILE>
 __global__ __launch_bounds__(GATHER_NT) void setop_taxid_gather_kernel(SetopArgs p) {
     setop_resolve_sizes(p, (u64)TILE);
@@ -807,62 +810,59 @@ __global__ __launch_bounds__(GATHER_NT) void setop_taxid_gather_kernel(SetopArgs
     // U records per thread and step: four rounds of loads -- the words, the taxids, the clade codes, the clade pairs -- each
     // round with all of its reads in flight, none inside a branch.  (Measured at 2 x 1e8, inter with one taxid per file as arrays:
     // 256 threads x 8 records 0.99 ms, x 4 1.06, x 2 1.13; a whole tile per 1024-thread workgroup in ONE step 1.22.)
-#ifndef GATHER_U
-#define GATHER_U 8
-#endif
     constexpr int U = GATHER_U;
     constexpr bool LCA = OP == UKM_OP_UNION || OP == UKM_OP_INTER;
     for (u64 i0 = base + threadIdx.x; i0 < end; i0 += (u64)GATHER_NT * U) {
-    u32 w[U], va[U], vb[U];
-#pragma unroll
-    for (int u = 0; u < U; u++) {
-        const u64 i = i0 + (u64)u * GATHER_NT;
-        w[u] = p.tout[i < end ? i : base];
-    }
-#pragma unroll
-    for (int u = 0; u < U; u++) {
-        const u32 ia = w[u] & 0x3FFFu, ib = (w[u] >> 14) & 0x3FFFu;
-        // Every lane reads BOTH inputs' taxid at its place, needed or not: the places of neighbouring records are neighbours, so
-        // the unneeded reads fall into lines the wave fetches anyway.  A place beyond its input (the B record behind the last
-        // one; an unsorted input, whose result the host discards) is clamped into it.
-        const u64 ga = a0 + ia, gb = b0 + ib;
-        va[u] = p.cta;
-        vb[u] = p.ctb;
-        if (p.ta) va[u] = *(p.na ? p.ta + (ga < p.na ? ga : p.na - 1) : safe32);  // (uniform branches)
-        if (p.tb) vb[u] = *(p.nb ? p.tb + (gb < p.nb ? gb : p.nb - 1) : safe32);
-    }
-    u32 quick[U];
-    u32 qmask = 0;
-    if (LCA && p.tax.pair != nullptr && p.tax.clade8 != nullptr) {  // (uniform)
-        u32 ca[U], cb[U];
+        u32 w[U], va[U], vb[U];
 #pragma unroll
         for (int u = 0; u < U; u++) {
-            const bool look = (w[u] & SRC_MATCH) != 0 && va[u] != vb[u] && va[u] != 0 && vb[u] != 0 && va[u] < p.tax.size && vb[u] < p.tax.size;
-            ca[u] = p.tax.clade8[look ? va[u] : 0u];
-            cb[u] = p.tax.clade8[look ? vb[u] : 0u];
+            const u64 i = i0 + (u64)u * GATHER_NT;
+            w[u] = p.tout[i < end ? i : base];
         }
 #pragma unroll
         for (int u = 0; u < U; u++) {
-            const bool q = ca[u] != cb[u] && ca[u] != 0 && cb[u] != 0;
-            qmask |= q ? (1u << u) : 0u;
-            quick[u] = p.tax.pair[q ? ca[u] * p.tax.kp + cb[u] : 0u];
+            const u32 ia = w[u] & 0x3FFFu, ib = (w[u] >> 14) & 0x3FFFu;
+            // Every lane reads BOTH inputs' taxid at its place, needed or not: the places of neighbouring records are neighbours, so
+            // the unneeded reads fall into lines the wave fetches anyway.  A place beyond its input (the B record behind the last
+            // one; an unsorted input, whose result the host discards) is clamped into it.
+            const u64 ga = a0 + ia, gb = b0 + ib;
+            va[u] = p.cta;
+            vb[u] = p.ctb;
+            if (p.ta) va[u] = *(p.na ? p.ta + (ga < p.na ? ga : p.na - 1) : safe32);  // (uniform branches)
+            if (p.tb) vb[u] = *(p.nb ? p.tb + (gb < p.nb ? gb : p.nb - 1) : safe32);
         }
-    }
+        u32 quick[U];
+        u32 qmask = 0;
+        if (LCA && p.tax.pair != nullptr && p.tax.clade8 != nullptr) {  // (uniform)
+            u32 ca[U], cb[U];
 #pragma unroll
-    for (int u = 0; u < U; u++) {
-        const u64 i = i0 + (u64)u * GATHER_NT;
-        if (i >= end) continue;
-        const bool from_b = (w[u] & SRC_FROM_B) != 0, m = (w[u] & SRC_MATCH) != 0;
-        u32 tv;
-        if (LCA && m) {
-            if (OP == UKM_OP_INTER && mix && (va[u] == 0 || vb[u] == 0)) tv = va[u] == 0 ? vb[u] : va[u];
-            else if ((qmask >> u) & 1u) tv = quick[u];
-            else tv = lca_dev(p.tax, va[u], vb[u]);  // relatives, zero / unknown / merged ids, no clade tables
-        } else {
-            tv = from_b ? vb[u] : va[u];
+            for (int u = 0; u < U; u++) {
+                const bool look = (w[u] & SRC_MATCH) != 0 && va[u] != vb[u] && va[u] != 0 && vb[u] != 0 && va[u] < p.tax.size && vb[u] < p.tax.size;
+                ca[u] = p.tax.clade8[look ? va[u] : 0u];
+                cb[u] = p.tax.clade8[look ? vb[u] : 0u];
+            }
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const bool q = ca[u] != cb[u] && ca[u] != 0 && cb[u] != 0;
+                qmask |= q ? (1u << u) : 0u;
+                quick[u] = p.tax.pair[q ? ca[u] * p.tax.kp + cb[u] : 0u];
+            }
         }
-        p.tout[i] = tv;
-    }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const u64 i = i0 + (u64)u * GATHER_NT;
+            if (i >= end) continue;
+            const bool from_b = (w[u] & SRC_FROM_B) != 0, m = (w[u] & SRC_MATCH) != 0;
+            u32 tv;
+            if (LCA && m) {
+                if (OP == UKM_OP_INTER && mix && (va[u] == 0 || vb[u] == 0)) tv = va[u] == 0 ? vb[u] : va[u];
+                else if ((qmask >> u) & 1u) tv = quick[u];
+                else tv = lca_dev(p.tax, va[u], vb[u]);  // relatives, zero / unknown / merged ids, no clade tables
+            } else {
+                tv = from_b ? vb[u] : va[u];
+            }
+            p.tout[i] = tv;
+        }
     }
 }
 
