@@ -46,6 +46,7 @@ extern "C" {
 #define UKM_ERR_NO_TAXONOMY (-6)  /* taxids present but ukm_taxonomy_load was not called */
 #define UKM_ERR_CAPACITY (-7)     /* out_cap too small; *n_out holds the required size */
 #define UKM_ERR_K (-8)            /* k out of range (1..32 codes, 1..64 hashes; count.go:81-87) */
+#define UKM_ERR_PEER (-9)         /* a collective call: another rank reported a failure; no rank went on (see that rank) */
 
 /* scan / merge modes: sort.go:484-572 (-u / -d / plain), util-sort.go:35-190 (chunk protocol) */
 #define UKM_PLAIN 0
@@ -123,7 +124,11 @@ int ukm_last_route(ukm_ctx *ctx);
  *        "place" 0 / 1 keep-everything merge by placement never / whenever possible;   "srmerge" 0 / 1 single-pass merge;
  *        "kway" 1 k-way merge also for tiny inputs;   "no_kway" 1 pairwise tree only;   "no_fold" / "no_pfold" 1 the
  *        one-launch range / probe folds of inter and diff off;   "pfold_tax" 0;   "common_probe" 0;   "sort_local" 0 all
- *        radix passes through HBM;   "win_strip" / "nthash_strip" 0 / 1;   "force_ticket" 1 dispatch-order independent kernels.
+ *        radix passes through HBM;   "win_strip" / "nthash_strip" 0 / 1;   "force_ticket" 1 dispatch-order independent kernels
+ *        (a context whose look-back watchdog has fired keeps them whatever this option says);   "sort_counting" 0 digit
+ *        passes inside every LDS bucket, "sort_fan" 0 no size-class fan-out;   "setop_src" 0 / 2 the two-launch source-word
+ *        route of a 2-way operation with per-record taxids never / also for union;   "punion_clade" / "srmerge_clade" 0 / 1
+ *        clade codes in the probe tables / the single pass's emit never / always.
  *      The environment is read ONCE, when a context is created: every UKM_* variable present then is the context's default
  *      for the matching key; no compute call calls getenv (a context created under UKM_ENV_LIVE=1 -- the test suite, which
  *      flips knobs between calls -- keeps looking).  An explicitly set option always wins.
@@ -290,7 +295,9 @@ int ukm_shard_exchange(ukm_ctx *ctx, const uint64_t *keys, const uint32_t *taxid
 /*      Capacity is decided COLLECTIVELY: the slice sizes travel together with every rank's out_cap, and either all
  *      ranks exchange or all ranks return UKM_ERR_CAPACITY (n_out = what this rank would have received), so a short
  *      buffer on one rank can never leave its peers blocked in RCCL.  ukm_shard_plan is that decision as a pure host
- *      function (all = [source rank][nranks slice sizes | out_cap of the source rank], the gathered matrix).
+ *      function (all = [source rank][nranks slice sizes | out_cap of the source rank], the gathered matrix; bit 63 of
+ *      the capacity word = UKM_SHARD_HAS_TAXIDS, "this rank passed taxids": ranks that disagree all return UKM_ERR_INVALID
+ *      before anything is posted -- a mixed call would leave taxid transfers unmatched).
  *      Hosts that move many files use the two-step form: ukm_shard_counts (send_counts[nfiles][nranks] ->
  *      recv_counts[nfiles][nranks], ONE all-gather and host round trip for all files; size the receive buffers
  *      from it), then ukm_shard_exchange_known per file, which has no gather and no host round trip in front of the
@@ -299,22 +306,32 @@ int ukm_shard_exchange(ukm_ctx *ctx, const uint64_t *keys, const uint32_t *taxid
  *      buffer is too small, or whose own entries of send_counts / recv_counts disagree, still takes part (what arrives is
  *      dropped in a scratch buffer of the largest slice) and returns UKM_ERR_CAPACITY / UKM_ERR_INVALID afterwards.  A
  *      device failure in front of the transfers (no memory for staging) leaves the peers blocked in RCCL: destroy the
- *      communicator, as after any lost rank. */
+ *      communicator, as after any lost rank.  Files WITH taxids: pass ukm_shard_counts_tax the flags has_taxids[nfiles]
+ *      (1: this rank will hand ukm_shard_exchange_known a taxid array for file f); the flags ride in the same gather and
+ *      ranks that disagree about a file all get UKM_ERR_INVALID here, before any transfer is posted
+ *      (ukm_shard_counts_plan: that decision as a pure host function over the gathered words, [rank][nfiles * nranks slice
+ *      sizes | nfiles flags, 2 = not declared]). */
+#define UKM_SHARD_HAS_TAXIDS (1ull << 63)
+#define UKM_SHARD_RANK_FAILED (~0ull) /* ukm_shard_splitters: a rank's record-count word when its preparation failed */
 int ukm_shard_plan(int nranks, int rank, const uint64_t *all, uint64_t *recv_counts, uint64_t *n_out);
 /*      Sampled splitters (k-mer codes are not uniform in their top bits -- README.md:177-180, sorted
  *      k-mers start AAAAAAAAA... -- so equal-width ranges leave the ranks unevenly loaded): ukm_shard_splitters is
  *      collective; every rank passes the sorted files it holds and gets the same nranks + 1 boundaries, cut so that the
  *      ranks receive about the same number of records (1024 regular samples per rank, one all-gather).  Use them in
  *      place of ukm_prefix_splitters; any non-decreasing boundaries give the same concatenated result.  A rank that
- *      fails locally (bad argument, no memory for staging) still takes part in the gather with no records and returns its
- *      error afterwards, so its peers are not left waiting; only a rank that cannot even allocate the 8 KB gather buffers
- *      hangs them (destroy the communicator, as after any lost rank).  Host arrays are sampled where they lie.
+ *      fails locally (bad argument, no memory for staging) still takes part in the gather -- with UKM_SHARD_RANK_FAILED as
+ *      its record count -- and returns its error afterwards; EVERY other rank then returns UKM_ERR_PEER, so all hosts
+ *      abort the exchange together (nobody goes on to ukm_shard_counts with a rank missing); only a rank that cannot even
+ *      allocate the 8 KB gather buffers hangs its peers (destroy the communicator, as after any lost rank).  Host arrays
+ *      are sampled where they lie.
  *      ukm_shard_splitters_plan is the decision as a pure host function over the gathered words
  *      ([rank][1 + per_rank] = record count, samples). */
 int ukm_shard_splitters(ukm_ctx *ctx, const uint64_t *const *keys, const uint64_t *lens, int nfiles, int key_bits,
                         uint64_t *splitters);
 int ukm_shard_splitters_plan(int nranks, int per_rank, const uint64_t *all, int key_bits, uint64_t *splitters);
 int ukm_shard_counts(ukm_ctx *ctx, const uint64_t *send_counts, int nfiles, uint64_t *recv_counts);
+int ukm_shard_counts_tax(ukm_ctx *ctx, const uint64_t *send_counts, int nfiles, const uint8_t *has_taxids, uint64_t *recv_counts);
+int ukm_shard_counts_plan(int nranks, int rank, int nfiles, const uint64_t *all, uint64_t *recv_counts);
 int ukm_shard_exchange_known(ukm_ctx *ctx, const uint64_t *keys, const uint32_t *taxids, const uint64_t *send_counts,
                              const uint64_t *recv_counts, uint64_t *out_keys, uint32_t *out_taxids, uint64_t out_cap,
                              uint64_t *n_out);

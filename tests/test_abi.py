@@ -73,6 +73,58 @@ def test_shard_plan_capacity_is_decided_collectively(lib):
             lib.Context.shard_plan(W, me, g)
 
 
+def test_shard_collectives_agree_on_taxids_and_on_a_failed_rank(lib):
+    """The decisions that only N > 1 can exercise, as the pure host functions every rank evaluates over the SAME gathered
+    words (round-5 review / advice):
+      * ukm_shard_plan: bit 63 of a rank's capacity word says "I passed taxids"; ranks that disagree ALL return
+        UKM_ERR_INVALID before anything is posted (a mixed call would leave taxid transfers unmatched inside the group);
+      * ukm_shard_counts_plan (ukm_shard_counts_tax's gather): the same per file for the two-step exchange;
+      * ukm_shard_splitters_plan: a rank whose preparation failed sends UKM_SHARD_RANK_FAILED as its record count and EVERY
+        rank returns UKM_ERR_PEER -- no host goes on to the next collective with a rank missing."""
+    L = lib.load()
+    HAS = 1 << 63
+    W = 2
+    g = np.array([[3, 4, 10 | HAS], [5, 6, 20 | HAS]], dtype=np.uint64)
+    for me, want in ((0, [3, 5]), (1, [4, 6])):
+        rc, n = lib.Context.shard_plan(W, me, g)                 # all with taxids: the bit is not part of the capacity
+        assert rc.tolist() == want and n == sum(want)
+    mixed = g.copy()
+    mixed[1, W] = 20
+    rcv = np.zeros(W, dtype=np.uint64)
+    n = C.c_uint64()
+    for me in range(W):
+        assert L.ukm_shard_plan(W, me, mixed.ctypes.data, rcv.ctypes.data, C.byref(n)) == lib.ERR_INVALID
+        assert b"taxids" in L.ukm_last_error()
+    short = g.copy()
+    short[0, W] = 7 | HAS                                        # 8 records arrive at rank 0
+    for me in range(W):
+        assert L.ukm_shard_plan(W, me, short.ctypes.data, rcv.ctypes.data, C.byref(n)) == lib.ERR_CAPACITY
+    # two-step exchange: [rank][nfiles * W sizes | nfiles flags]
+    nfiles = 3
+    rows = np.zeros((W, nfiles * (W + 1)), dtype=np.uint64)
+    rows[0, :nfiles * W] = [1, 2, 3, 4, 5, 6]
+    rows[1, :nfiles * W] = [7, 8, 9, 10, 11, 12]
+    rows[0, nfiles * W:] = [1, 0, 2]                             # file 2: rank 0 did not say
+    rows[1, nfiles * W:] = [1, 0, 1]
+    assert lib.Context.shard_counts_plan(W, 0, rows).tolist() == [[1, 7], [3, 9], [5, 11]]
+    assert lib.Context.shard_counts_plan(W, 1, rows).tolist() == [[2, 8], [4, 10], [6, 12]]
+    rows[1, nfiles * W + 1] = 1                                  # file 1: without taxids on rank 0, with on rank 1
+    for me in range(W):
+        with pytest.raises(lib.UkmError) as e:
+            lib.Context.shard_counts_plan(W, me, rows)
+        assert e.value.code == lib.ERR_INVALID and "file 1" in str(e.value)
+    # splitters: rank 2 of 3 failed
+    M = 8
+    allw = np.zeros((3, M + 1), dtype=np.uint64)
+    allw[0, 0], allw[0, 1:] = 80, np.arange(10, 90, 10)
+    allw[1, 0], allw[1, 1:] = 80, np.arange(15, 95, 10)
+    assert len(lib.Context.shard_splitters_plan(3, allw, 62)) == 4
+    allw[2, 0] = np.uint64(0xFFFFFFFFFFFFFFFF)
+    with pytest.raises(lib.UkmError) as e:
+        lib.Context.shard_splitters_plan(3, allw, 62)
+    assert e.value.code == lib.ERR_PEER and "rank 2" in str(e.value)
+
+
 def test_no_gpu_fails_loudly(lib):
     L = lib.load()
     n = C.c_int(-1)

@@ -159,6 +159,13 @@ extern "C" int ukm_shard_splitters_plan(int nranks, int per_rank, const uint64_t
     const u64 top = key_bits < 64 ? ((u64)1 << key_bits) : ~(u64)0;
     std::vector<std::pair<u64, u64>> sw;  // (value, weight)
     unsigned __int128 total = 0;
+    // A record count of all ones is a rank's ERROR WORD: it could not prepare its samples (bad argument, no memory).  Every
+    // rank sees the same words, so every rank returns here -- the failed rank with its own error, its peers with this one --
+    // and no host goes on to ukm_shard_counts / ukm_shard_exchange_known with a rank missing (round-5 advice: a failed rank
+    // that merely contributed nothing moved the hang to the next collective and cut the ranges without its samples).
+    for (int g = 0; g < W; g++)
+        if (all[(size_t)g * ((size_t)per_rank + 1)] == UKM_SHARD_RANK_FAILED)
+            UKM_FAIL(UKM_ERR_PEER, "ukm_shard_splitters: rank %d could not prepare its samples (no rank has splitters; see that rank's error)", g);
     for (int g = 0; g < W; g++) {
         const u64 *row = all + (size_t)g * ((size_t)per_rank + 1);
         const u64 n = row[0];
@@ -211,12 +218,18 @@ __global__ void shard_sample_kernel(const u64 *const *keys, const u64 *base, int
 extern "C" int ukm_shard_plan(int nranks, int me, const uint64_t *all, uint64_t *recv_counts, uint64_t *n_out) {
     if (nranks < 1 || me < 0 || me >= nranks || !all || !recv_counts || !n_out) UKM_FAIL(UKM_ERR_INVALID, "ukm_shard_plan: bad argument");
     const int W = nranks;
+    // bit 63 of a rank's capacity word = "this rank passed taxids".  A mixed call would post taxid sends that no peer
+    // receives (the group never completes): every rank sees the same bits and returns before anything is posted.
+    for (int g = 1; g < W; g++)
+        if ((all[(size_t)g * (W + 1) + W] ^ all[W]) & UKM_SHARD_HAS_TAXIDS)
+            UKM_FAIL(UKM_ERR_INVALID, "ukm_shard_exchange: rank %d %s taxids, rank 0 %s (no rank exchanges)", g,
+                     (all[(size_t)g * (W + 1) + W] & UKM_SHARD_HAS_TAXIDS) ? "passes" : "passes no", (all[W] & UKM_SHARD_HAS_TAXIDS) ? "does" : "does not");
     int short_rank = -1;
     u64 short_need = 0, short_cap = 0;
     for (int d = 0; d < W; d++) {
         u64 total = 0;
         for (int g = 0; g < W; g++) total += all[(size_t)g * (W + 1) + d];
-        const u64 cap = all[(size_t)d * (W + 1) + W];
+        const u64 cap = all[(size_t)d * (W + 1) + W] & ~UKM_SHARD_HAS_TAXIDS;
         if (d == me) {
             for (int g = 0; g < W; g++) recv_counts[g] = all[(size_t)g * (W + 1) + me];  // what rank g sends to me
             *n_out = total;
@@ -290,7 +303,34 @@ int post_exchange(ukm_ctx *c, Rccl *R, const u64 *k, const u32 *t, const u64 *se
 // Slice sizes of `nfiles` streams at once: send_counts[nfiles][nranks] (host) -> recv_counts[nfiles][nranks] (host),
 // recv_counts[f][g] = records of file f that rank g sends to this rank.  ONE all-gather and ONE host synchronisation
 // for all files; the data then moves with ukm_shard_exchange_known, which needs no gather of its own.
-extern "C" int ukm_shard_counts(ukm_ctx *c, const uint64_t *send_counts, int nfiles, uint64_t *recv_counts) {
+// The gathered words of one rank: [nfiles][nranks] slice sizes, then nfiles words "file f comes with taxids" (0 / 1; 2 = the
+// rank did not say: ukm_shard_counts).  ukm_shard_counts_plan is the decision over them as a pure host function: the
+// receive sizes of rank `me`, or UKM_ERR_INVALID on EVERY rank when two ranks that declared it disagree about a file's
+// taxids -- ukm_shard_exchange_known has no gather of its own, and a mixed call there posts taxid transfers that no peer
+// matches (the group never completes; round-5 review).
+extern "C" int ukm_shard_counts_plan(int nranks, int me, int nfiles, const uint64_t *all, uint64_t *recv_counts) {
+    if (nranks < 1 || me < 0 || me >= nranks || nfiles < 1 || !all || !recv_counts) UKM_FAIL(UKM_ERR_INVALID, "ukm_shard_counts_plan: bad argument");
+    const int W = nranks;
+    const size_t per = (size_t)nfiles * W + (size_t)nfiles;
+    for (int f = 0; f < nfiles; f++) {
+        int said = -1;
+        u64 flag = 2;
+        for (int g = 0; g < W; g++) {
+            const u64 v = all[(size_t)g * per + (size_t)nfiles * W + f];
+            if (v > 1) continue;
+            if (said >= 0 && v != flag)
+                UKM_FAIL(UKM_ERR_INVALID, "ukm_shard_counts: file %d comes %s taxids on rank %d and %s on rank %d (no rank may exchange it)", f,
+                         flag ? "with" : "without", said, v ? "with" : "without", g);
+            said = g;
+            flag = v;
+        }
+    }
+    for (int f = 0; f < nfiles; f++)
+        for (int g = 0; g < W; g++) recv_counts[(size_t)f * W + g] = all[(size_t)g * per + (size_t)f * W + me];
+    return UKM_OK;
+}
+
+extern "C" int ukm_shard_counts_tax(ukm_ctx *c, const uint64_t *send_counts, int nfiles, const uint8_t *has_taxids, uint64_t *recv_counts) {
     if (!c || !send_counts || !recv_counts || nfiles < 1) UKM_FAIL(UKM_ERR_INVALID, "ukm_shard_counts: bad argument");
     if (!c->comm) UKM_FAIL(UKM_ERR_INVALID, "ukm_shard_counts: ukm_comm_init has not been called on this context");
     Rccl *R = rccl();
@@ -299,13 +339,17 @@ extern "C" int ukm_shard_counts(ukm_ctx *c, const uint64_t *send_counts, int nfi
     CallScope s;
     UKM_TRY(ukm_begin(c, &s));
     int rc = [&]() -> int {
-        std::vector<u64> all;
-        UKM_TRY(gather_u64(c, R, send_counts, (size_t)nfiles * W, all));
-        for (int f = 0; f < nfiles; f++)
-            for (int g = 0; g < W; g++) recv_counts[(size_t)f * W + g] = all[((size_t)g * nfiles + f) * W + me];
-        return UKM_OK;
+        std::vector<u64> mine((size_t)nfiles * W + (size_t)nfiles), all;
+        std::copy(send_counts, send_counts + (size_t)nfiles * W, mine.begin());
+        for (int f = 0; f < nfiles; f++) mine[(size_t)nfiles * W + f] = has_taxids ? (has_taxids[f] ? 1u : 0u) : 2u;
+        UKM_TRY(gather_u64(c, R, mine.data(), mine.size(), all));
+        return ukm_shard_counts_plan(W, me, nfiles, all.data(), recv_counts);
     }();
     return ukm_finish(&s, rc);
+}
+
+extern "C" int ukm_shard_counts(ukm_ctx *c, const uint64_t *send_counts, int nfiles, uint64_t *recv_counts) {
+    return ukm_shard_counts_tax(c, send_counts, nfiles, nullptr, recv_counts);
 }
 
 // The exchange with slice sizes that are already known on both sides (ukm_shard_counts): no all-gather and no host
@@ -383,7 +427,7 @@ extern "C" int ukm_shard_exchange(ukm_ctx *c, const uint64_t *keys, const uint32
         //    the collective decision of ukm_shard_plan (all ranks exchange, or all ranks return UKM_ERR_CAPACITY)
         std::vector<u64> mine((size_t)W + 1), all;
         for (int g = 0; g < W; g++) mine[g] = send_counts[g];
-        mine[W] = out_cap;
+        mine[W] = (out_cap & ~UKM_SHARD_HAS_TAXIDS) | (taxids ? UKM_SHARD_HAS_TAXIDS : 0ull);
         UKM_TRY(gather_u64(c, R, mine.data(), (size_t)W + 1, all));
         UKM_TRY(ukm_shard_plan(W, me, all.data(), recv_counts, n_out));
         const u64 total = *n_out;
@@ -406,8 +450,8 @@ extern "C" int ukm_shard_exchange(ukm_ctx *c, const uint64_t *keys, const uint32
 
 // Collective: splitters[nranks + 1] (host) for this rank's sorted files `keys` (host or device pointers).  One small
 // kernel (device files; host files are sampled where they lie), one all-gather of 1025 words per rank; every rank that
-// succeeds returns the same array.  A rank that fails locally still takes part in the gather (with no records) and returns
-// its error afterwards.
+// succeeds returns the same array.  A rank that fails locally still takes part in the gather -- with an error word in
+// place of its record count -- and returns its error afterwards; every other rank then returns UKM_ERR_PEER.
 extern "C" int ukm_shard_splitters(ukm_ctx *c, const uint64_t *const *keys, const uint64_t *lens, int nfiles, int key_bits,
                                    uint64_t *splitters) {
     if (!c || !splitters || nfiles < 0 || (nfiles && (!keys || !lens)) || key_bits < 1 || key_bits > 64)
@@ -422,8 +466,8 @@ extern "C" int ukm_shard_splitters(ukm_ctx *c, const uint64_t *const *keys, cons
         // The gather buffers first: without them this rank cannot take part at all (the one failure that leaves the
         // peers waiting in RCCL -- destroy the communicator, as after any lost rank).  Everything that can fail LOCALLY
         // after this point (staging, the sample kernel) happens in `prep`; a rank whose prep failed still joins the
-        // all-gather, with a record count of 0, and reports its error afterwards: its peers get splitters from the ranks
-        // that did contribute and nobody hangs (round-4 advice).
+        // all-gather, with the error word UKM_SHARD_RANK_FAILED as its record count, and reports its error afterwards: its
+        // peers all return UKM_ERR_PEER, so every host aborts the exchange together and nobody hangs.
         u64 *d_mine = nullptr, *d_all = nullptr;
         UKM_TRY(ws_alloc_t(c, (size_t)M + 1, &d_mine));
         UKM_TRY(ws_alloc_t(c, ((size_t)M + 1) * W, &d_all));
@@ -488,7 +532,8 @@ extern "C" int ukm_shard_splitters(ukm_ctx *c, const uint64_t *const *keys, cons
         std::string perr;
         if (prc != UKM_OK) {
             perr = ukm_last_error();
-            std::fill(mine.begin(), mine.end(), 0);  // contributes nothing: the plan ignores ranks without records
+            std::fill(mine.begin(), mine.end(), 0);
+            mine[0] = UKM_SHARD_RANK_FAILED;  // the error word: every rank's plan returns UKM_ERR_PEER
             mine_on_host = true;
         }
         if (mine_on_host) {
@@ -499,7 +544,7 @@ extern "C" int ukm_shard_splitters(ukm_ctx *c, const uint64_t *const *keys, cons
         std::vector<u64> all(((size_t)M + 1) * W);
         UKM_HIP(hipMemcpyAsync(all.data(), d_all, all.size() * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
         UKM_HIP(hipStreamSynchronize(c->stream));
-        if (prc != UKM_OK) {
+        if (prc != UKM_OK) {  // (its peers return UKM_ERR_PEER from the plan below)
             ukm_set_error("%s", perr.c_str());
             return prc;
         }

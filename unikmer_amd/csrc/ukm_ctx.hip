@@ -37,7 +37,7 @@ extern char **environ;
 // the option keys a host may set (ukm_ctx_set_option): key "punion" is knob UKM_PUNION, and so on
 static const char *const UKM_OPTION_KEYS[] = {
     "punion", "punion_tax", "punion_ranked", "place", "srmerge", "kway", "no_kway", "no_fold", "no_pfold", "pfold_tax", "common_probe",
-    "sort_local", "win_strip", "nthash_strip", "force_ticket",
+    "sort_local", "sort_counting", "sort_fan", "win_strip", "nthash_strip", "force_ticket", "setop_src", "punion_clade", "srmerge_clade",
     // tuning / diagnostics (developer)
     "punion_k0", "punion_claim", "punion_debug", "kway_k", "kway_r", "kway_top2", "kway_debug", "srmerge_fill", "srmerge_spr", "srmerge_buckets",
     "srmerge_debug", "fold_debug", "sort_debug", "strip_l", "win_strip_l", "setop_fused_part",
@@ -66,7 +66,8 @@ extern "C" int ukm_ctx_set_option(ukm_ctx *c, const char *key, long long value) 
     for (const char *k : UKM_OPTION_KEYS)
         if (strcmp(k, key) == 0) {
             c->opts[knob_name(key)] = std::to_string(value);
-            if (strcmp(key, "force_ticket") == 0) c->setop_force_ticket = value != 0;
+            // (the watchdog's latch is a fact about the device, not an option: clearing the option never clears it)
+            if (strcmp(key, "force_ticket") == 0) c->setop_force_ticket = c->ticket_latched || value != 0;
             return UKM_OK;
         }
     UKM_FAIL(UKM_ERR_INVALID, "ukm_ctx_set_option: unknown option '%s'", key);
@@ -75,6 +76,7 @@ extern "C" int ukm_ctx_set_option(ukm_ctx *c, const char *key, long long value) 
 extern "C" int ukm_ctx_unset_option(ukm_ctx *c, const char *key) {
     if (!c || !key) UKM_FAIL(UKM_ERR_INVALID, "ukm_ctx_unset_option: NULL argument");
     c->opts.erase(knob_name(key));
+    if (strcmp(key, "force_ticket") == 0) c->setop_force_ticket = c->ticket_latched || ukm_env_is(c, "UKM_FORCE_TICKET", '1');
     return UKM_OK;
 }
 
@@ -411,6 +413,7 @@ void ukm_switch_to_tickets(ukm_ctx *c, const char *where) {
     if (!c->setop_force_ticket)
         fprintf(stderr, "[unikmer_hip] look-back watchdog fired in %s: workgroups were not dispatched in order on device %d; "
                         "switching this context to ticketed tile ids\n", where, c->device);
+    c->ticket_latched = true;
     c->setop_force_ticket = true;
 }
 

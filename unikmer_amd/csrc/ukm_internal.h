@@ -126,6 +126,7 @@ struct ukm_ctx {
     u32 *tax_pair = nullptr;
     u32 tax_kp = 0;
     uint4 *tax_top = nullptr;
+    u32 tax_top_n = 0;  // entries of tax_top
     u32 tax_nchunks = 0;
     u32 tax_size = 0;
     u32 tax_max = 0;
@@ -145,7 +146,8 @@ struct ukm_ctx {
     u64 stat_punion_attempts = 0;  // base sets the last probe union / counting probes built (2: the retry with 4 x the files ran)
 
     // set once the blockIdx-ordered set-op kernel hit its watchdog on this device
-    bool setop_force_ticket = false;
+    bool setop_force_ticket = false;  // = ticket_latched || option "force_ticket"
+    bool ticket_latched = false;      // the look-back watchdog fired on this device (ukm_switch_to_tickets): stays set
     // set once a sort found its keys crowded into few top-16-bit buckets (ukm_sort.hip): later sorts look at a sample first
     bool sort_skew_seen = false;
     // buckets of the last bucket-route sort that fell back from the counting step to the digit passes (device word, bumped by

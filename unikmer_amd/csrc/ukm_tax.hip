@@ -87,6 +87,14 @@ int to_host(ukm_ctx *c, const T *p, u64 n, std::vector<T> &v) {
 
 }  // namespace
 
+// device bytes of the taxonomy a context holds now (credited when it is about to be replaced)
+static u64 tax_bytes_held(const ukm_ctx *c) {
+    if (!c->tax_parent) return 0;
+    return (u64)c->tax_size * (sizeof(u32) + sizeof(u8) + (c->tax_merged ? sizeof(u32) : 0) + 2 * sizeof(u32) + (c->tax_clade ? 2 : (c->tax_clade8 ? 1 : 0))) +
+           (u64)c->tax_nchunks * c->tax_size * sizeof(uint4) + (c->tax_pair ? (u64)c->tax_kp * c->tax_kp * sizeof(u32) : 0) +
+           (c->tax_top ? (u64)c->tax_top_n * sizeof(uint4) : 0);
+}
+
 extern "C" int ukm_taxonomy_load(ukm_ctx *c, const uint32_t *child, const uint32_t *parent, uint64_t n,
                                  const uint32_t *merged_old, const uint32_t *merged_new, uint64_t m) {
     if (!c || !child || !parent || n == 0) UKM_FAIL(UKM_ERR_INVALID, "ukm_taxonomy_load: bad argument");
@@ -108,17 +116,20 @@ extern "C" int ukm_taxonomy_load(ukm_ctx *c, const uint32_t *child, const uint32
     {
         // the tables are dense in the taxid (at least 27 bytes per id on the device, about as much on the host while they
         // are built): refuse sparse huge ids here, before any of it is allocated
+        // (the tables being replaced are credited here as they are below: a reload on a nearly full device must not be
+        //  refused by this early guard when the later one, which frees the old tables first, would let it fit)
         size_t free_b = 0, total_b = 0;
         UKM_HIP(hipMemGetInfo(&free_b, &total_b));
-        if (size * 27 > (u64)free_b / 10 * 9) {  // (the context's cached workspace counts as free: give it back and look again)
+        const u64 old_b = tax_bytes_held(c);
+        if (size * 27 > ((u64)free_b + old_b) / 10 * 9) {  // (the context's cached workspace counts as free: give it back and look again)
             (void)ukm_ctx_trim(c);
             UKM_HIP(hipMemGetInfo(&free_b, &total_b));
         }
-        if (size * 27 > (u64)free_b / 10 * 9)
+        if (size * 27 > ((u64)free_b + old_b) / 10 * 9)
             UKM_FAIL(UKM_ERR_NOMEM,
-                     "ukm_taxonomy_load: dense tables for the largest taxid %u need at least %.2f GB, the device has %.2f GB free; "
-                     "renumber sparse taxids densely",
-                     mx, size * 27 / 1e9, free_b / 1e9);
+                     "ukm_taxonomy_load: dense tables for the largest taxid %u need at least %.2f GB, the device has %.2f GB free "
+                     "(the taxonomy being replaced counted); renumber sparse taxids densely",
+                     mx, size * 27 / 1e9, ((u64)free_b + old_b) / 1e9);
     }
     std::vector<u32> P(size, 0), M;
     std::vector<u8> D(size, 0);
@@ -321,10 +332,7 @@ extern "C" int ukm_taxonomy_load(ukm_ctx *c, const uint32_t *child, const uint32
         // is being replaced is credited (it is freed as soon as the new tables stand)
         size_t free_b = 0, total_b = 0;
         UKM_HIP(hipMemGetInfo(&free_b, &total_b));
-        u64 old_bytes = 0;
-        if (c->tax_parent)
-            old_bytes = (u64)c->tax_size * (sizeof(u32) + sizeof(u8) + (c->tax_merged ? sizeof(u32) : 0) + 2 * sizeof(u32) + (c->tax_clade ? 2 : (c->tax_clade8 ? 1 : 0))) +
-                        (u64)c->tax_nchunks * c->tax_size * sizeof(uint4);
+        const u64 old_bytes = tax_bytes_held(c);
         if (need > (u64)free_b / 10 * 9) {
             (void)ukm_ctx_trim(c);
             UKM_HIP(hipMemGetInfo(&free_b, &total_b));
@@ -340,7 +348,7 @@ extern "C" int ukm_taxonomy_load(ukm_ctx *c, const uint32_t *child, const uint32
             if (c->tax_top) (void)hipFree(c->tax_top);
             if (c->tax_clade8) (void)hipFree(c->tax_clade8);
             if (c->tax_pair) (void)hipFree(c->tax_pair);
-            c->tax_clade = nullptr; c->tax_top = nullptr; c->tax_clade8 = nullptr; c->tax_pair = nullptr; c->tax_kp = 0;
+            c->tax_clade = nullptr; c->tax_top = nullptr; c->tax_clade8 = nullptr; c->tax_pair = nullptr; c->tax_kp = 0; c->tax_top_n = 0;
             c->tax_parent = nullptr; c->tax_depth = nullptr; c->tax_merged = nullptr; c->tax_anc = nullptr;
             c->tax_euler = nullptr; c->tax_node_at = nullptr; c->tax_size = 0; c->tax_nchunks = 0; c->tax_max = 0;
             UKM_HIP(hipMemGetInfo(&free_b, &total_b));
@@ -424,6 +432,7 @@ extern "C" int ukm_taxonomy_load(ukm_ctx *c, const uint32_t *child, const uint32
     c->tax_clade = n_clade;
     c->tax_clade8 = n_clade8;
     c->tax_top = n_top;
+    c->tax_top_n = n_top ? (u32)T4.size() : 0u;
     c->tax_parent = n_parent;
     c->tax_depth = n_depth;
     c->tax_merged = n_merged;

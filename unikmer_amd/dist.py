@@ -229,12 +229,27 @@ def redistribute_pipelined(ctx, files_keys, key_bits, files_taxids=None, group=N
     for k in files_keys:
         c = [int(x) for x in ctx.partition_points(k, fine)] + [k.numel()]
         cuts.append(c)
-    # counts[i][g][q]: records of my file i for sub-range q of rank g
-    send = torch.tensor([[cuts[i][g * Q + q + 1] - cuts[i][g * Q + q] for i in range(nfiles) for q in range(Q)] for g in range(world)],
-                        dtype=torch.int64, device=dev)                       # [dest rank][file * Q + q]
+    # counts[i][g][q]: records of my file i for sub-range q of rank g.  Beside every count travel the slice's FIRST and LAST
+    # code (one device gather per file, no host round trip): the receiver decides "the pieces arrive in value order" for
+    # every unit from this one all-to-all and its one read-back, instead of a 2 * world element read-back + stream sync per
+    # (file, sub-range) unit on the critical path of the pipeline (round-5 advice).
+    U3 = nfiles * Q
+    cnt = torch.tensor([[cuts[i][g * Q + q + 1] - cuts[i][g * Q + q] for i in range(nfiles) for q in range(Q)] for g in range(world)],
+                       dtype=torch.int64, device=dev)                        # [dest rank][file * Q + q]
+    firsts = torch.zeros((world, U3), dtype=torch.int64, device=dev)
+    lasts = torch.zeros((world, U3), dtype=torch.int64, device=dev)
+    for i, k in enumerate(files_keys):
+        if k.numel() == 0:
+            continue
+        c = cuts[i]
+        lo = torch.tensor([[min(c[g * Q + q], k.numel() - 1) for q in range(Q)] for g in range(world)], dtype=torch.int64, device=dev)
+        hi = torch.tensor([[max(min(c[g * Q + q + 1], k.numel()) - 1, 0) for q in range(Q)] for g in range(world)], dtype=torch.int64, device=dev)
+        firsts[:, i * Q:(i + 1) * Q] = k[lo.flatten()].view(world, Q)
+        lasts[:, i * Q:(i + 1) * Q] = k[hi.flatten()].view(world, Q)
+    send = torch.cat([cnt, firsts, lasts], dim=1).contiguous()               # [dest rank][counts | firsts | lasts]
     recv = torch.empty_like(send)
     _all_to_all(recv, send, group=group)
-    rc = recv.cpu().tolist()                                                 # [source rank][file * Q + q]
+    rc = recv.cpu().tolist()                                                 # [source rank][...]: the ONE read-back
     global_sizes = None
     if with_sizes:
         gs = torch.tensor([k.numel() for k in files_keys], dtype=torch.int64, device=dev if dist.get_backend(group) != "gloo" else "cpu")
@@ -245,11 +260,24 @@ def redistribute_pipelined(ctx, files_keys, key_bits, files_taxids=None, group=N
     def counts_of(i, q):
         return [int(rc[src][i * Q + q]) for src in range(world)]
 
+    def in_value_order(i, q):
+        """pieces_in_value_order() from the exchanged ends: last code of every non-empty piece <= first code of the next one"""
+        prev = None
+        for src in range(world):
+            if not rc[src][i * Q + q]:
+                continue
+            first = rc[src][U3 + i * Q + q] & 0xFFFFFFFFFFFFFFFF             # (uint64 bit patterns in int64 tensors)
+            if prev is not None and prev > first:
+                return False
+            prev = rc[src][2 * U3 + i * Q + q] & 0xFFFFFFFFFFFFFFFF
+        return True
+
     def issue(i, q):
         k = files_keys[i]
         c = cuts[i]
         ins = [c[g * Q + q + 1] - c[g * Q + q] for g in range(world)]
-        sk = torch.cat([k[c[g * Q + q]:c[g * Q + q + 1]] for g in range(world)])   # the sub-range's slices, destination by destination
+        # the sub-range's slices, destination by destination (one sub-range per destination: they already lie back to back)
+        sk = k[c[0]:c[world]] if Q == 1 else torch.cat([k[c[g * Q + q]:c[g * Q + q + 1]] for g in range(world)])
         rcv = counts_of(i, q)
         out = torch.empty(sum(rcv), dtype=k.dtype, device=k.device)
         works = [_all_to_all(out, sk, rcv, ins, group, async_op=True)]
@@ -257,7 +285,7 @@ def redistribute_pipelined(ctx, files_keys, key_bits, files_taxids=None, group=N
         out_t = None
         if files_taxids is not None:
             t = files_taxids[i]
-            st = torch.cat([t[c[g * Q + q]:c[g * Q + q + 1]] for g in range(world)])
+            st = t[c[0]:c[world]] if Q == 1 else torch.cat([t[c[g * Q + q]:c[g * Q + q + 1]] for g in range(world)])
             out_t = torch.empty(sum(rcv), dtype=t.dtype, device=t.device)
             works.append(_all_to_all(out_t, st, rcv, ins, group, async_op=True))
             keep.append(st)
@@ -277,7 +305,7 @@ def redistribute_pipelined(ctx, files_keys, key_bits, files_taxids=None, group=N
         dst = local[i][offs[i]:offs[i] + n]
         dst_t = local_t[i][offs[i]:offs[i] + n] if local_t is not None else None
         if n:
-            if pieces_in_value_order(rk, counts):
+            if in_value_order(i, q):
                 dst.copy_(rk)
                 if dst_t is not None:
                     dst_t.copy_(rt)
@@ -360,7 +388,8 @@ def redistribute_cabi(ctx, files_keys, key_bits, files_taxids=None, splitters=No
         return [], ([] if files_taxids is not None else None)
     import numpy as np
     send = np.array([cuts_to_counts(ctx.partition_points(k, spl), k.numel()) for k in files_keys], dtype=np.uint64)
-    recv = ctx.shard_counts(send)                                  # [file][source rank]: one gather, one host round trip
+    # [file][source rank]: one gather, one host round trip; the "comes with taxids" flags ride along (ranks that disagree raise)
+    recv = ctx.shard_counts(send, [files_taxids is not None and files_taxids[i] is not None for i in range(nfiles)])
     local, local_t = [], ([] if files_taxids is not None else None)
     for i, k in enumerate(files_keys):
         t = files_taxids[i] if files_taxids is not None else None

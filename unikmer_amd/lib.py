@@ -15,7 +15,7 @@ SO_PATH = os.environ.get("UKM_LIB_PATH") or os.path.join(_HERE, "libunikmer_hip.
 
 OK = 0
 ERR_INVALID, ERR_HIP, ERR_NOMEM, ERR_ILLEGAL_BASE = -1, -2, -3, -4
-ERR_UNSORTED, ERR_NO_TAXONOMY, ERR_CAPACITY, ERR_K = -5, -6, -7, -8
+ERR_UNSORTED, ERR_NO_TAXONOMY, ERR_CAPACITY, ERR_K, ERR_PEER = -5, -6, -7, -8, -9
 PLAIN, UNIQUE, REPEATED, REPEATED_CHUNK, SINGLETON = 0, 1, 2, 3, 4
 OP_UNION, OP_INTER, OP_DIFF = 0, 1, 2
 F_MIX_TAXID, F_CMP_TAXID = 2, 4
@@ -31,7 +31,7 @@ SYMBOLS = [
     "ukm_common", "ukm_common_threshold", "ukm_partition_points",
     "ukm_comm_get_unique_id", "ukm_comm_init", "ukm_comm_destroy", "ukm_comm_info", "ukm_prefix_splitters",
     "ukm_shard_exchange", "ukm_shard_plan", "ukm_shard_counts", "ukm_shard_exchange_known",
-    "ukm_shard_splitters", "ukm_shard_splitters_plan",
+    "ukm_shard_splitters", "ukm_shard_splitters_plan", "ukm_shard_counts_tax", "ukm_shard_counts_plan",
     "ukm_ctx_set_option", "ukm_ctx_unset_option", "ukm_ctx_get_option", "ukm_ctx_get_stat",
     "ukm_setop2_ft", "ukm_union_ft", "ukm_inter_ft", "ukm_diff_ft", "ukm_common_ft", "ukm_merge_k_ft",
 ]
@@ -150,6 +150,8 @@ def load():
     L.ukm_shard_exchange.argtypes = [vp, vp, vp, vp, vp, vp, u64, vp, pu64]
     L.ukm_shard_plan.argtypes = [i32, i32, vp, vp, pu64]
     L.ukm_shard_counts.argtypes = [vp, vp, i32, vp]
+    L.ukm_shard_counts_tax.argtypes = [vp, vp, i32, vp, vp]
+    L.ukm_shard_counts_plan.argtypes = [i32, i32, i32, vp, vp]
     L.ukm_shard_exchange_known.argtypes = [vp, vp, vp, vp, vp, vp, vp, u64, pu64]
     L.ukm_shard_splitters.argtypes = [vp, pvp, pu64, i32, i32, vp]
     L.ukm_shard_splitters_plan.argtypes = [i32, i32, vp, i32, vp]
@@ -578,13 +580,31 @@ class Context:
             sp[-1] = 1 << key_bits
         return sp
 
-    def shard_counts(self, send_counts):
-        """send_counts [nfiles][nranks] -> recv_counts [nfiles][nranks] (one all-gather + one host sync for all files)"""
+    def shard_counts(self, send_counts, has_taxids=None):
+        """send_counts [nfiles][nranks] -> recv_counts [nfiles][nranks] (one all-gather + one host sync for all files).
+        has_taxids [nfiles] (bools): which files this rank will exchange WITH taxids; the flags ride in the same gather and
+        ranks that disagree about a file all raise (ukm_shard_counts_tax)."""
         sc = np.ascontiguousarray(send_counts, dtype=np.uint64)
         if sc.ndim == 1:
             sc = sc[None, :]
         rc = np.zeros_like(sc)
-        _check(self.L.ukm_shard_counts(self.h, sc.ctypes.data, sc.shape[0], rc.ctypes.data))
+        if has_taxids is None:
+            _check(self.L.ukm_shard_counts(self.h, sc.ctypes.data, sc.shape[0], rc.ctypes.data))
+        else:
+            ht = np.ascontiguousarray(has_taxids, dtype=np.uint8)
+            assert ht.shape == (sc.shape[0],)
+            _check(self.L.ukm_shard_counts_tax(self.h, sc.ctypes.data, sc.shape[0], ht.ctypes.data, rc.ctypes.data))
+        return rc
+
+    @staticmethod
+    def shard_counts_plan(nranks, rank, gathered):
+        """the decision of ukm_shard_counts_tax as a pure host function: gathered = [rank][nfiles * nranks sizes | nfiles
+        flags (0 / 1 / 2 = not declared)] -> recv_counts [nfiles][nranks] of `rank`; raises when two ranks disagree"""
+        g = np.ascontiguousarray(gathered, dtype=np.uint64)
+        nfiles = g.shape[1] // (nranks + 1)
+        assert g.shape == (nranks, nfiles * (nranks + 1))
+        rc = np.zeros((nfiles, nranks), dtype=np.uint64)
+        _check(load().ukm_shard_counts_plan(nranks, rank, nfiles, g.ctypes.data, rc.ctypes.data))
         return rc
 
     def shard_exchange(self, keys, send_counts, taxids=None, recv_counts=None):
@@ -596,7 +616,8 @@ class Context:
         pt, _, k2 = _ptr(taxids, np.uint32)
         sc = np.ascontiguousarray(send_counts, dtype=np.uint64)
         assert int(sc.sum()) == n
-        rc = np.ascontiguousarray(recv_counts, dtype=np.uint64) if recv_counts is not None else self.shard_counts(sc)[0]
+        rc = (np.ascontiguousarray(recv_counts, dtype=np.uint64) if recv_counts is not None
+              else self.shard_counts(sc, [taxids is not None])[0])
         cap = max(1, int(rc.sum()))
         out = _empty_like_kind(keys, cap, np.uint64)
         out_t = _empty_like_kind(keys, cap, np.uint32) if taxids is not None else None
