@@ -269,7 +269,7 @@ void ukmo_sort_u64(uint64_t *keys, uint64_t n) {
     if (n < 2) return;
     uint64_t *tmp = (uint64_t *)malloc(n * sizeof(uint64_t));
     uint64_t *src = keys, *dst = tmp;
-    static uint64_t hist[8][256];
+    uint64_t hist[8][256]; /* (on the stack: the test suite calls the oracle from several threads) */
     memset(hist, 0, sizeof(hist));
     for (uint64_t i = 0; i < n; i++) {
         uint64_t v = keys[i];

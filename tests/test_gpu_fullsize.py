@@ -399,17 +399,16 @@ def test_config4_inter_diff_common_1000_files_x_1e6_full_size(env, monkeypatch, 
     assert 0.85e9 < sum(x.numel() for x in files) < 1.3e9
     hf = [_np(x) for x in files]
     ht = [t.cpu().numpy().view(np.uint32) for t in taxs]
-    # (the oracle's loops are single-threaded C behind ctypes, which releases the GIL: its passes over the 1e9 records run
-    #  side by side on the host's cores)
-    from concurrent.futures import ThreadPoolExecutor
-    jobs = {"inter": lambda: O.inter(hf, ht, tax), "diff": lambda: O.diff(hf, ht, tax),
-            "diff_t": lambda: O.diff(hf, ht, tax, compare_taxid=True)}
+    # (the oracle's loops are single-threaded C behind ctypes, which releases the GIL: every operation acts code by code, so
+    #  its passes over all 1e9 records run value range by value range on the host's cores -- conftest.oracle_by_value_ranges;
+    #  round 5 ran one thread per operation: 137 s of a 556 s suite)
+    from conftest import oracle_by_value_ranges as by_ranges
+    want = {"inter": by_ranges(lambda k, t: O.inter(k, t, tax), hf, ht, kind="inter"),
+            "diff": by_ranges(lambda k, t: O.diff(k, t, tax), hf, ht),
+            "diff_t": by_ranges(lambda k, t: O.diff(k, t, tax, compare_taxid=True), hf, ht)}
     if core_share > 0:
-        jobs["common"] = lambda: O.common(hf, nfiles, ht, tax)
-        jobs["common_minus_1"] = lambda: O.common(hf, nfiles - 1, ht, tax)
-    with ThreadPoolExecutor(len(jobs)) as pool:
-        futs = {k: pool.submit(f) for k, f in jobs.items()}
-        want = {k: f.result() for k, f in futs.items()}
+        want["common"] = by_ranges(lambda k, t: O.common(k, nfiles, t, tax), hf, ht)
+        want["common_minus_1"] = by_ranges(lambda k, t: O.common(k, nfiles - 1, t, tax), hf, ht)
     if core_share > 0:
         assert len(want["inter"][0]) > 200_000 and len(want["diff"][0]) >= per // 10    # results that survive every file
     else:
@@ -477,10 +476,9 @@ def test_default_routes_1000_files_x_1e6_full_size(env, monkeypatch):
         that do not fit a tile);
       * `union` (union.go:186-305) of files that hold a tenth of a universe each -> the hash-probe union, whose first base
         set misses the hit-rate guard and whose SECOND attempt with four times the files runs (ukm_ctx_get_stat).
-    No knob is set.  The oracle's heap merges of 1e9 records run in threads beside one another."""
+    No knob is set.  The oracle's heap merges of 1e9 records run value range by value range on the host's cores."""
     torch, bench, lib, ctx, O, dev = env
     from conftest import synth_tree
-    from concurrent.futures import ThreadPoolExecutor
     for v in ("UKM_PUNION", "UKM_PLACE", "UKM_SRMERGE", "UKM_KWAY", "UKM_NO_KWAY", "UKM_PUNION_TAX"):
         monkeypatch.delenv(v, raising=False)
     child, parent = synth_tree(7, 8)
@@ -494,17 +492,18 @@ def test_default_routes_1000_files_x_1e6_full_size(env, monkeypatch):
         "probe": _draw_files(torch, bench, dev, nfiles, 10 * per, 0.1, T, 47),              # a tenth each
     }
     host = {k: ([_np(x) for x in fs], [t.cpu().numpy().view(np.uint32) for t in ts]) for k, (fs, ts) in shapes.items()}
-    jobs = {
-        "place": lambda: O.merge_k(host["place"][0], host["place"][1], mode=O.PLAIN, tax=tax),
-        "single": lambda: O.merge_k(host["single"][0], host["single"][1], mode=O.PLAIN, tax=tax),
-        "probe": lambda: O.union(host["probe"][0], host["probe"][1], tax),
+    from conftest import oracle_by_value_ranges as by_ranges
+    # (value range by value range on the host's cores: the heap merge is stable in the file order inside every range)
+    want = {
+        "place": by_ranges(lambda k, t: O.merge_k(k, t, mode=O.PLAIN, tax=tax), *host["place"]),
+        "single": by_ranges(lambda k, t: O.merge_k(k, t, mode=O.PLAIN, tax=tax), *host["single"]),
+        "probe": by_ranges(lambda k, t: O.union(k, t, tax), *host["probe"]),
     }
-    pool = ThreadPoolExecutor(len(jobs))
-    futs = {k: pool.submit(f) for k, f in jobs.items()}
+    del host
 
     def same(got, name):
         gk, gt = got
-        wk, wt = futs[name].result()
+        wk, wt = want[name]
         assert gk.numel() == len(wk), (name, gk.numel(), len(wk))
         assert np.array_equal(_np(gk), wk), name
         assert np.array_equal(gt.cpu().numpy().view(np.uint32), wt), name
@@ -525,4 +524,109 @@ def test_default_routes_1000_files_x_1e6_full_size(env, monkeypatch):
     got = ctx.union(files, taxs, out=ok, out_taxids=ot)
     assert ctx.last_route() == 3 and ctx.stat("punion_attempts") == 2, (ctx.last_route(), ctx.stat("punion_attempts"))
     same(got, "probe")
-    pool.shutdown()
+
+
+def _sorted_in_slices(t, step=1 << 30):
+    """non-decreasing, checked slice by slice (bounds torch's temporaries on multi-GB tensors)"""
+    n = t.numel()
+    return all(bool((t[lo + 1:min(n, lo + step + 1)] >= t[lo:min(n, lo + step + 1) - 1]).all()) for lo in range(0, n - 1, step))
+
+
+def _sort_windows_match_oracle(torch, O, src, srt, width=1_000_000):
+    """windows at both ends and in the middle of the sorted array `srt` against the ORACLE's sort of the records of the
+    unsorted array `src` whose values fall into the window's value range (selected with a torch mask)"""
+    n = srt.numel()
+    for start in (0, n // 2 - width // 2, n - width):
+        win = srt[start:start + width]
+        lo, hi = int(win[0].item()), int(win[-1].item())
+        sel = torch.cat([c[(c >= lo) & (c <= hi)] for c in torch.split(src, 1 << 30)])   # (masks of <= 2^30 elements)
+        # (equal values at the window's edges may extend beyond it: compare the window inside the selection)
+        want = O.sort_u64(_np(sel))
+        below = int((srt[max(0, start - 4096):start] == lo).sum().item()) if start else 0
+        assert below < 4096
+        assert np.array_equal(_np(win), want[below:below + width]), start
+
+
+def test_beyond_2_30_and_2_32_records(env, monkeypatch):
+    """The paths that only sizes beyond 2^30 / 2^32 reach (round-5 review: checked once by hand in round 1 with
+    tools/large_checks.py, while ukm_sort.hip gained the bucket route and its counting step since):
+      (1) sortutil.Uint64s (sort.go:463) on more than 2^30 keys -- the radix sort's look-back status words are 64-bit from
+          2^30 on -- through the CURRENT top-bits + LDS-bucket route and with UKM_SORT_LOCAL=0 (all passes through HBM);
+      (2) union / inter (union.go:186-305, inter.go:205-278) of two sets with |A| + |B| > 2^32 (64-bit tile indices);
+      (3) a sort of 2^32 + delta keys: the chunk-and-merge path include/unikmer_hip.h promises from 2^32 records on.
+    Each checked over the WHOLE output by order + XOR checksum (+ inclusion-exclusion), on 1e6-record windows against the
+    oracle, and (1) element for element against torch.sort (rocPRIM: an independent device sort)."""
+    torch, bench, lib, ctx, O, dev = env
+    ctx.trim()
+    torch.cuda.empty_cache()
+    # ---- (1) n > 2^30, 62-bit keys with duplicates
+    n = (1 << 30) + 77_777_777
+    g = torch.Generator(device=dev)
+    g.manual_seed(5)
+    K = torch.randint(0, 1 << 62, (n,), dtype=torch.int64, device=dev, generator=g)
+    K[12345:12345 + 1000] = K[999]                                   # a run of equal keys
+    x0 = _xor(torch, K)
+    ref = torch.sort(K).values
+    for knob in (None, "0"):
+        if knob is None:
+            monkeypatch.delenv("UKM_SORT_LOCAL", raising=False)
+        else:
+            monkeypatch.setenv("UKM_SORT_LOCAL", knob)
+        S = K.clone()
+        ctx.sort_u64(S, 62)
+        assert _sorted_in_slices(S) and _xor(torch, S) == x0, knob
+        assert torch.equal(S, ref), knob
+        if knob is None:
+            _sort_windows_match_oracle(torch, O, K, S)
+        del S
+    monkeypatch.delenv("UKM_SORT_LOCAL", raising=False)
+    del K, ref
+    ctx.trim()
+    torch.cuda.empty_cache()
+    # ---- (2) |A| + |B| > 2^32
+    nu = 3_070_000_000                                               # universe; |A| ~ |B| ~ 0.75 nu
+    A, B = bench.gen_sets_device(nu, 29, 0, bench.SEED + 3, dev)
+    na, nb = A.numel(), B.numel()
+    assert na + nb > (1 << 32)
+    out = torch.empty(na + nb, dtype=torch.int64, device=dev)
+    xa, xb = _xor(torch, A), _xor(torch, B)
+    U = ctx.setop2(lib.OP_UNION, A, B, out=out)
+    nuo, xu = U.numel(), _xor(torch, U)
+    assert _sorted_in_slices(U) and bool((U[1:1 << 28] > U[:(1 << 28) - 1]).all())
+    wins_u = []
+    for start in (0, nuo // 2 - W // 2, nuo - W):
+        win = U[start:start + W]
+        lo, hi = int(win[0].item()), int(win[-1].item())
+        a0, a1 = _lower(torch, A, lo), _lower(torch, A, hi + 1)
+        b0, b1 = _lower(torch, B, lo), _lower(torch, B, hi + 1)
+        assert np.array_equal(_np(win), O.union([_np(A[a0:a1]), _np(B[b0:b1])])), start
+        wins_u.append((start, a0, b0, lo))
+    del U
+    I = ctx.setop2(lib.OP_INTER, A, B, out=out)
+    ni, xi = I.numel(), _xor(torch, I)
+    assert nuo + ni == na + nb                                       # inclusion-exclusion
+    assert xu == xa ^ xb ^ xi                                        # checksum of checksums
+    assert _sorted_in_slices(I)
+    for start, a0, b0, lo in wins_u:                                 # the union windows' RANK from the inputs and I
+        assert start == a0 + b0 - _lower(torch, I, lo), start
+    for start in (0, ni // 2 - W // 2, ni - W):
+        win = I[start:start + W]
+        lo, hi = int(win[0].item()), int(win[-1].item())
+        a0, a1 = _lower(torch, A, lo), _lower(torch, A, hi + 1)
+        b0, b1 = _lower(torch, B, lo), _lower(torch, B, hi + 1)
+        assert np.array_equal(_np(win), O.inter([_np(A[a0:a1]), _np(B[b0:b1])])), start
+    del A, B, I, out
+    ctx.trim()
+    torch.cuda.empty_cache()
+    # ---- (3) 2^32 + delta keys
+    n = (1 << 32) + 123_456_789
+    g.manual_seed(9)
+    K = torch.randint(0, 1 << 62, (n,), dtype=torch.int64, device=dev, generator=g)
+    x0 = _xor(torch, K)
+    S = K.clone()
+    ctx.sort_u64(S, 62)
+    assert _sorted_in_slices(S) and _xor(torch, S) == x0
+    _sort_windows_match_oracle(torch, O, K, S)
+    del K, S
+    ctx.trim()
+    torch.cuda.empty_cache()

@@ -52,6 +52,21 @@ def _stable(streams, taxs=None):
     return (cat[o], np.concatenate(taxs)[o]) if taxs is not None else cat[o]
 
 
+_shapes = {}
+
+
+def _shape(nfiles, per, p, T):
+    """the files of one (nfiles, per, p) shape, drawn once for all its knob settings (700 draws over a universe of 3e6
+    codes are 10 s of numpy per call: 40 s of the round-5 suite)"""
+    key = (nfiles, per, p, T)
+    if key not in _shapes:
+        U = _universe(int(per / p))
+        files = [U[_member(len(U), f, p, 7)] for f in range(nfiles)]
+        files = [f for f in files if len(f)]
+        _shapes[key] = (files, [_taxids(f + np.uint64(i), T, i) for i, f in enumerate(files)])
+    return _shapes[key]
+
+
 @pytest.mark.parametrize("buckets", [None, "1", "0", "2"])
 @pytest.mark.parametrize("nfiles,per,p", [(200, 3000, 0.02), (1000, 700, 0.002), (1024, 300, 0.5), (65, 20000, 0.3), (700, 2500, 0.0008)])
 def test_merge_modes_and_union_many_streams(env, monkeypatch, nfiles, per, p, buckets):
@@ -64,10 +79,7 @@ def test_merge_modes_and_union_many_streams(env, monkeypatch, nfiles, per, p, bu
     monkeypatch.setenv("UKM_SRMERGE", "1")
     if buckets is not None:
         monkeypatch.setenv("UKM_SRMERGE_BUCKETS", buckets)
-    U = _universe(int(per / p))
-    files = [U[_member(len(U), f, p, 7)] for f in range(nfiles)]
-    files = [f for f in files if len(f)]
-    taxs = [_taxids(f + np.uint64(i), T, i) for i, f in enumerate(files)]
+    files, taxs = _shape(nfiles, per, p, T)
     gk, gt = ctx.merge_k(files, taxs, mode=L.PLAIN)
     assert ctx.last_route() == ROUTE_SR
     ek, et = _stable(files, taxs)

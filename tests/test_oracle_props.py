@@ -130,3 +130,36 @@ def test_allcores_sorted_merge_matches_reference_algorithms():
             exp = ref([a, b])
             assert threads >= 1
             assert np.array_equal(got, np.sort(exp))
+
+
+def test_oracle_by_value_ranges_equals_the_oracle_on_whole_files(tree):
+    """conftest.oracle_by_value_ranges (how the full-size GPU tests afford the oracle over 1e9 records: value range by value
+    range on the host's cores) returns exactly what the oracle returns on the whole files -- union / inter / diff / diff -t /
+    common / keep-everything merge with taxids, files that lack records in some ranges, a file that is empty altogether
+    (inter.go:211-217: the running result is kept), and a file with a duplicated code (the multiset rule)."""
+    from conftest import oracle_by_value_ranges as by_ranges
+    tax, _, T = tree
+    rng = np.random.default_rng(11)
+    U = np.cumsum(rng.integers(1, 1 << 18, 60_000).astype(np.uint64))
+    files = [U[rng.random(len(U)) < p] for p in (0.9, 0.8, 0.85, 0.7, 0.95)]
+    files[3] = files[3][files[3] > U[len(U) // 3]]                 # nothing in the lowest ranges
+    files[1] = np.sort(np.concatenate([files[1], files[1][100:101]]))  # a code twice in one file
+    taxs = [rng.integers(1, T + 1, len(f)).astype(np.uint32) for f in files]
+    ops = {
+        "union": (lambda k, t: O.union(k, t, tax), "set"),
+        "inter": (lambda k, t: O.inter(k, t, tax), "inter"),
+        "diff": (lambda k, t: O.diff(k, t, tax), "set"),
+        "diff_t": (lambda k, t: O.diff(k, t, tax, compare_taxid=True), "set"),
+        "common": (lambda k, t: O.common(k, 4, t, tax), "set"),
+        "merge": (lambda k, t: O.merge_k(k, t, mode=O.PLAIN, tax=tax), "set"),
+    }
+    for name, (fn, kind) in ops.items():
+        wk, wt = fn(files, taxs)
+        gk, gt = by_ranges(fn, files, taxs, nranges=37, kind=kind, threads=4)
+        assert np.array_equal(gk, wk) and np.array_equal(gt, wt), name
+    # plain keys, and an inter whose third file is EMPTY: the loop stops there and keeps the running result
+    with_empty = [files[0], files[2], np.empty(0, np.uint64), files[4]]
+    want = O.inter(with_empty)
+    assert len(want) > 0
+    assert np.array_equal(by_ranges(lambda k, t: O.inter(k), with_empty, None, nranges=16, kind="inter", threads=3), want)
+    assert np.array_equal(by_ranges(lambda k, t: O.union(k), files, None, nranges=16, threads=3), O.union(files))

@@ -131,10 +131,10 @@ def main():
         ms, u = wall(lambda: ctx.union(files, out=out), reps=args.reps)
         assert u.numel() <= nu and bool((u[1:] > u[:-1]).all())
         n_probe, x_probe = u.numel(), int(bench._xor_fold(u)) if hasattr(bench, "_xor_fold") else 0
-        os.environ["UKM_PUNION"] = "0"   # the k-way streaming merge alone (what answers when the sets do not overlap)
+        ctx.set_option("punion", 0)  # the k-way streaming merge alone (what answers when the sets do not overlap)
         ctx.union(files, out=out)
         ms_kway, uk = wall(lambda: ctx.union(files, out=out), reps=args.reps)
-        del os.environ["UKM_PUNION"]
+        ctx.set_option("punion", None)
         assert uk.numel() == n_probe and (not hasattr(bench, "_xor_fold") or int(bench._xor_fold(uk)) == x_probe)
         res["config3_union_%d_files_x_%.0e" % (nfiles, per)] = {"ms": ms, "input_kmers": total, "kmers_per_s": total / ms * 1e3,
                                                                   "out": u.numel(), "gpus": 1,
@@ -242,9 +242,9 @@ def main():
         ms_c, rc = wall(lambda: ctx.common(files2, nfiles, taxs2, out=okc, out_taxids=otc), reps=max(1, args.reps - 1))
         assert rc[0].numel() == n_inter
         sums = (int(rc[0].sum()), int(rc[1].long().sum()))
-        os.environ["UKM_COMMON_PROBE"] = "0"
+        ctx.set_option("common_probe", 0)
         ms_cm, rcm = wall(lambda: ctx.common(files2, nfiles, taxs2, out=okc, out_taxids=otc), reps=1)
-        del os.environ["UKM_COMMON_PROBE"]
+        ctx.set_option("common_probe", None)
         assert rcm[0].numel() == n_inter and sums == (int(rcm[0].sum()), int(rcm[1].long().sum()))
         # the same 1000 files through the keep-everything merge (mergeChunksFile), `common` one below the full threshold
         # (counting merge + run scan) and `union` with the taxid fold: the many-stream routes (ukm_srmerge.hip / ukm_kway.hip)

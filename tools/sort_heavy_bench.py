@@ -17,7 +17,7 @@ for n, ntops, share in ((16_000_000, 40, 0.6), (100_000_000, 20, 0.1), (100_000_
     exp = torch.sort(x).values
     res = {}
     for knob in ("1", "0"):
-        os.environ["UKM_SORT_LOCAL"] = knob
+        ctx.set_option("sort_local", int(knob))   # (contexts read the environment once, at creation)
         best = 1e9
         for _ in range(3):
             w = x.clone(); torch.cuda.synchronize(); t0 = time.perf_counter(); ctx.sort_u64(w, 62); torch.cuda.synchronize(); best = min(best, (time.perf_counter() - t0) * 1e3)
