@@ -287,6 +287,52 @@ def test_kway_long_runs_and_multisets(env):
 
 
 # ------------------------------------------------------------------- union by LDS hash probes (ukm_punion.hip)
+def test_probe_union_pipelined_steps_and_order_check(env, monkeypatch):
+    """The plain probe pass as one software pipeline per wave (pu2_probe_kernel, round 6): its steps are 16-byte pairs, a
+    slice that does not begin its file starts one record early, a last step of one record is moved back by one, lanes
+    beyond the end re-read the last pair, the order check takes a pair's predecessor from the neighbouring lane.  Shapes
+    that put every one of those cases at the edges: slices of 0 / 1 / 2 / 3 / 127 / 128 / 129 / 257 records at the start,
+    in the middle and at the end of their files, later files of 0, 1 and 2 records, and -- the order check -- ONE swapped
+    neighbouring pair anywhere in a later file (inside a lane's pair, between lanes, between steps, across a slice
+    boundary, at either end of the file) must send the call to the other routes (union.go:186-208 has no order
+    requirement: the result is the oracle's either way; what is asserted is that the probe pass noticed)."""
+    O, L, ctx, tax, T = env
+    rng = np.random.default_rng(606)
+    monkeypatch.setenv("UKM_PUNION", "2")
+    # base: eight files over a universe of ~3 ranges of 2048 entries; later files built from chosen slice lengths
+    U = _universe(6000, gap_bits=24)
+    base = [U[_member(len(U), f, 0.9, 3)] for f in range(8)]
+    bu = np.unique(np.concatenate(base))
+    cut1, cut2 = bu[2048], bu[4096]                      # the ranges' first entries (PU_RANGE = 2048)
+    lo_pool, mid_pool, hi_pool = U[U < cut1], U[(U >= cut1) & (U < cut2)], U[U >= cut2]
+    later = []
+    for a_, b_, c_ in ((0, 1, 0), (1, 0, 1), (2, 3, 1), (127, 128, 129), (128, 127, 1), (129, 257, 2), (257, 1, 128), (0, 0, 1),
+                       (1, 0, 0), (3, 129, 127), (500, 640, 385), (256, 256, 256)):
+        parts = [np.sort(rng.choice(pool, n, replace=False)) for pool, n in ((lo_pool, a_), (mid_pool, b_), (hi_pool, c_))]
+        later.append(np.concatenate(parts).astype(np.uint64))
+    later += [np.empty(0, np.uint64), U[77:78].copy(), U[100:102].copy(), np.array([bu[-1] + np.uint64(5)], np.uint64)]
+    # private codes too (misses that are claimed / listed)
+    later.append(np.unique(rng.integers(1, int(U[-1]), 700).astype(np.uint64)))
+    files = base + later
+    assert np.array_equal(ctx.union(files), O.union(files))
+    assert ctx.last_route() == 3
+    # one swapped neighbouring pair: every position class of a 900-record later file
+    victim = np.sort(rng.choice(U, 900, replace=False)).astype(np.uint64)
+    b1 = int(np.searchsorted(victim, cut1))               # first record of the second range's slice
+    b2 = int(np.searchsorted(victim, cut2))
+    spots = {0, 1, 2, 126, 127, 128, 129, 254, 255, 256, b1 - 2, b1 - 1, b1, b1 + 1, b1 + 126, b1 + 127, b2 - 1, b2, len(victim) - 2,
+             len(victim) - 3} | set(int(x) for x in rng.integers(0, len(victim) - 1, 12))
+    for sp in sorted(x for x in spots if 0 <= x < len(victim) - 1):
+        v = victim.copy()
+        v[sp], v[sp + 1] = v[sp + 1], v[sp]
+        trial = base + [later[3], v, later[10]]
+        assert np.array_equal(ctx.union(trial), O.union(trial)), sp
+        assert ctx.last_route() != 3, sp                   # the probe pass saw the inversion and backed out
+    clean = base + [later[3], victim, later[10]]
+    assert np.array_equal(ctx.union(clean), O.union(clean))
+    assert ctx.last_route() == 3
+
+
 def test_probe_union_matches_oracle(env, monkeypatch):
     """`union` of many plain sets that overlap heavily: the first eight files become the base set, every later record
     is one hash probe in the LDS table of its range, misses are sorted and merged in (ukm_punion.hip; the reference

@@ -458,6 +458,308 @@ __global__ __launch_bounds__(PU_NT) __attribute__((amdgpu_waves_per_eu(PU_WAVES,
         for (u32 i = (u32)tid; i < nl; i += PU_NT) a.miss[at + i] = s_miss[i];
 }
 
+// ---- round 6: the plain pass as ONE software pipeline per wave (pu2_probe_kernel) ----------------------------------------
+// What bound pu_probe_kernel (profiles/r03_punion_pmc.txt, r05_notes.md 1c): neither bytes nor the table reads but WAITING --
+// 58 % of the wave-cycles sat in s_waitcnt.  Its step() issues up to four loads, uses them all and only then issues the next
+// ones, and every slice (~1100 records of one file) starts with an empty pipeline: a wave pays a full HBM round trip per 512
+// records, with four waves per SIMD to cover it; its three step shapes x two validity paths x the inlined list code are
+// 16,000 lines of ISA (more than the instruction cache holds).  Here:
+//   * a wave's slices form ONE stream of STEPS (128 records: two per lane) produced by a scalar generator that runs D steps
+//     ahead of the consumer, ACROSS slice boundaries: D loads are in flight per wave at all times; the next slice's cut
+//     points, pointer and boundary record are scalar loads issued a slice ahead;
+//   * one step shape: a FULL step is one 16-byte load per lane at a wave-uniform base + lane * 16 (no address arithmetic, no
+//     clamps); the last, partial step of a slice loads its two records with two 8-byte loads clamped to the slice's last
+//     record (duplicates of a real record: harmless to the order check and to the table) -- the consumer code is the same;
+//   * the order check needs no third load: the record in front of a lane's pair is its neighbour's second record (DPP
+//     wave_shr:1), lane 0 takes the step's predecessor from a scalar (the previous step's last record, or the record in
+//     front of the slice);
+//   * 1024 threads share the 64 KB table: two workgroups = eight waves per SIMD (<= 64 registers);
+//   * the list / claim code exists once, behind one wave-uniform branch.
+#ifndef PU2_NT_N
+#define PU2_NT_N 1024
+#endif
+#ifndef PU2_D_N
+#define PU2_D_N 3
+#endif
+#ifndef PU2_EXP
+#define PU2_EXP 0
+#endif
+constexpr int PU2_NT = PU2_NT_N;
+constexpr int PU2_D = PU2_D_N;  // steps in flight per wave
+constexpr int PU2_WAVES = PU2_NT == 1024 ? 8 : 4;
+
+__device__ __forceinline__ u64 pu2_shr1(u64 v, u64 carry) {  // lane l gets v of lane l - 1, lane 0 gets `carry`
+    const u32 lo = (u32)__builtin_amdgcn_update_dpp((int)(u32)carry, (int)(u32)v, 0x138, 0xF, 0xF, false);          // wave_shr:1
+    const u32 hi = (u32)__builtin_amdgcn_update_dpp((int)(u32)(carry >> 32), (int)(u32)(v >> 32), 0x138, 0xF, 0xF, false);
+    return ((u64)hi << 32) | lo;
+}
+__device__ __forceinline__ u64 pu2_uniform(u64 v) {
+    return ((u64)(u32)__builtin_amdgcn_readfirstlane((int)(u32)(v >> 32)) << 32) | (u32)__builtin_amdgcn_readfirstlane((int)(u32)v);
+}
+
+__global__ __launch_bounds__(PU2_NT) __attribute__((amdgpu_waves_per_eu(PU2_WAVES, PU2_WAVES))) void pu2_probe_kernel(PuArgs a) {
+    // the table in two halves: slots 0 and 1 of every bucket in the first 32 KB (P), slots 2 and 3 behind them (Q).  Slots
+    // fill in order, so a record is looked up in its bucket's P pair first (one 16-byte read at a 16-byte stride: all bank
+    // groups in use) and only the lanes that did not find it there AND see slot 1 taken read the Q pair: a tenth of them.
+    __shared__ __attribute__((aligned(32))) u64 s_tab[PU_SLOTS];
+    __shared__ u64 s_miss[PU_LMISS];
+    auto slot = [&](u32 h, int q) -> u64 * { return &s_tab[(q >> 1) * (PU_SLOTS / 2) + 2 * h + (q & 1)]; };
+    __shared__ u32 s_next, s_nmiss, s_nins;
+    __shared__ u64 s_flush_at;
+    const int tid = (int)threadIdx.x, lane = lane_id();
+    const u32 r = blockIdx.x, S1 = a.S1;
+    for (int i = tid; i < PU_SLOTS; i += PU2_NT) s_tab[i] = PU_EMPTY;
+    if (tid == 0) { s_next = 0; s_nmiss = 0; s_nins = 0; }
+    __syncthreads();
+    {   // the table of this range's base entries (as pu_probe_kernel)
+        const u64 b0 = (u64)r * PU_RANGE;
+        const u32 nb = (u32)((a.n0 - b0 < (u64)PU_RANGE) ? (a.n0 - b0) : (u64)PU_RANGE);
+        constexpr int PER = (PU_RANGE + PU2_NT - 1) / PU2_NT;
+        u64 ent[PER];
+#pragma unroll
+        for (int i = 0; i < PER; i++) {
+            const u32 idx = (u32)tid + (u32)i * PU2_NT;
+            ent[i] = a.base[b0 + (idx < nb ? idx : 0)];
+            if (idx >= nb) ent[i] = PU_EMPTY;
+        }
+#pragma unroll
+        for (int i = 0; i < PER; i++) {
+            const u64 e = ent[i];
+            if (e == PU_EMPTY) continue;
+            u32 h = pu_hash(e);
+            for (bool placed = false; !placed; h = (h + 1) & (PU_BUCKETS - 1)) {
+#pragma unroll
+                for (int k = 0; k < 4 && !placed; k++) {
+                    const u64 old = atomicCAS((unsigned long long *)slot(h, k), (unsigned long long)PU_EMPTY, (unsigned long long)e);
+                    placed = old == PU_EMPTY || old == e;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    auto member_from = [&](u64 x, u32 h) -> bool {
+        for (;;) {
+            const ulonglong2 p = *reinterpret_cast<const ulonglong2 *>(slot(h, 0)), q = *reinterpret_cast<const ulonglong2 *>(slot(h, 2));
+            if (p.x == x || p.y == x || q.x == x || q.y == x) return x != PU_EMPTY;
+            if (q.y == PU_EMPTY) return false;
+            h = (h + 1) & (PU_BUCKETS - 1);
+        }
+    };
+    auto claim = [&](u64 x) -> bool {
+        if (x == PU_EMPTY || s_nins >= (u32)PU_RANGE) return true;
+        u32 h = pu_hash(x);
+        for (;; h = (h + 1) & (PU_BUCKETS - 1)) {
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const u64 old = atomicCAS((unsigned long long *)slot(h, k), (unsigned long long)PU_EMPTY, (unsigned long long)x);
+                if (old == PU_EMPTY) { atomicAdd(&s_nins, 1u); return true; }
+                if (old == x) return false;
+            }
+        }
+    };
+    const u64 lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+    u64 chunk_at = 0, fill = 0;  // wave-uniform
+    u32 chunk_cap = 0, chunk_used = 0;
+    auto close_chunk = [&]() {
+        if ((u32)lane < chunk_cap - chunk_used) a.miss[chunk_at + chunk_used + (u32)lane] = fill;
+        chunk_cap = chunk_used = 0;
+    };
+    auto append_global = [&](bool m, u64 x) {
+        const u64 mask = __ballot(m);
+        if (mask == 0ull) return;
+        const u32 n = (u32)__popcll(mask);
+        const int lead = __ffsll((long long)mask) - 1;
+        if (n > chunk_cap - chunk_used) {
+            close_chunk();
+            const u32 want = n > PU_CHUNK ? 64u : PU_CHUNK;
+            u64 at = 0;
+            if (lane == lead) at = atomicAdd((unsigned long long *)&a.ctl[0], (unsigned long long)want);
+            at = __shfl(at, lead, 64);
+            if (at + want > a.miss_cap) {
+                if (lane == lead) atomicOr((unsigned long long *)&a.ctl[1], (unsigned long long)PU_FLAG_OVERFLOW);
+                return;
+            }
+            chunk_at = at;
+            chunk_cap = want;
+        }
+        fill = __shfl(x, lead, 64);
+        if (m) a.miss[chunk_at + chunk_used + (u32)__popcll(mask & lt)] = x;
+        chunk_used += n;
+    };
+    // (the one copy of the list code: both records of a step go through it in a loop that is NOT unrolled)
+    auto append2 = [&](bool m0, u64 x0, bool m1, u64 x1) {
+#pragma nounroll
+        for (int h = 0; h < 2; h++) {
+            const bool missing = h ? m1 : m0;
+            const u64 x = h ? x1 : x0;
+            if (__ballot(missing) == 0ull) continue;
+            const bool m = missing && claim(x);
+            const u64 mask = __ballot(m);
+            if (mask == 0ull) continue;
+            const int lead = __ffsll((long long)mask) - 1;
+            u32 at = 0;
+            if (lane == lead) at = atomicAdd(&s_nmiss, (u32)__popcll(mask));
+            at = (u32)__shfl((int)at, lead, 64) + (u32)__popcll(mask & lt);
+            const bool in_lds = m && at < (u32)PU_LMISS;
+            if (in_lds) s_miss[at] = x;
+            append_global(m && !in_lds, x);
+        }
+    };
+    // ---- the generator: slices -> steps, everything in scalars ----
+    // A step = up to 128 records [lo, hi) of the 128 at `ptr` (two per lane: 2 l and 2 l + 1; lanes whose pair lies beyond
+    // hi - 2 re-read the last pair that fits: duplicates of real records, harmless to the table and masked out of the order
+    // check).  A slice that does not begin its file starts ONE RECORD EARLY with lo = 1: the pair (f[beg - 1], f[beg]) is
+    // then checked inside lane 0 like every other pair -- no separate load for the record in front of the slice -- and a
+    // last step of ONE record is moved back by one record the same way, so every load is a 16-byte pair inside the file
+    // (files of fewer than two records never come here: the host lists their record itself).
+    auto take = [&]() -> u32 {
+        u32 j = 0;
+        if (lane == 0) j = atomicAdd(&s_next, 1u);
+        return (u32)__builtin_amdgcn_readfirstlane((int)j);
+    };
+    struct Meta { u64 beg, end, f; };
+    auto fetch = [&](u32 j) -> Meta {
+        Meta m = {0, 0, 0};
+        if (j < S1) {
+            m.beg = sload_u64(&a.cuts[(u64)r * S1 + j]);
+            m.end = sload_u64(&a.cuts[(u64)(r + 1) * S1 + j]);
+            m.f = sload_u64((const u64 *)&a.files[j]);
+        }
+        return m;
+    };
+    bool bad = false, raw = false;
+    u32 g_j = take();          // the slice the generator opens next; its cut points and pointer are already on their way
+    Meta g_m = fetch(g_j);
+    u64 g_ptr = 0;             // address of the next step's first loaded record
+    u32 g_rem = 0;             // records from g_ptr to the end of the current slice
+    u32 g_lo = 0;              // 1: the first of them lies in front of the slice
+    // what the consumer needs of a step: lo | hi << 8 | first << 16 (hi <= 128)
+    auto next_step = [&](u64 &ptr, u32 &desc) -> bool {
+        u32 first = 0;
+        while (g_rem == 0) {   // open the next slice that is not empty
+            if (g_j >= S1) return false;
+            const u64 n = g_m.end > g_m.beg ? g_m.end - g_m.beg : 0ull;
+            if (n >= 0xFFFFFF00ull) raw = true;  // (a slice of 2^32 records: the caller's other routes)
+            else if (n) {
+                g_lo = g_m.beg ? 1u : 0u;
+                g_ptr = g_m.f + 8ull * (g_m.beg - g_lo);
+                g_rem = (u32)n + g_lo;
+                first = 1;
+            }
+            g_j = take();
+            g_m = fetch(g_j);
+        }
+        const u32 cnt = g_rem < 128u ? g_rem : 128u;
+        ptr = g_ptr;
+        u32 lo = g_lo, hi = cnt;
+        if (cnt == 1u) {
+            // one record: at the start of its file the pair (0, 1) -- the file has two records --, else the pair (-1, 0)
+            if (first) { lo = 0; hi = 1; }
+            else { ptr = g_ptr - 8; lo = 1; hi = 2; }
+        }
+        desc = lo | (hi << 8) | (first << 16);
+        g_lo = 0;
+        g_ptr += 128 * 8;
+        g_rem -= cnt;
+        return true;
+    };
+    // ---- the pipeline ----
+    // The loads are inline assembly and the waits are written by hand: the compiler's own s_waitcnt placement merges "load
+    // issued" with "no load issued" paths at every join of this loop and waits with vmcnt(0) in front of every step -- for
+    // the load it has just issued: no pipeline.  Loads return in order, so "at most D - 1 vector-memory operations still
+    // outstanding" implies that the load issued D steps ago has landed, whatever the list code issued in between (its stores
+    // only make the wait more conservative); a slot without a step re-reads the base set's first pair, so the count holds
+    // on every path.  The build checks that this kernel does not spill (a spill would copy registers that are in flight).
+    const u32 l2 = 2u * (u32)lane;
+    pu_u64x2 x[PU2_D];
+    u32 desc[PU2_D];
+    bool live[PU2_D];
+    auto issue = [&](int k) {
+        u64 ptr = 0;
+        u32 d = 0;
+        live[k] = next_step(ptr, d);
+        if (!live[k]) ptr = (u64)(uintptr_t)a.base;
+        desc[k] = d;
+        const u32 hi = (d >> 8) & 0xFFu;
+        const u32 pmax = hi > 2u ? hi - 2u : 0u;
+        const u32 voff = 8u * (l2 < pmax ? l2 : pmax);
+#ifdef PU2_CLOAD
+        x[k] = *(const pu_pair __attribute__((address_space(1))) *)((const char __attribute__((address_space(1))) *)(uintptr_t)ptr + voff);
+#else
+        // (s_nop 4: a vector-memory instruction that reads an SGPR a VALU instruction -- v_readfirstlane -- has just written
+        //  needs five wait states on gfx9; the compiler's hazard recogniser does not look into inline assembly)
+        asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2" : "=v"(x[k]) : "v"(voff), "s"(ptr) : "memory");
+#endif
+    };
+    u64 run_carry = 0;
+    auto consume = [&](int k) {
+        const u64 x0 = x[k].x, x1 = x[k].y;
+        const u32 lo = desc[k] & 0xFFu, hi = (desc[k] >> 8) & 0xFFu;
+        const bool first = (desc[k] >> 16) != 0;
+        const u32 pmax = hi > 2u ? hi - 2u : 0u;
+        const u64 prev = pu2_shr1(x1, first ? 0ull : run_carry);
+        bad |= (prev > x0 && l2 <= pmax) || x0 > x1;
+        run_carry = ((u64)(u32)__builtin_amdgcn_readlane((int)(u32)(x1 >> 32), 63) << 32) | (u32)__builtin_amdgcn_readlane((int)(u32)x1, 63);
+        const u32 h0 = pu_hash(x0), h1 = pu_hash(x1);
+        const ulonglong2 p0 = *reinterpret_cast<const ulonglong2 *>(slot(h0, 0)), p1 = *reinterpret_cast<const ulonglong2 *>(slot(h1, 0));
+        bool ha = p0.x == x0 || p0.y == x0, hb = p1.x == x1 || p1.y == x1;
+        bool more0 = false, more1 = false;
+        if (!ha && p0.y != PU_EMPTY) {
+            const ulonglong2 q0 = *reinterpret_cast<const ulonglong2 *>(slot(h0, 2));
+            ha = q0.x == x0 || q0.y == x0;
+            more0 = !ha && q0.y != PU_EMPTY;
+        }
+        if (!hb && p1.y != PU_EMPTY) {
+            const ulonglong2 q1 = *reinterpret_cast<const ulonglong2 *>(slot(h1, 2));
+            hb = q1.x == x1 || q1.y == x1;
+            more1 = !hb && q1.y != PU_EMPTY;
+        }
+        ha = ha && x0 != PU_EMPTY;
+        hb = hb && x1 != PU_EMPTY;
+        if (__ballot(more0 || more1)) {  // a full bucket (0.4 %): the slow way
+            if (more0) ha = member_from(x0, (h0 + 1) & (PU_BUCKETS - 1));
+            if (more1) hb = member_from(x1, (h1 + 1) & (PU_BUCKETS - 1));
+        }
+        const u32 i0 = l2 < pmax ? l2 : pmax;  // the records this lane holds: i0, i0 + 1
+        const bool m0 = !ha && i0 - lo < hi - lo, m1 = !hb && i0 + 1u - lo < hi - lo;
+        if (__ballot(m0 || m1)) append2(m0, x0, m1, x1);
+    };
+#pragma unroll
+    for (int k = 0; k < PU2_D; k++) issue(k);
+    for (bool any = true; any;) {
+        any = false;
+#pragma unroll
+        for (int k = 0; k < PU2_D; k++) {
+            // (the wait also stands in front of a slot WITHOUT a step: the compiler takes x[k] for dead there and computes
+            //  the next load's offset in one of its registers -- which the load still in flight would then overwrite)
+            asm volatile("s_waitcnt vmcnt(%1)" : "+v"(x[k]) : "n"(PU2_D - 1) : "memory");
+            if (live[k]) {
+                consume(k);
+                any = true;
+            }
+            issue(k);  // (always: see above)
+        }
+    }
+    // (the slots' registers stay live -- operands of the wait -- until the last loads have landed: see above)
+#pragma unroll
+    for (int k = 0; k < PU2_D; k++) asm volatile("s_waitcnt vmcnt(0)" : "+v"(x[k]) : : "memory");
+    if (raw && lane == 0) atomicOr((unsigned long long *)&a.ctl[1], (unsigned long long)PU_FLAG_OVERFLOW);
+    close_chunk();
+    if (bad) atomicOr((unsigned long long *)&a.ctl[1], (unsigned long long)PU_FLAG_UNSORTED);
+    __syncthreads();
+    const u32 nl = s_nmiss < (u32)PU_LMISS ? s_nmiss : (u32)PU_LMISS;
+    if (nl == 0) return;
+    if (tid == 0) {
+        const u64 at = atomicAdd((unsigned long long *)&a.ctl[0], (unsigned long long)nl);
+        if (at + nl > a.miss_cap) atomicOr((unsigned long long *)&a.ctl[1], (unsigned long long)PU_FLAG_OVERFLOW);
+        s_flush_at = at;
+    }
+    __syncthreads();
+    const u64 at = s_flush_at;
+    if (at + nl <= a.miss_cap)
+        for (u32 i = (u32)tid; i < nl; i += PU2_NT) a.miss[at + i] = s_miss[i];
+}
+
 // ---- the same pass over records WITH TaxIds (union.go:195-201: the TaxId of a code is the LCA over all its records) ----
 // Beside every table slot one 16-byte word of LDS: the TaxId the entry came with (t0: the base files' fold, or the first
 // record of a new code), the smallest pre-order number (TaxDev::euler) among its records, the COMPLEMENT of the largest
@@ -1777,6 +2079,31 @@ static int probe_union_k0(ukm_ctx *c, const u64 *const *keys, const u32 *const *
     if (fb || n0 == 0) return UKM_OK;
     lap("base");
 
+    // (the pipelined plain kernel loads 16-byte pairs: later files of fewer than two records do not go through it -- their
+    //  one record is put on the list of new codes by the host, which is what the list is: records the final union adds)
+    const bool claiming = tax || ukm_env(c, "UKM_PUNION_CLAIM") != nullptr;
+    const bool v2 = !claiming && ukm_env_int(c, "UKM_PUNION_V2", 1) != 0;
+    std::vector<const u64 *> tiny;
+    if (v2) {
+        int w = k0;
+        for (int j = k0; j < S; j++) {
+            if (lens_v[(size_t)j] == 1) { tiny.push_back(keys_v[(size_t)j]); continue; }
+            if (lens_v[(size_t)j] == 0) continue;
+            keys_v[(size_t)w] = keys_v[(size_t)j];
+            lens_v[(size_t)w] = lens_v[(size_t)j];
+            w++;
+        }
+        S = w;
+        if (S < k0 + 1) {  // (nothing left to probe: the base set and the listed records are everything)
+            keys_v.push_back(nullptr);
+            lens_v.push_back(0);
+            keys = keys_v.data();
+            lens = lens_v.data();
+            S = k0 + 1;
+            keys_v[(size_t)k0] = nullptr;
+            lens_v[(size_t)k0] = 0;
+        }
+    }
     // device tables of the later files: [pointers S1][lens S1][TaxId pointers S1][file taxid | its number << 32, S1]
     const int S1all = S - k0;
     std::vector<u64> tab((size_t)4 * S1all);
@@ -1845,7 +2172,6 @@ static int probe_union_k0(ukm_ctx *c, const u64 *const *keys, const u32 *const *
     //  512 of them listed from LDS, the rest in chunks -- and a record costs half of what it costs in the tables of the
     //  TaxId pass even without TaxIds: 1000 files x 1e6, a fifth / an eighth of a universe each: 4.1 / 5.9 ms against
     //  5.9 / 7.7.  UKM_PUNION_CLAIM=1: plain files through the TaxId pass's tables all the same, an experiment.)
-    const bool claiming = tax || ukm_env(c, "UKM_PUNION_CLAIM") != nullptr;
     if (claiming) range = pt_range_for(c, n0);
     const u64 R64 = (n0 + range - 1) / range;
     if (R64 > 0x7FFFFFFEull) return UKM_OK;
@@ -1856,9 +2182,17 @@ static int probe_union_k0(ukm_ctx *c, const u64 *const *keys, const u32 *const *
     // (+ one partly used chunk of 64 per wave of the grid)
     u64 miss_cap = (u64)((double)later * std::min(1.0, 2.0 * miss_rate + 0.01)) + (1u << 20);
     miss_cap = std::min(miss_cap, later) + 64ull * (std::max(PU_NT, PT_NT) / 64) * R64 * (u64)((S1all + PU_MAXS - 1) / PU_MAXS) + later / 32;
+    miss_cap += tiny.size();
     UKM_TRY(ws_alloc_t(c, miss_cap + 1, &a.miss));
     if (tax) UKM_TRY(ws_alloc_t(c, miss_cap + 1, &a.miss_tax));
     a.miss_cap = miss_cap;
+    if (!tiny.empty()) {  // (ctl[0] = records on the list)
+        for (size_t i = 0; i < tiny.size(); i++)
+            UKM_HIP(hipMemcpyAsync(a.miss + i, tiny[i], sizeof(u64), hipMemcpyDeviceToDevice, c->stream));
+        const u64 nt = tiny.size();
+        UKM_HIP(hipMemcpyAsync(ctl, &nt, sizeof(u64), hipMemcpyHostToDevice, c->stream));
+        UKM_HIP(hipStreamSynchronize(c->stream));  // (`nt` is an object of this frame)
+    }
     for (int s0 = 0; s0 < S1all; s0 += PU_MAXS) {
         const int s1 = std::min(PU_MAXS, S1all - s0);
         // (the pointer and length rows of a batch are not adjacent in d_tab: lens sits S1all entries behind)
@@ -1893,6 +2227,7 @@ static int probe_union_k0(ukm_ctx *c, const u64 *const *keys, const u32 *const *
         (void)hipEventRecord(c->ev_k0, c->stream);
         if (claiming && a.clade_mode) hipLaunchKernelGGL((pt_probe_kernel<false, true>), dim3(a.R), dim3(PT_NT), 0, c->stream, a);
         else if (claiming) hipLaunchKernelGGL((pt_probe_kernel<false, false>), dim3(a.R), dim3(PT_NT), 0, c->stream, a);
+        else if (v2) hipLaunchKernelGGL(pu2_probe_kernel, dim3(a.R), dim3(PU2_NT), 0, c->stream, a);
         else hipLaunchKernelGGL(pu_probe_kernel, dim3(a.R), dim3(PU_NT), 0, c->stream, a);
         (void)hipEventRecord(c->ev_k1, c->stream);
         c->evk_valid = true;
