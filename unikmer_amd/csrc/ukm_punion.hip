@@ -478,14 +478,11 @@ __global__ __launch_bounds__(PU_NT) __attribute__((amdgpu_waves_per_eu(PU_WAVES,
 #ifndef PU2_NT_N
 #define PU2_NT_N 1024
 #endif
-#ifndef PU2_D_N
-#define PU2_D_N 3
-#endif
-#ifndef PU2_EXP
-#define PU2_EXP 0
+#ifndef PU2_U_N
+#define PU2_U_N 4
 #endif
 constexpr int PU2_NT = PU2_NT_N;
-constexpr int PU2_D = PU2_D_N;  // steps in flight per wave
+constexpr int PU2_U = PU2_U_N;  // steps of a batch: their loads are in flight together
 constexpr int PU2_WAVES = PU2_NT == 1024 ? 8 : 4;
 
 __device__ __forceinline__ u64 pu2_shr1(u64 v, u64 carry) {  // lane l gets v of lane l - 1, lane 0 gets `carry`
@@ -497,6 +494,8 @@ __device__ __forceinline__ u64 pu2_uniform(u64 v) {
     return ((u64)(u32)__builtin_amdgcn_readfirstlane((int)(u32)(v >> 32)) << 32) | (u32)__builtin_amdgcn_readfirstlane((int)(u32)v);
 }
 
+// ONES: some later file ends in all-ones records (the table's empty marker): they must not "match" an empty slot
+template <bool ONES>
 __global__ __launch_bounds__(PU2_NT) __attribute__((amdgpu_waves_per_eu(PU2_WAVES, PU2_WAVES))) void pu2_probe_kernel(PuArgs a) {
     // the table in two halves: slots 0 and 1 of every bucket in the first 32 KB (P), slots 2 and 3 behind them (Q).  Slots
     // fill in order, so a record is looked up in its bucket's P pair first (one 16-byte read at a 16-byte stride: all bank
@@ -605,13 +604,15 @@ __global__ __launch_bounds__(PU2_NT) __attribute__((amdgpu_waves_per_eu(PU2_WAVE
             append_global(m && !in_lds, x);
         }
     };
-    // ---- the generator: slices -> steps, everything in scalars ----
+    // ---- slices -> batches of PU2_U steps ----
     // A step = up to 128 records [lo, hi) of the 128 at `ptr` (two per lane: 2 l and 2 l + 1; lanes whose pair lies beyond
     // hi - 2 re-read the last pair that fits: duplicates of real records, harmless to the table and masked out of the order
     // check).  A slice that does not begin its file starts ONE RECORD EARLY with lo = 1: the pair (f[beg - 1], f[beg]) is
     // then checked inside lane 0 like every other pair -- no separate load for the record in front of the slice -- and a
     // last step of ONE record is moved back by one record the same way, so every load is a 16-byte pair inside the file
-    // (files of fewer than two records never come here: the host lists their record itself).
+    // (files of fewer than two records never come here: the host lists their record itself).  The loads of a batch are
+    // issued together and UNCONDITIONALLY (a step behind the slice's end re-reads the batch's first pair): straight-line
+    // code, so the compiler's own s_waitcnt counts are exact; the scalar work per step is a handful of instructions.
     auto take = [&]() -> u32 {
         u32 j = 0;
         if (lane == 0) j = atomicAdd(&s_next, 1u);
@@ -628,76 +629,12 @@ __global__ __launch_bounds__(PU2_NT) __attribute__((amdgpu_waves_per_eu(PU2_WAVE
         return m;
     };
     bool bad = false, raw = false;
-    u32 g_j = take();          // the slice the generator opens next; its cut points and pointer are already on their way
-    Meta g_m = fetch(g_j);
-    u64 g_ptr = 0;             // address of the next step's first loaded record
-    u32 g_rem = 0;             // records from g_ptr to the end of the current slice
-    u32 g_lo = 0;              // 1: the first of them lies in front of the slice
-    // what the consumer needs of a step: lo | hi << 8 | first << 16 (hi <= 128)
-    auto next_step = [&](u64 &ptr, u32 &desc) -> bool {
-        u32 first = 0;
-        while (g_rem == 0) {   // open the next slice that is not empty
-            if (g_j >= S1) return false;
-            const u64 n = g_m.end > g_m.beg ? g_m.end - g_m.beg : 0ull;
-            if (n >= 0xFFFFFF00ull) raw = true;  // (a slice of 2^32 records: the caller's other routes)
-            else if (n) {
-                g_lo = g_m.beg ? 1u : 0u;
-                g_ptr = g_m.f + 8ull * (g_m.beg - g_lo);
-                g_rem = (u32)n + g_lo;
-                first = 1;
-            }
-            g_j = take();
-            g_m = fetch(g_j);
-        }
-        const u32 cnt = g_rem < 128u ? g_rem : 128u;
-        ptr = g_ptr;
-        u32 lo = g_lo, hi = cnt;
-        if (cnt == 1u) {
-            // one record: at the start of its file the pair (0, 1) -- the file has two records --, else the pair (-1, 0)
-            if (first) { lo = 0; hi = 1; }
-            else { ptr = g_ptr - 8; lo = 1; hi = 2; }
-        }
-        desc = lo | (hi << 8) | (first << 16);
-        g_lo = 0;
-        g_ptr += 128 * 8;
-        g_rem -= cnt;
-        return true;
-    };
-    // ---- the pipeline ----
-    // The loads are inline assembly and the waits are written by hand: the compiler's own s_waitcnt placement merges "load
-    // issued" with "no load issued" paths at every join of this loop and waits with vmcnt(0) in front of every step -- for
-    // the load it has just issued: no pipeline.  Loads return in order, so "at most D - 1 vector-memory operations still
-    // outstanding" implies that the load issued D steps ago has landed, whatever the list code issued in between (its stores
-    // only make the wait more conservative); a slot without a step re-reads the base set's first pair, so the count holds
-    // on every path.  The build checks that this kernel does not spill (a spill would copy registers that are in flight).
     const u32 l2 = 2u * (u32)lane;
-    pu_u64x2 x[PU2_D];
-    u32 desc[PU2_D];
-    bool live[PU2_D];
-    auto issue = [&](int k) {
-        u64 ptr = 0;
-        u32 d = 0;
-        live[k] = next_step(ptr, d);
-        if (!live[k]) ptr = (u64)(uintptr_t)a.base;
-        desc[k] = d;
-        const u32 hi = (d >> 8) & 0xFFu;
-        const u32 pmax = hi > 2u ? hi - 2u : 0u;
-        const u32 voff = 8u * (l2 < pmax ? l2 : pmax);
-#ifdef PU2_CLOAD
-        x[k] = *(const pu_pair __attribute__((address_space(1))) *)((const char __attribute__((address_space(1))) *)(uintptr_t)ptr + voff);
-#else
-        // (s_nop 4: a vector-memory instruction that reads an SGPR a VALU instruction -- v_readfirstlane -- has just written
-        //  needs five wait states on gfx9; the compiler's hazard recogniser does not look into inline assembly)
-        asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2" : "=v"(x[k]) : "v"(voff), "s"(ptr) : "memory");
-#endif
-    };
     u64 run_carry = 0;
-    auto consume = [&](int k) {
-        const u64 x0 = x[k].x, x1 = x[k].y;
-        const u32 lo = desc[k] & 0xFFu, hi = (desc[k] >> 8) & 0xFFu;
-        const bool first = (desc[k] >> 16) != 0;
+    auto consume = [&](const pu_pair &pr, u32 lo, u32 hi) {
+        const u64 x0 = pr.x, x1 = pr.y;
         const u32 pmax = hi > 2u ? hi - 2u : 0u;
-        const u64 prev = pu2_shr1(x1, first ? 0ull : run_carry);
+        const u64 prev = pu2_shr1(x1, run_carry);
         bad |= (prev > x0 && l2 <= pmax) || x0 > x1;
         run_carry = ((u64)(u32)__builtin_amdgcn_readlane((int)(u32)(x1 >> 32), 63) << 32) | (u32)__builtin_amdgcn_readlane((int)(u32)x1, 63);
         const u32 h0 = pu_hash(x0), h1 = pu_hash(x1);
@@ -714,8 +651,10 @@ __global__ __launch_bounds__(PU2_NT) __attribute__((amdgpu_waves_per_eu(PU2_WAVE
             hb = q1.x == x1 || q1.y == x1;
             more1 = !hb && q1.y != PU_EMPTY;
         }
-        ha = ha && x0 != PU_EMPTY;
-        hb = hb && x1 != PU_EMPTY;
+        if (ONES) {  // (all-ones records would "match" an empty slot)
+            ha = ha && x0 != PU_EMPTY;
+            hb = hb && x1 != PU_EMPTY;
+        }
         if (__ballot(more0 || more1)) {  // a full bucket (0.4 %): the slow way
             if (more0) ha = member_from(x0, (h0 + 1) & (PU_BUCKETS - 1));
             if (more1) hb = member_from(x1, (h1 + 1) & (PU_BUCKETS - 1));
@@ -724,25 +663,48 @@ __global__ __launch_bounds__(PU2_NT) __attribute__((amdgpu_waves_per_eu(PU2_WAVE
         const bool m0 = !ha && i0 - lo < hi - lo, m1 = !hb && i0 + 1u - lo < hi - lo;
         if (__ballot(m0 || m1)) append2(m0, x0, m1, x1);
     };
+    u32 g_j = take();          // the next slice; its cut points and pointer are already on their way
+    Meta g_m = fetch(g_j);
+    while (g_j < S1) {
+        const Meta m = g_m;
+        g_j = take();
+        g_m = fetch(g_j);
+        const u64 n = m.end > m.beg ? m.end - m.beg : 0ull;
+        if (n == 0) continue;
+        if (n >= 0xFFFFFF00ull) { raw = true; continue; }  // (a slice of 2^32 records: the caller's other routes)
+        u32 lo = m.beg ? 1u : 0u;                          // 1: the first loaded record lies in front of the slice
+        u64 ptr = m.f + 8ull * (m.beg - lo);
+        u32 rem = (u32)n + lo;
+        run_carry = 0;
+        bool first = true;
+        while (rem) {
+            pu_pair pr[PU2_U];
+            u32 slo[PU2_U], shi[PU2_U], voff0 = 0;
 #pragma unroll
-    for (int k = 0; k < PU2_D; k++) issue(k);
-    for (bool any = true; any;) {
-        any = false;
-#pragma unroll
-        for (int k = 0; k < PU2_D; k++) {
-            // (the wait also stands in front of a slot WITHOUT a step: the compiler takes x[k] for dead there and computes
-            //  the next load's offset in one of its registers -- which the load still in flight would then overwrite)
-            asm volatile("s_waitcnt vmcnt(%1)" : "+v"(x[k]) : "n"(PU2_D - 1) : "memory");
-            if (live[k]) {
-                consume(k);
-                any = true;
+            for (int u = 0; u < PU2_U; u++) {
+                const u32 done = 128u * (u32)u;
+                const u32 cnt = rem > done ? (rem - done < 128u ? rem - done : 128u) : 0u;
+                // one record: at the start of its file the pair (0, 1) -- the file has two records --, else the pair (-1, 0)
+                const u32 back = (cnt == 1u && !(first && u == 0)) ? 1u : 0u;
+                slo[u] = back ? 1u : ((first && u == 0) ? lo : 0u);
+                shi[u] = cnt + back;
+                const u32 pmax = shi[u] > 2u ? shi[u] - 2u : 0u;
+                // (offsets from ptr - 8, so that the moved-back pair has a non-negative one; a step behind the slice's end
+                //  re-reads what step 0 reads)
+                const u32 voff = 8u + 1024u * (u32)u - 8u * back + 8u * (l2 < pmax ? l2 : pmax);
+                if (u == 0) voff0 = voff;
+                pr[u] = *(const pu_pair __attribute__((address_space(1))) *)((const char __attribute__((address_space(1))) *)(uintptr_t)(ptr - 8) +
+                                                                              (cnt ? voff : voff0));
             }
-            issue(k);  // (always: see above)
+#pragma unroll
+            for (int u = 0; u < PU2_U; u++)
+                if (shi[u]) consume(pr[u], slo[u], shi[u]);
+            const u32 took = rem < 128u * PU2_U ? rem : 128u * PU2_U;
+            rem -= took;
+            ptr += 1024ull * PU2_U;
+            first = false;
         }
     }
-    // (the slots' registers stay live -- operands of the wait -- until the last loads have landed: see above)
-#pragma unroll
-    for (int k = 0; k < PU2_D; k++) asm volatile("s_waitcnt vmcnt(0)" : "+v"(x[k]) : : "memory");
     if (raw && lane == 0) atomicOr((unsigned long long *)&a.ctl[1], (unsigned long long)PU_FLAG_OVERFLOW);
     close_chunk();
     if (bad) atomicOr((unsigned long long *)&a.ctl[1], (unsigned long long)PU_FLAG_UNSORTED);
@@ -2227,7 +2189,7 @@ static int probe_union_k0(ukm_ctx *c, const u64 *const *keys, const u32 *const *
         (void)hipEventRecord(c->ev_k0, c->stream);
         if (claiming && a.clade_mode) hipLaunchKernelGGL((pt_probe_kernel<false, true>), dim3(a.R), dim3(PT_NT), 0, c->stream, a);
         else if (claiming) hipLaunchKernelGGL((pt_probe_kernel<false, false>), dim3(a.R), dim3(PT_NT), 0, c->stream, a);
-        else if (v2) hipLaunchKernelGGL(pu2_probe_kernel, dim3(a.R), dim3(PU2_NT), 0, c->stream, a);
+        else if (v2) hipLaunchKernelGGL(pu2_probe_kernel<true>, dim3(a.R), dim3(PU2_NT), 0, c->stream, a);
         else hipLaunchKernelGGL(pu_probe_kernel, dim3(a.R), dim3(PU_NT), 0, c->stream, a);
         (void)hipEventRecord(c->ev_k1, c->stream);
         c->evk_valid = true;
