@@ -479,7 +479,7 @@ __global__ __launch_bounds__(PU_NT) __attribute__((amdgpu_waves_per_eu(PU_WAVES,
 #define PU2_NT_N 1024
 #endif
 #ifndef PU2_U_N
-#define PU2_U_N 4
+#define PU2_U_N 2
 #endif
 constexpr int PU2_NT = PU2_NT_N;
 constexpr int PU2_U = PU2_U_N;  // steps of a batch: their loads are in flight together
@@ -631,40 +631,58 @@ __global__ __launch_bounds__(PU2_NT) __attribute__((amdgpu_waves_per_eu(PU2_WAVE
     bool bad = false, raw = false;
     const u32 l2 = 2u * (u32)lane;
     u64 run_carry = 0;
-    auto consume = [&](const pu_pair &pr, u32 lo, u32 hi) {
+    // FULL: all 128 records of the step are the slice's (lo = 0, hi = 128): no validity masks
+    auto consume = [&](auto FULL, const pu_pair &pr, u32 lo, u32 hi) {
+        constexpr bool full = decltype(FULL)::value;
         const u64 x0 = pr.x, x1 = pr.y;
         const u32 pmax = hi > 2u ? hi - 2u : 0u;
         const u64 prev = pu2_shr1(x1, run_carry);
-        bad |= (prev > x0 && l2 <= pmax) || x0 > x1;
+        if (full) bad |= prev > x0 || x0 > x1;
+        else bad |= (prev > x0 && l2 <= pmax) || x0 > x1;
         run_carry = ((u64)(u32)__builtin_amdgcn_readlane((int)(u32)(x1 >> 32), 63) << 32) | (u32)__builtin_amdgcn_readlane((int)(u32)x1, 63);
         const u32 h0 = pu_hash(x0), h1 = pu_hash(x1);
         const ulonglong2 p0 = *reinterpret_cast<const ulonglong2 *>(slot(h0, 0)), p1 = *reinterpret_cast<const ulonglong2 *>(slot(h1, 0));
         bool ha = p0.x == x0 || p0.y == x0, hb = p1.x == x1 || p1.y == x1;
-        bool more0 = false, more1 = false;
-        if (!ha && p0.y != PU_EMPTY) {
-            const ulonglong2 q0 = *reinterpret_cast<const ulonglong2 *>(slot(h0, 2));
-            ha = q0.x == x0 || q0.y == x0;
-            more0 = !ha && q0.y != PU_EMPTY;
-        }
-        if (!hb && p1.y != PU_EMPTY) {
-            const ulonglong2 q1 = *reinterpret_cast<const ulonglong2 *>(slot(h1, 2));
-            hb = q1.x == x1 || q1.y == x1;
-            more1 = !hb && q1.y != PU_EMPTY;
+        // ONE masked region for the lanes of which either record has to look at slots 2 and 3 (a tenth of the records)
+        if ((!ha && p0.y != PU_EMPTY) || (!hb && p1.y != PU_EMPTY)) {
+            const ulonglong2 q0 = *reinterpret_cast<const ulonglong2 *>(slot(h0, 2)), q1 = *reinterpret_cast<const ulonglong2 *>(slot(h1, 2));
+            ha = ha || q0.x == x0 || q0.y == x0;
+            hb = hb || q1.x == x1 || q1.y == x1;
+            // a full bucket (0.4 %): the slow way
+            if (!ha && q0.y != PU_EMPTY) ha = member_from(x0, (h0 + 1) & (PU_BUCKETS - 1));
+            if (!hb && q1.y != PU_EMPTY) hb = member_from(x1, (h1 + 1) & (PU_BUCKETS - 1));
         }
         if (ONES) {  // (all-ones records would "match" an empty slot)
             ha = ha && x0 != PU_EMPTY;
             hb = hb && x1 != PU_EMPTY;
         }
-        if (__ballot(more0 || more1)) {  // a full bucket (0.4 %): the slow way
-            if (more0) ha = member_from(x0, (h0 + 1) & (PU_BUCKETS - 1));
-            if (more1) hb = member_from(x1, (h1 + 1) & (PU_BUCKETS - 1));
+        bool m0 = !ha, m1 = !hb;
+        if (!full) {
+            const u32 i0 = l2 < pmax ? l2 : pmax;  // the records this lane holds: i0, i0 + 1
+            m0 = m0 && i0 - lo < hi - lo;
+            m1 = m1 && i0 + 1u - lo < hi - lo;
         }
-        const u32 i0 = l2 < pmax ? l2 : pmax;  // the records this lane holds: i0, i0 + 1
-        const bool m0 = !ha && i0 - lo < hi - lo, m1 = !hb && i0 + 1u - lo < hi - lo;
         if (__ballot(m0 || m1)) append2(m0, x0, m1, x1);
     };
     u32 g_j = take();          // the next slice; its cut points and pointer are already on their way
     Meta g_m = fetch(g_j);
+    u64 ptr = 0;
+    u32 rem = 0;
+    // one step that is not (known to be) full: the first step of a slice, and what is left behind its full steps
+    auto general_step = [&](u32 lo, bool first) {
+        const u32 cnt = rem < 128u ? rem : 128u;
+        // one record: at the start of its file the pair (0, 1) -- the file has two records --, else the pair (-1, 0)
+        const u32 back = (cnt == 1u && !first) ? 1u : 0u;
+        const u32 slo = back ? 1u : lo, shi = cnt + back;
+        const u32 pmax = shi > 2u ? shi - 2u : 0u;
+        // (offsets from ptr - 8, so that the moved-back pair has a non-negative one)
+        const u32 voff = 8u - 8u * back + 8u * (l2 < pmax ? l2 : pmax);
+        const pu_pair pr = *(const pu_pair __attribute__((address_space(1))) *)((const char __attribute__((address_space(1))) *)(uintptr_t)(ptr - 8) + voff);
+        consume(std::false_type{}, pr, slo, shi);
+        rem -= cnt;
+        ptr += 1024;
+    };
+    const u32 voff_full = 16u * (u32)lane;
     while (g_j < S1) {
         const Meta m = g_m;
         g_j = take();
@@ -672,38 +690,22 @@ __global__ __launch_bounds__(PU2_NT) __attribute__((amdgpu_waves_per_eu(PU2_WAVE
         const u64 n = m.end > m.beg ? m.end - m.beg : 0ull;
         if (n == 0) continue;
         if (n >= 0xFFFFFF00ull) { raw = true; continue; }  // (a slice of 2^32 records: the caller's other routes)
-        u32 lo = m.beg ? 1u : 0u;                          // 1: the first loaded record lies in front of the slice
-        u64 ptr = m.f + 8ull * (m.beg - lo);
-        u32 rem = (u32)n + lo;
+        const u32 lo = m.beg ? 1u : 0u;                    // 1: the first loaded record lies in front of the slice
+        ptr = m.f + 8ull * (m.beg - lo);
+        rem = (u32)n + lo;
         run_carry = 0;
-        bool first = true;
-        while (rem) {
+        general_step(lo, true);
+        while (rem >= 128u * PU2_U) {                      // batches of full steps: their loads are in flight together
             pu_pair pr[PU2_U];
-            u32 slo[PU2_U], shi[PU2_U], voff0 = 0;
-#pragma unroll
-            for (int u = 0; u < PU2_U; u++) {
-                const u32 done = 128u * (u32)u;
-                const u32 cnt = rem > done ? (rem - done < 128u ? rem - done : 128u) : 0u;
-                // one record: at the start of its file the pair (0, 1) -- the file has two records --, else the pair (-1, 0)
-                const u32 back = (cnt == 1u && !(first && u == 0)) ? 1u : 0u;
-                slo[u] = back ? 1u : ((first && u == 0) ? lo : 0u);
-                shi[u] = cnt + back;
-                const u32 pmax = shi[u] > 2u ? shi[u] - 2u : 0u;
-                // (offsets from ptr - 8, so that the moved-back pair has a non-negative one; a step behind the slice's end
-                //  re-reads what step 0 reads)
-                const u32 voff = 8u + 1024u * (u32)u - 8u * back + 8u * (l2 < pmax ? l2 : pmax);
-                if (u == 0) voff0 = voff;
-                pr[u] = *(const pu_pair __attribute__((address_space(1))) *)((const char __attribute__((address_space(1))) *)(uintptr_t)(ptr - 8) +
-                                                                              (cnt ? voff : voff0));
-            }
 #pragma unroll
             for (int u = 0; u < PU2_U; u++)
-                if (shi[u]) consume(pr[u], slo[u], shi[u]);
-            const u32 took = rem < 128u * PU2_U ? rem : 128u * PU2_U;
-            rem -= took;
+                pr[u] = *(const pu_pair __attribute__((address_space(1))) *)((const char __attribute__((address_space(1))) *)(uintptr_t)ptr + (voff_full + 1024u * (u32)u));
+#pragma unroll
+            for (int u = 0; u < PU2_U; u++) consume(std::true_type{}, pr[u], 0u, 128u);
+            rem -= 128u * PU2_U;
             ptr += 1024ull * PU2_U;
-            first = false;
         }
+        while (rem) general_step(0u, false);
     }
     if (raw && lane == 0) atomicOr((unsigned long long *)&a.ctl[1], (unsigned long long)PU_FLAG_OVERFLOW);
     close_chunk();
