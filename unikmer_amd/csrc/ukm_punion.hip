@@ -98,13 +98,16 @@ __device__ __forceinline__ u64 pu_splitmix(u64 x) {
 }
 
 // cuts[r][j] = lower bound of the first base entry of range r in later file j (r = 0: 0, r = R: the file's length).
-// Threads of one file are neighbours: their first probes coincide, their last ones share lines (bracketing every cut
-// around its interpolated position first made the kernel slower, 1.8 -> 2.9 ms: those probes are all distinct and cold).
+// (Bracketing every cut around its interpolated position made the kernel slower in round 3, 1.8 -> 2.9 ms; a two-level
+//  search -- every 64th range, then an interpolated window between two coarse cuts -- measured the same 1.76 ms in round 6:
+//  the kernel is bound by the ~8 cold lines of a search's last levels, which either form still touches.)
 __global__ void pu_cuts_kernel(PuArgs a) {
-    const u64 gid = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    const u64 per = (u64)a.R + 1;
-    if (gid >= per * a.S1) return;
-    const u32 j = (u32)(gid / per), r = (u32)(gid % per);
+    // a block = 16 ranges x 16 files; 16 neighbouring lanes hold one range's cuts in 16 consecutive files: one 128-byte store
+    // (with the threads of a block on 256 ranges of ONE file every store was a line of its own: 1.77 -> 1.63 ms on config 3)
+    const u32 tiles_j = (a.S1 + 15) / 16;
+    const u32 tr = blockIdx.x / tiles_j, tj = blockIdx.x % tiles_j;
+    const u32 j = tj * 16 + (threadIdx.x & 15), r = tr * 16 + (threadIdx.x >> 4);
+    if (j >= a.S1 || r > a.R) return;
     const u64 len = a.lens[j];
     u64 res;
     if (r == 0) {
@@ -122,6 +125,13 @@ __global__ void pu_cuts_kernel(PuArgs a) {
         res = lo;
     }
     a.cuts[(u64)r * a.S1 + j] = res;
+}
+
+static int pu_launch_cuts(ukm_ctx *c, const PuArgs &a) {
+    const u64 blocks = (((u64)a.R + 1 + 15) / 16) * (((u64)a.S1 + 15) / 16);
+    hipLaunchKernelGGL(pu_cuts_kernel, dim3((unsigned)blocks), dim3(256), 0, c->stream, a);
+    UKM_HIP(hipGetLastError());
+    return UKM_OK;
 }
 
 // heaviest range: records of all later files inside one range (ctl[4] = max over the ranges)
@@ -489,9 +499,6 @@ __device__ __forceinline__ u64 pu2_shr1(u64 v, u64 carry) {  // lane l gets v of
     const u32 lo = (u32)__builtin_amdgcn_update_dpp((int)(u32)carry, (int)(u32)v, 0x138, 0xF, 0xF, false);          // wave_shr:1
     const u32 hi = (u32)__builtin_amdgcn_update_dpp((int)(u32)(carry >> 32), (int)(u32)(v >> 32), 0x138, 0xF, 0xF, false);
     return ((u64)hi << 32) | lo;
-}
-__device__ __forceinline__ u64 pu2_uniform(u64 v) {
-    return ((u64)(u32)__builtin_amdgcn_readfirstlane((int)(u32)(v >> 32)) << 32) | (u32)__builtin_amdgcn_readfirstlane((int)(u32)v);
 }
 
 // ONES: some later file ends in all-ones records (the table's empty marker): they must not "match" an empty slot
@@ -1233,18 +1240,13 @@ __global__ void pr_settle_kernel(PrTables t, TaxDev T, u64 n0, u32 *base_tax) {
     if (i < n0) base_tax[i] = pr_settle(t, T, t.base_st[i]);
 }
 
-// Table layout (round 5, after the PMC of the other probe kernels: LDS 60-70 % busy, two thirds of it bank conflicts of the
-// random 16-byte reads -- the bytes a record reads from LDS are what the pass costs): per bucket of four slots ONE 16-byte
-// word of 4-byte TAGS (a second hash of the code, never 0; 0 = slot free), the 8-byte codes and the 4-byte rank words in
-// arrays of their own.  A record reads its bucket's tags (16 bytes), then -- only of the slot whose tag matches -- the code
-// (8 bytes, the exact check) and the rank word (4 bytes): 28 bytes instead of the 48 of codes + words side by side.  The
-// CODES stay the authority: a slot is claimed by a 64-bit CAS on its code, its tag is stored afterwards; a reader that
-// misses a tag that is not there yet (or meets a false positive) falls through to the claim, which walks the codes.
+// Table layout: round 5 kept 4-byte TAGS per slot beside the codes (a record read 16 bytes of tags, then the code and rank
+// word of the slot whose tag matched); round 6 reads the codes themselves, P pair first (see the kernel): 12 bytes per slot.
 #ifndef PR_TNT_N
 #define PR_TNT_N 1024
 #endif
 #ifndef PR_TBUCKETS_N
-#define PR_TBUCKETS_N 1152
+#define PR_TBUCKETS_N 1536
 #endif
 #ifndef PR_TWAVES
 #define PR_TWAVES 8
@@ -1252,7 +1254,7 @@ __global__ void pr_settle_kernel(PrTables t, TaxDev T, u64 n0, u32 *base_tax) {
 // (measured on config 3's shape at half size, probe pass: 2304 buckets x 1024 threads, one workgroup per CU = 4 waves per SIMD
 //  14.3 ms; 1152 x 512 x 2 workgroups 14.9; 768 x 512 x 3 = 6 waves 12.6; 1152 x 1024 x 2 = 8 waves per SIMD 12.55)
 constexpr int PR_TNT = PR_TNT_N;               // threads of a workgroup
-constexpr int PR_TBUCKETS = PR_TBUCKETS_N;     // x 4 slots x (4 + 8 + 4) bytes = 72 KB of LDS: two workgroups of 16 waves per CU
+constexpr int PR_TBUCKETS = PR_TBUCKETS_N;     // x 4 slots x (8 + 4) bytes = 72 KB of LDS: two workgroups of 16 waves per CU
 constexpr int PR_TSLOTS = 4 * PR_TBUCKETS;
 // ONE multiplicative hash per code (v_mul_lo_u32 runs at a quarter of the VALU rate: the two products + the mul_hi of
 // the first version were a fifth of the kernel's vector work): its top bits pick the bucket, the word itself (odd: never
@@ -1266,37 +1268,37 @@ __device__ __forceinline__ u32 prt_bucket_of(u32 h) {
     return (u32)(((u64)h * (u64)PR_TBUCKETS) >> 32);
 }
 __device__ __forceinline__ u32 prt_bucket(u64 x) { return prt_bucket_of(prt_hash(x)); }
-__device__ __forceinline__ u32 prt_tag(u64 x) { return prt_hash(x) | 1u; }
 
 __global__ __launch_bounds__(PR_TNT) __attribute__((amdgpu_waves_per_eu(PR_TWAVES, PR_TWAVES))) void pr_probe_kernel(PuArgs a, PrTables t) {
-    __shared__ __attribute__((aligned(16))) u32 s_tag[PR_TSLOTS];
+    // (round 6: no tag words any more -- the codes in two halves as in pu2_probe_kernel: slots 0 and 1 of every bucket in the
+    //  first half (P), slots 2 and 3 behind them (Q); a record reads its bucket's P pair, and only a lane that does not find
+    //  it there and sees slot 1 taken reads the Q pair; then the rank word of the slot that matched.  Four tag compares, a
+    //  select chain and the dependent code read per record are gone, and the table shrinks from 16 to 12 bytes per slot.)
     __shared__ __attribute__((aligned(16))) u64 s_key[PR_TSLOTS];
     __shared__ u32 s_st[PR_TSLOTS];
+    auto sidx = [](u32 h, int q) -> int { return (q >> 1) * (PR_TSLOTS / 2) + (int)(2 * h) + (q & 1); };
     __shared__ u32 s_next, s_nins;
     __shared__ u32 s_scan[PR_TNT / 64 + 1];
     __shared__ u64 s_flush_at;
     const int tid = (int)threadIdx.x, lane = lane_id();
     const u32 r = blockIdx.x, S1 = a.S1;
     for (int i = tid; i < PR_TSLOTS; i += PR_TNT) {
-        s_tag[i] = 0u;
         s_key[i] = PU_EMPTY;
         s_st[i] = PR_NONE;
     }
     if (tid == 0) { s_next = 0; s_nins = 0; }
     __syncthreads();
     auto next_bucket = [](u32 h) -> u32 { return h + 1 == (u32)PR_TBUCKETS ? 0u : h + 1; };
-    // first free slot of the first bucket of the probe sequence that is not full, or the slot that already holds x (the
-    // codes are the authority; the tag of a fresh slot is stored behind the claim)
+    // first free slot of the first bucket of the probe sequence that is not full, or the slot that already holds x
     auto insert = [&](u64 x, bool &fresh) -> int {
         u32 h = prt_bucket(x);
         for (;; h = next_bucket(h)) {
 #pragma unroll
             for (int k = 0; k < 4; k++) {
-                const u64 old = atomicCAS((unsigned long long *)&s_key[4 * h + k], (unsigned long long)PU_EMPTY, (unsigned long long)x);
+                const u64 old = atomicCAS((unsigned long long *)&s_key[sidx(h, k)], (unsigned long long)PU_EMPTY, (unsigned long long)x);
                 if (old == PU_EMPTY || old == x) {
                     fresh = old == PU_EMPTY;
-                    if (fresh) s_tag[4 * h + k] = prt_tag(x);
-                    return (int)(4 * h + k);
+                    return sidx(h, k);
                 }
             }
         }
@@ -1306,10 +1308,9 @@ __global__ __launch_bounds__(PR_TNT) __attribute__((amdgpu_waves_per_eu(PR_TWAVE
         if (x == PU_EMPTY) return -1;
         u32 h = prt_bucket(x);
         for (;; h = next_bucket(h)) {
-            const ulonglong2 *b = reinterpret_cast<const ulonglong2 *>(&s_key[4 * h]);
-            const ulonglong2 p = b[0], q = b[1];
+            const ulonglong2 p = *reinterpret_cast<const ulonglong2 *>(&s_key[sidx(h, 0)]), q = *reinterpret_cast<const ulonglong2 *>(&s_key[sidx(h, 2)]);
             const int k = p.x == x ? 0 : (p.y == x ? 1 : (q.x == x ? 2 : (q.y == x ? 3 : -1)));
-            if (k >= 0) return (int)(4 * h) + k;
+            if (k >= 0) return sidx(h, k);
             if (q.y == PU_EMPTY) return -1;
         }
     };
@@ -1404,86 +1405,48 @@ __global__ __launch_bounds__(PR_TNT) __attribute__((amdgpu_waves_per_eu(PR_TWAVE
         }
         append_global(raw, x, ftax);
     };
-    bool bad = false;
-    // One step = 128 x U records of one file of rank rk: the codes are loaded; the tag words of ALL the step's records are
-    // read; then, of the slots whose tag matched, the codes and rank words; then every record is judged from registers.
-    auto step = [&](auto UU, const ukm_gptr<u64> f, u64 p0, u64 end, u64 len, u32 rk, u32 crk, u32 ftax) {
-        constexpr int U = decltype(UU)::value;
-        pu_pair pr[U];
-        u64 nx[U];
+    bool bad = false, raw_slice = false;
+    // N records of one file of rank rk, from registers: the P pairs of ALL of them are read; one masked region reads the Q
+    // pairs of the lanes that need them; then the rank words of the slots that matched; then every record is judged.
+    auto judge = [&](auto NN, const u64 *x, const bool *v, u32 rk, u32 crk, u32 ftax) {
+        constexpr int N = decltype(NN)::value;
+        ulonglong2 pp[N];
+        u32 hh[N];
 #pragma unroll
-        for (int u = 0; u < U; u++) {  // branch-free loads from addresses clamped into the file (see pu_probe_kernel)
-            const u64 pos = p0 + (u64)u * 128 + 2u * (u32)lane;
-            const u64 q = pos < len - 2 ? pos : len - 2;
-            const u64 q2 = pos + 2 < len ? pos + 2 : len - 1;
-            pr[u] = *(const pu_pair __attribute__((address_space(1))) *)(f + q);
-            nx[u] = f[q2];
+        for (int i = 0; i < N; i++) {
+            hh[i] = prt_bucket(x[i]);
+            pp[i] = *reinterpret_cast<const ulonglong2 *>(&s_key[sidx(hh[i], 0)]);
         }
+        int sl[N];
+        bool needq = false;
 #pragma unroll
-        for (int u = 0; u < U; u++) {
-            u64 t0 = pr[u].x, t1 = pr[u].y;
-            asm volatile("" : "+v"(t0), "+v"(t1), "+v"(nx[u]));
-            pr[u].x = t0;
-            pr[u].y = t1;
+        for (int i = 0; i < N; i++) {
+            sl[i] = pp[i].x == x[i] ? sidx(hh[i], 0) : (pp[i].y == x[i] ? sidx(hh[i], 1) : -1);
+            needq = needq || (sl[i] < 0 && pp[i].y != PU_EMPTY);
         }
-        const bool whole = p0 + (u64)U * 128 <= end && p0 + (u64)U * 128 + 2 <= len;  // (wave-uniform) two records and one behind them in every lane
-        u64 x[2 * U];
-        bool v[2 * U];
+        if (needq) {
 #pragma unroll
-        for (int u = 0; u < U; u++) {
-            const u64 pos = p0 + (u64)u * 128 + 2u * (u32)lane;
-            if (whole) {
-                x[2 * u] = pr[u].x;
-                x[2 * u + 1] = pr[u].y;
-                v[2 * u] = v[2 * u + 1] = true;
-                bad |= pr[u].x > pr[u].y || pr[u].y > nx[u];
-            } else {
-                const u32 nv = pos + 1 < end ? 2u : (pos < end ? 1u : 0u);
-                const bool shifted = pos > len - 2;  // pos = len - 1 (or beyond: nv = 0): the record is the pair's second
-                const u64 x0 = shifted ? pr[u].y : pr[u].x;
-                const u64 x1 = nv == 2 ? pr[u].y : x0;
-                const u64 x2 = nv == 2 ? (pos + 2 < len ? nx[u] : PU_EMPTY) : ((!shifted && pos + 1 < len) ? pr[u].y : PU_EMPTY);
-                x[2 * u] = x0;
-                x[2 * u + 1] = x1;
-                v[2 * u] = nv >= 1;
-                v[2 * u + 1] = nv == 2;
-                if (nv >= 1) bad |= x0 > x1 || x1 > x2;
+            for (int i = 0; i < N; i++) {
+                const ulonglong2 q = *reinterpret_cast<const ulonglong2 *>(&s_key[sidx(hh[i], 2)]);
+                if (sl[i] < 0) sl[i] = q.x == x[i] ? sidx(hh[i], 2) : (q.y == x[i] ? sidx(hh[i], 3) : -1);
             }
         }
-        uint4 tg[2 * U];
-        u32 hh[2 * U], tt[2 * U];
+        u32 ww[N];
 #pragma unroll
-        for (int i = 0; i < 2 * U; i++) {
-            const u32 hx = prt_hash(x[i]);
-            hh[i] = prt_bucket_of(hx);
-            tt[i] = hx | 1u;
-            tg[i] = *reinterpret_cast<const uint4 *>(&s_tag[4 * hh[i]]);
-        }
-        int sl[2 * U];
-        bool mt[2 * U];
-        u64 kk[2 * U];
-        u32 ww[2 * U];
-#pragma unroll
-        for (int i = 0; i < 2 * U; i++) {
-            const bool m0 = tg[i].x == tt[i], m1 = tg[i].y == tt[i], m2 = tg[i].z == tt[i], m3 = tg[i].w == tt[i];
-            mt[i] = m0 | m1 | m2 | m3;
-            sl[i] = (int)(4 * hh[i]) + (m0 ? 0 : (m1 ? 1 : (m2 ? 2 : 3)));  // (no match: slot 3, harmless)
-            kk[i] = s_key[sl[i]];
-            ww[i] = s_st[sl[i]];
-        }
-        bool more[2 * U];
+        for (int i = 0; i < N; i++) ww[i] = s_st[sl[i] < 0 ? 0 : sl[i]];
+        bool more[N];
         bool any = false;
 #pragma unroll
-        for (int i = 0; i < 2 * U; i++) {
-            const bool hit = mt[i] && kk[i] == x[i] && x[i] != PU_EMPTY;
+        for (int i = 0; i < N; i++) {
+            const bool hit = sl[i] >= 0 && x[i] != PU_EMPTY;
             const bool outside = rk < (ww[i] & 0xFFFFu) || crk < (ww[i] >> 16);
-            if (!hit) sl[i] = -1;  // (no tag, a tag that is not stored yet, a false positive, a full bucket: the codes decide)
+            if (!hit) sl[i] = -1;  // (not in the bucket's four slots, or a full bucket: the codes of the probe sequence decide)
             more[i] = v[i] && (!hit || outside);
-            any |= more[i];
+            any = any || more[i];
         }
         if (__ballot(any) == 0ull) return;
 #pragma unroll
-        for (int i = 0; i < 2 * U; i++) {
+        for (int i = 0; i < N; i++) {
             if (__ballot(more[i]) == 0ull) continue;
             rare(more[i], sl[i], x[i], rk, crk, ftax);
         }
@@ -1505,30 +1468,84 @@ __global__ __launch_bounds__(PR_TNT) __attribute__((amdgpu_waves_per_eu(PR_TWAVE
         }
         return m;
     };
+    // The streaming skeleton of pu2_probe_kernel (round 6): a slice = one general first step (it starts one record early when
+    // the slice does not begin its file: the boundary pair is checked inside lane 0), batches of full steps without
+    // validity masks, general steps for what is left; the order check takes a pair's predecessor from the neighbouring
+    // lane (DPP wave_shr:1) instead of a third load per lane.
+    const u32 l2 = 2u * (u32)lane;
+    u64 run_carry = 0, ptr = 0;
+    u32 rem = 0, rk = 0, crk = 0, ftax = 0;
+    auto order = [&](u64 x0, u64 x1, bool cross) {
+        const u64 prev = pu2_shr1(x1, run_carry);
+        bad |= (cross && prev > x0) || x0 > x1;
+        run_carry = ((u64)(u32)__builtin_amdgcn_readlane((int)(u32)(x1 >> 32), 63) << 32) | (u32)__builtin_amdgcn_readlane((int)(u32)x1, 63);
+    };
+    auto general_step = [&](u32 lo, bool first) {
+        const u32 cnt = rem < 128u ? rem : 128u;
+        // one record: at the start of its file the pair (0, 1) -- the file has two records --, else the pair (-1, 0)
+        const u32 back = (cnt == 1u && !first) ? 1u : 0u;
+        const u32 slo = back ? 1u : lo, shi = cnt + back;
+        const u32 pmax = shi > 2u ? shi - 2u : 0u;
+        const u32 i0 = l2 < pmax ? l2 : pmax;  // the records this lane holds: i0, i0 + 1 (lanes beyond re-read the last pair)
+        const pu_pair pr = *(const pu_pair __attribute__((address_space(1))) *)((const char __attribute__((address_space(1))) *)(uintptr_t)(ptr - 8) +
+                                                                               (8u - 8u * back + 8u * i0));
+        order(pr.x, pr.y, l2 <= pmax);
+        const u64 x[2] = {pr.x, pr.y};
+        const bool v[2] = {i0 - slo < shi - slo, i0 + 1u - slo < shi - slo};
+        judge(std::integral_constant<int, 2>{}, x, v, rk, crk, ftax);
+        rem -= cnt;
+        ptr += 1024;
+    };
+    const u32 voff_full = 16u * (u32)lane;
+#ifndef PR_U_N
+#define PR_U_N 1
+#endif
+    constexpr int PRU = PR_U_N;
     u32 j = take();
     Meta cur = fetch(j);
     while (j < S1) {
         const u32 jn = take();
         const Meta nxt = fetch(jn);
-        const auto f = as_global((const u64 *)(uintptr_t)cur.f);
-        const u64 len = cur.len, end = cur.end < cur.beg ? cur.beg : cur.end;
-        const u32 ftax = (u32)cur.cte, rk = (u32)(cur.cte >> 32), crk = 0xFFFFu - rk;
-        if (len < 2) {  // (a one-record file: no 16-byte load fits)
-            if (end > cur.beg) {
-                const u64 x = f[0];
+        const u64 end = cur.end < cur.beg ? cur.beg : cur.end, n = end - cur.beg;
+        ftax = (u32)cur.cte;
+        rk = (u32)(cur.cte >> 32);
+        crk = 0xFFFFu - rk;
+        if (n >= 0xFFFFFF00ull) raw_slice = true;  // (a slice of 2^32 records: the caller's other routes)
+        else if (cur.len < 2) {  // (a one-record file: no 16-byte load fits)
+            if (n) {
+                const u64 x = as_global((const u64 *)(uintptr_t)cur.f)[0];
                 rare(lane == 0, -1, x, rk, crk, ftax);
             }
-        } else {
-            u64 p0 = cur.beg;
-            while (p0 < end) {
-                const u64 rem = end - p0;
-                if (rem > 128) { step(std::integral_constant<int, 2>{}, f, p0, end, len, rk, crk, ftax); p0 += 256; }
-                else { step(std::integral_constant<int, 1>{}, f, p0, end, len, rk, crk, ftax); p0 += 128; }
+        } else if (n) {
+            const u32 lo = cur.beg ? 1u : 0u;
+            ptr = cur.f + 8ull * (cur.beg - lo);
+            rem = (u32)n + lo;
+            run_carry = 0;
+            general_step(lo, true);
+            while (rem >= 128u * PRU) {
+                pu_pair pr[PRU];
+#pragma unroll
+                for (int u = 0; u < PRU; u++)
+                    pr[u] = *(const pu_pair __attribute__((address_space(1))) *)((const char __attribute__((address_space(1))) *)(uintptr_t)ptr + (voff_full + 1024u * (u32)u));
+                u64 x[2 * PRU];
+                bool v[2 * PRU];
+#pragma unroll
+                for (int u = 0; u < PRU; u++) {
+                    order(pr[u].x, pr[u].y, true);
+                    x[2 * u] = pr[u].x;
+                    x[2 * u + 1] = pr[u].y;
+                    v[2 * u] = v[2 * u + 1] = true;
+                }
+                judge(std::integral_constant<int, 2 * PRU>{}, x, v, rk, crk, ftax);
+                rem -= 128u * PRU;
+                ptr += 1024ull * PRU;
             }
+            while (rem) general_step(0u, false);
         }
         j = jn;
         cur = nxt;
     }
+    if (raw_slice && lane == 0) atomicOr((unsigned long long *)&a.ctl[1], (unsigned long long)PU_FLAG_OVERFLOW);
     close_chunk();
     if (bad) atomicOr((unsigned long long *)&a.ctl[1], (unsigned long long)PU_FLAG_UNSORTED);
     __syncthreads();
@@ -2167,8 +2184,7 @@ static int probe_union_k0(ukm_ctx *c, const u64 *const *keys, const u32 *const *
         a.S1 = (u32)s1;
         WsMark mark = ws_mark(c);
         UKM_TRY(ws_alloc_t(c, ((size_t)a.R + 1) * s1, &a.cuts));
-        const u64 ncuts = ((u64)a.R + 1) * (u64)s1;
-        hipLaunchKernelGGL(pu_cuts_kernel, dim3((unsigned)((ncuts + 255) / 256)), dim3(256), 0, c->stream, a);
+        UKM_TRY(pu_launch_cuts(c, a));
         lap("cuts");
         {
             // One workgroup streams everything that falls into its range: later files whose records crowd into a few
@@ -2235,7 +2251,7 @@ static int probe_union_k0(ukm_ctx *c, const u64 *const *keys, const u32 *const *
 
 // Base entries per range of the ranked pass (pt_range_for's rule with its own table size)
 static u32 pr_range_for(const ukm_ctx *c, u64 n0) {
-    const u64 slots = (u64)std::max(1, c->num_cu) * (u64)std::max(1, (160 * 1024) / (PR_TSLOTS * 16 + 1024));  // (workgroups resident at once)
+    const u64 slots = (u64)std::max(1, c->num_cu) * (u64)std::max(1, (160 * 1024) / (PR_TSLOTS * 12 + 1024));  // (workgroups resident at once)
     const u64 r_full = (n0 + PR_TBUCKETS - 1) / PR_TBUCKETS;
     if (r_full >= 16 * slots) return (u32)PR_TBUCKETS;
     const u64 rounds = (r_full + slots - 1) / slots;
@@ -2420,8 +2436,7 @@ static int probe_union_ranked(ukm_ctx *c, const u64 *const *keys_in, const u64 *
         a.S1 = (u32)s1;
         WsMark mark = ws_mark(c);
         UKM_TRY(ws_alloc_t(c, ((size_t)a.R + 1) * s1, &a.cuts));
-        const u64 ncuts = ((u64)a.R + 1) * (u64)s1;
-        hipLaunchKernelGGL(pu_cuts_kernel, dim3((unsigned)((ncuts + 255) / 256)), dim3(256), 0, c->stream, a);
+        UKM_TRY(pu_launch_cuts(c, a));
         lap("cuts");
         {
             hipLaunchKernelGGL(pu_load_kernel, dim3((a.R + 255) / 256), dim3(256), 0, c->stream, a);
@@ -2672,8 +2687,7 @@ int ukm_dev_probe_common(ukm_ctx *c, const u64 *const *keys, const u32 *const *t
     if (tax) UKM_TRY(ws_alloc_t(c, list_cap + 1, &a.miss_tax));
     a.miss_cap = list_cap;
     UKM_TRY(ws_alloc_t(c, ((size_t)a.R + 1) * S1, &a.cuts));
-    const u64 ncuts = ((u64)a.R + 1) * (u64)S1;
-    hipLaunchKernelGGL(pu_cuts_kernel, dim3((unsigned)((ncuts + 255) / 256)), dim3(256), 0, c->stream, a);
+    UKM_TRY(pu_launch_cuts(c, a));
     {
         hipLaunchKernelGGL(pu_load_kernel, dim3((a.R + 255) / 256), dim3(256), 0, c->stream, a);
         UKM_HIP(hipGetLastError());
@@ -2827,8 +2841,7 @@ int ukm_dev_place_merge(ukm_ctx *c, const u64 *const *keys, const u32 *const *ta
     a.miss = out;
     a.miss_tax = tax ? tout : nullptr;
     UKM_TRY(ws_alloc_t(c, ((size_t)a.R + 1) * S, &a.cuts));
-    const u64 ncuts = ((u64)a.R + 1) * (u64)S;
-    hipLaunchKernelGGL(pu_cuts_kernel, dim3((unsigned)((ncuts + 255) / 256)), dim3(256), 0, c->stream, a);
+    UKM_TRY(pu_launch_cuts(c, a));
     lap("cuts");
     (void)hipEventRecord(c->ev_k0, c->stream);
     if (tax) hipLaunchKernelGGL(pl_merge_kernel<true>, dim3(a.R), dim3(PL_NT), 0, c->stream, a);
