@@ -96,9 +96,13 @@ void pf_probe_kernel(PfArgs a) {
     __shared__ unsigned short s_idx[PF_SLOTS];
     constexpr bool EULER = OP == UKM_OP_INTER && TAX;  // inter with taxids: LCA of all files' taxids from pre-order numbers
     constexpr int PER = EULER ? PF_PER_TAXFOLD : PF_PER, MAXL = PF_NT * PER;
-    __shared__ u32 s_cnt[MAXL];
-    __shared__ u32 s_tax[TAX ? MAXL : 1];
-    __shared__ u32 s_min[EULER ? MAXL : 1], s_max[EULER ? MAXL : 1];
+    // inter with taxids keeps a record's four words side by side (round 6: x = counter + flags, y = its own taxid, z / w = the
+    // smallest / largest number folded so far): a hit reads them with ONE 16-byte LDS read instead of four or five reads
+    __shared__ u32 s_cnt[EULER ? 1 : MAXL];
+    __shared__ u32 s_tax[(TAX && !EULER) ? MAXL : 1];
+    __shared__ uint4 s_st4[EULER ? MAXL : 1];
+    auto CNT = [&](u32 i) -> u32 & { if constexpr (EULER) return s_st4[i].x; else return s_cnt[i]; };
+    auto TAXR = [&](u32 i) -> u32 & { if constexpr (EULER) return s_st4[i].y; else return s_tax[i]; };
     __shared__ u32 s_scan[PF_NT / 64 + 1];
     __shared__ u32 s_next, s_done, s_dead;  // s_dead: no record of the range can survive any more
     constexpr bool FOLD_TAX = TAX && (OP == UKM_OP_INTER || CMP);  // the later files' taxids are read
@@ -120,17 +124,17 @@ void pf_probe_kernel(PfArgs a) {
         if (i < ne) {
             const u64 e = f0[e0 + i];
             ent[k] = e;
-            s_cnt[i] = 0;
+            CNT(i) = 0;
             if (TAX) {
                 const u32 tf = t0 ? t0[e0 + i] : 0u;
-                s_tax[i] = tf;
-                if (EULER) {
+                TAXR(i) = tf;
+                if constexpr (EULER) {
                     u32 ef = tf < a.T.size ? a.T.euler[tf] : 0u;
                     // (with one-byte clade codes the words hold clade << 24 | number: see the step)
                     if (ef && a.T.clade8) ef |= (u32)a.T.clade8[tf] << 24;
-                    s_min[i] = ef ? ef : 0xFFFFFFFFu;
-                    s_max[i] = ef;
-                    if (!ef) s_cnt[i] = PF_BAD;
+                    s_st4[i].z = ef ? ef : 0xFFFFFFFFu;
+                    s_st4[i].w = ef;
+                    if (!ef) s_st4[i].x = PF_BAD;
                 }
             }
             if (e0 + i + 1 < len0) {  // file 0 strictly increasing (also across the range's end)
@@ -183,109 +187,56 @@ void pf_probe_kernel(PfArgs a) {
                 // diff -t (diff.go:404-409): the hit removes the code unless the file's taxid equals the survivor's own or
                 // lies below it.  The survivor's taxid never changes, so the files may come in any order; a code that is
                 // already gone needs no LCA (with taxids that rarely nest that is nearly every hit after the first).
-                if (s_cnt[idx] == 0) {
-                    const u32 ta = s_tax[idx];
+                if (CNT(idx) == 0) {
+                    const u32 ta = TAXR(idx);
                     const bool keep = ta == tb || lca_dev(a.T, tb, ta) == ta;
-                    if (!keep) s_cnt[idx] = 1;
+                    if (!keep) CNT(idx) = 1;
                 }
             } else {
-                s_cnt[idx] = 1;  // (every writer stores the same value)
+                CNT(idx) = 1;  // (every writer stores the same value)
             }
         } else {
-            atomicAdd(&s_cnt[idx], 1u);  // (inter with taxids does not come here: see the step)
+            atomicAdd(&CNT(idx), 1u);  // (inter with taxids does not come here: see the step)
         }
     };
-    auto step = [&](auto UU, const ukm_gptr<u64> f, const ukm_gptr<u32> t, u64 p0, u64 end, u64 len, bool dead) {
-        constexpr int U = decltype(UU)::value;
-        pf_pair pr[U];
-        pf_tpair tq[U];
-        u64 nx[U];
-        int li[OP == UKM_OP_INTER && TAX ? 2 * U : 1];
-        u32 lt[OP == UKM_OP_INTER && TAX ? 2 * U : 1];
-#pragma unroll
-        for (int u = 0; u < U; u++) {  // branch-free loads from addresses clamped into the file (see ukm_punion.hip)
-            const u64 pos = p0 + (u64)u * 128 + 2u * (u32)lane;
-            const u64 q = pos < len - 2 ? pos : len - 2;
-            const u64 q2 = pos + 2 < len ? pos + 2 : len - 1;
-            pr[u] = *(const pf_pair __attribute__((address_space(1))) *)(f + q);
-            nx[u] = f[q2];
-            tq[u] = pf_tpair{0, 0};
-            if (FOLD_TAX && t && !dead) tq[u] = *(const pf_tpair __attribute__((address_space(1))) *)(t + q);  // (wave-uniform test)
-        }
-#pragma unroll
-        for (int u = 0; u < U; u++) {
-            u64 v0 = pr[u].x, v1 = pr[u].y;
-            asm volatile("" : "+v"(v0), "+v"(v1), "+v"(nx[u]));  // (pins the loads in front of the processing)
-            pr[u].x = v0;
-            pr[u].y = v1;
-        }
-#pragma unroll
-        for (int u = 0; u < U; u++) {
-            const u64 pos = p0 + (u64)u * 128 + 2u * (u32)lane;
-            const u32 nv = pos + 1 < end ? 2u : (pos < end ? 1u : 0u);
-            const bool shifted = pos > len - 2;  // pos = len - 1: the record is the pair's second
-            const u64 x0 = shifted ? pr[u].y : pr[u].x;
-            const u64 x1 = pr[u].y;
-            const u32 tb0 = shifted ? tq[u].y : tq[u].x, tb1 = tq[u].y;
-            // strictly increasing, every neighbouring pair of the file once (also across slices)
-            if (nv == 2) {
-                if (x0 == x1) flags |= PF_FLAG_DUP;
-                if (x0 > x1) flags |= PF_FLAG_UNSORTED;
-                if (pos + 2 < len) {
-                    if (x1 == nx[u]) flags |= PF_FLAG_DUP;
-                    if (x1 > nx[u]) flags |= PF_FLAG_UNSORTED;
-                }
-            } else if (nv == 1 && !shifted && pos + 1 < len) {
-                if (x0 == x1) flags |= PF_FLAG_DUP;
-                if (x0 > x1) flags |= PF_FLAG_UNSORTED;
-            }
-            if (dead) {  // (wave-uniform) nothing of this range is left: the file is only checked for its order
-                if constexpr (OP == UKM_OP_INTER && TAX) li[2 * u] = li[2 * u + 1] = -1;
-                continue;
-            }
-            if constexpr (OP == UKM_OP_INTER && TAX) {
-                // inter with taxids: count the hits now, fold the taxids below with the table reads of all of the
-                // step's LCAs in flight together
-                li[2 * u] = nv >= 1 ? find(x0) : -1;
-                li[2 * u + 1] = nv == 2 ? find(x1) : -1;
-                lt[2 * u] = tb0;
-                lt[2 * u + 1] = tb1;
-            } else {
-                if (nv >= 1) {
-                    const int i0 = find(x0);
-                    if (i0 >= 0) hit(i0, tb0);
-                }
-                if (nv == 2) {
-                    const int i1 = find(x1);
-                    if (i1 >= 0) hit(i1, tb1);
-                }
-            }
-        }
-        if (dead) return;
+    // N records of one later file (from registers; v[q]: the record is one of the slice's): hits are counted / folded
+    auto process = [&](auto NN, const u64 *x, const u32 *tb, const bool *v) {
+        constexpr int N = decltype(NN)::value;
         if constexpr (OP == UKM_OP_INTER && TAX) {
+            // inter with taxids: count the hits now, fold the taxids below with the table reads of all of the
+            // step's LCAs in flight together
+            int li[N];
+#pragma unroll
+            for (int q = 0; q < N; q++) li[q] = v[q] ? find(x[q]) : -1;
+            const u32 *lt = tb;
             // The LCA of a SET of taxids is the LCA of its members with the smallest and the largest pre-order number
             // (TaxDev::euler): a hit only has to fold its taxid's number into the record's minimum and maximum — two
             // commutative LDS atomics, files in any order — and ONE table LCA per survivor follows at the end.  Taxid 0 /
             // unknown ids (number 0) make the result 0 (lca_dev: absorbing) unless every taxid of the record is the
             // same (lca_dev: a == b -> a), which the NEQ flag keeps track of.
-            u32 en[2 * U];
+            u32 en[N];
             const bool byc = a.T.clade8 != nullptr;  // (uniform over the launch)
             // hits whose taxid has to be folded, as a bit mask.  (Marking the others by li[q] = -1, as rounds 3-4 did, let a hit
             // that carries the record's own taxid through to the fold below once that fold had two branches: such hits came
             // with the table's entry for taxid 0 and voided the record -- found by test_range_fold_equals_chained_fold_large)
             u32 needm = 0;
+            // files finished BEFORE these hits are counted (acquire: the counts are not moved in front of the read): a record
+            // that is in every file has one hit from each of them in its counter by now, so a counter below that number
+            // belongs to a record some finished file did not have -- dead.  Read once per step: an older (smaller) number only
+            // lets a few dead records through to the fold, whose words nobody looks at.
+            const u32 finished = __hip_atomic_load(&s_done, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
 #pragma unroll
-            for (int q = 0; q < 2 * U; q++) {
+            for (int q = 0; q < N; q++) {
                 bool need = false;
                 if (li[q] >= 0) {
-                    // files finished BEFORE this hit is counted (acquire: the count is not moved in front of the read): a
-                    // record that is in every file has one hit from each of them in its counter by now, so a counter
-                    // that is not above that number belongs to a record some finished file did not have — dead
-                    const u32 finished = __hip_atomic_load(&s_done, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    const uint4 st = s_st4[li[q]];
                     // (a record that is already behind -- most hits in a collection's non-core codes are on such records --
-                    //  needs no count any more: a plain read instead of an atomic with a return value)
-                    if ((s_cnt[li[q]] & PF_CNT_MASK) >= finished)
-                        need = ((atomicAdd(&s_cnt[li[q]], 1u) + 1) & PF_CNT_MASK) > finished && lt[q] != s_tax[li[q]];
+                    //  needs no count any more; one that is not gets its count WITHOUT a return value: it can only grow, so
+                    //  it is above `finished` afterwards whatever the other waves add)
+                    if ((st.x & PF_CNT_MASK) >= finished) {
+                        __hip_atomic_fetch_add(&s_st4[li[q]].x, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        need = lt[q] != st.y;
+                    }
                 }
                 needm |= need ? (1u << q) : 0u;
                 const u32 tq_ = (need && lt[q] < a.T.size) ? lt[q] : 0u;
@@ -293,13 +244,14 @@ void pf_probe_kernel(PfArgs a) {
                 en[q] = byc ? (u32)a.T.clade8[tq_] : a.T.euler[tq_];
             }
 #pragma unroll
-            for (int q = 0; q < 2 * U; q++) {
+            for (int q = 0; q < N; q++) {
                 if (!((needm >> q) & 1u)) continue;
+                u32 *w = &s_st4[li[q]].x;
                 if (!byc) {
-                    atomicOr(&s_cnt[li[q]], en[q] ? PF_NEQ : (PF_NEQ | PF_BAD));
+                    atomicOr(w, en[q] ? PF_NEQ : (PF_NEQ | PF_BAD));
                     if (en[q]) {
-                        atomicMin(&s_min[li[q]], en[q]);
-                        atomicMax(&s_max[li[q]], en[q]);
+                        atomicMin(w + 2, en[q]);
+                        atomicMax(w + 3, en[q]);
                     }
                     continue;
                 }
@@ -308,22 +260,111 @@ void pf_probe_kernel(PfArgs a) {
                 // clades has the LCA of those two clade nodes whatever the exact numbers are: the 4-byte number of a
                 // taxid (a random read of a table of 4 B x ids) is only fetched while the record's interval lies inside
                 // ONE clade and the taxid is of that clade -- for taxids that are not related, next to never -- and a taxid
-                // inside an interval of several clades costs two LDS reads and no atomic at all.  (The interval only ever
+                // inside an interval of several clades costs one LDS read and no atomic at all.  (The interval only ever
                 // widens: a record that is still inside one clade at the end has had every one of its taxids folded exactly.)
                 const u32 c = en[q];
-                if (c == 0) { atomicOr(&s_cnt[li[q]], PF_NEQ | PF_BAD); continue; }
-                if (!(s_cnt[li[q]] & PF_NEQ)) atomicOr(&s_cnt[li[q]], PF_NEQ);
-                const u32 cmn = s_min[li[q]] >> 24, cmx = s_max[li[q]] >> 24;
+                if (c == 0) { atomicOr(w, PF_NEQ | PF_BAD); continue; }
+                const uint4 st = s_st4[li[q]];
+                if (!(st.x & PF_NEQ)) atomicOr(w, PF_NEQ);
+                const u32 cmn = st.z >> 24, cmx = st.w >> 24;
                 if (cmn == cmx && c == cmn) {
                     const u32 e = (c << 24) | a.T.euler[lt[q]];
-                    atomicMin(&s_min[li[q]], e);
-                    atomicMax(&s_max[li[q]], e);
+                    atomicMin(w + 2, e);
+                    atomicMax(w + 3, e);
                 } else {
-                    if (c < cmn) atomicMin(&s_min[li[q]], (c << 24) | 0xFFFFFFu);
-                    if (c > cmx) atomicMax(&s_max[li[q]], c << 24);
+                    if (c < cmn) atomicMin(w + 2, (c << 24) | 0xFFFFFFu);
+                    if (c > cmx) atomicMax(w + 3, c << 24);
                 }
             }
+        } else {
+#pragma unroll
+            for (int q = 0; q < N; q++)
+                if (v[q]) {
+                    const int i0 = find(x[q]);
+                    if (i0 >= 0) hit(i0, tb[q]);
+                }
         }
+    };
+    // The streaming skeleton of pu2_probe_kernel (ukm_punion.hip, round 6).  A STEP = up to 128 records [lo, hi) of the 128
+    // at `ptr` (two per lane; lanes whose pair lies beyond hi - 2 re-read the last pair that fits).  A slice that does not
+    // begin its file starts one record early (lo = 1): the pair (f[beg - 1], f[beg]) is then checked inside lane 0 like every
+    // other pair, and a last step of one record is moved back by one record the same way -- every load is a 16-byte pair
+    // inside the file, and no third load per lane fetches the record behind a pair: its predecessor is the neighbouring
+    // lane's second record (DPP wave_shr:1), lane 0 takes the previous step's last record from a scalar.  A slice = one
+    // general first step, batches of full steps (no validity masks), general steps for what is left.
+    const u32 l2 = 2u * (u32)lane;
+    u64 run_carry = 0, ptr = 0, tptr = 0;
+    bool carry_valid = false;
+    u32 rem = 0;
+    // strictly increasing, every neighbouring pair of the file once (also across slices); cross: this lane's pair is not a
+    // re-read one (its predecessor is the record in front of it)
+    auto order = [&](u64 x0, u64 x1, bool cross) {
+        const u32 lo = (u32)__builtin_amdgcn_update_dpp((int)(u32)run_carry, (int)(u32)x1, 0x138, 0xF, 0xF, false);          // wave_shr:1
+        const u32 hi = (u32)__builtin_amdgcn_update_dpp((int)(u32)(run_carry >> 32), (int)(u32)(x1 >> 32), 0x138, 0xF, 0xF, false);
+        const u64 prev = ((u64)hi << 32) | lo;
+        if (cross && (lane > 0 || carry_valid)) {
+            if (prev == x0) flags |= PF_FLAG_DUP;
+            if (prev > x0) flags |= PF_FLAG_UNSORTED;
+        }
+        if (x0 == x1) flags |= PF_FLAG_DUP;
+        if (x0 > x1) flags |= PF_FLAG_UNSORTED;
+        run_carry = ((u64)(u32)__builtin_amdgcn_readlane((int)(u32)(x1 >> 32), 63) << 32) | (u32)__builtin_amdgcn_readlane((int)(u32)x1, 63);
+        carry_valid = true;
+    };
+    auto general_step = [&](u32 lo, bool first, bool dead) {
+        const u32 cnt = rem < 128u ? rem : 128u;
+        // one record: at the start of its file the pair (0, 1) -- the file has two records --, else the pair (-1, 0)
+        const u32 back = (cnt == 1u && !first) ? 1u : 0u;
+        const u32 slo = back ? 1u : lo, shi = cnt + back;
+        const u32 pmax = shi > 2u ? shi - 2u : 0u;
+        const u32 i0 = l2 < pmax ? l2 : pmax;  // the records this lane holds: i0, i0 + 1
+        const u32 ri = 1u - back + i0;         // (record index from ptr - 8 bytes)
+        const pf_pair pr = *(const pf_pair __attribute__((address_space(1))) *)((const char __attribute__((address_space(1))) *)(uintptr_t)(ptr - 8) + 8u * ri);
+        pf_tpair tq = pf_tpair{0, 0};
+        if (FOLD_TAX && tptr && !dead)  // (wave-uniform test)
+            tq = *(const pf_tpair __attribute__((address_space(1))) *)((const char __attribute__((address_space(1))) *)(uintptr_t)(tptr - 4) + 4u * ri);
+        // (a moved-back pair begins with the previous step's last record itself: nothing in front of it to compare with)
+        order(pr.x, pr.y, l2 <= pmax && !back);
+        if (!dead) {
+            const u64 x[2] = {pr.x, pr.y};
+            const u32 tb[2] = {tq.x, tq.y};
+            // every record of the step exactly ONCE (hits are counted): the lanes whose own pair fits, and -- an odd number
+            // of records -- the first lane behind them for the last record (the others re-read that pair: not theirs)
+            const bool own = l2 <= pmax;
+            const bool v[2] = {own && i0 - slo < shi - slo, (own || l2 == pmax + 1u) && i0 + 1u - slo < shi - slo};
+            process(std::integral_constant<int, 2>{}, x, tb, v);
+        }
+        rem -= cnt;
+        ptr += 1024;
+        if (tptr) tptr += 512;
+    };
+    constexpr int PFU = 2;
+    auto full_batch = [&](bool dead) {
+        pf_pair pr[PFU];
+        pf_tpair tq[PFU];
+#pragma unroll
+        for (int u = 0; u < PFU; u++) {
+            pr[u] = *(const pf_pair __attribute__((address_space(1))) *)((const char __attribute__((address_space(1))) *)(uintptr_t)ptr + (16u * (u32)lane + 1024u * (u32)u));
+            tq[u] = pf_tpair{0, 0};
+            if (FOLD_TAX && tptr && !dead)
+                tq[u] = *(const pf_tpair __attribute__((address_space(1))) *)((const char __attribute__((address_space(1))) *)(uintptr_t)tptr + (8u * (u32)lane + 512u * (u32)u));
+        }
+        u64 x[2 * PFU];
+        u32 tb[2 * PFU];
+        bool v[2 * PFU];
+#pragma unroll
+        for (int u = 0; u < PFU; u++) {
+            order(pr[u].x, pr[u].y, true);
+            x[2 * u] = pr[u].x;
+            x[2 * u + 1] = pr[u].y;
+            tb[2 * u] = tq[u].x;
+            tb[2 * u + 1] = tq[u].y;
+            v[2 * u] = v[2 * u + 1] = true;
+        }
+        if (!dead) process(std::integral_constant<int, 2 * PFU>{}, x, tb, v);
+        rem -= 128u * PFU;
+        ptr += 1024ull * PFU;
+        if (tptr) tptr += 512ull * PFU;
     };
     auto take = [&]() -> u32 {
         u32 j = 0;
@@ -352,7 +393,7 @@ void pf_probe_kernel(PfArgs a) {
         const u32 finished = OP == UKM_OP_INTER ? __hip_atomic_load(&s_done, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) : 0u;
         bool any = false;
         for (u32 i = (u32)lane; i < ne; i += 64) {
-            const u32 w = s_cnt[i];
+            const u32 w = CNT(i);
             any |= OP == UKM_OP_INTER ? ((EULER ? (w & PF_CNT_MASK) : w) >= finished) : w == 0;
         }
         return __ballot(any) == 0ull;
@@ -370,19 +411,22 @@ void pf_probe_kernel(PfArgs a) {
             dead = true;
             if (lane == 0) s_dead = 1;
         }
-        if (len < 2) {  // (a one-record file: no 16-byte load fits)
-            if (!dead && end > cur.beg && lane == 0) {
+        const u64 n = end - cur.beg;
+        if (n >= 0xFFFFFF00ull) flags |= PF_FLAG_DUP;  // (a slice of 2^32 records: the exact routes)
+        else if (len < 2) {  // (a one-record file: no 16-byte load fits)
+            if (!dead && n && lane == 0) {
                 const int i0 = find(f[0]);
                 if (i0 >= 0) hit(i0, (FOLD_TAX && t) ? t[0] : 0u);
             }
-        } else {
-            u64 p0 = cur.beg;
-            while (p0 < end) {
-                const u64 rem = end - p0;
-                if (rem > 256) { step(std::integral_constant<int, 4>{}, f, t, p0, end, len, dead); p0 += 512; }
-                else if (rem > 128) { step(std::integral_constant<int, 2>{}, f, t, p0, end, len, dead); p0 += 256; }
-                else { step(std::integral_constant<int, 1>{}, f, t, p0, end, len, dead); p0 += 128; }
-            }
+        } else if (n) {
+            const u32 lo = cur.beg ? 1u : 0u;
+            ptr = cur.f + 8ull * (cur.beg - lo);
+            tptr = cur.t ? cur.t + 4ull * (cur.beg - lo) : 0ull;
+            rem = (u32)n + lo;
+            carry_valid = false;
+            general_step(lo, true, dead);
+            while (rem >= 128u * PFU) full_batch(dead);
+            while (rem) general_step(0u, false, dead);
         }
         // RELEASE: the wave's hit atomics on s_cnt are ordered before the count of finished files that the `need` shortcut
         // reads with ACQUIRE (the hardware keeps a wave's LDS operations in order; the release keeps the compiler from
@@ -401,7 +445,7 @@ void pf_probe_kernel(PfArgs a) {
         bool alive = false;
         u32 w = 0;
         if (i < ne) {
-            w = s_cnt[i];
+            w = CNT(i);
             alive = OP == UKM_OP_INTER ? (EULER ? (w & PF_CNT_MASK) : w) == S1 : w == 0;
         }
         u32 total = 0;
@@ -410,9 +454,9 @@ void pf_probe_kernel(PfArgs a) {
             const u64 o = (u64)r * L + base + excl;
             a.tmp_k[o] = ent[k];
             if (TAX) {
-                u32 tx = s_tax[i];
+                u32 tx = TAXR(i);
                 if (EULER && (w & PF_NEQ)) {
-                    const u32 mn = s_min[i], mx = s_max[i];
+                    const u32 mn = s_st4[EULER ? i : 0].z, mx = s_st4[EULER ? i : 0].w;
                     if (w & PF_BAD) tx = 0u;
                     else if (a.T.clade8 == nullptr) tx = lca_dev(a.T, a.T.node_at[mn], a.T.node_at[mx]);
                     else if ((mn >> 24) != (mx >> 24)) tx = lca_clade_pair(a.T, mn >> 24, mx >> 24);
