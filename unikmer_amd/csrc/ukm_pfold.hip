@@ -34,7 +34,11 @@ constexpr int PF_BUCKET_BITS = 10;
 constexpr int PF_BUCKETS = 1 << PF_BUCKET_BITS;
 constexpr int PF_SLOTS = 4 * PF_BUCKETS;
 constexpr int PF_PER = 3;                // records of file 0 per thread (range length <= 1536; three workgroups per CU)
-constexpr int PF_PER_TAXFOLD = 4;        // inter with taxids: 2048 (more per-record state: two workgroups per CU)
+
+#ifndef PF_NT_EULER_N
+#define PF_NT_EULER_N 1024
+#endif
+constexpr int PF_NT_EULER = PF_NT_EULER_N;  // inter with taxids: 16 waves per workgroup, two workgroups per CU = 8 waves per SIMD
 constexpr int PF_MAXL = PF_NT * PF_PER;
 constexpr u32 PF_CNT_MASK = 0x3FFFFFFFu, PF_NEQ = 0x40000000u, PF_BAD = 0x80000000u;  // inter + taxids: flags in the counter word
 constexpr int PF_MINL = 256;
@@ -90,12 +94,14 @@ typedef pf_u32x2 __attribute__((aligned(4))) pf_tpair;
 
 // (three 512-thread workgroups per CU = 6 waves per SIMD: 85 registers; inter with taxids: 72 KB of LDS, two per CU)
 template <int OP, bool TAX, bool CMP = false>
-__global__ __launch_bounds__(PF_NT) __attribute__((amdgpu_waves_per_eu((OP == UKM_OP_INTER && TAX) ? 4 : 6, (OP == UKM_OP_INTER && TAX) ? 4 : 6)))
+__global__ __launch_bounds__((OP == UKM_OP_INTER && TAX) ? PF_NT_EULER : PF_NT)
+__attribute__((amdgpu_waves_per_eu((OP == UKM_OP_INTER && TAX) ? PF_NT_EULER / 128 : 6, (OP == UKM_OP_INTER && TAX) ? PF_NT_EULER / 128 : 6)))
 void pf_probe_kernel(PfArgs a) {
     __shared__ __attribute__((aligned(32))) u64 s_tab[PF_SLOTS];
     __shared__ unsigned short s_idx[PF_SLOTS];
     constexpr bool EULER = OP == UKM_OP_INTER && TAX;  // inter with taxids: LCA of all files' taxids from pre-order numbers
-    constexpr int PER = EULER ? PF_PER_TAXFOLD : PF_PER, MAXL = PF_NT * PER;
+    constexpr int NT = EULER ? PF_NT_EULER : PF_NT;
+    constexpr int PER = EULER ? 2048 / PF_NT_EULER : PF_PER, MAXL = NT * PER;
     // inter with taxids keeps a record's four words side by side (round 6: x = counter + flags, y = its own taxid, z / w = the
     // smallest / largest number folded so far): a hit reads them with ONE 16-byte LDS read instead of four or five reads
     __shared__ u32 s_cnt[EULER ? 1 : MAXL];
@@ -103,7 +109,7 @@ void pf_probe_kernel(PfArgs a) {
     __shared__ uint4 s_st4[EULER ? MAXL : 1];
     auto CNT = [&](u32 i) -> u32 & { if constexpr (EULER) return s_st4[i].x; else return s_cnt[i]; };
     auto TAXR = [&](u32 i) -> u32 & { if constexpr (EULER) return s_st4[i].y; else return s_tax[i]; };
-    __shared__ u32 s_scan[PF_NT / 64 + 1];
+    __shared__ u32 s_scan[NT / 64 + 1];
     __shared__ u32 s_next, s_done, s_dead;  // s_dead: no record of the range can survive any more
     constexpr bool FOLD_TAX = TAX && (OP == UKM_OP_INTER || CMP);  // the later files' taxids are read
     const int tid = (int)threadIdx.x, lane = lane_id();
@@ -113,13 +119,13 @@ void pf_probe_kernel(PfArgs a) {
     const u64 len0 = sload_u64(&a.tab[2 * (u64)S]);
     const u64 e0 = (u64)r * L;
     const u32 ne = (u32)((len0 - e0 < (u64)L) ? (len0 - e0) : (u64)L);
-    for (int i = tid; i < PF_SLOTS; i += PF_NT) s_tab[i] = PF_EMPTY;
+    for (int i = tid; i < PF_SLOTS; i += NT) s_tab[i] = PF_EMPTY;
     if (tid == 0) { s_next = 0; s_done = 0; s_dead = 0; }
     u32 flags = 0;
     u64 ent[PER];
 #pragma unroll
     for (int k = 0; k < PER; k++) {
-        const u32 i = (u32)tid + (u32)k * PF_NT;
+        const u32 i = (u32)tid + (u32)k * NT;
         ent[k] = PF_EMPTY;
         if (i < ne) {
             const u64 e = f0[e0 + i];
@@ -148,7 +154,7 @@ void pf_probe_kernel(PfArgs a) {
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < PER; k++) {
-        const u32 i = (u32)tid + (u32)k * PF_NT;
+        const u32 i = (u32)tid + (u32)k * NT;
         const u64 e = ent[k];
         if (i >= ne || e == PF_EMPTY) continue;
         // first free slot of the first bucket of its probe sequence that is not full (slots fill in order, nothing is
@@ -441,7 +447,7 @@ void pf_probe_kernel(PfArgs a) {
     u32 base = 0;
 #pragma unroll
     for (int k = 0; k < PER; k++) {
-        const u32 i = (u32)tid + (u32)k * PF_NT;
+        const u32 i = (u32)tid + (u32)k * NT;
         bool alive = false;
         u32 w = 0;
         if (i < ne) {
@@ -449,7 +455,7 @@ void pf_probe_kernel(PfArgs a) {
             alive = OP == UKM_OP_INTER ? (EULER ? (w & PF_CNT_MASK) : w) == S1 : w == 0;
         }
         u32 total = 0;
-        const u32 excl = block_excl_scan_u32<PF_NT>(alive ? 1u : 0u, s_scan, &total);
+        const u32 excl = block_excl_scan_u32<NT>(alive ? 1u : 0u, s_scan, &total);
         if (alive) {
             const u64 o = (u64)r * L + base + excl;
             a.tmp_k[o] = ent[k];
@@ -510,13 +516,13 @@ int ukm_dev_probe_fold(ukm_ctx *c, int op, const u64 *const *keys, const u32 *co
     static std::atomic<int> slots_cache[2];
     if (!slots_cache[euler].load(std::memory_order_relaxed)) {
         int per_cu = 0;
-        const hipError_t e = euler ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pf_probe_kernel<UKM_OP_INTER, true>, PF_NT, 0)
+        const hipError_t e = euler ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pf_probe_kernel<UKM_OP_INTER, true>, PF_NT_EULER, 0)
                                    : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pf_probe_kernel<UKM_OP_DIFF, true, true>, PF_NT, 0);
         if (e != hipSuccess || per_cu <= 0) per_cu = 2;
         slots_cache[euler].store(per_cu * c->num_cu, std::memory_order_relaxed);
     }
     const u64 slots = (u64)slots_cache[euler].load(std::memory_order_relaxed);
-    const u64 maxl = (u64)PF_NT * (euler ? PF_PER_TAXFOLD : PF_PER);
+    const u64 maxl = euler ? 2048ull : (u64)PF_NT * PF_PER;
     u64 L = (lens[0] + slots - 1) / slots;
     L = std::min<u64>(std::max<u64>(L, PF_MINL), maxl);
     const u64 R64 = (lens[0] + L - 1) / L;
@@ -558,7 +564,7 @@ int ukm_dev_probe_fold(ukm_ctx *c, int op, const u64 *const *keys, const u32 *co
     hipLaunchKernelGGL(pf_cuts_kernel, dim3((unsigned)((ncuts + 255) / 256)), dim3(256), 0, c->stream, a);
     (void)hipEventRecord(c->ev_k0, c->stream);
     if (op == UKM_OP_INTER) {
-        if (tax) hipLaunchKernelGGL((pf_probe_kernel<UKM_OP_INTER, true>), dim3(a.R), dim3(PF_NT), 0, c->stream, a);
+        if (tax) hipLaunchKernelGGL((pf_probe_kernel<UKM_OP_INTER, true>), dim3(a.R), dim3(PF_NT_EULER), 0, c->stream, a);
         else hipLaunchKernelGGL((pf_probe_kernel<UKM_OP_INTER, false>), dim3(a.R), dim3(PF_NT), 0, c->stream, a);
     } else {
         if (cmp) hipLaunchKernelGGL((pf_probe_kernel<UKM_OP_DIFF, true, true>), dim3(a.R), dim3(PF_NT), 0, c->stream, a);
