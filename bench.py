@@ -335,6 +335,10 @@ def main():
                           "union_frac": (12.0 * (na + nb) + 12.0 * nu) / (tu2 * 1e-3) / 1e9 / 8000.0,
                           "inter_frac": (12.0 * (na + nb) + 12.0 * ni) / (ti2 * 1e-3) / 1e9 / 8000.0,
                           "algorithmic_bytes": "12 B per input and output record (u64 code + u32 taxid)",
+                          "checked": "a sanity check of the bench leg, NOT parity: output sizes, and one window of %d intersection "
+                                     "records against the library's own bulk LCA entry point (ukm_lca) on the matching input taxids; "
+                                     "the per-record union is size-checked only.  Parity of this kernel against the oracle: "
+                                     "tests/test_gpu_parity.py (taxid set operations), tests/test_gpu_filetax.py" % w,
                           "generator": "taxid = 1 + splitmix64(seed ^ code) mod T with one seed per file, complete 8-ary tree of depth 7 "
                                        "(SURVEY 8(d)): uniformly random, every match is an LCA of two unrelated nodes"}
             taxid_variant = {"outside_timed_region": True, "set_size": n, "one_taxid_per_file": per_file, "per_record_taxids": per_record,

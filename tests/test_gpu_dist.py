@@ -193,14 +193,14 @@ def test_sampled_splitters_two_ranks_real_context(tmp_path):
     assert load("sampled").max() / load("sampled").mean() < 1.10
 
 
-def _run_bench_two_ranks(extra):
+def _run_bench_two_ranks(extra, world=2):
     import json
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, UKM_BENCH_ONE_GPU="1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", str(world), "--steps", "2", "--warmup", "1",
            "--set-size", "1e6", "--cpu-sample", "0"] + extra
     r = subprocess.run(cmd, capture_output=True, text=True, env=env, cwd=root, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
@@ -234,6 +234,23 @@ def test_bench_two_ranks_incl_exchange():
     assert res["config"]["global_set_size"] == 2_000_000
     assert res["roofline"]["frac"] > 0 and res["cpu_baseline"] is None
     assert res["roofline"]["traffic"] is None or res["roofline"]["traffic_from_profile"]["note"].startswith("profile-derived")
+
+
+def test_bench_eight_ranks_replay_of_the_drivers_launch_line():
+    """The driver's N = 8 launch line (`python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 ... bench.py --gpus 8`)
+    replayed on ONE GPU (UKM_BENCH_ONE_GPU: eight ranks share cuda:0, gloo control plane): no 8-GPU node has ever run it
+    (SCALE_rNN.json: skipped), so this is what keeps `bench.py --gpus 8` launchable -- the W = 8 splitters, eight-way
+    all-to-all-v, per-rank rebuilds and the line's fields."""
+    res = _run_bench_two_ranks([], world=8)
+    assert res["n_gpus"] == 8 and res["value"] > 0 and res["scaling"] == "weak"
+    assert res["config"]["per_gpu_set_size"] == 1_000_000 and res["config"]["global_set_size"] == 8_000_000
+    assert res["value_is"].startswith("end to end")
+    assert res["value"] == res["value_incl_exchange"] == res["incl_exchange"]["value"]
+    assert "error" not in res.get("exchange", {}), res.get("exchange")
+    assert "skipped" in res["incl_exchange"]["exchange_cabi"]      # (RCCL needs a device per rank)
+    assert res["value_prepartitioned"] > 0
+    pipe = res["incl_exchange"]["pipelined_4_subranges"]
+    assert "error" not in pipe and pipe["value"] > 0, pipe
 
 
 def test_bench_two_ranks_strong_scaling_and_no_exchange():

@@ -141,7 +141,11 @@ def main():
         t, med = best(f)
         assert bool((work[1:] >= work[:-1]).all())
         res["sort_u64_62bit"] = {"call_ms": t, "median_ms": med, "keys_per_s": n / t * 1e3,
-                                 "GBps_algorithmic(8n+8*16n)": (8 * n + 8 * 16 * n) / t / 1e6}
+                                 # bytes the route moves (one histogram read, two scatter passes, one LDS bucket pass): THE figure
+                                 "GBps_moved(8n+2*16n+16n)": (8 * n + 2 * 16 * n + 16 * n) / t / 1e6,
+                                 "frac_of_8TBps": (8 * n + 2 * 16 * n + 16 * n) / t / 1e6 / 8000.0,
+                                 # (SURVEY 8(d)'s 8-pass LSD count, 8n + 8 * 16n, describes a route that no longer exists: footnote only)
+                                 "survey_formula_bytes(8n+8*16n)": float(8 * n + 8 * 16 * n)}
         # library reference on the same box: torch.sort -> rocPRIM radix sort (64-bit keys, all 8 bytes)
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ts = []

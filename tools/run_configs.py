@@ -104,13 +104,15 @@ def main():
         w = nb - 100 * 30
         res["config2_count_sort_k31_100Mbp"] = {"ms": ms, "bases_per_s": nb / ms * 1e3, "distinct": u.numel(),
                                                 "phases_ms": dict(t), "windows": w,
-                                                "roofline": roof_hbm((nb + 8 * w) + (8 * w + 16 * w * 8) + (8 * w + 8 * u.numel()), ms,
-                                                                     "SURVEY 8(d): encode 1 B/base + 8 B/window; LSB radix sort 8n + 16nP with "
-                                                                     "P = 8 passes; unique 8n + 8u"),
-                                                "roofline_moved": roof_hbm((nb + 8 * w) + (8 * w + 2 * 16 * w + 16 * w) + (8 * w + 8 * u.numel()), ms,
-                                                                           "what the route actually moves: the sort is one histogram read, TWO scatter "
-                                                                           "passes and one LDS bucket pass (5.6 GB per 1e8 keys instead of 13.6)"),
-                                                "roofline_sort_moved": roof_hbm(8 * w + 2 * 16 * w + 16 * w, t["sort"], "sort alone, bytes the route moves")}
+                                                # THE fraction = bytes the route moves (round-5 review: the survey's 8-pass LSD byte
+                                                # count describes a route that no longer exists and gave "fractions" above 1)
+                                                "roofline": roof_hbm((nb + 8 * w) + (8 * w + 2 * 16 * w + 16 * w) + (8 * w + 8 * u.numel()), ms,
+                                                                     "bytes the route moves: encode 1 B/base + 8 B/window; sort = one histogram read, "
+                                                                     "TWO scatter passes and one LDS bucket pass (5.6 GB per 1e8 keys); unique 8n + 8u"),
+                                                "roofline_sort": roof_hbm(8 * w + 2 * 16 * w + 16 * w, t["sort"], "sort alone, bytes the route moves"),
+                                                "survey_formula": {"bytes": float((nb + 8 * w) + (8 * w + 16 * w * 8) + (8 * w + 8 * u.numel())),
+                                                                   "is": "SURVEY 8(d)'s count for an 8-pass LSD sort (8n + 16nP, P = 8): a footnote, "
+                                                                         "NOT a roofline fraction -- this route makes three passes over HBM"}}
         del bases, codes, uniq
 
     if "3" in want:
