@@ -37,13 +37,9 @@ namespace {
 #define PU_K0_N 8
 #endif
 constexpr int PU_K0 = PU_K0_N;    // files merged into the base set
-#ifndef PU_NT_N
-#define PU_NT_N 512
-#endif
 #ifndef PU_WAVES
 #define PU_WAVES 4
 #endif
-constexpr int PU_NT = PU_NT_N;    // threads of a probe workgroup
 constexpr int PU_RANGE = 2048;    // base entries per range
 constexpr int PU_BUCKET_BITS = 11;  // 2048 buckets x 4 slots x 8 B = 64 KB of LDS: two workgroups per CU
 constexpr int PU_BUCKETS = 1 << PU_BUCKET_BITS;
@@ -223,268 +219,23 @@ static u32 pu_clade_mode(const ukm_ctx *c, const TaxDev &T, bool tax, u64 hits, 
     return (hits > 0 && same * 16 < hits && runs * 2 < hits) ? 1u : 0u;
 }
 
-__global__ __launch_bounds__(PU_NT) __attribute__((amdgpu_waves_per_eu(PU_WAVES, PU_WAVES))) void pu_probe_kernel(PuArgs a) {
-    __shared__ __attribute__((aligned(32))) u64 s_tab[PU_SLOTS];
-    __shared__ u64 s_miss[PU_LMISS];
-    __shared__ u32 s_next, s_nmiss, s_nins;
-    __shared__ u64 s_flush_at;
-    const int tid = (int)threadIdx.x, lane = lane_id();
-    const u32 r = blockIdx.x, S1 = a.S1;
-    for (int i = tid; i < PU_SLOTS; i += PU_NT) s_tab[i] = PU_EMPTY;
-    if (tid == 0) { s_next = 0; s_nmiss = 0; s_nins = 0; }
-    __syncthreads();
-    // the table of this range's base entries (distinct; an all-ones code can not be told from an empty slot and is
-    // left out: records with that code are "misses" and meet their base entry again in the final union)
-    {
-        const u64 b0 = (u64)r * PU_RANGE;
-        const u32 nb = (u32)((a.n0 - b0 < (u64)PU_RANGE) ? (a.n0 - b0) : (u64)PU_RANGE);
-        constexpr int PER = (PU_RANGE + PU_NT - 1) / PU_NT;
-        u64 ent[PER];
-#pragma unroll
-        for (int i = 0; i < PER; i++) {  // (all loads in flight before the first insert)
-            const u32 idx = (u32)tid + (u32)i * PU_NT;
-            ent[i] = a.base[b0 + (idx < nb ? idx : 0)];
-            if (idx >= nb) ent[i] = PU_EMPTY;
-        }
-#pragma unroll
-        for (int i = 0; i < PER; i++) {
-            const u64 e = ent[i];
-            if (e == PU_EMPTY) continue;
-            // first free slot of the first bucket of its probe sequence that is not full (slots fill in order, nothing
-            // is ever removed: "slot 3 taken" = "bucket full" for every later reader)
-            u32 h = pu_hash(e);
-            for (bool placed = false; !placed; h = (h + 1) & (PU_BUCKETS - 1)) {
-#pragma unroll
-                for (int k = 0; k < 4 && !placed; k++) {
-                    const u64 old = atomicCAS((unsigned long long *)&s_tab[4 * h + k], (unsigned long long)PU_EMPTY, (unsigned long long)e);
-                    placed = old == PU_EMPTY || old == e;
-                }
-            }
-        }
-    }
-    __syncthreads();
-    // one bucket = 32 bytes = two ds_read_b128: with one entry per bucket on average 0.4 % of the buckets are full, so a
-    // wave's lookup runs 1.2 rounds (slot-by-slot linear probing ran as many rounds as the unluckiest of 64 lanes needed:
-    // ~160 instructions per record)
-    auto member_from = [&](u64 x, u32 h) -> bool {
-        for (;;) {
-            const ulonglong2 *b = reinterpret_cast<const ulonglong2 *>(&s_tab[4 * h]);
-            const ulonglong2 p = b[0], q = b[1];
-            if (p.x == x || p.y == x || q.x == x || q.y == x) return x != PU_EMPTY;
-            if (q.y == PU_EMPTY) return false;
-            h = (h + 1) & (PU_BUCKETS - 1);
-        }
-    };
-    auto member = [&](u64 x) -> bool { return member_from(x, pu_hash(x)); };
-    // two lookups with their four LDS reads in flight together; a full bucket (0.4 %) continues the slow way
-    auto member2 = [&](u64 xa, u64 xb, bool &ha, bool &hb) {
-        const u32 h0 = pu_hash(xa), h1 = pu_hash(xb);
-        const ulonglong2 *b0 = reinterpret_cast<const ulonglong2 *>(&s_tab[4 * h0]);
-        const ulonglong2 *b1 = reinterpret_cast<const ulonglong2 *>(&s_tab[4 * h1]);
-        const ulonglong2 p0 = b0[0], q0 = b0[1], p1 = b1[0], q1 = b1[1];
-        ha = (p0.x == xa) | (p0.y == xa) | (q0.x == xa) | (q0.y == xa);
-        hb = (p1.x == xb) | (p1.y == xb) | (q1.x == xb) | (q1.y == xb);
-        const bool more0 = !ha && q0.y != PU_EMPTY, more1 = !hb && q1.y != PU_EMPTY;
-        ha = ha && xa != PU_EMPTY;
-        hb = hb && xb != PU_EMPTY;
-        if (more0) ha = member_from(xa, (h0 + 1) & (PU_BUCKETS - 1));
-        if (more1) hb = member_from(xb, (h1 + 1) & (PU_BUCKETS - 1));
-    };
-    // A record that is not in the table is a NEW code of this range: the first lane to put it into the table (same
-    // insertion as above) owns it, every later occurrence — the same code comes with every other file — is a hit.
-    // On config 3 that leaves 8e5 list entries instead of 3.6e7.  (All-ones codes and, once the table has doubled,
-    // further new codes are listed without being inserted: duplicates in the list are harmless.)
-    auto claim = [&](u64 x) -> bool {
-        if (x == PU_EMPTY || s_nins >= (u32)PU_RANGE) return true;
-        u32 h = pu_hash(x);
-        for (;; h = (h + 1) & (PU_BUCKETS - 1)) {
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const u64 old = atomicCAS((unsigned long long *)&s_tab[4 * h + k], (unsigned long long)PU_EMPTY, (unsigned long long)x);
-                if (old == PU_EMPTY) { atomicAdd(&s_nins, 1u); return true; }
-                if (old == x) return false;
-            }
-        }
-    };
-    // New codes collect in an LDS list that leaves with ONE atomic on the global counter at the end.  What does not fit
-    // goes to the global list directly, in CHUNKS of PU_CHUNK slots that a wave reserves with one atomic (an atomic per
-    // wave step that saw a miss — 3e7 of them before the codes were claimed — serialised the kernel at 380 ms); slots
-    // of a chunk that stay unused are filled with a copy of one of the wave's codes (duplicates vanish in sort + unique).
-    const u64 lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
-    u64 chunk_at = 0, fill = 0;  // wave-uniform
-    u32 chunk_cap = 0, chunk_used = 0;
-    auto close_chunk = [&]() {
-        if ((u32)lane < chunk_cap - chunk_used) a.miss[chunk_at + chunk_used + (u32)lane] = fill;
-        chunk_cap = chunk_used = 0;
-    };
-    auto append_global = [&](bool m, u64 x) {
-        const u64 mask = __ballot(m);
-        if (mask == 0ull) return;
-        const u32 n = (u32)__popcll(mask);
-        const int lead = __ffsll((long long)mask) - 1;
-        if (n > chunk_cap - chunk_used) {
-            close_chunk();
-            const u32 want = n > PU_CHUNK ? 64u : PU_CHUNK;
-            u64 at = 0;
-            if (lane == lead) at = atomicAdd((unsigned long long *)&a.ctl[0], (unsigned long long)want);
-            at = __shfl(at, lead, 64);
-            if (at + want > a.miss_cap) {
-                if (lane == lead) atomicOr((unsigned long long *)&a.ctl[1], (unsigned long long)PU_FLAG_OVERFLOW);
-                return;  // (the host discards everything)
-            }
-            chunk_at = at;
-            chunk_cap = want;
-        }
-        fill = __shfl(x, lead, 64);
-        if (m) a.miss[chunk_at + chunk_used + (u32)__popcll(mask & lt)] = x;
-        chunk_used += n;
-    };
-    auto append = [&](bool missing, u64 x) {
-        if (__ballot(missing) == 0ull) return;
-        const bool m = missing && claim(x);
-        const u64 mask = __ballot(m);
-        if (mask == 0ull) return;
-        const int lead = __ffsll((long long)mask) - 1;
-        u32 at = 0;
-        if (lane == lead) at = atomicAdd(&s_nmiss, (u32)__popcll(mask));
-        at = (u32)__shfl((int)at, lead, 64) + (u32)__popcll(mask & lt);
-        const bool in_lds = m && at < (u32)PU_LMISS;
-        if (in_lds) s_miss[at] = x;
-        append_global(m && !in_lds, x);
-    };
-    // A WAVE takes one file's slice at a time (next free one from an LDS counter): everything about the slice is
-    // wave-uniform, the lanes stream it 128 records per step, up to four steps of loads in flight; the cut points of
-    // the NEXT slice are fetched (scalar loads) while this one is streamed.
-    bool bad = false;
-    auto step = [&](auto UU, const ukm_gptr<u64> f, u64 p0, u64 end, u64 len) {
-        constexpr int U = decltype(UU)::value;
-        // Branch-free loads (a load inside a conditional made the compiler wait for each one in turn: 8 round trips
-        // per step): the pair is read from an address clamped into the file, what it means is sorted out afterwards.
-        pu_pair pr[U];
-        u64 nx[U];
-#pragma unroll
-        for (int u = 0; u < U; u++) {
-            const u64 pos = p0 + (u64)u * 128 + 2u * (u32)lane;
-            const u64 q = pos < len - 2 ? pos : len - 2;
-            const u64 q2 = pos + 2 < len ? pos + 2 : len - 1;
-            pr[u] = *(const pu_pair __attribute__((address_space(1))) *)(f + q);
-            nx[u] = f[q2];
-        }
-#pragma unroll
-        for (int u = 0; u < U; u++) {
-            // (pins every load in front of the processing: the compiler otherwise sinks the `nx` load of the first step
-            //  into the branch that uses it and waits for it there — a second round trip per step)
-            u64 t0 = pr[u].x, t1 = pr[u].y;
-            asm volatile("" : "+v"(t0), "+v"(t1), "+v"(nx[u]));
-            pr[u].x = t0;
-            pr[u].y = t1;
-        }
-        if (p0 + (u64)U * 128 <= end && p0 + (u64)U * 128 + 2 <= len) {
-            // every lane has two records and a record behind them (wave-uniform test): no validity logic
-#pragma unroll
-            for (int u = 0; u < U; u++) {
-                const u64 x0 = pr[u].x, x1 = pr[u].y;
-                bad |= x0 > x1 || x1 > nx[u];
-                bool h0, h1;
-                member2(x0, x1, h0, h1);
-                append(!h0, x0);
-                append(!h1, x1);
-            }
-            return;
-        }
-#pragma unroll
-        for (int u = 0; u < U; u++) {
-            const u64 pos = p0 + (u64)u * 128 + 2u * (u32)lane;
-            const u32 nv = pos + 1 < end ? 2u : (pos < end ? 1u : 0u);
-            const bool shifted = pos > len - 2;  // pos = len - 1 (or beyond: nv = 0): the record is the pair's second
-            const u64 x0 = shifted ? pr[u].y : pr[u].x;
-            const u64 x1 = nv == 2 ? pr[u].y : x0;
-            // the record behind the last valid one (order check, also across slices); all ones behind the file
-            const u64 x2 = nv == 2 ? (pos + 2 < len ? nx[u] : PU_EMPTY) : ((!shifted && pos + 1 < len) ? pr[u].y : PU_EMPTY);
-            const bool v0 = nv >= 1, v1 = nv == 2;
-            if (v0) bad |= x0 > x1 || x1 > x2;
-            bool h0, h1;
-            member2(x0, x1, h0, h1);
-            append(v0 && !h0, x0);
-            append(v1 && !h1, x1);
-        }
-    };
-    auto take = [&]() -> u32 {
-        u32 j = 0;
-        if (lane == 0) j = atomicAdd(&s_next, 1u);
-        return (u32)__builtin_amdgcn_readfirstlane((int)j);
-    };
-    struct Meta { u64 beg, end, len, f; };
-    auto fetch = [&](u32 j) -> Meta {
-        Meta m = {0, 0, 0, 0};
-        if (j < S1) {
-            m.beg = sload_u64(&a.cuts[(u64)r * S1 + j]);
-            m.end = sload_u64(&a.cuts[(u64)(r + 1) * S1 + j]);
-            m.len = sload_u64(&a.lens[j]);
-            m.f = sload_u64((const u64 *)&a.files[j]);
-        }
-        return m;
-    };
-    u32 j = take();
-    Meta cur = fetch(j);
-    while (j < S1) {
-        const u32 jn = take();
-        const Meta nxt = fetch(jn);
-        const auto f = as_global((const u64 *)(uintptr_t)cur.f);
-        const u64 len = cur.len, end = cur.end < cur.beg ? cur.beg : cur.end;
-        if (len < 2) {  // (a one-record file: no 16-byte load fits)
-            if (end > cur.beg) {
-                const u64 x = f[0];
-                append(lane == 0 && !member(x), x);
-            }
-        } else {
-            u64 p0 = cur.beg;
-            while (p0 < end) {
-                const u64 rem = end - p0;
-#ifndef PU_MAXU
-#define PU_MAXU 4
-#endif
-                if (PU_MAXU >= 4 && rem > 256) { step(std::integral_constant<int, 4>{}, f, p0, end, len); p0 += 512; }
-                else if (rem > 128) { step(std::integral_constant<int, 2>{}, f, p0, end, len); p0 += 256; }
-                else { step(std::integral_constant<int, 1>{}, f, p0, end, len); p0 += 128; }
-            }
-        }
-        j = jn;
-        cur = nxt;
-    }
-    close_chunk();
-    if (bad) atomicOr((unsigned long long *)&a.ctl[1], (unsigned long long)PU_FLAG_UNSORTED);
-    __syncthreads();
-    const u32 nl = s_nmiss < (u32)PU_LMISS ? s_nmiss : (u32)PU_LMISS;
-    if (nl == 0) return;
-    if (tid == 0) {
-        const u64 at = atomicAdd((unsigned long long *)&a.ctl[0], (unsigned long long)nl);
-        if (at + nl > a.miss_cap) atomicOr((unsigned long long *)&a.ctl[1], (unsigned long long)PU_FLAG_OVERFLOW);
-        s_flush_at = at;
-    }
-    __syncthreads();
-    const u64 at = s_flush_at;
-    if (at + nl <= a.miss_cap)
-        for (u32 i = (u32)tid; i < nl; i += PU_NT) a.miss[at + i] = s_miss[i];
-}
-
-// ---- round 6: the plain pass as ONE software pipeline per wave (pu2_probe_kernel) ----------------------------------------
-// What bound pu_probe_kernel (profiles/r03_punion_pmc.txt, r05_notes.md 1c): neither bytes nor the table reads but WAITING --
-// 58 % of the wave-cycles sat in s_waitcnt.  Its step() issues up to four loads, uses them all and only then issues the next
-// ones, and every slice (~1100 records of one file) starts with an empty pipeline: a wave pays a full HBM round trip per 512
-// records, with four waves per SIMD to cover it; its three step shapes x two validity paths x the inlined list code are
-// 16,000 lines of ISA (more than the instruction cache holds).  Here:
-//   * a wave's slices form ONE stream of STEPS (128 records: two per lane) produced by a scalar generator that runs D steps
-//     ahead of the consumer, ACROSS slice boundaries: D loads are in flight per wave at all times; the next slice's cut
-//     points, pointer and boundary record are scalar loads issued a slice ahead;
-//   * one step shape: a FULL step is one 16-byte load per lane at a wave-uniform base + lane * 16 (no address arithmetic, no
-//     clamps); the last, partial step of a slice loads its two records with two 8-byte loads clamped to the slice's last
-//     record (duplicates of a real record: harmless to the order check and to the table) -- the consumer code is the same;
+// ---- the plain pass (pu2_probe_kernel, round 6; rounds 3-5: pu_probe_kernel) -------------------------------------------------
+// What bound pu_probe_kernel (profiles/r03_punion_pmc.txt, r05_notes.md 1c): it had three step shapes (U = 4 / 2 / 1) x two
+// validity paths with the list code inlined in each -- 16,000 lines of ISA --, a THIRD load per lane and step for the order
+// check (the record behind a lane's pair), 64-bit clamps on every address, 45 scalar instructions per record of slice
+// bookkeeping, and four waves per SIMD at 93 registers: 16.5 ms on config 3 (4.5 TB/s).  Here (12.9 ms, 5.7 TB/s; what was
+// measured on the way: profiles/r06_notes.md 1):
+//   * ONE step shape: 128 records, two per lane, one 16-byte load per lane from a wave-uniform base + a 32-bit lane offset.
+//     A slice = one general first step, batches of FULL steps (no validity masks, the batch's loads in flight together,
+//     straight-line code: the compiler's s_waitcnt counts are exact), general steps for what is left;
 //   * the order check needs no third load: the record in front of a lane's pair is its neighbour's second record (DPP
-//     wave_shr:1), lane 0 takes the step's predecessor from a scalar (the previous step's last record, or the record in
-//     front of the slice);
-//   * 1024 threads share the 64 KB table: two workgroups = eight waves per SIMD (<= 64 registers);
-//   * the list / claim code exists once, behind one wave-uniform branch.
+//     wave_shr:1), lane 0 takes the previous step's last record from a scalar; a slice that does not begin its file starts
+//     one record early, so the boundary pair is checked inside lane 0 like every other pair;
+//   * 1024 threads share the 64 KB table: two workgroups = eight waves per SIMD (55 registers);
+//   * the table in two halves, P pair first (below); the list / claim code exists once, behind one wave-uniform branch.
+// (A pipeline ACROSS slices with loads in inline assembly and hand-written waits was built first and measured the same for
+//  2 / 3 / 4 steps in flight: latency was not the limit -- and inline-assembly loads hide hazards from the compiler, see the
+//  notes.)
 #ifndef PU2_NT_N
 #define PU2_NT_N 1024
 #endif
@@ -501,8 +252,6 @@ __device__ __forceinline__ u64 pu2_shr1(u64 v, u64 carry) {  // lane l gets v of
     return ((u64)hi << 32) | lo;
 }
 
-// ONES: some later file ends in all-ones records (the table's empty marker): they must not "match" an empty slot
-template <bool ONES>
 __global__ __launch_bounds__(PU2_NT) __attribute__((amdgpu_waves_per_eu(PU2_WAVES, PU2_WAVES))) void pu2_probe_kernel(PuArgs a) {
     // the table in two halves: slots 0 and 1 of every bucket in the first 32 KB (P), slots 2 and 3 behind them (Q).  Slots
     // fill in order, so a record is looked up in its bucket's P pair first (one 16-byte read at a 16-byte stride: all bank
@@ -517,7 +266,8 @@ __global__ __launch_bounds__(PU2_NT) __attribute__((amdgpu_waves_per_eu(PU2_WAVE
     for (int i = tid; i < PU_SLOTS; i += PU2_NT) s_tab[i] = PU_EMPTY;
     if (tid == 0) { s_next = 0; s_nmiss = 0; s_nins = 0; }
     __syncthreads();
-    {   // the table of this range's base entries (as pu_probe_kernel)
+    {   // the table of this range's base entries (distinct; an all-ones code can not be told from an empty slot and is left
+        // out: records with that code are "misses" and meet their base entry again in the final union)
         const u64 b0 = (u64)r * PU_RANGE;
         const u32 nb = (u32)((a.n0 - b0 < (u64)PU_RANGE) ? (a.n0 - b0) : (u64)PU_RANGE);
         constexpr int PER = (PU_RANGE + PU2_NT - 1) / PU2_NT;
@@ -659,10 +409,8 @@ __global__ __launch_bounds__(PU2_NT) __attribute__((amdgpu_waves_per_eu(PU2_WAVE
             if (!ha && q0.y != PU_EMPTY) ha = member_from(x0, (h0 + 1) & (PU_BUCKETS - 1));
             if (!hb && q1.y != PU_EMPTY) hb = member_from(x1, (h1 + 1) & (PU_BUCKETS - 1));
         }
-        if (ONES) {  // (all-ones records would "match" an empty slot)
-            ha = ha && x0 != PU_EMPTY;
-            hb = hb && x1 != PU_EMPTY;
-        }
+        ha = ha && x0 != PU_EMPTY;  // (an all-ones record would "match" an empty slot)
+        hb = hb && x1 != PU_EMPTY;
         bool m0 = !ha, m1 = !hb;
         if (!full) {
             const u32 i0 = l2 < pmax ? l2 : pmax;  // the records this lane holds: i0, i0 + 1
@@ -2063,7 +1811,7 @@ static int probe_union_k0(ukm_ctx *c, const u64 *const *keys, const u32 *const *
     // (the pipelined plain kernel loads 16-byte pairs: later files of fewer than two records do not go through it -- their
     //  one record is put on the list of new codes by the host, which is what the list is: records the final union adds)
     const bool claiming = tax || ukm_env(c, "UKM_PUNION_CLAIM") != nullptr;
-    const bool v2 = !claiming && ukm_env_int(c, "UKM_PUNION_V2", 1) != 0;
+    const bool v2 = !claiming;
     std::vector<const u64 *> tiny;
     if (v2) {
         int w = k0;
@@ -2162,7 +1910,7 @@ static int probe_union_k0(ukm_ctx *c, const u64 *const *keys, const u32 *const *
     // 3. probe pass
     // (+ one partly used chunk of 64 per wave of the grid)
     u64 miss_cap = (u64)((double)later * std::min(1.0, 2.0 * miss_rate + 0.01)) + (1u << 20);
-    miss_cap = std::min(miss_cap, later) + 64ull * (std::max(PU_NT, PT_NT) / 64) * R64 * (u64)((S1all + PU_MAXS - 1) / PU_MAXS) + later / 32;
+    miss_cap = std::min(miss_cap, later) + 64ull * (std::max(PU2_NT, PT_NT) / 64) * R64 * (u64)((S1all + PU_MAXS - 1) / PU_MAXS) + later / 32;
     miss_cap += tiny.size();
     UKM_TRY(ws_alloc_t(c, miss_cap + 1, &a.miss));
     if (tax) UKM_TRY(ws_alloc_t(c, miss_cap + 1, &a.miss_tax));
@@ -2207,8 +1955,7 @@ static int probe_union_k0(ukm_ctx *c, const u64 *const *keys, const u32 *const *
         (void)hipEventRecord(c->ev_k0, c->stream);
         if (claiming && a.clade_mode) hipLaunchKernelGGL((pt_probe_kernel<false, true>), dim3(a.R), dim3(PT_NT), 0, c->stream, a);
         else if (claiming) hipLaunchKernelGGL((pt_probe_kernel<false, false>), dim3(a.R), dim3(PT_NT), 0, c->stream, a);
-        else if (v2) hipLaunchKernelGGL(pu2_probe_kernel<true>, dim3(a.R), dim3(PU2_NT), 0, c->stream, a);
-        else hipLaunchKernelGGL(pu_probe_kernel, dim3(a.R), dim3(PU_NT), 0, c->stream, a);
+        else hipLaunchKernelGGL(pu2_probe_kernel, dim3(a.R), dim3(PU2_NT), 0, c->stream, a);
         (void)hipEventRecord(c->ev_k1, c->stream);
         c->evk_valid = true;
         UKM_HIP(hipGetLastError());
