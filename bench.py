@@ -117,7 +117,8 @@ def cpu_baseline(sample_universe, gap_bits):
         "cores": 1,
         "kind": "port",
         "sample": "union+inter of 2 x %d synthetic k=31 codes (same generator; C restatement of the "
-                  "reference's hash-map union and 2-pointer inter, 1 thread; Go toolchain absent)" % len(A),
+                  "reference's hash-map union and 2-pointer inter, 1 thread; Go toolchain absent; the survey's sizes 2 x 1e8 "
+                  "and 2 x 1.25e8 were run once: profiles/r06_cpu_baseline_sizes.json, 2.51e7 / 2.24e7 k-mers/s)" % len(A),
         "union_s": tu, "inter_s": ti, "union_out": int(len(u)), "inter_out": int(len(i)),
         "host_cores_available": os.cpu_count(),
         "allcores_sorted_merge": {"value": kmers / (best[0] + best[1]), "unit": "k-mers/s", "cores": best[2],
