@@ -608,6 +608,66 @@ def test_probe_union_taxid_fold_on_a_forest_with_merged_zero_and_unknown_ids(mon
 
 
 # ---------------------------------------------------------- inter / diff by LDS hash probes (ukm_pfold.hip)
+def test_probe_fold_step_edges_exactly_once_and_strict_order(env, monkeypatch):
+    """The streaming skeleton of round 6 inside the probe fold (pf_probe_kernel): `inter` COUNTS hits, so every record of a
+    later file must be seen exactly once whatever its slice's length -- 0 / 1 / 2 / 3 / 127 / 128 / 129 / 255 / 257 records
+    at the start, in the middle and at the end of a file, files of 1 and 2 records -- and every file must be STRICTLY
+    increasing: one duplicated or one swapped neighbouring pair at every position class of a later file (inside a lane's
+    pair, between lanes, between steps, across a range boundary, at either end) must reach the exact routes and still
+    give the oracle's answer (inter.go:205-286, diff.go:379-454 incl. -t; a duplicate changes `inter`'s multiset result).
+    First file of two ranges (L <= 1536 / 2048), taxids on every file."""
+    O, L, ctx, tax, T = env
+    rng = np.random.default_rng(6061)
+    monkeypatch.setenv("UKM_PFOLD_TAX", "1")
+    U = _universe(4000, gap_bits=24)
+    first = U[::2][:1800].copy()                          # 1800 records: two ranges of the inter-with-taxids variant (L = 900)
+    cut = first[900]
+    lo_pool, hi_pool = U[U < cut], U[U >= cut]
+    later = []
+    for a_, b_ in ((0, 1), (1, 0), (2, 3), (127, 128), (128, 129), (129, 127), (255, 257), (257, 1), (1, 1), (3, 2), (640, 513)):
+        later.append(np.concatenate([np.sort(rng.choice(lo_pool, a_, replace=False)), np.sort(rng.choice(hi_pool, b_, replace=False))]).astype(np.uint64))
+    later += [first[5:6].copy(), first[10:12].copy()]
+    files = [first] + later
+    taxs = [_taxids(f, T, i) for i, f in enumerate(files)]
+
+    def check(fs, ts):
+        for got, want in ((ctx.inter(fs, ts), O.inter(fs, ts, tax)), (ctx.diff(fs, ts), O.diff(fs, ts, tax)),
+                          (ctx.diff(fs, ts, compare_taxid=True), O.diff(fs, ts, tax, compare_taxid=True))):
+            assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
+        assert np.array_equal(ctx.inter(fs), O.inter(fs)) and np.array_equal(ctx.diff(fs), O.diff(fs))
+    check(files, taxs)
+    # files that all hold a common core (a non-empty intersection whose hit counts must come out exact) in slices of every length
+    core = np.sort(rng.choice(first, 300, replace=False))
+    for n in (1, 2, 127, 128, 129, 255, 256, 257, 511, 900):
+        fs = [first] + [np.unique(np.concatenate([core, np.sort(rng.choice(U, n, replace=False))])).astype(np.uint64) for _ in range(5)]
+        ts = [_taxids(f, T, 100 + i) for i, f in enumerate(fs)]
+        got, want = ctx.inter(fs, ts), O.inter(fs, ts, tax)
+        assert len(want[0]) >= 300 and np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1]), n
+    # one duplicated / one swapped neighbouring pair in a later file of 700 records
+    victim = np.unique(np.concatenate([core, np.sort(rng.choice(U, 500, replace=False))])).astype(np.uint64)
+    b1 = int(np.searchsorted(victim, cut))
+    spots = sorted({0, 1, 2, 126, 127, 128, 129, 254, 255, 256, b1 - 2, b1 - 1, b1, b1 + 1, len(victim) - 2, len(victim) - 3} |
+                   set(int(x) for x in rng.integers(0, len(victim) - 1, 8)))
+    others = [np.unique(np.concatenate([core, np.sort(rng.choice(U, 400, replace=False))])).astype(np.uint64) for _ in range(4)]
+    for sp in (x for x in spots if 0 <= x < len(victim) - 1):
+        for kind in ("dup", "swap"):
+            v = victim.copy()
+            if kind == "dup":
+                v[sp + 1] = v[sp]
+            else:
+                v[sp], v[sp + 1] = v[sp + 1], v[sp]
+            fs = [first] + others[:2] + [v] + others[2:]
+            ts = [_taxids(f, T, 200 + i) for i, f in enumerate(fs)]
+            if kind == "swap":   # an unsorted stream is an error of these operations (as in the other routes)
+                with pytest.raises(L.UnsortedError):
+                    ctx.inter(fs, ts)
+                continue
+            got, want = ctx.inter(fs, ts), O.inter(fs, ts, tax)
+            assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1]), (sp, kind)
+            got, want = ctx.diff(fs, ts), O.diff(fs, ts, tax)
+            assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1]), (sp, kind)
+
+
 def test_probe_fold_shapes(env, monkeypatch):
     """`inter` (plain, LCA of taxids) and `diff` (plain) over many files through the hash-probe fold: same answers as the
     oracle's sequential folds (inter.go:205-286, diff.go:379-454) AND as the range fold of ukm_fold.hip (UKM_NO_PFOLD=1),

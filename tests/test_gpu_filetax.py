@@ -442,3 +442,41 @@ def test_merge_by_placement_with_file_taxids(env, monkeypatch):
                 assert ctx.last_route() == 7, (name, ctx.last_route())
             ok, ot = O.merge_k(files, ex, mode=mode, tax=tax)
             assert np.array_equal(gk, ok) and np.array_equal(gt, ot), (name, mode)
+
+
+def test_ranked_probe_union_step_edges(env, monkeypatch):
+    """The ranked probe pass (pr_probe_kernel, one taxid per file) with the round-6 streaming skeleton.  A base set of 4e5
+    codes gives ranges of ~780 entries (pr_range_for), so later files that hold a half / a third / a twentieth / a thousandth of
+    the universe have slices of ~390 / 260 / 39 / 0-2 records: general first steps, full steps, partial and one-record tails,
+    slices at either end of their files; plus files of 0, 1 and 2 records and private codes -- against the oracle fed the
+    expanded arrays.  Then ONE swapped neighbouring pair anywhere in a later file (inside a lane's pair, between lanes,
+    between steps, across a range boundary, at either end): the pass must notice (the call then takes another route and still
+    gives the oracle's answer: union.go:186-208 does not need sorted files)."""
+    O, L, ctx, tax, pool, kind = env
+    rng = np.random.default_rng(6062)
+    monkeypatch.setenv("UKM_PUNION", "2")
+    U = _universe(400_000, gap_bits=24)
+    base = [U[_member(len(U), f, 0.9, 3)] for f in range(8)]
+    later = [U[_member(len(U), 20 + i, p, 3)] for i, p in enumerate((0.5, 0.5, 0.33, 0.33, 0.05, 0.05, 0.001, 0.001, 0.6, 0.25))]
+    later += [np.empty(0, np.uint64), U[77:78].copy(), U[100:102].copy(), np.array([U[-1] + np.uint64(5)], np.uint64),
+              np.unique(rng.integers(1, int(U[-1]), 3000).astype(np.uint64)), U[:129].copy(), U[-257:].copy()]
+    files = base + later
+    taxs = [int(pool[(5 * i + 3) % len(pool)]) for i in range(len(files))]
+    _eq(ctx.union(files, taxs), O.union(files, _expand(files, taxs), tax))
+    assert ctx.last_route() == 3
+    victim = later[2]
+    spots = sorted({0, 1, 2, 126, 127, 128, 129, 254, 255, 256, 257, len(victim) - 2, len(victim) - 3} |
+                   set(int(x) for x in rng.integers(0, len(victim) - 1, 14)))
+    small = base + [later[4], None, later[6]]
+    tt = taxs[:8] + [taxs[12], taxs[10], taxs[14]]
+    for sp in spots:
+        v = victim.copy()
+        v[sp], v[sp + 1] = v[sp + 1], v[sp]
+        trial = list(small)
+        trial[9] = v
+        _eq(ctx.union(trial, tt), O.union(trial, _expand(trial, tt), tax), sp)
+        assert ctx.last_route() != 3, sp
+    trial = list(small)
+    trial[9] = victim
+    _eq(ctx.union(trial, tt), O.union(trial, _expand(trial, tt), tax))
+    assert ctx.last_route() == 3
