@@ -183,6 +183,15 @@ int ukm_minimizer(ukm_ctx *ctx, const uint8_t *bases, const uint64_t *rec_off, u
                   uint64_t *out_pos, uint64_t out_cap, uint64_t *n_out);
 /* count.go:98  maxHash = uint64(float64(^uint64(0)) / float64(scale)) */
 uint64_t ukm_max_hash(uint64_t scale);
+/* ---- `count` in one call: replaces the body of the Run closure count.go:285-436 (iterator + `m[code] = struct{}{}` per
+ *      k-mer, the -u / -d marks of count.go:424-432) and its sort count.go:581: every window of every record (codes when
+ *      hashed = 0, ntHash v1 with the Scaled filter max_hash != 0 when hashed = 1) -> sort -> mode UKM_UNIQUE (the distinct
+ *      set), UKM_REPEATED (`-d`: codes seen at least twice) or UKM_SINGLETON (`-u`: exactly once), sorted ascending (`-s`).
+ *      The windows stay in the context's device workspace (8 B per base while the call runs); only the result is written to
+ *      out[out_cap] (host or device).  The same result as ukm_encode_kmers / ukm_nthash + ukm_sort_u64 + ukm_unique with one
+ *      stream synchronisation instead of three.  Too small an out_cap: UKM_ERR_CAPACITY, *n_out = the size needed. */
+int ukm_count(ukm_ctx *ctx, const uint8_t *bases, const uint64_t *rec_off, uint64_t n_rec, int k, int canonical,
+              int circular, int hashed, uint64_t max_hash, int mode, uint64_t *out, uint64_t out_cap, uint64_t *n_out);
 
 /* ---- sorts: replace sortutil.Uint64s (count.go:581, union.go:274,295, sort.go:463 ...) and
  *      sorts.Quicksort(CodeTaxidSlice) (sort.go:268,331,457).  In place, ascending by code;

@@ -475,6 +475,46 @@ def test_unique_modes(ctx, O, L, tree, n):
         assert np.array_equal(gk, ok) and np.array_equal(gt, ot)
 
 
+def test_count_in_one_call(ctx, O, L, genomes):
+    """ukm_count = every window -> sort -> the distinct / repeated / singleton set in ONE call (the body of `count`'s Run closure,
+    count.go:285-436, and its sort count.go:581) against the oracle's rolling encoder / hasher, its sort and its scans: codes
+    for several k, canonical or not, circular records, ntHash with and without the Scaled filter, ragged / short / empty
+    records, the README's genome counts (README.md:200-204), a device-resident input, too small an output."""
+    rng = np.random.default_rng(66)
+    seq = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, 300_000)].copy()
+    seq[1000:1040] = ord("N")                                      # degenerate bases collapse (kmers: N -> A)
+    off = np.array([0, 10, 10, 5000, 5020, 120_000, 299_990, 300_000], dtype=np.uint64)   # short, empty, long records
+    # (a window repeats when the same stretch occurs twice: plant repeats so that -d / -u are not trivial)
+    seq[200_000:201_000] = seq[50_000:51_000]
+    for k, canonical, circular in ((31, True, False), (21, False, False), (5, True, False), (23, True, True), (32, True, False)):
+        w = O.count_windows(seq, off, k, canonical=canonical, circular=circular)
+        srt = O.sort_u64(w)
+        for mode in (L.UNIQUE, L.REPEATED, L.SINGLETON):
+            got = ctx.count(seq, off, k, canonical=canonical, circular=circular, mode=mode)
+            assert np.array_equal(got, O.unique(srt, mode=mode)), (k, canonical, circular, mode)
+    for k, scale in ((51, 0), (23, 0), (51, 50), (31, 1000)):
+        mh = O.max_hash(scale) if scale else 0
+        w = O.count_windows(seq, off, k, hashed=True, canonical=True, max_hash=mh)
+        srt = O.sort_u64(w)
+        for mode in (L.UNIQUE, L.REPEATED, L.SINGLETON):
+            assert np.array_equal(ctx.count(seq, off, k, hashed=True, max_hash=mh, mode=mode), O.unique(srt, mode=mode)), (k, scale, mode)
+    # the reference's own numbers: distinct canonical 23-mers of the fixture genomes (README.md:200-204)
+    from conftest import AMUC, MG1655
+    for name, n in ((MG1655, 4546632), (AMUC, 2630905)):
+        s, o = genomes(name)
+        assert len(ctx.count(s, o, 23)) == n
+    # device-resident input and output
+    import torch
+    ds, do = torch.from_numpy(seq).cuda(), torch.from_numpy(off.view(np.int64)).cuda()
+    got = ctx.count(ds, do, 31)
+    assert got.is_cuda and np.array_equal(got.cpu().numpy().view(np.uint64), O.unique(O.sort_u64(O.count_windows(seq, off, 31))))
+    with pytest.raises(L.CapacityError):
+        ctx.count(seq, off, 31, out=np.empty(10, np.uint64))
+    with pytest.raises(L.UkmError):
+        ctx.count(seq, off, 31, mode=L.PLAIN)
+    assert len(ctx.count(seq[:0], np.array([0], np.uint64), 31)) == 0
+
+
 def test_unique_unsorted_is_an_error(ctx, L):
     with pytest.raises(L.UnsortedError):
         ctx.unique(np.array([3, 1, 2], dtype=np.uint64))

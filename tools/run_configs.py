@@ -101,9 +101,13 @@ def main():
             t["encode"], t["sort"], t["unique"] = (t1 - t0) * 1e3, (t2 - t1) * 1e3, (t3 - t2) * 1e3
             return u
         ms, u = wall(run)
+        # the same job through the one-call entry point (round 6: ukm_count = windows -> sort -> unique on the device, one
+        # stream synchronisation and one read-back instead of three)
+        ms_one, u1 = wall(lambda: ctx.count(bases, off, 31, canonical=True, out=uniq))
+        assert u1.numel() == u.numel()
         w = nb - 100 * 30
         res["config2_count_sort_k31_100Mbp"] = {"ms": ms, "bases_per_s": nb / ms * 1e3, "distinct": u.numel(),
-                                                "phases_ms": dict(t), "windows": w,
+                                                "phases_ms": dict(t), "windows": w, "ms_ukm_count_one_call": ms_one,
                                                 # THE fraction = bytes the route moves (round-5 review: the survey's 8-pass LSD byte
                                                 # count describes a route that no longer exists and gave "fractions" above 1)
                                                 "roofline": roof_hbm((nb + 8 * w) + (8 * w + 2 * 16 * w + 16 * w) + (8 * w + 8 * u.numel()), ms,

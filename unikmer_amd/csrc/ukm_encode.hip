@@ -1519,6 +1519,63 @@ extern "C" int ukm_minimizer(ukm_ctx *ctx, const uint8_t *bases, const uint64_t 
     return ukm_finish(&s, rc);
 }
 
+// `count` in ONE call: every window (codes, or ntHash with the Scaled filter) -> sort -> the distinct / repeated / singleton
+// set, the body of the Run closure count.go:285-436 (iterator, `m[code] = struct{}{}` per k-mer, the `-u` / `-d` marks) and
+// its sort count.go:581.  The windows never leave the device: they are produced into the context's workspace, sorted there
+// and reduced into `out`; one stream synchronisation and one read-back for the whole call instead of three of each (round-5
+// review: the CLI's count_on_device was the caller the fused entry point did not have).
+extern "C" int ukm_count(ukm_ctx *ctx, const uint8_t *bases, const uint64_t *rec_off, uint64_t n_rec, int k, int canonical,
+                         int circular, int hashed, uint64_t max_hash, int mode, uint64_t *out, uint64_t out_cap, uint64_t *n_out) {
+    const char *name = "ukm_count";
+    if (!ctx || !n_out || (!out && out_cap) || (n_rec && (!rec_off || !bases))) UKM_FAIL(UKM_ERR_INVALID, "%s: NULL argument", name);
+    if (k < 1 || k > (hashed ? 64 : 32)) UKM_FAIL(UKM_ERR_K, "%s: k = %d out of range", name, k);
+    if (mode != UKM_UNIQUE && mode != UKM_REPEATED && mode != UKM_SINGLETON)
+        UKM_FAIL(UKM_ERR_INVALID, "%s: mode must be UKM_UNIQUE, UKM_REPEATED (-d) or UKM_SINGLETON (-u)", name);
+    if (!hashed && max_hash) UKM_FAIL(UKM_ERR_INVALID, "%s: max_hash (--scale) needs hashed = 1", name);
+    *n_out = 0;
+    if (n_rec == 0) return UKM_OK;
+    CallScope s;
+    UKM_TRY(ukm_begin(ctx, &s));
+    int rc = [&]() -> int {
+        const u64 *off = nullptr;
+        UKM_TRY(ukm_in_t(ctx, rec_off, n_rec + 1, &off));
+        u64 total_bases = 0, first = 0;
+        if (ukm_is_device_ptr(rec_off)) {
+            UKM_TRY(ukm_read_u64(ctx, off + n_rec, &total_bases));
+            UKM_TRY(ukm_read_u64(ctx, off, &first));
+        } else {
+            total_bases = rec_off[n_rec];
+            first = rec_off[0];
+        }
+        if (first != 0) UKM_FAIL(UKM_ERR_INVALID, "%s: rec_off[0] must be 0", name);
+        const u8 *b = nullptr;
+        u64 *o = nullptr;
+        UKM_TRY(ukm_in_t(ctx, bases, total_bases, &b));
+        UKM_TRY(ukm_out_t(ctx, out, out_cap, &o));
+        // windows <= bases (circular records: one per base); with a Scaled filter a small share of them
+        u64 wcap = total_bases + 1;
+        if (hashed && max_hash && max_hash != ~0ull) {
+            const double keep = 2.0 * ((double)max_hash / 18446744073709551615.0);  // canonical = the smaller of two hashes
+            wcap = std::min<u64>(wcap, (u64)((double)total_bases * std::min(1.0, 1.5 * keep)) + (1u << 20));
+        }
+        u64 *w = nullptr;
+        UKM_TRY(ws_alloc_t(ctx, (size_t)wcap, &w));
+        u64 nw = 0;
+        UKM_TRY(run_windows(ctx, hashed != 0, b, off, n_rec, k, canonical, circular, max_hash, w, wcap, &nw, total_bases));
+        if (nw == 0) {
+            ukm_out_resize(ctx, out, 0);
+            return UKM_OK;
+        }
+        int bits = hashed ? 64 : 2 * k;
+        if (hashed && max_hash && max_hash != ~0ull) bits = 64 - __builtin_clzll(max_hash);
+        UKM_TRY(ukm_dev_sort(ctx, w, nullptr, nw, bits));
+        int r = ukm_dev_unique(ctx, w, nullptr, nw, mode, o, nullptr, out_cap, n_out);
+        ukm_out_resize(ctx, out, (r == UKM_OK ? *n_out : 0) * sizeof(u64));
+        return r;
+    }();
+    return ukm_finish(&s, rc);
+}
+
 // count.go:98  maxHash := uint64(float64(^uint64(0)) / float64(scale))
 extern "C" uint64_t ukm_max_hash(uint64_t scale) {
     if (scale <= 1) return ~0ull;

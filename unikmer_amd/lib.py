@@ -31,7 +31,7 @@ SYMBOLS = [
     "ukm_common", "ukm_common_threshold", "ukm_partition_points",
     "ukm_comm_get_unique_id", "ukm_comm_init", "ukm_comm_destroy", "ukm_comm_info", "ukm_prefix_splitters",
     "ukm_shard_exchange", "ukm_shard_plan", "ukm_shard_counts", "ukm_shard_exchange_known",
-    "ukm_shard_splitters", "ukm_shard_splitters_plan", "ukm_shard_counts_tax", "ukm_shard_counts_plan",
+    "ukm_shard_splitters", "ukm_shard_splitters_plan", "ukm_shard_counts_tax", "ukm_shard_counts_plan", "ukm_count",
     "ukm_ctx_set_option", "ukm_ctx_unset_option", "ukm_ctx_get_option", "ukm_ctx_get_stat",
     "ukm_setop2_ft", "ukm_union_ft", "ukm_inter_ft", "ukm_diff_ft", "ukm_common_ft", "ukm_merge_k_ft",
 ]
@@ -120,6 +120,7 @@ def load():
     L.ukm_lca.argtypes = [vp, vp, vp, u64, vp]
     L.ukm_encode_kmers.argtypes = [vp, vp, vp, u64, i32, i32, i32, vp, u64, pu64]
     L.ukm_nthash.argtypes = [vp, vp, vp, u64, i32, i32, i32, u64, vp, u64, pu64]
+    L.ukm_count.argtypes = [vp, vp, vp, u64, i32, i32, i32, i32, u64, i32, vp, u64, pu64]
     L.ukm_minimizer.argtypes = [vp, vp, vp, u64, i32, i32, i32, u64, vp, vp, u64, pu64]
     L.ukm_max_hash.argtypes = [u64]
     L.ukm_max_hash.restype = u64
@@ -351,6 +352,22 @@ class Context:
         _check(self.L.ukm_minimizer(self.h, pb, poff, noff - 1, k, w, int(circular), max_hash, po, pp, cap,
                                     C.byref(n)))
         return (out[: n.value], pos[: n.value]) if with_pos else out[: n.value]
+
+    def count(self, bases, rec_off, k, canonical=True, circular=False, hashed=False, max_hash=0, mode=UNIQUE, out=None):
+        """`unikmer count -s` in one call (count.go:285-436,581): every window -> sort -> the distinct (`mode=UNIQUE`), repeated
+        (`-d`: REPEATED) or singleton (`-u`: SINGLETON) set, sorted.  The windows stay on the device."""
+        pb, nb, _ = _ptr(bases, np.uint8)
+        poff, noff, _ = _ptr(rec_off, np.uint64)
+        if out is None:
+            cap = nb + 1
+            if hashed and max_hash:
+                cap = min(cap, int(nb * min(1.0, 3.0 * max_hash / float(1 << 64))) + (1 << 20))
+            out = _empty_like_kind(bases, cap, np.uint64)
+        po, cap, _ = _ptr(out, np.uint64)
+        n = C.c_uint64()
+        _check(self.L.ukm_count(self.h, pb, poff, noff - 1, int(k), int(canonical), int(circular), int(hashed), int(max_hash), int(mode), po,
+                                cap, C.byref(n)))
+        return out[: n.value]
 
     def max_hash(self, scale):
         return self.L.ukm_max_hash(scale)
