@@ -133,7 +133,8 @@ int ukm_last_route(ukm_ctx *ctx);
  *      for the matching key; no compute call calls getenv (a context created under UKM_ENV_LIVE=1 -- the test suite, which
  *      flips knobs between calls -- keeps looking).  An explicitly set option always wins.
  *      ukm_ctx_get_stat: "punion_attempts" = base sets the last hash-probe union / counting-probe call built (2: its retry
- *      with four times the files ran), "workspace_bytes" = device workspace currently held by the context. */
+ *      with four times the files ran), "workspace_bytes" = device workspace currently held by the context, "sort_fused_hist" = sorts of this context whose first
+ *      digit histogram came from the kernel that produced the keys (ukm_count) instead of a pass of their own. */
 int ukm_ctx_set_option(ukm_ctx *ctx, const char *key, long long value);
 int ukm_ctx_unset_option(ukm_ctx *ctx, const char *key);
 int ukm_ctx_get_option(ukm_ctx *ctx, const char *key, long long *value, int *is_set);

@@ -320,6 +320,11 @@ def test_config2_count_sort_100Mbp_full_size(env, monkeypatch, genomes):
         u = ctx.unique(c)
         assert np.array_equal(_np(u), ou), knob
         del c, u
+        # the same through the one-call entry point (ukm_count): on the bucket route the sort takes its first histogram from
+        # the strip encode kernel instead of a pass of its own
+        fused0 = ctx.stat("sort_fused_hist")
+        assert np.array_equal(_np(ctx.count(bases, doff, 31, canonical=True)), ou), knob
+        assert ctx.stat("sort_fused_hist") == fused0 + (1 if knob is None else 0), knob
     monkeypatch.delenv("UKM_SORT_LOCAL", raising=False)
     del bases, hb, ow, osorted, ou
     # the fixture genomes, twice
@@ -353,6 +358,9 @@ def test_config2_count_sort_100Mbp_full_size(env, monkeypatch, genomes):
         ctx.sort_u64(c, 62)
         assert np.array_equal(_np(c), gs), knob
         assert np.array_equal(_np(ctx.unique(c)), gu), knob
+        assert np.array_equal(_np(ctx.count(dseq, dgoff, 31, canonical=True)), gu), knob
+        for mode, omode in ((lib.REPEATED, O.REPEATED), (lib.SINGLETON, O.SINGLETON)):
+            assert np.array_equal(_np(ctx.count(dseq, dgoff, 31, canonical=True, mode=mode)), O.unique(gs, mode=omode)), (knob, mode)
     monkeypatch.delenv("UKM_SORT_LOCAL", raising=False)
 
 

@@ -92,6 +92,7 @@ extern "C" int ukm_ctx_get_option(ukm_ctx *c, const char *key, long long *value,
 extern "C" int ukm_ctx_get_stat(ukm_ctx *c, const char *key, unsigned long long *value) {
     if (!c || !key || !value) UKM_FAIL(UKM_ERR_INVALID, "ukm_ctx_get_stat: NULL argument");
     if (strcmp(key, "punion_attempts") == 0) *value = c->stat_punion_attempts;
+    else if (strcmp(key, "sort_fused_hist") == 0) *value = c->stat_sort_fused_hist;
     else if (strcmp(key, "workspace_bytes") == 0) {
         u64 t = 0;
         for (auto &b : c->blocks) t += b.cap;

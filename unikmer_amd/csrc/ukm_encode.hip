@@ -793,6 +793,11 @@ struct SwArgs {
     u64 *out;
     u64 *result;          // [1] flags: bit0 illegal base in an emitted window, bit2 record table overflow
     const u64 *tile_rec;  // [ntiles + 3]
+    // ukm_count (round 6): the sort that follows wants the 256-bin histogram of digit (value >> fshift) & 255 of everything this
+    // launch writes -- counted here (one LDS atomic per value, 256 global atomics per workgroup) it saves the sort's own
+    // pre-pass over the values; null: not wanted
+    u64 *fhist;
+    int fshift;
 };
 
 template <bool HASH>
@@ -804,8 +809,10 @@ __global__ __launch_bounds__(SW_NT) __attribute__((amdgpu_waves_per_eu(HASH ? 3 
     __shared__ u32 s_gap[SW_REC + 2];  // gap of a record minus the gap of the tile's first record (< tile positions + k per record)
     __shared__ u64 s_row[SW_NWV][64 * SW_ROW];
     __shared__ u64 s_desc[SW_NWV][64];
+    __shared__ u32 s_fh[128];  // fhist: two 16-bit counters per word (a tile writes at most SW_NT x L <= 65,535 values: the host checks)
     const int tid = (int)threadIdx.x, lane = lane_id(), wave = tid >> 6;
     const int k = p.k, L = p.L;
+    if (p.fhist && tid < 128) s_fh[tid] = 0;
     if constexpr (HASH) {
         const u32 si = (u32)g_byte_table.v[tid] >> 4;
         const u64 f = si == 0 ? SEED_A : si == 1 ? SEED_C : si == 2 ? SEED_G : si == 3 ? SEED_T : 0ull;
@@ -1029,6 +1036,11 @@ __global__ __launch_bounds__(SW_NT) __attribute__((amdgpu_waves_per_eu(HASH ? 3 
                         } else if (w1) {
                             p.out[i1] = v1;
                         }
+                        if (p.fhist) {  // (uniform)
+                            const u32 d0 = (u32)(v0 >> p.fshift) & 255u, d1 = (u32)(v1 >> p.fshift) & 255u;
+                            if (w0) atomicAdd(&s_fh[d0 >> 1], (d0 & 1u) ? 65536u : 1u);
+                            if (w1) atomicAdd(&s_fh[d1 >> 1], (d1 & 1u) ? 65536u : 1u);
+                        }
                     }
                 }
                 __builtin_amdgcn_wave_barrier();
@@ -1037,12 +1049,20 @@ __global__ __launch_bounds__(SW_NT) __attribute__((amdgpu_waves_per_eu(HASH ? 3 
     }
 #undef SW_NEXT_RECORD
     if (!HASH && illegal) atomicOr((unsigned long long *)&p.result[1], 1ull);
+    if (p.fhist) {
+        __syncthreads();
+        if (tid < 128) {
+            const u32 w = s_fh[tid];
+            if (w & 0xFFFFu) atomicAdd((unsigned long long *)&p.fhist[2 * tid], (unsigned long long)(w & 0xFFFFu));
+            if (w >> 16) atomicAdd((unsigned long long *)&p.fhist[2 * tid + 1], (unsigned long long)(w >> 16));
+        }
+    }
 }
 
 // returns UKM_OK with *done = false when the strip kernel does not apply (short records, tiny input, a tile
 // with too many records): the caller then runs window_kernel.  `ctl` is the zeroed control block.
 int run_strip_windows(ukm_ctx *c, bool hash, const u8 *bases, const u64 *rec_off, const u64 *out_off, u64 n_rec, int k,
-                      int canonical, u64 *out, u64 total_bases, u64 *ctl, bool *done) {
+                      int canonical, u64 *out, u64 total_bases, u64 *ctl, bool *done, u64 *fhist = nullptr, int fshift = -1) {
     *done = false;
     const char *fe = ukm_env(c, "UKM_WIN_STRIP");  // developer / test knob: 0 never, 1 whenever it is correct
     const int force = fe ? atoi(fe) : -1;
@@ -1075,6 +1095,8 @@ int run_strip_windows(ukm_ctx *c, bool hash, const u8 *bases, const u64 *rec_off
     memset(&p, 0, sizeof(p));
     p.bases = bases; p.rec_off = rec_off; p.out_off = out_off; p.n_rec = n_rec; p.total_bases = total_bases;
     p.k = k; p.canonical = canonical; p.L = L; p.out = out; p.result = ctl; p.tile_rec = tile_rec;
+    // (k <= 16 writes the rows a record cuts value by value, without the count; 16-bit counters: a tile of <= 65,535 positions)
+    if (fhist && fshift >= 0 && k >= 17 && tile_pos <= 65535) { p.fhist = fhist; p.fshift = fshift; }
     (void)hipEventRecord(c->ev_k0, c->stream);
     if (hash) hipLaunchKernelGGL(stripwin_kernel<true>, dim3((unsigned)ntiles), dim3(SW_NT), 0, c->stream, p);
     else hipLaunchKernelGGL(stripwin_kernel<false>, dim3((unsigned)ntiles), dim3(SW_NT), 0, c->stream, p);
@@ -1092,10 +1114,16 @@ int run_strip_windows(ukm_ctx *c, bool hash, const u8 *bases, const u64 *rec_off
     return UKM_OK;
 }
 
+// fused (may be null; ukm_count): fused->hist = 256 zeroed device words, fused->key_bits = the width the values will be sorted
+// by.  On return fused->shift >= 0 says the histogram of digit (value >> shift) & 255 of ALL values written is in fused->hist
+// (the strip kernel ran with it); -1: nobody counted, the sort runs its own pre-pass.
+struct FusedHist { u64 *hist; int key_bits; int shift; };
+
 int run_windows(ukm_ctx *c, bool hash, const u8 *bases, const u64 *rec_off, u64 n_rec, int k,
                 int canonical, int circular, u64 max_hash, u64 *out, u64 out_cap, u64 *n_out,
-                u64 total_bases, const u64 **win_off = nullptr) {
+                u64 total_bases, const u64 **win_off = nullptr, FusedHist *fused = nullptr) {
     *n_out = 0;
+    if (fused) fused->shift = -1;
     if (win_off) *win_off = nullptr;
     if (n_rec == 0 || total_bases == 0) return UKM_OK;
     if (hash && max_hash != 0 && !circular && !win_off) {
@@ -1129,8 +1157,14 @@ int run_windows(ukm_ctx *c, bool hash, const u8 *bases, const u64 *rec_off, u64 
     if (!circular && !filter) {
         // long records: the rolling strip kernel
         bool done = false;
-        UKM_TRY(run_strip_windows(c, hash, bases, rec_off, off, n_rec, k, canonical, out, total_bases, ctl, &done));
-        if (done) { *n_out = total_windows; return UKM_OK; }
+        const int fsh = (fused && fused->hist) ? ukm_sort_first_shift(c, total_windows, fused->key_bits) : -1;
+        UKM_TRY(run_strip_windows(c, hash, bases, rec_off, off, n_rec, k, canonical, out, total_bases, ctl, &done, fsh >= 0 ? fused->hist : nullptr, fsh));
+        if (done) {
+            *n_out = total_windows;
+            if (fused && fsh >= 0 && k >= 17) fused->shift = fsh;  // (the conditions under which run_strip_windows handed the histogram on)
+            return UKM_OK;
+        }
+        if (fused && fsh >= 0) UKM_HIP(hipMemsetAsync(fused->hist, 0, 256 * sizeof(u64), c->stream));  // (a partial count of the launch that gave up)
     }
     WinArgs p;
     memset(&p, 0, sizeof(p));
@@ -1560,15 +1594,19 @@ extern "C" int ukm_count(ukm_ctx *ctx, const uint8_t *bases, const uint64_t *rec
         }
         u64 *w = nullptr;
         UKM_TRY(ws_alloc_t(ctx, (size_t)wcap, &w));
+        int bits = hashed ? 64 : 2 * k;
+        if (hashed && max_hash && max_hash != ~0ull) bits = 64 - __builtin_clzll(max_hash);
+        // the sort's first histogram is counted by the kernel that writes the windows (the strip kernel, when it runs)
+        FusedHist fh = {nullptr, bits, -1};
+        UKM_TRY(ws_alloc_t(ctx, 256, &fh.hist));
+        UKM_HIP(hipMemsetAsync(fh.hist, 0, 256 * sizeof(u64), ctx->stream));
         u64 nw = 0;
-        UKM_TRY(run_windows(ctx, hashed != 0, b, off, n_rec, k, canonical, circular, max_hash, w, wcap, &nw, total_bases));
+        UKM_TRY(run_windows(ctx, hashed != 0, b, off, n_rec, k, canonical, circular, max_hash, w, wcap, &nw, total_bases, nullptr, &fh));
         if (nw == 0) {
             ukm_out_resize(ctx, out, 0);
             return UKM_OK;
         }
-        int bits = hashed ? 64 : 2 * k;
-        if (hashed && max_hash && max_hash != ~0ull) bits = 64 - __builtin_clzll(max_hash);
-        UKM_TRY(ukm_dev_sort(ctx, w, nullptr, nw, bits));
+        UKM_TRY(ukm_dev_sort_hist(ctx, w, nullptr, nw, bits, fh.shift >= 0 ? fh.hist : nullptr, fh.shift));
         int r = ukm_dev_unique(ctx, w, nullptr, nw, mode, o, nullptr, out_cap, n_out);
         ukm_out_resize(ctx, out, (r == UKM_OK ? *n_out : 0) * sizeof(u64));
         return r;

@@ -147,6 +147,7 @@ struct ukm_ctx {
 
     // set once the blockIdx-ordered set-op kernel hit its watchdog on this device
     bool setop_force_ticket = false;  // = ticket_latched || option "force_ticket"
+    unsigned long long stat_sort_fused_hist = 0;  // sorts of this context that took their first histogram from the producer of the keys (ukm_count)
     bool ticket_latched = false;      // the look-back watchdog fired on this device (ukm_switch_to_tickets): stays set
     // set once a sort found its keys crowded into few top-16-bit buckets (ukm_sort.hip): later sorts look at a sample first
     bool sort_skew_seen = false;
@@ -282,6 +283,9 @@ int ukm_dev_fill_u32_from(ukm_ctx *c, u32 *dst, u64 n, u32 value, const u32 *val
 // flag bits of the set-op result word [1]
 enum { UKM_SETOP_FLAG_DUP = 1, UKM_SETOP_FLAG_UNSORTED = 2, UKM_SETOP_FLAG_TIMEOUT = 4 };
 int ukm_dev_sort(ukm_ctx *c, u64 *keys, u32 *vals, u64 n, int key_bits);
+// the same with the first scatter pass's digit histogram already counted by the producer of the keys (ukm_count)
+int ukm_dev_sort_hist(ukm_ctx *c, u64 *keys, u32 *vals, u64 n, int key_bits, const u64 *first_hist, int first_shift);
+int ukm_sort_first_shift(const ukm_ctx *c, u64 n, int key_bits);
 int ukm_dev_unique(ukm_ctx *c, const u64 *keys, const u32 *taxids, u64 n, int mode, u64 *out,
                    u32 *tout, u64 out_cap, u64 *n_out);
 // mode 5 = UNIQUE_LAST (last record of each run), 6 = COMMON (run length >= threshold)

@@ -763,17 +763,28 @@ bool sort_local_enabled(const ukm_ctx *c) { return !ukm_env_is(c, "UKM_SORT_LOCA
 // The buckets are the top `topb` bits with 2^topb ~ n / 1400: up to 1.3e8 keys the array is sorted by its top 16 bits (two
 // scatter passes), beyond that by its top 24 (three passes, the result sits in the scratch copy and the bucket kernels
 // write the caller's array from there).
-int sort_top16_local(ukm_ctx *c, u64 *keys, u32 *vals, u64 n, int key_bits, bool *done) {
-    *done = false;
+// topb / npass of the bucket route for n keys (shared with ukm_sort_first_shift below)
+static void ls_plan(u64 n, int *topb_out, int *npass_out) {
     int topb;
-    if ((n >> 16) <= 2048) {  // two passes as long as 65,536 buckets hold the keys (a third pass costs more than larger buckets)
+    if ((n >> 16) <= 2048) {
         topb = LS_TOP_MIN;
         while (topb < 16 && (n >> topb) > 1400) topb++;
     } else {
         topb = 17;
         while (topb < LS_TOP_MAX && (n >> topb) > 1400) topb++;
     }
-    const int npass = topb <= 16 ? 2 : 3;
+    *topb_out = topb;
+    *npass_out = topb <= 16 ? 2 : 3;
+}
+
+// first_hist (may be null): the 256-bin histogram of digit (key >> first_shift) & 255 over exactly these n keys, counted by
+// whoever PRODUCED them (ukm_count: the encode kernel) -- it replaces this route's histogram pre-pass when the shift is the
+// one the route would use
+int sort_top16_local(ukm_ctx *c, u64 *keys, u32 *vals, u64 n, int key_bits, bool *done, const u64 *first_hist, int first_shift) {
+    *done = false;
+    // two passes as long as 65,536 buckets hold the keys (a third pass costs more than larger buckets)
+    int topb, npass;
+    ls_plan(n, &topb, &npass);
     const u32 nbuckets = 1u << topb;
     u64 *fh = nullptr, *gb = nullptr, *tk = nullptr, *start = nullptr;
     UKM_TRY(ws_alloc_t(c, (size_t)MAX_PASSES * RADIX + 1, &fh));
@@ -813,7 +824,11 @@ int sort_top16_local(ukm_ctx *c, u64 *keys, u32 *vals, u64 n, int key_bits, bool
     for (int attempt = 0; attempt < 2; attempt++) {
         UKM_HIP(hipMemsetAsync(fh, 0, (MAX_PASSES * RADIX + 1) * sizeof(u64), c->stream));
         u64 *or_all = (key_bits == 64 && attempt == 0) ? fh + (size_t)MAX_PASSES * RADIX : nullptr;
-        hipLaunchKernelGGL(radix_hist_kernel, dim3(hb), dim3(NT), 0, c->stream, keys, n, 1, fh, or_all, kb - 8 * npass);
+        if (first_hist && !or_all && first_shift == kb - 8 * npass) {
+            UKM_HIP(hipMemcpyAsync(fh, first_hist, RADIX * sizeof(u64), hipMemcpyDeviceToDevice, c->stream));
+            c->stat_sort_fused_hist++;
+        } else
+            hipLaunchKernelGGL(radix_hist_kernel, dim3(hb), dim3(NT), 0, c->stream, keys, n, 1, fh, or_all, kb - 8 * npass);
         UKM_HIP(hipGetLastError());
         if (!or_all) break;
         u64 orv = 0;
@@ -981,7 +996,20 @@ int sort_top16_local(ukm_ctx *c, u64 *keys, u32 *vals, u64 n, int key_bits, bool
 }  // namespace
 
 // keys (and vals, may be NULL) are device pointers; sorted in place (stable for pairs)
-int ukm_dev_sort(ukm_ctx *c, u64 *keys, u32 *vals, u64 n, int key_bits) {
+// The shift of the digit whose histogram the bucket route's pre-pass would build for n keys of key_bits bits, or -1 when
+// a sort of such keys does not take that route (or reads an OR of all keys first: key_bits = 64).
+int ukm_sort_first_shift(const ukm_ctx *c, u64 n, int key_bits) {
+    if (key_bits <= 0 || key_bits >= 64 || n >= (1ull << 32) || n < (1ull << 23) || RB != 8 || key_bits < 32) return -1;
+    if (!sort_local_enabled(c) || c->sort_general_only) return -1;
+    int topb, npass;
+    ls_plan(n, &topb, &npass);
+    if (key_bits < 8 * npass + 16) return -1;
+    return key_bits - 8 * npass;
+}
+
+int ukm_dev_sort(ukm_ctx *c, u64 *keys, u32 *vals, u64 n, int key_bits) { return ukm_dev_sort_hist(c, keys, vals, n, key_bits, nullptr, -1); }
+
+int ukm_dev_sort_hist(ukm_ctx *c, u64 *keys, u32 *vals, u64 n, int key_bits, const u64 *first_hist, int first_shift) {
     if (n < 2) return UKM_OK;
     if (key_bits <= 0 || key_bits > 64) key_bits = 64;
     if (n >= (1ull << 32)) {
@@ -1038,7 +1066,7 @@ int ukm_dev_sort(ukm_ctx *c, u64 *keys, u32 *vals, u64 n, int key_bits) {
         // two passes over the top 16 bits, then every bucket in LDS (above); stable, so taxids may ride along
         WsMark mark = ws_mark(c);
         bool done = false;
-        const int rc = sort_top16_local(c, keys, vals, n, key_bits, &done);
+        const int rc = sort_top16_local(c, keys, vals, n, key_bits, &done, first_hist, first_shift);
         ws_release(c, mark);
         UKM_TRY(rc);
         if (done) return UKM_OK;
