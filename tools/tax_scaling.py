@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """developer tool: the 2-way kernel with per-record taxids against the set size (round-5 review: 12 x the time for 10 x the
-data).  usage: python tools/tax_scaling.py [sizes...]   (with a -DUKM_PROFILE_PHASES build the library prints cycles per tile
+data).  usage: [KIND=random|file|runs] python tools/tax_scaling.py [sizes...]   (with a -DUKM_PROFILE_PHASES build the library prints cycles per tile
 and phase to stderr)"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -13,12 +13,20 @@ T = sum(8 ** d for d in range(8))
 child = np.arange(1, T + 1, dtype=np.uint32)
 parent = ((child.astype(np.int64) - 2) // 8 + 1).astype(np.uint32); parent[0] = 1
 ctx.taxonomy_load(child, parent)
+KIND = os.environ.get("KIND", "random")
 sizes = [int(float(x)) for x in sys.argv[1:]] or [100_000_000, 300_000_000, 1_000_000_000]
 for n in sizes:
     A, B = bench.gen_sets_device((4 * n + 2) // 3, 32, 0, bench.SEED, dev)
     na, nb = A.numel(), B.numel()
-    ta = (1 + (bench.splitmix64_torch(A ^ bench._i64(bench.SEED + 2)) & ((1 << 40) - 1)) % T).to(torch.int32)
-    tb = (1 + (bench.splitmix64_torch(B ^ bench._i64(bench.SEED + 3)) & ((1 << 40) - 1)) % T).to(torch.int32)
+    if KIND == "file":      # one taxid per file, handed over as arrays
+        ta = torch.full((na,), 123457, dtype=torch.int32, device=dev)
+        tb = torch.full((nb,), 2345678, dtype=torch.int32, device=dev)
+    elif KIND == "runs":    # runs of 4096 records with one taxid (clustered taxa)
+        ta = (1 + (bench.splitmix64_torch((torch.arange(na, device=dev) >> 12) ^ bench._i64(bench.SEED + 2)) & ((1 << 40) - 1)) % T).to(torch.int32)
+        tb = (1 + (bench.splitmix64_torch((torch.arange(nb, device=dev) >> 12) ^ bench._i64(bench.SEED + 3)) & ((1 << 40) - 1)) % T).to(torch.int32)
+    else:                   # uniformly random per record (SURVEY 8(d)'s generator)
+        ta = (1 + (bench.splitmix64_torch(A ^ bench._i64(bench.SEED + 2)) & ((1 << 40) - 1)) % T).to(torch.int32)
+        tb = (1 + (bench.splitmix64_torch(B ^ bench._i64(bench.SEED + 3)) & ((1 << 40) - 1)) % T).to(torch.int32)
     out = torch.empty(na + nb, dtype=torch.int64, device=dev); tout = torch.empty(na + nb, dtype=torch.int32, device=dev)
     res = {}
     for name, op, tx in (("union_tax", lib.OP_UNION, True), ("inter_tax", lib.OP_INTER, True), ("union", lib.OP_UNION, False), ("inter", lib.OP_INTER, False)):

@@ -292,6 +292,49 @@ __device__ __forceinline__ u32 lca_finish(const TaxDev &T, const LcaReq &q) {
     }
     return lca_from_rows(T, a, b, pa, pb);
 }
+// ---- the clade-pair step out of LDS (round 6) ----------------------------------------------------------------------
+// A divergent gather costs a 128-byte line of L1 fill whatever it returns; of the three an unrelated pair used to take
+// (two clade bytes, one pair word) the pair word was 46 % of the time (2 x 3e8 records, union with random taxids: 5.75 ms,
+// 4.28 with the pair word computed instead of read, 2.54 without any look-up).  The pair step now reads two 16-byte rows
+// and one word of a 5 KB table the workgroup holds in LDS (TaxDev::cpath / cnode).
+struct CladeLds {
+    uint4 path[TAX_CPATH_ROWS];
+    u32 node[TAX_CPATH_ROWS];
+};
+template <bool ON> struct CladeLdsOpt { CladeLds t; };  // (a kernel template's LDS member: nothing when it has no taxids)
+template <> struct CladeLdsOpt<false> { u32 t; };
+// (every thread of the workgroup; the caller's next barrier publishes the table)
+__device__ __forceinline__ void clade_lds_load(const TaxDev &T, CladeLds &L, int tid, int nthreads) {
+    if (T.cpath == nullptr) return;  // (uniform)
+    for (u32 i = (u32)tid; i < TAX_CPATH_ROWS; i += (u32)nthreads) {
+        L.path[i] = T.cpath[i];
+        L.node[i] = T.cnode[i];
+    }
+}
+// ca != cb, both non-zero
+__device__ __forceinline__ u32 lca_clade_pair_lds(const TaxDev &T, const CladeLds &L, u32 ca, u32 cb) {
+    const uint4 A = L.path[ca], B = L.path[cb];
+    const u64 al = ((u64)A.y << 32) | A.x, ah = ((u64)A.w << 32) | A.z;
+    const u64 xl = al ^ (((u64)B.y << 32) | B.x), xh = ah ^ (((u64)B.w << 32) | B.z);
+    if ((xl | xh) == 0) return T.pair[ca * T.kp + cb];  // 16 shared levels: both far down one chain (rare)
+    const bool in_lo = xl != 0;
+    const int n = (__builtin_ctzll(in_lo ? xl : xh) >> 3) + (in_lo ? 0 : 8);  // levels the two root paths share
+    if (n == 0) return 0;                                                     // different trees
+    const int m = n - 1;
+    const u32 code = (u32)((m < 8 ? al : ah) >> (8 * (m & 7))) & 255u;
+    return L.node[code];
+}
+// lca_dev with the pair step out of LDS (the caller has checked T.cpath != nullptr: the one-byte codes are loaded)
+__device__ __forceinline__ u32 lca_dev_lds(const TaxDev &T, const CladeLds &L, u32 a, u32 b) {
+    if (a == 0 || b == 0) return 0;
+    if (a == b) return a;
+    const uint4 zero = make_uint4(0, 0, 0, 0);
+    if (a < T.size && b < T.size) {
+        const u32 ca = T.clade8[a], cb = T.clade8[b];
+        if (ca != cb && ca != 0 && cb != 0) return lca_clade_pair_lds(T, L, ca, cb);
+    }
+    return lca_from_rows(T, a, b, a < T.size ? T.anc[a] : zero, b < T.size ? T.anc[b] : zero);
+}
 // With clade codes: unrelated pairs -- different codes -- are settled by two small reads and two rows of the `top` table,
 // relatives (and absent / merged ids) take the root paths behind them.
 __device__ __forceinline__ u32 lca_dev(const TaxDev &T, u32 a, u32 b) {

@@ -73,7 +73,15 @@ struct TaxDev {
     // clade or no code -> the root paths answer); at most 256 x 256 words, one read instead of two rows of `top`
     const u32 *pair;
     u32 kp;
+    // behind the pair table, in the same allocation (round 6): what a workgroup copies into LDS so that an unrelated pair
+    // costs NO third gather.  cpath[c] = 16 bytes: byte d = the code of clade node c's ancestor at depth d (c itself at its
+    // own depth, 0 below it; the first 16 levels of a deeper node), 256 rows; cnode[c] = the taxid of clade node c, 256
+    // words.  Two different codes whose rows differ have the LCA cnode[the last byte their rows share] (no shared byte:
+    // different trees, 0); rows that agree in all 16 bytes (both nodes 16 or more levels down one chain) ask `pair`.
+    const uint4 *cpath;
+    const u32 *cnode;
 };
+constexpr u32 TAX_CPATH_ROWS = 256;
 
 // ---- workspace arena: chunked bump allocator on the ctx's device ------------------------------
 struct WsBlock {
@@ -249,6 +257,11 @@ static inline TaxDev ukm_taxdev(const ukm_ctx *c) {
     t.clade8 = c->tax_clade8;
     t.pair = c->tax_pair;
     t.kp = c->tax_kp;
+    {   // [pair kp x kp | pad to 16 bytes | cpath 256 x 16 B | cnode 256 x 4 B]
+        const size_t off = (((size_t)c->tax_kp * c->tax_kp) + 3) & ~(size_t)3;
+        t.cpath = c->tax_pair ? reinterpret_cast<const uint4 *>(c->tax_pair + off) : nullptr;
+        t.cnode = c->tax_pair ? c->tax_pair + off + 4 * TAX_CPATH_ROWS : nullptr;
+    }
     t.top = c->tax_top;
     t.nchunks = c->tax_nchunks;
     t.size = c->tax_size;

@@ -397,15 +397,26 @@ __device__ __forceinline__ void tile_load(const SetopArgs &p, const TileGeom &g,
         const bool v0 = s0 >= lo && s0 < hi, v1 = s1 >= lo && s1 < hi;
         const bool both = v0 && v1;
         const u64 *src = in_a ? pa : pb;
-        const ulonglong2 q = *reinterpret_cast<const ulonglong2 *>(both ? src + s0 : safe);  // aligned by construction
+        // (per-record taxids: the streams go past L2 with the non-temporal hint, in and out, so that the clade table stays in
+        //  it -- union of 2 x 3e8 with random taxids 5.75 -> 5.03 ms, of which the stores are 0.5; the plain kernel, which
+        //  gathers nothing, was slower with the hint: profiles/r01_notes.md)
+        ulonglong2 q;
+        if (TAX) {
+            typedef u64 v2u64 __attribute__((ext_vector_type(2)));
+            const v2u64 w = __builtin_nontemporal_load(reinterpret_cast<const v2u64 *>(both ? src + s0 : safe));
+            q.x = w.x;
+            q.y = w.y;
+        } else {
+            q = *reinterpret_cast<const ulonglong2 *>(both ? src + s0 : safe);  // aligned by construction
+        }
         rk[2 * j] = q.x;      // slots without a real element keep whatever was read: they are
         rk[2 * j + 1] = q.y;  // never compared (order check and merge only touch real slots)
         u32 t0 = 0, t1 = 0, r0 = 0, r1 = 0;
         if (TAX) {
             const u32 *ts = in_a ? pta : ptb;
             const bool h0 = ts && v0, h1 = ts && v1;
-            t0 = *(h0 ? ts + s0 : safe32);
-            t1 = *(h1 ? ts + s1 : safe32);
+            t0 = __builtin_nontemporal_load(h0 ? ts + s0 : safe32);
+            t1 = __builtin_nontemporal_load(h1 ? ts + s1 : safe32);
             const u32 tc = in_a ? p.cta : p.ctb;  // a stream without per-record taxids carries its file's taxid (0: none, mix-taxid)
             t0 = ts ? t0 : tc;
             t1 = ts ? t1 : tc;
@@ -554,10 +565,129 @@ __device__ __forceinline__ u32 tile_check_order_lds(const TileGeom &g, int tid, 
 // CT (both streams carry one taxid per FILE): the step also records which side an item came from (amask) and whether it
 // was a matched pair (mmask) -- two bit masks instead of a taxid per item; ct_keep (diff -t, resolved once per call)
 // leaves matched codes in the result.
-template <int OP, bool TAX, bool RANK, bool INTERIOR, bool CT, int VT>
+// union / inter with per-record taxids, the LCAs BEHIND the merge loop and DENSE (round 6; needs the clade table in LDS).
+// With the look-ups inside the loop every one of the VT serial steps waits for its own round trip to L2 with a quarter of
+// the lanes active (53 % of a tile's cycles in the phase profile, profiles/r06_notes.md section 4).  Here the loop only
+// notes which steps need an LCA (`need`) and keeps B's taxid of every step; after the compaction each such step queues
+// (place of its output record, B's taxid) in the LDS words the matched records have left free -- a union's tile gives up
+// one place per match, an intersection's more -- and the workgroup walks the queue with every lane busy: two clade bytes
+// per lane and round, the pair step out of LDS (lca_clade_pair_lds), relatives / unknown / merged ids (about 1 % of
+// uniformly random pairs) through the root paths in place.  ~3 dense rounds per tile instead of VT sparse ones.
+// (Measured and dropped on the way: the same look-ups per THREAD behind the loop, 2 x 4 / 6 / 12 gathers in flight per
+// lane with idle lanes reading entry 0 -- 6.35 / 6.65 / 7.5 ms against 5.56 inside the loop at 2 x 3e8.)
+#ifndef SETOP_TAX_DEFER
+#define SETOP_TAX_DEFER 1
+#endif
+template <int OP, bool RANK, bool INTERIOR, int VT>
+__device__ __forceinline__ void tile_merge_loop_deferred(const SetopArgs &p, const TileGeom &g, int pa, int pb, const u64 *s_keys,
+                                                         const u32 *s_tax, const u32 *s_rank, u64 (&ok)[VT], u32 (&ot)[VT],
+                                                         u32 &mask, u32 (&tbm)[VT], u32 &need) {
+    static_assert(OP == UKM_OP_UNION || OP == UKM_OP_INTER, "operations whose survivors do not depend on an LCA");
+    const int base_a = g.base_a, end_a = g.end_a, end_b = g.end_b;
+    const int end_bx = end_b + (g.has_next_b ? 1 : 0);
+    u64 ak = s_keys[pa], bk = s_keys[pb];
+    u32 ar = 0, br = 0;
+    if (RANK) { ar = s_rank[pa]; br = s_rank[pb]; }
+    bool eq_prev = false;
+    if (OP == UKM_OP_UNION) {
+        const bool pv = (pa > base_a) || g.has_prev_a;
+        eq_prev = pv && (INTERIOR || pb < end_b) && key_eq<RANK>(s_keys[pa - 1], RANK ? s_rank[pa - 1] : 0, bk, br);
+    }
+    const bool mix = OP == UKM_OP_INTER && (p.flags & UKM_F_MIX_TAXID) != 0;
+    need = 0;  // matched steps whose two taxids differ and are both non-zero: ot[s] holds A's, tbm[s] B's
+    mask = 0;
+#pragma unroll
+    for (int s = 0; s < VT; s++) {
+        bool take_a, take_b, match;
+        if (INTERIOR) {
+            take_a = key_le<RANK>(ak, ar, bk, br);
+            take_b = !take_a;
+            match = key_eq<RANK>(ak, ar, bk, br);
+        } else {
+            const bool a_ok = pa < end_a, b_ok = pb < end_b;
+            take_a = a_ok && (!b_ok || key_le<RANK>(ak, ar, bk, br));
+            take_b = !take_a && b_ok;
+            match = take_a && (pb < end_bx) && key_eq<RANK>(ak, ar, bk, br);
+        }
+        bool emit;
+        u64 ek = ak;
+        if (OP == UKM_OP_UNION) {
+            emit = take_a || (take_b && !eq_prev);
+            ek = take_a ? ak : bk;
+            eq_prev = match;
+        } else {
+            emit = match;
+        }
+        const u32 ta = s_tax[pa], tb = s_tax[pb];
+        u32 et = (OP == UKM_OP_UNION && !take_a) ? tb : ta;  // (a match takes A: et = A's taxid)
+        const bool zero = ta == 0 || tb == 0;
+        if (match && zero) et = mix ? (ta | tb) : 0u;  // LCA(x, 0) = 0; inter --mix-taxid: the other one (inter.go:229-236)
+        need |= (match && !zero && ta != tb) ? (1u << s) : 0u;
+        tbm[s] = tb;
+        ok[s] = ek;
+        ot[s] = et;
+        mask |= emit ? (1u << s) : 0u;
+        pa += take_a ? 1 : 0;
+        pb += take_b ? 1 : 0;
+        const int idx = take_a ? pa : pb;
+        const u64 nk = s_keys[idx];
+        ak = take_a ? nk : ak;
+        bk = take_a ? bk : nk;
+        if (RANK) {
+            const u32 nr = s_rank[idx];
+            ar = take_a ? nr : ar;
+            br = take_a ? br : nr;
+        }
+    }
+}
+// the queue: one 8-byte word per step in `need`, behind the tile's compacted records (call with tile_compact)
+template <int VT>
+__device__ __forceinline__ void tile_queue_lca(u32 excl, u32 mask, u32 need, u32 qpos, const u32 (&tbm)[VT], u64 *s_queue) {
+#pragma unroll
+    for (int s = 0; s < VT; s++) {
+        if (need & (1u << s)) {
+            const u32 below = (1u << s) - 1u;
+            const u32 w = excl + (u32)__popc(mask & below);
+            s_queue[qpos + (u32)__popc(need & below)] = ((u64)w << 32) | tbm[s];
+        }
+    }
+}
+// every lane busy: s_tax[w] = LCA(s_tax[w], b) for the n queued (w, b)
+template <int NTH>
+__device__ __forceinline__ void tile_lca_dense(const TaxDev &T, const CladeLds &L, int tid, u32 n, const u64 *s_queue, u32 *s_tax) {
+    const uint4 zero4 = make_uint4(0, 0, 0, 0);
+    for (u32 i = (u32)tid; i < n; i += 2 * NTH) {
+        const bool two = i + NTH < n;
+        const u64 e0 = s_queue[i], e1 = s_queue[two ? i + NTH : i];
+        const u32 w0 = (u32)(e0 >> 32), w1 = (u32)(e1 >> 32), b0 = (u32)e0, b1 = (u32)e1;
+        const u32 a0 = s_tax[w0], a1 = s_tax[w1];
+        const bool in0 = a0 < T.size && b0 < T.size, in1 = two && a1 < T.size && b1 < T.size;
+        const u32 ca0 = T.clade8[in0 ? a0 : 0u], cb0 = T.clade8[in0 ? b0 : 0u];
+        const u32 ca1 = T.clade8[in1 ? a1 : 0u], cb1 = T.clade8[in1 ? b1 : 0u];
+        u32 r0, r1 = 0;
+        if (ca0 != cb0 && ca0 != 0 && cb0 != 0) r0 = lca_clade_pair_lds(T, L, ca0, cb0);
+        else r0 = lca_from_rows(T, a0, b0, a0 < T.size ? T.anc[a0] : zero4, b0 < T.size ? T.anc[b0] : zero4);
+        if (two) {
+            if (ca1 != cb1 && ca1 != 0 && cb1 != 0) r1 = lca_clade_pair_lds(T, L, ca1, cb1);
+            else r1 = lca_from_rows(T, a1, b1, a1 < T.size ? T.anc[a1] : zero4, b1 < T.size ? T.anc[b1] : zero4);
+        }
+        s_tax[w0] = r0;
+        if (two) s_tax[w1] = r1;
+    }
+}
+
+template <int OP, bool TAX, bool RANK, bool INTERIOR, bool CT, int VT, bool DEFER>
 __device__ __forceinline__ void tile_merge_loop(const SetopArgs &p, const TileGeom &g, int pa, int pb,
                                                 const u64 *s_keys, const u32 *s_tax, const u32 *s_rank,
-                                                u64 (&ok)[VT], u32 (&ot)[VT], u32 &mask, u32 &amask, u32 &mmask, bool ct_keep) {
+                                                u64 (&ok)[VT], u32 (&ot)[VT], u32 &mask, u32 &amask, u32 &mmask, bool ct_keep,
+                                                const CladeLds *cl, u32 (&tbm)[VT], u32 &need) {
+    if constexpr (DEFER) {  // (chosen by the host: the taxonomy comes with one-byte clade codes, TaxDev::cpath)
+        static_assert(TAX && !CT, "per-record taxids");
+        amask = 0;
+        mmask = 0;
+        tile_merge_loop_deferred<OP, RANK, INTERIOR, VT>(p, g, pa, pb, s_keys, s_tax, s_rank, ok, ot, mask, tbm, need);
+        return;
+    }
     const int base_a = g.base_a, end_a = g.end_a, end_b = g.end_b;
     const int end_bx = end_b + (g.has_next_b ? 1 : 0);
     u64 ak = s_keys[pa], bk = s_keys[pb];
@@ -573,9 +703,10 @@ __device__ __forceinline__ void tile_merge_loop(const SetopArgs &p, const TileGe
     // Files carry few distinct taxids over long stretches (one per genome, or one per clade after LCA
     // assignment), so consecutive matches of a thread mostly ask for the same pair: remember the last one.
     u32 memo_a = 0, memo_b = 0, memo_l = 0;  // LCA(0, 0) = 0
+    const bool lds_pairs = TAX && p.tax.cpath != nullptr;  // (uniform) the clade-pair step out of LDS
     auto lca_memo = [&](u32 a, u32 b) -> u32 {
         if (a != memo_a || b != memo_b) {
-            memo_l = lca_dev(p.tax, a, b);
+            memo_l = lds_pairs ? lca_dev_lds(p.tax, *cl, a, b) : lca_dev(p.tax, a, b);
             memo_a = a;
             memo_b = b;
         }
@@ -652,10 +783,11 @@ __device__ __forceinline__ void tile_merge_loop(const SetopArgs &p, const TileGe
     }
 }
 
-template <int OP, bool TAX, bool RANK, bool CT, int NTH, int VT>
+template <int OP, bool TAX, bool RANK, bool CT, int NTH, int VT, bool DEFER>
 __device__ __forceinline__ void tile_merge(const SetopArgs &p, const TileGeom &g, int tid, const u64 *s_keys,
                                            const u32 *s_tax, const u32 *s_rank, u64 (&ok)[VT], u32 (&ot)[VT],
-                                           u32 &mask, u32 &amask, u32 &mmask, bool ct_keep, int &ia0, int &ib0) {
+                                           u32 &mask, u32 &amask, u32 &mmask, bool ct_keep, int &ia0, int &ib0, const CladeLds *cl,
+                                           u32 (&tbm)[VT], u32 &need) {
     const int na_t = g.na_t, nb_t = g.nb_t, total = na_t + nb_t;
     const int base_a = g.base_a, base_b = g.base_b;
     int diag = tid * VT;
@@ -674,9 +806,9 @@ __device__ __forceinline__ void tile_merge(const SetopArgs &p, const TileGeom &g
     ib0 = diag - lo;
     // wave-uniform choice (tile geometry): no divergence
     if (total == NTH * VT && g.has_next_a && g.has_next_b)
-        tile_merge_loop<OP, TAX, RANK, true, CT, VT>(p, g, pa, pb, s_keys, s_tax, s_rank, ok, ot, mask, amask, mmask, ct_keep);
+        tile_merge_loop<OP, TAX, RANK, true, CT, VT, DEFER>(p, g, pa, pb, s_keys, s_tax, s_rank, ok, ot, mask, amask, mmask, ct_keep, cl, tbm, need);
     else
-        tile_merge_loop<OP, TAX, RANK, false, CT, VT>(p, g, pa, pb, s_keys, s_tax, s_rank, ok, ot, mask, amask, mmask, ct_keep);
+        tile_merge_loop<OP, TAX, RANK, false, CT, VT, DEFER>(p, g, pa, pb, s_keys, s_tax, s_rank, ok, ot, mask, amask, mmask, ct_keep, cl, tbm, need);
 }
 
 // compact the emitted items of this thread into LDS at its exclusive offset
@@ -706,13 +838,19 @@ __device__ __forceinline__ void tile_flush(const SetopArgs &p, int tid, u64 base
             const int i0 = 2 * m - sh, i1 = i0 + 1;
             const bool v0 = i0 >= 0, v1 = i1 < (int)count;
             const u64 k0 = s_keys[v0 ? i0 : 0], k1 = s_keys[v1 ? i1 : 0];
-            if (v0 && v1) *reinterpret_cast<ulonglong2 *>(o + i0) = make_ulonglong2(k0, k1);
+            if (TAX && v0 && v1) {  // (non-temporal beside the taxid look-ups: see tile_load)
+                typedef u64 v2u64 __attribute__((ext_vector_type(2)));
+                v2u64 w;
+                w.x = k0;
+                w.y = k1;
+                __builtin_nontemporal_store(w, reinterpret_cast<v2u64 *>(o + i0));
+            } else if (v0 && v1) *reinterpret_cast<ulonglong2 *>(o + i0) = make_ulonglong2(k0, k1);
             else if (v0) o[i0] = k0;
             else if (v1) o[i1] = k1;
         }
         if (TAX) {
             u32 *to = p.tout + base;
-            for (u32 i = (u32)tid; i < count; i += NTH) to[i] = s_tax[i];
+            for (u32 i = (u32)tid; i < count; i += NTH) __builtin_nontemporal_store(s_tax[i], to + i);
         }
     } else {  // capacity overflow: guarded stores; the host reports UKM_ERR_CAPACITY
         for (u32 i = (u32)tid; i < count; i += NTH) {
@@ -807,6 +945,13 @@ __global__ __launch_bounds__(GATHER_NT) void setop_taxid_gather_kernel(SetopArgs
     const u64 a0 = p.mp[tile], b0 = tile * (u64)TILE - a0;
     const bool mix = (p.flags & UKM_F_MIX_TAXID) != 0;
     const u32 *safe32 = reinterpret_cast<const u32 *>(p.result);  // (always mapped: where a lane has nothing to read)
+    constexpr bool LCA_OP = OP == UKM_OP_UNION || OP == UKM_OP_INTER;
+    __shared__ CladeLdsOpt<LCA_OP> s_clade_tab;  // the clade-pair step out of LDS (ukm_device.h)
+    const bool lds_pairs = LCA_OP && p.tax.cpath != nullptr;  // (uniform; every early return above is uniform too)
+    if constexpr (LCA_OP) {
+        clade_lds_load(p.tax, s_clade_tab.t, (int)threadIdx.x, GATHER_NT);
+        __syncthreads();
+    }
     // U records per thread and step: four rounds of loads -- the words, the taxids, the clade codes, the clade pairs -- each
     // round with all of its reads in flight, none inside a branch.  (Measured at 2 x 1e8, inter with one taxid per file as arrays:
     // 256 threads x 8 records 0.99 ms, x 4 1.06, x 2 1.13; a whole tile per 1024-thread workgroup in ONE step 1.22.)
@@ -845,7 +990,10 @@ __global__ __launch_bounds__(GATHER_NT) void setop_taxid_gather_kernel(SetopArgs
             for (int u = 0; u < U; u++) {
                 const bool q = ca[u] != cb[u] && ca[u] != 0 && cb[u] != 0;
                 qmask |= q ? (1u << u) : 0u;
-                quick[u] = p.tax.pair[q ? ca[u] * p.tax.kp + cb[u] : 0u];
+                if constexpr (LCA_OP) {
+                    if (lds_pairs) quick[u] = q ? lca_clade_pair_lds(p.tax, s_clade_tab.t, ca[u], cb[u]) : 0u;
+                    else quick[u] = p.tax.pair[q ? ca[u] * p.tax.kp + cb[u] : 0u];
+                }
             }
         }
 #pragma unroll
@@ -895,7 +1043,7 @@ __global__ void setop_ct_kernel(SetopArgs p, int op) {
 #ifndef SETOP_WAVES
 #define SETOP_WAVES 4  /* experiments only: 6 = three workgroups per CU (needs SETOP_VT <= 12) */
 #endif
-template <int OP, bool TAX, bool RANK, bool TICKET, int NTH, int VT, bool CT = false>
+template <int OP, bool TAX, bool RANK, bool TICKET, int NTH, int VT, bool CT = false, bool DEFER = false>
 __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu((TAX && RANK) ? 2 : SETOP_WAVES, (TAX && RANK) ? 8 : SETOP_WAVES)))
 void setop_tile_kernel(SetopArgs p) {
     static_assert(!(CT && TAX), "CT: no per-record taxids");
@@ -907,6 +1055,7 @@ void setop_tile_kernel(SetopArgs p) {
     __shared__ __attribute__((aligned(16))) u32 s_rank[RANK ? SLOTS : 2];
     __shared__ u32 s_scan[NTH / 64 + 1];
     __shared__ u64 s_misc[2];
+    __shared__ CladeLdsOpt<TAX> s_clade_tab;
     const int tid = (int)threadIdx.x;
 #ifdef UKM_PROFILE_PHASES
     u64 ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -936,6 +1085,7 @@ void setop_tile_kernel(SetopArgs p) {
         u64 rk[2 * NP];
         u32 rt[2 * NP], rr[2 * NP];
         tile_load<TAX, RANK, NTH, VT>(p, g, tid, rk, rt, rr);
+        if constexpr (TAX) clade_lds_load(p.tax, s_clade_tab.t, tid, NTH);
         tile_to_lds<TAX, RANK, NTH, VT>(tid, rk, rt, rr, s_keys, s_tax, s_rank);
         __syncthreads();
         PH(1);
@@ -943,6 +1093,8 @@ void setop_tile_kernel(SetopArgs p) {
     }
     u64 ok[VT];
     u32 ot[VT];
+    u32 tbm[VT];  // DEFER only: B's taxid of every step, `need` = the steps that wait for an LCA
+    u32 need = 0, nneed = 0, qpos = 0;
     u32 mask, amask = 0, mmask = 0;
     int ia0 = 0, ib0 = 0;
     u32 ct_lca = 0;
@@ -957,7 +1109,8 @@ void setop_tile_kernel(SetopArgs p) {
 #pragma unroll
     for (int s = 0; s < VT; s++) { ok[s] = s_keys[tid * VT + s]; ot[s] = 0; }
 #else
-    tile_merge<OP, TAX, RANK, CT, NTH, VT>(p, g, tid, s_keys, s_tax, s_rank, ok, ot, mask, amask, mmask, ct_keep, ia0, ib0);
+    tile_merge<OP, TAX, RANK, CT, NTH, VT, DEFER>(p, g, tid, s_keys, s_tax, s_rank, ok, ot, mask, amask, mmask, ct_keep, ia0, ib0,
+                                           TAX ? reinterpret_cast<const CladeLds *>(&s_clade_tab.t) : nullptr, tbm, need);
 #endif
     PH(2);
     u32 tile_total;
@@ -969,7 +1122,8 @@ void setop_tile_kernel(SetopArgs p) {
     u32 excl;
     {
         constexpr int NW = NTH / 64;
-        const u32 v = (u32)__popc(mask);
+        // (DEFER: the queue positions ride in the upper half of the same scan; both sums stay below 2^16)
+        const u32 v = (u32)__popc(mask) | (DEFER ? (u32)__popc(need) << 16 : 0u);
         const int lane = lane_id(), wave = tid >> 6;
         const u32 incl = wave_incl_scan_u32(v);
         if (lane == 63) s_scan[wave] = incl;
@@ -983,6 +1137,13 @@ void setop_tile_kernel(SetopArgs p) {
         }
         tile_total = tot;
         excl = wbase + incl - v;
+        if (DEFER) {
+            static_assert(!DEFER || NTH * VT + 8 < (1 << 16), "two 16-bit sums in one word");
+            nneed = tot >> 16;
+            qpos = excl >> 16;
+            tile_total = tot & 0xFFFFu;
+            excl &= 0xFFFFu;
+        }
         if (OP != UKM_OP_MERGE_INTERNAL && tid == 0) lb_publish(p.status, tile, (u64)tile_total);
         if (fast) bad |= tile_check_order_lds<NTH, VT>(g, tid, s_keys);
         __syncthreads();  // every thread has finished reading the tile from LDS; s_scan may be reused
@@ -990,6 +1151,13 @@ void setop_tile_kernel(SetopArgs p) {
 #ifndef SETOP_ABL_NOCOMPACT
     tile_compact<TAX, VT>(excl, mask, ok, ot, s_keys, s_tax);
 #endif
+    if constexpr (DEFER) {
+        // the LCAs, dense: the queue lies behind the compacted records (a match leaves one place free in a union's tile
+        // -- its B record is dropped, here or as the next tile's first step -- and more in an intersection's)
+        tile_queue_lca<VT>(excl, mask, need, qpos, tbm, s_keys + tile_total);
+        __syncthreads();
+        tile_lca_dense<NTH>(p.tax, s_clade_tab.t, tid, nneed, s_keys + tile_total, s_tax);
+    }
     PH(3);
     if (OP == UKM_OP_MERGE_INTERNAL) {
         if (tid == 0) s_misc[1] = tile * (u64)TILE;  // every record is kept: the tile's output offset is known
@@ -1067,23 +1235,23 @@ __global__ void lower_bound_kernel(const u64 *k, u64 n, const u64 *q, int nq, u6
     out[i] = lo;
 }
 
-template <int OP, bool TAX, bool RANK, int NTH, int VT, bool CT = false>
+template <int OP, bool TAX, bool RANK, int NTH, int VT, bool CT = false, bool DEFER = false>
 void launch_tile(const SetopArgs &p, hipStream_t st, bool ticket) {
     if (CT) hipLaunchKernelGGL(setop_ct_kernel, dim3(1), dim3(1), 0, st, p, OP);
     if (ticket)
-        hipLaunchKernelGGL((setop_tile_kernel<OP, TAX, RANK, true, NTH, VT, CT>), dim3((unsigned)p.ntiles), dim3(NTH), 0, st, p);
+        hipLaunchKernelGGL((setop_tile_kernel<OP, TAX, RANK, true, NTH, VT, CT, DEFER>), dim3((unsigned)p.ntiles), dim3(NTH), 0, st, p);
     else
-        hipLaunchKernelGGL((setop_tile_kernel<OP, TAX, RANK, false, NTH, VT, CT>), dim3((unsigned)p.ntiles), dim3(NTH), 0, st, p);
+        hipLaunchKernelGGL((setop_tile_kernel<OP, TAX, RANK, false, NTH, VT, CT, DEFER>), dim3((unsigned)p.ntiles), dim3(NTH), 0, st, p);
     if constexpr (CT && !RANK) {
         if (p.ta != nullptr || p.tb != nullptr)  // the source words of the launch above -> taxids
             hipLaunchKernelGGL((setop_taxid_gather_kernel<OP, NTH * VT>), dim3((unsigned)p.ntiles), dim3(GATHER_NT), 0, st, p);
     }
 }
 
-template <bool TAX, bool RANK, int NTH, int VT, bool CT = false>
+template <bool TAX, bool RANK, int NTH, int VT, bool CT = false, bool DEFER = false>
 void launch_op(int op, const SetopArgs &p, hipStream_t st, bool ticket) {
-    if (op == UKM_OP_UNION) launch_tile<UKM_OP_UNION, TAX, RANK, NTH, VT, CT>(p, st, ticket);
-    else if (op == UKM_OP_INTER) launch_tile<UKM_OP_INTER, TAX, RANK, NTH, VT, CT>(p, st, ticket);
+    if (op == UKM_OP_UNION) launch_tile<UKM_OP_UNION, TAX, RANK, NTH, VT, CT, DEFER>(p, st, ticket);
+    else if (op == UKM_OP_INTER) launch_tile<UKM_OP_INTER, TAX, RANK, NTH, VT, CT, DEFER>(p, st, ticket);
     else if (op == UKM_OP_MERGE_INTERNAL) {
         if constexpr (!RANK) launch_tile<UKM_OP_MERGE_INTERNAL, TAX, false, NTH, VT, CT>(p, st, ticket);
     } else launch_tile<UKM_OP_DIFF, TAX, RANK, NTH, VT, CT>(p, st, ticket);
@@ -1092,7 +1260,7 @@ void launch_op(int op, const SetopArgs &p, hipStream_t st, bool ticket) {
 constexpr int NTS = SETOP_NT;       // threads per workgroup (512: two workgroups per CU)
 constexpr int VT_PLAIN = SETOP_VT;  // 19 items per thread: 76 KiB of keys in LDS per workgroup (2 x 78 KB fit the CU's 160 KB)
 #ifndef SETOP_VT_TAX
-#define SETOP_VT_TAX 13
+#define SETOP_VT_TAX 12
 #endif
 constexpr int VT_TAX = SETOP_VT_TAX;     // fewer when taxids/ranks ride along
 
@@ -1177,7 +1345,10 @@ int run_setop_pass(ukm_ctx *c, int op, const u64 *a, const u32 *ta, const u32 *r
             else if (ct) launch_op<false, true, NTS, VT_TAX, true>(op, p, c->stream, ticket);
             else launch_op<false, true, NTS, VT_TAX>(op, p, c->stream, ticket);
         } else {
-            if (tax) launch_op<true, false, NTS, VT_TAX>(op, p, c->stream, ticket);
+            // union / inter with per-record taxids and one-byte clade codes: the LCAs behind the merge loop (tile_merge_loop_deferred)
+            const bool defer = SETOP_TAX_DEFER != 0 && p.tax.cpath != nullptr && !ukm_env_is(c, "UKM_SETOP_DEFER", '0');
+            if (tax && defer) launch_op<true, false, NTS, VT_TAX, false, true>(op, p, c->stream, ticket);
+            else if (tax) launch_op<true, false, NTS, VT_TAX>(op, p, c->stream, ticket);
             else if (ct) launch_op<false, false, NTS, VT_PLAIN, true>(op, p, c->stream, ticket);
             else launch_op<false, false, NTS, VT_PLAIN>(op, p, c->stream, ticket);
         }

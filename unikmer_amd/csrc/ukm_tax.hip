@@ -91,7 +91,7 @@ int to_host(ukm_ctx *c, const T *p, u64 n, std::vector<T> &v) {
 static u64 tax_bytes_held(const ukm_ctx *c) {
     if (!c->tax_parent) return 0;
     return (u64)c->tax_size * (sizeof(u32) + sizeof(u8) + (c->tax_merged ? sizeof(u32) : 0) + 2 * sizeof(u32) + (c->tax_clade ? 2 : (c->tax_clade8 ? 1 : 0))) +
-           (u64)c->tax_nchunks * c->tax_size * sizeof(uint4) + (c->tax_pair ? (u64)c->tax_kp * c->tax_kp * sizeof(u32) : 0) +
+           (u64)c->tax_nchunks * c->tax_size * sizeof(uint4) + (c->tax_pair ? ((u64)c->tax_kp * c->tax_kp + 4 + 5 * TAX_CPATH_ROWS) * sizeof(u32) : 0) +
            (c->tax_top ? (u64)c->tax_top_n * sizeof(uint4) : 0);
 }
 
@@ -293,6 +293,20 @@ extern "C" int ukm_taxonomy_load(ukm_ctx *c, const uint32_t *child, const uint32
                     while (a != b && P[a] != a && P[b] != b) { a = P[a]; b = P[b]; }
                     PAIR[(size_t)i2 * kp + j2] = a == b ? a : 0u;  // (different trees: 0)
                 }
+            // behind it (TaxDev::cpath / cnode): the first 16 levels of every clade node's root path as code bytes, and the
+            // nodes themselves -- 5 KB a workgroup keeps in LDS.  The set is closed upwards, so a clade node's depth in the
+            // forest is its depth among the clade nodes and every ancestor has a code.
+            PAIR.resize((PAIR.size() + 3) & ~(size_t)3, 0u);
+            const size_t off = PAIR.size();
+            PAIR.resize(off + 5 * (size_t)TAX_CPATH_ROWS, 0u);
+            unsigned char *rows = reinterpret_cast<unsigned char *>(PAIR.data() + off);
+            for (u32 i2 = 1; i2 < kp; i2++) {
+                PAIR[off + 4 * (size_t)TAX_CPATH_ROWS + i2] = fnode[i2];
+                for (u32 t = fnode[i2];; t = P[t]) {
+                    if (depth[t] < 16) rows[(size_t)i2 * 16 + depth[t]] = (unsigned char)Q[t];
+                    if (P[t] == t) break;
+                }
+            }
         } else if (Dq >= 0) {
             Q.assign(size, 0);
             for (size_t i = 1; i < N.size(); i++) {
