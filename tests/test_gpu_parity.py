@@ -188,6 +188,70 @@ def test_setop2_per_record_taxids_source_words(ctx, O, L, tree, monkeypatch, mod
     assert len(gk) == 0 and len(gt) == 0
 
 
+@pytest.mark.parametrize("mode", ["0", "1", "2"])
+def test_setop2_taxids_deep_forest_clade_paths(O, L, monkeypatch, mode):
+    """Round 6: the clade-pair step reads two 16-level root paths out of LDS (ukm_device.h: lca_clade_pair_lds) and the
+    LCAs of a tile are walked densely behind the merge loop (tile_merge_loop_deferred / tile_lca_dense).  A forest whose
+    clade cut runs 40 levels down a spine (every spine node has two small subtrees beside the next one: the cut follows
+    the largest subtree), so that pairs below DIFFERENT clade nodes share all 16 levels (the pair-table fallback), pairs
+    in other trees (LCA 0), relatives inside one clade (root paths), merged ids, zero and unknown ids; union / inter /
+    diff [-t] / inter --mix-taxid against the oracle's ancestor walk through all three routes (UKM_SETOP_SRC) and with the
+    dense pass switched off."""
+    monkeypatch.setenv("UKM_SETOP_SRC", mode)
+    child, parent = [1], [1]
+    nxt = 2
+    spine = 1
+    for d in range(40):                       # spine + two bushes of 1 + 3 + 9 nodes per level
+        nodes = []
+        for b in range(2):
+            root = nxt; nxt += 1
+            child.append(root); parent.append(spine); nodes.append(root)
+            for k in range(3):
+                m = nxt; nxt += 1
+                child.append(m); parent.append(root)
+                for k2 in range(3):
+                    child.append(nxt); parent.append(m); nxt += 1
+        s2 = nxt; nxt += 1
+        child.append(s2); parent.append(spine)
+        spine = s2
+    for k in range(3000):                     # a large bush at the end of the spine: the cut goes all the way down
+        child.append(nxt); parent.append(spine if k < 30 else nxt - 30); nxt += 1
+    r2 = nxt; nxt += 1                        # a second and a third tree
+    child.append(r2); parent.append(r2)
+    for k in range(200):
+        child.append(nxt); parent.append(r2 if k < 5 else nxt - 5); nxt += 1
+    r3 = nxt + 10
+    child.append(r3); parent.append(r3)
+    child, parent = np.array(child, np.uint32), np.array(parent, np.uint32)
+    mo, mn = np.array([r3 + 5, r3 + 6], np.uint32), np.array([int(child[777]), 999_999], np.uint32)
+    tax = O.Taxonomy(child, parent, mo, mn)
+    pool = np.concatenate([child, child, child, [0, 0, r3 + 5, r3 + 6, r3 + 7, 2**31]]).astype(np.uint32)
+    rng = np.random.default_rng(11)
+    for defer in ("1", "0"):
+        monkeypatch.setenv("UKM_SETOP_DEFER", defer)
+        c = L.Context(0)
+        c.taxonomy_load(child, parent, mo, mn)
+        got = c.lca(pool[:4000], pool[::-1][:4000])
+        assert np.array_equal(got, np.array([tax.lca(x, y) for x, y in zip(pool[:4000], pool[::-1][:4000])], np.uint32))
+        for n in (50, 6143, 6144, 6145, 120_000):
+            A, B = synth_sets(n, 20)
+            ta, tb = rng.choice(pool, len(A)).astype(np.uint32), rng.choice(pool, len(B)).astype(np.uint32)
+            for op, ofn, fl, kw in ((L.OP_UNION, O.union, 0, {}), (L.OP_INTER, O.inter, 0, {}),
+                                    (L.OP_INTER, O.inter, L.F_MIX_TAXID, {"mix_taxid": True}), (L.OP_DIFF, O.diff, 0, {}),
+                                    (L.OP_DIFF, O.diff, L.F_CMP_TAXID, {"compare_taxid": True})):
+                gk, gt = c.setop2(op, A, B, ta, tb, flags=fl)
+                ek, et = ofn([A, B], [ta, tb], tax, **kw)
+                assert np.array_equal(gk, ek) and np.array_equal(gt, et), (mode, defer, n, op, fl)
+        # identical sets: every record a match (the queue takes every place the B records leave), all pairs need an LCA
+        A = np.arange(1, 20001, dtype=np.uint64) * 5
+        ta, tb = rng.choice(child, len(A)).astype(np.uint32), rng.choice(child, len(A)).astype(np.uint32)
+        for op, ofn in ((L.OP_UNION, O.union), (L.OP_INTER, O.inter)):
+            gk, gt = c.setop2(op, A, A, ta, tb)
+            ek, et = ofn([A, A], [ta, tb], tax)
+            assert np.array_equal(gk, ek) and np.array_equal(gt, et), (mode, defer, op, "all matched")
+        c.close()
+
+
 def test_lca_matches_oracle(ctx, O, tree):
     tax, T = tree
     rng = np.random.default_rng(3)
