@@ -126,8 +126,9 @@ int ukm_last_route(ukm_ctx *ctx);
  *        one-launch range / probe folds of inter and diff off;   "pfold_tax" 0;   "common_probe" 0;   "sort_local" 0 all
  *        radix passes through HBM;   "win_strip" / "nthash_strip" 0 / 1;   "force_ticket" 1 dispatch-order independent kernels
  *        (a context whose look-back watchdog has fired keeps them whatever this option says);   "sort_counting" 0 digit
- *        passes inside every LDS bucket, "sort_fan" 0 no size-class fan-out;   "setop_src" 0 / 2 the two-launch source-word
- *        route of a 2-way operation with per-record taxids never / also for union;   "punion_clade" / "srmerge_clade" 0 / 1
+ *        passes inside every LDS bucket, "sort_fan" 0 no size-class fan-out;   "setop_src" 0 / 1 / 2 the two-launch source-word
+ *        route of a 2-way operation with per-record taxids never / for inter / also for union (default: 0 on a taxonomy
+ *        with one-byte clade codes, else 1);   "punion_clade" / "srmerge_clade" 0 / 1
  *        clade codes in the probe tables / the single pass's emit never / always.
  *      The environment is read ONCE, when a context is created: every UKM_* variable present then is the context's default
  *      for the matching key; no compute call calls getenv (a context created under UKM_ENV_LIVE=1 -- the test suite, which

@@ -147,7 +147,8 @@ def test_setop2_taxids_lca(ctx, O, L, tree, n):
 def test_setop2_per_record_taxids_source_words(ctx, O, L, tree, monkeypatch, mode):
     """Round 5: `inter` with per-record taxids runs the plain-key kernel, whose epilogue writes one SOURCE WORD per output
     record, and a second launch turns the words into taxids (ukm_setops.hip: tile_flush_src / setop_taxid_gather_kernel).
-    UKM_SETOP_SRC: 0 = the taxid instantiation everywhere, 1 = the default (inter), 2 = every operation that allows it.
+    UKM_SETOP_SRC: 0 = the taxid instantiation everywhere (round 6: the default on a taxonomy with one-byte clade codes),
+    1 = inter through source words, 2 = every operation that allows it.
     All three against the oracle on sizes around tile boundaries (a tile is 9728 merged records), on one-sided taxids
     (a file taxid on the other stream), zeros (mix-taxid), a match at a tile's last place, and empty inputs."""
     tax, T = tree

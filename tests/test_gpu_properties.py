@@ -292,7 +292,7 @@ def test_range_fold_equals_chained_fold_large(env, monkeypatch):
 
 def test_inter_per_record_taxids_two_launches_equal_the_taxid_kernel_large(env, monkeypatch):
     """Round 5: 2-way `inter` with per-record taxids = the plain-key kernel writing source words + a gather launch
-    (UKM_SETOP_SRC default) against the taxid instantiation (UKM_SETOP_SRC=0) -- two independent device paths -- on the
+    (UKM_SETOP_SRC=1) against the taxid instantiation (UKM_SETOP_SRC=0, the default since round 6 where one-byte clade codes exist) -- two independent device paths -- on the
     module's two sets (~2e7 records each, 2000+ tiles: source words of every tile shape, pairs split across tile
     boundaries) with uniformly random taxids that include zeros, ids beyond the taxonomy, absent ids inside it and merged
     ids; plain and --mix-taxid; and with a file taxid on one side.  The taxonomy is reloaded in all three clade-code forms

@@ -1043,8 +1043,11 @@ __global__ void setop_ct_kernel(SetopArgs p, int op) {
 #ifndef SETOP_WAVES
 #define SETOP_WAVES 4  /* experiments only: 6 = three workgroups per CU (needs SETOP_VT <= 12) */
 #endif
+#ifndef SETOP_WAVES_TAX
+#define SETOP_WAVES_TAX 6  /* per-record taxids, no ranks: THREE workgroups per CU (SETOP_VT_TAX <= 7) */
+#endif
 template <int OP, bool TAX, bool RANK, bool TICKET, int NTH, int VT, bool CT = false, bool DEFER = false>
-__global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu((TAX && RANK) ? 2 : SETOP_WAVES, (TAX && RANK) ? 8 : SETOP_WAVES)))
+__global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu((TAX && RANK) ? 2 : (TAX ? SETOP_WAVES_TAX : SETOP_WAVES), (TAX && RANK) ? 8 : (TAX ? SETOP_WAVES_TAX : SETOP_WAVES))))
 void setop_tile_kernel(SetopArgs p) {
     static_assert(!(CT && TAX), "CT: no per-record taxids");
     constexpr int TILE = NTH * VT;
@@ -1259,10 +1262,16 @@ void launch_op(int op, const SetopArgs &p, hipStream_t st, bool ticket) {
 
 constexpr int NTS = SETOP_NT;       // threads per workgroup (512: two workgroups per CU)
 constexpr int VT_PLAIN = SETOP_VT;  // 19 items per thread: 76 KiB of keys in LDS per workgroup (2 x 78 KB fit the CU's 160 KB)
+// With per-record taxids the tile is SMALL: 7 items per thread = 43 KB of tile + the 5 KB clade table, so that THREE
+// workgroups share a CU (6 waves per SIMD at 75 registers).  A tile spends most of its time in round trips that depend on
+// each other (loads, the clade bytes of its matches, look-back, flush); with two large tiles per CU neither HBM nor the
+// address unit was busy.  2 x 3e8, random taxids: 12 items (two per CU) union 4.41 / inter 4.08 ms, 9: 4.55 / 4.22,
+// 7 (three per CU): 3.94 / 3.66, 6: 4.08 / 3.81, 5 (four per CU, 8 waves per SIMD): 4.01 / 3.72.
 #ifndef SETOP_VT_TAX
-#define SETOP_VT_TAX 12
+#define SETOP_VT_TAX 7
 #endif
-constexpr int VT_TAX = SETOP_VT_TAX;     // fewer when taxids/ranks ride along
+constexpr int VT_TAX = SETOP_VT_TAX;
+constexpr int VT_RANK = 12;  // ranks ride along (the multiset re-run), with or without taxids
 
 // One pass of the tiled set operation.  result_host[0] = total, [1] = flags.
 // (cta, ctb): the file taxid of a stream whose ta / tb is null (SetopArgs); tax && !ta && !tb = the CT instantiation
@@ -1271,16 +1280,19 @@ int run_setop_pass(ukm_ctx *c, int op, const u64 *a, const u32 *ta, const u32 *r
                    u64 *out, u32 *tout, u64 out_cap, u64 result_host[2], u32 cta = 0, u32 ctb = 0) {
     const bool rank = ra != nullptr;
     bool ct = tax && !ta && !tb;
-    // per-record taxids on plain sets, `inter`: the plain-key kernel writes source words, a second launch turns them into
-    // taxids (tile_flush_src / setop_taxid_gather_kernel).  Measured at 2 x 1e8 records against the taxid instantiation
-    // (profiles/r05_notes.md, section 9): inter 1.60 against 1.78 ms with random taxids, 0.99 against 1.24 with taxids a
-    // thread's memo answers; diff 0.67 = 0.67; union 2.04 against 1.95 and 1.59 against 1.38 -- twice the output records go
-    // through the second launch, which runs at ~130 G records/s -- so only `inter` takes it (UKM_SETOP_SRC: 0 = never, 2 =
-    // every operation but diff -t, whose survivors depend on their taxids; never the multiset re-run with ranks).
-    const int src_mode = ukm_env_int(c, "UKM_SETOP_SRC", 1);
+    // per-record taxids on plain sets: EITHER the taxid instantiation (on a taxonomy with one-byte clade codes its DEFER
+    // form: small tiles, the LCAs walked densely behind the merge loop) OR the plain-key kernel writing a source word per
+    // output record + a second launch that turns the words into taxids (tile_flush_src / setop_taxid_gather_kernel).
+    // Round 6, 2 x 3e8 records, inter: uniformly random taxids 3.66 against 4.32 ms, taxids that repeat (one per file as
+    // arrays, runs of 4096) 2.62 against 2.41 -- the taxid instantiation is the default where its DEFER form exists, the
+    // source words where it does not (round 5: 1.60 against 1.78 ms at 2 x 1e8 with the look-ups inside the merge step);
+    // union loses through the words by 20 % either way.  UKM_SETOP_SRC: 0 = never, 1 = inter, 2 = every operation but
+    // diff -t, whose survivors depend on their taxids; never the multiset re-run with ranks.
+    const bool defer_form = SETOP_TAX_DEFER != 0 && c->tax_pair != nullptr && !ukm_env_is(c, "UKM_SETOP_DEFER", '0');
+    const int src_mode = ukm_env_int(c, "UKM_SETOP_SRC", defer_form ? 0 : 1);
     if (tax && !ct && !rank && src_mode != 0 && (op == UKM_OP_INTER || (src_mode == 2 && !(op == UKM_OP_DIFF && (flags & UKM_F_CMP_TAXID))))) ct = true;
     if (ct) tax = false;  // the plain-key kernel; the taxids are an epilogue of it
-    const int vt = (tax || rank) ? VT_TAX : VT_PLAIN;
+    const int vt = rank ? VT_RANK : (tax ? VT_TAX : VT_PLAIN);
     const u64 tile_items = (u64)NTS * vt;
     const u64 N = na + nb;
     SetopArgs p;
@@ -1341,13 +1353,12 @@ int run_setop_pass(ukm_ctx *c, int op, const u64 *a, const u32 *ta, const u32 *r
         }
         (void)hipEventRecord(c->ev_k0, c->stream);
         if (rank) {
-            if (tax) launch_op<true, true, NTS, VT_TAX>(op, p, c->stream, ticket);
-            else if (ct) launch_op<false, true, NTS, VT_TAX, true>(op, p, c->stream, ticket);
-            else launch_op<false, true, NTS, VT_TAX>(op, p, c->stream, ticket);
+            if (tax) launch_op<true, true, NTS, VT_RANK>(op, p, c->stream, ticket);
+            else if (ct) launch_op<false, true, NTS, VT_RANK, true>(op, p, c->stream, ticket);
+            else launch_op<false, true, NTS, VT_RANK>(op, p, c->stream, ticket);
         } else {
             // union / inter with per-record taxids and one-byte clade codes: the LCAs behind the merge loop (tile_merge_loop_deferred)
-            const bool defer = SETOP_TAX_DEFER != 0 && p.tax.cpath != nullptr && !ukm_env_is(c, "UKM_SETOP_DEFER", '0');
-            if (tax && defer) launch_op<true, false, NTS, VT_TAX, false, true>(op, p, c->stream, ticket);
+            if (tax && defer_form) launch_op<true, false, NTS, VT_TAX, false, true>(op, p, c->stream, ticket);
             else if (tax) launch_op<true, false, NTS, VT_TAX>(op, p, c->stream, ticket);
             else if (ct) launch_op<false, false, NTS, VT_PLAIN, true>(op, p, c->stream, ticket);
             else launch_op<false, false, NTS, VT_PLAIN>(op, p, c->stream, ticket);
