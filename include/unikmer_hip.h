@@ -128,7 +128,8 @@ int ukm_last_route(ukm_ctx *ctx);
  *        (a context whose look-back watchdog has fired keeps them whatever this option says);   "sort_counting" 0 digit
  *        passes inside every LDS bucket, "sort_fan" 0 no size-class fan-out;   "setop_src" 0 / 1 / 2 the two-launch source-word
  *        route of a 2-way operation with per-record taxids never / for inter / also for union (default: 0 on a taxonomy
- *        with one-byte clade codes, else 1);   "punion_clade" / "srmerge_clade" 0 / 1
+ *        with one-byte clade codes, else 1);   "setop_defer" 0 the LCAs of a 2-way union / inter with per-record taxids inside the
+ *        merge step instead of densely behind it;   "punion_clade" / "srmerge_clade" 0 / 1
  *        clade codes in the probe tables / the single pass's emit never / always.
  *      The environment is read ONCE, when a context is created: every UKM_* variable present then is the context's default
  *      for the matching key; no compute call calls getenv (a context created under UKM_ENV_LIVE=1 -- the test suite, which

@@ -164,3 +164,35 @@ def test_default_route_on_related_genomes_is_among_the_fastest(genomes):
             print(name, {k: round(v * 1e3, 2) for k, v in times.items()})
     finally:
         ctx.close()
+
+
+def test_two_way_taxid_routes_as_options(monkeypatch):
+    """Round 6: the routes of a 2-way operation with per-record taxids are option keys of a production context ("setop_src":
+    0 the taxid instantiation, 1 / 2 source words + a gather launch for inter / for every operation; "setop_defer" 0: the
+    LCAs inside the merge step instead of densely behind it) -- every combination against the oracle."""
+    from oracle import oracle as O
+    from unikmer_amd import lib as L
+    from conftest import synth_tree
+    monkeypatch.delenv("UKM_ENV_LIVE", raising=False)
+    for k in ("UKM_SETOP_SRC", "UKM_SETOP_DEFER"):
+        monkeypatch.delenv(k, raising=False)
+    ctx = L.Context(0)
+    try:
+        child, parent = synth_tree(depth=5, arity=8)
+        ctx.taxonomy_load(child, parent)
+        tax, T = O.Taxonomy(child, parent), len(child)
+        files = _files(2, 60_000, 0.6)
+        A, B = files
+        rng = np.random.default_rng(3)
+        ta, tb = rng.integers(0, T + 3, len(A)).astype(np.uint32), rng.integers(0, T + 3, len(B)).astype(np.uint32)
+        exp = {op: fn([A, B], [ta, tb], tax) for op, fn in ((L.OP_UNION, O.union), (L.OP_INTER, O.inter), (L.OP_DIFF, O.diff))}
+        assert ctx.get_option("setop_src") is None and ctx.get_option("setop_defer") is None
+        for src in (None, 0, 1, 2):
+            for defer in (None, 0, 1):
+                ctx.set_option("setop_src", src)
+                ctx.set_option("setop_defer", defer)
+                for op, (ek, et) in exp.items():
+                    gk, gt = ctx.setop2(op, A, B, ta, tb)
+                    assert np.array_equal(gk, ek) and np.array_equal(gt, et), (src, defer, op)
+    finally:
+        ctx.close()

@@ -37,7 +37,7 @@ extern char **environ;
 // the option keys a host may set (ukm_ctx_set_option): key "punion" is knob UKM_PUNION, and so on
 static const char *const UKM_OPTION_KEYS[] = {
     "punion", "punion_tax", "punion_ranked", "place", "srmerge", "kway", "no_kway", "no_fold", "no_pfold", "pfold_tax", "common_probe",
-    "sort_local", "sort_counting", "sort_fan", "win_strip", "nthash_strip", "force_ticket", "setop_src", "punion_clade", "srmerge_clade",
+    "sort_local", "sort_counting", "sort_fan", "win_strip", "nthash_strip", "force_ticket", "setop_src", "setop_defer", "punion_clade", "srmerge_clade",
     // tuning / diagnostics (developer)
     "punion_k0", "punion_claim", "punion_debug", "kway_k", "kway_r", "kway_top2", "kway_debug", "srmerge_fill", "srmerge_spr", "srmerge_buckets",
     "srmerge_debug", "fold_debug", "sort_debug", "strip_l", "win_strip_l", "setop_fused_part",
