@@ -341,7 +341,10 @@ def main():
                                      "the per-record union is size-checked only.  Parity of this kernel against the oracle: "
                                      "tests/test_gpu_parity.py (taxid set operations), tests/test_gpu_filetax.py" % w,
                           "generator": "taxid = 1 + splitmix64(seed ^ code) mod T with one seed per file, complete 8-ary tree of depth 7 "
-                                       "(SURVEY 8(d)): uniformly random, every match is an LCA of two unrelated nodes"}
+                                       "(SURVEY 8(d)): uniformly random, every match is an LCA of two unrelated nodes",
+                          "second_bound": "beside the bytes, every match costs two random one-byte reads of the 2.4 MB clade table: "
+                                          "%.2e of them per operation; torch's own gather reads that table at 194 G reads/s "
+                                          "(tools/gather_ceiling.py, profiles/r06_notes.md section 10)" % (2.0 * ni)}
             taxid_variant = {"outside_timed_region": True, "set_size": n, "one_taxid_per_file": per_file, "per_record_taxids": per_record,
                              "unit": "kernel ms by hipEvents (best of 4); frac = algorithmic bytes / kernel time / 8 TB/s"}
             del ta, tb, tout_u, tout_i, exp
