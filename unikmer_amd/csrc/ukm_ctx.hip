@@ -40,7 +40,7 @@ static const char *const UKM_OPTION_KEYS[] = {
     "sort_local", "sort_counting", "sort_fan", "win_strip", "nthash_strip", "force_ticket", "setop_src", "setop_defer", "punion_clade", "srmerge_clade",
     // tuning / diagnostics (developer)
     "punion_k0", "punion_claim", "punion_debug", "kway_k", "kway_r", "kway_top2", "kway_debug", "srmerge_fill", "srmerge_spr", "srmerge_buckets",
-    "srmerge_debug", "fold_debug", "sort_debug", "strip_l", "win_strip_l", "setop_fused_part",
+    "srmerge_debug", "fold_debug", "sort_debug", "strip_l", "win_strip_l", "setop_fused_part", "setop_fix",
 };
 
 static std::string knob_name(const char *key) {

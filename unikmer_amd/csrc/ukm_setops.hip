@@ -61,7 +61,13 @@ struct SetopArgs {
     // output taxid is one of three values -- A's, B's, or LCA(A's, B's) on a match -- resolved ONCE by setop_ct_kernel into
     // result[4] = lca | keep << 32 (keep: diff -t leaves a matched code in the result, diff.go:404-409).
     u32 cta, ctb;
+    // DEFER instantiation (round 6): the pairs a tile does not settle itself -- relatives inside one clade, unknown and merged
+    // ids: the root-path reads -- go to the tile's FIX_SLOTS places of this list as (output position, A's taxid, B's taxid) and
+    // setop_taxid_fix_kernel settles them behind the launch; fix_cnt[tile] = how many (every tile writes it).  nullptr: none.
+    uint4 *fix;
+    u32 *fix_cnt;
 };
+constexpr u32 FIX_SLOTS = 16;
 
 // the actual sizes of a chained call (workgroup-uniform: one scalar load)
 __device__ __forceinline__ void setop_resolve_sizes(SetopArgs &p, u64 tile_items) {
@@ -652,10 +658,34 @@ __device__ __forceinline__ void tile_queue_lca(u32 excl, u32 mask, u32 need, u32
         }
     }
 }
-// every lane busy: s_tax[w] = LCA(s_tax[w], b) for the n queued (w, b)
+// every lane busy: s_tax[w] = LCA(s_tax[w], b) for the n queued (w, b).  A pair the clade codes do not settle (about 1 % of
+// uniformly random pairs) would cost its wave two or three more dependent table reads -- 7 % of the kernel, since most waves
+// hold one: the tile's first FIX_SLOTS such pairs are handed to setop_taxid_fix_kernel instead (s_fix, s_nfix; their places
+// keep A's taxid until then), only what does not fit is settled here.
+struct FixLds {
+    u32 n;
+    u32 w[FIX_SLOTS], a[FIX_SLOTS], b[FIX_SLOTS];
+};
+template <bool ON> struct FixLdsOpt { FixLds t; };
+template <> struct FixLdsOpt<false> { u32 t; };
 template <int NTH>
-__device__ __forceinline__ void tile_lca_dense(const TaxDev &T, const CladeLds &L, int tid, u32 n, const u64 *s_queue, u32 *s_tax) {
+__device__ __forceinline__ void tile_lca_dense(const TaxDev &T, const CladeLds &L, int tid, u32 n, const u64 *s_queue, u32 *s_tax,
+                                               FixLds *fx) {
     const uint4 zero4 = make_uint4(0, 0, 0, 0);
+    auto settle = [&](u32 w, u32 a, u32 b, u32 ca, u32 cb) {
+        if (ca != cb && ca != 0 && cb != 0) {
+            s_tax[w] = lca_clade_pair_lds(T, L, ca, cb);
+            return;
+        }
+        if (fx) {
+            const u32 k = atomicAdd(&fx->n, 1u);
+            if (k < FIX_SLOTS) {
+                fx->w[k] = w; fx->a[k] = a; fx->b[k] = b;
+                return;
+            }
+        }
+        s_tax[w] = lca_from_rows(T, a, b, a < T.size ? T.anc[a] : zero4, b < T.size ? T.anc[b] : zero4);
+    };
     for (u32 i = (u32)tid; i < n; i += 2 * NTH) {
         const bool two = i + NTH < n;
         const u64 e0 = s_queue[i], e1 = s_queue[two ? i + NTH : i];
@@ -664,15 +694,8 @@ __device__ __forceinline__ void tile_lca_dense(const TaxDev &T, const CladeLds &
         const bool in0 = a0 < T.size && b0 < T.size, in1 = two && a1 < T.size && b1 < T.size;
         const u32 ca0 = T.clade8[in0 ? a0 : 0u], cb0 = T.clade8[in0 ? b0 : 0u];
         const u32 ca1 = T.clade8[in1 ? a1 : 0u], cb1 = T.clade8[in1 ? b1 : 0u];
-        u32 r0, r1 = 0;
-        if (ca0 != cb0 && ca0 != 0 && cb0 != 0) r0 = lca_clade_pair_lds(T, L, ca0, cb0);
-        else r0 = lca_from_rows(T, a0, b0, a0 < T.size ? T.anc[a0] : zero4, b0 < T.size ? T.anc[b0] : zero4);
-        if (two) {
-            if (ca1 != cb1 && ca1 != 0 && cb1 != 0) r1 = lca_clade_pair_lds(T, L, ca1, cb1);
-            else r1 = lca_from_rows(T, a1, b1, a1 < T.size ? T.anc[a1] : zero4, b1 < T.size ? T.anc[b1] : zero4);
-        }
-        s_tax[w0] = r0;
-        if (two) s_tax[w1] = r1;
+        settle(w0, a0, b0, ca0, cb0);
+        if (two) settle(w1, a1, b1, ca1, cb1);
     }
 }
 
@@ -1014,6 +1037,21 @@ __global__ __launch_bounds__(GATHER_NT) void setop_taxid_gather_kernel(SetopArgs
     }
 }
 
+// the pairs the DEFER tiles left behind (SetopArgs::fix): one thread per place of the list
+__global__ __launch_bounds__(256) void setop_taxid_fix_kernel(SetopArgs p) {
+    const u64 g = (u64)blockIdx.x * 256 + threadIdx.x;
+    const u64 tile = g / FIX_SLOTS;
+    if (tile >= p.ntiles) return;
+    if (sload_u64(&p.result[1]) & FLAG_TIMEOUT) return;  // (the host runs the pass again: not every tile has written its count)
+    if ((u32)(g % FIX_SLOTS) >= p.fix_cnt[tile]) return;
+    const uint4 e = p.fix[g];
+    const u64 pos = ((u64)e.y << 32) | e.x;
+    // (a != b, both non-zero, not settled by their clade codes: straight to the root paths, as the tile would have gone)
+    const uint4 zero4 = make_uint4(0, 0, 0, 0);
+    const TaxDev &T = p.tax;
+    if (pos < p.out_cap) p.tout[pos] = lca_from_rows(T, e.z, e.w, e.z < T.size ? T.anc[e.z] : zero4, e.w < T.size ? T.anc[e.w] : zero4);
+}
+
 // result[4] of a CT call: [31:0] the taxid of a matched pair (inter --mix-taxid: a zero on either side yields the other,
 // inter.go:229-236), [32] diff -t keeps matched codes (diff.go:404-409: the later file's taxid equals the first file's or
 // lies below it).  One thread; runs between the partition launch (which clears the control words) and the tile kernel.
@@ -1059,7 +1097,11 @@ void setop_tile_kernel(SetopArgs p) {
     __shared__ u32 s_scan[NTH / 64 + 1];
     __shared__ u64 s_misc[2];
     __shared__ CladeLdsOpt<TAX> s_clade_tab;
+    __shared__ FixLdsOpt<DEFER> s_fix;
     const int tid = (int)threadIdx.x;
+    if constexpr (DEFER) {
+        if (tid == 0) s_fix.t.n = 0;  // (read behind the barriers of the tile's staging)
+    }
 #ifdef UKM_PROFILE_PHASES
     u64 ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     u64 tlast = clock64();
@@ -1159,7 +1201,7 @@ void setop_tile_kernel(SetopArgs p) {
         // -- its B record is dropped, here or as the next tile's first step -- and more in an intersection's)
         tile_queue_lca<VT>(excl, mask, need, qpos, tbm, s_keys + tile_total);
         __syncthreads();
-        tile_lca_dense<NTH>(p.tax, s_clade_tab.t, tid, nneed, s_keys + tile_total, s_tax);
+        tile_lca_dense<NTH>(p.tax, s_clade_tab.t, tid, nneed, s_keys + tile_total, s_tax, p.fix ? &s_fix.t : nullptr);
     }
     PH(3);
     if (OP == UKM_OP_MERGE_INTERNAL) {
@@ -1190,6 +1232,16 @@ void setop_tile_kernel(SetopArgs p) {
     }
     __syncthreads();
     const u64 base = s_misc[1];
+    if constexpr (DEFER) {
+        if (p.fix) {  // (uniform) the pairs left to setop_taxid_fix_kernel, at their output positions
+            const u32 nf = s_fix.t.n < FIX_SLOTS ? s_fix.t.n : FIX_SLOTS;
+            if ((u32)tid < nf) {
+                const u64 pos = base + s_fix.t.w[tid];
+                p.fix[tile * FIX_SLOTS + (u32)tid] = make_uint4((u32)pos, (u32)(pos >> 32), s_fix.t.a[tid], s_fix.t.b[tid]);
+            }
+            if (tid == 0) p.fix_cnt[tile] = nf;
+        }
+    }
 #ifndef SETOP_ABL_NOFLUSH
     tile_flush<TAX, NTH>(p, tid, base, tile_total, s_keys, s_tax);
     if (CT) {
@@ -1245,6 +1297,9 @@ void launch_tile(const SetopArgs &p, hipStream_t st, bool ticket) {
         hipLaunchKernelGGL((setop_tile_kernel<OP, TAX, RANK, true, NTH, VT, CT, DEFER>), dim3((unsigned)p.ntiles), dim3(NTH), 0, st, p);
     else
         hipLaunchKernelGGL((setop_tile_kernel<OP, TAX, RANK, false, NTH, VT, CT, DEFER>), dim3((unsigned)p.ntiles), dim3(NTH), 0, st, p);
+    if constexpr (DEFER) {
+        if (p.fix) hipLaunchKernelGGL(setop_taxid_fix_kernel, dim3((unsigned)((p.ntiles * FIX_SLOTS + 255) / 256)), dim3(256), 0, st, p);
+    }
     if constexpr (CT && !RANK) {
         if (p.ta != nullptr || p.tb != nullptr)  // the source words of the launch above -> taxids
             hipLaunchKernelGGL((setop_taxid_gather_kernel<OP, NTH * VT>), dim3((unsigned)p.ntiles), dim3(GATHER_NT), 0, st, p);
@@ -1315,6 +1370,10 @@ int run_setop_pass(ukm_ctx *c, int op, const u64 *a, const u32 *ta, const u32 *r
     p.ticket = (u32 *)(ctl + 2);
     p.status = ctl + 8;
     p.mp = ctl + nzero;
+    if (tax && !rank && defer_form && (op == UKM_OP_UNION || op == UKM_OP_INTER) && !ukm_env_is(c, "UKM_SETOP_FIX", '0')) {
+        UKM_TRY(ws_alloc_t(c, (size_t)p.ntiles * FIX_SLOTS, &p.fix));
+        UKM_TRY(ws_alloc_t(c, (size_t)p.ntiles, &p.fix_cnt));
+    }
 #ifdef UKM_PROFILE_PHASES
     UKM_TRY(ws_alloc_t(c, (size_t)p.ntiles * 8, &p.dbg));
     UKM_HIP(hipMemsetAsync(p.dbg, 0, (size_t)p.ntiles * 8 * sizeof(u64), c->stream));
