@@ -228,8 +228,9 @@ def test_setop2_taxids_deep_forest_clade_paths(O, L, monkeypatch, mode):
     tax = O.Taxonomy(child, parent, mo, mn)
     pool = np.concatenate([child, child, child, [0, 0, r3 + 5, r3 + 6, r3 + 7, 2**31]]).astype(np.uint32)
     rng = np.random.default_rng(11)
-    for defer in ("1", "0"):
+    for defer, fix in (("1", "1"), ("1", "0"), ("0", "1")):  # (fix: the root-path pairs leave the tile through the fix-up list)
         monkeypatch.setenv("UKM_SETOP_DEFER", defer)
+        monkeypatch.setenv("UKM_SETOP_FIX", fix)
         c = L.Context(0)
         c.taxonomy_load(child, parent, mo, mn)
         got = c.lca(pool[:4000], pool[::-1][:4000])
@@ -250,6 +251,12 @@ def test_setop2_taxids_deep_forest_clade_paths(O, L, monkeypatch, mode):
             gk, gt = c.setop2(op, A, A, ta, tb)
             ek, et = ofn([A, A], [ta, tb], tax)
             assert np.array_equal(gk, ek) and np.array_equal(gt, et), (mode, defer, op, "all matched")
+        # a result that does not fit: the call fails, nothing is written behind the caller's arrays (the fix-up list holds
+        # output positions)
+        guard = np.full(len(A) // 2 + 64, 0xABCDEF01, np.uint32)
+        with pytest.raises(L.CapacityError):
+            c.setop2(L.OP_UNION, A, A, ta, tb, out=np.empty(len(A) // 2, np.uint64), out_taxids=guard[:len(A) // 2])
+        assert (guard[len(A) // 2:] == 0xABCDEF01).all()
         c.close()
 
 
