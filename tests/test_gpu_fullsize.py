@@ -104,6 +104,75 @@ def test_metric_config_2x1e9_full_size(env):
         assert start == a0 - _lower(torch, I, lo), start
 
 
+def test_metric_config_2x1e9_with_per_record_taxids_full_size(env, monkeypatch):
+    """north_star's second half -- "with per-k-mer TaxId LCA reduction" -- on the metric's two sets at FULL size: every record
+    carries a uniformly random taxid of the complete 8-ary tree of depth 7, union and inter through the 2-way
+    kernel's taxid instantiation (round 6: small tiles, the LCAs of a tile walked densely behind the merge loop, relatives
+    through the fix-up list).  Checked over the WHOLE output: the codes are the plain kernel's; every taxid equals what the
+    bulk LCA entry point (ukm_lca: the root-path / clade-table walk, no LDS table, no queue, no fix-up list) gives on the
+    taxids of the input records found by torch.searchsorted -- A's own, B's own, or the LCA where both hold the code; inter
+    through the two-launch source-word route gives the same arrays; and 1e6-record windows at both ends and in the middle
+    against the oracle's ancestor walk."""
+    torch, bench, lib, ctx, O, dev = env
+    from conftest import synth_tree
+    n = 1_000_000_000
+    A, B = bench.gen_sets_device((4 * n + 2) // 3, 32, 0, bench.SEED, dev)
+    na, nb = A.numel(), B.numel()
+    child, parent = synth_tree(7, 8)
+    ctx.taxonomy_load(child, parent)
+    tax, T = O.Taxonomy(child, parent), len(child)
+    ta = (1 + (bench.splitmix64_torch(A ^ bench._i64(bench.SEED + 2)) & ((1 << 40) - 1)) % T).to(torch.int32)
+    tb = (1 + (bench.splitmix64_torch(B ^ bench._i64(bench.SEED + 3)) & ((1 << 40) - 1)) % T).to(torch.int32)
+    out_k = torch.empty(na + nb, dtype=torch.int64, device=dev)
+    out_t = torch.empty(na + nb, dtype=torch.int32, device=dev)
+    plain = torch.empty(na + nb, dtype=torch.int64, device=dev)
+
+    def check(op, name):
+        K, Tx = ctx.setop2(op, A, B, ta, tb, out=out_k, out_taxids=out_t)
+        P = ctx.setop2(op, A, B, out=plain)
+        assert K.numel() == P.numel() and bool((K == P).all()), name
+        # where every output record comes from
+        ia = torch.searchsorted(A, K).clamp_(max=na - 1)
+        in_a = A[ia] == K
+        ib = torch.searchsorted(B, K).clamp_(max=nb - 1)
+        in_b = B[ib] == K
+        assert bool((in_a | in_b).all()), name
+        va, vb = ta[ia], tb[ib]
+        del ia, ib
+        both = in_a & in_b
+        exp = torch.where(in_a, va, vb)
+        idx = both.nonzero().squeeze(1)
+        del both
+        step = 1 << 28                                            # (bounds the bulk call's temporaries)
+        for lo in range(0, idx.numel(), step):
+            sel = idx[lo:lo + step]
+            exp[sel] = ctx.lca(va[sel].contiguous(), vb[sel].contiguous()).to(torch.int32)
+        assert bool((Tx == exp).all()), name
+        nmatch = idx.numel()
+        del va, vb, exp, idx, in_a, in_b
+        # windows against the oracle
+        nk = K.numel()
+        ofn = O.union if op == lib.OP_UNION else O.inter
+        for start in (0, nk // 2 - W // 2, nk - W):
+            lo, hi = int(K[start].item()), int(K[start + W - 1].item())
+            a0, a1 = _lower(torch, A, lo), _lower(torch, A, hi + 1)
+            b0, b1 = _lower(torch, B, lo), _lower(torch, B, hi + 1)
+            ek, et = ofn([_np(A[a0:a1]), _np(B[b0:b1])], [ta[a0:a1].cpu().numpy().view(np.uint32), tb[b0:b1].cpu().numpy().view(np.uint32)], tax)
+            assert np.array_equal(_np(K[start:start + W]), ek) and np.array_equal(Tx[start:start + W].cpu().numpy().view(np.uint32), et), (name, start)
+        return nmatch
+
+    m_u = check(lib.OP_UNION, "union")
+    m_i = check(lib.OP_INTER, "inter")
+    assert m_u == m_i and m_i > 600_000_000                       # every record of the intersection is a matched pair
+    # the two-launch source-word route of inter: the same arrays
+    ni = m_i
+    ref_t = out_t[:ni].clone()
+    monkeypatch.setenv("UKM_SETOP_SRC", "1")
+    K2, T2 = ctx.setop2(lib.OP_INTER, A, B, ta, tb, out=out_k, out_taxids=out_t)
+    monkeypatch.delenv("UKM_SETOP_SRC", raising=False)
+    assert K2.numel() == ni and bool((T2 == ref_t).all())
+
+
 def test_config3_union_of_100_files_x_1e8_full_size(env, monkeypatch):
     """BASELINE config 3 on one GPU: 100 sorted files of ~1e8 codes drawn (p = 0.5) from one universe of 2e8.
     The union — the library's own choice (the hash-probe pass of ukm_punion.hip) AND the k-way streaming merge alone
