@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """developer tool: the 2-way kernel with per-record taxids against the set size (round-5 review: 12 x the time for 10 x the
-data).  usage: [KIND=random|file|runs] python tools/tax_scaling.py [sizes...]   (with a -DUKM_PROFILE_PHASES build the library prints cycles per tile
+data).  usage: [KIND=random|file|runs] [DIFF=1] python tools/tax_scaling.py [sizes...]   (with a -DUKM_PROFILE_PHASES build the library prints cycles per tile
 and phase to stderr)"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -29,10 +29,13 @@ for n in sizes:
         tb = (1 + (bench.splitmix64_torch(B ^ bench._i64(bench.SEED + 3)) & ((1 << 40) - 1)) % T).to(torch.int32)
     out = torch.empty(na + nb, dtype=torch.int64, device=dev); tout = torch.empty(na + nb, dtype=torch.int32, device=dev)
     res = {}
-    for name, op, tx in (("union_tax", lib.OP_UNION, True), ("inter_tax", lib.OP_INTER, True), ("union", lib.OP_UNION, False), ("inter", lib.OP_INTER, False)):
+    ops = [("union_tax", lib.OP_UNION, True, 0), ("inter_tax", lib.OP_INTER, True, 0), ("union", lib.OP_UNION, False, 0), ("inter", lib.OP_INTER, False, 0)]
+    if os.environ.get("DIFF"):
+        ops += [("diff_tax", lib.OP_DIFF, True, 0), ("diff_t_tax", lib.OP_DIFF, True, lib.F_CMP_TAXID)]
+    for name, op, tx, fl in ops:
         best = 1e9
         for _ in range(4):
-            r = ctx.setop2(op, A, B, ta, tb, out=out, out_taxids=tout) if tx else ctx.setop2(op, A, B, out=out)
+            r = ctx.setop2(op, A, B, ta, tb, flags=fl, out=out, out_taxids=tout) if tx else ctx.setop2(op, A, B, out=out)
             best = min(best, ctx.last_kernel_ms())
         res[name] = round(best, 3)
     print("n=%d" % n, res, "ns per input record:", {k: round(v * 1e6 / (na + nb), 4) for k, v in res.items()}, flush=True)

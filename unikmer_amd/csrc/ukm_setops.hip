@@ -1085,7 +1085,7 @@ __global__ void setop_ct_kernel(SetopArgs p, int op) {
 #define SETOP_WAVES_TAX 6  /* per-record taxids, no ranks: THREE workgroups per CU (SETOP_VT_TAX <= 7) */
 #endif
 template <int OP, bool TAX, bool RANK, bool TICKET, int NTH, int VT, bool CT = false, bool DEFER = false>
-__global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu((TAX && RANK) ? 2 : (TAX ? SETOP_WAVES_TAX : SETOP_WAVES), (TAX && RANK) ? 8 : (TAX ? SETOP_WAVES_TAX : SETOP_WAVES))))
+__global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu((TAX && RANK) ? 2 : ((TAX && VT <= 8) ? SETOP_WAVES_TAX : SETOP_WAVES), (TAX && RANK) ? 8 : ((TAX && VT <= 8) ? SETOP_WAVES_TAX : SETOP_WAVES))))
 void setop_tile_kernel(SetopArgs p) {
     static_assert(!(CT && TAX), "CT: no per-record taxids");
     constexpr int TILE = NTH * VT;
@@ -1347,7 +1347,10 @@ int run_setop_pass(ukm_ctx *c, int op, const u64 *a, const u32 *ta, const u32 *r
     const int src_mode = ukm_env_int(c, "UKM_SETOP_SRC", defer_form ? 0 : 1);
     if (tax && !ct && !rank && src_mode != 0 && (op == UKM_OP_INTER || (src_mode == 2 && !(op == UKM_OP_DIFF && (flags & UKM_F_CMP_TAXID))))) ct = true;
     if (ct) tax = false;  // the plain-key kernel; the taxids are an epilogue of it
-    const int vt = rank ? VT_RANK : (tax ? VT_TAX : VT_PLAIN);
+    // (diff WITHOUT -t carries the taxids along and looks nothing up: the large tile, two workgroups per CU -- 2.22 against
+    //  2.35 ms at 2 x 3e8 through the small one)
+    const bool tax_stream = tax && !rank && op == UKM_OP_DIFF && !(flags & UKM_F_CMP_TAXID);
+    const int vt = rank ? VT_RANK : (tax ? (tax_stream ? VT_RANK : VT_TAX) : VT_PLAIN);
     const u64 tile_items = (u64)NTS * vt;
     const u64 N = na + nb;
     SetopArgs p;
@@ -1417,7 +1420,8 @@ int run_setop_pass(ukm_ctx *c, int op, const u64 *a, const u32 *ta, const u32 *r
             else launch_op<false, true, NTS, VT_RANK>(op, p, c->stream, ticket);
         } else {
             // union / inter with per-record taxids and one-byte clade codes: the LCAs behind the merge loop (tile_merge_loop_deferred)
-            if (tax && defer_form) launch_op<true, false, NTS, VT_TAX, false, true>(op, p, c->stream, ticket);
+            if (tax_stream) launch_tile<UKM_OP_DIFF, true, false, NTS, VT_RANK>(p, c->stream, ticket);
+            else if (tax && defer_form) launch_op<true, false, NTS, VT_TAX, false, true>(op, p, c->stream, ticket);
             else if (tax) launch_op<true, false, NTS, VT_TAX>(op, p, c->stream, ticket);
             else if (ct) launch_op<false, false, NTS, VT_PLAIN, true>(op, p, c->stream, ticket);
             else launch_op<false, false, NTS, VT_PLAIN>(op, p, c->stream, ticket);
